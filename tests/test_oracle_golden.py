@@ -1,0 +1,159 @@
+"""The oracle (oracle/*.py) against the fixtures generated from the imported reference
+(oracle/make_golden.py -> tests/golden).  CPU only."""
+import glob
+import os
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden
+from oracle import dmol_ref, dscm_ref, hvae_ref, train_ref
+from oracle import hparams as ohp
+
+TINY = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "tiny_*.pt")))
+TOL = dict(rtol=2e-5, atol=2e-6)
+
+
+def _sd(fx, grad=False):
+    return {k: v.clone().requires_grad_(grad and v.is_floating_point()) for k, v in fx["state_dict"].items()}
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_forward_and_grads(name):
+    fx = load_golden(name)
+    hp = SimpleNamespace(**fx["hp"])
+    sd = _sd(fx, grad=True)
+    f = fx["fwd"]
+    out = hvae_ref.hvae_forward(sd, hp, fx["x"], fx["pa"], beta=f["beta"], noise=f["eps"], want_stats=True)
+    for k in ("elbo", "nll", "kl"):
+        torch.testing.assert_close(out[k].detach(), f[k], **TOL)
+    torch.testing.assert_close(out["_h"].detach(), f["h"], **TOL)
+    assert len(out["_kl_maps"]) == len(f["kl_maps"])
+    for a, b in zip(out["_kl_maps"], f["kl_maps"]):
+        torch.testing.assert_close(a.detach(), b, **TOL)
+    out["elbo"].backward()
+    for n, g in f["grads"].items():
+        torch.testing.assert_close(sd[n].grad, g, rtol=1e-4, atol=1e-6, msg=lambda m: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_variants_and_cf(name):
+    fx = load_golden(name)
+    hp = SimpleNamespace(**fx["hp"])
+    sd = _sd(fx)
+    x, pa, cf_pa = fx["x"], fx["pa"], fx["cf_pa"]
+    with torch.no_grad():
+        if "fwd_drop" in fx:
+            d = fx["fwd_drop"]
+            o = hvae_ref.hvae_forward(sd, hp, x, pa, beta=1.0, noise=d["eps"], drop=d["drop"])
+            for k in ("elbo", "nll", "kl"):
+                torch.testing.assert_close(o[k], d[k], **TOL)
+        d = fx["fwd_freebits"]
+        hp_fb = SimpleNamespace(**{**fx["hp"], "kl_free_bits": d["free_bits"]})
+        o = hvae_ref.hvae_forward(sd, hp_fb, x, pa, beta=1.0, noise=d["eps"])
+        for k in ("elbo", "nll", "kl"):
+            torch.testing.assert_close(o[k], d[k], **TOL)
+        # abduct -> forward_latents -> cf pixels (dscm.py:52-56)
+        ab = fx["abduct"]
+        o = dscm_ref.counterfactual(sd, hp, x, pa, cf_pa, t_abduct=ab["t"], noise=ab["eps"])
+        for a, b in zip(o["zs"], ab["zs"]):
+            torch.testing.assert_close(a, b, **TOL)
+        for k in ("rec_loc", "rec_scale", "cf_loc", "cf_scale", "cf_x"):
+            torch.testing.assert_close(o[k], fx["cf"][k], rtol=1e-4, atol=1e-5)
+        # partial latents
+        pl = fx["partial_latents"]
+        loc, sc = hvae_ref.hvae_forward_latents(sd, hp, ab["zs"][: pl["n"]], cf_pa, t=pl["t"], noise=pl["eps"])
+        torch.testing.assert_close(loc, pl["loc"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(sc, pl["scale"], rtol=1e-4, atol=1e-5)
+        if "mediator" in fx:
+            md = fx["mediator"]
+            zstar = hvae_ref.hvae_abduct(sd, hp, x, pa, cf_parents=cf_pa, alpha=md["alpha"], t=md["t"], noise=md["eps"])
+            for a, b in zip(zstar, md["zstar"]):
+                torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+        sm = fx["sample"]
+        loc, sc = hvae_ref.hvae_sample(sd, hp, pa, t=sm["t"], noise=sm["eps"])
+        torch.testing.assert_close(loc, sm["loc"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(sc, sm["scale"], rtol=1e-4, atol=1e-5)
+
+
+def test_op_vectors():
+    fx = load_golden("ops.pt")
+    g = fx["gaussian_kl"]
+    torch.testing.assert_close(hvae_ref.gaussian_kl(g["q_loc"], g["q_logscale"], g["p_loc"], g["p_logscale"]), g["kl"],
+                               rtol=1e-6, atol=1e-6)
+    for C in (1, 3):
+        d = fx[f"dgauss_c{C}"]
+        hp = ohp.tiny_hparams(input_channels=C)
+        sd = {"likelihood." + k: v for k, v in d["state_dict"].items()}
+        h = d["h"].clone().requires_grad_(True)
+        nll = hvae_ref.dgauss_nll(sd, hp, h, d["x"])
+        torch.testing.assert_close(nll.detach(), d["nll"], **TOL)
+        (gh,) = torch.autograd.grad(nll.sum(), h)
+        torch.testing.assert_close(gh, d["grad_h"], rtol=1e-4, atol=1e-6)
+        loc, ls = hvae_ref.dgauss_params(sd, hp, d["h"], d["x"])
+        torch.testing.assert_close(loc, d["loc"], **TOL)
+        torch.testing.assert_close(ls, d["logscale"], **TOL)
+        sx, ss = hvae_ref.dgauss_sample(sd, hp, d["h"])
+        torch.testing.assert_close(sx, d["sample_x"], **TOL)
+        torch.testing.assert_close(ss, d["sample_scale"], **TOL)
+    d = fx["dmol"]
+    l = d["l"].clone().requires_grad_(True)
+    loss = dmol_ref.dmol_nll(d["x"], l)
+    torch.testing.assert_close(loss.detach(), d["loss"], **TOL)
+    (gl,) = torch.autograd.grad(loss.sum(), l)
+    torch.testing.assert_close(gl, d["grad_l"], rtol=1e-4, atol=1e-7)
+    for mask in ("soft", "hard", "top3"):
+        mx, ms = dmol_ref.dmol_mean(d["l"], mask)
+        torch.testing.assert_close(mx, d[f"mean_{mask}"], **TOL)
+        torch.testing.assert_close(ms, d[f"scale_{mask}"], **TOL)
+
+
+@pytest.mark.parametrize("name", ["morphomnist", "cmnist"])
+def test_anchor_init_and_forward(name):
+    """Full-size presets: the oracle's init consumes the RNG in the reference's order (sum|theta| equal)
+    and reproduces (elbo, nll, kl) at the seeded input."""
+    row = load_golden("anchors.pt")[name]
+    hp = ohp.make_hparams(name)
+    torch.manual_seed(7)
+    sd = hvae_ref.init_state_dict(hp)
+    assert list(sd.keys()) == row["keys"]
+    assert [tuple(v.shape) for v in sd.values()] == row["shapes"]
+    assert hvae_ref.count_params(sd) == row["n_params"]
+    assert abs(float(sum(v.abs().double().sum() for v in sd.values())) - row["abs_sum"]) < 1e-6 * row["abs_sum"]
+    g = torch.Generator().manual_seed(123)
+    R, C = hp.input_res, hp.input_channels
+    x = (torch.randint(0, 256, (2, C, R, R), generator=g).float() - 127.5) / 127.5
+    pa = torch.randn(2, hp.context_dim, generator=g)[..., None, None].repeat(1, 1, R, R)
+    torch.manual_seed(11)
+    with torch.no_grad():
+        o = hvae_ref.hvae_forward(sd, hp, x, pa, beta=hp.beta)
+    for k in ("elbo", "nll", "kl"):
+        assert abs(float(o[k]) - row[k]) <= 2e-5 * abs(row[k]) + 1e-7, (k, float(o[k]), row[k])
+
+
+def test_anchor_ukbb192_init():
+    row = load_golden("anchors.pt")["ukbb192"]
+    hp = ohp.make_hparams("ukbb192")
+    torch.manual_seed(7)
+    sd = hvae_ref.init_state_dict(hp)
+    assert list(sd.keys()) == row["keys"]
+    assert hvae_ref.count_params(sd) == row["n_params"] == 17371122
+    assert abs(float(sum(v.abs().double().sum() for v in sd.values())) - row["abs_sum"]) < 1e-6 * row["abs_sum"]
+
+
+def test_train_steps_adamw_ema():
+    fx = load_golden("train_steps.pt")
+    hp = SimpleNamespace(**fx["hp"])
+    tr = train_ref.RefTrainer(fx["p0"], hp)
+    n = max(fx["snaps"])
+    for s in range(n):
+        gn = tr.apply_grads({k: fx["grads"][k][s] for k in fx["p0"]})
+        assert abs(gn - fx["norms"][s]) <= 1e-5 * fx["norms"][s]
+        if s + 1 in fx["snaps"]:
+            snap = fx["snaps"][s + 1]
+            for k in fx["p0"]:
+                torch.testing.assert_close(tr.sd[k].detach(), snap["params"][k], rtol=1e-5, atol=1e-7)
+                torch.testing.assert_close(tr.ema[k], snap["ema"][k], rtol=1e-5, atol=1e-7)
+            assert abs(tr.lr() - snap["lr"]) < 1e-12
+    assert tr.skipped == 1
