@@ -1,0 +1,146 @@
+"""ctypes binding of libcgen_hip.so (include/cgen_hip.h).  Loading never needs a GPU; calling does."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcgen_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+MAX_SEG = 4
+
+
+class View(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("sn", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64), ("c", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+NULL_VIEW = View(None, 0, 0, 0, 0, 0)
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("ks", C.c_int32),
+                ("nseg", C.c_int32), ("act", C.c_int32), ("dact", C.c_int32), ("seg", View * MAX_SEG),
+                ("weight", C.c_void_p), ("bias", C.c_void_p), ("out", View), ("aux", View), ("res1", View), ("res2", View)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("ks", C.c_int32),
+                ("nseg", C.c_int32), ("act", C.c_int32), ("nsplit", C.c_int32), ("seg", View * MAX_SEG), ("gout", View),
+                ("partial_w", C.c_void_p), ("partial_b", C.c_void_p)]
+
+
+class WprepDesc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("co", C.c_int32), ("ci_total", C.c_int32), ("ks", C.c_int32),
+                ("mode", C.c_int32), ("nseg", C.c_int32), ("seg_off", C.c_int32), ("seg_c", C.c_int32 * MAX_SEG),
+                ("dtype", C.c_int32), ("rows_pad", C.c_int32), ("k_pad", C.c_int32), ("reserved", C.c_int32),
+                ("numel", C.c_int64)]
+
+
+class WredDesc(C.Structure):
+    _fields_ = [("partial_w", C.c_void_p), ("partial_b", C.c_void_p), ("grad_w", C.c_void_p), ("grad_b", C.c_void_p),
+                ("co", C.c_int32), ("ci_total", C.c_int32), ("ks", C.c_int32), ("nsplit", C.c_int32),
+                ("accumulate", C.c_int32), ("reserved", C.c_int32), ("numel", C.c_int64)]
+
+
+class AdamwArgs(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
+                ("count", C.c_int64), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("wd", C.c_float), ("ema_beta", C.c_float), ("warmup_steps", C.c_int32), ("ema_update_after", C.c_int32),
+                ("state_dev", C.c_void_p)]
+
+
+i32, i64, u32, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_void_p
+
+# name -> argtypes (all return int unless listed in _RESTYPES).  Kept in lock-step with include/cgen_hip.h;
+# tests/test_abi.py parses the header and checks every declared symbol is exported and bound here.
+PROTOTYPES = {
+    "cgen_version": [],
+    "cgen_last_error": [],
+    "cgen_conv2d": [C.POINTER(ConvArgs), vp],
+    "cgen_conv2d_wgrad_splits": [i32, i32, i32, i32, i32, i32],
+    "cgen_conv2d_wgrad": [C.POINTER(WgradArgs), vp],
+    "cgen_weight_prep": [vp, vp, vp, i32, vp],
+    "cgen_wgrad_reduce": [vp, vp, vp, i32, vp],
+    "cgen_avgpool_fwd": [i32, i32, i32, i32, i32, View, View, vp],
+    "cgen_avgpool_bwd": [i32, i32, i32, i32, i32, View, View, i32, vp],
+    "cgen_upsample_fwd": [i32, i32, i32, i32, i32, i32, View, vp, View, vp],
+    "cgen_upsample_bwd": [i32, i32, i32, i32, i32, i32, View, View, i32, vp],
+    "cgen_batch_reduce": [i32, i32, i32, i32, View, vp, i32, vp],
+    "cgen_batch_broadcast": [i32, i32, i32, i32, vp, View, vp],
+    "cgen_axpby": [i32, i32, i32, i32, View, View, f32, f32, i32, i32, vp],
+    "cgen_nchw_to_nhwc": [i32, i32, i32, i32, i32, i32, vp, View, f32, f32, vp],
+    "cgen_nhwc_to_nchw": [i32, i32, i32, i32, i32, View, vp, vp],
+    "cgen_reparam_kl_chunks": [i32, i32, i32],
+    "cgen_reparam_kl_fwd": [i32, i32, i32, i32, i32, View, View, View, View, View, vp, u32, f32, View, View, vp, i32, vp],
+    "cgen_reparam_kl_bwd": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, View, vp, i32, View, View, View,
+                            View, i32, i32, vp],
+    "cgen_sample_gaussian": [i32, i32, i32, i32, i32, View, View, View, vp, u32, f32, View, vp],
+    "cgen_mediator_mix": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, f32, f32, View, vp],
+    "cgen_like_chunks": [i32, i32],
+    "cgen_dgauss_nll_fwd": [i32, i32, i32, i32, i32, View, View, vp, vp],
+    "cgen_dgauss_nll_bwd": [i32, i32, i32, i32, i32, View, View, vp, i32, View, vp],
+    "cgen_dgauss_sample": [i32, i32, i32, i32, i32, View, f32, vp, vp, vp],
+    "cgen_dmol_nll_fwd": [i32, i32, i32, i32, View, View, vp, vp],
+    "cgen_dmol_nll_bwd": [i32, i32, i32, i32, View, View, vp, i32, View, vp],
+    "cgen_dmol_decode": [i32, i32, i32, i32, View, i32, vp, u32, f32, vp, vp, vp],
+    "cgen_elbo_finalize": [i32, vp, i32, f32, vp, i32, f32, f32, vp, vp],
+    "cgen_cf_pixels": [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "cgen_sumsq_partial": [vp, i64, vp, i32, vp],
+    "cgen_clip_decide": [vp, i32, vp, f32, f32, vp, vp],
+    "cgen_adamw_ema": [C.POINTER(AdamwArgs), vp],
+    "cgen_step_commit": [vp, vp],
+    "cgen_philox_normal": [vp, i64, vp, u32, vp],
+    "cgen_rng_advance": [vp, u64, vp],
+}
+_RESTYPES = {"cgen_last_error": C.c_char_p}
+_NOCHECK = {"cgen_version", "cgen_last_error", "cgen_conv2d_wgrad_splits", "cgen_reparam_kl_chunks", "cgen_like_chunks"}
+
+
+class CgenError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self, path):
+        self.path = path
+        self.cdll = C.CDLL(path)
+        for name, argtypes in PROTOTYPES.items():
+            fn = getattr(self.cdll, name)  # AttributeError if the .so lacks a declared symbol
+            fn.argtypes = argtypes
+            fn.restype = _RESTYPES.get(name, C.c_int)
+            setattr(self, "_raw_" + name, fn)
+            setattr(self, name[len("cgen_"):], fn if name in _NOCHECK else self._checked(name, fn))
+
+    def _checked(self, name, fn):
+        def call(*a):
+            rc = fn(*a)
+            if rc != 0:
+                raise CgenError(f"{name} failed ({rc}): {self.cdll.cgen_last_error().decode()}")
+        call.__name__ = name
+        return call
+
+
+_LIB = None
+
+
+def load():
+    """Load libcgen_hip.so (no GPU needed).  Raises with build instructions when it is absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise CgenError(f"{LIB_PATH} not found: build it with causal-gen_amd/build.sh "
+                            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        _LIB = _Lib(LIB_PATH)
+    return _LIB
+
+
+def require_gpu():
+    """The product path runs on an MI355X only; fail loudly otherwise."""
+    import torch
+
+    lib = load()
+    if not torch.cuda.is_available():
+        raise CgenError("causal-gen_amd needs a ROCm GPU (gfx950); torch.cuda.is_available() is False and there is "
+                        "no CPU fallback by design")
+    return lib

@@ -1,0 +1,139 @@
+// Shared device/host helpers for libcgen_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/cgen_hip.h"
+
+namespace cgen {
+
+// ----------------------------------------------------------------------------- errors
+extern thread_local char g_err[512];
+int fail(int code, const char* fmt, ...);
+int check_launch(const char* what);
+#define CGEN_REQUIRE(cond, ...)                       \
+  do {                                                \
+    if (!(cond)) return cgen::fail(CGEN_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+// ----------------------------------------------------------------------------- dtypes
+typedef uint16_t bf16_t;  // raw bits
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float to(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+  static __device__ __forceinline__ bf16_t to(float v) { return f2bf(v); }
+};
+
+// ----------------------------------------------------------------------------- views
+struct View {  // device-side mirror of cgen_view with typed access
+  char* p;
+  int64_t sn, sh, sw;
+  int c;
+};
+static inline View mk(const cgen_view& v) {
+  View o;
+  o.p = (char*)v.p; o.sn = v.sn; o.sh = v.sh; o.sw = v.sw; o.c = v.c;
+  return o;
+}
+template <typename T>
+__device__ __forceinline__ T* vptr(const View& v, int n, int y, int x) {
+  return (T*)v.p + (n * v.sn + y * v.sh + x * v.sw);
+}
+// 16-byte vector access is legal for a view iff base and all strides are multiples of 16 bytes
+static inline bool vec16_ok(const cgen_view& v, int esz) {
+  if (!v.p) return true;
+  return (((uintptr_t)v.p) % 16 == 0) && ((v.sn * esz) % 16 == 0) && ((v.sh * esz) % 16 == 0) && ((v.sw * esz) % 16 == 0);
+}
+
+// ----------------------------------------------------------------------------- activations (vae.py:50,59)
+#define CGEN_SQRT1_2 0.70710678118654752440f
+#define CGEN_INV_SQRT_2PI 0.39894228040143267794f
+__device__ __forceinline__ float act_fwd(int act, float x) {
+  if (act == CGEN_ACT_RELU) return x > 0.f ? x : 0.f;
+  if (act == CGEN_ACT_GELU) return 0.5f * x * (1.f + erff(x * CGEN_SQRT1_2));  // nn.GELU() default = erf form
+  return x;
+}
+__device__ __forceinline__ float act_bwd(int act, float x) {
+  if (act == CGEN_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+  if (act == CGEN_ACT_GELU) return 0.5f * (1.f + erff(x * CGEN_SQRT1_2)) + x * CGEN_INV_SQRT_2PI * __expf(-0.5f * x * x);
+  return 1.f;
+}
+
+// ----------------------------------------------------------------------------- wave / block reductions (wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// deterministic block sum for blockDim.x == 256; result valid in thread 0; `sm` >= 4 floats
+__device__ __forceinline__ float block_sum_256(float v, float* sm) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  __syncthreads();
+  return r;
+}
+
+// ----------------------------------------------------------------------------- Philox4x32-10 + Box-Muller
+struct Philox {
+  static __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+  }
+  // 4 x 32 random bits for (seed, offset+stream, index)
+  static __device__ __forceinline__ void gen(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t idx, uint32_t (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)offset ^ (stream * 0x9E3779B9u), (uint32_t)(offset >> 32) + stream};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      round(c, k0, k1);
+      k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+  }
+  static __device__ __forceinline__ float u01(uint32_t r) { return ((float)(r >> 8) + 0.5f) * (1.0f / 16777216.0f); }  // (0,1)
+  // 4 standard normals for element group `idx`
+  static __device__ __forceinline__ void normal4(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t idx, float (&z)[4]) {
+    uint32_t r[4];
+    gen(seed, offset, stream, idx, r);
+    float u0 = u01(r[0]), u1 = u01(r[1]), u2 = u01(r[2]), u3 = u01(r[3]);
+    float ra = sqrtf(-2.f * __logf(u0)), rb = sqrtf(-2.f * __logf(u2));
+    float s0, c0, s1, c1;
+    __sincosf(6.28318530717958647692f * u1, &s0, &c0);
+    __sincosf(6.28318530717958647692f * u3, &s1, &c1);
+    z[0] = ra * c0; z[1] = ra * s0; z[2] = rb * c1; z[3] = rb * s1;
+  }
+  // one normal for a flat element index (uses lane idx&3 of group idx>>2)
+  static __device__ __forceinline__ float normal1(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t i) {
+    float z[4];
+    normal4(seed, offset, stream, i >> 2, z);
+    int k = (int)(i & 3);
+    return k == 0 ? z[0] : k == 1 ? z[1] : k == 2 ? z[2] : z[3];
+  }
+};
+
+static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+}  // namespace cgen

@@ -1,0 +1,620 @@
+// Implicit-GEMM convolution for gfx950: forward / data-gradient (one kernel) and weight-gradient.
+//
+// GEMM view (operands swapped so every lane owns 4 consecutive output channels of one pixel):
+//   D[co][px] = sum_k  Wimg[co][k] * A[k][px],   k = (tap, segment, channel)
+//   A[k][px]  = act( seg_s[n, y+dy, x+dx, c] )   (zero outside the image; act(0) == 0)
+// f32 path : v_mfma_f32_16x16x4_f32  (exact f32 fmaf chains -> the 1e-4 ELBO parity path)
+// bf16 path: v_mfma_f32_16x16x32_bf16 (f32 accumulate)
+// Workgroup = 256 threads (4 waves) -> 128 pixels x (16*NTC) output channels; K advances 32 channels per step.
+// Global -> register -> LDS staging with the next K-step's loads issued before the current MFMAs.
+#include "common.h"
+
+namespace cgen {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define CONV_PT 128  // pixels per workgroup
+#define CONV_BK 32   // K per step
+#define CONV_LDK 40  // LDS row stride in elements (bank-conflict-free 16B fragment reads)
+
+struct ConvP {
+  int N, H, W, KS, pad, nseg, act, dact, Co, P, taps, kpad;
+  View seg[CGEN_MAX_SEG];
+  int seg_koff[CGEN_MAX_SEG];  // offset of the segment inside the padded K axis of the weight image
+  int seg_vec[CGEN_MAX_SEG];
+  const void* w;
+  const float* bias;
+  View out, aux, res1, res2;
+  int epi_vec;
+};
+
+// 4-element (16B f32 / 8B bf16) vector access
+template <typename T> __device__ __forceinline__ void ld4(const T* p, float (&v)[4]);
+template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&v)[4]) {
+  const float4 t = *(const float4*)p;
+  v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+  const uint2 t = *(const uint2*)p;
+  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, const float (&v)[4]);
+template <> __device__ __forceinline__ void st4<float>(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+  uint2 t;
+  t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  *(uint2*)p = t;
+}
+template <typename T, int N> union Pack {
+  T e[N];
+  uint4 v4;
+};
+
+template <typename T> struct Frag;
+template <> struct Frag<float> { typedef f32x4 type; };
+template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+
+template <typename T, int NTC>
+__global__ __launch_bounds__(256) void conv_kernel(ConvP p) {
+  constexpr int G = 16 / sizeof(T);   // elements per 16-byte group
+  constexpr int NG = 16 / G;          // groups per thread for the activation tile (16 elements per thread)
+  constexpr int WROWS = NTC * 16;
+  constexpr int WGROUPS = WROWS * (CONV_BK / G);
+  constexpr int WPT = (WGROUPS + 255) / 256;
+  __shared__ __attribute__((aligned(16))) T Xs[CONV_PT * CONV_LDK];
+  __shared__ __attribute__((aligned(16))) T Ws[WROWS * CONV_LDK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = tid >> 1, half = tid & 1;
+  const int m = blockIdx.x * CONV_PT + row;
+  const bool mvalid = m < p.P;
+  int n = 0, y = 0, x = 0;
+  if (mvalid) {
+    n = m / (p.H * p.W);
+    int r = m - n * p.H * p.W;
+    y = r / p.W;
+    x = r - y * p.W;
+  }
+  const int co_base = blockIdx.y * WROWS;
+
+  f32x4 acc[NTC][2];
+#pragma unroll
+  for (int t = 0; t < NTC; ++t)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) acc[t][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- K-step iterator state: (tap, seg, c0)
+  int tap = 0, s = 0, c0 = 0;
+  uint4 xr[NG];   // staged activation groups (raw 16 bytes each)
+  uint4 wr[WPT];  // staged weight groups
+
+  auto load_step = [&](int tap_, int s_, int c0_) {
+    const int dy = tap_ / p.KS - p.pad, dx = tap_ % p.KS - p.pad;
+    const int yy = y + dy, xx = x + dx;
+    const bool inb = mvalid && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+    const View& sv = p.seg[s_];
+    const T* src = inb ? vptr<T>(sv, n, yy, xx) : nullptr;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const int cs = c0_ + half * 16 + g * G;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (inb) {
+        if (p.seg_vec[s_] && cs + G <= sv.c) {
+          v = *(const uint4*)(src + cs);
+        } else if (cs < sv.c) {
+          Pack<T, G> tmp;
+#pragma unroll
+          for (int e = 0; e < G; ++e) tmp.e[e] = (cs + e < sv.c) ? src[cs + e] : (T)0;
+          v = tmp.v4;
+        }
+      }
+      if (p.act != CGEN_ACT_NONE) {
+        Pack<T, G> tv;
+        tv.v4 = v;
+#pragma unroll
+        for (int e = 0; e < G; ++e) tv.e[e] = Elem<T>::to(act_fwd(p.act, Elem<T>::ld(&tv.e[e])));
+        v = tv.v4;
+      }
+      xr[g] = v;
+    }
+    const T* wbase = (const T*)p.w + (size_t)tap_ * p.kpad + p.seg_koff[s_] + c0_;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int gi = tid + i * 256;
+      if (gi < WGROUPS) {
+        const int r = gi / (CONV_BK / G), kg = gi % (CONV_BK / G);
+        wr[i] = *(const uint4*)(wbase + (size_t)(co_base + r) * p.taps * p.kpad + kg * G);
+      }
+    }
+  };
+  auto store_step = [&]() {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) *(uint4*)(Xs + row * CONV_LDK + half * 16 + g * G) = xr[g];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int gi = tid + i * 256;
+      if (gi < WGROUPS) {
+        const int r = gi / (CONV_BK / G), kg = gi % (CONV_BK / G);
+        *(uint4*)(Ws + r * CONV_LDK + kg * G) = wr[i];
+      }
+    }
+  };
+  auto advance = [&]() -> bool {  // returns false when the K loop is exhausted
+    c0 += CONV_BK;
+    if (c0 >= p.seg[s].c) {
+      c0 = 0;
+      ++s;
+      if (s >= p.nseg) {
+        s = 0;
+        ++tap;
+      }
+    }
+    return tap < p.taps;
+  };
+
+  load_step(tap, s, c0);
+  bool more = true;
+  while (more) {
+    __syncthreads();  // previous step's fragment reads are done
+    store_step();
+    __syncthreads();
+    more = advance();
+    if (more) load_step(tap, s, c0);  // in flight during the MFMAs below
+    const int fr = lane & 15, fg = lane >> 4;
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        f32x4 b[2], a[NTC];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) b[f] = *(const f32x4*)(Xs + (wave * 32 + f * 16 + fr) * CONV_LDK + kk * 16 + fg * 4);
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) a[t] = *(const f32x4*)(Ws + (t * 16 + fr) * CONV_LDK + kk * 16 + fg * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < NTC; ++t)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j], b[f][j], acc[t][f], 0, 0, 0);
+      }
+    } else {
+      bf16x8 b[2], a[NTC];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) b[f] = *(const bf16x8*)(Xs + (wave * 32 + f * 16 + fr) * CONV_LDK + fg * 8);
+#pragma unroll
+      for (int t = 0; t < NTC; ++t) a[t] = *(const bf16x8*)(Ws + (t * 16 + fr) * CONV_LDK + fg * 8);
+#pragma unroll
+      for (int t = 0; t < NTC; ++t)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b[f], acc[t][f], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane owns pixel (lane&15) of fragment f and channels (lane>>4)*4 .. +4 of fragment t
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int pm = blockIdx.x * CONV_PT + wave * 32 + f * 16 + (lane & 15);
+    if (pm >= p.P) continue;
+    const int pn = pm / (p.H * p.W);
+    const int pr = pm - pn * p.H * p.W;
+    const int py = pr / p.W, px = pr - py * p.W;
+    T* optr = vptr<T>(p.out, pn, py, px);
+    const T* aptr = p.aux.p ? vptr<T>(p.aux, pn, py, px) : nullptr;
+    const T* r1 = p.res1.p ? vptr<T>(p.res1, pn, py, px) : nullptr;
+    const T* r2 = p.res2.p ? vptr<T>(p.res2, pn, py, px) : nullptr;
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) {
+      const int co = co_base + t * 16 + (lane >> 4) * 4;
+      if (co >= p.Co) continue;
+      float v[4] = {acc[t][f][0], acc[t][f][1], acc[t][f][2], acc[t][f][3]};
+      const bool full = (co + 4 <= p.Co) && p.epi_vec;
+      if (full) {
+        if (p.bias) {
+          const float4 bb = *(const float4*)(p.bias + co);
+          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
+        float t4[4];
+        if (aptr) {
+          ld4<T>(aptr + co, t4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= act_bwd(p.dact, t4[e]);
+        }
+        if (r1) {
+          ld4<T>(r1 + co, t4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += t4[e];
+        }
+        if (r2) {
+          ld4<T>(r2 + co, t4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += t4[e];
+        }
+        st4<T>(optr + co, v);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (co + e < p.Co) {
+            float u = v[e] + (p.bias ? p.bias[co + e] : 0.f);
+            if (aptr) u *= act_bwd(p.dact, Elem<T>::ld(aptr + co + e));
+            if (r1) u += Elem<T>::ld(r1 + co + e);
+            if (r2) u += Elem<T>::ld(r2 + co + e);
+            Elem<T>::st(optr + co + e, u);
+          }
+        }
+      }
+    }
+  }
+}
+
+static inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+template <typename T>
+static int launch_conv(const ConvP& p, hipStream_t st) {
+  dim3 block(256);
+  const int px_tiles = ceil_div(p.P, CONV_PT);
+  if (p.Co <= 16) {
+    hipLaunchKernelGGL((conv_kernel<T, 1>), dim3(px_tiles, 1), block, 0, st, p);
+  } else if (p.Co <= 32) {
+    hipLaunchKernelGGL((conv_kernel<T, 2>), dim3(px_tiles, 1), block, 0, st, p);
+  } else {
+    hipLaunchKernelGGL((conv_kernel<T, 4>), dim3(px_tiles, ceil_div(p.Co, 64)), block, 0, st, p);
+  }
+  return check_launch("cgen_conv2d");
+}
+
+// ============================================================================= weight gradient
+// dW[co][tap][ci] = sum_px G[px][co] * act(X)[px + tap][ci]          (f32 MFMA 16x16x4 for both storage dtypes)
+// Workgroup tile: (16*NTC output channels) x (32 input channels) x (<= 9 taps) x one pixel split.
+#define WG_PK 64
+#define WG_MAXT 9
+
+struct WgP {
+  int N, H, W, KS, pad, nseg, act, Co, P, taps, ci_total, nsplit, pix_per_split, n_tapgroups, n_cichunks;
+  View seg[CGEN_MAX_SEG];
+  int seg_off[CGEN_MAX_SEG];
+  int seg_vec[CGEN_MAX_SEG];
+  int seg_chunk0[CGEN_MAX_SEG + 1];  // first 32-wide chunk index of each segment
+  View gout;
+  int gout_vec;
+  float* pw;
+  float* pb;
+};
+
+template <typename T, int NTC>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
+  constexpr int COT = NTC * 16;
+  constexpr int LDG = COT + 16;  // stride == 16 (mod 32) -> conflict-free b32 fragment reads
+  constexpr int LDX = 32 + 16;
+  constexpr int NPAIR = NTC * 2;                 // (co-frag, ci-frag) pairs
+  constexpr int KW = NPAIR >= 4 ? 1 : 4 / NPAIR; // K-ways across waves
+  constexpr int PPW = NPAIR >= 4 ? NPAIR / 4 : 1;
+  constexpr int G = 16 / sizeof(T);
+  __shared__ float Gs[WG_PK * LDG];
+  __shared__ float Xs[WG_PK * LDX];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sp = blockIdx.x;
+  const int chunk = blockIdx.y;  // global 32-wide ci chunk
+  const int co_tile = blockIdx.z / p.n_tapgroups, tg = blockIdx.z % p.n_tapgroups;
+  const int co_base = co_tile * COT;
+  const int t0 = tg * WG_MAXT;
+  const int ntap = min(WG_MAXT, p.taps - t0);
+  int s = 0;
+  while (s + 1 < p.nseg && chunk >= p.seg_chunk0[s + 1]) ++s;
+  const int c0 = (chunk - p.seg_chunk0[s]) * 32;
+  const View sv = p.seg[s];
+
+  const int px0 = sp * p.pix_per_split;
+  const int px1 = min(p.P, px0 + p.pix_per_split);
+
+  f32x4 acc[WG_MAXT][PPW];
+#pragma unroll
+  for (int t = 0; t < WG_MAXT; ++t)
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) acc[t][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+
+  const int kpart = (KW > 1) ? (wave / NPAIR) : 0;
+  const int pair0 = (KW > 1) ? (wave % NPAIR) : wave * PPW;
+
+  for (int pc = px0; pc < px1; pc += WG_PK) {
+    __syncthreads();
+    // ---- gradient tile Gs[64][COT] (f32)
+    for (int g = tid; g < WG_PK * COT / 4; g += 256) {
+      const int r = g / (COT / 4), cg = (g % (COT / 4)) * 4;
+      const int m = pc + r, co = co_base + cg;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (m < px1 && co < p.Co) {
+        const int n = m / (p.H * p.W);
+        const int rr = m - n * p.H * p.W;
+        const int y = rr / p.W, x = rr - y * p.W;
+        const T* src = vptr<T>(p.gout, n, y, x) + co;
+        if (p.gout_vec && co + 4 <= p.Co) {
+          ld4<T>(src, v);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (co + e < p.Co) v[e] = Elem<T>::ld(src + e);
+        }
+      }
+      *(float4*)(Gs + r * LDG + cg) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+#pragma unroll
+    for (int tt = 0; tt < WG_MAXT; ++tt) {
+      if (tt < ntap) {
+        const int tap = t0 + tt;
+        const int dy = tap / p.KS - p.pad, dx = tap % p.KS - p.pad;
+        if (tt > 0) __syncthreads();
+        // ---- activation tile Xs[64][32] for this tap
+        for (int g = tid; g < WG_PK * 32 / G; g += 256) {
+          const int r = g / (32 / G), cg = (g % (32 / G)) * G;
+          const int m = pc + r, cs = c0 + cg;
+          float v[G];
+#pragma unroll
+          for (int e = 0; e < G; ++e) v[e] = 0.f;
+          if (m < px1 && cs < sv.c) {
+            const int n = m / (p.H * p.W);
+            const int rr = m - n * p.H * p.W;
+            const int y = rr / p.W + dy, x = rr % p.W + dx;
+            if (y >= 0 && y < p.H && x >= 0 && x < p.W) {
+              const T* src = vptr<T>(sv, n, y, x) + cs;
+              if (p.seg_vec[s] && cs + G <= sv.c) {
+                Pack<T, G> tmp;
+                tmp.v4 = *(const uint4*)src;
+#pragma unroll
+                for (int e = 0; e < G; ++e) v[e] = act_fwd(p.act, Elem<T>::ld(&tmp.e[e]));
+              } else {
+#pragma unroll
+                for (int e = 0; e < G; ++e) if (cs + e < sv.c) v[e] = act_fwd(p.act, Elem<T>::ld(src + e));
+              }
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < G; e += 4) *(float4*)(Xs + r * LDX + cg + e) = make_float4(v[e], v[e + 1], v[e + 2], v[e + 3]);
+        }
+        __syncthreads();
+        if (tt == 0 && p.pb && chunk == 0 && tg == 0 && tid < COT) {
+          float a = 0.f;
+          for (int r = 0; r < WG_PK; ++r) a += Gs[r * LDG + tid];
+          bsum += a;
+        }
+        // ---- MFMA: D[co][ci] += G^T[co][px] * X[px][ci]
+        const int kq0 = kpart * (WG_PK / 4 / KW), kq1 = kq0 + WG_PK / 4 / KW;
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+          const int pr = pair0 + q;
+          const int cf = pr >> 1, jf = pr & 1;
+          for (int k4 = kq0; k4 < kq1; ++k4) {
+            const int prow = k4 * 4 + (lane >> 4);
+            const float a = Gs[prow * LDG + cf * 16 + (lane & 15)];
+            const float b = Xs[prow * LDX + jf * 16 + (lane & 15)];
+            acc[tt][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[tt][q], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- write partials (K-ways are combined through LDS in a fixed order)
+  __syncthreads();
+  float* red = Gs;  // reuse (>= 64*32 floats)
+#pragma unroll
+  for (int tt = 0; tt < WG_MAXT; ++tt) {
+    if (tt < ntap) {
+#pragma unroll
+      for (int q = 0; q < PPW; ++q) {
+        f32x4 v = acc[tt][q];
+        if (KW > 1) {
+          // waves with kpart > 0 publish, kpart == 0 sums in kpart order
+          for (int kp = 1; kp < KW; ++kp) {
+            __syncthreads();
+            if (kpart == kp) *(f32x4*)(red + ((wave % NPAIR) * 64 + lane) * 4) = v;
+            __syncthreads();
+            if (kpart == 0) {
+              const f32x4 o = *(const f32x4*)(red + ((wave % NPAIR) * 64 + lane) * 4);
+              v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+            }
+          }
+        }
+        if (kpart == 0) {
+          const int pr = pair0 + q;
+          const int cf = pr >> 1, jf = pr & 1;
+          const int ci = c0 + jf * 16 + (lane & 15);
+          if (ci < sv.c) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int co = co_base + cf * 16 + (lane >> 4) * 4 + e;
+              if (co < p.Co)
+                p.pw[(((size_t)sp * p.Co + co) * p.taps + (t0 + tt)) * p.ci_total + p.seg_off[s] + ci] = v[e];
+            }
+          }
+        }
+      }
+    }
+  }
+  if (p.pb && chunk == 0 && tg == 0 && tid < COT && co_base + tid < p.Co) p.pb[(size_t)sp * p.Co + co_base + tid] = bsum;
+}
+
+static inline int wgrad_ntc(int co) { return co <= 16 ? 1 : (co <= 32 ? 2 : 4); }
+
+static void wgrad_geometry(int P, int co, int ci_chunks, int ks, int& nsplit, int& pps) {
+  const int ntc = wgrad_ntc(co);
+  const int tiles = ci_chunks * ceil_div(co, ntc * 16) * ceil_div(ks * ks, WG_MAXT);
+  int want = ceil_div(2048, tiles);
+  int maxs = ceil_div(P, 4 * WG_PK);
+  nsplit = want < 1 ? 1 : (want > maxs ? maxs : want);
+  if (nsplit < 1) nsplit = 1;
+  pps = pad_to(ceil_div(P, nsplit), WG_PK);
+  nsplit = ceil_div(P, pps);
+}
+
+template <typename T>
+static int launch_wgrad(const WgP& p, hipStream_t st) {
+  const int ntc = wgrad_ntc(p.Co);
+  dim3 grid(p.nsplit, p.n_cichunks, ceil_div(p.Co, ntc * 16) * p.n_tapgroups), block(256);
+  if (ntc == 1) hipLaunchKernelGGL((wgrad_kernel<T, 1>), grid, block, 0, st, p);
+  else if (ntc == 2) hipLaunchKernelGGL((wgrad_kernel<T, 2>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((wgrad_kernel<T, 4>), grid, block, 0, st, p);
+  return check_launch("cgen_conv2d_wgrad");
+}
+
+// ============================================================================= multi-tensor weight prep / reduce
+#define MT_CHUNK 1024  // elements per block
+
+__global__ __launch_bounds__(256) void wprep_kernel(const cgen_wprep_desc* descs, const int* csite, const int* cidx) {
+  const cgen_wprep_desc d = descs[csite[blockIdx.x]];
+  const int taps = d.ks * d.ks;
+  const int64_t base = (int64_t)cidx[blockIdx.x] * MT_CHUNK;
+  for (int i = threadIdx.x; i < MT_CHUNK; i += 256) {
+    const int64_t o = base + i;
+    if (o >= d.numel) break;
+    const int k = (int)(o % d.k_pad);
+    const int tap = (int)((o / d.k_pad) % taps);
+    const int r = (int)(o / ((int64_t)d.k_pad * taps));
+    float v = 0.f;
+    if (d.mode == 0) {  // forward image: r = co, k -> (segment, channel)
+      if (r < d.co) {
+        int kk = k, off = 0, ci = -1;
+        for (int s = 0; s < d.nseg; ++s) {
+          const int cp = (d.seg_c[s] + 31) / 32 * 32;
+          if (kk < cp) { if (kk < d.seg_c[s]) ci = off + kk; break; }
+          kk -= cp; off += d.seg_c[s];
+        }
+        if (ci >= 0) v = d.src[((int64_t)r * d.ci_total + ci) * taps + tap];
+      }
+    } else {  // dgrad image of one segment: r = local ci, k = co, taps flipped
+      if (r < d.seg_c[0] && k < d.co) v = d.src[((int64_t)k * d.ci_total + d.seg_off + r) * taps + (taps - 1 - tap)];
+    }
+    if (d.dtype == CGEN_F32) ((float*)d.dst)[o] = v; else ((bf16_t*)d.dst)[o] = f2bf(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, const int* csite, const int* cidx) {
+  const cgen_wred_desc d = descs[csite[blockIdx.x]];
+  const int taps = d.ks * d.ks;
+  const int64_t nw = (int64_t)d.co * d.ci_total * taps;
+  const int64_t base = (int64_t)cidx[blockIdx.x] * MT_CHUNK;
+  for (int i = threadIdx.x; i < MT_CHUNK; i += 256) {
+    const int64_t o = base + i;
+    if (o >= d.numel) break;
+    if (o < nw) {  // o indexes the OIHW gradient
+      const int tap = (int)(o % taps);
+      const int ci = (int)((o / taps) % d.ci_total);
+      const int co = (int)(o / ((int64_t)taps * d.ci_total));
+      const int64_t src = ((int64_t)co * taps + tap) * d.ci_total + ci;
+      float a = 0.f;
+      for (int sp = 0; sp < d.nsplit; ++sp) a += d.partial_w[(int64_t)sp * nw + src];
+      d.grad_w[o] = d.accumulate ? d.grad_w[o] + a : a;
+    } else if (d.grad_b) {
+      const int co = (int)(o - nw);
+      float a = 0.f;
+      for (int sp = 0; sp < d.nsplit; ++sp) a += d.partial_b[(int64_t)sp * d.co + co];
+      d.grad_b[co] = d.accumulate ? d.grad_b[co] + a : a;
+    }
+  }
+}
+
+}  // namespace cgen
+
+using namespace cgen;
+
+extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
+  CGEN_REQUIRE(a, "cgen_conv2d: null args");
+  CGEN_REQUIRE(a->dtype == CGEN_F32 || a->dtype == CGEN_BF16, "cgen_conv2d: bad dtype %d", a->dtype);
+  CGEN_REQUIRE(a->ks == 1 || a->ks == 3 || a->ks == 5 || a->ks == 7, "cgen_conv2d: kernel size %d unsupported", a->ks);
+  CGEN_REQUIRE(a->nseg >= 1 && a->nseg <= CGEN_MAX_SEG, "cgen_conv2d: nseg %d", a->nseg);
+  CGEN_REQUIRE(a->n > 0 && a->h > 0 && a->w > 0 && a->out.c > 0 && a->out.p && a->weight, "cgen_conv2d: bad shape/pointers");
+  CGEN_REQUIRE((int64_t)a->n * a->h * a->w < (1ll << 31), "cgen_conv2d: too many pixels");
+  const int esz = a->dtype == CGEN_F32 ? 4 : 2;
+  ConvP p;
+  memset(&p, 0, sizeof(p));
+  p.N = a->n; p.H = a->h; p.W = a->w; p.KS = a->ks; p.pad = a->ks / 2; p.nseg = a->nseg; p.act = a->act; p.dact = a->dact;
+  p.Co = a->out.c; p.P = a->n * a->h * a->w; p.taps = a->ks * a->ks;
+  int koff = 0;
+  for (int s = 0; s < a->nseg; ++s) {
+    CGEN_REQUIRE(a->seg[s].p && a->seg[s].c > 0, "cgen_conv2d: segment %d empty", s);
+    p.seg[s] = mk(a->seg[s]);
+    p.seg_koff[s] = koff;
+    p.seg_vec[s] = vec16_ok(a->seg[s], esz);
+    koff += pad_to(a->seg[s].c, 32);
+  }
+  p.kpad = koff;
+  p.w = a->weight; p.bias = a->bias;
+  CGEN_REQUIRE(((uintptr_t)a->weight) % 16 == 0, "cgen_conv2d: weight image must be 16-byte aligned");
+  p.out = mk(a->out); p.aux = mk(a->aux); p.res1 = mk(a->res1); p.res2 = mk(a->res2);
+  if (!a->dact) p.aux.p = nullptr;
+  // 4-channel vector epilogue: needs 4*esz-byte alignment on every view it touches
+  auto epi_ok = [&](const cgen_view& v) {
+    if (!v.p) return true;
+    const int q = 4 * esz;
+    return ((uintptr_t)v.p % q == 0) && ((v.sn * esz) % q == 0) && ((v.sh * esz) % q == 0) && ((v.sw * esz) % q == 0);
+  };
+  p.epi_vec = epi_ok(a->out) && epi_ok(a->aux) && epi_ok(a->res1) && epi_ok(a->res2) && (!a->bias || ((uintptr_t)a->bias % 16 == 0));
+  return a->dtype == CGEN_F32 ? launch_conv<float>(p, (hipStream_t)stream) : launch_conv<bf16_t>(p, (hipStream_t)stream);
+}
+
+static int count_chunks(const cgen_view* seg, int nseg) {
+  int c = 0;
+  for (int s = 0; s < nseg; ++s) c += (seg[s].c + 31) / 32;
+  return c;
+}
+
+extern "C" int cgen_conv2d_wgrad_splits(int32_t n, int32_t h, int32_t w, int32_t co, int32_t ci_total, int32_t ks) {
+  // conservative: chunk count of a single-segment input (more segments only add tiles => fewer splits needed)
+  int nsplit, pps;
+  wgrad_geometry(n * h * w, co, (ci_total + 31) / 32, ks, nsplit, pps);
+  return nsplit;
+}
+
+extern "C" int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream) {
+  CGEN_REQUIRE(a && a->partial_w, "cgen_conv2d_wgrad: null args");
+  CGEN_REQUIRE(a->dtype == CGEN_F32 || a->dtype == CGEN_BF16, "cgen_conv2d_wgrad: bad dtype");
+  CGEN_REQUIRE(a->nseg >= 1 && a->nseg <= CGEN_MAX_SEG && a->gout.p && a->gout.c > 0, "cgen_conv2d_wgrad: bad args");
+  const int esz = a->dtype == CGEN_F32 ? 4 : 2;
+  WgP p;
+  memset(&p, 0, sizeof(p));
+  p.N = a->n; p.H = a->h; p.W = a->w; p.KS = a->ks; p.pad = a->ks / 2; p.nseg = a->nseg; p.act = a->act;
+  p.Co = a->gout.c; p.P = a->n * a->h * a->w; p.taps = a->ks * a->ks;
+  int off = 0, ch = 0;
+  for (int s = 0; s < a->nseg; ++s) {
+    p.seg[s] = mk(a->seg[s]);
+    p.seg_off[s] = off;
+    p.seg_vec[s] = vec16_ok(a->seg[s], esz);
+    p.seg_chunk0[s] = ch;
+    off += a->seg[s].c;
+    ch += (a->seg[s].c + 31) / 32;
+  }
+  p.seg_chunk0[a->nseg] = ch;
+  p.ci_total = off;
+  p.n_cichunks = ch;
+  p.n_tapgroups = ceil_div(p.taps, WG_MAXT);
+  // geometry must match what the caller sized the partial buffer with
+  int ns, pps;
+  wgrad_geometry(p.P, p.Co, (p.ci_total + 31) / 32, p.KS, ns, pps);
+  CGEN_REQUIRE(ns == a->nsplit, "cgen_conv2d_wgrad: nsplit %d != expected %d", a->nsplit, ns);
+  p.nsplit = ns; p.pix_per_split = pps;
+  p.gout = mk(a->gout);
+  {
+    const int q = 4 * esz;
+    p.gout_vec = ((uintptr_t)a->gout.p % q == 0) && ((a->gout.sn * esz) % q == 0) && ((a->gout.sh * esz) % q == 0) && ((a->gout.sw * esz) % q == 0);
+  }
+  p.pw = a->partial_w; p.pb = a->partial_b;
+  return a->dtype == CGEN_F32 ? launch_wgrad<float>(p, (hipStream_t)stream) : launch_wgrad<bf16_t>(p, (hipStream_t)stream);
+}
+
+extern "C" int cgen_weight_prep(const cgen_wprep_desc* descs, const int32_t* csite, const int32_t* cidx, int32_t nchunks,
+                                cgen_stream_t stream) {
+  if (nchunks <= 0) return CGEN_OK;
+  CGEN_REQUIRE(descs && csite && cidx, "cgen_weight_prep: null table");
+  hipLaunchKernelGGL(wprep_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, descs, csite, cidx);
+  return check_launch("cgen_weight_prep");
+}
+
+extern "C" int cgen_wgrad_reduce(const cgen_wred_desc* descs, const int32_t* csite, const int32_t* cidx, int32_t nchunks,
+                                 cgen_stream_t stream) {
+  if (nchunks <= 0) return CGEN_OK;
+  CGEN_REQUIRE(descs && csite && cidx, "cgen_wgrad_reduce: null table");
+  hipLaunchKernelGGL(wred_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, descs, csite, cidx);
+  return check_launch("cgen_wgrad_reduce");
+}

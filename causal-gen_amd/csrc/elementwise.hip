@@ -1,0 +1,370 @@
+// Data-movement and element-wise kernels on NHWC views (HBM-bound; one pass, 4-channel vector access when the
+// views allow it).  See include/cgen_hip.h for the reference lines each entry point replaces.
+#include "common.h"
+
+namespace cgen {
+
+template <typename T, int V> struct VecIO;
+template <typename T> struct VecIO<T, 1> {
+  static __device__ __forceinline__ void ld(const T* p, float (&v)[1]) { v[0] = Elem<T>::ld(p); }
+  static __device__ __forceinline__ void st(T* p, const float (&v)[1]) { Elem<T>::st(p, v[0]); }
+};
+template <> struct VecIO<float, 4> {
+  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
+    const float4 t = *(const float4*)p;
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct VecIO<bf16_t, 4> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[4]) {
+    const uint2 t = *(const uint2*)p;
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[4]) {
+    uint2 t;
+    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *(uint2*)p = t;
+  }
+};
+
+struct Shape4 { int n, h, w, c; };
+
+// index helper: flat group index -> (n, y, x, c0) for groups of V channels
+template <int V>
+__device__ __forceinline__ bool decode(int64_t g, const Shape4& s, int& n, int& y, int& x, int& c) {
+  const int cg = s.c / V;
+  const int64_t total = (int64_t)s.n * s.h * s.w * cg;
+  if (g >= total) return false;
+  c = (int)(g % cg) * V;
+  int64_t r = g / cg;
+  x = (int)(r % s.w); r /= s.w;
+  y = (int)(r % s.h);
+  n = (int)(r / s.h);
+  return true;
+}
+
+#define GRID_STRIDE(g) for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ; g += (int64_t)gridDim.x * blockDim.x)
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(Shape4 so, int d, View in, View out) {
+  GRID_STRIDE(g) {
+    int n, y, x, c;
+    if (!decode<V>(g, so, n, y, x, c)) return;
+    float a[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] = 0.f;
+    for (int dy = 0; dy < d; ++dy)
+      for (int dx = 0; dx < d; ++dx) {
+        float v[V];
+        VecIO<T, V>::ld(vptr<T>(in, n, y * d + dy, x * d + dx) + c, v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += v[e];
+      }
+    const float inv = 1.f / (float)(d * d);
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] *= inv;
+    VecIO<T, V>::st(vptr<T>(out, n, y, x) + c, a);
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(Shape4 si, int d, View gout, View gin, int accumulate) {
+  const float inv = 1.f / (float)(d * d);
+  GRID_STRIDE(g) {
+    int n, y, x, c;
+    if (!decode<V>(g, si, n, y, x, c)) return;
+    float v[V];
+    VecIO<T, V>::ld(vptr<T>(gout, n, y / d, x / d) + c, v);
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] *= inv;
+    T* dst = vptr<T>(gin, n, y, x) + c;
+    if (accumulate) {
+      float o[V];
+      VecIO<T, V>::ld(dst, o);
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] += o[e];
+    }
+    VecIO<T, V>::st(dst, v);
+  }
+}
+
+// nearest-neighbour source index exactly as ATen's upsample_nearest2d with an explicit scale_factor:
+// src = min(floorf(dst * (float)(1/scale_factor)), in-1)
+__device__ __forceinline__ int nn_src(int dst, float inv_scale, int in_size) {
+  const int s = (int)floorf((float)dst * inv_scale);
+  return s < in_size - 1 ? s : in_size - 1;
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(Shape4 so, int hi, int wi, float ish, float isw, View in,
+                                                           const float* bias, View out) {
+  GRID_STRIDE(g) {
+    int n, y, x, c;
+    if (!decode<V>(g, so, n, y, x, c)) return;
+    float v[V];
+    VecIO<T, V>::ld(vptr<T>(in, n, nn_src(y, ish, hi), nn_src(x, isw, wi)) + c, v);
+    if (bias) {
+      const float* b = bias + ((int64_t)y * so.w + x) * so.c + c;
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] = b[e] + v[e];
+    }
+    VecIO<T, V>::st(vptr<T>(out, n, y, x) + c, v);
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(Shape4 si, int ho, int wo, float ish, float isw, View gout,
+                                                           View gin, int accumulate) {
+  GRID_STRIDE(g) {
+    int n, y, x, c;
+    if (!decode<V>(g, si, n, y, x, c)) return;
+    float a[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] = 0.f;
+    // candidate destination rows/cols: a generous window around y/ish, filtered by the exact forward map
+    int y0 = (int)floorf((float)y / ish) - 1, y1 = (int)floorf((float)(y + 1) / ish) + 1;
+    int x0 = (int)floorf((float)x / isw) - 1, x1 = (int)floorf((float)(x + 1) / isw) + 1;
+    y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0;
+    y1 = y1 > ho - 1 ? ho - 1 : y1; x1 = x1 > wo - 1 ? wo - 1 : x1;
+    for (int yo = y0; yo <= y1; ++yo) {
+      if (nn_src(yo, ish, si.h) != y) continue;
+      for (int xo = x0; xo <= x1; ++xo) {
+        if (nn_src(xo, isw, si.w) != x) continue;
+        float v[V];
+        VecIO<T, V>::ld(vptr<T>(gout, n, yo, xo) + c, v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += v[e];
+      }
+    }
+    T* dst = vptr<T>(gin, n, y, x) + c;
+    if (accumulate) {
+      float o[V];
+      VecIO<T, V>::ld(dst, o);
+#pragma unroll
+      for (int e = 0; e < V; ++e) a[e] += o[e];
+    }
+    VecIO<T, V>::st(dst, a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void batch_reduce_kernel(Shape4 s, View in, float* out, int accumulate) {
+  const int64_t per = (int64_t)s.h * s.w * s.c;
+  GRID_STRIDE(g) {
+    if (g >= per) return;
+    const int c = (int)(g % s.c);
+    const int x = (int)((g / s.c) % s.w);
+    const int y = (int)(g / ((int64_t)s.c * s.w));
+    float a = 0.f;
+    for (int n = 0; n < s.n; ++n) a += Elem<T>::ld(vptr<T>(in, n, y, x) + c);
+    out[g] = accumulate ? out[g] + a : a;
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void batch_broadcast_kernel(Shape4 s, const float* src, View out) {
+  GRID_STRIDE(g) {
+    int n, y, x, c;
+    if (!decode<V>(g, s, n, y, x, c)) return;
+    float v[V];
+    const float* b = src + ((int64_t)y * s.w + x) * s.c + c;
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = b[e];
+    VecIO<T, V>::st(vptr<T>(out, n, y, x) + c, v);
+  }
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void axpby_kernel(Shape4 s, View in, View out, float alpha, float beta, int c_from, int accumulate) {
+  GRID_STRIDE(g) {
+    int n, y, x, c;
+    if (!decode<V>(g, s, n, y, x, c)) return;
+    float v[V];
+    if (in.p) {
+      VecIO<T, V>::ld(vptr<T>(in, n, y, x) + c, v);
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] *= (c + e >= c_from) ? alpha * beta : alpha;
+    } else {
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] = alpha;
+    }
+    T* dst = vptr<T>(out, n, y, x) + c;
+    if (accumulate) {
+      float o[V];
+      VecIO<T, V>::ld(dst, o);
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] += o[e];
+    }
+    VecIO<T, V>::st(dst, v);
+  }
+}
+
+template <typename T, typename S>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(Shape4 s, const S* src, View out, float sub, float mul) {
+  GRID_STRIDE(g) {
+    int n, y, x, c;
+    if (!decode<1>(g, s, n, y, x, c)) return;
+    const float v = ((float)src[(((int64_t)n * s.c + c) * s.h + y) * s.w + x] - sub) * mul;
+    Elem<T>::st(vptr<T>(out, n, y, x) + c, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(Shape4 s, View in, float* dst) {
+  const int64_t total = (int64_t)s.n * s.c * s.h * s.w;
+  GRID_STRIDE(g) {
+    if (g >= total) return;
+    const int x = (int)(g % s.w);
+    const int y = (int)((g / s.w) % s.h);
+    const int c = (int)((g / ((int64_t)s.w * s.h)) % s.c);
+    const int n = (int)(g / ((int64_t)s.w * s.h * s.c));
+    dst[g] = Elem<T>::ld(vptr<T>(in, n, y, x) + c);
+  }
+}
+
+static inline int grid_for(int64_t items) {
+  int64_t b = (items + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 256 * 16) b = 256 * 16;  // grid-stride beyond ~16 blocks per CU
+  return (int)b;
+}
+
+static inline bool vec4_ok(int esz, int c, std::initializer_list<const cgen_view*> vs) {
+  if (c % 4) return false;
+  const int q = 4 * esz;
+  for (const cgen_view* v : vs) {
+    if (!v || !v->p) continue;
+    if (((uintptr_t)v->p % q) || ((v->sn * esz) % q) || ((v->sh * esz) % q) || ((v->sw * esz) % q)) return false;
+  }
+  return true;
+}
+
+#define DISPATCH_TV(dtype, vec, KERNEL, items, stream, ...)                                                   \
+  do {                                                                                                        \
+    const int grid__ = grid_for(items);                                                                       \
+    if ((dtype) == CGEN_F32) {                                                                                \
+      if (vec) hipLaunchKernelGGL((KERNEL<float, 4>), dim3(grid__), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<float, 1>), dim3(grid__), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);     \
+    } else {                                                                                                  \
+      if (vec) hipLaunchKernelGGL((KERNEL<bf16_t, 4>), dim3(grid__), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<bf16_t, 1>), dim3(grid__), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);     \
+    }                                                                                                         \
+  } while (0)
+
+}  // namespace cgen
+
+using namespace cgen;
+
+#define CHECK_DTYPE(name) CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, name ": bad dtype %d", dtype)
+static inline int esz_of(int dtype) { return dtype == CGEN_F32 ? 4 : 2; }
+
+extern "C" int cgen_avgpool_fwd(int32_t dtype, int32_t n, int32_t ho, int32_t wo, int32_t d, cgen_view in, cgen_view out,
+                                cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_avgpool_fwd");
+  CGEN_REQUIRE(in.p && out.p && d >= 1 && in.c == out.c && n > 0 && ho > 0 && wo > 0, "cgen_avgpool_fwd: bad args");
+  Shape4 so{n, ho, wo, out.c};
+  const bool v = vec4_ok(esz_of(dtype), out.c, {&in, &out});
+  const int64_t items = (int64_t)n * ho * wo * (v ? out.c / 4 : out.c);
+  DISPATCH_TV(dtype, v, avgpool_fwd_kernel, items, stream, so, d, mk(in), mk(out));
+  return check_launch("cgen_avgpool_fwd");
+}
+
+extern "C" int cgen_avgpool_bwd(int32_t dtype, int32_t n, int32_t ho, int32_t wo, int32_t d, cgen_view gout, cgen_view gin,
+                                int32_t accumulate, cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_avgpool_bwd");
+  CGEN_REQUIRE(gout.p && gin.p && d >= 1 && gin.c == gout.c, "cgen_avgpool_bwd: bad args");
+  Shape4 si{n, ho * d, wo * d, gin.c};
+  const bool v = vec4_ok(esz_of(dtype), gin.c, {&gout, &gin});
+  const int64_t items = (int64_t)n * si.h * si.w * (v ? gin.c / 4 : gin.c);
+  DISPATCH_TV(dtype, v, avgpool_bwd_kernel, items, stream, si, d, mk(gout), mk(gin), accumulate);
+  return check_launch("cgen_avgpool_bwd");
+}
+
+static inline float inv_scale(int out, int in) { return (float)(1.0 / ((double)out / (double)in)); }
+
+extern "C" int cgen_upsample_fwd(int32_t dtype, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo, cgen_view in,
+                                 const float* bias, cgen_view out, cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_upsample_fwd");
+  CGEN_REQUIRE(in.p && out.p && in.c == out.c && hi > 0 && wi > 0 && ho >= hi && wo >= wi, "cgen_upsample_fwd: bad args");
+  Shape4 so{n, ho, wo, out.c};
+  const bool v = vec4_ok(esz_of(dtype), out.c, {&in, &out});
+  const int64_t items = (int64_t)n * ho * wo * (v ? out.c / 4 : out.c);
+  DISPATCH_TV(dtype, v, upsample_fwd_kernel, items, stream, so, hi, wi, inv_scale(ho, hi), inv_scale(wo, wi), mk(in), bias, mk(out));
+  return check_launch("cgen_upsample_fwd");
+}
+
+extern "C" int cgen_upsample_bwd(int32_t dtype, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo, cgen_view gout,
+                                 cgen_view gin, int32_t accumulate, cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_upsample_bwd");
+  CGEN_REQUIRE(gout.p && gin.p && gin.c == gout.c, "cgen_upsample_bwd: bad args");
+  Shape4 si{n, hi, wi, gin.c};
+  const bool v = vec4_ok(esz_of(dtype), gin.c, {&gout, &gin});
+  const int64_t items = (int64_t)n * hi * wi * (v ? gin.c / 4 : gin.c);
+  DISPATCH_TV(dtype, v, upsample_bwd_kernel, items, stream, si, ho, wo, inv_scale(ho, hi), inv_scale(wo, wi), mk(gout), mk(gin), accumulate);
+  return check_launch("cgen_upsample_bwd");
+}
+
+extern "C" int cgen_batch_reduce(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view in, float* out, int32_t accumulate,
+                                 cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_batch_reduce");
+  CGEN_REQUIRE(in.p && out, "cgen_batch_reduce: bad args");
+  Shape4 s{n, h, w, in.c};
+  const int64_t items = (int64_t)h * w * in.c;
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(batch_reduce_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, mk(in), out, accumulate);
+  else hipLaunchKernelGGL(batch_reduce_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, mk(in), out, accumulate);
+  return check_launch("cgen_batch_reduce");
+}
+
+extern "C" int cgen_batch_broadcast(int32_t dtype, int32_t n, int32_t h, int32_t w, const float* src, cgen_view out,
+                                    cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_batch_broadcast");
+  CGEN_REQUIRE(src && out.p, "cgen_batch_broadcast: bad args");
+  Shape4 s{n, h, w, out.c};
+  const bool v = vec4_ok(esz_of(dtype), out.c, {&out});
+  const int64_t items = (int64_t)n * h * w * (v ? out.c / 4 : out.c);
+  DISPATCH_TV(dtype, v, batch_broadcast_kernel, items, stream, s, src, mk(out));
+  return check_launch("cgen_batch_broadcast");
+}
+
+extern "C" int cgen_axpby(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view in, cgen_view out, float alpha, float beta,
+                          int32_t c_from, int32_t accumulate, cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_axpby");
+  CGEN_REQUIRE(out.p && (!in.p || in.c == out.c), "cgen_axpby: bad args");
+  Shape4 s{n, h, w, out.c};
+  const bool v = vec4_ok(esz_of(dtype), out.c, {&in, &out});
+  const int64_t items = (int64_t)n * h * w * (v ? out.c / 4 : out.c);
+  DISPATCH_TV(dtype, v, axpby_kernel, items, stream, s, mk(in), mk(out), alpha, beta, c_from, accumulate);
+  return check_launch("cgen_axpby");
+}
+
+extern "C" int cgen_nchw_to_nhwc(int32_t src_is_u8, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, const void* src,
+                                 cgen_view out, float sub, float mul, cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_nchw_to_nhwc");
+  CGEN_REQUIRE(src && out.p && out.c == c, "cgen_nchw_to_nhwc: bad args");
+  Shape4 s{n, h, w, c};
+  const int64_t items = (int64_t)n * h * w * c;
+  const dim3 g(grid_for(items)), b(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == CGEN_F32) {
+    if (src_is_u8) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, uint8_t>), g, b, 0, st, s, (const uint8_t*)src, mk(out), sub, mul);
+    else hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, float>), g, b, 0, st, s, (const float*)src, mk(out), sub, mul);
+  } else {
+    if (src_is_u8) hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t, uint8_t>), g, b, 0, st, s, (const uint8_t*)src, mk(out), sub, mul);
+    else hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t, float>), g, b, 0, st, s, (const float*)src, mk(out), sub, mul);
+  }
+  return check_launch("cgen_nchw_to_nhwc");
+}
+
+extern "C" int cgen_nhwc_to_nchw(int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, cgen_view in, float* dst,
+                                 cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_nhwc_to_nchw");
+  CGEN_REQUIRE(in.p && dst && in.c == c, "cgen_nhwc_to_nchw: bad args");
+  Shape4 s{n, h, w, c};
+  const int64_t items = (int64_t)n * h * w * c;
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, mk(in), dst);
+  else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, mk(in), dst);
+  return check_launch("cgen_nhwc_to_nchw");
+}

@@ -1,0 +1,213 @@
+// Per-stochastic-layer Gaussian kernels: fused reparameterise + KL (forward / backward), prior sampling and the
+// counterfactual mediator mix.  HBM-bound: one read of (q_loc,q_ls,p_loc,p_ls[,eps]), one write of z, and a
+// deterministic two-stage per-sample reduction of the KL (wave shuffles -> LDS -> one partial per block).
+#include "common.h"
+
+namespace cgen {
+
+#define LAT_CHUNK 2048  // per-sample elements handled by one block (8 per thread)
+
+struct LatP {
+  int n, h, w, c;
+  View q_loc, q_ls, p_loc, p_ls, eps_in, z, eps_out;
+  const uint64_t* rng;
+  uint32_t stream_id;
+  float logt;
+  float* kl_part;
+  int kl_stride;
+};
+
+__device__ __forceinline__ void lat_decode(int e, int w, int c, int& y, int& x, int& ch) {
+  ch = e % c;
+  const int r = e / c;
+  x = r % w;
+  y = r / w;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(LatP p) {
+  __shared__ float sm[4];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int per = p.h * p.w * p.c;
+  uint64_t seed = 0, off = 0;
+  if (!p.eps_in.p) { seed = p.rng[0]; off = p.rng[1]; }
+  float kl_acc = 0.f;
+  for (int i = 0; i < LAT_CHUNK / 256; ++i) {
+    const int e = chunk * LAT_CHUNK + i * 256 + threadIdx.x;
+    if (e < per) {
+      int y, x, ch;
+      lat_decode(e, p.w, p.c, y, x, ch);
+      const float ql = Elem<T>::ld(vptr<T>(p.q_loc, b, y, x) + ch);
+      const float qs = Elem<T>::ld(vptr<T>(p.q_ls, b, y, x) + ch) + p.logt;
+      const float pl = Elem<T>::ld(vptr<T>(p.p_loc, b, y, x) + ch);
+      const float ps = Elem<T>::ld(vptr<T>(p.p_ls, b, y, x) + ch) + p.logt;
+      float eps;
+      if (p.eps_in.p) eps = Elem<T>::ld(vptr<T>(p.eps_in, b, y, x) + ch);
+      else eps = Philox::normal1(seed, off, p.stream_id, (uint64_t)b * per + e);
+      const float sq = expf(qs);
+      Elem<T>::st(vptr<T>(p.z, b, y, x) + ch, ql + sq * eps);
+      if (p.eps_out.p) Elem<T>::st(vptr<T>(p.eps_out, b, y, x) + ch, eps);
+      // vae.py:18-25, same association as the reference: -0.5 + p - q + 0.5*(e^{q}^2 + d^2)/e^{p}^2
+      const float sp = expf(ps);
+      const float d = ql - pl;
+      kl_acc += -0.5f + ps - qs + 0.5f * (sq * sq + d * d) / (sp * sp);
+    }
+  }
+  const float tot = block_sum_256(kl_acc, sm);
+  if (threadIdx.x == 0) p.kl_part[(int64_t)b * p.kl_stride + chunk] = tot;
+}
+
+struct LatBwdP {
+  int n, h, w, c;
+  View q_loc, q_ls, p_loc, p_ls, z, gz, g_q_loc, g_q_ls, g_p_loc, g_p_ls;
+  const float* coef;
+  int coef_stride, acc_q, acc_p;
+  float logt;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(LatBwdP p) {
+  const int per = p.h * p.w * p.c;
+  const int64_t total = (int64_t)p.n * per;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+    const int b = (int)(g / per), e = (int)(g % per);
+    int y, x, ch;
+    lat_decode(e, p.w, p.c, y, x, ch);
+    const float ql = Elem<T>::ld(vptr<T>(p.q_loc, b, y, x) + ch);
+    const float qs = Elem<T>::ld(vptr<T>(p.q_ls, b, y, x) + ch) + p.logt;
+    const float pl = Elem<T>::ld(vptr<T>(p.p_loc, b, y, x) + ch);
+    const float ps = Elem<T>::ld(vptr<T>(p.p_ls, b, y, x) + ch) + p.logt;
+    const float k = p.coef[(int64_t)b * p.coef_stride];
+    const float e2q = expf(2.f * qs), ie2p = expf(-2.f * ps);
+    const float d = ql - pl;
+    float gql = k * d * ie2p;
+    float gqs = k * (e2q * ie2p - 1.f);
+    const float gpl = -k * d * ie2p;
+    const float gps = k * (1.f - (e2q + d * d) * ie2p);
+    if (p.gz.p) {
+      const float gzv = Elem<T>::ld(vptr<T>(p.gz, b, y, x) + ch);
+      const float zv = Elem<T>::ld(vptr<T>(p.z, b, y, x) + ch);
+      gql += gzv;
+      gqs += gzv * (zv - ql);  // dz/dq_ls = e^{q_ls} eps = z - q_loc
+    }
+    T* o;
+    o = vptr<T>(p.g_q_loc, b, y, x) + ch; Elem<T>::st(o, p.acc_q ? Elem<T>::ld(o) + gql : gql);
+    o = vptr<T>(p.g_q_ls, b, y, x) + ch;  Elem<T>::st(o, p.acc_q ? Elem<T>::ld(o) + gqs : gqs);
+    o = vptr<T>(p.g_p_loc, b, y, x) + ch; Elem<T>::st(o, p.acc_p ? Elem<T>::ld(o) + gpl : gpl);
+    o = vptr<T>(p.g_p_ls, b, y, x) + ch;  Elem<T>::st(o, p.acc_p ? Elem<T>::ld(o) + gps : gps);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sample_gaussian_kernel(int n, int h, int w, int c, View loc, View ls, View eps_in,
+                                                              const uint64_t* rng, uint32_t stream_id, float logt, View z) {
+  const int per = h * w * c;
+  const int64_t total = (int64_t)n * per;
+  uint64_t seed = 0, off = 0;
+  if (!eps_in.p) { seed = rng[0]; off = rng[1]; }
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+    const int b = (int)(g / per), e = (int)(g % per);
+    int y, x, ch;
+    lat_decode(e, w, c, y, x, ch);
+    const float l = Elem<T>::ld(vptr<T>(loc, b, y, x) + ch);
+    const float s = Elem<T>::ld(vptr<T>(ls, b, y, x) + ch) + logt;
+    const float eps = eps_in.p ? Elem<T>::ld(vptr<T>(eps_in, b, y, x) + ch) : Philox::normal1(seed, off, stream_id, (uint64_t)g);
+    Elem<T>::st(vptr<T>(z, b, y, x) + ch, l + expf(s) * eps);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mediator_kernel(int n, int h, int w, int c, View z, View q_loc, View q_ls, View p_loc,
+                                                       View p_ls, float alpha, float t, float logt, View out) {
+  const int per = h * w * c;
+  const int64_t total = (int64_t)n * per;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+    const int b = (int)(g / per), e = (int)(g % per);
+    int y, x, ch;
+    lat_decode(e, w, c, y, x, ch);
+    const float zv = Elem<T>::ld(vptr<T>(z, b, y, x) + ch);
+    const float ql = Elem<T>::ld(vptr<T>(q_loc, b, y, x) + ch);
+    const float qsc = expf(Elem<T>::ld(vptr<T>(q_ls, b, y, x) + ch) + logt);
+    const float pl = Elem<T>::ld(vptr<T>(p_loc, b, y, x) + ch);
+    const float psc = expf(Elem<T>::ld(vptr<T>(p_ls, b, y, x) + ch) + logt);
+    const float u = (zv - ql) / qsc;
+    const float r_loc = alpha * ql + (1.f - alpha) * pl;
+    float r_scale = sqrtf(alpha * alpha * qsc * qsc + (1.f - alpha) * (1.f - alpha) * psc * psc);
+    if (t > 0.f) r_scale *= t;
+    Elem<T>::st(vptr<T>(out, b, y, x) + ch, r_loc + r_scale * u);
+  }
+}
+
+static inline int lat_grid(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace cgen
+
+using namespace cgen;
+
+extern "C" int cgen_reparam_kl_chunks(int32_t h, int32_t w, int32_t c) { return ceil_div((int64_t)h * w * c, LAT_CHUNK); }
+
+extern "C" int cgen_reparam_kl_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls,
+                                   cgen_view p_loc, cgen_view p_ls, cgen_view eps_in, const uint64_t* rng, uint32_t stream_id,
+                                   float logt, cgen_view z, cgen_view eps_out, float* kl_part, int32_t kl_stride,
+                                   cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_reparam_kl_fwd: bad dtype");
+  CGEN_REQUIRE(q_loc.p && q_ls.p && p_loc.p && p_ls.p && z.p && kl_part, "cgen_reparam_kl_fwd: null view");
+  CGEN_REQUIRE(eps_in.p || rng, "cgen_reparam_kl_fwd: need eps or rng");
+  LatP p;
+  p.n = n; p.h = h; p.w = w; p.c = c;
+  p.q_loc = mk(q_loc); p.q_ls = mk(q_ls); p.p_loc = mk(p_loc); p.p_ls = mk(p_ls);
+  p.eps_in = mk(eps_in); p.z = mk(z); p.eps_out = mk(eps_out);
+  p.rng = rng; p.stream_id = stream_id; p.logt = logt; p.kl_part = kl_part; p.kl_stride = kl_stride;
+  dim3 grid(cgen_reparam_kl_chunks(h, w, c), n);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(reparam_kl_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(reparam_kl_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("cgen_reparam_kl_fwd");
+}
+
+extern "C" int cgen_reparam_kl_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls,
+                                   cgen_view p_loc, cgen_view p_ls, cgen_view z, float logt, cgen_view gz,
+                                   const float* kl_coef_dev, int32_t coef_stride, cgen_view g_q_loc, cgen_view g_q_ls,
+                                   cgen_view g_p_loc, cgen_view g_p_ls, int32_t acc_q, int32_t acc_p, cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_reparam_kl_bwd: bad dtype");
+  CGEN_REQUIRE(q_loc.p && q_ls.p && p_loc.p && p_ls.p && kl_coef_dev && g_q_loc.p && g_q_ls.p && g_p_loc.p && g_p_ls.p,
+               "cgen_reparam_kl_bwd: null view");
+  CGEN_REQUIRE(!gz.p || z.p, "cgen_reparam_kl_bwd: gz given without z");
+  LatBwdP p;
+  p.n = n; p.h = h; p.w = w; p.c = c;
+  p.q_loc = mk(q_loc); p.q_ls = mk(q_ls); p.p_loc = mk(p_loc); p.p_ls = mk(p_ls); p.z = mk(z); p.gz = mk(gz);
+  p.g_q_loc = mk(g_q_loc); p.g_q_ls = mk(g_q_ls); p.g_p_loc = mk(g_p_loc); p.g_p_ls = mk(g_p_ls);
+  p.coef = kl_coef_dev; p.coef_stride = coef_stride; p.acc_q = acc_q; p.acc_p = acc_p; p.logt = logt;
+  const int grid = lat_grid((int64_t)n * h * w * c);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(reparam_kl_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(reparam_kl_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("cgen_reparam_kl_bwd");
+}
+
+extern "C" int cgen_sample_gaussian(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view loc, cgen_view ls,
+                                    cgen_view eps_in, const uint64_t* rng, uint32_t stream_id, float logt, cgen_view z,
+                                    cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_sample_gaussian: bad dtype");
+  CGEN_REQUIRE(loc.p && ls.p && z.p && (eps_in.p || rng), "cgen_sample_gaussian: bad args");
+  const int grid = lat_grid((int64_t)n * h * w * c);
+  if (dtype == CGEN_F32)
+    hipLaunchKernelGGL(sample_gaussian_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(loc), mk(ls), mk(eps_in), rng, stream_id, logt, mk(z));
+  else
+    hipLaunchKernelGGL(sample_gaussian_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(loc), mk(ls), mk(eps_in), rng, stream_id, logt, mk(z));
+  return check_launch("cgen_sample_gaussian");
+}
+
+extern "C" int cgen_mediator_mix(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view z, cgen_view q_loc,
+                                 cgen_view q_ls, cgen_view p_loc, cgen_view p_ls, float alpha, float t, float logt,
+                                 cgen_view out, cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_mediator_mix: bad dtype");
+  CGEN_REQUIRE(z.p && q_loc.p && q_ls.p && p_loc.p && p_ls.p && out.p, "cgen_mediator_mix: null view");
+  const int grid = lat_grid((int64_t)n * h * w * c);
+  if (dtype == CGEN_F32)
+    hipLaunchKernelGGL(mediator_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(z), mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), alpha, t, logt, mk(out));
+  else
+    hipLaunchKernelGGL(mediator_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(z), mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), alpha, t, logt, mk(out));
+  return check_launch("cgen_mediator_mix");
+}

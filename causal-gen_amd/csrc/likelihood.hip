@@ -1,0 +1,496 @@
+// Likelihood kernels: discretised Gaussian (vae.py:352-422), discretised mixture of logistics (dmol.py), ELBO
+// assembly (vae.py:450-457) and the counterfactual pixel step (dscm.py:55-63).  All f32 math; HBM-bound.
+#include "common.h"
+
+namespace cgen {
+
+#define LIKE_PIX 1024  // pixels per block (4 per thread)
+
+// ----------------------------------------------------------------------------- discretised Gaussian
+#define DG_MIN_LS (-9.0f)
+#define DG_K0 0.79788456080286535588f  // sqrt(2/pi)
+#define DG_K1 0.044715f
+
+__device__ __forceinline__ float dg_cdf(float u) { return 0.5f * (1.0f + tanhf(DG_K0 * (u + DG_K1 * u * u * u))); }
+__device__ __forceinline__ float dg_cdf_grad(float u) {
+  const float t = tanhf(DG_K0 * (u + DG_K1 * u * u * u));
+  return 0.5f * (1.f - t * t) * DG_K0 * (1.f + 3.f * DG_K1 * u * u);
+}
+
+struct DgP {
+  int n, h, w, c;
+  View params, x, g;
+  float* part;
+  const float* coef;
+  int coef_stride;
+};
+
+// per-pixel parameter decode shared by fwd/bwd: loc[c], ls[c] (clamped), tanh coeffs
+template <typename T>
+__device__ __forceinline__ void dg_load(const DgP& p, int b, int y, int x, float (&loc)[3], float (&ls_raw)[3], float (&k)[3],
+                                        float (&xv)[3]) {
+  const T* pp = vptr<T>(p.params, b, y, x);
+  const T* xp = vptr<T>(p.x, b, y, x);
+  for (int c = 0; c < p.c; ++c) {
+    loc[c] = Elem<T>::ld(pp + c);
+    ls_raw[c] = Elem<T>::ld(pp + p.c + c);
+    xv[c] = Elem<T>::ld(xp + c);
+  }
+  if (p.c == 3) {
+    for (int j = 0; j < 3; ++j) k[j] = tanhf(Elem<T>::ld(pp + 6 + j));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dgauss_nll_fwd_kernel(DgP p) {
+  __shared__ float sm[4];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int npix = p.h * p.w;
+  float acc = 0.f;
+  for (int i = 0; i < LIKE_PIX / 256; ++i) {
+    const int px = chunk * LIKE_PIX + i * 256 + threadIdx.x;
+    if (px < npix) {
+      const int y = px / p.w, x = px % p.w;
+      float loc[3], lsr[3], k[3], xv[3];
+      dg_load<T>(p, b, y, x, loc, lsr, k, xv);
+      if (p.c == 3) {  // training-time autoregressive means use the true x (vae.py:370-377)
+        loc[2] = loc[2] + k[1] * xv[0] + k[2] * xv[1];
+        loc[1] = loc[1] + k[0] * xv[0];
+      }
+      for (int c = 0; c < p.c; ++c) {
+        const float ls = fmaxf(lsr[c], DG_MIN_LS);
+        const float inv = expf(-ls), d = xv[c] - loc[c];
+        const float cp = dg_cdf(inv * (d + 1.f / 255.f)), cm = dg_cdf(inv * (d - 1.f / 255.f));
+        float lp;
+        if (xv[c] < -0.999f) lp = logf(fmaxf(cp, 1e-12f));
+        else if (xv[c] > 0.999f) lp = logf(fmaxf(1.f - cm, 1e-12f));
+        else lp = logf(fmaxf(cp - cm, 1e-12f));
+        acc -= lp;
+      }
+    }
+  }
+  const float tot = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) p.part[(int64_t)b * gridDim.x + chunk] = tot;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dgauss_nll_bwd_kernel(DgP p) {
+  const int npix = p.h * p.w;
+  const int64_t total = (int64_t)p.n * npix;
+  for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * 256) {
+    const int b = (int)(gi / npix), px = (int)(gi % npix);
+    const int y = px / p.w, x = px % p.w;
+    float loc[3], lsr[3], k[3], xv[3];
+    dg_load<T>(p, b, y, x, loc, lsr, k, xv);
+    if (p.c == 3) {
+      loc[2] = loc[2] + k[1] * xv[0] + k[2] * xv[1];
+      loc[1] = loc[1] + k[0] * xv[0];
+    }
+    const float coef = p.coef[(int64_t)b * p.coef_stride];
+    float gloc[3], gls[3];
+    for (int c = 0; c < p.c; ++c) {
+      const float ls = fmaxf(lsr[c], DG_MIN_LS);
+      const float inv = expf(-ls), d = xv[c] - loc[c];
+      const float up = inv * (d + 1.f / 255.f), um = inv * (d - 1.f / 255.f);
+      const float cp = dg_cdf(up), cm = dg_cdf(um);
+      float dup = 0.f, dum = 0.f;  // d lp / d up, d lp / d um
+      if (xv[c] < -0.999f) { if (cp >= 1e-12f) dup = dg_cdf_grad(up) / cp; }
+      else if (xv[c] > 0.999f) { if (1.f - cm >= 1e-12f) dum = -dg_cdf_grad(um) / (1.f - cm); }
+      else { const float de = cp - cm; if (de >= 1e-12f) { dup = dg_cdf_grad(up) / de; dum = -dg_cdf_grad(um) / de; } }
+      // up = inv*(d+1/255): d up/d loc = -inv ; d up/d ls = -up
+      const float dlp_dloc = -(dup + dum) * inv;
+      const float dlp_dls = (lsr[c] >= DG_MIN_LS) ? -(dup * up + dum * um) : 0.f;
+      gloc[c] = -coef * dlp_dloc;
+      gls[c] = -coef * dlp_dls;
+    }
+    T* go = vptr<T>(p.g, b, y, x);
+    for (int c = 0; c < p.c; ++c) {
+      Elem<T>::st(go + c, gloc[c]);
+      Elem<T>::st(go + p.c + c, gls[c]);
+    }
+    if (p.c == 3) {  // coeff_raw -> tanh -> k0 (g<-r), k1 (b<-r), k2 (b<-g)
+      Elem<T>::st(go + 6, gloc[1] * xv[0] * (1.f - k[0] * k[0]));
+      Elem<T>::st(go + 7, gloc[2] * xv[0] * (1.f - k[1] * k[1]));
+      Elem<T>::st(go + 8, gloc[2] * xv[1] * (1.f - k[2] * k[2]));
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dgauss_sample_kernel(int n, int h, int w, int c, View params, float logt, float* xo, float* so) {
+  const int npix = h * w;
+  const int64_t total = (int64_t)n * npix;
+  for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * 256) {
+    const int b = (int)(gi / npix), px = (int)(gi % npix);
+    const T* pp = vptr<T>(params, b, px / w, px % w);
+    float loc[3];
+    for (int ch = 0; ch < c; ++ch) loc[ch] = Elem<T>::ld(pp + ch);
+    if (c == 3) {  // inference: autoregressive on the clamped predicted channels (vae.py:360-369)
+      const float k0 = tanhf(Elem<T>::ld(pp + 6)), k1 = tanhf(Elem<T>::ld(pp + 7)), k2 = tanhf(Elem<T>::ld(pp + 8));
+      const float r = fminf(fmaxf(loc[0], -1.f), 1.f);
+      const float g = fminf(fmaxf(loc[1] + k0 * r, -1.f), 1.f);
+      const float bl = fminf(fmaxf(loc[2] + k1 * r + k2 * g, -1.f), 1.f);
+      loc[0] = r; loc[1] = g; loc[2] = bl;
+    }
+    for (int ch = 0; ch < c; ++ch) {
+      const int64_t o = ((int64_t)b * c + ch) * npix + px;
+      xo[o] = fminf(fmaxf(loc[ch], -1.f), 1.f);
+      so[o] = expf(fmaxf(Elem<T>::ld(pp + c + ch), DG_MIN_LS) + logt);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- discretised mixture of logistics
+#define DM_NMIX 10
+#define DM_MIN_LS (-7.0f)
+#define DM_LOG_127_5 4.84810637233259f
+
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_t(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float softplus_grad(float x) { return x > 20.f ? 1.f : sigmoid_t(x); }
+
+// log-prob of one (channel, mixture) and its derivatives w.r.t. mean and RAW log-scale
+__device__ __forceinline__ float dm_logprob(float xv, float mean, float ls_raw, float* d_mean, float* d_ls) {
+  const float ls = fmaxf(ls_raw, DM_MIN_LS);
+  const float inv = expf(-ls), d = xv - mean;
+  const float up = inv * (d + 1.f / 255.f), um = inv * (d - 1.f / 255.f), mid = inv * d;
+  float lp, dup = 0.f, dum = 0.f, dmid = 0.f, dls_direct = 0.f;
+  if (xv < -0.999f) {
+    lp = up - softplus_t(up);
+    dup = 1.f - softplus_grad(up);
+  } else if (xv > 0.999f) {
+    lp = -softplus_t(um);
+    dum = -softplus_grad(um);
+  } else {
+    const float cp = sigmoid_t(up), cm = sigmoid_t(um), de = cp - cm;
+    if (de > 1e-5f) {
+      lp = logf(fmaxf(de, 1e-12f));
+      dup = cp * (1.f - cp) / de;
+      dum = -cm * (1.f - cm) / de;
+    } else {
+      lp = mid - ls - 2.f * softplus_t(mid) - DM_LOG_127_5;
+      dmid = 1.f - 2.f * softplus_grad(mid);
+      dls_direct = -1.f;
+    }
+  }
+  if (d_mean) {
+    *d_mean = -(dup + dum + dmid) * inv;
+    *d_ls = (ls_raw > DM_MIN_LS) ? (-(dup * up + dum * um + dmid * mid) + dls_direct) : 0.f;
+  }
+  return lp;
+}
+
+template <typename T>
+__device__ __forceinline__ void dm_load(const T* lp, float (&l)[100]) {
+#pragma unroll
+  for (int i = 0; i < 100; ++i) l[i] = Elem<T>::ld(lp + i);
+}
+
+struct DmP {
+  int n, h, w;
+  View logits, x, g;
+  float* part;
+  const float* coef;
+  int coef_stride;
+};
+
+// returns log p(x) for the pixel; if G != nullptr writes d(log p)/d logits into G[100]
+__device__ __forceinline__ float dm_pixel(const float (&l)[100], const float (&xv)[3], float* G) {
+  float S[DM_NMIX];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int m = 0; m < DM_NMIX; ++m) mx = fmaxf(mx, l[m]);
+  float se = 0.f;
+#pragma unroll
+  for (int m = 0; m < DM_NMIX; ++m) se += expf(l[m] - mx);
+  const float lse_logits = mx + logf(se);
+  float dmean[3][DM_NMIX], dls[3][DM_NMIX], kk[3][DM_NMIX];
+#pragma unroll
+  for (int m = 0; m < DM_NMIX; ++m) {
+    const float k0 = tanhf(l[10 + 20 + m]), k1 = tanhf(l[10 + 30 + 20 + m]), k2 = tanhf(l[10 + 60 + 20 + m]);
+    kk[0][m] = k0; kk[1][m] = k1; kk[2][m] = k2;
+    const float mr = l[10 + m];
+    const float mg = l[10 + 30 + m] + k0 * xv[0];
+    const float mb = l[10 + 60 + m] + k1 * xv[0] + k2 * xv[1];
+    float s = l[m] - lse_logits;
+    s += dm_logprob(xv[0], mr, l[10 + 10 + m], G ? &dmean[0][m] : nullptr, G ? &dls[0][m] : nullptr);
+    s += dm_logprob(xv[1], mg, l[10 + 30 + 10 + m], G ? &dmean[1][m] : nullptr, G ? &dls[1][m] : nullptr);
+    s += dm_logprob(xv[2], mb, l[10 + 60 + 10 + m], G ? &dmean[2][m] : nullptr, G ? &dls[2][m] : nullptr);
+    S[m] = s;
+  }
+  float smx = -INFINITY;
+#pragma unroll
+  for (int m = 0; m < DM_NMIX; ++m) smx = fmaxf(smx, S[m]);
+  float sse = 0.f;
+#pragma unroll
+  for (int m = 0; m < DM_NMIX; ++m) sse += expf(S[m] - smx);
+  const float out = smx + logf(sse);
+  if (G) {
+#pragma unroll
+    for (int m = 0; m < DM_NMIX; ++m) {
+      const float wm = expf(S[m] - out);          // posterior responsibility
+      const float pim = expf(l[m] - lse_logits);  // prior mixture weight
+      G[m] = wm - pim;
+      G[10 + m] = wm * dmean[0][m];
+      G[10 + 10 + m] = wm * dls[0][m];
+      G[10 + 20 + m] = wm * dmean[1][m] * xv[0] * (1.f - kk[0][m] * kk[0][m]);
+      G[10 + 30 + m] = wm * dmean[1][m];
+      G[10 + 30 + 10 + m] = wm * dls[1][m];
+      G[10 + 30 + 20 + m] = wm * dmean[2][m] * xv[0] * (1.f - kk[1][m] * kk[1][m]);
+      G[10 + 60 + m] = wm * dmean[2][m];
+      G[10 + 60 + 10 + m] = wm * dls[2][m];
+      G[10 + 60 + 20 + m] = wm * dmean[2][m] * xv[1] * (1.f - kk[2][m] * kk[2][m]);
+    }
+  }
+  return out;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dmol_nll_fwd_kernel(DmP p) {
+  __shared__ float sm[4];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int npix = p.h * p.w;
+  float acc = 0.f;
+  for (int i = 0; i < LIKE_PIX / 256; ++i) {
+    const int px = chunk * LIKE_PIX + i * 256 + threadIdx.x;
+    if (px < npix) {
+      const int y = px / p.w, x = px % p.w;
+      float l[100], xv[3];
+      dm_load<T>(vptr<T>(p.logits, b, y, x), l);
+      const T* xp = vptr<T>(p.x, b, y, x);
+      xv[0] = Elem<T>::ld(xp); xv[1] = Elem<T>::ld(xp + 1); xv[2] = Elem<T>::ld(xp + 2);
+      acc -= dm_pixel(l, xv, nullptr);
+    }
+  }
+  const float tot = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) p.part[(int64_t)b * gridDim.x + chunk] = tot;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dmol_nll_bwd_kernel(DmP p) {
+  const int npix = p.h * p.w;
+  const int64_t total = (int64_t)p.n * npix;
+  for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * 256) {
+    const int b = (int)(gi / npix), px = (int)(gi % npix);
+    const int y = px / p.w, x = px % p.w;
+    float l[100], xv[3], G[100];
+    dm_load<T>(vptr<T>(p.logits, b, y, x), l);
+    const T* xp = vptr<T>(p.x, b, y, x);
+    xv[0] = Elem<T>::ld(xp); xv[1] = Elem<T>::ld(xp + 1); xv[2] = Elem<T>::ld(xp + 2);
+    dm_pixel(l, xv, G);
+    const float coef = -p.coef[(int64_t)b * p.coef_stride];
+    T* go = vptr<T>(p.g, b, y, x);
+#pragma unroll
+    for (int i = 0; i < 100; ++i) Elem<T>::st(go + i, coef * G[i]);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dmol_decode_kernel(int n, int h, int w, View logits, int mode, const uint64_t* rng,
+                                                          uint32_t stream_id, float logt, float* xo, float* so) {
+  const int npix = h * w;
+  const int64_t total = (int64_t)n * npix;
+  uint64_t seed = 0, off = 0;
+  if (mode == 2) { seed = rng[0]; off = rng[1]; }
+  for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * 256) {
+    const int b = (int)(gi / npix), px = (int)(gi % npix);
+    float l[100];
+    dm_load<T>(vptr<T>(logits, b, px / w, px % w), l);
+    float sel[DM_NMIX];
+    uint32_t r[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0}, r3[4] = {0, 0, 0, 0};
+    if (mode == 0) {  // soft: softmax weights (dmol.py:170-172)
+      float mx = -INFINITY, se = 0.f;
+#pragma unroll
+      for (int m = 0; m < DM_NMIX; ++m) mx = fmaxf(mx, l[m]);
+#pragma unroll
+      for (int m = 0; m < DM_NMIX; ++m) se += expf(l[m] - mx);
+      const float lse = mx + logf(se);
+#pragma unroll
+      for (int m = 0; m < DM_NMIX; ++m) sel[m] = expf(l[m] - lse);
+    } else {
+      if (mode == 2) {  // Gumbel-max with uniforms in [1e-5, 1-1e-5] (dmol.py:128-129)
+        Philox::gen(seed, off, stream_id, (uint64_t)gi * 4 + 0, r);
+        Philox::gen(seed, off, stream_id, (uint64_t)gi * 4 + 1, r2);
+        Philox::gen(seed, off, stream_id, (uint64_t)gi * 4 + 2, r3);
+      }
+      int am = 0;
+      float best = -INFINITY;
+#pragma unroll
+      for (int m = 0; m < DM_NMIX; ++m) {
+        float v = l[m];
+        if (mode == 2) {
+          const uint32_t rr = m < 4 ? r[m] : (m < 8 ? r2[m - 4] : r3[m - 8]);
+          const float u = 1e-5f + (1.f - 2e-5f) * Philox::u01(rr);
+          v -= logf(-logf(u));
+        }
+        if (v > best) { best = v; am = m; }
+      }
+#pragma unroll
+      for (int m = 0; m < DM_NMIX; ++m) sel[m] = (m == am) ? 1.f : 0.f;
+    }
+    float mu[3], ls[3], co[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float a = 0.f, s = 0.f, k = 0.f;
+#pragma unroll
+      for (int m = 0; m < DM_NMIX; ++m) {
+        a += l[10 + 30 * c + m] * sel[m];
+        s += l[10 + 30 * c + 10 + m] * sel[m];
+        k += tanhf(l[10 + 30 * c + 20 + m]) * sel[m];
+      }
+      mu[c] = a; ls[c] = fmaxf(s, DM_MIN_LS); co[c] = k;
+    }
+    if (mode == 2) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        ls[c] += logt;
+        const float u = 1e-5f + (1.f - 2e-5f) * Philox::u01(c == 0 ? r3[2] : (c == 1 ? r3[3] : r2[3] ^ 0x9E3779B9u));
+        mu[c] += expf(ls[c]) * (logf(u) - logf(1.f - u));
+      }
+    }
+    const float x0 = fminf(fmaxf(mu[0], -1.f), 1.f);
+    const float x1 = fminf(fmaxf(mu[1] + co[0] * x0, -1.f), 1.f);
+    const float x2 = fminf(fmaxf(mu[2] + co[1] * x0 + co[2] * x1, -1.f), 1.f);
+    const float xs[3] = {x0, x1, x2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int64_t o = ((int64_t)b * 3 + c) * npix + px;
+      xo[o] = xs[c];
+      so[o] = expf(ls[c]);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- ELBO assembly + cf pixels
+__global__ __launch_bounds__(256) void elbo_finalize_kernel(int n, const float* nll_part, int nll_count, float nll_div,
+                                                            const float* kl_part, int kl_count, float kl_div, float beta,
+                                                            float* out3) {
+  extern __shared__ float per[];  // [2*n]
+  for (int b = threadIdx.x; b < n; b += 256) {
+    float a = 0.f, k = 0.f;
+    for (int j = 0; j < nll_count; ++j) a += nll_part[(int64_t)b * nll_count + j];
+    for (int j = 0; j < kl_count; ++j) k += kl_part[(int64_t)b * kl_count + j];
+    per[b] = a / nll_div;
+    per[n + b] = k / kl_div;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, k = 0.f;
+    for (int b = 0; b < n; ++b) { a += per[b]; k += per[n + b]; }
+    a /= (float)n; k /= (float)n;
+    out3[0] = a + beta * k; out3[1] = a; out3[2] = k;
+  }
+}
+
+__global__ __launch_bounds__(256) void cf_pixels_kernel(int64_t count, const float* x, const float* rec_loc, const float* rec_scale,
+                                                        const float* cf_loc, const float* cf_scale, float* cf_x, float* sum_x,
+                                                        float* sum_x2) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    const float u = (x[i] - rec_loc[i]) / fmaxf(rec_scale[i], 1e-12f);
+    const float v = fminf(fmaxf(cf_loc[i] + cf_scale[i] * u, -1.f), 1.f);
+    cf_x[i] = v;
+    if (sum_x) sum_x[i] += v;
+    if (sum_x2) sum_x2[i] += v * v;
+  }
+}
+
+static inline int like_grid(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace cgen
+
+using namespace cgen;
+
+extern "C" int cgen_like_chunks(int32_t h, int32_t w) { return ceil_div((int64_t)h * w, LIKE_PIX); }
+
+extern "C" int cgen_dgauss_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x,
+                                   float* nll_part, cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dgauss_nll_fwd: bad dtype");
+  CGEN_REQUIRE((c == 1 || c == 3) && params.p && x.p && nll_part && params.c >= 2 * c + (c == 3 ? 3 : 0), "cgen_dgauss_nll_fwd: bad args");
+  DgP p;
+  memset(&p, 0, sizeof(p));
+  p.n = n; p.h = h; p.w = w; p.c = c; p.params = mk(params); p.x = mk(x); p.part = nll_part;
+  dim3 grid(cgen_like_chunks(h, w), n);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(dgauss_nll_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(dgauss_nll_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("cgen_dgauss_nll_fwd");
+}
+
+extern "C" int cgen_dgauss_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x,
+                                   const float* coef_dev, int32_t coef_stride, cgen_view g_params, cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dgauss_nll_bwd: bad dtype");
+  CGEN_REQUIRE((c == 1 || c == 3) && params.p && x.p && coef_dev && g_params.p, "cgen_dgauss_nll_bwd: bad args");
+  DgP p;
+  memset(&p, 0, sizeof(p));
+  p.n = n; p.h = h; p.w = w; p.c = c; p.params = mk(params); p.x = mk(x); p.g = mk(g_params); p.coef = coef_dev; p.coef_stride = coef_stride;
+  const int grid = like_grid((int64_t)n * h * w);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(dgauss_nll_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(dgauss_nll_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("cgen_dgauss_nll_bwd");
+}
+
+extern "C" int cgen_dgauss_sample(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, float logt,
+                                  float* x_nchw, float* scale_nchw, cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dgauss_sample: bad dtype");
+  CGEN_REQUIRE((c == 1 || c == 3) && params.p && x_nchw && scale_nchw, "cgen_dgauss_sample: bad args");
+  const int grid = like_grid((int64_t)n * h * w);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(dgauss_sample_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), logt, x_nchw, scale_nchw);
+  else hipLaunchKernelGGL(dgauss_sample_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), logt, x_nchw, scale_nchw);
+  return check_launch("cgen_dgauss_sample");
+}
+
+extern "C" int cgen_dmol_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, cgen_view x, float* nll_part,
+                                 cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dmol_nll_fwd: bad dtype");
+  CGEN_REQUIRE(logits.p && x.p && nll_part && logits.c == 100 && x.c == 3, "cgen_dmol_nll_fwd: bad args");
+  DmP p;
+  memset(&p, 0, sizeof(p));
+  p.n = n; p.h = h; p.w = w; p.logits = mk(logits); p.x = mk(x); p.part = nll_part;
+  dim3 grid(cgen_like_chunks(h, w), n);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(dmol_nll_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(dmol_nll_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("cgen_dmol_nll_fwd");
+}
+
+extern "C" int cgen_dmol_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, cgen_view x,
+                                 const float* coef_dev, int32_t coef_stride, cgen_view g_logits, cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dmol_nll_bwd: bad dtype");
+  CGEN_REQUIRE(logits.p && x.p && coef_dev && g_logits.p && logits.c == 100 && g_logits.c == 100, "cgen_dmol_nll_bwd: bad args");
+  DmP p;
+  memset(&p, 0, sizeof(p));
+  p.n = n; p.h = h; p.w = w; p.logits = mk(logits); p.x = mk(x); p.g = mk(g_logits); p.coef = coef_dev; p.coef_stride = coef_stride;
+  const int grid = like_grid((int64_t)n * h * w);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(dmol_nll_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(dmol_nll_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("cgen_dmol_nll_bwd");
+}
+
+extern "C" int cgen_dmol_decode(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, int32_t mode,
+                                const uint64_t* rng, uint32_t stream_id, float logt, float* x_nchw, float* scale_nchw,
+                                cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dmol_decode: bad dtype");
+  CGEN_REQUIRE(logits.p && logits.c == 100 && x_nchw && scale_nchw && mode >= 0 && mode <= 2 && (mode != 2 || rng), "cgen_dmol_decode: bad args");
+  const int grid = like_grid((int64_t)n * h * w);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(dmol_decode_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, mk(logits), mode, rng, stream_id, logt, x_nchw, scale_nchw);
+  else hipLaunchKernelGGL(dmol_decode_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, mk(logits), mode, rng, stream_id, logt, x_nchw, scale_nchw);
+  return check_launch("cgen_dmol_decode");
+}
+
+extern "C" int cgen_elbo_finalize(int32_t n, const float* nll_part, int32_t nll_count, float nll_div, const float* kl_part,
+                                  int32_t kl_count, float kl_div, float beta, float* out3, cgen_stream_t stream) {
+  CGEN_REQUIRE(n > 0 && n <= 8192 && nll_part && out3 && (kl_count == 0 || kl_part), "cgen_elbo_finalize: bad args");
+  hipLaunchKernelGGL(elbo_finalize_kernel, dim3(1), dim3(256), 2 * n * sizeof(float), (hipStream_t)stream, n, nll_part, nll_count,
+                     nll_div, kl_part, kl_count, kl_div, beta, out3);
+  return check_launch("cgen_elbo_finalize");
+}
+
+extern "C" int cgen_cf_pixels(int64_t count, const float* x, const float* rec_loc, const float* rec_scale, const float* cf_loc,
+                              const float* cf_scale, float* cf_x, float* sum_x, float* sum_x2, cgen_stream_t stream) {
+  CGEN_REQUIRE(count >= 0 && x && rec_loc && rec_scale && cf_loc && cf_scale && cf_x, "cgen_cf_pixels: null");
+  if (count == 0) return CGEN_OK;
+  hipLaunchKernelGGL(cf_pixels_kernel, dim3(like_grid(count)), dim3(256), 0, (hipStream_t)stream, count, x, rec_loc, rec_scale,
+                     cf_loc, cf_scale, cf_x, sum_x, sum_x2);
+  return check_launch("cgen_cf_pixels");
+}

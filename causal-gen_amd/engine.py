@@ -1,0 +1,635 @@
+"""Execution engine: NHWC views over a bump arena, one Python call per fused HIP launch, and a reverse tape.
+
+The reference leans on torch.autograd over ~10 tiny ATen ops per conv.  Here the forward is a short
+list of fused launches (conv with virtual concat + activation prologue + residual epilogue, pool, upsample+bias,
+reparam+KL, NLL) and the backward replays the tape with hand-written gradient kernels: dgrad is the same conv kernel
+on a flipped weight image with the activation derivative in the epilogue, wgrad is split-K partials reduced by one
+multi-tensor launch.  Every buffer comes from an arena that is reset per step, so a step has a fixed launch
+sequence with fixed addresses and can be captured in a hipGraph.
+
+PyTorch supplies device memory, streams and the nn.Module parameter containers only.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, NULL_VIEW, View
+
+_ALIGN = 256
+
+
+def _ceil(a, m):
+    return (a + m - 1) // m * m
+
+
+class NT:
+    """NHWC strided view (channel stride 1) -- the Python twin of cgen_view."""
+    __slots__ = ("ptr", "n", "h", "w", "c", "sn", "sh", "sw", "base", "coff", "rg", "keep", "_cv", "es")
+
+    def __init__(self, ptr, n, h, w, c, sn, sh, sw, es, base=None, coff=0, rg=True, keep=None):
+        self.ptr, self.n, self.h, self.w, self.c = ptr, n, h, w, c
+        self.sn, self.sh, self.sw, self.es = sn, sh, sw, es
+        self.base = base if base is not None else self
+        self.coff, self.rg, self.keep, self._cv = coff, rg, keep, None
+
+    def cv(self):
+        if self._cv is None:
+            self._cv = View(self.ptr, self.sn, self.sh, self.sw, self.c, 0)
+        return self._cv
+
+    def chan(self, a, b):
+        assert 0 <= a < b <= self.c
+        return NT(self.ptr + a * self.es, self.n, self.h, self.w, b - a, self.sn, self.sh, self.sw, self.es,
+                  base=self.base, coff=self.coff + a, rg=self.rg, keep=self.keep)
+
+    def crop(self, r):
+        """[:, :r, :r, :] -- only used on tensors that need no gradient (parents)."""
+        if r == self.h and r == self.w:
+            return self
+        assert not self.rg
+        return NT(self.ptr, self.n, r, r, self.c, self.sn, self.sh, self.sw, self.es, base=None, coff=0, rg=False,
+                  keep=self.keep)
+
+    @property
+    def shape(self):
+        return (self.n, self.h, self.w, self.c)
+
+
+class Arena:
+    """Bump allocator over a few large device buffers; reset() per step keeps addresses stable across steps."""
+
+    def __init__(self, device, chunk_bytes=1 << 30):
+        self.device, self.chunk_bytes = device, chunk_bytes
+        self.chunks, self.ci, self.off = [], 0, 0
+        self.high_water = 0
+
+    def reset(self):
+        self.ci, self.off = 0, 0
+
+    def alloc(self, nbytes):
+        nbytes = _ceil(max(nbytes, 1), _ALIGN)
+        while True:
+            if self.ci >= len(self.chunks):
+                size = max(self.chunk_bytes, nbytes)
+                self.chunks.append(torch.empty(size, dtype=torch.uint8, device=self.device))
+                self.off = 0
+            buf = self.chunks[self.ci]
+            base = buf.data_ptr()
+            start = _ceil(base + self.off, _ALIGN) - base
+            if start + nbytes <= buf.numel():
+                self.off = start + nbytes
+                self.high_water = max(self.high_water, sum(c.numel() for c in self.chunks[:self.ci]) + self.off)
+                return base + start
+            self.ci += 1
+            self.off = 0
+
+
+class ConvSite:
+    """One nn.Conv2d of the model together with how its input channels are split into segments."""
+
+    def __init__(self, name, conv, seg_c, seg_rg, index):
+        self.name, self.conv, self.index = name, conv, index
+        self.ks = conv.kernel_size[0]
+        self.co, self.ci = conv.out_channels, conv.in_channels
+        assert sum(seg_c) == self.ci, (name, seg_c, self.ci)
+        self.seg_c, self.seg_rg = tuple(seg_c), tuple(seg_rg)
+        self.seg_off = [sum(seg_c[:i]) for i in range(len(seg_c))]
+        self.taps = self.ks * self.ks
+        self.kpad = sum(_ceil(c, 32) for c in seg_c)
+        self.fwd_numel = _ceil(self.co, 16) * self.taps * self.kpad
+        self.dg_numel = [(_ceil(c, 16) * self.taps * _ceil(self.co, 32)) if rg else 0 for c, rg in zip(seg_c, seg_rg)]
+        self.img_fwd = None   # device address
+        self.img_dg = [None] * len(seg_c)
+
+
+class Engine:
+    CHUNK = 1024  # elements per block of the multi-tensor kernels (MT_CHUNK in conv.hip)
+
+    def __init__(self, device, dtype="f32"):
+        self.lib = _lib.require_gpu()
+        self.device = torch.device(device)
+        assert self.device.type == "cuda"
+        self.dt = {"f32": F32, "bf16": BF16}[dtype]
+        self.dtype_name = dtype
+        self.es = 4 if self.dt == F32 else 2
+        self.tdtype = torch.float32 if self.dt == F32 else torch.bfloat16
+        self.arena = Arena(self.device)
+        self.tape, self.recording = [], False
+        self.grads = {}
+        self.sites, self.site_by_id = [], {}
+        self.stream = 0
+        self._img_buf = None
+        self._prep_tab = None
+        self._wg_events = []
+        self._partials = {}
+        self._red_tabs = {}
+        self.params = None          # list of nn.Parameter in model.parameters() order
+        self.flat_p = self.flat_g = None
+        self.p_off = {}
+        self.pgrad_init = set()
+        self.rng = None
+        self.launches = 0
+
+    # ------------------------------------------------------------------ memory
+    def begin(self):
+        """Start a new step/pass: recycle the arena, clear the tape and gradient bookkeeping."""
+        self.arena.reset()
+        self.tape.clear()
+        self.grads.clear()
+        self._wg_events = []
+        self.pgrad_init = set()
+        self._pnhwc, self._pgrad_tmp = {}, {}
+        self.passes = 0
+        self.stream = torch.cuda.current_stream(self.device).cuda_stream
+
+    def new(self, n, h, w, c, rg=True, es=None):
+        es = self.es if es is None else es
+        ptr = self.arena.alloc(n * h * w * c * es)
+        return NT(ptr, n, h, w, c, h * w * c, w * c, c, es, rg=rg)
+
+    def new_f32(self, count):
+        return self.arena.alloc(count * 4)
+
+    def wrap_nhwc(self, t, rg=False):
+        """torch tensor [N,H,W,C] contiguous in the engine dtype -> NT (keeps a reference)."""
+        assert t.is_contiguous() and t.dtype == self.tdtype and t.device == self.device
+        n, h, w, c = t.shape
+        return NT(t.data_ptr(), n, h, w, c, h * w * c, w * c, c, self.es, rg=rg, keep=t)
+
+    def from_nchw(self, t, rg=False, sub=0.0, mul=1.0):
+        """torch NCHW (f32 or u8) -> engine NHWC tensor.  Zero-copy when C == 1, f32 and no affine."""
+        assert t.device == self.device and t.dim() == 4
+        n, c, h, w = t.shape
+        if t.dtype == torch.float32 and self.dt == F32 and sub == 0.0 and mul == 1.0:
+            if c == 1 and t.is_contiguous():
+                return NT(t.data_ptr(), n, h, w, 1, h * w, w, 1, 4, rg=rg, keep=t)
+            if t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous():
+                return NT(t.data_ptr(), n, h, w, c, h * w * c, w * c, c, 4, rg=rg, keep=t)
+        assert t.dtype in (torch.float32, torch.uint8), t.dtype
+        t = t.contiguous()
+        out = self.new(n, h, w, c, rg=rg)
+        out.keep = t
+        self.lib.nchw_to_nhwc(1 if t.dtype == torch.uint8 else 0, self.dt, n, c, h, w, t.data_ptr(), out.cv(), sub, mul,
+                              self.stream)
+        self.launches += 1
+        return out
+
+    def to_nchw(self, x):
+        """engine NHWC tensor -> fresh torch f32 NCHW tensor."""
+        out = torch.empty((x.n, x.c, x.h, x.w), dtype=torch.float32, device=self.device)
+        self.lib.nhwc_to_nchw(self.dt, x.n, x.c, x.h, x.w, x.cv(), out.data_ptr(), self.stream)
+        self.launches += 1
+        return out
+
+    def to_torch_cl(self, x):
+        """engine tensor -> torch tensor of NCHW *shape* in channels-last memory (zero-copy view of a clone)."""
+        t = torch.empty((x.n, x.h, x.w, x.c), dtype=self.tdtype, device=self.device)
+        dst = self.wrap_nhwc(t)
+        self.lib.axpby(self.dt, x.n, x.h, x.w, x.cv(), dst.cv(), 1.0, 1.0, 1 << 30, 0, self.stream)
+        self.launches += 1
+        return t.permute(0, 3, 1, 2)
+
+    # ------------------------------------------------------------------ parameters and weight images
+    def bind(self, model, sites):
+        """Register the model's parameters (flattened into one f32 buffer) and its conv sites."""
+        self.params = list(model.parameters())
+        self._flatten()
+        self.sites = sites
+        self.site_by_id = {id(s.conv): s for s in sites}
+        total = 0
+        offs = []
+        for s in sites:
+            offs.append(total)
+            total += _ceil(s.fwd_numel * self.es, _ALIGN)
+            for d in s.dg_numel:
+                offs.append(total)
+                total += _ceil(d * self.es, _ALIGN)
+        self._img_buf = torch.zeros(max(total, 1), dtype=torch.uint8, device=self.device)
+        base = self._img_buf.data_ptr()
+        it = iter(offs)
+        for s in sites:
+            s.img_fwd = base + next(it)
+            for k in range(len(s.seg_c)):
+                o = next(it)
+                s.img_dg[k] = base + o if s.dg_numel[k] else None
+        self._build_prep_table()
+        self._weights_version = None
+
+    def _flatten(self):
+        ps = self.params
+        n = sum(p.numel() for p in ps)
+        if self.flat_p is not None and self.flat_p.numel() == n and all(
+                p.data_ptr() == self.flat_p.data_ptr() + 4 * self.p_off[id(p)] for p in ps):
+            return False
+        flat = torch.empty(n, dtype=torch.float32, device=self.device)
+        off = 0
+        self.p_off = {}
+        for p in ps:
+            assert p.dtype == torch.float32, "parameters stay f32 (master weights)"
+            k = p.numel()
+            flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + k].view(p.shape)
+            self.p_off[id(p)] = off
+            off += k
+        self.flat_p = flat
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self._red_tabs = {}
+        return True
+
+    def check_params(self):
+        """Parameters may have been moved (model.to(), load_state_dict keeps storage): re-bind if so."""
+        if self._flatten() or self._prep_src_sig != self._src_sig():
+            self._build_prep_table()
+            self._weights_version = None
+
+    def _src_sig(self):
+        return (self.flat_p.data_ptr(), self._img_buf.data_ptr())
+
+    def _build_prep_table(self):
+        descs, csite, cidx = [], [], []
+        for s in self.sites:
+            w = s.conv.weight
+            d = _lib.WprepDesc()
+            d.src, d.dst = w.data_ptr(), s.img_fwd
+            d.co, d.ci_total, d.ks, d.mode, d.nseg, d.seg_off = s.co, s.ci, s.ks, 0, len(s.seg_c), 0
+            for k, c in enumerate(s.seg_c):
+                d.seg_c[k] = c
+            d.dtype, d.rows_pad, d.k_pad, d.numel = self.dt, _ceil(s.co, 16), s.kpad, s.fwd_numel
+            descs.append(d)
+            for k, c in enumerate(s.seg_c):
+                if not s.dg_numel[k]:
+                    continue
+                d = _lib.WprepDesc()
+                d.src, d.dst = w.data_ptr(), s.img_dg[k]
+                d.co, d.ci_total, d.ks, d.mode, d.nseg, d.seg_off = s.co, s.ci, s.ks, 1, 1, s.seg_off[k]
+                d.seg_c[0] = c
+                d.dtype, d.rows_pad, d.k_pad, d.numel = self.dt, _ceil(c, 16), _ceil(s.co, 32), s.dg_numel[k]
+                descs.append(d)
+        for i, d in enumerate(descs):
+            nch = (d.numel + self.CHUNK - 1) // self.CHUNK
+            csite += [i] * nch
+            cidx += list(range(nch))
+        arr = (_lib.WprepDesc * len(descs))(*descs)
+        self._prep_tab = (self._to_dev(bytes(arr)), torch.tensor(csite, dtype=torch.int32, device=self.device),
+                          torch.tensor(cidx, dtype=torch.int32, device=self.device), len(csite))
+        self._prep_src_sig = self._src_sig()
+
+    def _to_dev(self, raw):
+        return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+
+    def prepare_weights(self, force=False):
+        """OIHW f32 parameters -> forward/dgrad weight images (one multi-tensor launch).  Skipped when no
+        parameter changed since the last call (inference)."""
+        ver = sum(p._version for p in self.params)
+        if not force and ver == self._weights_version:
+            return
+        d, cs, ci, n = self._prep_tab
+        self.lib.weight_prep(d.data_ptr(), cs.data_ptr(), ci.data_ptr(), n, self.stream)
+        self.launches += 1
+        self._weights_version = ver
+
+    def param_nhwc(self, p):
+        """Device pointer to the f32 [h][w][C] image of a [1,C,h,w] parameter (decoder.bias, vae.py:211-218)."""
+        _, c, h, w = p.shape
+        if h * w == 1 or c == 1:
+            return p.data_ptr()
+        ptr = self._pnhwc.get(id(p))
+        if ptr is None:
+            ptr = self.arena.alloc(c * h * w * 4)
+            v = NT(ptr, 1, h, w, c, h * w * c, w * c, c, 4, rg=False)
+            self.lib.nchw_to_nhwc(0, F32, 1, c, h, w, p.data_ptr(), v.cv(), 0.0, 1.0, self.stream)
+            self.launches += 1
+            self._pnhwc[id(p)] = ptr
+        return ptr
+
+    def param_grad_ptr(self, p):
+        return self.flat_g.data_ptr() + 4 * self.p_off[id(p)]
+
+    def param_grad_view(self, p):
+        o = self.p_off[id(p)]
+        return self.flat_g[o:o + p.numel()].view(p.shape)
+
+    # ------------------------------------------------------------------ forward ops
+    def conv(self, site, segs, act=ACT_NONE, res1=None, res2=None, out=None):
+        x0 = segs[0]
+        if out is None:
+            out = self.new(x0.n, x0.h, x0.w, site.co)
+        assert out.c == site.co and len(segs) == len(site.seg_c)
+        a = _lib.ConvArgs()
+        a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = self.dt, x0.n, x0.h, x0.w, site.ks, len(segs), act, 0
+        for k, s in enumerate(segs):
+            assert s.c == site.seg_c[k] and (s.n, s.h, s.w) == (x0.n, x0.h, x0.w), (site.name, k, s.shape, site.seg_c)
+            a.seg[k] = s.cv()
+        a.weight = site.img_fwd
+        b = site.conv.bias
+        a.bias = b.data_ptr() if b is not None else None
+        a.out = out.cv()
+        a.aux = NULL_VIEW
+        a.res1 = res1.cv() if res1 is not None else NULL_VIEW
+        a.res2 = res2.cv() if res2 is not None else NULL_VIEW
+        self.lib.conv2d(C.byref(a), self.stream)
+        self.launches += 1
+        if self.recording:
+            self.tape.append((self._bw_conv, (site, segs, act, out, res1, res2)))
+        return out
+
+    def pool(self, x, d):
+        out = self.new(x.n, x.h // d, x.w // d, x.c)
+        self.lib.avgpool_fwd(self.dt, x.n, out.h, out.w, d, x.cv(), out.cv(), self.stream)
+        self.launches += 1
+        if self.recording:
+            self.tape.append((self._bw_pool, (x, out, d)))
+        return out
+
+    def upsample(self, x, res, bias_param=None):
+        out = self.new(x.n, res, res, x.c)
+        self.lib.upsample_fwd(self.dt, x.n, x.h, x.w, res, res, x.cv(), self.param_nhwc(bias_param) if bias_param is not None else None,
+                              out.cv(), self.stream)
+        self.launches += 1
+        if self.recording:
+            self.tape.append((self._bw_upsample, (x, out, bias_param)))
+        return out
+
+    def bcast(self, param, n):
+        """param [1,C,h,w] repeated over the batch (vae.py:233)."""
+        _, c, h, w = param.shape
+        out = self.new(n, h, w, c)
+        self.lib.batch_broadcast(self.dt, n, h, w, self.param_nhwc(param), out.cv(), self.stream)
+        self.launches += 1
+        if self.recording:
+            self.tape.append((self._bw_bcast, (param, out)))
+        return out
+
+    def pad_br(self, x):
+        """F.pad(x, [0,1,0,1]) (vae.py:131-133)."""
+        out = self.new(x.n, x.h + 1, x.w + 1, x.c)
+        self.fill(out, 0.0)
+        inner = NT(out.ptr, x.n, x.h, x.w, x.c, out.sn, out.sh, out.sw, out.es, rg=False)
+        self.lib.axpby(self.dt, x.n, x.h, x.w, x.cv(), inner.cv(), 1.0, 1.0, 1 << 30, 0, self.stream)
+        self.launches += 1
+        if self.recording:
+            self.tape.append((self._bw_pad, (x, out)))
+        return out
+
+    def fill(self, x, value):
+        self.lib.axpby(self.dt, x.n, x.h, x.w, NULL_VIEW, x.cv(), float(value), 1.0, 1 << 30, 0, self.stream)
+        self.launches += 1
+
+    def scale_channels(self, x, c_from, factor):
+        """out = x with channels >= c_from multiplied by factor (pa_sto, vae.py:244-247)."""
+        out = self.new(x.n, x.h, x.w, x.c, rg=False)
+        self.lib.axpby(self.dt, x.n, x.h, x.w, x.cv(), out.cv(), 1.0, float(factor), c_from, 0, self.stream)
+        self.launches += 1
+        return out
+
+    def reparam_kl(self, q_loc, q_ls, p_loc, p_ls, eps, stream_id, logt, kl_ptr, kl_stride):
+        z = self.new(q_loc.n, q_loc.h, q_loc.w, q_loc.c)
+        self.lib.reparam_kl_fwd(self.dt, z.n, z.h, z.w, z.c, q_loc.cv(), q_ls.cv(), p_loc.cv(), p_ls.cv(),
+                                eps.cv() if eps is not None else NULL_VIEW, self.rng_ptr(), stream_id, logt, z.cv(), NULL_VIEW,
+                                kl_ptr, kl_stride, self.stream)
+        self.launches += 1
+        if self.recording:
+            self.tape.append((self._bw_reparam, (q_loc, q_ls, p_loc, p_ls, z, logt)))
+        return z
+
+    def sample_gaussian(self, loc, ls, eps, stream_id, logt):
+        z = self.new(loc.n, loc.h, loc.w, loc.c)
+        self.lib.sample_gaussian(self.dt, z.n, z.h, z.w, z.c, loc.cv(), ls.cv(), eps.cv() if eps is not None else NULL_VIEW,
+                                 self.rng_ptr(), stream_id, logt, z.cv(), self.stream)
+        self.launches += 1
+        return z
+
+    def rng_ptr(self):
+        if self.rng is None:
+            self.rng = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=self.device)
+        return self.rng.data_ptr()
+
+    def rng_advance(self, inc=1):
+        self.lib.rng_advance(self.rng_ptr(), inc, self.stream)
+        self.launches += 1
+
+    # ------------------------------------------------------------------ gradient bookkeeping
+    def _gentry(self, base):
+        e = self.grads.get(id(base))
+        if e is None:
+            g = self.new(base.n, base.h, base.w, base.c, rg=False)
+            e = [g, [], base]
+            self.grads[id(base)] = e
+        return e
+
+    @staticmethod
+    def _missing(ivs, a, b):
+        out, cur = [], a
+        for (s, e) in sorted(ivs):
+            if e <= cur:
+                continue
+            if s >= b:
+                break
+            if s > cur:
+                out.append((cur, min(s, b)))
+            cur = max(cur, e)
+            if cur >= b:
+                break
+        if cur < b:
+            out.append((cur, b))
+        return out
+
+    def grad_write(self, t):
+        """Gradient view for `t` plus whether it already holds a value (=> the writer must accumulate)."""
+        assert t.rg
+        g, ivs, base = self._gentry(t.base)
+        a, b = t.coff, t.coff + t.c
+        miss = self._missing(ivs, a, b)
+        gv = g.chan(a, b)
+        if not miss:
+            return gv, True
+        if miss == [(a, b)]:
+            ivs.append((a, b))
+            return gv, False
+        for (s, e) in miss:  # partially initialised: zero the gaps, then accumulate
+            self.fill(g.chan(s, e), 0.0)
+            ivs.append((s, e))
+        return gv, True
+
+    def grad_read(self, t):
+        """Gradient of `t` for reading (zero-filling channels nobody wrote); None when nothing flowed into it."""
+        e = self.grads.get(id(t.base))
+        if e is None:
+            return None
+        g, ivs, _ = e
+        a, b = t.coff, t.coff + t.c
+        miss = self._missing(ivs, a, b)
+        if miss == [(a, b)]:
+            return None
+        for (s, e2) in miss:
+            self.fill(g.chan(s, e2), 0.0)
+            ivs.append((s, e2))
+        return g.chan(a, b)
+
+    def grad_add(self, t, g):
+        gv, acc = self.grad_write(t)
+        self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
+        self.launches += 1
+
+    def seed_grad(self, t):
+        """Gradient buffer of an output tensor, to be written by a loss kernel."""
+        gv, acc = self.grad_write(t)
+        assert not acc
+        return gv
+
+    # ------------------------------------------------------------------ backward
+    def backward(self):
+        for fn, args in reversed(self.tape):
+            fn(*args)
+        self._reduce_wgrads()
+        for p, ptr in self._pgrad_tmp.values():  # NHWC-accumulated gradients of [1,C,h,w] parameters -> NCHW
+            _, c, h, w = p.shape
+            v = NT(ptr, 1, h, w, c, h * w * c, w * c, c, 4, rg=False)
+            self.lib.nhwc_to_nchw(F32, 1, c, h, w, v.cv(), self.param_grad_ptr(p), self.stream)
+            self.launches += 1
+        self.tape.clear()
+
+    def _bw_conv(self, site, segs, act, out, res1, res2):
+        g = self.grad_read(out)
+        if g is None:
+            return
+        for r in (res1, res2):
+            if r is not None and r.rg:
+                self.grad_add(r, g)
+        x0 = segs[0]
+        if site.conv.weight.requires_grad:
+            self._wgrad(site, segs, act, g)
+        for k, s in enumerate(segs):
+            if not (s.rg and site.seg_rg[k]):
+                continue
+            gv, acc = self.grad_write(s)
+            a = _lib.ConvArgs()
+            a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = self.dt, x0.n, x0.h, x0.w, site.ks, 1, ACT_NONE, act
+            a.seg[0] = g.cv()
+            a.weight = site.img_dg[k]
+            a.bias = None
+            a.out = gv.cv()
+            a.aux = s.cv() if act != ACT_NONE else NULL_VIEW
+            a.res1 = gv.cv() if acc else NULL_VIEW
+            a.res2 = NULL_VIEW
+            self.lib.conv2d(C.byref(a), self.stream)
+            self.launches += 1
+
+    def _wgrad(self, site, segs, act, g):
+        x0 = segs[0]
+        nsplit = self.lib.conv2d_wgrad_splits(x0.n, x0.h, x0.w, site.co, site.ci, site.ks)
+        use = sum(1 for e in self._wg_events if e[0] is site)
+        key = (site.index, use, x0.n, x0.h, x0.w)
+        buf = self._partials.get(key)
+        nw = site.co * site.taps * site.ci
+        if buf is None:
+            buf = torch.empty(nsplit * (nw + site.co), dtype=torch.float32, device=self.device)
+            self._partials[key] = buf
+            self._red_tabs = {}
+        a = _lib.WgradArgs()
+        a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.nsplit = self.dt, x0.n, x0.h, x0.w, site.ks, len(segs), act, nsplit
+        for k, s in enumerate(segs):
+            a.seg[k] = s.cv()
+        a.gout = g.cv()
+        a.partial_w = buf.data_ptr()
+        a.partial_b = buf.data_ptr() + 4 * nsplit * nw if site.conv.bias is not None else None
+        self.lib.conv2d_wgrad(C.byref(a), self.stream)
+        self.launches += 1
+        self._wg_events.append((site, key, nsplit))
+
+    def _reduce_wgrads(self):
+        if not self._wg_events:
+            return
+        sig = tuple(k for _, k, _ in self._wg_events)
+        tab = self._red_tabs.get(sig)
+        if tab is None:
+            descs, csite, cidx, seen = [], [], [], set()
+            for site, key, nsplit in self._wg_events:
+                buf = self._partials[key]
+                nw = site.co * site.taps * site.ci
+                d = _lib.WredDesc()
+                d.partial_w = buf.data_ptr()
+                d.partial_b = buf.data_ptr() + 4 * nsplit * nw if site.conv.bias is not None else None
+                d.grad_w = self.param_grad_ptr(site.conv.weight)
+                d.grad_b = self.param_grad_ptr(site.conv.bias) if site.conv.bias is not None else None
+                d.co, d.ci_total, d.ks, d.nsplit = site.co, site.ci, site.ks, nsplit
+                d.accumulate = 1 if site.index in seen else 0
+                seen.add(site.index)
+                d.numel = nw + (site.co if site.conv.bias is not None else 0)
+                descs.append(d)
+            for i, d in enumerate(descs):
+                nch = (d.numel + self.CHUNK - 1) // self.CHUNK
+                csite += [i] * nch
+                cidx += list(range(nch))
+            arr = (_lib.WredDesc * len(descs))(*descs)
+            tab = (self._to_dev(bytes(arr)), torch.tensor(csite, dtype=torch.int32, device=self.device),
+                   torch.tensor(cidx, dtype=torch.int32, device=self.device), len(csite))
+            self._red_tabs[sig] = tab
+        d, cs, ci, n = tab
+        self.lib.wgrad_reduce(d.data_ptr(), cs.data_ptr(), ci.data_ptr(), n, self.stream)
+        self.launches += 1
+        for site, _, _ in self._wg_events:
+            self.pgrad_init.add(id(site.conv.weight))
+            if site.conv.bias is not None:
+                self.pgrad_init.add(id(site.conv.bias))
+
+    def _bw_pool(self, x, out, d):
+        g = self.grad_read(out)
+        if g is None:
+            return
+        gv, acc = self.grad_write(x)
+        self.lib.avgpool_bwd(self.dt, x.n, out.h, out.w, d, g.cv(), gv.cv(), 1 if acc else 0, self.stream)
+        self.launches += 1
+
+    def _param_reduce(self, param, g):
+        acc = id(param) in self.pgrad_init
+        _, c, h, w = param.shape
+        if h * w == 1 or c == 1:
+            dst = self.param_grad_ptr(param)
+        else:
+            ent = self._pgrad_tmp.get(id(param))
+            if ent is None:
+                ent = (param, self.arena.alloc(c * h * w * 4))
+                self._pgrad_tmp[id(param)] = ent
+            dst = ent[1]
+        self.lib.batch_reduce(self.dt, g.n, g.h, g.w, g.cv(), dst, 1 if acc else 0, self.stream)
+        self.launches += 1
+        self.pgrad_init.add(id(param))
+
+    def _bw_upsample(self, x, out, bias_param):
+        g = self.grad_read(out)
+        if g is None:
+            return
+        if bias_param is not None and bias_param.requires_grad:
+            self._param_reduce(bias_param, g)
+        if x.rg:
+            gv, acc = self.grad_write(x)
+            self.lib.upsample_bwd(self.dt, x.n, x.h, x.w, out.h, out.w, g.cv(), gv.cv(), 1 if acc else 0, self.stream)
+            self.launches += 1
+
+    def _bw_bcast(self, param, out):
+        g = self.grad_read(out)
+        if g is None or not param.requires_grad:
+            return
+        self._param_reduce(param, g)
+
+    def _bw_pad(self, x, out):
+        g = self.grad_read(out)
+        if g is None:
+            return
+        inner = NT(g.ptr, x.n, x.h, x.w, x.c, g.sn, g.sh, g.sw, g.es, rg=False)
+        self.grad_add(x, inner)
+
+    def _bw_reparam(self, q_loc, q_ls, p_loc, p_ls, z, logt):
+        gz = self.grad_read(z)
+        gql, a1 = self.grad_write(q_loc)
+        gqs, a2 = self.grad_write(q_ls)
+        gpl, a3 = self.grad_write(p_loc)
+        gps, a4 = self.grad_write(p_ls)
+        assert a1 == a2 and a3 == a4
+        self.lib.reparam_kl_bwd(self.dt, z.n, z.h, z.w, z.c, q_loc.cv(), q_ls.cv(), p_loc.cv(), p_ls.cv(), z.cv(), logt,
+                                gz.cv() if gz is not None else NULL_VIEW, self.kl_coef_ptr, 0, gql.cv(), gqs.cv(), gpl.cv(),
+                                gps.cv(), 1 if a1 else 0, 1 if a3 else 0, self.stream)
+        self.launches += 1

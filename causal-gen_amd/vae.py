@@ -1,0 +1,605 @@
+"""HVAE image mechanism on MI355X -- drop-in for the reference's ``src/vae.py`` surface.
+
+Same constructor (``HVAE(args)``), same four methods (``forward / sample / abduct / forward_latents``, vae.py:439-522),
+same module tree and therefore the same ``state_dict`` keys and the same default-init RNG consumption
+(``encoder.blocks.0.conv.1.weight`` ... ``likelihood.x_loc.bias``), so checkpoints, ``model.apply(init_bias)``,
+``copy.deepcopy`` (EMA) and ``setup_tensorboard``'s introspection keep working.  The nn.Conv2d objects are parameter
+*holders*: no module in this file has a PyTorch forward that computes anything.  All arithmetic is issued by
+``HVAE`` through ``engine.Engine`` as fused HIP launches (libcgen_hip.so); there is no ATen / CPU fallback.
+
+Layout: activations live NHWC in an arena; API tensors are accepted as NCHW (either memory format) and returned
+as NCHW-shaped tensors.  ``HVAE.compute_dtype`` selects "f32" (exact f32-MFMA path, parity) or "bf16".
+"""
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, NULL_VIEW
+from .engine import ConvSite, Engine
+
+EPS = -9  # minimum logscale (vae.py:11)
+
+
+def gaussian_kl(q_loc, q_logscale, p_loc, p_logscale):
+    """Import-compatible name (vae.py:14-25).  The model itself uses the fused cgen_reparam_kl kernels; this
+    helper runs that kernel's KL branch on NCHW tensors for callers that want the map."""
+    raise NotImplementedError("use HVAE.forward; the per-element KL map is not materialised on the GPU path")
+
+
+def sample_gaussian(loc, logscale):
+    raise NotImplementedError("use HVAE.sample / forward_latents; sampling is fused into cgen_reparam_kl_fwd")
+
+
+class Block(nn.Module):
+    """Parameter holder mirroring vae.py:33-84 (two variants, optional width_proj)."""
+
+    def __init__(self, in_width, bottleneck, out_width, kernel_size=3, residual=True, down_rate=None, version=None):
+        super().__init__()
+        self.d = down_rate
+        self.residual = residual
+        self.light = version == "light"
+        padding = 0 if kernel_size == 1 else 1
+        if self.light:
+            activation = nn.ReLU()
+            self.conv = nn.Sequential(activation, nn.Conv2d(in_width, bottleneck, kernel_size, 1, padding),
+                                      activation, nn.Conv2d(bottleneck, out_width, kernel_size, 1, padding))
+        else:
+            activation = nn.GELU()
+            self.conv = nn.Sequential(activation, nn.Conv2d(in_width, bottleneck, 1, 1),
+                                      activation, nn.Conv2d(bottleneck, bottleneck, kernel_size, 1, padding),
+                                      activation, nn.Conv2d(bottleneck, bottleneck, kernel_size, 1, padding),
+                                      activation, nn.Conv2d(bottleneck, out_width, 1, 1))
+        if self.residual and (self.d or in_width > out_width):
+            self.width_proj = nn.Conv2d(in_width, out_width, 1, 1)
+
+    def convs(self):
+        return [m for m in self.conv if isinstance(m, nn.Conv2d)]
+
+    def forward(self, x):
+        raise RuntimeError("Block is a parameter holder; run it through HVAE (HIP engine)")
+
+
+class Encoder(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        stages = []
+        for i, stage in enumerate(args.enc_arch.split(",")):
+            start = stage.index("b") + 1
+            end = stage.index("d") if "d" in stage else None
+            n_blocks = int(stage[start:end])
+            if i == 0:
+                self.stem = nn.Conv2d(args.input_channels, args.widths[0], kernel_size=7, stride=1, padding=3)
+            stages += [(args.widths[i], None) for _ in range(n_blocks)]
+            if "d" in stage:
+                stages += [(args.widths[i + 1], int(stage[stage.index("d") + 1]))]
+        blocks = []
+        for i, (width, d) in enumerate(stages):
+            prev_width = stages[max(0, i - 1)][0]
+            blocks.append(Block(prev_width, int(prev_width / args.bottleneck), width, down_rate=d, version=args.vr))
+        for b in blocks:
+            b.conv[-1].weight.data *= np.sqrt(1 / len(blocks))
+        self.blocks = nn.ModuleList(blocks)
+
+    def forward(self, x):
+        raise RuntimeError("Encoder is a parameter holder; run it through HVAE (HIP engine)")
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, args, in_width, out_width, resolution):
+        super().__init__()
+        bottleneck = int(in_width / args.bottleneck)
+        self.res = resolution
+        self.stochastic = self.res <= args.z_max_res
+        self.z_dim = args.z_dim
+        self.cond_prior = args.cond_prior
+        self.q_correction = args.q_correction
+        self.in_width, self.out_width = in_width, out_width
+        k = 3 if self.res > 2 else 1
+        self.prior = Block(in_width + args.context_dim if self.cond_prior else in_width, bottleneck,
+                           2 * self.z_dim + in_width, kernel_size=k, residual=False, version=args.vr)
+        if self.stochastic:
+            self.posterior = Block(2 * in_width + args.context_dim, bottleneck, 2 * self.z_dim, kernel_size=k,
+                                   residual=False, version=args.vr)
+        self.z_proj = nn.Conv2d(self.z_dim + args.context_dim, in_width, 1)
+        if not self.q_correction:
+            self.z_feat_proj = nn.Conv2d(self.z_dim + in_width, out_width, 1)
+        self.conv = Block(in_width, bottleneck, out_width, kernel_size=k, version=args.vr)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("DecoderBlock is a parameter holder; run it through HVAE (HIP engine)")
+
+
+class Decoder(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        stages = []
+        for i, stage in enumerate(args.dec_arch.split(",")):
+            res = int(stage.split("b")[0])
+            n_blocks = int(stage[stage.index("b") + 1:])
+            stages += [(res, args.widths[::-1][i]) for _ in range(n_blocks)]
+        blocks = []
+        for i, (res, width) in enumerate(stages):
+            next_width = stages[min(len(stages) - 1, i + 1)][1]
+            blocks.append(DecoderBlock(args, width, next_width, res))
+        scale = np.sqrt(1 / len(blocks))
+        for b in blocks:  # vae.py:303-308
+            b.z_proj.weight.data *= scale
+            b.conv.conv[-1].weight.data *= scale
+            b.prior.conv[-1].weight.data *= 0.0
+        self.blocks = nn.ModuleList(blocks)
+        self.all_res = list(np.unique([stages[i][0] for i in range(len(stages))]))
+        bias = []
+        for i, res in enumerate(self.all_res):
+            if res <= args.bias_max_res:
+                bias.append(nn.Parameter(torch.zeros(1, args.widths[::-1][i], res, res)))
+        self.bias = nn.ParameterList(bias)
+        self.cond_prior = args.cond_prior
+        self.is_drop_cond = True if "morphomnist" in args.hps else False
+
+    @torch.no_grad()
+    def drop_cond(self):
+        """One categorical per step for the whole batch (vae.py:310-319).  Drawn on the host CPU generator so that
+        data-parallel ranks seeded alike share the draw."""
+        opt = int(torch.distributions.Categorical(1 / 3 * torch.ones(3)).sample())
+        return {0: (0, 1), 1: (1, 0), 2: (1, 1)}[opt]
+
+    def forward(self, *a, **k):
+        raise RuntimeError("Decoder is a parameter holder; run it through HVAE (HIP engine)")
+
+
+class DGaussNet(nn.Module):
+    """Discretised-Gaussian likelihood head (vae.py:322-422): parameter holder + kernel front-end."""
+    kind = "dgauss"
+
+    def __init__(self, args):
+        super().__init__()
+        self.x_loc = nn.Conv2d(args.widths[0], args.input_channels, kernel_size=1, stride=1)
+        self.x_logscale = nn.Conv2d(args.widths[0], args.input_channels, kernel_size=1, stride=1)
+        self.channels = args.input_channels
+        if args.input_channels == 3:
+            self.channel_coeffs = nn.Conv2d(args.widths[0], 3, kernel_size=1, stride=1)
+        if args.std_init > 0:
+            nn.init.zeros_(self.x_logscale.weight)
+            nn.init.constant_(self.x_logscale.bias, np.log(args.std_init))
+            covariance = args.x_like.split("_")[0]
+            if covariance == "fixed":
+                self.x_logscale.weight.requires_grad = False
+                self.x_logscale.bias.requires_grad = False
+            elif covariance == "shared":
+                self.x_logscale.weight.requires_grad = False
+                self.x_logscale.bias.requires_grad = True
+
+    def heads(self):
+        hs = [self.x_loc, self.x_logscale]
+        if self.channels == 3:
+            hs.append(self.channel_coeffs)
+        return hs
+
+    def out_channels(self):
+        return 2 * self.channels + (3 if self.channels == 3 else 0)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("DGaussNet is a parameter holder; run it through HVAE (HIP engine)")
+
+
+class _HVAEFunction(torch.autograd.Function):
+    """Bridges ``out['elbo'].backward()`` to the engine's tape.  Parameter gradients are written by the HIP
+    kernels straight into the engine's flat gradient buffer and attached as ``p.grad`` views."""
+
+    @staticmethod
+    def forward(ctx, trigger, model, x, parents, beta):
+        ctx.model = model
+        out3 = model._run_forward(x, parents, beta, record=True)
+        ctx.beta = float(beta)
+        return out3[0], out3[1], out3[2]
+
+    @staticmethod
+    def backward(ctx, g_elbo, g_nll, g_kl):
+        ctx.model._run_backward(g_elbo, g_nll, g_kl, ctx.beta)
+        return None, None, None, None, None
+
+
+class HVAE(nn.Module):
+    compute_dtype = "f32"
+
+    def __init__(self, args):
+        super().__init__()
+        args.vr = "light" if "ukbb" in args.hps else None  # vae.py:428
+        self.encoder = Encoder(args)
+        self.decoder = Decoder(args)
+        if args.x_like.split("_")[1] == "dgauss":
+            self.likelihood = DGaussNet(args)
+        else:
+            raise NotImplementedError(f"{args.x_like} not implemented.")
+        self.cond_prior = args.cond_prior
+        self.free_bits = args.kl_free_bits
+        self.light = args.vr == "light"
+        self.z_dim, self.context_dim = args.z_dim, args.context_dim
+        self.input_channels = args.input_channels
+        self.q_correction = args.q_correction
+        self.__dict__["_eng"] = None
+        self.__dict__["_trigger"] = None
+        self.__dict__["noise"] = None  # optional list of NCHW eps tensors consumed in draw order (parity tests)
+
+    # engine state is per-instance and never copied (copy.deepcopy(model) for the EMA builds its own lazily)
+    def __deepcopy__(self, memo):
+        eng, trig, noise = self.__dict__.pop("_eng"), self.__dict__.pop("_trigger"), self.__dict__.pop("noise")
+        try:
+            cls = self.__class__
+            new = cls.__new__(cls)
+            memo[id(self)] = new
+            import copy as _copy
+            for k, v in self.__dict__.items():
+                new.__dict__[k] = _copy.deepcopy(v, memo)
+        finally:
+            self.__dict__["_eng"], self.__dict__["_trigger"], self.__dict__["noise"] = eng, trig, noise
+        new.__dict__["_eng"], new.__dict__["_trigger"], new.__dict__["noise"] = None, None, None
+        return new
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _act(self):
+        return ACT_RELU if self.light else ACT_GELU
+
+    def engine(self) -> Engine:
+        dev = next(self.parameters()).device
+        eng = self.__dict__["_eng"]
+        if eng is None or eng.device != dev or eng.dtype_name != self.compute_dtype:
+            if dev.type != "cuda":
+                raise _lib.CgenError("HVAE runs on an MI355X only: move the model to the GPU (model.to('cuda')); "
+                                     "there is no CPU fallback")
+            eng = Engine(dev, self.compute_dtype)
+            eng.bind(self, self._make_sites())
+            self.__dict__["_eng"] = eng
+        else:
+            eng.check_params()
+        return eng
+
+    def _make_sites(self):
+        """Enumerate every conv with its input segmentation (the virtual torch.cat's of vae.py:176,188,294,300)."""
+        sites = []
+
+        def add(name, conv, seg_c, seg_rg):
+            sites.append(ConvSite(name, conv, seg_c, seg_rg, len(sites)))
+
+        def add_block(name, blk, seg_c, seg_rg):
+            cs = blk.convs()
+            add(f"{name}.conv.1", cs[0], seg_c, seg_rg)
+            for j, c in enumerate(cs[1:]):
+                add(f"{name}.conv.{3 + 2 * j}", c, [c.in_channels], [True])
+            if hasattr(blk, "width_proj"):
+                add(f"{name}.width_proj", blk.width_proj, seg_c, seg_rg)
+
+        C = self.input_channels
+        add("encoder.stem", self.encoder.stem, [C], [False])
+        for i, b in enumerate(self.encoder.blocks):
+            add_block(f"encoder.blocks.{i}", b, [b.convs()[0].in_channels], [True])
+        zd, ctx = self.z_dim, self.context_dim
+        for i, b in enumerate(self.decoder.blocks):
+            w = b.in_width
+            n = f"decoder.blocks.{i}"
+            if b.cond_prior:
+                add_block(n + ".prior", b.prior, [w, ctx], [True, False])
+            else:
+                add_block(n + ".prior", b.prior, [w], [True])
+            if b.stochastic:
+                add_block(n + ".posterior", b.posterior, [w, ctx, w], [True, False, True])
+            add(n + ".z_proj", b.z_proj, [zd, ctx], [True, False])
+            if not b.q_correction:
+                add(n + ".z_feat_proj", b.z_feat_proj, [zd, w], [True, True])
+            add_block(n + ".conv", b.conv, [w], [True])
+        lk = self.likelihood
+        if lk.kind == "dgauss":
+            for nme, cv in zip(("x_loc", "x_logscale", "channel_coeffs"), lk.heads()):
+                add("likelihood." + nme, cv, [cv.in_channels], [True])
+        else:
+            add("likelihood.conv", lk.conv, [lk.conv.in_channels], [True])
+        return sites
+
+    def _site(self, eng, conv):
+        return eng.site_by_id[id(conv)]
+
+    # ------------------------------------------------------------------ graph pieces
+    def _run_block(self, eng, blk, segs):
+        """Block.forward (vae.py:73-84) as fused launches."""
+        act = ACT_RELU if blk.light else ACT_GELU
+        cs = blk.convs()
+        res = None
+        if blk.residual:
+            x = segs[0]
+            if x.c != cs[-1].out_channels:
+                res = eng.conv(self._site(eng, blk.width_proj), segs, ACT_NONE)
+            else:
+                res = x
+        h = eng.conv(self._site(eng, cs[0]), segs, act, res1=res if len(cs) == 1 else None)
+        for j, c in enumerate(cs[1:]):
+            last = j == len(cs) - 2
+            h = eng.conv(self._site(eng, c), [h], act, res1=res if last else None)
+        if blk.d:
+            if isinstance(blk.d, float):
+                raise NotImplementedError("adaptive_avg_pool2d down-rates are not used by any preset")
+            h = eng.pool(h, blk.d)
+        return h
+
+    def _encode(self, eng, x):
+        h = eng.conv(self._site(eng, self.encoder.stem), [x], ACT_NONE)
+        acts = {}
+        for blk in self.encoder.blocks:
+            h = self._run_block(eng, blk, [h])
+            if h.h % 2 and h.h > 1:
+                h = eng.pad_br(h)
+            acts[h.w] = h
+        return acts
+
+    def _next_eps(self, eng, shape_nhwc):
+        src = self.__dict__["noise"]
+        if src is None:
+            return None
+        e = src.pop(0)
+        n, h, w, c = shape_nhwc
+        assert tuple(e.shape) == (n, c, h, w), (tuple(e.shape), shape_nhwc)
+        return eng.from_nchw(e.to(eng.device, torch.float32))
+
+    def _decode(self, eng, parents, acts=None, t=None, latents=None, collect=None, drop=(1, 1), kl=None):
+        """Decoder.forward (vae.py:222-301).  `collect`: None | "z" | "q" (q stats for cond-prior abduction) |
+        "p" (prior stats).  `kl` = (ptr, stride, offsets) when the KL is wanted."""
+        dec = self.decoder
+        B = parents.n
+        bias = {int(p.shape[2]): p for p in dec.bias}
+        logt = 0.0 if t is None else float(torch.tensor(t).log())
+        h = z = eng.bcast(bias[1], B)
+        pa_sto_full = parents
+        if dec.is_drop_cond and drop[0] != 1:
+            pa_sto_full = eng.scale_channels(parents, 2, drop[0])
+        out = []
+        latents = [] if latents is None else latents
+        # Philox stream ids: unique per (decoder pass within this engine step, stochastic layer)
+        eng.passes = getattr(eng, "passes", 0) + 1
+        sid = 1000 * eng.passes
+        for i, blk in enumerate(dec.blocks):
+            res = blk.res
+            pa = parents.crop(res)
+            pa_sto = pa_sto_full.crop(res)
+            if h.h < res:
+                bp = bias.get(res)
+                same = z is h
+                h = eng.upsample(h, res, bp)
+                if not blk.q_correction:
+                    z = h if same else eng.upsample(z, res, bp)
+            p_in = h if blk.q_correction else z
+            pout = self._run_block(eng, blk.prior, [p_in, pa_sto] if blk.cond_prior else [p_in])
+            zd = blk.z_dim
+            p_loc, p_ls, p_feat = pout.chan(0, zd), pout.chan(zd, 2 * zd), pout.chan(2 * zd, pout.c)
+            if blk.stochastic:
+                sid += 1
+                if acts is not None:
+                    qout = self._run_block(eng, blk.posterior, [h, pa, acts[res]])
+                    q_loc, q_ls = qout.chan(0, zd), qout.chan(zd, 2 * zd)
+                    eps = self._next_eps(eng, q_loc.shape)
+                    kptr = kl[0] + 4 * kl[2][i] if kl is not None else self._scratch_kl(eng, B, res, zd)
+                    kstride = kl[1] if kl is not None else _lib.load().reparam_kl_chunks(res, res, zd)
+                    z = eng.reparam_kl(q_loc, q_ls, p_loc, p_ls, eps, sid, logt, kptr, kstride)
+                    if collect == "z":
+                        out.append(z)
+                    elif collect == "q":
+                        out.append((z, q_loc, q_ls))
+                else:
+                    zi = latents[i] if i < len(latents) else None
+                    if zi is not None:
+                        z = zi
+                    else:
+                        eps = self._next_eps(eng, p_loc.shape)
+                        z = eng.sample_gaussian(p_loc, p_ls, eps, sid, logt)
+                        if i >= len(latents) and collect == "p":
+                            out.append((p_loc, p_ls))
+            else:
+                z = p_loc
+            h = eng.conv(self._site(eng, blk.z_proj), [z, pa], ACT_NONE, res1=h, res2=p_feat)
+            h = self._run_block(eng, blk.conv, [h])
+            if not blk.q_correction and i + 1 < len(dec.blocks):
+                z = eng.conv(self._site(eng, blk.z_feat_proj), [z, p_feat], ACT_NONE)
+        return h, out
+
+    def _scratch_kl(self, eng, B, res, zd):
+        return eng.new_f32(B * _lib.load().reparam_kl_chunks(res, res, zd))
+
+    def _kl_layout(self, eng):
+        lib = _lib.load()
+        offs, tot = {}, 0
+        for i, blk in enumerate(self.decoder.blocks):
+            if blk.stochastic:
+                offs[i] = tot
+                tot += lib.reparam_kl_chunks(blk.res, blk.res, blk.z_dim)
+        return offs, tot
+
+    def _likelihood_params(self, eng, h):
+        """The 1x1 heads write side by side into one buffer: [loc | logscale | coeffs] (or the 100 DMoL logits)."""
+        lk = self.likelihood
+        if lk.kind == "dgauss":
+            buf = eng.new(h.n, h.h, h.w, lk.out_channels())
+            o = 0
+            for cv in lk.heads():
+                eng.conv(self._site(eng, cv), [h], ACT_NONE, out=buf.chan(o, o + cv.out_channels))
+                o += cv.out_channels
+            return buf
+        return eng.conv(self._site(eng, lk.conv), [h], ACT_NONE)
+
+    def _prep_inputs(self, eng, x, parents):
+        assert x.dim() == 4 and parents.dim() == 4 and parents.shape[1] == self.context_dim
+        xin = eng.from_nchw(x.to(eng.device), rg=False) if x is not None else None
+        pa = eng.from_nchw(parents.to(eng.device, torch.float32), rg=False)
+        return xin, pa
+
+    # ------------------------------------------------------------------ training forward / backward
+    def _run_forward(self, x, parents, beta, record):
+        if self.free_bits > 0:
+            raise NotImplementedError("kl_free_bits > 0 needs per-channel batch means; not on the HIP path yet")
+        eng = self.engine()
+        eng.begin()
+        eng.recording = record
+        eng.prepare_weights()
+        if self.__dict__["noise"] is None:
+            eng.rng_advance(1)
+        xin, pa = self._prep_inputs(eng, x, parents)
+        drop = (1, 1)
+        if self.training and self.cond_prior:
+            drop = self.decoder.drop_cond()
+        B, R, Cx = xin.n, xin.h, xin.c
+        lib = eng.lib
+        offs, kl_total = self._kl_layout(eng)
+        kl_ptr = eng.new_f32(B * max(kl_total, 1))
+        acts = self._encode(eng, xin)
+        h, _ = self._decode(eng, pa, acts=acts, drop=drop, kl=(kl_ptr, kl_total, offs))
+        params = self._likelihood_params(eng, h)
+        nchunk = lib.like_chunks(R, R)
+        nll_ptr = eng.new_f32(B * nchunk)
+        lk = self.likelihood
+        if lk.kind == "dgauss":
+            lib.dgauss_nll_fwd(eng.dt, B, R, R, Cx, params.cv(), xin.cv(), nll_ptr, eng.stream)
+        else:
+            lib.dmol_nll_fwd(eng.dt, B, R, R, params.cv(), xin.cv(), nll_ptr, eng.stream)
+        out3 = torch.empty(3, dtype=torch.float32, device=eng.device)
+        dims = float(Cx * R * R)
+        lib.elbo_finalize(B, nll_ptr, nchunk, dims, kl_ptr, kl_total, dims, float(beta), out3.data_ptr(), eng.stream)
+        eng.launches += 2
+        eng.recording = False
+        self.__dict__["_saved"] = (params, xin, B, R, Cx, dims)
+        return out3
+
+    def _run_backward(self, g_elbo, g_nll, g_kl, beta):
+        eng = self.__dict__["_eng"]
+        params, xin, B, R, Cx, dims = self.__dict__["_saved"]
+        lib = eng.lib
+        z = torch.zeros((), device=eng.device)
+        ge = g_elbo if g_elbo is not None else z
+        gn = g_nll if g_nll is not None else z
+        gk = g_kl if g_kl is not None else z
+        # d/d(sum_b nll_b) and d/d(sum_b kl_b): scalar glue on 0-dim tensors
+        coef = torch.stack([(ge + gn) / (B * dims), (ge * beta + gk) / (B * dims)]).float().contiguous()
+        self.__dict__["_coef"] = coef
+        eng.stream = torch.cuda.current_stream(eng.device).cuda_stream
+        eng.kl_coef_ptr = coef.data_ptr() + 4
+        gparams = eng.seed_grad(params)
+        if self.likelihood.kind == "dgauss":
+            lib.dgauss_nll_bwd(eng.dt, B, R, R, Cx, params.cv(), xin.cv(), coef.data_ptr(), 0, gparams.cv(), eng.stream)
+        else:
+            lib.dmol_nll_bwd(eng.dt, B, R, R, params.cv(), xin.cv(), coef.data_ptr(), 0, gparams.cv(), eng.stream)
+        eng.launches += 1
+        eng.backward()
+        for p in self.parameters():
+            if id(p) in eng.pgrad_init:
+                g = eng.param_grad_view(p)
+                if p.grad is None:
+                    p.grad = g
+                elif p.grad.data_ptr() != g.data_ptr():
+                    raise NotImplementedError("gradient accumulation over several backward passes (accu_steps > 1) "
+                                              "is not supported by the HIP path yet")
+
+    def forward(self, x: Tensor, parents: Tensor, beta: int = 1) -> Dict[str, Tensor]:
+        """vae.py:439-458 -> {elbo, nll, kl} as 0-dim tensors in nats/dim; ``elbo`` is differentiable."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            trig = self.__dict__["_trigger"]
+            dev = next(self.parameters()).device
+            if trig is None or trig.device != dev:
+                trig = torch.zeros(1, device=dev, requires_grad=True)
+                self.__dict__["_trigger"] = trig
+            elbo, nll, kl = _HVAEFunction.apply(trig, self, x, parents, beta)
+        else:
+            out3 = self._run_forward(x, parents, beta, record=False)
+            elbo, nll, kl = out3[0], out3[1], out3[2]
+        return dict(elbo=elbo, nll=nll, kl=kl)
+
+    # ------------------------------------------------------------------ inference API
+    def _sample_likelihood(self, eng, h, return_loc=True, t=None):
+        params = self._likelihood_params(eng, h)
+        lk = self.likelihood
+        B, R, Cx = h.n, h.h, self.input_channels
+        xo = torch.empty((B, Cx, R, R), dtype=torch.float32, device=eng.device)
+        so = torch.empty_like(xo)
+        if lk.kind == "dgauss":
+            if not return_loc:
+                raise NotImplementedError("DGaussNet.sample(return_loc=False) is unused by the reference's callers")
+            eng.lib.dgauss_sample(eng.dt, B, R, R, Cx, params.cv(), 0.0, xo.data_ptr(), so.data_ptr(), eng.stream)
+        else:
+            mode = {"soft": 0, "hard": 1}[lk.mask] if return_loc else 2
+            logt = 0.0 if t is None else float(torch.tensor(t).log())
+            eng.lib.dmol_decode(eng.dt, B, R, R, params.cv(), mode, eng.rng_ptr(), 977, logt, xo.data_ptr(), so.data_ptr(),
+                                eng.stream)
+        eng.launches += 1
+        return xo, so
+
+    def _begin_inference(self):
+        eng = self.engine()
+        eng.begin()
+        eng.recording = False
+        eng.prepare_weights()
+        if self.__dict__["noise"] is None:
+            eng.rng_advance(1)
+        return eng
+
+    @torch.no_grad()
+    def sample(self, parents: Tensor, return_loc: bool = True, t: Optional[float] = None):
+        """vae.py:460-464."""
+        eng = self._begin_inference()
+        pa = eng.from_nchw(parents.to(eng.device, torch.float32))
+        h, _ = self._decode(eng, pa, t=t)
+        return self._sample_likelihood(eng, h, return_loc, t)
+
+    @torch.no_grad()
+    def abduct(self, x: Tensor, parents: Tensor, cf_parents: Optional[Tensor] = None, alpha: float = 0.5,
+               t: Optional[float] = None):
+        """vae.py:466-514.  Returns the exogenous z list, the list of {z,q_loc,q_logscale} dicts (cond. prior), or the
+        mediator z* list when ``cf_parents`` is given."""
+        eng = self._begin_inference()
+        xin, pa = self._prep_inputs(eng, x, parents)
+        acts = self._encode(eng, xin)
+        logt = 0.0 if t is None else float(torch.tensor(t).log())
+        if not self.cond_prior:
+            _, zs = self._decode(eng, pa, acts=acts, t=t, collect="z")
+            return [eng.to_torch_cl(z) for z in zs]
+        _, qs = self._decode(eng, pa, acts=acts, t=t, collect="q")
+        if cf_parents is None:
+            out = []
+            for z, ql, qs_ in qs:
+                d = dict(z=eng.to_torch_cl(z), q_loc=eng.to_torch_cl(ql), q_logscale=eng.to_torch_cl(qs_))
+                if logt != 0.0:
+                    d["q_logscale"] = d["q_logscale"] + logt  # the reference stores q_logscale + log t
+                out.append(d)
+            return out
+        cfp = eng.from_nchw(cf_parents.to(eng.device, torch.float32))
+        _, ps = self._decode(eng, cfp, t=t, collect="p")
+        assert len(ps) == len(qs)
+        outs = []
+        for (z, ql, qs_), (pl, pls) in zip(qs, ps):
+            o = eng.new(z.n, z.h, z.w, z.c, rg=False)
+            eng.lib.mediator_mix(eng.dt, z.n, z.h, z.w, z.c, z.cv(), ql.cv(), qs_.cv(), pl.cv(), pls.cv(), float(alpha),
+                                 float(t) if t is not None else -1.0, logt, o.cv(), eng.stream)
+            eng.launches += 1
+            outs.append(eng.to_torch_cl(o))
+        return outs
+
+    def _latents_in(self, eng, latents):
+        ins = []
+        for z in latents:
+            if z is None:
+                ins.append(None)
+                continue
+            if isinstance(z, dict):
+                z = z["z"]
+            z = z.to(eng.device)
+            if z.dtype == eng.tdtype and z.permute(0, 2, 3, 1).is_contiguous():
+                ins.append(eng.wrap_nhwc(z.permute(0, 2, 3, 1)))
+            else:
+                ins.append(eng.from_nchw(z.float()))
+        return ins
+
+    @torch.no_grad()
+    def forward_latents(self, latents: List[Tensor], parents: Tensor, t: Optional[float] = None):
+        """vae.py:516-522: replay (possibly partial) latents under `parents`; returns (loc in [-1,1], scale)."""
+        eng = self._begin_inference()
+        pa = eng.from_nchw(parents.to(eng.device, torch.float32))
+        h, _ = self._decode(eng, pa, latents=self._latents_in(eng, latents), t=t)
+        return self._sample_likelihood(eng, h, True, t)

@@ -1,0 +1,217 @@
+/* cgen_hip.h -- C ABI of libcgen_hip.so: the MI355X (gfx950) kernels behind the HVAE image-mechanism /
+ * counterfactual hot path of biomedia-mira/causal-gen.
+ *
+ * The reference has no FFI layer: its L0 is stock ATen.  Each entry point below replaces the
+ * ATen op class(es) the reference dispatches at the cited src/ file:line; the host-side mirror of the
+ * reference's Python surface (causal-gen_amd/vae.py, dscm.py, dmol.py) is the only caller.
+ *
+ * Conventions
+ *   - Activations are NHWC *views*: channel stride 1, arbitrary (n,h,w) strides in ELEMENTS.  A channel slice
+ *     or a [:res,:res] crop of a bigger tensor is therefore a view, and torch.cat along C is never materialised
+ *     (multi-segment inputs).  dtype: CGEN_F32 (exact path: f32 MFMA 16x16x4, bit-level fmaf chains) or
+ *     CGEN_BF16 (bf16 storage + bf16 MFMA 16x16x32, f32 accumulate).  Parameters/gradients are always f32.
+ *   - Ownership: the caller owns every buffer including workspaces; the library never allocates, frees or
+ *     synchronises, and keeps no mutable global state (deepcopy / fork / hipGraph-capture safe).
+ *   - Every call only enqueues work on `stream` and returns 0, or a negative cgen_status (message via
+ *     cgen_last_error()).  Numerical NaNs are data, not errors (trainer.py:71-85 tests for them).
+ *   - Thread-safe and re-entrant; cgen_last_error() is thread-local.
+ */
+#ifndef CGEN_HIP_H
+#define CGEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cgen_stream_t; /* hipStream_t */
+
+enum cgen_status { CGEN_OK = 0, CGEN_EINVAL = -1, CGEN_ELAUNCH = -2, CGEN_EUNSUPPORTED = -3 };
+enum cgen_dtype { CGEN_F32 = 0, CGEN_BF16 = 1 };
+enum cgen_act { CGEN_ACT_NONE = 0, CGEN_ACT_RELU = 1, CGEN_ACT_GELU = 2 };
+
+/* NHWC strided view; strides in elements; p == NULL means "absent". */
+typedef struct cgen_view {
+  void* p;
+  int64_t sn, sh, sw;
+  int32_t c;
+  int32_t reserved;
+} cgen_view;
+
+#define CGEN_MAX_SEG 4
+
+int cgen_version(void);
+const char* cgen_last_error(void);
+
+/* ------------------------------------------------------------------ convolution (K1/K2/K3/K4/K5/K8/K9)
+ * out = (bias + conv_{KSxKS, stride 1, pad KS/2}( act(cat_C(seg[0..nseg))) )) * act'(aux) + res1 + res2
+ * Replaces aten::convolution (+ the gelu/relu before it, the torch.cat feeding it, the residual adds after it)
+ * at vae.py:53-55,61-67,71 (Block), :104-110 (stem), :165,167 (z_proj, z_feat_proj), :176,188 (cat), :78,292-294
+ * (adds), :325-333 (likelihood heads), dmol.py:223.  The SAME entry point is the data-gradient kernel:
+ * seg = grad_out, weight = the "dgrad image" from cgen_weight_prep, dact/aux = the forward activation and
+ * its input, res1 = out (accumulate).  res1/res2 may alias out.
+ * weight: image built by cgen_weight_prep: [ceil16(Co)][KS*KS][sum_s ceil32(C_s)] in `dtype`, zero padded. */
+typedef struct cgen_conv_args {
+  int32_t dtype, n, h, w, ks, nseg, act, dact;
+  cgen_view seg[CGEN_MAX_SEG];
+  const void* weight;
+  const float* bias; /* [Co] or NULL */
+  cgen_view out;     /* out.c = Co */
+  cgen_view aux, res1, res2;
+} cgen_conv_args;
+int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream);
+
+/* Weight gradient (aten::convolution_backward, weight/bias part) as split-K partials:
+ *   partial_w[split][Co][KS*KS][Ci_total] (f32), partial_b[split][Co] (f32, may be NULL)
+ * with Ci_total = sum_s seg[s].c and nsplit = cgen_conv2d_wgrad_splits(...).  Deterministic: partials are
+ * summed in a fixed order by cgen_wgrad_reduce. */
+typedef struct cgen_wgrad_args {
+  int32_t dtype, n, h, w, ks, nseg, act, nsplit;
+  cgen_view seg[CGEN_MAX_SEG];
+  cgen_view gout; /* gout.c = Co */
+  float* partial_w;
+  float* partial_b;
+} cgen_wgrad_args;
+int cgen_conv2d_wgrad_splits(int32_t n, int32_t h, int32_t w, int32_t co, int32_t ci_total, int32_t ks);
+int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream);
+
+/* Multi-tensor descriptor tables (device memory, built once by the host).  One launch serves every conv site. */
+typedef struct cgen_wprep_desc { /* OIHW f32 parameter -> forward image or dgrad image */
+  const float* src;
+  void* dst;
+  int32_t co, ci_total, ks, mode; /* mode 0: fwd image, 1: dgrad image of segment [seg_off, seg_off+seg_c[0]) */
+  int32_t nseg, seg_off;
+  int32_t seg_c[CGEN_MAX_SEG];
+  int32_t dtype, rows_pad, k_pad, reserved;
+  int64_t numel; /* rows_pad * ks*ks * k_pad */
+} cgen_wprep_desc;
+int cgen_weight_prep(const cgen_wprep_desc* descs_dev, const int32_t* chunk_site_dev, const int32_t* chunk_index_dev,
+                     int32_t nchunks, cgen_stream_t stream);
+
+typedef struct cgen_wred_desc { /* split-K partials -> OIHW f32 gradient (+bias gradient) */
+  const float* partial_w;
+  const float* partial_b;
+  float* grad_w; /* [Co][Ci][KS][KS] */
+  float* grad_b; /* [Co] or NULL */
+  int32_t co, ci_total, ks, nsplit;
+  int32_t accumulate, reserved;
+  int64_t numel; /* co*ci_total*ks*ks + co */
+} cgen_wred_desc;
+int cgen_wgrad_reduce(const cgen_wred_desc* descs_dev, const int32_t* chunk_site_dev, const int32_t* chunk_index_dev,
+                      int32_t nchunks, cgen_stream_t stream);
+
+/* ------------------------------------------------------------------ element-wise / data movement
+ * aten::avg_pool2d fwd/bwd (vae.py:79-83), upsample_nearest2d (+ learned per-res bias, vae.py:251-262),
+ * F.pad / slicing / clone (vae.py:131-133, 241), repeat of bias[1] (vae.py:233), pa_sto scaling (vae.py:244-247),
+ * layout + u8->[-1,1] preprocessing (trainer.py:16-21). */
+int cgen_avgpool_fwd(int32_t dtype, int32_t n, int32_t ho, int32_t wo, int32_t d, cgen_view in, cgen_view out, cgen_stream_t);
+int cgen_avgpool_bwd(int32_t dtype, int32_t n, int32_t ho, int32_t wo, int32_t d, cgen_view gout, cgen_view gin,
+                     int32_t accumulate, cgen_stream_t);
+/* out[n,y,x,:] = in[n, floor(y*hi/ho), floor(x*wi/wo), :] + (bias ? bias[y,x,:] : 0); bias is f32 [ho][wo][C] */
+int cgen_upsample_fwd(int32_t dtype, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo, cgen_view in,
+                      const float* bias, cgen_view out, cgen_stream_t);
+int cgen_upsample_bwd(int32_t dtype, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo, cgen_view gout,
+                      cgen_view gin, int32_t accumulate, cgen_stream_t);
+/* out[y,x,c] (+)= sum_n in[n,y,x,c]  (gradient of a batch-broadcast parameter); out f32 contiguous [h][w][C] */
+int cgen_batch_reduce(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view in, float* out, int32_t accumulate,
+                      cgen_stream_t);
+/* out[n,y,x,c] = src[y,x,c] (batch broadcast of an f32 [h][w][C] parameter) */
+int cgen_batch_broadcast(int32_t dtype, int32_t n, int32_t h, int32_t w, const float* src, cgen_view out, cgen_stream_t);
+/* out = alpha*in (+ out if accumulate); channels >= c_from additionally scaled by beta.  in may be absent (fill alpha). */
+int cgen_axpby(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view in, cgen_view out, float alpha, float beta,
+               int32_t c_from, int32_t accumulate, cgen_stream_t);
+/* NCHW (f32 or u8, contiguous) -> NHWC view in `dtype`: out = (in - sub) * mul */
+int cgen_nchw_to_nhwc(int32_t src_is_u8, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, const void* src,
+                      cgen_view out, float sub, float mul, cgen_stream_t);
+/* NHWC view -> contiguous NCHW f32 */
+int cgen_nhwc_to_nchw(int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, cgen_view in, float* dst, cgen_stream_t);
+
+/* ------------------------------------------------------------------ latent layer (K10, K16)
+ * Fused sample_gaussian + gaussian_kl (vae.py:14-30, 268-269):
+ *   z = q_loc + exp(q_ls + logt) * eps ; kl = -.5 + p - q + .5 (e^{2q} + (q_loc-p_loc)^2) e^{-2p}  (p = p_ls+logt, q = q_ls+logt)
+ * eps: explicit tensor (parity runs) or NULL => Philox4x32-10 + Box-Muller keyed by rng[0]=seed, rng[1]=offset
+ * (device memory, so a captured graph replays fresh noise) and `stream_id`; eps_out (optional) receives it.
+ * kl_part[b*kl_stride + chunk] = per-sample partial sums (deterministic two-stage reduction), chunk <
+ * cgen_reparam_kl_chunks(h,w,c); the caller lays all layers' chunks of one sample side by side (kl_stride = total). */
+int cgen_reparam_kl_chunks(int32_t h, int32_t w, int32_t c);
+int cgen_reparam_kl_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls,
+                        cgen_view p_loc, cgen_view p_ls, cgen_view eps_in, const uint64_t* rng, uint32_t stream_id,
+                        float logt, cgen_view z, cgen_view eps_out, float* kl_part, int32_t kl_stride, cgen_stream_t);
+/* Backward: gz = d/dz (view, may be absent), kl_coef_dev[b*coef_stride] = d elbo / d kl_sum[b] (device, f32;
+ * coef_stride 0 broadcasts one value).  dz/dq_ls = e^{q_ls} eps is taken as (z - q_loc), so eps is not needed.
+ * Writes (or accumulates into) the four gradients. */
+int cgen_reparam_kl_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls,
+                        cgen_view p_loc, cgen_view p_ls, cgen_view z, float logt, cgen_view gz,
+                        const float* kl_coef_dev, int32_t coef_stride, cgen_view g_q_loc, cgen_view g_q_ls,
+                        cgen_view g_p_loc, cgen_view g_p_ls, int32_t acc_q, int32_t acc_p, cgen_stream_t);
+/* z = loc + exp(ls + logt) * eps (prior sampling, vae.py:283-286); eps as above */
+int cgen_sample_gaussian(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view loc, cgen_view ls,
+                         cgen_view eps_in, const uint64_t* rng, uint32_t stream_id, float logt, cgen_view z,
+                         cgen_stream_t);
+/* Mediator latent z* (vae.py:485-513), q = q_ls+logt, p = p_ls+logt: u=(z-q_loc)/e^{q}; r_loc=a q_loc+(1-a)p_loc;
+ * r_var=a^2 e^{2q}+(1-a)^2 e^{2p}; z* = r_loc + sqrt(r_var)*t*u   (t<=0 => no temperature factor) */
+int cgen_mediator_mix(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view z, cgen_view q_loc,
+                      cgen_view q_ls, cgen_view p_loc, cgen_view p_ls, float alpha, float t, float logt, cgen_view out,
+                      cgen_stream_t);
+
+/* ------------------------------------------------------------------ likelihoods (K11-K14) and ELBO
+ * Discretised Gaussian (vae.py:352-411).  params view holds [loc(C) | logscale(C) | coeff(3, only C==3)] per pixel
+ * (the raw 1x1-conv outputs); x is NHWC.  nll_part[b*nchunk+chunk] = partial sums of -log p over (C,H,W). */
+int cgen_like_chunks(int32_t h, int32_t w);
+int cgen_dgauss_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x,
+                        float* nll_part, cgen_stream_t);
+/* g_params = coef_dev[b*coef_stride] * d(sum -log p)/d params */
+int cgen_dgauss_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x,
+                        const float* coef_dev, int32_t coef_stride, cgen_view g_params, cgen_stream_t);
+/* DGaussNet.sample(return_loc=True) (vae.py:413-422): loc (RGB autoregressive, clamped) and exp(logscale)+log t, NCHW f32 out */
+int cgen_dgauss_sample(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, float logt,
+                       float* x_nchw, float* scale_nchw, cgen_stream_t);
+/* Discretised mixture of logistics, 10 mixtures, 3 channels (dmol.py:24-118, 164-215, 121-161). logits: [.,100] */
+int cgen_dmol_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, cgen_view x, float* nll_part,
+                      cgen_stream_t);
+int cgen_dmol_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, cgen_view x,
+                      const float* coef_dev, int32_t coef_stride, cgen_view g_logits, cgen_stream_t);
+/* mode 0 soft mean, 1 hard (argmax) mean, 2 sample (Gumbel argmax + logistic noise from rng, temperature logt) */
+int cgen_dmol_decode(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, int32_t mode,
+                     const uint64_t* rng, uint32_t stream_id, float logt, float* x_nchw, float* scale_nchw, cgen_stream_t);
+/* elbo/nll/kl (vae.py:450-457): nll = mean_b( sum(nll_part[b]) / nll_div ), kl = mean_b( sum(kl_part[b]) / kl_div ),
+ * out3 = {nll + beta*kl, nll, kl}.  kl_part: [nkl][B] per-sample sums already reduced per layer by the caller's
+ * layout: kl_part[b*kl_stride + j], j < kl_count. */
+int cgen_elbo_finalize(int32_t n, const float* nll_part, int32_t nll_count, float nll_div, const float* kl_part,
+                       int32_t kl_count, float kl_div, float beta, float* out3, cgen_stream_t);
+/* Counterfactual pixel step (dscm.py:55-63): u=(x-rec_loc)/max(rec_scale,1e-12); cf=clamp(cf_loc+cf_scale*u,-1,1);
+ * optional running sums sum_x += cf, sum_x2 += cf^2.  All NCHW f32 contiguous, `count` elements. */
+int cgen_cf_pixels(int64_t count, const float* x, const float* rec_loc, const float* rec_scale, const float* cf_loc,
+                   const float* cf_scale, float* cf_x, float* sum_x, float* sum_x2, cgen_stream_t);
+
+/* ------------------------------------------------------------------ step tail (K17; trainer.py:67-87, utils.py:178-225)
+ * Flat-buffer fused global-norm -> clip -> skip predicate -> AdamW -> EMA.
+ * state_dev: f32[8] = {sum_sq, grad_norm, clip_coef, skip_flag, n_skipped, opt_steps, -, -}.  LambdaLR warm-up, Adam
+ * bias correction and the EMA warm-up decay are all derived ON DEVICE from opt_steps (successful steps so far), so
+ * the host never reads the skip decision (the reference syncs three times per step).
+ * out3 (optional) = {elbo, nll, kl}: NaN nll/kl forces a skip as trainer.py:71-74 does. */
+int cgen_sumsq_partial(const float* g, int64_t count, float* partial /*[nblk]*/, int32_t nblk, cgen_stream_t);
+int cgen_clip_decide(const float* partial, int32_t nblk, const float* out3, float max_norm, float skip_norm,
+                     float* state_dev, cgen_stream_t);
+typedef struct cgen_adamw_args {
+  float* p; const float* g; float* m; float* v; float* ema; /* ema may be NULL */
+  int64_t count;
+  float lr, beta1, beta2, eps, wd, ema_beta;
+  int32_t warmup_steps, ema_update_after;
+  const float* state_dev; /* reads clip_coef, skip_flag, opt_steps */
+} cgen_adamw_args;
+int cgen_adamw_ema(const cgen_adamw_args* a, cgen_stream_t);
+/* opt_steps += 1 unless the step was skipped (run once after all cgen_adamw_ema launches of a step) */
+int cgen_step_commit(float* state_dev, cgen_stream_t);
+
+/* Philox normal fill (f32 contiguous) -- exposed for tests of the in-kernel generator */
+int cgen_philox_normal(float* out, int64_t count, const uint64_t* rng, uint32_t stream_id, cgen_stream_t);
+/* rng[1] += inc (device-side counter bump so graph replays draw fresh noise) */
+int cgen_rng_advance(uint64_t* rng, uint64_t inc, cgen_stream_t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGEN_HIP_H */

@@ -1,0 +1,285 @@
+"""Op-level parity of the C-ABI kernels (called through the engine) against plain torch-CPU formulas / the oracle."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def make_engine(convs, segs, dtype="f32"):
+    from causal_gen_amd.engine import ConvSite, Engine
+
+    eng = Engine("cuda", dtype)
+    holder = torch.nn.ModuleList(convs).cuda()
+    sites = [ConvSite(f"c{i}", c, sc, [True] * len(sc), i) for i, (c, sc) in enumerate(zip(holder, segs))]
+    eng.bind(holder, sites)
+    eng.begin()
+    eng.prepare_weights(force=True)
+    return eng, sites
+
+
+def nhwc_to_torch(eng, t):
+    return eng.to_nchw(t).cpu()
+
+
+CONV_CASES = [
+    # (N, H, W, seg channels, Co, ks, act, with_res)
+    (2, 9, 7, [5], 3, 3, 1, False),
+    (3, 16, 16, [32], 8, 3, 1, True),
+    (2, 8, 8, [16, 3], 36, 1, 2, True),
+    (2, 12, 12, [64, 4, 64], 16, 3, 1, False),
+    (4, 1, 1, [130], 70, 3, 2, False),
+    (2, 20, 20, [1], 16, 7, 0, False),
+    (2, 6, 6, [3], 32, 7, 0, False),
+    (1, 33, 31, [40], 100, 1, 0, False),
+    (2, 4, 4, [48, 20], 1, 1, 0, False),
+    (130, 2, 2, [8], 8, 1, 2, True),
+]
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_bwd(case, dtype):
+    N, H, W, segc, Co, ks, act, with_res = case
+    g = torch.Generator().manual_seed(hash(case[:6]) % 1000)
+    conv = torch.nn.Conv2d(sum(segc), Co, ks, padding=ks // 2)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / math.sqrt(sum(segc) * ks * ks))
+        conv.bias.copy_(torch.randn(Co, generator=g) * 0.3)
+    xs = [torch.randn(N, c, H, W, generator=g) for c in segc]
+    res = torch.randn(N, Co, H, W, generator=g) if with_res else None
+    gout = torch.randn(N, Co, H, W, generator=g)
+    if dtype == "bf16":  # quantise inputs so both sides see the same values
+        xs = [x.bfloat16().float() for x in xs]
+        res = res.bfloat16().float() if with_res else None
+        gout = gout.bfloat16().float()
+    # ---- reference (torch CPU, f32; weights quantised the same way for bf16)
+    w_ref = conv.weight.detach().clone()
+    if dtype == "bf16":
+        w_ref = w_ref.bfloat16().float()
+    w_ref.requires_grad_(True)
+    b_ref = conv.bias.detach().clone().requires_grad_(True)
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    a = torch.cat(xr, dim=1)
+    a = F.relu(a) if act == 1 else (F.gelu(a) if act == 2 else a)
+    y_ref = F.conv2d(a, w_ref, b_ref, padding=ks // 2)
+    if with_res:
+        y_ref = y_ref + res
+    y_ref.backward(gout)
+    # ---- HIP
+    eng, (site,) = make_engine([conv], [segc], dtype)
+    eng.recording = True
+    nts = [eng.from_nchw(x.cuda(), rg=True) for x in xs]
+    for t in nts:
+        t.rg = True
+    rt = eng.from_nchw(res.cuda(), rg=False) if with_res else None
+    y = eng.conv(site, nts, act, res1=rt)
+    tol = dict(rtol=2e-4, atol=2e-5) if dtype == "f32" else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(nhwc_to_torch(eng, y), y_ref.detach(), **tol)
+    gy = eng.seed_grad(y)
+    eng.lib.axpby(eng.dt, N, H, W, eng.from_nchw(gout.cuda()).cv(), gy.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
+    eng.backward()
+    torch.cuda.synchronize()
+    for t, x in zip(nts, xr):
+        gx = nhwc_to_torch(eng, eng.grad_read(t))
+        torch.testing.assert_close(gx, x.grad, **tol)
+    wtol = dict(rtol=1e-3, atol=1e-4 * max(1.0, math.sqrt(N * H * W) / 8)) if dtype == "f32" else dict(rtol=5e-2, atol=5e-2 * math.sqrt(N * H * W) / 4)
+    torch.testing.assert_close(eng.param_grad_view(site.conv.weight).cpu(), w_ref.grad, **wtol)
+    torch.testing.assert_close(eng.param_grad_view(site.conv.bias).cpu(), b_ref.grad, **wtol)
+
+
+def test_double_use_accumulates_input_grad():
+    """A tensor consumed by two convs and as a residual gets the sum of the three gradients."""
+    g = torch.Generator().manual_seed(3)
+    c1, c2 = torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.Conv2d(8, 8, 1)
+    x = torch.randn(2, 8, 10, 10, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref = c1(F.relu(xr)) + xr + c2(xr)
+    gout = torch.randn(2, 8, 10, 10, generator=g)
+    y_ref.backward(gout)
+    eng, (s1, s2) = make_engine([c1, c2], [[8], [8]])
+    eng.recording = True
+    xt = eng.from_nchw(x.cuda(), rg=True)
+    xt.rg = True
+    t = eng.conv(s2, [xt], 0)
+    y = eng.conv(s1, [xt], 1, res1=xt, res2=t)
+    torch.testing.assert_close(nhwc_to_torch(eng, y), y_ref.detach(), rtol=1e-4, atol=1e-5)
+    gy = eng.seed_grad(y)
+    eng.lib.axpby(eng.dt, 2, 10, 10, eng.from_nchw(gout.cuda()).cv(), gy.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
+    eng.backward()
+    torch.testing.assert_close(nhwc_to_torch(eng, eng.grad_read(xt)), xr.grad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("d", [2, 4, 6, 8])
+def test_avgpool(d):
+    g = torch.Generator().manual_seed(d)
+    x = torch.randn(3, 12, 8 * d // 2 * 2 if d != 6 else 12, 8 * d // 2 * 2 if d != 6 else 12, generator=g)
+    x = x[:, :, : (x.shape[2] // d) * d, : (x.shape[3] // d) * d].contiguous()
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.avg_pool2d(xr, d, d)
+    gout = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gout)
+    eng, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]])
+    eng.recording = True
+    xt = eng.from_nchw(x.cuda(), rg=True)
+    xt.rg = True
+    y = eng.pool(xt, d)
+    torch.testing.assert_close(nhwc_to_torch(eng, y), y_ref.detach(), rtol=1e-5, atol=1e-6)
+    gy = eng.seed_grad(y)
+    eng.lib.axpby(eng.dt, y.n, y.h, y.w, eng.from_nchw(gout.cuda()).cv(), gy.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
+    eng.backward()
+    torch.testing.assert_close(nhwc_to_torch(eng, eng.grad_read(xt)), xr.grad, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("hi,ho", [(1, 4), (1, 6), (4, 8), (6, 12), (8, 14), (14, 28), (48, 96)])
+def test_upsample_matches_interpolate(hi, ho):
+    g = torch.Generator().manual_seed(hi * 100 + ho)
+    x = torch.randn(2, 8, hi, hi, generator=g)
+    bias = torch.nn.Parameter(torch.randn(1, 8, ho, ho, generator=g))
+    xr = x.clone().requires_grad_(True)
+    y_ref = bias + F.interpolate(xr, scale_factor=ho / hi)
+    gout = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gout)
+    holder = torch.nn.Conv2d(1, 1, 1)
+    holder.extra = bias
+    eng, _ = make_engine([holder], [[1]])
+    bias_dev = [p for p in eng.params if p.shape == bias.shape][0]
+    eng.recording = True
+    xt = eng.from_nchw(x.cuda(), rg=True)
+    xt.rg = True
+    y = eng.upsample(xt, ho, bias_dev)
+    torch.testing.assert_close(nhwc_to_torch(eng, y), y_ref.detach(), rtol=1e-6, atol=1e-6)
+    gy = eng.seed_grad(y)
+    eng.lib.axpby(eng.dt, y.n, y.h, y.w, eng.from_nchw(gout.cuda()).cv(), gy.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
+    eng.backward()
+    torch.testing.assert_close(nhwc_to_torch(eng, eng.grad_read(xt)), xr.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(eng.param_grad_view(bias_dev).cpu(), bias.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_reparam_kl_golden_and_grads():
+    from oracle import hvae_ref
+
+    fx = load_golden("ops.pt")["gaussian_kl"]
+    g = torch.Generator().manual_seed(1)
+    ql, qs, pl, ps = (fx[k] for k in ("q_loc", "q_logscale", "p_loc", "p_logscale"))
+    eps = torch.randn(ql.shape, generator=g)
+    gz = torch.randn(ql.shape, generator=g)
+    logt = math.log(0.8)
+    leaves = [t.clone().requires_grad_(True) for t in (ql, qs, pl, ps)]
+    z_ref = leaves[0] + (leaves[1] + logt).exp() * eps
+    kl_ref = hvae_ref.gaussian_kl(leaves[0], leaves[1] + logt, leaves[2], leaves[3] + logt)
+    coef = 0.37
+    ((z_ref * gz).sum() + coef * kl_ref.sum()).backward()
+    eng, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]])
+    eng.recording = True
+    N, Cc, H, W = ql.shape
+    ts = [eng.from_nchw(t.cuda(), rg=True) for t in (ql, qs, pl, ps)]
+    for t in ts:
+        t.rg = True
+    nch = eng.lib.reparam_kl_chunks(H, W, Cc)
+    klp = torch.zeros(N * nch, device="cuda")
+    z = eng.reparam_kl(ts[0], ts[1], ts[2], ts[3], eng.from_nchw(eps.cuda()), 1, logt, klp.data_ptr(), nch)
+    torch.testing.assert_close(nhwc_to_torch(eng, z), z_ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(klp.view(N, nch).sum(1).cpu(), kl_ref.detach().sum(dim=(1, 2, 3)), rtol=1e-5, atol=1e-3)
+    # golden (logt = 0)
+    klp0 = torch.zeros(N * nch, device="cuda")
+    eng.recording = False
+    eng.reparam_kl(ts[0], ts[1], ts[2], ts[3], eng.from_nchw(eps.cuda()), 1, 0.0, klp0.data_ptr(), nch)
+    torch.testing.assert_close(klp0.view(N, nch).sum(1).cpu(), fx["kl"].sum(dim=(1, 2, 3)), rtol=1e-5, atol=1e-3)
+    eng.recording = True
+    gzv = eng.seed_grad(z)
+    eng.lib.axpby(eng.dt, N, H, W, eng.from_nchw(gz.cuda()).cv(), gzv.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
+    cf = torch.tensor([0.0, coef], device="cuda")
+    eng.kl_coef_ptr = cf.data_ptr() + 4
+    eng.backward()
+    for t, leaf in zip(ts, leaves):
+        got = nhwc_to_torch(eng, eng.grad_read(t))
+        torch.testing.assert_close(got, leaf.grad, rtol=2e-4, atol=2e-3 * leaf.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("C", [1, 3])
+def test_dgauss_nll_golden(C):
+    d = load_golden("ops.pt")[f"dgauss_c{C}"]
+    sdk = d["state_dict"]
+    h, x = d["h"], d["x"]
+    N, _, H, W = x.shape
+    names = ["x_loc", "x_logscale"] + (["channel_coeffs"] if C == 3 else [])
+    raw = torch.cat([F.conv2d(h, sdk[n + ".weight"], sdk[n + ".bias"]) for n in names], dim=1).requires_grad_(True)
+    # torch reference on the raw head outputs
+    from oracle import hvae_ref
+
+    loc, ls = raw[:, :C], raw[:, C:2 * C].clamp(min=-9.0)
+    if C == 3:
+        k = torch.tanh(raw[:, 6:9])
+        loc = torch.stack([loc[:, 0], loc[:, 1] + k[:, 0] * x[:, 0], loc[:, 2] + k[:, 1] * x[:, 0] + k[:, 2] * x[:, 1]], dim=1)
+    nll_ref = hvae_ref.dgauss_nll_from_params(loc, ls, x)
+    torch.testing.assert_close(nll_ref.detach(), d["nll"], rtol=1e-5, atol=1e-6)
+    (g_ref,) = torch.autograd.grad(nll_ref.sum(), raw)
+    eng, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]])
+    pt = eng.from_nchw(raw.detach().cuda())
+    xt = eng.from_nchw(x.cuda())
+    nch = eng.lib.like_chunks(H, W)
+    part = torch.zeros(N * nch, device="cuda")
+    eng.lib.dgauss_nll_fwd(eng.dt, N, H, W, C, pt.cv(), xt.cv(), part.data_ptr(), eng.stream)
+    got = part.view(N, nch).sum(1).cpu() / (C * H * W)
+    torch.testing.assert_close(got, d["nll"], rtol=2e-5, atol=1e-6)
+    gp = eng.new(N, H, W, raw.shape[1])
+    coef = torch.tensor([1.0 / (C * H * W)], device="cuda")
+    eng.lib.dgauss_nll_bwd(eng.dt, N, H, W, C, pt.cv(), xt.cv(), coef.data_ptr(), 0, gp.cv(), eng.stream)
+    torch.testing.assert_close(nhwc_to_torch(eng, gp), g_ref, rtol=2e-3, atol=1e-5 * g_ref.abs().max().item() + 1e-7)
+    xo, so = torch.empty(N, C, H, W, device="cuda"), torch.empty(N, C, H, W, device="cuda")
+    eng.lib.dgauss_sample(eng.dt, N, H, W, C, pt.cv(), 0.0, xo.data_ptr(), so.data_ptr(), eng.stream)
+    torch.testing.assert_close(xo.cpu(), d["sample_x"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(so.cpu(), d["sample_scale"], rtol=1e-5, atol=1e-7)
+
+
+def test_dmol_golden():
+    d = load_golden("ops.pt")["dmol"]
+    l, x = d["l"], d["x"]  # channels-last already
+    N, H, W, _ = l.shape
+    eng, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]])
+    lt = eng.wrap_nhwc(l.cuda().contiguous())
+    xt = eng.wrap_nhwc(x.cuda().contiguous())
+    nch = eng.lib.like_chunks(H, W)
+    part = torch.zeros(N * nch, device="cuda")
+    eng.lib.dmol_nll_fwd(eng.dt, N, H, W, lt.cv(), xt.cv(), part.data_ptr(), eng.stream)
+    got = part.view(N, nch).sum(1).cpu() / (3 * H * W)
+    torch.testing.assert_close(got, d["loss"], rtol=1e-4, atol=1e-6)  # north-star: DMoL nats/dim within 1e-4 rel
+    gl = eng.new(N, H, W, 100)
+    coef = torch.tensor([1.0 / (3 * H * W)], device="cuda")
+    eng.lib.dmol_nll_bwd(eng.dt, N, H, W, lt.cv(), xt.cv(), coef.data_ptr(), 0, gl.cv(), eng.stream)
+    g = nhwc_to_torch(eng, gl).permute(0, 2, 3, 1)
+    torch.testing.assert_close(g, d["grad_l"], rtol=2e-3, atol=2e-6)
+    for mode, mask in ((0, "soft"), (1, "hard")):
+        xo, so = torch.empty(N, 3, H, W, device="cuda"), torch.empty(N, 3, H, W, device="cuda")
+        eng.lib.dmol_decode(eng.dt, N, H, W, lt.cv(), mode, None, 0, 0.0, xo.data_ptr(), so.data_ptr(), eng.stream)
+        torch.testing.assert_close(xo.cpu().permute(0, 2, 3, 1), d[f"mean_{mask}"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(so.cpu().permute(0, 2, 3, 1), d[f"scale_{mask}"], rtol=1e-4, atol=1e-6)
+    # sampling: finite, in range, deterministic per (seed, offset)
+    rng = torch.tensor([7, 0], dtype=torch.int64, device="cuda")
+    a, b = torch.empty(N, 3, H, W, device="cuda"), torch.empty(N, 3, H, W, device="cuda")
+    eng.lib.dmol_decode(eng.dt, N, H, W, lt.cv(), 2, rng.data_ptr(), 5, 0.0, a.data_ptr(), b.data_ptr(), eng.stream)
+    a2 = torch.empty_like(a)
+    eng.lib.dmol_decode(eng.dt, N, H, W, lt.cv(), 2, rng.data_ptr(), 5, 0.0, a2.data_ptr(), b.data_ptr(), eng.stream)
+    assert torch.isfinite(a).all() and a.abs().max() <= 1 and torch.equal(a, a2)
+
+
+def test_cf_pixels_and_particles():
+    from causal_gen_amd.dscm import cf_pixels
+
+    g = torch.Generator().manual_seed(2)
+    sh = (3, 1, 9, 9)
+    x, rl, cl = (torch.rand(sh, generator=g) * 2 - 1 for _ in range(3))
+    rs, cs = torch.rand(sh, generator=g) * 0.2 + 1e-3, torch.rand(sh, generator=g) * 0.2
+    rs[0, 0, 0, 0] = 0.0  # clamp(1e-12) branch
+    ref = torch.clamp(cl + cs * ((x - rl) / rs.clamp(min=1e-12)), -1, 1)
+    sx, sx2 = torch.zeros(sh, device="cuda"), torch.zeros(sh, device="cuda")
+    out = cf_pixels(x.cuda(), rl.cuda(), rs.cuda(), cl.cuda(), cs.cuda(), sx, sx2)
+    out = cf_pixels(x.cuda(), rl.cuda(), rs.cuda(), cl.cuda(), cs.cuda(), sx, sx2)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(sx.cpu(), 2 * ref, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(sx2.cpu(), 2 * ref ** 2, rtol=1e-6, atol=1e-6)
