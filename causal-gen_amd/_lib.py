@@ -128,6 +128,10 @@ def load():
     """Load libcgen_hip.so (no GPU needed).  Raises with build instructions when it is absent."""
     global _LIB
     if _LIB is None:
+        # torch must be in the process first: it bundles its own libamdhip64, and the kernels here must launch
+        # through the SAME HIP runtime instance that owns torch's streams and allocations.
+        import torch  # noqa: F401
+
         if not os.path.exists(LIB_PATH):
             raise CgenError(f"{LIB_PATH} not found: build it with causal-gen_amd/build.sh "
                             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")

@@ -111,6 +111,8 @@ class Engine:
         self.lib = _lib.require_gpu()
         self.device = torch.device(device)
         assert self.device.type == "cuda"
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.dt = {"f32": F32, "bf16": BF16}[dtype]
         self.dtype_name = dtype
         self.es = 4 if self.dt == F32 else 2

@@ -221,23 +221,24 @@ class HVAE(nn.Module):
         self.z_dim, self.context_dim = args.z_dim, args.context_dim
         self.input_channels = args.input_channels
         self.q_correction = args.q_correction
-        self.__dict__["_eng"] = None
-        self.__dict__["_trigger"] = None
-        self.__dict__["noise"] = None  # optional list of NCHW eps tensors consumed in draw order (parity tests)
+        self._reset_runtime()
+
+    _RUNTIME_KEYS = ("_eng", "_trigger", "noise", "_saved", "_coef")
+
+    def _reset_runtime(self):
+        for k in self._RUNTIME_KEYS:
+            self.__dict__[k] = None  # noise: optional list of NCHW eps tensors consumed in draw order (parity tests)
 
     # engine state is per-instance and never copied (copy.deepcopy(model) for the EMA builds its own lazily)
     def __deepcopy__(self, memo):
-        eng, trig, noise = self.__dict__.pop("_eng"), self.__dict__.pop("_trigger"), self.__dict__.pop("noise")
-        try:
-            cls = self.__class__
-            new = cls.__new__(cls)
-            memo[id(self)] = new
-            import copy as _copy
-            for k, v in self.__dict__.items():
+        import copy as _copy
+
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in self._RUNTIME_KEYS:
                 new.__dict__[k] = _copy.deepcopy(v, memo)
-        finally:
-            self.__dict__["_eng"], self.__dict__["_trigger"], self.__dict__["noise"] = eng, trig, noise
-        new.__dict__["_eng"], new.__dict__["_trigger"], new.__dict__["noise"] = None, None, None
+        new._reset_runtime()
         return new
 
     # ------------------------------------------------------------------ engine plumbing

@@ -45,7 +45,7 @@ CONV_CASES = [
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_bwd(case, dtype):
     N, H, W, segc, Co, ks, act, with_res = case
-    g = torch.Generator().manual_seed(hash(case[:6]) % 1000)
+    g = torch.Generator().manual_seed(N * 1000 + H * 37 + Co)
     conv = torch.nn.Conv2d(sum(segc), Co, ks, padding=ks // 2)
     with torch.no_grad():
         conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / math.sqrt(sum(segc) * ks * ks))
