@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the HVAE train step (and the counterfactual loop) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            # N=1 directly, N>1 under torch.distributed.run
+
+A "step" is one pass of the hot path over one synthetic batch already resident in HBM: weight images -> HVAE forward
+-> hand-written backward -> (DP: RCCL gradient all-reduce) -> grad-norm / clip / skip -> fused AdamW + EMA.
+Prints ONE JSON line on rank 0 (contract in the task description) with the `roofline` of the dominant kernel class
+(measured live with HIP events on the launch stream over one profiled step of the same workload) and the
+`cpu_baseline` (the oracle = bit-matched restatement of the reference's PyTorch-CPU path, timed on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# conv FLOPs per trained image (fwd + dgrad + wgrad = 3x forward), SURVEY 8(d) / BASELINE.md section 3
+TRAIN_GFLOP_PER_IMG = {"morphomnist": 0.260, "cmnist": 0.275, "ukbb192": 69.19, "mimic192": 27.38, "mimic224": 37.38}
+CF_GFLOP = {"morphomnist": 0.185, "cmnist": 0.192, "ukbb192": 47.67, "mimic192": 19.57, "mimic224": 26.71}
+MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0}  # dense, MI355X_MICROARCH.md
+
+
+def synth_batch(name, hp, B, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    R, C = hp.input_res, hp.input_channels
+    x = (torch.randint(0, 256, (B, C, R, R), generator=g).float() - 127.5) / 127.5
+    if name == "morphomnist":
+        pa = torch.cat([torch.rand(B, 2, generator=g) * 2 - 1,
+                        torch.nn.functional.one_hot(torch.randint(0, 10, (B,), generator=g), 10).float()], 1)
+    elif name == "cmnist":
+        pa = torch.cat([torch.nn.functional.one_hot(torch.randint(0, 10, (B,), generator=g), 10).float() for _ in range(2)], 1)
+    elif name == "ukbb192":
+        pa = torch.stack([torch.randint(0, 2, (B,), generator=g).float(), torch.randn(B, generator=g),
+                          torch.randn(B, generator=g), torch.randint(0, 2, (B,), generator=g).float()], 1)
+    else:
+        pa = torch.randn(B, hp.context_dim, generator=g)
+    pa = pa[..., None, None].repeat(1, 1, R, R)
+    return x.to(device), pa.to(device)
+
+
+def build_model(name, dtype, dmol=False):
+    from causal_gen_amd import vae
+    from causal_gen_amd.hps import setup_hparams
+
+    hp = setup_hparams(name)
+    torch.manual_seed(7)
+    m = vae.HVAE(hp)
+    if dmol:
+        from causal_gen_amd.dmol import DmolNet
+
+        m.likelihood = DmolNet(hp)
+
+    def init_bias(mod):  # main.py:51-55
+        if type(mod) == torch.nn.Conv2d:
+            torch.nn.init.zeros_(mod.bias)
+
+    m.apply(init_bias)
+    m.compute_dtype = dtype
+    return m, hp
+
+
+def cpu_baseline(name, budget_s=20.0):
+    """The oracle's train step (fwd + bwd + clip + AdamW + EMA, trainer.py:54-87) on this host's cores."""
+    from oracle import hparams as ohp
+    from oracle import hvae_ref, train_ref
+
+    hp = ohp.make_hparams(name)
+    B = 32 if hp.input_res <= 64 else 4
+    torch.manual_seed(7)
+    sd = hvae_ref.init_state_dict(hp)
+    tr = train_ref.RefTrainer(sd, hp)
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randint(0, 256, (B, hp.input_channels, hp.input_res, hp.input_res), generator=g).float() - 127.5) / 127.5
+    pa = torch.randn(B, hp.context_dim, generator=g)[..., None, None].repeat(1, 1, hp.input_res, hp.input_res)
+    tr.step(x, pa)  # warm-up
+    t0, it = time.time(), 0
+    while it < 3 or (time.time() - t0 < budget_s and it < 50):
+        tr.step(x, pa)
+        it += 1
+    dt = time.time() - t0
+    return dict(value=B * it / dt, unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{it} train steps of {name} at batch {B} (fwd+bwd+clip+AdamW+EMA), f32, after 1 warm-up step")
+
+
+def profile_step(ts, x, pa, dtype):
+    """One eager step with HIP events around every conv launch (on the launch stream) -> per-class totals."""
+    eng = ts.eng
+    eng.prof = {}
+    ts._eager(x, pa, ts.beta)
+    torch.cuda.synchronize()
+    classes = {}
+    shapes = {}
+    for (kind, ks, ci, co, res), (flops, evs, n) in eng.prof.items():
+        ms = sum(a.elapsed_time(b) for a, b in evs)
+        c = classes.setdefault(kind, [0.0, 0.0, 0])
+        c[0] += flops; c[1] += ms; c[2] += n
+        shapes[(kind, ks, ci, co, res)] = (flops, ms, n)
+    eng.prof = None
+    dom = max(classes, key=lambda k: classes[k][1])
+    flops, ms, n = classes[dom]
+    top = sorted(shapes.items(), key=lambda kv: -kv[1][1])[:8]
+    return dict(
+        bound="mfma", kernel=dom, achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_PEAK_TF[dtype], unit="TFLOP/s",
+        frac=flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dtype], traffic=None, launches=n, avg_launch_us=1e3 * ms / n,
+        classes={k: dict(tflops=v[0] / (v[1] * 1e-3) / 1e12, ms=v[1], launches=v[2]) for k, v in classes.items()},
+        top_shapes=[dict(kind=k[0], ks=k[1], ci=k[2], co=k[3], res=k[4], ms=v[1], tflops=v[0] / (v[1] * 1e-3) / 1e12, n=v[2])
+                    for k, v in top])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="ukbb192", choices=sorted(TRAIN_GFLOP_PER_IMG))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 32 at 192^2/224^2, 256 at 32^2)")
+    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"])
+    ap.add_argument("--dmol", action="store_true", help="DMoL likelihood head (cmnist)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cf", action="store_true")
+    ap.add_argument("--prep-steps", type=int, default=20, help="untimed optimiser steps so the prior heads are non-zero")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        pg = dist.group.WORLD
+
+    from causal_gen_amd.train import TrainStep
+
+    m, hp = build_model(a.config, a.dtype, a.dmol)
+    m = m.to(dev)
+    B = a.batch or (256 if hp.input_res <= 64 else 32)
+    ts = TrainStep(m, hp, ema=True, use_graph=not a.no_graph, process_group=pg)
+    x, pa = synth_batch(a.config, hp, B, dev, seed=100 + rank)
+
+    out = None
+    for _ in range(a.prep_steps + a.warmup):
+        out = ts.step(x, pa)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = ts.step(x, pa)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    elbo, nll, kl = [float(v) for v in out.cpu()]
+    stats = ts.stats()
+    img_s = B * world * a.steps / dt
+
+    if rank == 0:
+        gf = TRAIN_GFLOP_PER_IMG[a.config]
+        res = {
+            "metric": "HVAE train images/sec", "value": img_s, "unit": "images/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"{a.config} HVAE train step ({hp.input_res}x{hp.input_res}x{hp.input_channels}, "
+                                   f"{'DMoL' if a.dmol else 'DGauss'} likelihood, beta={hp.beta}, z_max_res={hp.z_max_res})",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "hipgraph": not a.no_graph, "params": sum(p.numel() for p in m.parameters())},
+            "elbo_nats_per_dim": elbo, "nll": nll, "kl": kl, "opt_steps": stats["opt_steps"], "skipped": stats["n_skipped"],
+            "model_tflops": img_s * gf * 1e9 / 1e12,
+            "model_mfma_frac": img_s * gf * 1e9 / 1e12 / (MFMA_PEAK_TF[a.dtype] * world),
+        }
+        res["roofline"] = profile_step(ts, x, pa, a.dtype)
+        if not a.no_cf:
+            from causal_gen_amd.dscm import counterfactual
+
+            ema = ts.ema_model
+            cfp = pa.roll(1, 0)  # train_cf.py:149 feeds a permutation of the batch's parents as `do`
+            for _ in range(2):
+                counterfactual(ema, x, pa, cfp)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_cf = 5
+            for _ in range(n_cf):
+                counterfactual(ema, x, pa, cfp)
+            torch.cuda.synchronize()
+            cf_s = B * n_cf / (time.perf_counter() - t1)
+            res["counterfactuals_per_s"] = cf_s
+            res["cf_tflops"] = cf_s * CF_GFLOP[a.config] * 1e9 / 1e12
+        if world == 1 and not a.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(a.config)
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -133,6 +133,7 @@ class Engine:
         self.pgrad_init = set()
         self.rng = None
         self.launches = 0
+        self.prof = None  # {"conv_fwd": [flops, [(ev0, ev1), ...]], ...} when profiling is on
 
     # ------------------------------------------------------------------ memory
     def begin(self):
@@ -331,11 +332,28 @@ class Engine:
         a.aux = NULL_VIEW
         a.res1 = res1.cv() if res1 is not None else NULL_VIEW
         a.res2 = res2.cv() if res2 is not None else NULL_VIEW
-        self.lib.conv2d(C.byref(a), self.stream)
-        self.launches += 1
+        self._timed("conv_fwd", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream))
         if self.recording:
             self.tape.append((self._bw_conv, (site, segs, act, out, res1, res2)))
         return out
+
+    def _timed(self, kind, site, x0, fn, ci=None):
+        """Launch `fn`; when profiling, bracket it with events on the launch stream and tally algorithmic FLOPs
+        (2 * Ci * k*k * Co per output pixel) under (kind, shape)."""
+        self.launches += 1
+        if self.prof is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        ci = site.ci if ci is None else ci
+        flops = 2.0 * ci * site.taps * site.co * x0.n * x0.h * x0.w
+        key = (kind, site.ks, ci, site.co, x0.h)
+        ent = self.prof.setdefault(key, [0.0, [], 0])
+        ent[0] += flops
+        ent[1].append((e0, e1))
+        ent[2] += 1
 
     def pool(self, x, d):
         out = self.new(x.n, x.h // d, x.w // d, x.c)
@@ -516,8 +534,7 @@ class Engine:
             a.aux = s.cv() if act != ACT_NONE else NULL_VIEW
             a.res1 = gv.cv() if acc else NULL_VIEW
             a.res2 = NULL_VIEW
-            self.lib.conv2d(C.byref(a), self.stream)
-            self.launches += 1
+            self._timed("conv_dgrad", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream), ci=s.c)
 
     def _wgrad(self, site, segs, act, g):
         x0 = segs[0]
@@ -537,8 +554,7 @@ class Engine:
         a.gout = g.cv()
         a.partial_w = buf.data_ptr()
         a.partial_b = buf.data_ptr() + 4 * nsplit * nw if site.conv.bias is not None else None
-        self.lib.conv2d_wgrad(C.byref(a), self.stream)
-        self.launches += 1
+        self._timed("conv_wgrad", site, x0, lambda: self.lib.conv2d_wgrad(C.byref(a), self.stream))
         self._wg_events.append((site, key, nsplit))
 
     def _reduce_wgrads(self):

@@ -1,0 +1,177 @@
+"""The per-step training harness of the reference (trainer.py:49-87, train_setup.py:42-53, utils.py:87-228) as a
+fixed launch sequence on the GPU:
+
+    weight images -> HVAE forward -> hand-written backward -> [DP: gradient all-reduce] -> global grad-norm ->
+    clip / NaN-or-norm skip predicate (on device) -> fused AdamW + EMA -> step counter commit
+
+No autograd, no host synchronisation inside the step (the reference has three): the skip decision,
+the LR warm-up, Adam's bias correction and the EMA warm-up schedule are all evaluated on the device from a
+device-side count of successful steps.  The whole sequence is captured in a hipGraph after one eager step.
+Under data parallelism (one process per GPU, RCCL over xGMI) the flat f32 gradient is averaged across ranks in
+buckets between the backward and the norm; ranks share the seed-driven draws and the skip flag by construction
+(the flag is a function of the all-reduced gradient and of the all-reduced nll/kl).
+"""
+import copy
+import ctypes as C
+
+import torch
+
+from . import _lib, dp
+
+
+def linear_warmup(warmup_iters):
+    """utils.py:32-36."""
+    return lambda it: 1.0 if it > warmup_iters else it / warmup_iters
+
+
+class TrainStep:
+    NORM_BLOCKS = 1024
+
+    def __init__(self, model, args, ema=True, use_graph=True, process_group=None, bucket_mb=32):
+        self.model, self.args = model, args
+        self.lib = _lib.require_gpu()
+        self.use_graph = use_graph
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+        model.train()
+        eng = model.engine()
+        self.eng = eng
+        n = eng.flat_p.numel()
+        dev = eng.device
+        self.m = torch.zeros(n, device=dev)
+        self.v = torch.zeros(n, device=dev)
+        self.ema_model = None
+        if ema:
+            self.ema_model = copy.deepcopy(model).to(dev)
+            self.ema_model.requires_grad_(False)
+            self.ema_model.eval()
+            self.ema_flat = self.ema_model.engine().flat_p
+        self.state = torch.zeros(8, device=dev)
+        self.partial = torch.zeros(self.NORM_BLOCKS, device=dev)
+        self.coef = None
+        self.ranges = None
+        self.graphs = {}
+        self.static = None
+        self.out3 = None
+        self.beta = float(args.beta)
+        self.it = 0
+
+    # -- pieces -----------------------------------------------------------------------------------------
+    def _fwd_bwd(self, x, pa, beta):
+        m, eng = self.model, self.eng
+        out3 = m._run_forward(x, pa, beta, record=True)
+        params, xin, B, R, Cx, dims = m.__dict__["_saved"]
+        if self.coef is None or self.coef_key != (B, dims, beta):
+            self.coef = torch.tensor([1.0 / (B * dims), beta / (B * dims)], device=eng.device)
+            self.coef_key = (B, dims, beta)
+        eng.kl_coef_ptr = self.coef.data_ptr() + 4
+        gparams = eng.seed_grad(params)
+        if m.likelihood.kind == "dgauss":
+            self.lib.dgauss_nll_bwd(eng.dt, B, R, R, Cx, params.cv(), xin.cv(), self.coef.data_ptr(), 0, gparams.cv(), eng.stream)
+        else:
+            self.lib.dmol_nll_bwd(eng.dt, B, R, R, params.cv(), xin.cv(), self.coef.data_ptr(), 0, gparams.cv(), eng.stream)
+        eng.backward()
+        return out3
+
+    def _allreduce(self, out3):
+        """Average the flat gradient (and the reported scalars, whose NaN-ness feeds the skip predicate) over the
+        data-parallel ranks: a few large buckets, not 800 small tensors (xGMI rings are per-link bound)."""
+        if self.world > 1:
+            dp.bucketed_allreduce_mean(self.eng.flat_g, self.bucket_elems, self.pg, extra=(out3,))
+
+    def _used_ranges(self):
+        eng = self.eng
+        rs, cur = [], None
+        for p in eng.params:
+            o, k = eng.p_off[id(p)], p.numel()
+            used = id(p) in eng.pgrad_init and p.requires_grad
+            if used:
+                if cur is not None and cur[1] == o:
+                    cur[1] = o + k
+                else:
+                    cur = [o, o + k]
+                    rs.append(cur)
+            else:
+                cur = None
+        return [(a, b) for a, b in rs]
+
+    def _optim(self, out3):
+        eng, a = self.eng, self.args
+        st = eng.stream
+        self.lib.sumsq_partial(eng.flat_g.data_ptr(), eng.flat_g.numel(), self.partial.data_ptr(), self.NORM_BLOCKS, st)
+        self.lib.clip_decide(self.partial.data_ptr(), self.NORM_BLOCKS, out3.data_ptr(), float(a.grad_clip), float(a.grad_skip),
+                             self.state.data_ptr(), st)
+        if self.ranges is None:
+            self.ranges = self._used_ranges()
+        for (lo, hi) in self.ranges:
+            q = _lib.AdamwArgs()
+            q.p = eng.flat_p.data_ptr() + 4 * lo
+            q.g = eng.flat_g.data_ptr() + 4 * lo
+            q.m = self.m.data_ptr() + 4 * lo
+            q.v = self.v.data_ptr() + 4 * lo
+            q.ema = self.ema_flat.data_ptr() + 4 * lo if self.ema_model is not None else None
+            q.count = hi - lo
+            q.lr, q.beta1, q.beta2, q.eps, q.wd = float(a.lr), float(a.betas[0]), float(a.betas[1]), 1e-8, float(a.wd)
+            q.ema_beta, q.warmup_steps, q.ema_update_after = float(a.ema_rate), int(a.lr_warmup_steps), 100
+            q.state_dev = self.state.data_ptr()
+            self.lib.adamw_ema(C.byref(q), st)
+        self.lib.step_commit(self.state.data_ptr(), st)
+
+    def _eager(self, x, pa, beta):
+        out3 = self._fwd_bwd(x, pa, beta)
+        self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
+        self._allreduce(out3)
+        self._optim(out3)
+        return out3
+
+    # -- public -------------------------------------------------------------------------------------------
+    def step(self, x, pa):
+        """One optimiser step on a batch already resident on the GPU.  Returns the device tensor [elbo, nll, kl]."""
+        a = self.args
+        self.it += 1
+        beta = self.beta
+        if getattr(a, "beta_warmup_steps", 0) > 0:
+            beta = self.beta * linear_warmup(a.beta_warmup_steps)(self.it)
+        if not self.use_graph:
+            return self._eager(x, pa, beta)
+        m = self.model
+        drop = (1, 1)
+        if m.cond_prior:  # host draw (shared across DP ranks through the common seed), one graph per outcome
+            drop = type(m.decoder).drop_cond(m.decoder)
+            m.decoder.__dict__["drop_cond"] = lambda d=drop: d
+        key = (tuple(x.shape), x.dtype, beta, drop)
+        ent = self.graphs.get(key)
+        if ent is None:
+            out = self._eager(x, pa, beta)  # eager warm-up: sizes the arena, builds the tables
+            sx, sp = x.clone(), pa.clone()
+            torch.cuda.synchronize()
+            # NCCL inside a captured graph is avoided: under DP the step is two graphs around an eager all-reduce
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                so = self._fwd_bwd(sx, sp, beta)
+                if self.world == 1:
+                    self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
+                    self._optim(so)
+            g2 = None
+            if self.world > 1:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
+                    self._optim(so)
+            self.graphs[key] = (g1, g2, sx, sp, so)
+            return out
+        g1, g2, sx, sp, so = ent
+        if sx.data_ptr() != x.data_ptr():
+            sx.copy_(x, non_blocking=True)
+            sp.copy_(pa, non_blocking=True)
+        g1.replay()
+        if g2 is not None:
+            self._allreduce(so)
+            g2.replay()
+        return so
+
+    def stats(self):
+        """Host read of the device-side step state (one sync; call every N steps, not every step)."""
+        s = self.state.cpu().tolist()
+        return dict(grad_norm=s[1], clip_coef=s[2], skipped_last=bool(s[3]), n_skipped=int(s[4]), opt_steps=int(s[5]))

@@ -441,7 +441,7 @@ class HVAE(nn.Module):
         eng = self.engine()
         eng.begin()
         eng.recording = record
-        eng.prepare_weights()
+        eng.prepare_weights(force=record)  # a training step always re-images: fused AdamW bypasses torch's version counter
         if self.__dict__["noise"] is None:
             eng.rng_advance(1)
         xin, pa = self._prep_inputs(eng, x, parents)

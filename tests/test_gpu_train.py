@@ -1,0 +1,116 @@
+"""Fused train step (forward, hand-written backward, device-side clip/skip, AdamW+EMA) against the oracle's
+restatement of trainer.py:54-87; hipGraph replay against eager execution."""
+import copy
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def setup(name="tiny_light_c1.pt", **over):
+    from causal_gen_amd import vae
+    from causal_gen_amd.hps import Hparams
+
+    fx = load_golden(name)
+    hpd = dict(fx["hp"])
+    hpd.update(lr=2e-3, lr_warmup_steps=2, wd=0.05, beta=2.0)
+    hpd.update(over)
+    m = vae.HVAE(Hparams(**hpd))
+    m.load_state_dict(fx["state_dict"])
+    return fx, hpd, m.cuda()
+
+
+def test_train_steps_match_oracle():
+    from causal_gen_amd.train import TrainStep
+    from oracle import train_ref
+
+    fx, hpd, m = setup()
+    hp = SimpleNamespace(**hpd)
+    ref = train_ref.RefTrainer(fx["state_dict"], hp)
+    ts = TrainStep(m, hp, ema=True, use_graph=False)
+    x, pa = fx["x"], fx["pa"]
+    g = torch.Generator().manual_seed(0)
+    for step in range(5):
+        eps = [torch.randn(e.shape, generator=g) for e in fx["fwd"]["eps"]]
+        r_out, r_gn = ref.step(x, pa, noise=[e.clone() for e in eps])
+        m.noise = [e.clone() for e in eps]
+        out = ts.step(x.cuda(), pa.cuda())
+        st = ts.stats()
+        got = [float(v) for v in out.cpu()]
+        for a, b in zip(got, (r_out["elbo"], r_out["nll"], r_out["kl"])):
+            assert abs(a - b) / abs(b) < 2e-4, (step, got, r_out)
+        assert abs(st["grad_norm"] - r_gn) / r_gn < 2e-3, (step, st, r_gn)
+        assert st["opt_steps"] == ref.opt_steps
+    sd = m.state_dict()
+    ema = ts.ema_model.state_dict()
+    for k, v in ref.sd.items():
+        torch.testing.assert_close(sd[k].cpu(), v.detach(), rtol=2e-3, atol=2e-5, msg=lambda s: f"{k}: {s}")
+        torch.testing.assert_close(ema[k].cpu(), ref.ema[k], rtol=2e-3, atol=2e-5, msg=lambda s: f"ema {k}: {s}")
+
+
+def test_skip_on_huge_gradient_leaves_everything_untouched():
+    from causal_gen_amd.train import TrainStep
+
+    fx, hpd, m = setup(grad_skip=1e-6)  # every step is "too large"
+    ts = TrainStep(m, SimpleNamespace(**hpd), ema=True, use_graph=False)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    for _ in range(2):
+        ts.step(fx["x"].cuda(), fx["pa"].cuda())
+    st = ts.stats()
+    assert st["n_skipped"] == 2 and st["opt_steps"] == 0 and st["skipped_last"]
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+
+
+def test_graph_replay_equals_eager():
+    from causal_gen_amd.train import TrainStep
+
+    outs = []
+    for use_graph in (False, True):
+        fx, hpd, m = setup()
+        torch.manual_seed(123)
+        ts = TrainStep(m, SimpleNamespace(**hpd), ema=True, use_graph=use_graph)
+        x, pa = fx["x"].cuda(), fx["pa"].cuda()
+        for _ in range(4):
+            o = ts.step(x, pa)
+        torch.cuda.synchronize()
+        outs.append(([float(v) for v in o.cpu()], {k: v.clone() for k, v in m.state_dict().items()}, ts.stats()))
+    (o0, s0, t0), (o1, s1, t1) = outs
+    assert t0["opt_steps"] == t1["opt_steps"] == 4
+    assert o0 == o1, (o0, o1)  # same kernels, same addresses, same Philox counters => bitwise equal
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
+def test_counterfactual_api_and_dscm_forward():
+    from causal_gen_amd import dscm
+
+    fx, hpd, m = setup("tiny_default_c1.pt")
+    m.eval()
+    x, pa, cf = fx["x"].cuda(), fx["pa"].cuda(), fx["cf_pa"].cuda()
+    ab = fx["abduct"]
+    m.noise = [e.clone() for e in ab["eps"]]
+    cf_x = dscm.counterfactual(m, x, pa, cf, t_abduct=ab["t"])
+    ok = fx["cf"]["rec_scale"] > 1e-3
+    assert ((cf_x.cpu() - fx["cf"]["cf_x"]).abs()[ok]).max() < 1e-3
+    # null intervention => the counterfactual is the observation (up to the clamp), whatever the noise
+    m.noise = None
+    same = dscm.counterfactual(m, x, pa, pa)
+    assert (same - x).abs().max() < 1e-4
+
+    class StubPGM(torch.nn.Module):
+        def counterfactual(self, obs, intervention, num_particles=1):
+            return {k: intervention.get(k, v) for k, v in obs.items()}
+
+    args = SimpleNamespace(**hpd, parents_x=["a", "b", "c"], dataset="none", lmbda_init=1.0, elbo_constraint=2.0, damping=10.0)
+    model = dscm.DSCM(args, StubPGM(), None, m)
+    obs = {"x": x, "a": pa[:, 0, 0, 0], "b": pa[:, 1, 0, 0], "c": pa[:, 2:3, 0, 0]}
+    do = {"a": cf[:, 0, 0, 0]}
+    out = model(obs, do, None, cf_particles=3, t_abduct=0.9)
+    assert out["cfs"]["x"].shape == x.shape and out["var_cf_x"].shape == x.shape
+    assert torch.isfinite(out["cfs"]["x"]).all() and (out["var_cf_x"] >= -1e-6).all()
+    assert dscm.vae_preprocess(args, {"a": torch.ones(2, 1), "b": torch.ones(2, 1), "c": torch.ones(2, 1)}).shape == (2, 3, 16, 16)

@@ -1,0 +1,100 @@
+"""Host-side logic that needs no GPU: module tree / init parity with the reference, conv-site segmentation,
+gradient-interval bookkeeping, data-parallel plumbing over gloo (world_size 2)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import load_golden
+
+
+@pytest.mark.parametrize("name", ["morphomnist", "cmnist", "ukbb192"])
+def test_module_tree_and_init_match_reference(name):
+    from causal_gen_amd import vae
+    from causal_gen_amd.hps import setup_hparams
+
+    row = load_golden("anchors.pt")[name]
+    torch.manual_seed(7)
+    m = vae.HVAE(setup_hparams(name))
+
+    def init_bias(mod):
+        if type(mod) == torch.nn.Conv2d:
+            torch.nn.init.zeros_(mod.bias)
+
+    m.apply(init_bias)
+    sd = m.state_dict()
+    assert list(sd.keys()) == row["keys"]
+    assert [tuple(v.shape) for v in sd.values()] == row["shapes"]
+    tot = float(sum(p.detach().abs().double().sum() for p in m.parameters()))
+    assert abs(tot - row["abs_sum"]) < 1e-6 * row["abs_sum"]
+    sites = m._make_sites()
+    n_convs = sum(1 for mod in m.modules() if isinstance(mod, torch.nn.Conv2d))
+    assert len(sites) == n_convs
+    for s in sites:
+        assert sum(s.seg_c) == s.conv.in_channels
+    # decoder introspection used by the reference's setup_tensorboard (train_setup.py:96-103)
+    assert all(hasattr(b, "stochastic") and hasattr(b, "res") for b in m.decoder.blocks)
+
+
+def test_missing_intervals():
+    from causal_gen_amd.engine import Engine
+
+    f = Engine._missing
+    assert f([], 0, 8) == [(0, 8)]
+    assert f([(0, 8)], 0, 8) == []
+    assert f([(0, 4)], 0, 8) == [(4, 8)]
+    assert f([(2, 4), (6, 7)], 0, 8) == [(0, 2), (4, 6), (7, 8)]
+    assert f([(0, 16)], 4, 8) == []
+    assert f([(8, 16)], 0, 8) == [(0, 8)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    from causal_gen_amd import dp
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(7)  # seed_all(args.seed): identical on every rank
+    draws = [dp.shared_categorical_draw() for _ in range(16)]
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(10_007, generator=g)
+    mine = flat.clone()
+    scal = torch.tensor([float(rank), float("nan") if rank == 1 else 1.0, 2.0])
+    n = dp.bucketed_allreduce_mean(flat, 4096, None, extra=(scal,))
+    full = torch.arange(12.0).view(6, 2)
+    q.put((rank, draws, mine.numpy(), flat.numpy(), scal.numpy(), n, dp.shard_batch(full, rank, world).numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_gloo_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    res = [tuple(torch.from_numpy(v) if hasattr(v, "dtype") else v for v in r) for r in res]
+    (_, d0, m0, f0, s0, n0, sh0), (_, d1, m1, f1, s1, n1, sh1) = res
+    assert d0 == d1 and len(set(d0)) > 1          # ranks share the conditioning-dropout draw without a collective
+    torch.testing.assert_close(f0, (m0 + m1) / 2)  # mean gradient
+    assert torch.equal(f0, f1)
+    assert n0 == n1 == 3 + 1                       # 3 buckets + the scalar rider
+    assert torch.isnan(s0[1]) and torch.isnan(s1[1])  # a NaN nll on ONE rank is seen by all => identical skip decision
+    assert s0[0].item() == 0.5
+    assert torch.equal(torch.cat([sh0, sh1]), torch.arange(12.0).view(6, 2)[:6])
