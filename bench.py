@@ -105,7 +105,13 @@ def profile_step(ts, x, pa, dtype):
     eng.prof = None
     dom = max(classes, key=lambda k: classes[k][1])
     flops, ms, n = classes[dom]
-    top = sorted(shapes.items(), key=lambda kv: -kv[1][1])[:8]
+    top = sorted(shapes.items(), key=lambda kv: -kv[1][1])
+    dump = os.environ.get("CGEN_SHAPE_DUMP")
+    if dump:
+        with open(dump, "w") as f:
+            for k, v in top:
+                f.write("%-10s ks%d ci%-4d co%-4d res%-4d n%-3d ms %8.3f  TF/s %8.2f\n" % (k[0], k[1], k[2], k[3], k[4], v[2], v[1], v[0] / (v[1] * 1e-3) / 1e12))
+    top = top[:8]
     return dict(
         bound="mfma", kernel=dom, achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_PEAK_TF[dtype], unit="TFLOP/s",
         frac=flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dtype], traffic=None, launches=n, avg_launch_us=1e3 * ms / n,
