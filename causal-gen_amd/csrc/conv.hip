@@ -7,6 +7,8 @@
 // bf16 path: v_mfma_f32_16x16x32_bf16 (f32 accumulate)
 // Workgroup = 256 threads (4 waves) -> 128 pixels x (16*NTC) output channels; K advances 32 channels per step.
 // Global -> register -> LDS staging with the next K-step's loads issued before the current MFMAs.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace cgen {
@@ -19,14 +21,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define CONV_LDK 40  // LDS row stride in elements (bank-conflict-free 16B fragment reads)
 
 struct ConvP {
-  int N, H, W, KS, pad, nseg, act, dact, Co, P, taps, kpad;
+  int N, H, W, KS, pad, nseg, act, dact, Co, P, taps, ctot8, krow;
   View seg[CGEN_MAX_SEG];
-  int seg_koff[CGEN_MAX_SEG];  // offset of the segment inside the padded K axis of the weight image
+  int seg_koff[CGEN_MAX_SEG];  // offset of the segment inside the 8-granular concatenated channel axis
   int seg_vec[CGEN_MAX_SEG];
   const void* w;
   const float* bias;
   View out, aux, res1, res2;
-  int epi_vec;
+  int epi_vec, force_generic;
 };
 
 // 4-element (16B f32 / 8B bf16) vector access
@@ -52,6 +54,51 @@ template <typename T, int N> union Pack {
   T e[N];
   uint4 v4;
 };
+
+// (bias + acc) * act'(aux) + res1 + res2 for 4 consecutive output channels of one pixel
+template <typename T>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4& a, int pn, int py, int px, int co) {
+  if (co >= p.Co) return;
+  T* optr = vptr<T>(p.out, pn, py, px);
+  const T* aptr = p.aux.p ? vptr<T>(p.aux, pn, py, px) : nullptr;
+  const T* r1 = p.res1.p ? vptr<T>(p.res1, pn, py, px) : nullptr;
+  const T* r2 = p.res2.p ? vptr<T>(p.res2, pn, py, px) : nullptr;
+  float v[4] = {a[0], a[1], a[2], a[3]};
+  if ((co + 4 <= p.Co) && p.epi_vec) {
+    if (p.bias) {
+      const float4 bb = *(const float4*)(p.bias + co);
+      v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+    }
+    float t4[4];
+    if (aptr) {
+      ld4<T>(aptr + co, t4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= act_bwd(p.dact, t4[e]);
+    }
+    if (r1) {
+      ld4<T>(r1 + co, t4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += t4[e];
+    }
+    if (r2) {
+      ld4<T>(r2 + co, t4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += t4[e];
+    }
+    st4<T>(optr + co, v);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (co + e < p.Co) {
+        float u = v[e] + (p.bias ? p.bias[co + e] : 0.f);
+        if (aptr) u *= act_bwd(p.dact, Elem<T>::ld(aptr + co + e));
+        if (r1) u += Elem<T>::ld(r1 + co + e);
+        if (r2) u += Elem<T>::ld(r2 + co + e);
+        Elem<T>::st(optr + co + e, u);
+      }
+    }
+  }
+}
 
 template <typename T> struct Frag;
 template <> struct Frag<float> { typedef f32x4 type; };
@@ -120,13 +167,13 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvP p) {
       }
       xr[g] = v;
     }
-    const T* wbase = (const T*)p.w + (size_t)tap_ * p.kpad + p.seg_koff[s_] + c0_;
+    const T* wbase = (const T*)p.w + (size_t)tap_ * p.ctot8 + p.seg_koff[s_] + c0_;
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       const int gi = tid + i * 256;
       if (gi < WGROUPS) {
         const int r = gi / (CONV_BK / G), kg = gi % (CONV_BK / G);
-        wr[i] = *(const uint4*)(wbase + (size_t)(co_base + r) * p.taps * p.kpad + kg * G);
+        wr[i] = *(const uint4*)(wbase + (size_t)(co_base + r) * p.krow + kg * G);
       }
     }
   };
@@ -200,58 +247,240 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvP p) {
     const int pn = pm / (p.H * p.W);
     const int pr = pm - pn * p.H * p.W;
     const int py = pr / p.W, px = pr - py * p.W;
-    T* optr = vptr<T>(p.out, pn, py, px);
-    const T* aptr = p.aux.p ? vptr<T>(p.aux, pn, py, px) : nullptr;
-    const T* r1 = p.res1.p ? vptr<T>(p.res1, pn, py, px) : nullptr;
-    const T* r2 = p.res2.p ? vptr<T>(p.res2, pn, py, px) : nullptr;
 #pragma unroll
-    for (int t = 0; t < NTC; ++t) {
-      const int co = co_base + t * 16 + (lane >> 4) * 4;
-      if (co >= p.Co) continue;
-      float v[4] = {acc[t][f][0], acc[t][f][1], acc[t][f][2], acc[t][f][3]};
-      const bool full = (co + 4 <= p.Co) && p.epi_vec;
-      if (full) {
-        if (p.bias) {
-          const float4 bb = *(const float4*)(p.bias + co);
-          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-        }
-        float t4[4];
-        if (aptr) {
-          ld4<T>(aptr + co, t4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= act_bwd(p.dact, t4[e]);
-        }
-        if (r1) {
-          ld4<T>(r1 + co, t4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += t4[e];
-        }
-        if (r2) {
-          ld4<T>(r2 + co, t4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += t4[e];
-        }
-        st4<T>(optr + co, v);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (co + e < p.Co) {
-            float u = v[e] + (p.bias ? p.bias[co + e] : 0.f);
-            if (aptr) u *= act_bwd(p.dact, Elem<T>::ld(aptr + co + e));
-            if (r1) u += Elem<T>::ld(r1 + co + e);
-            if (r2) u += Elem<T>::ld(r2 + co + e);
-            Elem<T>::st(optr + co + e, u);
-          }
-        }
-      }
-    }
+    for (int t = 0; t < NTC; ++t) conv_epilogue<T>(p, acc[t][f], pn, py, px, co_base + t * 16 + (lane >> 4) * 4);
   }
 }
 
 static inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
+// ----------------------------------------------------------------------------- halo-tiled kernel (H >= 8, W >= 16)
+// One workgroup = one 8x16 spatial tile of one image (4 waves, each 2 rows of 16 pixels).
+// The (8+2h)x(16+2h) input halo tile -- all segments concatenated, i.e. the reference's torch.cat materialised only in
+// LDS -- and the matching weight slab are staged ONCE per channel window; then the whole K axis
+//     K = (tap, channel) flattened with channels at 8-element granularity
+// runs out of LDS with no further barrier.  Each input element is fetched from HBM once per (tile, co-tile) instead of
+// KS*KS times, narrow inputs (Ci = 8, 16, 24) pack several taps into one 32-wide MFMA K-step instead of padding every tap
+// to 32, and LDS is sized at run time to the window so narrow layers keep 4-6 workgroups per CU in flight.
+#define TILE_H 8
+#define TILE_W 16
+
+struct TileP {
+  int tiles_x, tiles_y;
+  int cw;    // channel window per pass (multiple of 8; == ctot8 when everything fits in one pass)
+  int ldc;   // LDS row stride of the halo tile (elements)
+  int kp;    // K length of a pass, padded to the MFMA K-step
+  int ldw;   // LDS row stride of the weight slab (elements)
+};
+
+__device__ uint4 g_zero16[4];  // 64 bytes of zeros: DMA source for out-of-image / padding groups
+
+// in-register activation of one 16-byte group
+template <typename T>
+__device__ __forceinline__ uint4 act_group(uint4 v, int act) {
+  constexpr int G = 16 / sizeof(T);
+  Pack<T, G> tv;
+  tv.v4 = v;
+  if constexpr (sizeof(T) == 2) {
+    if (act == CGEN_ACT_RELU) {  // bf16 ReLU on packed pairs: clear every half whose sign bit is set
+      uint32_t* w = (uint32_t*)&tv.v4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] &= ~(((w[e] >> 15) & 0x00010001u) * 0xFFFFu);
+      return tv.v4;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < G; ++e) tv.e[e] = Elem<T>::to(act_fwd(act, Elem<T>::ld(&tv.e[e])));
+  return tv.v4;
+}
+
+template <typename T, int NTC, int KS>
+__global__ __launch_bounds__(256, 4) void conv_tile_kernel(ConvP p, TileP q) {
+  constexpr int G = 16 / sizeof(T);
+  constexpr int HALO = KS / 2, HH = TILE_H + 2 * HALO, HW = TILE_W + 2 * HALO, HPX = HH * HW;
+  constexpr int TAPS = KS * KS;
+  constexpr int WROWS = NTC * 16;
+  constexpr int KSTEP = sizeof(T) == 4 ? 16 : 32;
+  constexpr int GK = KSTEP / 4;  // K elements one lane contributes per K-step (f32: 4 via the j-trick, bf16: 8)
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // LDS image: [weight slab: WROWS rows of ldw] [halo tile: HPX rows of ldc], each region padded to whole 1-KiB pieces
+  const int wgroups = WROWS * (q.ldw / G), wpieces = (wgroups + 63) >> 6;
+  const int xgroups = HPX * (q.ldc / G), xpieces = (xgroups + 63) >> 6;
+  T* Ws = (T*)smem;
+  T* Xs = (T*)(smem + (size_t)wpieces * 1024);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int b = blockIdx.x;
+  const int tx = b % q.tiles_x; b /= q.tiles_x;
+  const int ty = b % q.tiles_y;
+  const int n = b / q.tiles_y;
+  const int y0 = ty * TILE_H, x0 = tx * TILE_W;
+  const int co_base = blockIdx.y * WROWS;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  f32x4 acc[NTC][2];
+#pragma unroll
+  for (int t = 0; t < NTC; ++t)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) acc[t][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int gpr_w = q.ldw / G, gpr_x = q.ldc / G;  // 16-byte groups per LDS row (incl. padding)
+  const bool single = q.cw == p.ctot8;
+
+  for (int cA = 0; cA < p.ctot8; cA += q.cw) {
+    const int cw = min(q.cw, p.ctot8 - cA);  // last window may be narrower (still a multiple of 8)
+    const int kend = TAPS * cw;
+    const int kreal = (kend + KSTEP - 1) / KSTEP * KSTEP;
+    if (cA > 0) __syncthreads();  // the previous pass's fragment reads are done
+    // ---- weights: LDS row [co][tap*cw + c'] <- image row [co][tap*ctot8 + cA + c']   (global -> LDS DMA, no VGPR staging)
+    for (int piece = wave; piece < wpieces; piece += 4) {
+      const int pu = __builtin_amdgcn_readfirstlane(piece);
+      const int gi = pu * 64 + lane;
+      const int r = gi / gpr_w, k = (gi - r * gpr_w) * G;
+      if (gi < wgroups && k < kreal) {
+        const T* row = (const T*)p.w + (size_t)(co_base + r) * p.krow;
+        const T* src;
+        if (single) {
+          src = row + k;
+        } else {
+          const int tap = k / cw, c = k - tap * cw;
+          src = tap < TAPS ? row + tap * p.ctot8 + cA + c : (const T*)g_zero16;
+        }
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(smem + (size_t)pu * 1024), 16, 0, 0);
+      }
+    }
+    // ---- halo tile: virtual concat of the segments; zeros outside the image / past a segment's channels
+    for (int piece = wave; piece < xpieces; piece += 4) {
+      const int pu = __builtin_amdgcn_readfirstlane(piece);
+      const int gi = pu * 64 + lane;
+      const int hp = gi / gpr_x, cl = (gi - hp * gpr_x) * G;  // channel inside the window
+      if (gi < xgroups && cl < cw) {
+        const int c = cA + cl;
+        const int yy = y0 + hp / HW - HALO, xx = x0 + hp % HW - HALO;
+        int sidx = 0;
+#pragma unroll
+        for (int k = 1; k < CGEN_MAX_SEG; ++k) sidx += (k < p.nseg && c >= p.seg_koff[k]) ? 1 : 0;
+        const View& sv = p.seg[sidx];
+        const int cs = c - p.seg_koff[sidx];
+        const bool inside = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && cs < sv.c;
+        char* dst = (char*)Xs + (size_t)pu * 1024;
+        if (!inside) {
+          __builtin_amdgcn_global_load_lds((gbl_ptr)g_zero16, (lds_ptr)dst, 16, 0, 0);
+        } else {
+          const T* src = vptr<T>(sv, n, yy, xx) + cs;
+          if (p.seg_vec[sidx] && cs + G <= sv.c) {
+            __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)dst, 16, 0, 0);
+          } else {  // ragged tail of a segment (channel count not a multiple of the group): guarded element loads
+            Pack<T, G> tmp;
+#pragma unroll
+            for (int e = 0; e < G; ++e) tmp.e[e] = (cs + e < sv.c) ? src[e] : (T)0;
+            *(uint4*)(dst + lane * 16) = tmp.v4;
+          }
+        }
+      }
+    }
+    __syncthreads();  // hipcc drains vmcnt (incl. the LDS DMA) before the barrier
+    if (p.act != CGEN_ACT_NONE) {  // activation once per element, in place (not once per tap at fragment-read time)
+      const int cgx = cw / G;
+      for (int gi = tid; gi < HPX * cgx; gi += 256) {
+        const int hp = gi / cgx;
+        uint4* ptr = (uint4*)(Xs + hp * q.ldc + (gi - hp * cgx) * G);
+        *ptr = act_group<T>(*ptr, p.act);
+      }
+      __syncthreads();
+    }
+
+    // ---- K loop over (tap, channel) of this window, incremental decode per lane group
+    const int kq = KSTEP / cw, krem = KSTEP - kq * cw;
+    int tap = (fg * GK) / cw, c = fg * GK - tap * cw;
+    const T* xb = Xs + ((wave * 2) * HW + fr) * q.ldc;
+    const T* wb = Ws + fr * q.ldw + fg * GK;
+    for (int k0 = 0; k0 < kend; k0 += KSTEP) {
+      const int tp = tap < TAPS ? tap : TAPS - 1;  // lanes past the last tap multiply zero weights; keep the address legal
+      const int off = ((tp / KS) * HW + (tp % KS)) * q.ldc + c;
+      if constexpr (sizeof(T) == 4) {
+        f32x4 bq[2], aq[NTC];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) bq[f] = *(const f32x4*)(xb + f * HW * q.ldc + off);
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) aq[t] = *(const f32x4*)(wb + t * 16 * q.ldw + k0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < NTC; ++t)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[t][j], bq[f][j], acc[t][f], 0, 0, 0);
+      } else {
+        bf16x8 bq[2], aq[NTC];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) bq[f] = *(const bf16x8*)(xb + f * HW * q.ldc + off);
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) aq[t] = *(const bf16x8*)(wb + t * 16 * q.ldw + k0);
+#pragma unroll
+        for (int t = 0; t < NTC; ++t)
+#pragma unroll
+          for (int f = 0; f < 2; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[t], bq[f], acc[t][f], 0, 0, 0);
+      }
+      tap += kq; c += krem;
+      if (c >= cw) { c -= cw; ++tap; }
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int py = y0 + wave * 2 + f, px = x0 + fr;
+    if (py >= p.H || px >= p.W) continue;
+#pragma unroll
+    for (int t = 0; t < NTC; ++t) conv_epilogue<T>(p, acc[t][f], n, py, px, co_base + t * 16 + fg * 4);
+  }
+}
+
+// LDS row strides: +8 elements (16 B bf16 / 32 B f32) keeps consecutive rows on distinct 16-byte bank slots
+static inline int lds_stride(int width, int esz) {
+  int s = width + 8;
+  if (((s * esz / 16) & 1) == 0) s += 16 / esz;  // make the stride an odd number of 16-byte slots
+  return s;
+}
+
+template <typename T, int KS>
+static bool launch_conv_tile(const ConvP& p, hipStream_t st) {
+  constexpr int HALO = KS / 2, HPX = (TILE_H + 2 * HALO) * (TILE_W + 2 * HALO), TAPS = KS * KS;
+  constexpr int esz = sizeof(T), G = 16 / esz, KSTEP = esz == 4 ? 16 : 32;
+  TileP q;
+  q.tiles_x = ceil_div(p.W, TILE_W); q.tiles_y = ceil_div(p.H, TILE_H);
+  const int ntiles = p.N * q.tiles_y * q.tiles_x;
+  int ntc = p.Co <= 16 ? 1 : (p.Co <= 32 ? 2 : 4);
+  if (ntiles < 512 && ntc > 1) ntc = ntiles < 192 ? 1 : 2;  // few tiles -> spread output channels over more workgroups
+  const int wrows = ntc * 16;
+  auto lds_bytes = [&](int cw, int& kp, int& ldc, int& ldw) {
+    kp = pad_to(TAPS * cw, KSTEP);
+    ldc = lds_stride(cw, esz); ldw = lds_stride(kp, esz);
+    const long wp = ((long)wrows * (ldw / G) + 63) / 64, xp = ((long)HPX * (ldc / G) + 63) / 64;
+    return (wp + xp) * 1024;
+  };
+  // widest channel window whose weight slab + halo tile fit the LDS budget (budget keeps >= 2 workgroups per CU)
+  const long budget = 64 * 1024;  // default dynamic-LDS limit; also keeps >= 2 workgroups per CU
+  int cw = p.ctot8;
+  long lds = 0;
+  for (;; cw -= 8) {
+    if (cw < 8) return false;
+    lds = lds_bytes(cw, q.kp, q.ldc, q.ldw);
+    if (lds <= budget) { q.cw = cw; break; }
+  }
+  dim3 block(256);
+  if (ntc == 1) hipLaunchKernelGGL((conv_tile_kernel<T, 1, KS>), dim3(ntiles, ceil_div(p.Co, 16)), block, lds, st, p, q);
+  else if (ntc == 2) hipLaunchKernelGGL((conv_tile_kernel<T, 2, KS>), dim3(ntiles, ceil_div(p.Co, 32)), block, lds, st, p, q);
+  else hipLaunchKernelGGL((conv_tile_kernel<T, 4, KS>), dim3(ntiles, ceil_div(p.Co, 64)), block, lds, st, p, q);
+  return true;
+}
+
 template <typename T>
 static int launch_conv(const ConvP& p, hipStream_t st) {
+  if ((p.KS == 1 || p.KS == 3) && p.H >= 8 && p.W >= 16 && !p.force_generic) {
+    const bool ok = p.KS == 3 ? launch_conv_tile<T, 3>(p, st) : launch_conv_tile<T, 1>(p, st);
+    if (ok) return check_launch("cgen_conv2d(tile)");
+  }
   dim3 block(256);
   const int px_tiles = ceil_div(p.P, CONV_PT);
   if (p.Co <= 16) {
@@ -463,28 +692,34 @@ static int launch_wgrad(const WgP& p, hipStream_t st) {
 #define MT_CHUNK 1024  // elements per block
 
 __global__ __launch_bounds__(256) void wprep_kernel(const cgen_wprep_desc* descs, const int* csite, const int* cidx) {
+  // image row r, column k:  k = tap * ctot8 + c  with c running over the segments at 8-channel granularity
   const cgen_wprep_desc d = descs[csite[blockIdx.x]];
   const int taps = d.ks * d.ks;
   const int64_t base = (int64_t)cidx[blockIdx.x] * MT_CHUNK;
+  int ctot8 = 0;
+  if (d.mode == 0) { for (int s = 0; s < d.nseg; ++s) ctot8 += (d.seg_c[s] + 7) & ~7; }
+  else ctot8 = (d.co + 7) & ~7;
   for (int i = threadIdx.x; i < MT_CHUNK; i += 256) {
     const int64_t o = base + i;
     if (o >= d.numel) break;
     const int k = (int)(o % d.k_pad);
-    const int tap = (int)((o / d.k_pad) % taps);
-    const int r = (int)(o / ((int64_t)d.k_pad * taps));
+    const int r = (int)(o / d.k_pad);
+    const int tap = k / ctot8, c = k - tap * ctot8;
     float v = 0.f;
-    if (d.mode == 0) {  // forward image: r = co, k -> (segment, channel)
-      if (r < d.co) {
-        int kk = k, off = 0, ci = -1;
-        for (int s = 0; s < d.nseg; ++s) {
-          const int cp = (d.seg_c[s] + 31) / 32 * 32;
-          if (kk < cp) { if (kk < d.seg_c[s]) ci = off + kk; break; }
-          kk -= cp; off += d.seg_c[s];
+    if (tap < taps) {
+      if (d.mode == 0) {  // forward image: r = co
+        if (r < d.co) {
+          int cc = c, off = 0, ci = -1;
+          for (int s = 0; s < d.nseg; ++s) {
+            const int c8 = (d.seg_c[s] + 7) & ~7;
+            if (cc < c8) { if (cc < d.seg_c[s]) ci = off + cc; break; }
+            cc -= c8; off += d.seg_c[s];
+          }
+          if (ci >= 0) v = d.src[((int64_t)r * d.ci_total + ci) * taps + tap];
         }
-        if (ci >= 0) v = d.src[((int64_t)r * d.ci_total + ci) * taps + tap];
+      } else {  // dgrad image of one segment: r = local ci, c = co, taps flipped
+        if (r < d.seg_c[0] && c < d.co) v = d.src[((int64_t)c * d.ci_total + d.seg_off + r) * taps + (taps - 1 - tap)];
       }
-    } else {  // dgrad image of one segment: r = local ci, k = co, taps flipped
-      if (r < d.seg_c[0] && k < d.co) v = d.src[((int64_t)k * d.ci_total + d.seg_off + r) * taps + (taps - 1 - tap)];
     }
     if (d.dtype == CGEN_F32) ((float*)d.dst)[o] = v; else ((bf16_t*)d.dst)[o] = f2bf(v);
   }
@@ -537,9 +772,11 @@ extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
     p.seg[s] = mk(a->seg[s]);
     p.seg_koff[s] = koff;
     p.seg_vec[s] = vec16_ok(a->seg[s], esz);
-    koff += pad_to(a->seg[s].c, 32);
+    koff += pad_to(a->seg[s].c, 8);
   }
-  p.kpad = koff;
+  for (int s = a->nseg; s < CGEN_MAX_SEG; ++s) p.seg_koff[s] = 1 << 30;
+  p.ctot8 = koff;
+  p.krow = pad_to(p.taps * koff, 32) + 32;
   p.w = a->weight; p.bias = a->bias;
   CGEN_REQUIRE(((uintptr_t)a->weight) % 16 == 0, "cgen_conv2d: weight image must be 16-byte aligned");
   p.out = mk(a->out); p.aux = mk(a->aux); p.res1 = mk(a->res1); p.res2 = mk(a->res2);
@@ -550,6 +787,7 @@ extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
     const int q = 4 * esz;
     return ((uintptr_t)v.p % q == 0) && ((v.sn * esz) % q == 0) && ((v.sh * esz) % q == 0) && ((v.sw * esz) % q == 0);
   };
+  p.force_generic = getenv("CGEN_CONV_GENERIC") != nullptr;
   p.epi_vec = epi_ok(a->out) && epi_ok(a->aux) && epi_ok(a->res1) && epi_ok(a->res2) && (!a->bias || ((uintptr_t)a->bias % 16 == 0));
   return a->dtype == CGEN_F32 ? launch_conv<float>(p, (hipStream_t)stream) : launch_conv<bf16_t>(p, (hipStream_t)stream);
 }

@@ -97,9 +97,11 @@ class ConvSite:
         self.seg_c, self.seg_rg = tuple(seg_c), tuple(seg_rg)
         self.seg_off = [sum(seg_c[:i]) for i in range(len(seg_c))]
         self.taps = self.ks * self.ks
-        self.kpad = sum(_ceil(c, 32) for c in seg_c)
-        self.fwd_numel = _ceil(self.co, 16) * self.taps * self.kpad
-        self.dg_numel = [(_ceil(c, 16) * self.taps * _ceil(self.co, 32)) if rg else 0 for c, rg in zip(seg_c, seg_rg)]
+        # weight images (include/cgen_hip.h): rows x krow, column = tap * C8 + channel, C8 = sum ceil8(C_s)
+        self.krow = _ceil(self.taps * sum(_ceil(c, 8) for c in seg_c), 32) + 32
+        self.krow_dg = _ceil(self.taps * _ceil(self.co, 8), 32) + 32
+        self.fwd_numel = _ceil(self.co, 16) * self.krow
+        self.dg_numel = [(_ceil(c, 16) * self.krow_dg) if rg else 0 for c, rg in zip(seg_c, seg_rg)]
         self.img_fwd = None   # device address
         self.img_dg = [None] * len(seg_c)
 
@@ -148,9 +150,12 @@ class Engine:
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
 
     def new(self, n, h, w, c, rg=True, es=None):
+        """Fresh NHWC tensor.  The pixel stride is rounded up to 8 channels so every pixel starts on a 16-byte
+        boundary (16-byte vector / LDS-DMA access needs it); the padding channels are never read as data."""
         es = self.es if es is None else es
-        ptr = self.arena.alloc(n * h * w * c * es)
-        return NT(ptr, n, h, w, c, h * w * c, w * c, c, es, rg=rg)
+        cp = _ceil(c, 8)
+        ptr = self.arena.alloc(n * h * w * cp * es)
+        return NT(ptr, n, h, w, c, h * w * cp, w * cp, cp, es, rg=rg)
 
     def new_f32(self, count):
         return self.arena.alloc(count * 4)
@@ -259,7 +264,7 @@ class Engine:
             d.co, d.ci_total, d.ks, d.mode, d.nseg, d.seg_off = s.co, s.ci, s.ks, 0, len(s.seg_c), 0
             for k, c in enumerate(s.seg_c):
                 d.seg_c[k] = c
-            d.dtype, d.rows_pad, d.k_pad, d.numel = self.dt, _ceil(s.co, 16), s.kpad, s.fwd_numel
+            d.dtype, d.rows_pad, d.k_pad, d.numel = self.dt, _ceil(s.co, 16), s.krow, s.fwd_numel
             descs.append(d)
             for k, c in enumerate(s.seg_c):
                 if not s.dg_numel[k]:
@@ -268,7 +273,7 @@ class Engine:
                 d.src, d.dst = w.data_ptr(), s.img_dg[k]
                 d.co, d.ci_total, d.ks, d.mode, d.nseg, d.seg_off = s.co, s.ci, s.ks, 1, 1, s.seg_off[k]
                 d.seg_c[0] = c
-                d.dtype, d.rows_pad, d.k_pad, d.numel = self.dt, _ceil(c, 16), _ceil(s.co, 32), s.dg_numel[k]
+                d.dtype, d.rows_pad, d.k_pad, d.numel = self.dt, _ceil(c, 16), s.krow_dg, s.dg_numel[k]
                 descs.append(d)
         for i, d in enumerate(descs):
             nch = (d.numel + self.CHUNK - 1) // self.CHUNK

@@ -52,7 +52,8 @@ const char* cgen_last_error(void);
  * (adds), :325-333 (likelihood heads), dmol.py:223.  The SAME entry point is the data-gradient kernel:
  * seg = grad_out, weight = the "dgrad image" from cgen_weight_prep, dact/aux = the forward activation and
  * its input, res1 = out (accumulate).  res1/res2 may alias out.
- * weight: image built by cgen_weight_prep: [ceil16(Co)][KS*KS][sum_s ceil32(C_s)] in `dtype`, zero padded. */
+ * weight: image built by cgen_weight_prep: [ceil16(Co)][krow], column k = tap * C8 + c with C8 = sum_s ceil8(C_s)
+ * (segments side by side at 8-channel granularity), krow = ceil32(KS*KS*C8) + 32, in `dtype`, zero padded. */
 typedef struct cgen_conv_args {
   int32_t dtype, n, h, w, ks, nseg, act, dact;
   cgen_view seg[CGEN_MAX_SEG];
@@ -84,8 +85,8 @@ typedef struct cgen_wprep_desc { /* OIHW f32 parameter -> forward image or dgrad
   int32_t co, ci_total, ks, mode; /* mode 0: fwd image, 1: dgrad image of segment [seg_off, seg_off+seg_c[0]) */
   int32_t nseg, seg_off;
   int32_t seg_c[CGEN_MAX_SEG];
-  int32_t dtype, rows_pad, k_pad, reserved;
-  int64_t numel; /* rows_pad * ks*ks * k_pad */
+  int32_t dtype, rows_pad, k_pad, reserved; /* k_pad = krow of the image */
+  int64_t numel; /* rows_pad * k_pad */
 } cgen_wprep_desc;
 int cgen_weight_prep(const cgen_wprep_desc* descs_dev, const int32_t* chunk_site_dev, const int32_t* chunk_index_dev,
                      int32_t nchunks, cgen_stream_t stream);

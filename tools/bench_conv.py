@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of single conv shapes through the C ABI (kernel-only time over many back-to-back launches).
+usage: python tools/bench_conv.py [dtype] [kind] ; kind in fwd|wgrad|all"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from causal_gen_amd import _lib
+from causal_gen_amd.engine import ConvSite, Engine
+
+SHAPES = [  # (N, res, seg channels, Co, ks)   ukbb192 trunk shapes at batch 32
+    (32, 192, [32], 8, 3), (32, 192, [8], 32, 3), (32, 96, [64], 16, 3), (32, 96, [16], 64, 3),
+    (32, 48, [96], 24, 3), (32, 48, [24], 96, 3), (32, 24, [128], 32, 3), (32, 24, [32], 128, 3),
+    (32, 12, [160], 40, 3), (32, 12, [40], 160, 3), (32, 6, [192], 48, 3), (32, 48, [96, 4, 96], 24, 3),
+    (32, 48, [16, 96], 96, 1), (32, 96, [16, 4], 64, 1),
+]
+
+
+def main():
+    dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+    kind = sys.argv[2] if len(sys.argv) > 2 else "fwd"
+    iters = int(os.environ.get("ITERS", "20"))
+    convs = [torch.nn.Conv2d(sum(s[2]), s[3], s[4], padding=s[4] // 2) for s in SHAPES]
+    eng = Engine("cuda", dtype)
+    holder = torch.nn.ModuleList(convs).cuda()
+    sites = [ConvSite(f"c{i}", c, s[2], [True] * len(s[2]), i) for i, (c, s) in enumerate(zip(holder, SHAPES))]
+    eng.bind(holder, sites)
+    es = eng.es
+    for site, (N, R, segc, Co, ks) in zip(sites, SHAPES):
+        eng.begin()
+        eng.prepare_weights(force=True)
+        xs = [eng.new(N, R, R, c) for c in segc]
+        for x in xs:
+            eng.lib.philox_normal  # noqa
+            eng.fill(x, 0.5)
+        torch.cuda.synchronize()
+        flops = 2.0 * sum(segc) * ks * ks * Co * N * R * R
+        bytes_alg = N * R * R * (sum(segc) + Co) * es
+        res = {}
+        if kind in ("fwd", "all"):
+            y = eng.conv(site, xs, 1)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                eng.conv(site, xs, 1, out=y)
+            e1.record()
+            torch.cuda.synchronize()
+            res["fwd"] = e0.elapsed_time(e1) * 1e3 / iters
+        if kind in ("wgrad", "all"):
+            g = eng.new(N, R, R, Co)
+            eng.fill(g, 0.25)
+            eng._wg_events = []
+            eng._wgrad(site, xs, 1, g)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                eng._wg_events = []
+                eng._wgrad(site, xs, 1, g)
+            e1.record()
+            torch.cuda.synchronize()
+            res["wgrad"] = e0.elapsed_time(e1) * 1e3 / iters
+        for k, us in res.items():
+            print("%-5s %s N%d res%-3d ci%-12s co%-3d ks%d : %8.1f us  %7.1f TF/s  %6.2f TB/s(alg)" % (
+                k, dtype, N, R, str(segc), Co, ks, us, flops / us / 1e6, bytes_alg / us / 1e6))
+
+
+if __name__ == "__main__":
+    main()
