@@ -12,7 +12,7 @@ MAX_SEG = 4
 
 class View(C.Structure):
     _fields_ = [("p", C.c_void_p), ("sn", C.c_int64), ("sh", C.c_int64), ("sw", C.c_int64), ("c", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("cpad", C.c_int32)]
 
 
 NULL_VIEW = View(None, 0, 0, 0, 0, 0)
@@ -58,7 +58,7 @@ PROTOTYPES = {
     "cgen_version": [],
     "cgen_last_error": [],
     "cgen_conv2d": [C.POINTER(ConvArgs), vp],
-    "cgen_conv2d_wgrad_splits": [i32, i32, i32, i32, i32, i32],
+    "cgen_conv2d_wgrad_plan": [C.POINTER(WgradArgs), C.POINTER(i32)],
     "cgen_conv2d_wgrad": [C.POINTER(WgradArgs), vp],
     "cgen_weight_prep": [vp, vp, vp, i32, vp],
     "cgen_wgrad_reduce": [vp, vp, vp, i32, vp],
@@ -94,7 +94,7 @@ PROTOTYPES = {
     "cgen_rng_advance": [vp, u64, vp],
 }
 _RESTYPES = {"cgen_last_error": C.c_char_p}
-_NOCHECK = {"cgen_version", "cgen_last_error", "cgen_conv2d_wgrad_splits", "cgen_reparam_kl_chunks", "cgen_like_chunks"}
+_NOCHECK = {"cgen_version", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks"}
 
 
 class CgenError(RuntimeError):

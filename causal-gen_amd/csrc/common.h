@@ -46,12 +46,14 @@ struct View {  // device-side mirror of cgen_view with typed access
   char* p;
   int64_t sn, sh, sw;
   int c;
+  int cpad;
 };
 static inline View mk(const cgen_view& v) {
   View o;
-  o.p = (char*)v.p; o.sn = v.sn; o.sh = v.sh; o.sw = v.sw; o.c = v.c;
+  o.p = (char*)v.p; o.sn = v.sn; o.sh = v.sh; o.sw = v.sw; o.c = v.c; o.cpad = v.cpad;
   return o;
 }
+
 template <typename T>
 __device__ __forceinline__ T* vptr(const View& v, int n, int y, int x) {
   return (T*)v.p + (n * v.sn + y * v.sh + x * v.sw);
@@ -60,6 +62,13 @@ __device__ __forceinline__ T* vptr(const View& v, int n, int y, int x) {
 static inline bool vec16_ok(const cgen_view& v, int esz) {
   if (!v.p) return true;
   return (((uintptr_t)v.p) % 16 == 0) && ((v.sn * esz) % 16 == 0) && ((v.sh * esz) % 16 == 0) && ((v.sw * esz) % 16 == 0);
+}
+// every 16-byte channel group of the view can be fetched whole (LDS-DMA): aligned, and the channel count is a multiple
+// of the group or the caller vouches for zero padding up to the next multiple
+static inline bool dma_clean(const cgen_view& v, int esz) {
+  const int G = 16 / esz;
+  const int cg = (v.c + G - 1) / G * G;
+  return vec16_ok(v, esz) && (v.c % G == 0 || v.cpad >= cg);
 }
 
 // ----------------------------------------------------------------------------- activations (vae.py:50,59)

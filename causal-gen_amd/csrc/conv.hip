@@ -16,6 +16,27 @@ namespace cgen {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Division by a run-time constant without v_rcp/loops: q = umulhi(n, mul) >> shift, exact for 0 <= n < 2^31
+// (round-up method: mul = ceil(2^(32+shift) / d)).  Built on the host, used in the per-lane address generation.
+struct FastDiv {
+  uint32_t mul, shift, d, pad;
+};
+static inline FastDiv mk_fastdiv(uint32_t d) {
+  FastDiv f;
+  f.d = d; f.pad = 0;
+  if (d == 1) { f.mul = 0; f.shift = 0; return f; }
+  uint32_t sh = 0;
+  while ((1u << sh) < d) ++sh;  // ceil(log2 d)
+  f.shift = sh;
+  f.mul = (uint32_t)((((uint64_t)1 << (32 + sh)) + d - 1) / d - ((uint64_t)1 << 32));
+  return f;
+}
+// q = (umulhi(n, mul) + n) >> shift   (the "add" variant keeps mul in 32 bits)
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+  if (f.d == 1) return n;
+  return (int)(((uint64_t)__umulhi((uint32_t)n, f.mul) + (uint32_t)n) >> f.shift);
+}
+
 #define CONV_PT 128  // pixels per workgroup
 #define CONV_BK 32   // K per step
 #define CONV_LDK 40  // LDS row stride in elements (bank-conflict-free 16B fragment reads)
@@ -28,7 +49,7 @@ struct ConvP {
   const void* w;
   const float* bias;
   View out, aux, res1, res2;
-  int epi_vec, force_generic;
+  int epi_vec, force_generic, dma_ok;
 };
 
 // 4-element (16B f32 / 8B bf16) vector access
@@ -271,6 +292,7 @@ struct TileP {
   int ldc;   // LDS row stride of the halo tile (elements)
   int kp;    // K length of a pass, padded to the MFMA K-step
   int ldw;   // LDS row stride of the weight slab (elements)
+  FastDiv d_gprw, d_gprx, d_cw;
 };
 
 __device__ uint4 g_zero16[4];  // 64 bytes of zeros: DMA source for out-of-image / padding groups
@@ -338,14 +360,14 @@ __global__ __launch_bounds__(256, 4) void conv_tile_kernel(ConvP p, TileP q) {
     for (int piece = wave; piece < wpieces; piece += 4) {
       const int pu = __builtin_amdgcn_readfirstlane(piece);
       const int gi = pu * 64 + lane;
-      const int r = gi / gpr_w, k = (gi - r * gpr_w) * G;
+      const int r = fdiv(gi, q.d_gprw), k = (gi - r * gpr_w) * G;
       if (gi < wgroups && k < kreal) {
         const T* row = (const T*)p.w + (size_t)(co_base + r) * p.krow;
         const T* src;
         if (single) {
           src = row + k;
         } else {
-          const int tap = k / cw, c = k - tap * cw;
+          const int tap = cw == q.cw ? fdiv(k, q.d_cw) : k / cw, c = k - tap * cw;
           src = tap < TAPS ? row + tap * p.ctot8 + cA + c : (const T*)g_zero16;
         }
         __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(smem + (size_t)pu * 1024), 16, 0, 0);
@@ -355,39 +377,39 @@ __global__ __launch_bounds__(256, 4) void conv_tile_kernel(ConvP p, TileP q) {
     for (int piece = wave; piece < xpieces; piece += 4) {
       const int pu = __builtin_amdgcn_readfirstlane(piece);
       const int gi = pu * 64 + lane;
-      const int hp = gi / gpr_x, cl = (gi - hp * gpr_x) * G;  // channel inside the window
+      const int hp = fdiv(gi, q.d_gprx), cl = (gi - hp * gpr_x) * G;  // channel inside the window
       if (gi < xgroups && cl < cw) {
         const int c = cA + cl;
         const int yy = y0 + hp / HW - HALO, xx = x0 + hp % HW - HALO;
         int sidx = 0;
 #pragma unroll
         for (int k = 1; k < CGEN_MAX_SEG; ++k) sidx += (k < p.nseg && c >= p.seg_koff[k]) ? 1 : 0;
-        const View& sv = p.seg[sidx];
-        const int cs = c - p.seg_koff[sidx];
+        View sv = p.seg[0];
+        int koff = p.seg_koff[0];
+#pragma unroll
+        for (int k = 1; k < CGEN_MAX_SEG; ++k)
+          if (sidx == k) { sv = p.seg[k]; koff = p.seg_koff[k]; }
+        const int cs = c - koff;
         const bool inside = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W && cs < sv.c;
         char* dst = (char*)Xs + (size_t)pu * 1024;
-        if (!inside) {
-          __builtin_amdgcn_global_load_lds((gbl_ptr)g_zero16, (lds_ptr)dst, 16, 0, 0);
-        } else {
-          const T* src = vptr<T>(sv, n, yy, xx) + cs;
-          if (p.seg_vec[sidx] && cs + G <= sv.c) {
-            __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)dst, 16, 0, 0);
-          } else {  // ragged tail of a segment (channel count not a multiple of the group): guarded element loads
-            Pack<T, G> tmp;
-#pragma unroll
-            for (int e = 0; e < G; ++e) tmp.e[e] = (cs + e < sv.c) ? src[e] : (T)0;
-            *(uint4*)(dst + lane * 16) = tmp.v4;
-          }
-        }
+        // no LDS store may sit between the DMAs (hipcc would drain vmcnt before it and serialise them): the host only
+        // selects this kernel for dma_clean() segments, so every group is a whole 16-byte fetch or zeros
+        const T* src = inside ? vptr<T>(sv, n, yy, xx) + cs : (const T*)g_zero16;
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)dst, 16, 0, 0);
       }
     }
     __syncthreads();  // hipcc drains vmcnt (incl. the LDS DMA) before the barrier
     if (p.act != CGEN_ACT_NONE) {  // activation once per element, in place (not once per tap at fragment-read time)
-      const int cgx = cw / G;
-      for (int gi = tid; gi < HPX * cgx; gi += 256) {
-        const int hp = gi / cgx;
-        uint4* ptr = (uint4*)(Xs + hp * q.ldc + (gi - hp * cgx) * G);
-        *ptr = act_group<T>(*ptr, p.act);
+      const int rstep = fdiv(256, q.d_gprx), cstep = 256 - rstep * gpr_x;
+      int rr = fdiv(tid, q.d_gprx), cc = tid - rr * gpr_x;
+#pragma unroll 1
+      while (rr < HPX) {
+        if (cc * G < cw) {
+          uint4* ptr = (uint4*)(Xs + rr * q.ldc + cc * G);
+          *ptr = act_group<T>(*ptr, p.act);
+        }
+        rr += rstep; cc += cstep;
+        if (cc >= gpr_x) { cc -= gpr_x; ++rr; }
       }
       __syncthreads();
     }
@@ -468,6 +490,7 @@ static bool launch_conv_tile(const ConvP& p, hipStream_t st) {
     lds = lds_bytes(cw, q.kp, q.ldc, q.ldw);
     if (lds <= budget) { q.cw = cw; break; }
   }
+  q.d_gprw = mk_fastdiv(q.ldw / G); q.d_gprx = mk_fastdiv(q.ldc / G); q.d_cw = mk_fastdiv(q.cw);
   dim3 block(256);
   if (ntc == 1) hipLaunchKernelGGL((conv_tile_kernel<T, 1, KS>), dim3(ntiles, ceil_div(p.Co, 16)), block, lds, st, p, q);
   else if (ntc == 2) hipLaunchKernelGGL((conv_tile_kernel<T, 2, KS>), dim3(ntiles, ceil_div(p.Co, 32)), block, lds, st, p, q);
@@ -477,7 +500,7 @@ static bool launch_conv_tile(const ConvP& p, hipStream_t st) {
 
 template <typename T>
 static int launch_conv(const ConvP& p, hipStream_t st) {
-  if ((p.KS == 1 || p.KS == 3) && p.H >= 8 && p.W >= 16 && !p.force_generic) {
+  if ((p.KS == 1 || p.KS == 3) && p.H >= 8 && p.W >= 16 && !p.force_generic && p.dma_ok) {
     const bool ok = p.KS == 3 ? launch_conv_tile<T, 3>(p, st) : launch_conv_tile<T, 1>(p, st);
     if (ok) return check_launch("cgen_conv2d(tile)");
   }
@@ -665,6 +688,306 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
   if (p.pb && chunk == 0 && tg == 0 && tid < COT && co_base + tid < p.Co) p.pb[(size_t)sp * p.Co + co_base + tid] = bsum;
 }
 
+// ============================================================================= weight gradient, tiled / streaming (bf16)
+// dW[co][tap][ci] = sum_px G[px][co] * act(X)[px + tap][ci] with the PIXEL axis as the MFMA K dimension.
+// Both operands live in HBM with channels contiguous, so K (pixels) is strided: the fragments are assembled with the
+// gfx950 LDS transpose read ds_read_b64_tr_b16 (4 pixels x 16 channels -> each lane gets 4 consecutive-K values of its
+// channel) straight from NHWC tiles in LDS -- no explicit transposes.
+// A persistent workgroup owns the whole [16*NCF co] x [taps x cwin ci] gradient slab in MFMA accumulators
+// (output-stationary) and streams 8x16 pixel tiles through LDS by global->LDS DMA: every activation / gradient element
+// is read from HBM exactly once per (co range, ci window).  2 workgroups per CU: one's DMA wait overlaps the other's MFMAs.
+//
+// LDS pixel-tile layout ("row pieces"): a tile row is cut into 1-KiB pieces of `ppp` pixels x `gpr` 16-byte groups
+// (gpr odd => conflict-free fragment reads).  One wave-wide DMA instruction fills one piece, so everything about a piece
+// except a per-lane constant is wave-uniform: the per-tile address generation is a few SALU ops + ~6 VALU per piece.
+#define WG2_MAXACC 24  // accumulator fragments per wave (96 VGPRs)
+
+struct PixTile {
+  int gpr, ppp, ppr, rows, npx, rowbytes, bytes, pad;
+  FastDiv d_gpr, d_ppr;
+};
+static inline PixTile mk_pixtile(int width_elems, int esz, int rows, int npx) {
+  PixTile t;
+  int gpr = (width_elems * esz + 15) / 16 + 1;
+  if ((gpr & 1) == 0) ++gpr;
+  t.gpr = gpr; t.ppp = 64 / gpr; t.rows = rows; t.npx = npx;
+  t.ppr = (npx + t.ppp - 1) / t.ppp;
+  t.rowbytes = t.ppr * 1024; t.bytes = rows * t.rowbytes; t.pad = 0;
+  t.d_gpr = mk_fastdiv(gpr); t.d_ppr = mk_fastdiv(t.ppr);
+  return t;
+}
+// byte offset of pixel (row, x) inside a PixTile
+__device__ __forceinline__ int pix_off(const PixTile& t, int row, int x) {
+  const int pc = x / t.ppp;
+  return row * t.rowbytes + pc * 1024 + (x - pc * t.ppp) * t.gpr * 16;
+}
+
+struct Wg2P {
+  int N, H, W, KS, nseg, act, Co, taps, ci_total, ctot8;
+  View seg[CGEN_MAX_SEG];
+  int seg_koff[CGEN_MAX_SEG];  // 8-granular concat offsets
+  int seg_off[CGEN_MAX_SEG];   // real channel offsets in the OIHW gradient
+  View gout;
+  float* pw;
+  float* pb;
+  int tiles_x, tiles_y, ntiles, nsplit, tiles_per_split;
+  int cwin, cog;  // channel window, co columns staged per workgroup (16*NCF)
+  PixTile xt, gt;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p1);
+  union { s16x4 h[2]; bf16x8 v; } u;
+  u.h[0] = lo; u.h[1] = hi;
+  return u.v;
+}
+
+template <int NCF, int NJW, int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
+  typedef bf16_t T;
+  constexpr int G = 8;
+  constexpr int HALO = KS / 2, HH = TILE_H + 2 * HALO, HW = TILE_W + 2 * HALO;
+  constexpr int TAPS = KS * KS;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xb = smem;
+  char* Gb = smem + p.xt.bytes;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sp = blockIdx.x;
+  const int cA = blockIdx.y * p.cwin;
+  const int cw = min(p.cwin, p.ctot8 - cA);      // multiple of 8
+  const int cw16 = (cw + 15) & ~15;
+  const int cgrp = cw16 >> 4;
+  const int njf = TAPS * cgrp;                   // (tap, 16-channel group) fragments of this window
+  const int co_base = blockIdx.z * (NCF * 16);
+  const int t_begin = sp * p.tiles_per_split, t_end = min(p.ntiles, t_begin + p.tiles_per_split);
+
+  f32x4 acc[NCF][NJW];
+  f32x4 accb[NCF];
+#pragma unroll
+  for (int a = 0; a < NCF; ++a) {
+    accb[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NJW; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = p.pb != nullptr && blockIdx.y == 0 && wave == 0;
+
+  // ---- per-lane DMA constants (identical for every piece of every tile)
+  // activation tile: lane -> (pixel xl inside the piece, channel group) -> segment / channel / element offset
+  const int xl = fdiv(lane, p.xt.d_gpr), xcg = lane - xl * p.xt.gpr;
+  int x_si = 0, x_off = 0;
+  bool x_lane = xl < p.xt.ppp && xcg * G < cw16, x_data = false;
+  {
+    const int c = cA + xcg * G;
+#pragma unroll
+    for (int k = 1; k < CGEN_MAX_SEG; ++k) x_si += (k < p.nseg && c >= p.seg_koff[k]) ? 1 : 0;
+    View sv = p.seg[0];
+    int koff = p.seg_koff[0];
+#pragma unroll
+    for (int k = 1; k < CGEN_MAX_SEG; ++k)
+      if (x_si == k) { sv = p.seg[k]; koff = p.seg_koff[k]; }
+    const int cs = c - koff;
+    x_data = x_lane && xcg * G < cw && cs < sv.c;
+    x_off = (int)(xl * sv.sw) + cs;
+  }
+  // gradient tile
+  const int gl = fdiv(lane, p.gt.d_gpr), gcg = lane - gl * p.gt.gpr;
+  const bool g_lane = gl < p.gt.ppp && gcg * G < p.cog;
+  const bool g_data = g_lane && co_base + gcg * G < p.Co;
+  const int g_off = (int)(gl * p.gout.sw) + co_base + gcg * G;
+  const int xpieces = p.xt.rows * p.xt.ppr, gpieces = p.gt.rows * p.gt.ppr;
+
+  auto issue_tile = [&](int t) {
+    int b = t;
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y;
+    const int n = b / p.tiles_y;
+    const int y0 = ty * TILE_H, x0 = tx * TILE_W;
+    const T* org0 = vptr<T>(p.seg[0], n, y0 - HALO, x0 - HALO);
+    const T* org1 = p.nseg > 1 ? vptr<T>(p.seg[1], n, y0 - HALO, x0 - HALO) : org0;
+    const T* org2 = p.nseg > 2 ? vptr<T>(p.seg[2], n, y0 - HALO, x0 - HALO) : org0;
+    const T* org3 = p.nseg > 3 ? vptr<T>(p.seg[3], n, y0 - HALO, x0 - HALO) : org0;
+    const T* my_org = org0;  // this lane's segment
+    int64_t my_sh = p.seg[0].sh, my_swp = p.seg[0].sw * p.xt.ppp;
+    if (p.nseg > 1) {
+      if (x_si == 1) { my_org = org1; my_sh = p.seg[1].sh; my_swp = p.seg[1].sw * p.xt.ppp; }
+      if (x_si == 2) { my_org = org2; my_sh = p.seg[2].sh; my_swp = p.seg[2].sw * p.xt.ppp; }
+      if (x_si == 3) { my_org = org3; my_sh = p.seg[3].sh; my_swp = p.seg[3].sw * p.xt.ppp; }
+    }
+    my_org += x_off;
+    for (int pi = wave; pi < xpieces; pi += 4) {
+      const int pu = __builtin_amdgcn_readfirstlane(pi);
+      const int hy = fdiv(pu, p.xt.d_ppr), pc = pu - hy * p.xt.ppr;
+      if (x_lane) {
+        const int hx = pc * p.xt.ppp + xl;
+        const int yy = y0 - HALO + hy, xx = x0 - HALO + hx;
+        const bool ok = x_data && hx < HW && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        const T* src = ok ? my_org + (hy * my_sh + pc * my_swp) : (const T*)g_zero16;
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Xb + pu * 1024), 16, 0, 0);  // never an LDS store between DMAs
+      }
+    }
+    const T* orgg = vptr<T>(p.gout, n, y0, x0) + g_off;
+    const int64_t g_swp = p.gout.sw * p.gt.ppp;
+    for (int pi = wave; pi < gpieces; pi += 4) {
+      const int pu = __builtin_amdgcn_readfirstlane(pi);
+      const int py = fdiv(pu, p.gt.d_ppr), pc = pu - py * p.gt.ppr;
+      if (g_lane) {
+        const int pxx = pc * p.gt.ppp + gl;
+        const bool ok = g_data && pxx < TILE_W && y0 + py < p.H && x0 + pxx < p.W;
+        const T* src = ok ? orgg + (py * p.gout.sh + pc * g_swp) : (const T*)g_zero16;
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Gb + pu * 1024), 16, 0, 0);
+      }
+    }
+  };
+  // in-place activation of the staged halo tile: every lane re-visits the groups it DMA'd (same piece mapping)
+  auto act_pass = [&]() {
+    if (!x_data) return;
+    for (int pi = wave; pi < xpieces; pi += 4) {
+      uint4* ptr = (uint4*)(Xb + pi * 1024 + lane * 16);
+      *ptr = act_group<T>(*ptr, p.act);
+    }
+  };
+
+  // lane geometry of the transpose reads: group g = k-block, t = 4r + q supplies (pixel r of the read, channels 4q..4q+3)
+  const int g = lane >> 4, t16 = lane & 15, r = t16 >> 2, qd = t16 & 3;
+  const int krow = g >> 1, kx = (g & 1) * 8 + r;  // this lane's FIRST read inside a 2-row K-step: pixel (row, x); second: x + 4
+  // tile-independent LDS byte offsets of this lane's two reads per (tap, channel group) fragment
+  int xo0[NJW], xo1[NJW];
+#pragma unroll
+  for (int j = 0; j < NJW; ++j) {
+    const int jf = wave + 4 * j;
+    const int tap = jf / cgrp, cb = (jf - tap * cgrp) * 16;
+    const int dy = tap / KS, dx = tap % KS;
+    xo0[j] = pix_off(p.xt, krow + dy, kx + dx) + (cb + qd * 4) * 2;
+    xo1[j] = pix_off(p.xt, krow + dy, kx + dx + 4) + (cb + qd * 4) * 2;
+  }
+  const int nj_wave = njf > wave ? (njf - wave + 3) >> 2 : 0;
+  const int go0 = pix_off(p.gt, krow, kx) + qd * 8, go1 = pix_off(p.gt, krow, kx + 4) + qd * 8;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+
+  for (int t = t_begin; t < t_end; ++t) {
+    issue_tile(t);
+    __syncthreads();  // hipcc waits vmcnt(0) here: the tile has landed
+    if (p.act != CGEN_ACT_NONE) {
+      act_pass();
+      __syncthreads();
+    }
+#pragma unroll
+    for (int ks = 0; ks < TILE_H / 2; ++ks) {
+      bf16x8 af[NCF];
+      const char* gk = Gb + ks * 2 * p.gt.rowbytes;
+#pragma unroll
+      for (int a = 0; a < NCF; ++a) af[a] = tr_pair(gk + go0 + a * 32, gk + go1 + a * 32);
+      if (do_bias) {
+#pragma unroll
+        for (int a = 0; a < NCF; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, accb[a], 0, 0, 0);
+      }
+      const char* xk = Xb + ks * 2 * p.xt.rowbytes;
+#pragma unroll
+      for (int j = 0; j < NJW; ++j) {
+        if (j < nj_wave) {
+          const bf16x8 bfv = tr_pair(xk + xo0[j], xk + xo1[j]);
+#pragma unroll
+          for (int a = 0; a < NCF; ++a) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfv, acc[a][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // everyone is done with the buffers before the next tile's DMA overwrites them
+  }
+
+  // ---- write the partial slab: D[i = co][j = ci]: lane holds column j = lane&15, rows (lane>>4)*4 + e
+#pragma unroll
+  for (int j = 0; j < NJW; ++j) {
+    const int jf = wave + 4 * j;
+    if (jf < njf) {
+      const int tap = jf / cgrp, c = cA + (jf - tap * cgrp) * 16 + (lane & 15);
+      int sidx = 0;
+#pragma unroll
+      for (int k = 1; k < CGEN_MAX_SEG; ++k) sidx += (k < p.nseg && c >= p.seg_koff[k]) ? 1 : 0;
+      int koff = p.seg_koff[0], segc = p.seg[0].c, soff = p.seg_off[0];
+#pragma unroll
+      for (int k = 1; k < CGEN_MAX_SEG; ++k)
+        if (sidx == k) { koff = p.seg_koff[k]; segc = p.seg[k].c; soff = p.seg_off[k]; }
+      const int cs = c - koff;
+      if (c < cA + cw && cs < segc) {
+#pragma unroll
+        for (int a = 0; a < NCF; ++a)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int co = co_base + a * 16 + (lane >> 4) * 4 + e;
+            if (co < p.Co) p.pw[(((size_t)sp * p.Co + co) * TAPS + tap) * p.ci_total + soff + cs] = acc[a][j][e];
+          }
+      }
+    }
+  }
+  if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+    for (int a = 0; a < NCF; ++a)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int co = co_base + a * 16 + (lane >> 4) * 4 + e;
+        if (co < p.Co) p.pb[(size_t)sp * p.Co + co] = accb[a][e];
+      }
+  }
+}
+
+struct Wg2Geom { int ncf, njw, cwin, nsplit, tps, ntiles, tiles_x, tiles_y, n_cwin, n_co; PixTile xt, gt; size_t lds; };
+
+// returns false when the shape is not served by the tiled kernel
+static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2Geom& g) {
+  if (!(ks == 1 || ks == 3) || H < 8 || W < 16) return false;
+  const int taps = ks * ks;
+  const int halo = ks / 2;
+  g.ncf = co <= 16 ? 1 : (co <= 32 ? 2 : (co <= 64 ? 4 : (co <= 96 ? 6 : 8)));
+  g.njw = g.ncf == 1 ? 16 : WG2_MAXACC / g.ncf;
+  g.n_co = ceil_div(co, g.ncf * 16);
+  int maxgrp = (4 * g.njw) / taps;  // 16-channel groups per window that fit the accumulators
+  if (maxgrp < 1) return false;
+  int cwin = maxgrp * 16;
+  const int c16 = pad_to(ctot8, 16);
+  if (cwin > c16) cwin = c16;
+  g.gt = mk_pixtile(g.ncf * 16, 2, TILE_H, TILE_W);
+  for (;; cwin -= 16) {  // LDS budget: two workgroups per CU
+    if (cwin < 16) return false;
+    g.xt = mk_pixtile(cwin, 2, TILE_H + 2 * halo, TILE_W + 2 * halo);
+    if (g.xt.ppp >= 1 && g.xt.bytes + g.gt.bytes <= 78 * 1024) break;
+  }
+  if (g.gt.ppp < 1) return false;
+  g.lds = (size_t)g.xt.bytes + g.gt.bytes;
+  g.cwin = cwin;
+  g.n_cwin = ceil_div(ctot8, cwin);
+  g.tiles_x = ceil_div(W, TILE_W); g.tiles_y = ceil_div(H, TILE_H);
+  g.ntiles = N * g.tiles_x * g.tiles_y;
+  int want = ceil_div(512, g.n_cwin * g.n_co);  // two persistent workgroups per CU
+  if (want < 1) want = 1;
+  g.tps = ceil_div(g.ntiles, want);
+  if (g.tps < 2 && g.ntiles >= 2) g.tps = 2;
+  g.nsplit = ceil_div(g.ntiles, g.tps);
+  return true;
+}
+
+template <int NCF, int NJW>
+static void launch_wgrad2_ks(const Wg2P& p, const Wg2Geom& g, hipStream_t st) {
+  dim3 grid(g.nsplit, g.n_cwin, g.n_co), block(256);
+  if (p.KS == 3) {
+    static bool once3 = false;
+    if (!once3) { (void)hipFuncSetAttribute((const void*)wgrad_tile_kernel<NCF, NJW, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once3 = true; }
+    hipLaunchKernelGGL((wgrad_tile_kernel<NCF, NJW, 3>), grid, block, g.lds, st, p);
+  } else {
+    static bool once1 = false;
+    if (!once1) { (void)hipFuncSetAttribute((const void*)wgrad_tile_kernel<NCF, NJW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once1 = true; }
+    hipLaunchKernelGGL((wgrad_tile_kernel<NCF, NJW, 1>), grid, block, g.lds, st, p);
+  }
+}
+
 static inline int wgrad_ntc(int co) { return co <= 16 ? 1 : (co <= 32 ? 2 : 4); }
 
 static void wgrad_geometry(int P, int co, int ci_chunks, int ks, int& nsplit, int& pps) {
@@ -775,6 +1098,8 @@ extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
     koff += pad_to(a->seg[s].c, 8);
   }
   for (int s = a->nseg; s < CGEN_MAX_SEG; ++s) p.seg_koff[s] = 1 << 30;
+  p.dma_ok = 1;
+  for (int s = 0; s < a->nseg; ++s) p.dma_ok = p.dma_ok && dma_clean(a->seg[s], esz);
   p.ctot8 = koff;
   p.krow = pad_to(p.taps * koff, 32) + 32;
   p.w = a->weight; p.bias = a->bias;
@@ -798,10 +1123,36 @@ static int count_chunks(const cgen_view* seg, int nseg) {
   return c;
 }
 
-extern "C" int cgen_conv2d_wgrad_splits(int32_t n, int32_t h, int32_t w, int32_t co, int32_t ci_total, int32_t ks) {
-  // conservative: chunk count of a single-segment input (more segments only add tiles => fewer splits needed)
+static int ctot8_of(const int32_t* seg_c, int nseg) {
+  int c = 0;
+  for (int s = 0; s < nseg; ++s) c += pad_to(seg_c[s], 8);
+  return c;
+}
+
+// can the streaming tiled kernel serve this call?
+static bool wgrad_tiled_ok(const cgen_wgrad_args* a, Wg2Geom& g) {
+  if (a->dtype != CGEN_BF16 || getenv("CGEN_WGRAD_GENERIC")) return false;
+  if (!dma_clean(a->gout, 2)) return false;
+  int segc[CGEN_MAX_SEG];
+  for (int s = 0; s < a->nseg; ++s) {
+    if (!dma_clean(a->seg[s], 2)) return false;
+    segc[s] = a->seg[s].c;
+  }
+  return wgrad2_geometry(a->n, a->h, a->w, a->gout.c, ctot8_of(segc, a->nseg), a->ks, g);
+}
+
+extern "C" int cgen_conv2d_wgrad_plan(const cgen_wgrad_args* a, int32_t* tiled_out) {
+  if (!a || a->nseg < 1 || a->nseg > CGEN_MAX_SEG) return 0;
+  Wg2Geom g;
+  if (wgrad_tiled_ok(a, g)) {
+    if (tiled_out) *tiled_out = 1;
+    return g.nsplit;
+  }
+  if (tiled_out) *tiled_out = 0;
+  int ci_total = 0;
+  for (int s = 0; s < a->nseg; ++s) ci_total += a->seg[s].c;
   int nsplit, pps;
-  wgrad_geometry(n * h * w, co, (ci_total + 31) / 32, ks, nsplit, pps);
+  wgrad_geometry(a->n * a->h * a->w, a->gout.c, (ci_total + 31) / 32, a->ks, nsplit, pps);
   return nsplit;
 }
 
@@ -827,6 +1178,38 @@ extern "C" int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream)
   p.ci_total = off;
   p.n_cichunks = ch;
   p.n_tapgroups = ceil_div(p.taps, WG_MAXT);
+  {  // tiled bf16 kernel when the shape allows it
+    int segc[CGEN_MAX_SEG];
+    for (int s = 0; s < a->nseg; ++s) segc[s] = a->seg[s].c;
+    Wg2Geom g;
+    if (wgrad_tiled_ok(a, g)) {
+      CGEN_REQUIRE(g.nsplit == a->nsplit, "cgen_conv2d_wgrad: nsplit %d != expected %d", a->nsplit, g.nsplit);
+      Wg2P q;
+      memset(&q, 0, sizeof(q));
+      q.N = a->n; q.H = a->h; q.W = a->w; q.KS = a->ks; q.nseg = a->nseg; q.act = a->act; q.Co = a->gout.c; q.taps = p.taps;
+      q.ci_total = off;
+      int k8 = 0, o2 = 0;
+      for (int s = 0; s < a->nseg; ++s) {
+        q.seg[s] = mk(a->seg[s]); q.seg_koff[s] = k8; q.seg_off[s] = o2;
+        k8 += pad_to(a->seg[s].c, 8); o2 += a->seg[s].c;
+      }
+      for (int s = a->nseg; s < CGEN_MAX_SEG; ++s) q.seg_koff[s] = 1 << 30;
+      q.ctot8 = k8;
+      q.gout = mk(a->gout);
+      q.pw = a->partial_w; q.pb = a->partial_b;
+      q.tiles_x = g.tiles_x; q.tiles_y = g.tiles_y; q.ntiles = g.ntiles; q.nsplit = g.nsplit; q.tiles_per_split = g.tps;
+      q.cwin = g.cwin; q.cog = g.ncf * 16; q.xt = g.xt; q.gt = g.gt;
+      hipStream_t st = (hipStream_t)stream;
+      switch (g.ncf) {
+        case 1: launch_wgrad2_ks<1, 16>(q, g, st); break;
+        case 2: launch_wgrad2_ks<2, 12>(q, g, st); break;
+        case 4: launch_wgrad2_ks<4, 6>(q, g, st); break;
+        case 6: launch_wgrad2_ks<6, 4>(q, g, st); break;
+        default: launch_wgrad2_ks<8, 3>(q, g, st); break;
+      }
+      return check_launch("cgen_conv2d_wgrad(tile)");
+    }
+  }
   // geometry must match what the caller sized the partial buffer with
   int ns, pps;
   wgrad_geometry(p.P, p.Co, (p.ci_total + 31) / 32, p.KS, ns, pps);

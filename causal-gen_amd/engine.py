@@ -26,17 +26,18 @@ def _ceil(a, m):
 
 class NT:
     """NHWC strided view (channel stride 1) -- the Python twin of cgen_view."""
-    __slots__ = ("ptr", "n", "h", "w", "c", "sn", "sh", "sw", "base", "coff", "rg", "keep", "_cv", "es")
+    __slots__ = ("ptr", "n", "h", "w", "c", "sn", "sh", "sw", "base", "coff", "rg", "keep", "_cv", "es", "cpad")
 
     def __init__(self, ptr, n, h, w, c, sn, sh, sw, es, base=None, coff=0, rg=True, keep=None):
         self.ptr, self.n, self.h, self.w, self.c = ptr, n, h, w, c
         self.sn, self.sh, self.sw, self.es = sn, sh, sw, es
         self.base = base if base is not None else self
         self.coff, self.rg, self.keep, self._cv = coff, rg, keep, None
+        self.cpad = 0  # channels [c, cpad) are guaranteed zero (see cgen_view.cpad)
 
     def cv(self):
         if self._cv is None:
-            self._cv = View(self.ptr, self.sn, self.sh, self.sw, self.c, 0)
+            self._cv = View(self.ptr, self.sn, self.sh, self.sw, self.c, self.cpad)
         return self._cv
 
     def chan(self, a, b):
@@ -49,8 +50,9 @@ class NT:
         if r == self.h and r == self.w:
             return self
         assert not self.rg
-        return NT(self.ptr, self.n, r, r, self.c, self.sn, self.sh, self.sw, self.es, base=None, coff=0, rg=False,
-                  keep=self.keep)
+        v = NT(self.ptr, self.n, r, r, self.c, self.sn, self.sh, self.sw, self.es, base=None, coff=0, rg=False, keep=self.keep)
+        v.cpad = self.cpad
+        return v
 
     @property
     def shape(self):
@@ -179,6 +181,9 @@ class Engine:
         t = t.contiguous()
         out = self.new(n, h, w, c, rg=rg)
         out.keep = t
+        if c % 8:  # ragged width: zero the padding channels once so whole 16-byte groups can be fetched by DMA
+            self.fill(self._padded(out), 0.0)
+            out.cpad = _ceil(c, 8)
         self.lib.nchw_to_nhwc(1 if t.dtype == torch.uint8 else 0, self.dt, n, c, h, w, t.data_ptr(), out.cv(), sub, mul,
                               self.stream)
         self.launches += 1
@@ -398,6 +403,11 @@ class Engine:
             self.tape.append((self._bw_pad, (x, out)))
         return out
 
+    @staticmethod
+    def _padded(x):
+        """View of x widened to its physical (8-aligned) channel count."""
+        return NT(x.ptr, x.n, x.h, x.w, _ceil(x.c, 8), x.sn, x.sh, x.sw, x.es, rg=False)
+
     def fill(self, x, value):
         self.lib.axpby(self.dt, x.n, x.h, x.w, NULL_VIEW, x.cv(), float(value), 1.0, 1 << 30, 0, self.stream)
         self.launches += 1
@@ -405,7 +415,11 @@ class Engine:
     def scale_channels(self, x, c_from, factor):
         """out = x with channels >= c_from multiplied by factor (pa_sto, vae.py:244-247)."""
         out = self.new(x.n, x.h, x.w, x.c, rg=False)
-        self.lib.axpby(self.dt, x.n, x.h, x.w, x.cv(), out.cv(), 1.0, float(factor), c_from, 0, self.stream)
+        src, dst = x, out
+        if x.cpad:  # carry the zero padding along
+            src, dst = self._padded(x), self._padded(out)
+            out.cpad = x.cpad
+        self.lib.axpby(self.dt, x.n, x.h, x.w, src.cv(), dst.cv(), 1.0, float(factor), c_from, 0, self.stream)
         self.launches += 1
         return out
 
@@ -543,20 +557,22 @@ class Engine:
 
     def _wgrad(self, site, segs, act, g):
         x0 = segs[0]
-        nsplit = self.lib.conv2d_wgrad_splits(x0.n, x0.h, x0.w, site.co, site.ci, site.ks)
-        use = sum(1 for e in self._wg_events if e[0] is site)
-        key = (site.index, use, x0.n, x0.h, x0.w)
-        buf = self._partials.get(key)
-        nw = site.co * site.taps * site.ci
-        if buf is None:
-            buf = torch.empty(nsplit * (nw + site.co), dtype=torch.float32, device=self.device)
-            self._partials[key] = buf
-            self._red_tabs = {}
         a = _lib.WgradArgs()
-        a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.nsplit = self.dt, x0.n, x0.h, x0.w, site.ks, len(segs), act, nsplit
+        a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act = self.dt, x0.n, x0.h, x0.w, site.ks, len(segs), act
         for k, s in enumerate(segs):
             a.seg[k] = s.cv()
         a.gout = g.cv()
+        use = sum(1 for e in self._wg_events if e[0] is site)
+        key = (site.index, use, x0.n, x0.h, x0.w)
+        ent = self._partials.get(key)
+        nw = site.co * site.taps * site.ci
+        if ent is None:
+            nsplit = self.lib.conv2d_wgrad_plan(C.byref(a), None)
+            ent = (torch.empty(nsplit * (nw + site.co), dtype=torch.float32, device=self.device), nsplit)
+            self._partials[key] = ent
+            self._red_tabs = {}
+        buf, nsplit = ent
+        a.nsplit = nsplit
         a.partial_w = buf.data_ptr()
         a.partial_b = buf.data_ptr() + 4 * nsplit * nw if site.conv.bias is not None else None
         self._timed("conv_wgrad", site, x0, lambda: self.lib.conv2d_wgrad(C.byref(a), self.stream))
@@ -570,7 +586,7 @@ class Engine:
         if tab is None:
             descs, csite, cidx, seen = [], [], [], set()
             for site, key, nsplit in self._wg_events:
-                buf = self._partials[key]
+                buf = self._partials[key][0]
                 nw = site.co * site.taps * site.ci
                 d = _lib.WredDesc()
                 d.partial_w = buf.data_ptr()

@@ -32,12 +32,14 @@ enum cgen_status { CGEN_OK = 0, CGEN_EINVAL = -1, CGEN_ELAUNCH = -2, CGEN_EUNSUP
 enum cgen_dtype { CGEN_F32 = 0, CGEN_BF16 = 1 };
 enum cgen_act { CGEN_ACT_NONE = 0, CGEN_ACT_RELU = 1, CGEN_ACT_GELU = 2 };
 
-/* NHWC strided view; strides in elements; p == NULL means "absent". */
+/* NHWC strided view; strides in elements; p == NULL means "absent".
+ * cpad (optional, 0 = none): the caller guarantees that channels [c, cpad) of every pixel are readable and hold
+ * finite values (zeros); lets the tiled kernels fetch whole 16-byte groups of a ragged-width tensor by LDS-DMA. */
 typedef struct cgen_view {
   void* p;
   int64_t sn, sh, sw;
   int32_t c;
-  int32_t reserved;
+  int32_t cpad;
 } cgen_view;
 
 #define CGEN_MAX_SEG 4
@@ -66,8 +68,9 @@ int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream);
 
 /* Weight gradient (aten::convolution_backward, weight/bias part) as split-K partials:
  *   partial_w[split][Co][KS*KS][Ci_total] (f32), partial_b[split][Co] (f32, may be NULL)
- * with Ci_total = sum_s seg[s].c and nsplit = cgen_conv2d_wgrad_splits(...).  Deterministic: partials are
- * summed in a fixed order by cgen_wgrad_reduce. */
+ * with Ci_total = sum_s seg[s].c and nsplit = cgen_conv2d_wgrad_plan(args) (call it with the views filled in; it also
+ * reports whether the streaming tiled bf16 kernel will serve the call).  Deterministic: partials are summed in a fixed
+ * order by cgen_wgrad_reduce. */
 typedef struct cgen_wgrad_args {
   int32_t dtype, n, h, w, ks, nseg, act, nsplit;
   cgen_view seg[CGEN_MAX_SEG];
@@ -75,7 +78,7 @@ typedef struct cgen_wgrad_args {
   float* partial_w;
   float* partial_b;
 } cgen_wgrad_args;
-int cgen_conv2d_wgrad_splits(int32_t n, int32_t h, int32_t w, int32_t co, int32_t ci_total, int32_t ks);
+int cgen_conv2d_wgrad_plan(const cgen_wgrad_args* a, int32_t* tiled_out);
 int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream);
 
 /* Multi-tensor descriptor tables (device memory, built once by the host).  One launch serves every conv site. */

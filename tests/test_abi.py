@@ -55,7 +55,14 @@ def test_pure_queries_and_arg_validation_without_gpu():
     lib = _lib.load()
     assert lib.reparam_kl_chunks(96, 96, 16) == 72
     assert lib.like_chunks(192, 192) == 36
-    assert lib.conv2d_wgrad_splits(32, 192, 192, 8, 32, 3) >= 1
+    import ctypes
+
+    w = _lib.WgradArgs()
+    w.dtype, w.n, w.h, w.w, w.ks, w.nseg = 1, 32, 192, 192, 3, 1
+    w.seg[0] = _lib.View(4096, 192 * 192 * 32, 192 * 32, 32, 32, 0)
+    w.gout = _lib.View(8192, 192 * 192 * 8, 192 * 8, 8, 8, 0)
+    tiled = ctypes.c_int32(-1)
+    assert lib.conv2d_wgrad_plan(ctypes.byref(w), ctypes.byref(tiled)) >= 1 and tiled.value == 1
     # argument validation happens before any launch, so it is testable on a CPU-only host
     a = _lib.ConvArgs()
     a.dtype = 7

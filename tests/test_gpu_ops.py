@@ -38,6 +38,10 @@ CONV_CASES = [
     (1, 33, 31, [40], 100, 1, 0, False),
     (2, 4, 4, [48, 20], 1, 1, 0, False),
     (130, 2, 2, [8], 8, 1, 2, True),
+    (2, 24, 24, [24, 4, 40], 24, 3, 1, False),
+    (2, 16, 32, [16], 96, 3, 2, True),
+    (3, 40, 24, [8], 64, 3, 1, False),
+    (2, 16, 16, [200], 16, 1, 0, False),
 ]
 
 

@@ -12,6 +12,7 @@ import torch
 from causal_gen_amd import _lib
 from causal_gen_amd.engine import ConvSite, Engine
 
+ONLY = os.environ.get("ONLY")
 SHAPES = [  # (N, res, seg channels, Co, ks)   ukbb192 trunk shapes at batch 32
     (32, 192, [32], 8, 3), (32, 192, [8], 32, 3), (32, 96, [64], 16, 3), (32, 96, [16], 64, 3),
     (32, 48, [96], 24, 3), (32, 48, [24], 96, 3), (32, 24, [128], 32, 3), (32, 24, [32], 128, 3),
@@ -30,7 +31,9 @@ def main():
     sites = [ConvSite(f"c{i}", c, s[2], [True] * len(s[2]), i) for i, (c, s) in enumerate(zip(holder, SHAPES))]
     eng.bind(holder, sites)
     es = eng.es
-    for site, (N, R, segc, Co, ks) in zip(sites, SHAPES):
+    for idx, (site, (N, R, segc, Co, ks)) in enumerate(zip(sites, SHAPES)):
+        if ONLY is not None and str(idx) not in ONLY.split(','):
+            continue
         eng.begin()
         eng.prepare_weights(force=True)
         xs = [eng.new(N, R, R, c) for c in segc]
@@ -41,30 +44,36 @@ def main():
         flops = 2.0 * sum(segc) * ks * ks * Co * N * R * R
         bytes_alg = N * R * R * (sum(segc) + Co) * es
         res = {}
-        if kind in ("fwd", "all"):
-            y = eng.conv(site, xs, 1)
+        def timed(fn):
+            """GPU time per launch: the launches are captured in a hipGraph so the host is out of the picture."""
+            fn()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                eng.stream = torch.cuda.current_stream().cuda_stream
+                for _ in range(iters):
+                    fn()
+            eng.stream = torch.cuda.current_stream().cuda_stream
+            g.replay()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(iters):
-                eng.conv(site, xs, 1, out=y)
+            g.replay()
             e1.record()
             torch.cuda.synchronize()
-            res["fwd"] = e0.elapsed_time(e1) * 1e3 / iters
+            return e0.elapsed_time(e1) * 1e3 / iters
+
+        if kind in ("fwd", "all"):
+            y = eng.conv(site, xs, 1)
+            res["fwd"] = timed(lambda: eng.conv(site, xs, 1, out=y))
         if kind in ("wgrad", "all"):
             g = eng.new(N, R, R, Co)
             eng.fill(g, 0.25)
-            eng._wg_events = []
-            eng._wgrad(site, xs, 1, g)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(iters):
+            def wg():
                 eng._wg_events = []
                 eng._wgrad(site, xs, 1, g)
-            e1.record()
-            torch.cuda.synchronize()
-            res["wgrad"] = e0.elapsed_time(e1) * 1e3 / iters
+
+            res["wgrad"] = timed(wg)
         for k, us in res.items():
             print("%-5s %s N%d res%-3d ci%-12s co%-3d ks%d : %8.1f us  %7.1f TF/s  %6.2f TB/s(alg)" % (
                 k, dtype, N, R, str(segc), Co, ks, us, flops / us / 1e6, bytes_alg / us / 1e6))
