@@ -74,15 +74,20 @@ static inline bool dma_clean(const cgen_view& v, int esz) {
 // ----------------------------------------------------------------------------- activations (vae.py:50,59)
 #define CGEN_SQRT1_2 0.70710678118654752440f
 #define CGEN_INV_SQRT_2PI 0.39894228040143267794f
+// The erf-GELU bodies are deliberately NOT inlinable: as inline code hipcc if-converts the activation switch and
+// evaluates the erf polynomial for every element even when the layer is a ReLU (measured: half the wgrad kernel's
+// time).  Behind a call the GELU math sits on a real, wave-uniform branch.
+__device__ __noinline__ float gelu_fwd_slow(float x) { return 0.5f * x * (1.f + erff(x * CGEN_SQRT1_2)); }  // nn.GELU() default
+__device__ __noinline__ float gelu_bwd_slow(float x) {
+  return 0.5f * (1.f + erff(x * CGEN_SQRT1_2)) + x * CGEN_INV_SQRT_2PI * __expf(-0.5f * x * x);
+}
 __device__ __forceinline__ float act_fwd(int act, float x) {
-  if (act == CGEN_ACT_RELU) return x > 0.f ? x : 0.f;
-  if (act == CGEN_ACT_GELU) return 0.5f * x * (1.f + erff(x * CGEN_SQRT1_2));  // nn.GELU() default = erf form
-  return x;
+  if (act == CGEN_ACT_GELU) return gelu_fwd_slow(x);
+  return (act == CGEN_ACT_RELU && x <= 0.f) ? 0.f : x;  // NaN stays NaN, as torch.relu
 }
 __device__ __forceinline__ float act_bwd(int act, float x) {
-  if (act == CGEN_ACT_RELU) return x > 0.f ? 1.f : 0.f;
-  if (act == CGEN_ACT_GELU) return 0.5f * (1.f + erff(x * CGEN_SQRT1_2)) + x * CGEN_INV_SQRT_2PI * __expf(-0.5f * x * x);
-  return 1.f;
+  if (act == CGEN_ACT_GELU) return gelu_bwd_slow(x);
+  return (act == CGEN_ACT_RELU && !(x > 0.f)) ? 0.f : 1.f;
 }
 
 // ----------------------------------------------------------------------------- wave / block reductions (wave = 64)

@@ -500,7 +500,7 @@ static bool launch_conv_tile(const ConvP& p, hipStream_t st) {
 
 template <typename T>
 static int launch_conv(const ConvP& p, hipStream_t st) {
-  if ((p.KS == 1 || p.KS == 3) && p.H >= 8 && p.W >= 16 && !p.force_generic && p.dma_ok) {
+  if ((p.KS == 1 || p.KS == 3) && p.H >= 5 && p.W >= 5 && !p.force_generic && p.dma_ok) {
     const bool ok = p.KS == 3 ? launch_conv_tile<T, 3>(p, st) : launch_conv_tile<T, 1>(p, st);
     if (ok) return check_launch("cgen_conv2d(tile)");
   }
@@ -732,6 +732,7 @@ struct Wg2P {
   float* pb;
   int tiles_x, tiles_y, ntiles, nsplit, tiles_per_split;
   int cwin, cog;  // channel window, co columns staged per workgroup (16*NCF)
+  int dbg;        // ablation mask (CGEN_WG2_DBG): 1 skip DMA, 2 skip activation pass, 4 skip MFMA loop
   PixTile xt, gt;
 };
 
@@ -874,12 +875,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
   for (int t = t_begin; t < t_end; ++t) {
-    issue_tile(t);
+    if (!(p.dbg & 1)) issue_tile(t);
     __syncthreads();  // hipcc waits vmcnt(0) here: the tile has landed
-    if (p.act != CGEN_ACT_NONE) {
+    if (p.act != CGEN_ACT_NONE && !(p.dbg & 2)) {
       act_pass();
       __syncthreads();
     }
+    if (!(p.dbg & 4))
 #pragma unroll
     for (int ks = 0; ks < TILE_H / 2; ++ks) {
       bf16x8 af[NCF];
@@ -943,7 +945,7 @@ struct Wg2Geom { int ncf, njw, cwin, nsplit, tps, ntiles, tiles_x, tiles_y, n_cw
 
 // returns false when the shape is not served by the tiled kernel
 static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2Geom& g) {
-  if (!(ks == 1 || ks == 3) || H < 8 || W < 16) return false;
+  if (!(ks == 1 || ks == 3) || H < 5 || W < 5) return false;
   const int taps = ks * ks;
   const int halo = ks / 2;
   g.ncf = co <= 16 ? 1 : (co <= 32 ? 2 : (co <= 64 ? 4 : (co <= 96 ? 6 : 8)));
@@ -1199,6 +1201,7 @@ extern "C" int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream)
       q.pw = a->partial_w; q.pb = a->partial_b;
       q.tiles_x = g.tiles_x; q.tiles_y = g.tiles_y; q.ntiles = g.ntiles; q.nsplit = g.nsplit; q.tiles_per_split = g.tps;
       q.cwin = g.cwin; q.cog = g.ncf * 16; q.xt = g.xt; q.gt = g.gt;
+      { const char* e = getenv("CGEN_WG2_DBG"); q.dbg = e ? atoi(e) : 0; }
       hipStream_t st = (hipStream_t)stream;
       switch (g.ncf) {
         case 1: launch_wgrad2_ks<1, 16>(q, g, st); break;
