@@ -71,6 +71,7 @@ PROTOTYPES = {
     "cgen_axpby": [i32, i32, i32, i32, View, View, f32, f32, i32, i32, vp],
     "cgen_nchw_to_nhwc": [i32, i32, i32, i32, i32, i32, vp, View, f32, f32, vp],
     "cgen_nhwc_to_nchw": [i32, i32, i32, i32, i32, View, vp, vp],
+    "cgen_im2col": [i32, i32, i32, i32, i32, View, View, vp],
     "cgen_reparam_kl_chunks": [i32, i32, i32],
     "cgen_reparam_kl_fwd": [i32, i32, i32, i32, i32, View, View, View, View, View, vp, u32, f32, View, View, vp, i32, vp],
     "cgen_reparam_kl_bwd": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, View, vp, i32, View, View, View,

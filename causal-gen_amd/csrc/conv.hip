@@ -293,6 +293,7 @@ struct TileP {
   int kp;    // K length of a pass, padded to the MFMA K-step
   int ldw;   // LDS row stride of the weight slab (elements)
   FastDiv d_gprw, d_gprx, d_cw;
+  int dbg, pad0;  // ablation mask (CGEN_TILE_DBG): 1 skip weight DMA, 2 skip halo DMA, 4 skip act pass, 8 skip K loop, 16 skip epilogue
 };
 
 __device__ uint4 g_zero16[4];  // 64 bytes of zeros: DMA source for out-of-image / padding groups
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(256, 4) void conv_tile_kernel(ConvP p, TileP q) {
     const int kreal = (kend + KSTEP - 1) / KSTEP * KSTEP;
     if (cA > 0) __syncthreads();  // the previous pass's fragment reads are done
     // ---- weights: LDS row [co][tap*cw + c'] <- image row [co][tap*ctot8 + cA + c']   (global -> LDS DMA, no VGPR staging)
+    if (!(q.dbg & 1))
     for (int piece = wave; piece < wpieces; piece += 4) {
       const int pu = __builtin_amdgcn_readfirstlane(piece);
       const int gi = pu * 64 + lane;
@@ -374,6 +376,7 @@ __global__ __launch_bounds__(256, 4) void conv_tile_kernel(ConvP p, TileP q) {
       }
     }
     // ---- halo tile: virtual concat of the segments; zeros outside the image / past a segment's channels
+    if (!(q.dbg & 2))
     for (int piece = wave; piece < xpieces; piece += 4) {
       const int pu = __builtin_amdgcn_readfirstlane(piece);
       const int gi = pu * 64 + lane;
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(256, 4) void conv_tile_kernel(ConvP p, TileP q) {
       }
     }
     __syncthreads();  // hipcc drains vmcnt (incl. the LDS DMA) before the barrier
-    if (p.act != CGEN_ACT_NONE) {  // activation once per element, in place (not once per tap at fragment-read time)
+    if (p.act != CGEN_ACT_NONE && !(q.dbg & 4)) {  // activation once per element, in place (not once per tap at fragment-read time)
       const int rstep = fdiv(256, q.d_gprx), cstep = 256 - rstep * gpr_x;
       int rr = fdiv(tid, q.d_gprx), cc = tid - rr * gpr_x;
 #pragma unroll 1
@@ -419,6 +422,7 @@ __global__ __launch_bounds__(256, 4) void conv_tile_kernel(ConvP p, TileP q) {
     int tap = (fg * GK) / cw, c = fg * GK - tap * cw;
     const T* xb = Xs + ((wave * 2) * HW + fr) * q.ldc;
     const T* wb = Ws + fr * q.ldw + fg * GK;
+    if (!(q.dbg & 8))
     for (int k0 = 0; k0 < kend; k0 += KSTEP) {
       const int tp = tap < TAPS ? tap : TAPS - 1;  // lanes past the last tap multiply zero weights; keep the address legal
       const int off = ((tp / KS) * HW + (tp % KS)) * q.ldc + c;
@@ -449,6 +453,7 @@ __global__ __launch_bounds__(256, 4) void conv_tile_kernel(ConvP p, TileP q) {
       if (c >= cw) { c -= cw; ++tap; }
     }
   }
+  if (!(q.dbg & 16))
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const int py = y0 + wave * 2 + f, px = x0 + fr;
@@ -491,6 +496,7 @@ static bool launch_conv_tile(const ConvP& p, hipStream_t st) {
     if (lds <= budget) { q.cw = cw; break; }
   }
   q.d_gprw = mk_fastdiv(q.ldw / G); q.d_gprx = mk_fastdiv(q.ldc / G); q.d_cw = mk_fastdiv(q.cw);
+  { const char* e = getenv("CGEN_TILE_DBG"); q.dbg = e ? atoi(e) : 0; q.pad0 = 0; }
   dim3 block(256);
   if (ntc == 1) hipLaunchKernelGGL((conv_tile_kernel<T, 1, KS>), dim3(ntiles, ceil_div(p.Co, 16)), block, lds, st, p, q);
   else if (ntc == 2) hipLaunchKernelGGL((conv_tile_kernel<T, 2, KS>), dim3(ntiles, ceil_div(p.Co, 32)), block, lds, st, p, q);

@@ -225,6 +225,39 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(Shape4 s, View in, fl
   }
 }
 
+// im2col for the KSxKS stem: out[n,y,x, c*KS*KS + tap] = in[n, y+dy, x+dx, c] (zero outside the image and in the padding
+// channels [C*KS*KS, out.cpad)).  Turns the thin-K 7x7 stem (Ci = 1 or 3) into a 1x1 conv over 49*Ci channels that the
+// tiled MFMA kernels serve; the OIHW weight [Co][Ci][7][7] is already the [Co][49*Ci] matrix this needs.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(Shape4 s, int ks, int cin, View in, View out, int cphys) {
+  const int taps = ks * ks, pad = ks / 2;
+  const int groups = cphys / 8;
+  const int64_t total = (int64_t)s.n * s.h * s.w * groups;
+  GRID_STRIDE(g) {
+    if (g >= total) return;
+    const int cg = (int)(g % groups) * 8;
+    int64_t r = g / groups;
+    const int x = (int)(r % s.w); r /= s.w;
+    const int y = (int)(r % s.h);
+    const int n = (int)(r / s.h);
+    T vals[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int oc = cg + e;
+      T v = (T)0;
+      if (oc < cin * taps) {
+        const int c = oc / taps, tap = oc - c * taps;
+        const int yy = y + tap / ks - pad, xx = x + tap % ks - pad;
+        if (yy >= 0 && yy < s.h && xx >= 0 && xx < s.w) v = *(vptr<T>(in, n, yy, xx) + c);
+      }
+      vals[e] = v;
+    }
+    T* dst = vptr<T>(out, n, y, x) + cg;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = vals[e];
+  }
+}
+
 static inline int grid_for(int64_t items) {
   int64_t b = (items + 255) / 256;
   if (b < 1) b = 1;
@@ -356,6 +389,19 @@ extern "C" int cgen_nchw_to_nhwc(int32_t src_is_u8, int32_t dtype, int32_t n, in
     else hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t, float>), g, b, 0, st, s, (const float*)src, mk(out), sub, mul);
   }
   return check_launch("cgen_nchw_to_nhwc");
+}
+
+extern "C" int cgen_im2col(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t ks, cgen_view in, cgen_view out,
+                           cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_im2col");
+  CGEN_REQUIRE(in.p && out.p && (ks == 3 || ks == 5 || ks == 7) && out.c == in.c * ks * ks, "cgen_im2col: bad args");
+  const int cphys = (out.c + 7) / 8 * 8;
+  CGEN_REQUIRE(out.cpad >= cphys, "cgen_im2col: out.cpad must cover the 8-channel padding (%d < %d)", out.cpad, cphys);
+  Shape4 s{n, h, w, out.c};
+  const int64_t items = (int64_t)n * h * w * (cphys / 8);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
+  else hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
+  return check_launch("cgen_im2col");
 }
 
 extern "C" int cgen_nhwc_to_nchw(int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, cgen_view in, float* dst,

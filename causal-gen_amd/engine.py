@@ -91,10 +91,15 @@ class Arena:
 class ConvSite:
     """One nn.Conv2d of the model together with how its input channels are split into segments."""
 
-    def __init__(self, name, conv, seg_c, seg_rg, index):
+    def __init__(self, name, conv, seg_c, seg_rg, index, as_1x1=False):
         self.name, self.conv, self.index = name, conv, index
         self.ks = conv.kernel_size[0]
         self.co, self.ci = conv.out_channels, conv.in_channels
+        self.im2col = 0
+        if as_1x1:  # thin-K stem: run on an im2col'd input as a 1x1 conv over ks*ks*Ci channels (same OIHW memory)
+            self.im2col = self.ks
+            self.ci *= self.ks * self.ks
+            self.ks = 1
         assert sum(seg_c) == self.ci, (name, seg_c, self.ci)
         self.seg_c, self.seg_rg = tuple(seg_c), tuple(seg_rg)
         self.seg_off = [sum(seg_c[:i]) for i in range(len(seg_c))]
@@ -364,6 +369,14 @@ class Engine:
         ent[0] += flops
         ent[1].append((e0, e1))
         ent[2] += 1
+
+    def im2col(self, x, ks):
+        c = x.c * ks * ks
+        out = self.new(x.n, x.h, x.w, c, rg=False)
+        out.cpad = _ceil(c, 8)
+        self.lib.im2col(self.dt, x.n, x.h, x.w, ks, x.cv(), out.cv(), self.stream)
+        self.launches += 1
+        return out
 
     def pool(self, x, d):
         out = self.new(x.n, x.h // d, x.w // d, x.c)

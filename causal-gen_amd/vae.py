@@ -263,8 +263,8 @@ class HVAE(nn.Module):
         """Enumerate every conv with its input segmentation (the virtual torch.cat's of vae.py:176,188,294,300)."""
         sites = []
 
-        def add(name, conv, seg_c, seg_rg):
-            sites.append(ConvSite(name, conv, seg_c, seg_rg, len(sites)))
+        def add(name, conv, seg_c, seg_rg, as_1x1=False):
+            sites.append(ConvSite(name, conv, seg_c, seg_rg, len(sites), as_1x1=as_1x1))
 
         def add_block(name, blk, seg_c, seg_rg):
             cs = blk.convs()
@@ -275,7 +275,7 @@ class HVAE(nn.Module):
                 add(f"{name}.width_proj", blk.width_proj, seg_c, seg_rg)
 
         C = self.input_channels
-        add("encoder.stem", self.encoder.stem, [C], [False])
+        add("encoder.stem", self.encoder.stem, [C * 49], [False], as_1x1=True)
         for i, b in enumerate(self.encoder.blocks):
             add_block(f"encoder.blocks.{i}", b, [b.convs()[0].in_channels], [True])
         zd, ctx = self.z_dim, self.context_dim
@@ -326,7 +326,8 @@ class HVAE(nn.Module):
         return h
 
     def _encode(self, eng, x):
-        h = eng.conv(self._site(eng, self.encoder.stem), [x], ACT_NONE)
+        stem = self._site(eng, self.encoder.stem)
+        h = eng.conv(stem, [eng.im2col(x, stem.im2col)], ACT_NONE)
         acts = {}
         for blk in self.encoder.blocks:
             h = self._run_block(eng, blk, [h])

@@ -129,6 +129,10 @@ int cgen_axpby(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view in, cge
 /* NCHW (f32 or u8, contiguous) -> NHWC view in `dtype`: out = (in - sub) * mul */
 int cgen_nchw_to_nhwc(int32_t src_is_u8, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, const void* src,
                       cgen_view out, float sub, float mul, cgen_stream_t);
+/* im2col for the thin-K stem conv (vae.py:104-110): out[n,y,x, c*ks*ks + tap] = in[n, y+dy, x+dx, c], zeros outside the
+ * image and in out's padding channels (out.c = in.c*ks*ks, out.cpad = ceil8(out.c)).  The 7x7 stem then runs as a 1x1
+ * conv over 49*Ci channels on the MFMA kernels, with the OIHW weight used as the [Co][49*Ci] matrix unchanged. */
+int cgen_im2col(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t ks, cgen_view in, cgen_view out, cgen_stream_t);
 /* NHWC view -> contiguous NCHW f32 */
 int cgen_nhwc_to_nchw(int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, cgen_view in, float* dst, cgen_stream_t);
 

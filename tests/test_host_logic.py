@@ -33,7 +33,7 @@ def test_module_tree_and_init_match_reference(name):
     n_convs = sum(1 for mod in m.modules() if isinstance(mod, torch.nn.Conv2d))
     assert len(sites) == n_convs
     for s in sites:
-        assert sum(s.seg_c) == s.conv.in_channels
+        assert sum(s.seg_c) == s.conv.in_channels * (s.im2col ** 2 if s.im2col else 1)
     # decoder introspection used by the reference's setup_tensorboard (train_setup.py:96-103)
     assert all(hasattr(b, "stochastic") and hasattr(b, "res") for b in m.decoder.blocks)
 
