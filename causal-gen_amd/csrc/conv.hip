@@ -423,6 +423,7 @@ __global__ __launch_bounds__(256, 4) void conv_tile_kernel(ConvP p, TileP q) {
     const T* xb = Xs + ((wave * 2) * HW + fr) * q.ldc;
     const T* wb = Ws + fr * q.ldw + fg * GK;
     if (!(q.dbg & 8))
+#pragma unroll 3
     for (int k0 = 0; k0 < kend; k0 += KSTEP) {
       const int tp = tap < TAPS ? tap : TAPS - 1;  // lanes past the last tap multiply zero weights; keep the address legal
       const int off = ((tp / KS) * HW + (tp % KS)) * q.ldc + c;
@@ -868,13 +869,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
   int xo0[NJW], xo1[NJW];
 #pragma unroll
   for (int j = 0; j < NJW; ++j) {
-    const int jf = wave + 4 * j;
+    const int jf = min(wave + 4 * j, njf - 1);  // waves short of a fragment compute a duplicate that is never written out
     const int tap = jf / cgrp, cb = (jf - tap * cgrp) * 16;
     const int dy = tap / KS, dx = tap % KS;
     xo0[j] = pix_off(p.xt, krow + dy, kx + dx) + (cb + qd * 4) * 2;
     xo1[j] = pix_off(p.xt, krow + dy, kx + dx + 4) + (cb + qd * 4) * 2;
   }
-  const int nj_wave = njf > wave ? (njf - wave + 3) >> 2 : 0;
+  const int nj_eff = (njf + 3) >> 2;  // fragments per wave, the same for all four waves
   const int go0 = pix_off(p.gt, krow, kx) + qd * 8, go1 = pix_off(p.gt, krow, kx + 4) + qd * 8;
   bf16x8 ones;
 #pragma unroll
@@ -887,24 +888,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
       act_pass();
       __syncthreads();
     }
-    if (!(p.dbg & 4))
+    if (!(p.dbg & 4)) {
+      // fragments are processed in chunks of CH: all transpose reads of a chunk are issued before its MFMAs (one LDS
+      // latency per chunk instead of per fragment); the chunk test is wave-uniform and identical for the four waves
+      constexpr int CH = (NJW % 4 == 0) ? 4 : 3;
 #pragma unroll
-    for (int ks = 0; ks < TILE_H / 2; ++ks) {
-      bf16x8 af[NCF];
-      const char* gk = Gb + ks * 2 * p.gt.rowbytes;
+      for (int ks = 0; ks < TILE_H / 2; ++ks) {
+        bf16x8 af[NCF];
+        const char* gk = Gb + ks * 2 * p.gt.rowbytes;
 #pragma unroll
-      for (int a = 0; a < NCF; ++a) af[a] = tr_pair(gk + go0 + a * 32, gk + go1 + a * 32);
-      if (do_bias) {
+        for (int a = 0; a < NCF; ++a) af[a] = tr_pair(gk + go0 + a * 32, gk + go1 + a * 32);
+        if (do_bias) {
 #pragma unroll
-        for (int a = 0; a < NCF; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, accb[a], 0, 0, 0);
-      }
-      const char* xk = Xb + ks * 2 * p.xt.rowbytes;
+          for (int a = 0; a < NCF; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, accb[a], 0, 0, 0);
+        }
+        const char* xk = Xb + ks * 2 * p.xt.rowbytes;
 #pragma unroll
-      for (int j = 0; j < NJW; ++j) {
-        if (j < nj_wave) {
-          const bf16x8 bfv = tr_pair(xk + xo0[j], xk + xo1[j]);
+        for (int j0 = 0; j0 < NJW; j0 += CH) {
+          if (j0 < nj_eff) {
+            bf16x8 bfv[CH];
 #pragma unroll
-          for (int a = 0; a < NCF; ++a) acc[a][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfv, acc[a][j], 0, 0, 0);
+            for (int u = 0; u < CH; ++u) bfv[u] = tr_pair(xk + xo0[j0 + u], xk + xo1[j0 + u]);
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+#pragma unroll
+              for (int a = 0; a < NCF; ++a) acc[a][j0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfv[u], acc[a][j0 + u], 0, 0, 0);
+          }
         }
       }
     }
