@@ -505,8 +505,15 @@ static bool launch_conv_tile(const ConvP& p, hipStream_t st) {
   return true;
 }
 
+static bool launch_conv_ws(const ConvP& p, hipStream_t st);  // weight-stationary persistent kernel (bf16), defined below
+
 template <typename T>
 static int launch_conv(const ConvP& p, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    if ((p.KS == 1 || p.KS == 3) && p.H >= 5 && p.W >= 5 && p.dma_ok && !p.force_generic && !getenv("CGEN_CONV_NO_WS")) {
+      if (launch_conv_ws(p, st)) return check_launch("cgen_conv2d(ws)");
+    }
+  }
   if ((p.KS == 1 || p.KS == 3) && p.H >= 5 && p.W >= 5 && !p.force_generic && p.dma_ok) {
     const bool ok = p.KS == 3 ? launch_conv_tile<T, 3>(p, st) : launch_conv_tile<T, 1>(p, st);
     if (ok) return check_launch("cgen_conv2d(tile)");
@@ -718,6 +725,11 @@ static inline PixTile mk_pixtile(int width_elems, int esz, int rows, int npx) {
   int gpr = (width_elems * esz + 15) / 16 + 1;
   if ((gpr & 1) == 0) ++gpr;
   t.gpr = gpr; t.ppp = 64 / gpr; t.rows = rows; t.npx = npx;
+  if (t.ppp < 1) {  // pixel wider than one 1-KiB piece: caller must fall back (checks ppp < 1)
+    t.ppr = 0; t.rowbytes = 0; t.bytes = 0; t.pad = 0;
+    t.d_gpr = mk_fastdiv(1); t.d_ppr = mk_fastdiv(1);
+    return t;
+  }
   t.ppr = (npx + t.ppp - 1) / t.ppp;
   t.rowbytes = t.ppr * 1024; t.bytes = rows * t.rowbytes; t.pad = 0;
   t.d_gpr = mk_fastdiv(gpr); t.d_ppr = mk_fastdiv(t.ppr);
@@ -975,7 +987,7 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
   for (;; cwin -= 16) {  // LDS budget: two workgroups per CU
     if (cwin < 16) return false;
     g.xt = mk_pixtile(cwin, 2, TILE_H + 2 * halo, TILE_W + 2 * halo);
-    if (g.xt.ppp >= 1 && g.xt.bytes + g.gt.bytes <= 78 * 1024) break;
+    if (g.gt.ppp >= 1 && g.xt.ppp >= 1 && g.xt.bytes + g.gt.bytes <= 78 * 1024) break;
   }
   if (g.gt.ppp < 1) return false;
   g.lds = (size_t)g.xt.bytes + g.gt.bytes;
@@ -1003,6 +1015,218 @@ static void launch_wgrad2_ks(const Wg2P& p, const Wg2Geom& g, hipStream_t st) {
     if (!once1) { (void)hipFuncSetAttribute((const void*)wgrad_tile_kernel<NCF, NJW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once1 = true; }
     hipLaunchKernelGGL((wgrad_tile_kernel<NCF, NJW, 1>), grid, block, g.lds, st, p);
   }
+}
+
+// ============================================================================= weight-stationary persistent conv (bf16)
+// fwd / dgrad for KS in {1,3} on >= 5x5 images.  The forward kernel above re-stages the weight slab in LDS for every
+// 128-pixel tile (for a 96->24 3x3 conv that is 55 KB of weights per 25 KB of activations).  Here the K axis
+// (tap, channel) is split across the four waves and every wave keeps ITS K-steps of the weight image in registers for
+// the whole launch; a persistent workgroup then streams 8x16 pixel tiles through LDS (row-piece DMA as in the wgrad
+// kernel), each wave accumulates all 128 pixels x (16*NTC) channels over its K-steps, and the four partial sums are
+// combined through LDS in a fixed order (deterministic) before the fused epilogue.  LDS holds only the halo tile.
+struct WsP {
+  PixTile xt;
+  int tiles_x, tiles_y, ntiles, nk;  // nk = K-steps that carry weights
+  int rows_pad, red_bytes, dbg, pad0;
+  FastDiv d_ctot8;
+};
+
+template <int NTC, int NKW>
+__global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
+  typedef bf16_t T;
+  constexpr int G = 8, NF = NTC * TILE_H;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Xb = smem;
+  const int KS = p.KS, HALO = KS / 2, TAPS = p.taps;
+  const int HW = TILE_W + 2 * HALO;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int co_base = blockIdx.y * (NTC * 16);
+
+  // ---- this wave's K-steps of the weight image, resident in registers
+  bf16x8 aw[NTC][NKW];
+  int koff[NKW];
+  {
+    int pxo[3];  // LDS byte offset of pixel x = fr + dx inside a tile row
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) pxo[dx] = pix_off(q.xt, 0, fr + (dx < KS ? dx : 0));
+#pragma unroll
+    for (int i = 0; i < NKW; ++i) {
+      const int ks = wave + 4 * i;
+#pragma unroll
+      for (int t = 0; t < NTC; ++t) {
+        const int row = co_base + t * 16 + fr;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.0f;
+        if (ks < q.nk && row < q.rows_pad) v = *(const bf16x8*)((const T*)p.w + (size_t)row * p.krow + ks * 32 + fg * 8);
+        aw[t][i] = v;
+      }
+      const int kidx = min(ks, q.nk - 1) * 32 + fg * 8;
+      int tap = fdiv(kidx, q.d_ctot8);
+      const int c = kidx - tap * p.ctot8;
+      tap = tap < TAPS ? tap : TAPS - 1;  // columns past the last tap carry zero weights; keep the address legal
+      const int dy = tap / KS, dx = tap - dy * KS;
+      koff[i] = dy * q.xt.rowbytes + (dx == 0 ? pxo[0] : (dx == 1 ? pxo[1] : pxo[2])) + c * 2;
+    }
+  }
+
+  // ---- per-lane DMA constants (see wgrad_tile_kernel)
+  const int xl = fdiv(lane, q.xt.d_gpr), xcg = lane - xl * q.xt.gpr;
+  int x_si = 0, x_off = 0;
+  const bool x_lane = xl < q.xt.ppp && xcg * G < p.ctot8;
+  bool x_data = false;
+  {
+    const int c = xcg * G;
+#pragma unroll
+    for (int k = 1; k < CGEN_MAX_SEG; ++k) x_si += (k < p.nseg && c >= p.seg_koff[k]) ? 1 : 0;
+    View sv = p.seg[0];
+    int ko = p.seg_koff[0];
+#pragma unroll
+    for (int k = 1; k < CGEN_MAX_SEG; ++k)
+      if (x_si == k) { sv = p.seg[k]; ko = p.seg_koff[k]; }
+    const int cs = c - ko;
+    x_data = x_lane && cs < sv.c;
+    x_off = (int)(xl * sv.sw) + cs;
+  }
+  const int xpieces = q.xt.rows * q.xt.ppr;
+
+  for (int t = blockIdx.x; t < q.ntiles; t += gridDim.x) {
+    int b = t;
+    const int tx = b % q.tiles_x; b /= q.tiles_x;
+    const int ty = b % q.tiles_y;
+    const int n = b / q.tiles_y;
+    const int y0 = ty * TILE_H, x0 = tx * TILE_W;
+    // ---- halo tile DMA (row pieces): a few SALU ops + ~6 VALU per piece
+    if (!(q.dbg & 1)) {
+      const T* org0 = vptr<T>(p.seg[0], n, y0 - HALO, x0 - HALO);
+      const T* my_org = org0;
+      int64_t my_sh = p.seg[0].sh, my_swp = p.seg[0].sw * q.xt.ppp;
+      if (p.nseg > 1) {
+        if (x_si == 1) { my_org = vptr<T>(p.seg[1], n, y0 - HALO, x0 - HALO); my_sh = p.seg[1].sh; my_swp = p.seg[1].sw * q.xt.ppp; }
+        if (x_si == 2) { my_org = vptr<T>(p.seg[2], n, y0 - HALO, x0 - HALO); my_sh = p.seg[2].sh; my_swp = p.seg[2].sw * q.xt.ppp; }
+        if (x_si == 3) { my_org = vptr<T>(p.seg[3], n, y0 - HALO, x0 - HALO); my_sh = p.seg[3].sh; my_swp = p.seg[3].sw * q.xt.ppp; }
+      }
+      my_org += x_off;
+      for (int pi = wave; pi < xpieces; pi += 4) {
+        const int pu = __builtin_amdgcn_readfirstlane(pi);
+        const int hy = fdiv(pu, q.xt.d_ppr), pc = pu - hy * q.xt.ppr;
+        if (x_lane) {
+          const int hx = pc * q.xt.ppp + xl;
+          const int yy = y0 - HALO + hy, xx = x0 - HALO + hx;
+          const bool ok = x_data && hx < HW && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+          const T* src = ok ? my_org + (hy * my_sh + pc * my_swp) : (const T*)g_zero16;
+          __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Xb + pu * 1024), 16, 0, 0);  // never an LDS store between DMAs
+        }
+      }
+    }
+    __syncthreads();  // hipcc waits vmcnt(0) here: the tile has landed
+    if (p.act != CGEN_ACT_NONE && !(q.dbg & 2)) {
+      if (x_data) {
+        for (int pi = wave; pi < xpieces; pi += 4) {
+          uint4* ptr = (uint4*)(Xb + pi * 1024 + lane * 16);
+          *ptr = act_group<T>(*ptr, p.act);
+        }
+      }
+      __syncthreads();
+    }
+    // ---- MFMAs: this wave's K-steps x all 8 tile rows
+    f32x4 acc[NTC][TILE_H];
+#pragma unroll
+    for (int tt = 0; tt < NTC; ++tt)
+#pragma unroll
+      for (int f = 0; f < TILE_H; ++f) acc[tt][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (!(q.dbg & 4)) {
+#pragma unroll
+      for (int i = 0; i < NKW; ++i) {
+        bf16x8 bq[TILE_H];
+#pragma unroll
+        for (int f = 0; f < TILE_H; ++f) bq[f] = *(const bf16x8*)(Xb + f * q.xt.rowbytes + koff[i]);
+#pragma unroll
+        for (int f = 0; f < TILE_H; ++f)
+#pragma unroll
+          for (int tt = 0; tt < NTC; ++tt) acc[tt][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[tt][i], bq[f], acc[tt][f], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // everyone is done reading the tile: its LDS is reused for the partial sums
+    {
+      f32x4* red = (f32x4*)smem + (size_t)wave * NF * 64 + lane;
+#pragma unroll
+      for (int tt = 0; tt < NTC; ++tt)
+#pragma unroll
+        for (int f = 0; f < TILE_H; ++f) red[(tt * TILE_H + f) * 64] = acc[tt][f];
+    }
+    __syncthreads();
+    if (!(q.dbg & 8)) {
+#pragma unroll
+      for (int ff = 0; ff < 2; ++ff) {
+        const int f = wave * 2 + ff;
+        const int py = y0 + f, px = x0 + fr;
+#pragma unroll
+        for (int tt = 0; tt < NTC; ++tt) {
+          const f32x4* rd = (const f32x4*)smem + (size_t)(tt * TILE_H + f) * 64 + lane;
+          f32x4 v = rd[0];
+#pragma unroll
+          for (int wv = 1; wv < 4; ++wv) {  // fixed summation order: deterministic
+            const f32x4 o = rd[(size_t)wv * NF * 64];
+            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+          }
+          if (py < p.H && px < p.W) conv_epilogue<T>(p, v, n, py, px, co_base + tt * 16 + fg * 4);
+        }
+      }
+    }
+    __syncthreads();  // partial sums consumed before the next tile's DMA overwrites them
+  }
+}
+
+template <int NTC, int NKW>
+static void launch_ws_inst(const ConvP& p, const WsP& q, int grid_x, int grid_y, size_t lds, hipStream_t st) {
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)conv_ws_kernel<NTC, NKW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  hipLaunchKernelGGL((conv_ws_kernel<NTC, NKW>), dim3(grid_x, grid_y), dim3(256), lds, st, p, q);
+}
+
+static bool launch_conv_ws(const ConvP& p, hipStream_t st) {
+  WsP q;
+  memset(&q, 0, sizeof(q));
+  const int halo = p.KS / 2;
+  const int ntc = p.Co <= 16 ? 1 : 2;
+  q.nk = ceil_div(p.taps * p.ctot8, 32);
+  const int nkw = ceil_div(q.nk, 4);
+  static const int buckets[] = {1, 2, 3, 4, 5, 6, 8, 10, 12};
+  int bk = -1;
+  for (int b : buckets) if (b >= nkw) { bk = b; break; }
+  if (bk < 0) return false;                      // K too long for the register-resident weights: multi-pass kernel
+  q.xt = mk_pixtile(p.ctot8, 2, TILE_H + 2 * halo, TILE_W + 2 * halo);
+  if (q.xt.ppp < 1) return false;
+  q.red_bytes = 4 * ntc * TILE_H * 1024;
+  const size_t lds = (size_t)(q.xt.bytes > q.red_bytes ? q.xt.bytes : q.red_bytes);
+  if (lds > 78 * 1024) return false;             // keep two workgroups per CU
+  q.tiles_x = ceil_div(p.W, TILE_W); q.tiles_y = ceil_div(p.H, TILE_H);
+  q.ntiles = p.N * q.tiles_x * q.tiles_y;
+  q.rows_pad = pad_to(p.Co, 16);
+  q.d_ctot8 = mk_fastdiv(p.ctot8);
+  { const char* e = getenv("CGEN_WS_DBG"); q.dbg = e ? atoi(e) : 0; }
+  const int grid_y = ceil_div(p.Co, ntc * 16);
+  // measured on MI355X: the register-resident weights pay off when every wave owns >= 3 K-steps and the halo tile is
+  // re-staged for at most nkw/2 output-channel tiles; short-K / wide-output (expanding) convs stay on the tile kernel
+  if (!getenv("CGEN_CONV_FORCE_WS") && (nkw < 3 || nkw < 2 * grid_y)) return false;
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  int grid_x = 256 * per_cu / grid_y;
+  if (grid_x < 1) grid_x = 1;
+  if (grid_x > q.ntiles) grid_x = q.ntiles;
+#define WS_CASE(NKW) case NKW: if (ntc == 1) launch_ws_inst<1, NKW>(p, q, grid_x, grid_y, lds, st); else launch_ws_inst<2, NKW>(p, q, grid_x, grid_y, lds, st); break;
+  switch (bk) {
+    WS_CASE(1) WS_CASE(2) WS_CASE(3) WS_CASE(4) WS_CASE(5) WS_CASE(6) WS_CASE(8) WS_CASE(10) WS_CASE(12)
+    default: return false;
+  }
+#undef WS_CASE
+  return true;
 }
 
 static inline int wgrad_ntc(int co) { return co <= 16 ? 1 : (co <= 32 ? 2 : 4); }
