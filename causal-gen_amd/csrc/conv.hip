@@ -49,7 +49,7 @@ struct ConvP {
   const void* w;
   const float* bias;
   View out, aux, res1, res2;
-  int epi_vec, force_generic, dma_ok;
+  int epi_vec, force_generic, dma_ok, epi_vec16;
 };
 
 // 4-element (16B f32 / 8B bf16) vector access
@@ -116,6 +116,53 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4& a, in
         if (r1) u += Elem<T>::ld(r1 + co + e);
         if (r2) u += Elem<T>::ld(r2 + co + e);
         Elem<T>::st(optr + co + e, u);
+      }
+    }
+  }
+}
+
+// 8 consecutive output channels of one pixel (16-byte bf16 I/O): same math as conv_epilogue, used by the LDS-staged
+// epilogues where consecutive lanes own consecutive 16-byte chunks of a pixel row (fully coalesced stores / loads)
+__device__ __forceinline__ void conv_epilogue8_bf16(const ConvP& p, float (&v)[8], int pn, int py, int px, int co) {
+  typedef bf16_t T;
+  if (co >= p.Co) return;
+  T* optr = vptr<T>(p.out, pn, py, px) + co;
+  const T* aptr = p.aux.p ? vptr<T>(p.aux, pn, py, px) + co : nullptr;
+  const T* r1 = p.res1.p ? vptr<T>(p.res1, pn, py, px) + co : nullptr;
+  const T* r2 = p.res2.p ? vptr<T>(p.res2, pn, py, px) + co : nullptr;
+  if (co + 8 <= p.Co && p.epi_vec16) {
+    if (p.bias) {
+      const float4 b0 = *(const float4*)(p.bias + co), b1 = *(const float4*)(p.bias + co + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    Pack<T, 8> t;
+    if (aptr) {
+      t.v4 = *(const uint4*)aptr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= act_bwd(p.dact, bf2f(t.e[e]));
+    }
+    if (r1) {
+      t.v4 = *(const uint4*)r1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bf2f(t.e[e]);
+    }
+    if (r2) {
+      t.v4 = *(const uint4*)r2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bf2f(t.e[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t.e[e] = f2bf(v[e]);
+    *(uint4*)optr = t.v4;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (co + e < p.Co) {
+        float u = v[e] + (p.bias ? p.bias[co + e] : 0.f);
+        if (aptr) u *= act_bwd(p.dact, bf2f(aptr[e]));
+        if (r1) u += bf2f(r1[e]);
+        if (r2) u += bf2f(r2[e]);
+        optr[e] = f2bf(u);
       }
     }
   }
@@ -454,13 +501,38 @@ __global__ __launch_bounds__(256, 4) void conv_tile_kernel(ConvP p, TileP q) {
       if (c >= cw) { c -= cw; ++tap; }
     }
   }
-  if (!(q.dbg & 16))
+  if (q.dbg & 16) return;
+  if constexpr (sizeof(T) == 2) {
+    // LDS-staged epilogue: the MFMA layout gives a lane 4 channels of one pixel (8-byte pieces, 32 B runs per pixel);
+    // re-reading the wave's 32 pixels x COT channels from LDS as 16-byte chunks makes consecutive lanes cover consecutive
+    // chunks of a pixel row, so the aux / residual loads and the output store are whole 128-byte+ runs.
+    constexpr int COT = NTC * 16, LDE = COT + 4, CPP = COT / 8;  // chunks per pixel
+    __syncthreads();  // everyone is done with the weight slab / halo tile
+    float* es = (float*)smem + wave * (32 * LDE);
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const int py = y0 + wave * 2 + f, px = x0 + fr;
-    if (py >= p.H || px >= p.W) continue;
+    for (int f = 0; f < 2; ++f)
 #pragma unroll
-    for (int t = 0; t < NTC; ++t) conv_epilogue<T>(p, acc[t][f], n, py, px, co_base + t * 16 + fg * 4);
+      for (int t = 0; t < NTC; ++t) *(f32x4*)(es + (f * 16 + fr) * LDE + t * 16 + fg * 4) = acc[t][f];
+    // wave-private region: LDS operations of one wave complete in order, no block barrier needed
+#pragma unroll
+    for (int k = 0; k < NTC; ++k) {
+      const int idx = lane + 64 * k;
+      const int pl = idx / CPP, ch = idx % CPP;
+      const int py = y0 + wave * 2 + (pl >> 4), px = x0 + (pl & 15);
+      if (py < p.H && px < p.W) {
+        const f32x4 lo = *(const f32x4*)(es + pl * LDE + ch * 8), hi = *(const f32x4*)(es + pl * LDE + ch * 8 + 4);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        conv_epilogue8_bf16(p, v, n, py, px, co_base + ch * 8);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int py = y0 + wave * 2 + f, px = x0 + fr;
+      if (py >= p.H || px >= p.W) continue;
+#pragma unroll
+      for (int t = 0; t < NTC; ++t) conv_epilogue<T>(p, acc[t][f], n, py, px, co_base + t * 16 + fg * 4);
+    }
   }
 }
 
@@ -496,6 +568,7 @@ static bool launch_conv_tile(const ConvP& p, hipStream_t st) {
     lds = lds_bytes(cw, q.kp, q.ldc, q.ldw);
     if (lds <= budget) { q.cw = cw; break; }
   }
+  { const long epi = 4L * 32 * (wrows + 4) * 4; if (lds < epi) lds = epi; }
   q.d_gprw = mk_fastdiv(q.ldw / G); q.d_gprx = mk_fastdiv(q.ldc / G); q.d_cw = mk_fastdiv(q.cw);
   { const char* e = getenv("CGEN_TILE_DBG"); q.dbg = e ? atoi(e) : 0; q.pad0 = 0; }
   dim3 block(256);
@@ -1161,20 +1234,27 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
     }
     __syncthreads();
     if (!(q.dbg & 8)) {
+      // each wave finalises 2 tile rows; a lane owns an 8-channel (16-byte) chunk of one pixel so that consecutive lanes
+      // cover consecutive chunks of a pixel row (coalesced epilogue I/O).  Fixed summation order: deterministic.
+      constexpr int COT = NTC * 16, CPP = COT / 8;
 #pragma unroll
-      for (int ff = 0; ff < 2; ++ff) {
-        const int f = wave * 2 + ff;
-        const int py = y0 + f, px = x0 + fr;
+      for (int k = 0; k < NTC; ++k) {
+        const int idx = lane + 64 * k;
+        const int pl = idx / CPP, ch = idx % CPP;      // pixel 0..31 of this wave's two rows, chunk inside the pixel
+        const int f = wave * 2 + (pl >> 4), pxl = pl & 15;
+        const int tt = ch >> 1, cg = (ch & 1) * 2;     // MFMA fragment and lane group pair that hold channels ch*8..+8
+        const f32x4* rd = (const f32x4*)smem + (size_t)(tt * TILE_H + f) * 64 + cg * 16 + pxl;
+        f32x4 lo = rd[0], hi = rd[16];
 #pragma unroll
-        for (int tt = 0; tt < NTC; ++tt) {
-          const f32x4* rd = (const f32x4*)smem + (size_t)(tt * TILE_H + f) * 64 + lane;
-          f32x4 v = rd[0];
-#pragma unroll
-          for (int wv = 1; wv < 4; ++wv) {  // fixed summation order: deterministic
-            const f32x4 o = rd[(size_t)wv * NF * 64];
-            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-          }
-          if (py < p.H && px < p.W) conv_epilogue<T>(p, v, n, py, px, co_base + tt * 16 + fg * 4);
+        for (int wv = 1; wv < 4; ++wv) {
+          const f32x4 a = rd[(size_t)wv * NF * 64], bq2 = rd[(size_t)wv * NF * 64 + 16];
+          lo[0] += a[0]; lo[1] += a[1]; lo[2] += a[2]; lo[3] += a[3];
+          hi[0] += bq2[0]; hi[1] += bq2[1]; hi[2] += bq2[2]; hi[3] += bq2[3];
+        }
+        const int py = y0 + f, px = x0 + pxl;
+        if (py < p.H && px < p.W) {
+          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          conv_epilogue8_bf16(p, v, n, py, px, co_base + ch * 8);
         }
       }
     }
@@ -1355,6 +1435,7 @@ extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
   };
   p.force_generic = getenv("CGEN_CONV_GENERIC") != nullptr;
   p.epi_vec = epi_ok(a->out) && epi_ok(a->aux) && epi_ok(a->res1) && epi_ok(a->res2) && (!a->bias || ((uintptr_t)a->bias % 16 == 0));
+  p.epi_vec16 = vec16_ok(a->out, esz) && vec16_ok(a->aux, esz) && vec16_ok(a->res1, esz) && vec16_ok(a->res2, esz) && (!a->bias || ((uintptr_t)a->bias % 16 == 0));
   return a->dtype == CGEN_F32 ? launch_conv<float>(p, (hipStream_t)stream) : launch_conv<bf16_t>(p, (hipStream_t)stream);
 }
 
