@@ -50,6 +50,7 @@ struct ConvP {
   const float* bias;
   View out, aux, res1, res2;
   int epi_vec, force_generic, dma_ok, epi_vec16;
+  int tap0, tap1;  // taps that can touch the image (a 3x3 conv on a 1x1 image only ever sees its centre tap)
 };
 
 // 4-element (16B f32 / 8B bf16) vector access
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvP p) {
     for (int f = 0; f < 2; ++f) acc[t][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- K-step iterator state: (tap, seg, c0)
-  int tap = 0, s = 0, c0 = 0;
+  int tap = p.tap0, s = 0, c0 = 0;
   uint4 xr[NG];   // staged activation groups (raw 16 bytes each)
   uint4 wr[WPT];  // staged weight groups
 
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvP p) {
         ++tap;
       }
     }
-    return tap < p.taps;
+    return tap < p.tap1;
   };
 
   load_step(tap, s, c0);
@@ -1419,6 +1420,8 @@ extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
     koff += pad_to(a->seg[s].c, 8);
   }
   for (int s = a->nseg; s < CGEN_MAX_SEG; ++s) p.seg_koff[s] = 1 << 30;
+  p.tap0 = 0; p.tap1 = p.taps;
+  if (a->h == 1 && a->w == 1 && a->ks > 1) { p.tap0 = p.taps / 2; p.tap1 = p.tap0 + 1; }
   p.dma_ok = 1;
   for (int s = 0; s < a->nseg; ++s) p.dma_ok = p.dma_ok && dma_clean(a->seg[s], esz);
   p.ctot8 = koff;

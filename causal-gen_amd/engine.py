@@ -153,6 +153,7 @@ class Engine:
         self._wg_events = []
         self.pgrad_init = set()
         self._pnhwc, self._pgrad_tmp = {}, {}
+        self._adopted = set()
         self.passes = 0
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
 
@@ -525,6 +526,22 @@ class Engine:
         self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
         self.launches += 1
 
+    def _grad_residual(self, r, g, out, segs):
+        """d(out)/d(residual) = identity.  When `r` is a whole tensor that has no gradient yet and `out`'s gradient is a
+        whole buffer, r simply ADOPTS that buffer (no copy): every later contribution to grad(r) is accumulated in place
+        by a kernel epilogue, after this op's own reads of it have been enqueued (same stream => ordered).
+        Not when r is also an input segment of this op (its dgrad would read the buffer with a halo while accumulating
+        into it), and only one tensor may adopt a given buffer."""
+        gbuf = self.grads[id(out.base)][0]
+        whole_r = r.base is r and id(r) not in self.grads
+        whole_g = out.base is out and g.c == out.c
+        clash = any(sg.base is r for sg in segs) or id(gbuf) in self._adopted
+        if whole_r and whole_g and not clash and (r.n, r.h, r.w, r.c, r.sn, r.sh, r.sw) == (g.n, g.h, g.w, g.c, g.sn, g.sh, g.sw):
+            self.grads[id(r)] = [gbuf, [(0, r.c)], r]
+            self._adopted.add(id(gbuf))
+            return
+        self.grad_add(r, g)
+
     def seed_grad(self, t):
         """Gradient buffer of an output tensor, to be written by a loss kernel."""
         gv, acc = self.grad_write(t)
@@ -549,7 +566,7 @@ class Engine:
             return
         for r in (res1, res2):
             if r is not None and r.rg:
-                self.grad_add(r, g)
+                self._grad_residual(r, g, out, segs)
         x0 = segs[0]
         if site.conv.weight.requires_grad:
             self._wgrad(site, segs, act, g)
