@@ -826,6 +826,7 @@ struct Wg2P {
   int tiles_x, tiles_y, ntiles, nsplit, tiles_per_split;
   int cwin, cog;  // channel window, co columns staged per workgroup (16*NCF)
   int dbg;        // ablation mask (CGEN_WG2_DBG): 1 skip DMA, 2 skip activation pass, 4 skip MFMA loop
+  unsigned long long* stamps;  // optional (CGEN_WG2_STAMPS): per-phase cycle stamps of workgroup 0
   PixTile xt, gt;
 };
 
@@ -871,6 +872,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
     for (int j = 0; j < NJW; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   const bool do_bias = p.pb != nullptr && blockIdx.y == 0 && wave == 0;
+  const unsigned long long t_entry = __builtin_readcyclecounter();
 
   // ---- per-lane DMA constants (identical for every piece of every tile)
   // activation tile: lane -> (pixel xl inside the piece, channel group) -> segment / channel / element offset
@@ -967,13 +969,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
+  const bool stamp = p.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+  int nst = 0;
+#define WG2_STAMP() do { if (stamp && nst < 60) p.stamps[nst++] = __builtin_readcyclecounter(); } while (0)
+  if (stamp) p.stamps[nst++] = t_entry;
+  WG2_STAMP();
   for (int t = t_begin; t < t_end; ++t) {
     if (!(p.dbg & 1)) issue_tile(t);
+    WG2_STAMP();
     __syncthreads();  // hipcc waits vmcnt(0) here: the tile has landed
+    WG2_STAMP();
     if (p.act != CGEN_ACT_NONE && !(p.dbg & 2)) {
       act_pass();
       __syncthreads();
     }
+    WG2_STAMP();
     if (!(p.dbg & 4)) {
       // fragments are processed in chunks of CH: all transpose reads of a chunk are issued before its MFMAs (one LDS
       // latency per chunk instead of per fragment); the chunk test is wave-uniform and identical for the four waves
@@ -1003,31 +1013,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
         }
       }
     }
+    WG2_STAMP();
     __syncthreads();  // everyone is done with the buffers before the next tile's DMA overwrites them
+    WG2_STAMP();
   }
 
-  // ---- write the partial slab: D[i = co][j = ci]: lane holds column j = lane&15, rows (lane>>4)*4 + e
+  // ---- write the partial slab through LDS so the stores are coalesced (rows of `cw` consecutive f32 per (co, tap));
+  // straight from the MFMA layout this tail cost more cycles than a whole tile (432 scattered 4-byte stores per wave).
+  {
+    float* stage = (float*)smem;  // [16 co][TAPS][cw16] per co-fragment
+    const int q4 = cw16 >> 2;     // float4 groups per row
+    const int ngroups = 16 * TAPS * q4;
+    const bool one_seg_vec = p.nseg == 1 && (p.ci_total & 3) == 0 && (cA & 3) == 0;
 #pragma unroll
-  for (int j = 0; j < NJW; ++j) {
-    const int jf = wave + 4 * j;
-    if (jf < njf) {
-      const int tap = jf / cgrp, c = cA + (jf - tap * cgrp) * 16 + (lane & 15);
-      int sidx = 0;
+    for (int a = 0; a < NCF; ++a) {
+      __syncthreads();  // previous users of the LDS region are done
 #pragma unroll
-      for (int k = 1; k < CGEN_MAX_SEG; ++k) sidx += (k < p.nseg && c >= p.seg_koff[k]) ? 1 : 0;
-      int koff = p.seg_koff[0], segc = p.seg[0].c, soff = p.seg_off[0];
+      for (int j = 0; j < NJW; ++j) {
+        const int jf = wave + 4 * j;
+        if (jf < njf) {
+          const int tap = jf / cgrp, cb = (jf - tap * cgrp) * 16;
 #pragma unroll
-      for (int k = 1; k < CGEN_MAX_SEG; ++k)
-        if (sidx == k) { koff = p.seg_koff[k]; segc = p.seg[k].c; soff = p.seg_off[k]; }
-      const int cs = c - koff;
-      if (c < cA + cw && cs < segc) {
-#pragma unroll
-        for (int a = 0; a < NCF; ++a)
+          for (int e = 0; e < 4; ++e) stage[(((lane >> 4) * 4 + e) * TAPS + tap) * cw16 + cb + (lane & 15)] = acc[a][j][e];
+        }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < ngroups; idx += 256) {
+        const int r = idx / q4, c4 = (idx - r * q4) * 4;
+        const int col = r / TAPS, tap = r - col * TAPS;
+        const int co = co_base + a * 16 + col;
+        if (co >= p.Co || c4 >= cw) continue;
+        const float4 v = *(const float4*)(stage + r * cw16 + c4);
+        float* row = p.pw + (((size_t)sp * p.Co + co) * TAPS + tap) * p.ci_total;
+        if (one_seg_vec && cA + c4 + 4 <= p.seg[0].c) {
+          *(float4*)(row + cA + c4) = v;
+        } else {
+          const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const int co = co_base + a * 16 + (lane >> 4) * 4 + e;
-            if (co < p.Co) p.pw[(((size_t)sp * p.Co + co) * TAPS + tap) * p.ci_total + soff + cs] = acc[a][j][e];
+            const int c = cA + c4 + e;
+            int sidx = 0;
+#pragma unroll
+            for (int k = 1; k < CGEN_MAX_SEG; ++k) sidx += (k < p.nseg && c >= p.seg_koff[k]) ? 1 : 0;
+            int koff = p.seg_koff[0], segc = p.seg[0].c, soff = p.seg_off[0];
+#pragma unroll
+            for (int k = 1; k < CGEN_MAX_SEG; ++k)
+              if (sidx == k) { koff = p.seg_koff[k]; segc = p.seg[k].c; soff = p.seg_off[k]; }
+            const int cs = c - koff;
+            if (c4 + e < cw && cs < segc) row[soff + cs] = vv[e];
           }
+        }
       }
     }
   }
@@ -1040,6 +1075,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
         if (co < p.Co) p.pb[(size_t)sp * p.Co + co] = accb[a][e];
       }
   }
+  WG2_STAMP();
+  if (stamp) p.stamps[63] = nst;
+#undef WG2_STAMP
 }
 
 struct Wg2Geom { int ncf, njw, cwin, nsplit, tps, ntiles, tiles_x, tiles_y, n_cwin, n_co; PixTile xt, gt; size_t lds; };
@@ -1065,11 +1103,23 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
   }
   if (g.gt.ppp < 1) return false;
   g.lds = (size_t)g.xt.bytes + g.gt.bytes;
+  {
+    const size_t stage = (size_t)16 * taps * pad_to(cwin, 16) * 4;  // coalesced partial write-out (one co-fragment at a time)
+    if (stage > g.lds) g.lds = stage;
+    if (g.lds > 80 * 1024) return false;
+  }
   g.cwin = cwin;
   g.n_cwin = ceil_div(ctot8, cwin);
   g.tiles_x = ceil_div(W, TILE_W); g.tiles_y = ceil_div(H, TILE_H);
   g.ntiles = N * g.tiles_x * g.tiles_y;
   int want = ceil_div(512, g.n_cwin * g.n_co);  // two persistent workgroups per CU
+  {  // bound the split-K partials of one conv (they are written and re-read by cgen_wgrad_reduce)
+    const char* e = getenv("CGEN_WG2_PARTIAL_MB");
+    const long cap = (e ? atol(e) : 4096) << 20;  // off by default: capping costs more wgrad time than it saves in the reduce
+    const long wbytes = 4L * co * taps * ctot8;
+    const int maxs = (int)(cap / (wbytes > 0 ? wbytes : 1));
+    if (want > maxs) want = maxs;
+  }
   if (want < 1) want = 1;
   g.tps = ceil_div(g.ntiles, want);
   if (g.tps < 2 && g.ntiles >= 2) g.tps = 2;
@@ -1525,6 +1575,7 @@ extern "C" int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream)
       q.tiles_x = g.tiles_x; q.tiles_y = g.tiles_y; q.ntiles = g.ntiles; q.nsplit = g.nsplit; q.tiles_per_split = g.tps;
       q.cwin = g.cwin; q.cog = g.ncf * 16; q.xt = g.xt; q.gt = g.gt;
       { const char* e = getenv("CGEN_WG2_DBG"); q.dbg = e ? atoi(e) : 0; }
+      { const char* e = getenv("CGEN_WG2_STAMPS"); q.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
       hipStream_t st = (hipStream_t)stream;
       switch (g.ncf) {
         case 1: launch_wgrad2_ks<1, 16>(q, g, st); break;

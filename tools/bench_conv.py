@@ -74,6 +74,17 @@ def main():
                 eng._wgrad(site, xs, 1, g)
 
             res["wgrad"] = timed(wg)
+            if os.environ.get("STAMPS"):
+                st = torch.zeros(64, dtype=torch.int64, device="cuda")
+                os.environ["CGEN_WG2_STAMPS"] = hex(st.data_ptr())
+                wg()
+                torch.cuda.synchronize()
+                del os.environ["CGEN_WG2_STAMPS"]
+                v = st.cpu().tolist()
+                n = v[63]
+                d = [v[i + 1] - v[i] for i in range(n - 1)]
+                print("   stamps(cycles): setup %d | per tile [issue, wait, act, mfma, bar]: %s | tail %d" % (
+                    d[0], [d[1 + k * 5:1 + k * 5 + 5] for k in range(min(3, (n - 3) // 5))], d[-1]))
         for k, us in res.items():
             print("%-5s %s N%d res%-3d ci%-12s co%-3d ks%d : %8.1f us  %7.1f TF/s  %6.2f TB/s(alg)" % (
                 k, dtype, N, R, str(segc), Co, ks, us, flops / us / 1e6, bytes_alg / us / 1e6))
