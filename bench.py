@@ -89,6 +89,17 @@ def cpu_baseline(name, budget_s=20.0):
                 sample=f"{it} train steps of {name} at batch {B} (fwd+bwd+clip+AdamW+EMA), f32, after 1 warm-up step")
 
 
+def pmc_traffic(kernel_class, dtype):
+    """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE collected separately; tools/pmc_traffic.py applies the gfx950 FETCH_SIZE x2 correction).  PMC counters
+    cannot be read from inside this process, so this is the figure of the profiled run of the same command."""
+    path = os.path.join(ROOT, "profiles", f"r01_hbm_traffic_{dtype}_b32.json")
+    try:
+        return json.load(open(path))[kernel_class]["hbm_bytes_per_dispatch"]
+    except Exception:
+        return None
+
+
 def profile_step(ts, x, pa, dtype):
     """One eager step with HIP events around every conv launch (on the launch stream) -> per-class totals."""
     eng = ts.eng
@@ -103,8 +114,14 @@ def profile_step(ts, x, pa, dtype):
         c[0] += flops; c[1] += ms; c[2] += n
         shapes[(kind, ks, ci, co, res)] = (flops, ms, n)
     eng.prof = None
-    dom = max(classes, key=lambda k: classes[k][1])
-    flops, ms, n = classes[dom]
+    # fwd and dgrad are the same kernels (conv_tile / conv_ws / conv_kernel): one class for the roofline
+    merged = {"conv_fwd+dgrad": [0.0, 0.0, 0], "conv_wgrad": [0.0, 0.0, 0]}
+    for k, v in classes.items():
+        m = merged["conv_wgrad" if k == "conv_wgrad" else "conv_fwd+dgrad"]
+        m[0] += v[0]; m[1] += v[1]; m[2] += v[2]
+    classes.update(merged)
+    dom = max(merged, key=lambda k: merged[k][1])
+    flops, ms, n = merged[dom]
     top = sorted(shapes.items(), key=lambda kv: -kv[1][1])
     dump = os.environ.get("CGEN_SHAPE_DUMP")
     if dump:
@@ -114,7 +131,8 @@ def profile_step(ts, x, pa, dtype):
     top = top[:8]
     return dict(
         bound="mfma", kernel=dom, achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_PEAK_TF[dtype], unit="TFLOP/s",
-        frac=flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dtype], traffic=None, launches=n, avg_launch_us=1e3 * ms / n,
+        frac=flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dtype], traffic=pmc_traffic(dom, dtype), launches=n, avg_launch_us=1e3 * ms / n,
+        algorithmic_flops_per_launch=flops / n,
         classes={k: dict(tflops=v[0] / (v[1] * 1e-3) / 1e12, ms=v[1], launches=v[2]) for k, v in classes.items()},
         top_shapes=[dict(kind=k[0], ks=k[1], ci=k[2], co=k[3], res=k[4], ms=v[1], tflops=v[0] / (v[1] * 1e-3) / 1e12, n=v[2])
                     for k, v in top])
@@ -190,6 +208,8 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "hipgraph": not a.no_graph, "params": sum(p.numel() for p in m.parameters())},
             "elbo_nats_per_dim": elbo, "nll": nll, "kl": kl, "opt_steps": stats["opt_steps"], "skipped": stats["n_skipped"],
+            "wgrad_partial_bytes_per_step": sum(b.numel() * 4 for b, _ in ts.eng._partials.values()),
+            "arena_bytes": ts.eng.arena.high_water, "launches_per_step": None,
             "model_tflops": img_s * gf * 1e9 / 1e12,
             "model_mfma_frac": img_s * gf * 1e9 / 1e12 / (MFMA_PEAK_TF[a.dtype] * world),
         }
