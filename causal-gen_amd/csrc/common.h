@@ -22,11 +22,18 @@ int check_launch(const char* what);
 typedef uint16_t bf16_t;  // raw bits
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
+  union { __bf16 b; bf16_t u; } c;
+  c.b = (__bf16)f;
+  return c.u;
+}
+__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {  // two floats -> packed bf16 pair, one instruction
+  union { bf16x2_t b; uint32_t u; } c;
+  const f32x2_t v = {lo, hi};
+  c.b = __builtin_convertvector(v, bf16x2_t);
+  return c.u;
 }
 
 template <typename T> struct Elem;

@@ -122,6 +122,57 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4& a, in
   }
 }
 
+// Split form of the 8-channel epilogue: on gfx950 loads and stores share one in-order counter (vmcnt), so a load issued
+// after a store cannot be waited for without also waiting for the store's acknowledgement.  An epilogue that interleaves
+// "load aux/residual -> store" per chunk therefore serialises a full load + store round trip per chunk.  The kernels
+// issue ALL operand loads of a tile first (Epi8, before or during the MFMA loop) and finish with pure math + stores.
+struct Epi8 {
+  uint4 a, r1, r2;
+};
+struct Bias8 {
+  float4 b0, b1;
+};
+__device__ __forceinline__ void bias8_load(const ConvP& p, int co, Bias8& l) {
+  l.b0 = l.b1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias) { l.b0 = *(const float4*)(p.bias + co); l.b1 = *(const float4*)(p.bias + co + 4); }
+}
+__device__ __forceinline__ void epi8_load(const ConvP& p, int pn, int py, int px, int co, Epi8& l) {
+  typedef bf16_t T;
+  l.a = l.r1 = l.r2 = make_uint4(0, 0, 0, 0);
+  if (p.aux.p) l.a = *(const uint4*)(vptr<T>(p.aux, pn, py, px) + co);
+  if (p.res1.p) l.r1 = *(const uint4*)(vptr<T>(p.res1, pn, py, px) + co);
+  if (p.res2.p) l.r2 = *(const uint4*)(vptr<T>(p.res2, pn, py, px) + co);
+}
+// v = (bias + v) * act'(aux) + res1 + res2, rounded once, stored as one 16-byte chunk (fast path only: whole aligned chunk)
+__device__ __forceinline__ void epi8_finish(const ConvP& p, float (&v)[8], const Epi8& l, const Bias8& bb, int pn, int py, int px, int co) {
+  typedef bf16_t T;
+  v[0] += bb.b0.x; v[1] += bb.b0.y; v[2] += bb.b0.z; v[3] += bb.b0.w; v[4] += bb.b1.x; v[5] += bb.b1.y; v[6] += bb.b1.z; v[7] += bb.b1.w;
+  Pack<T, 8> t;
+  if (p.aux.p) {
+    t.v4 = l.a;
+    if (p.dact == CGEN_ACT_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= gelu_bwd_slow(bf2f(t.e[e]));
+    } else if (p.dact == CGEN_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = bf2f(t.e[e]) > 0.f ? v[e] : 0.f;
+    }
+  }
+  if (p.res1.p) {
+    t.v4 = l.r1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += bf2f(t.e[e]);
+  }
+  if (p.res2.p) {
+    t.v4 = l.r2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += bf2f(t.e[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t.e[e] = f2bf(v[e]);
+  *(uint4*)(vptr<T>(p.out, pn, py, px) + co) = t.v4;
+}
+
 // 8 consecutive output channels of one pixel (16-byte bf16 I/O): same math as conv_epilogue, used by the LDS-staged
 // epilogues where consecutive lanes own consecutive 16-byte chunks of a pixel row (fully coalesced stores / loads)
 __device__ __forceinline__ void conv_epilogue8_bf16(const ConvP& p, float (&v)[8], int pn, int py, int px, int co) {
@@ -366,7 +417,7 @@ __device__ __forceinline__ uint4 act_group(uint4 v, int act) {
 }
 
 template <typename T, int NTC, int KS>
-__global__ __launch_bounds__(256, 4) void conv_tile_kernel(ConvP p, TileP q) {
+__global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP p, TileP q) {
   constexpr int G = 16 / sizeof(T);
   constexpr int HALO = KS / 2, HH = TILE_H + 2 * HALO, HW = TILE_W + 2 * HALO, HPX = HH * HW;
   constexpr int TAPS = KS * KS;
@@ -399,6 +450,25 @@ __global__ __launch_bounds__(256, 4) void conv_tile_kernel(ConvP p, TileP q) {
 
   const int gpr_w = q.ldw / G, gpr_x = q.ldc / G;  // 16-byte groups per LDS row (incl. padding)
   const bool single = q.cw == p.ctot8;
+
+  // epilogue operands (bf16): issued first, in flight with the DMAs and the K loop (see Epi8)
+  Epi8 epl[NTC];
+  Bias8 ebias;
+  bool efast[NTC];
+  if constexpr (sizeof(T) == 2) {
+    constexpr int CPP = NTC * 2;  // 16-byte chunks per pixel; divides 64, so a lane's chunk (=> bias) is the same for every k
+    ebias.b0 = ebias.b1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.epi_vec16 && co_base + (lane % CPP) * 8 + 8 <= p.Co) bias8_load(p, co_base + (lane % CPP) * 8, ebias);
+#pragma unroll
+    for (int k = 0; k < NTC; ++k) {
+      const int idx = lane + 64 * k;
+      const int pl = idx / CPP, ch = idx % CPP;
+      const int py = y0 + wave * 2 + (pl >> 4), px = x0 + (pl & 15);
+      const int co = co_base + ch * 8;
+      efast[k] = py < p.H && px < p.W && p.epi_vec16 && co + 8 <= p.Co && !(q.dbg & 16);
+      if (efast[k]) epi8_load(p, n, py, px, co, epl[k]);
+    }
+  }
 
   for (int cA = 0; cA < p.ctot8; cA += q.cw) {
     const int cw = min(q.cw, p.ctot8 - cA);  // last window may be narrower (still a multiple of 8)
@@ -523,7 +593,8 @@ __global__ __launch_bounds__(256, 4) void conv_tile_kernel(ConvP p, TileP q) {
       if (py < p.H && px < p.W) {
         const f32x4 lo = *(const f32x4*)(es + pl * LDE + ch * 8), hi = *(const f32x4*)(es + pl * LDE + ch * 8 + 4);
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        conv_epilogue8_bf16(p, v, n, py, px, co_base + ch * 8);
+        if (efast[k]) epi8_finish(p, v, epl[k], ebias, n, py, px, co_base + ch * 8);
+        else conv_epilogue8_bf16(p, v, n, py, px, co_base + ch * 8);
       }
     }
   } else {
@@ -580,10 +651,17 @@ static bool launch_conv_tile(const ConvP& p, hipStream_t st) {
 }
 
 static bool launch_conv_ws(const ConvP& p, hipStream_t st);  // weight-stationary persistent kernel (bf16), defined below
+static bool launch_conv_px(const ConvP& p, hipStream_t st);  // lean persistent kernel for short-K convs (bf16), defined below
+#define PX_MAXKS 16
 
 template <typename T>
 static int launch_conv(const ConvP& p, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
+    if ((p.KS == 1 || p.KS == 3) && p.H >= 5 && p.W >= 5 && p.dma_ok && !p.force_generic && !getenv("CGEN_CONV_NO_PX")) {
+      const int nks = ceil_div(p.taps * p.ctot8, 32);
+      const bool expanding = nks <= PX_MAXKS && p.Co >= 2 * p.ctot8;  // short K, wide output
+      if ((expanding || getenv("CGEN_CONV_FORCE_PX")) && launch_conv_px(p, st)) return check_launch("cgen_conv2d(px)");
+    }
     if ((p.KS == 1 || p.KS == 3) && p.H >= 5 && p.W >= 5 && p.dma_ok && !p.force_generic && !getenv("CGEN_CONV_NO_WS")) {
       if (launch_conv_ws(p, st)) return check_launch("cgen_conv2d(ws)");
     }
@@ -1141,6 +1219,313 @@ static void launch_wgrad2_ks(const Wg2P& p, const Wg2Geom& g, hipStream_t st) {
   }
 }
 
+// ============================================================================= lean persistent conv for short-K convs (bf16)
+// PMC counters on MI355X showed what actually bounds the short-K / wide-output convs (the C/4 -> C half of every Block,
+// forward and data-gradient, and the 1x1 projections): the one-tile-per-workgroup kernel issues ~1150 VALU and ~700 SALU
+// instructions per wave for 40 MFMAs -- 64-bit address arithmetic per epilogue chunk, software bf16 rounding, per-piece
+// DMA address decoding, the weight-slab copy repeated for every tile.  A wave64 VALU instruction occupies the SIMD for
+// 4 cycles (quarter-rate integer multiplies 16), an MFMA 16x16x32 for 16: the kernel was VALU-issue bound.
+// This kernel does the same math with ~5x fewer instructions per tile:
+//   * persistent workgroups: the weight slab of the workgroup's output channels is copied to LDS ONCE;
+//   * everything that depends only on the lane (DMA lane -> channel/segment mapping, K-step -> LDS offset table,
+//     epilogue element offsets, bias) is computed once per launch; per tile the tile origin is SCALAR arithmetic and
+//     every global address is (uniform 64-bit base) + (32-bit lane offset);
+//   * weight rows are permuted inside each 32-row block so that a lane ends up holding 8 CONSECUTIVE output channels of
+//     its pixel (two MFMA results): the epilogue is a 16-byte load / store per lane straight from the accumulators --
+//     no LDS staging, no extra barrier; bias is the accumulators' initial value; bf16 rounding is v_cvt_pk_bf16_f32;
+//   * epilogue operands (aux, residual) are requested before the halo DMA wait and consumed after the MFMA loop.
+struct PxP {
+  PixTile xt;
+  int tiles_x, tiles_y, ntiles, nks;
+  int ldw, wpieces, rows_pad, pad0;
+  FastDiv d_gprw, d_ctot8;
+};
+
+// bf16 pair -> two floats
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+template <int NP, int KS>
+__global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
+  typedef bf16_t T;
+  constexpr int G = 8, HALO = KS / 2, HW = TILE_W + 2 * HALO, TAPS = KS * KS;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Wsb = smem;
+  char* Xb = smem + (size_t)q.wpieces * 1024;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int co_base = blockIdx.y * (NP * 32);
+
+  // ---- weight slab, once.  LDS row (pr*32 + h*16 + j) holds output channel pr*32 + (j>>2)*8 + h*4 + (j&3): MFMA "h" of
+  // pair pr then leaves channels 8*fg + 4*h + {0..3} of the pair in lane group fg
+  {
+    const int gpr_w = q.ldw / G, wgroups = NP * 32 * gpr_w;
+    for (int piece = wave; piece < q.wpieces; piece += 4) {
+      const int pu = __builtin_amdgcn_readfirstlane(piece);
+      const int gi = pu * 64 + lane;
+      const int r = fdiv(gi, q.d_gprw), k = (gi - r * gpr_w) * G;
+      if (gi < wgroups) {
+        const int j = r & 15, h = (r >> 4) & 1, pr = r >> 5;
+        const int row = co_base + pr * 32 + (j >> 2) * 8 + h * 4 + (j & 3);
+        const T* src = (row < q.rows_pad && k < p.krow) ? (const T*)p.w + (size_t)row * p.krow + k : (const T*)g_zero16;
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Wsb + (size_t)pu * 1024), 16, 0, 0);
+      }
+    }
+  }
+
+  // ---- lane constants
+  int koff[PX_MAXKS];  // K-step -> byte offset of this lane's 8 input channels inside a tile row (tap shift included)
+  {
+    int pxo[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) pxo[dx] = pix_off(q.xt, 0, fr + (dx < KS ? dx : 0));
+#pragma unroll
+    for (int i = 0; i < PX_MAXKS; ++i) {
+      const int kidx = min(i, q.nks - 1) * 32 + fg * 8;
+      int tap = fdiv(kidx, q.d_ctot8);
+      const int c = kidx - tap * p.ctot8;
+      tap = tap < TAPS ? tap : TAPS - 1;  // columns past the last tap carry zero weights; keep the address legal
+      const int dy = tap / KS, dx = tap - dy * KS;
+      koff[i] = dy * q.xt.rowbytes + (dx == 0 ? pxo[0] : (dx == 1 ? pxo[1] : pxo[2])) + c * 2;
+    }
+  }
+  // halo DMA: lane -> (pixel inside a piece, 16-byte channel group) -> segment, element offset (see wgrad_tile_kernel)
+  const int xl = fdiv(lane, q.xt.d_gpr), xcg = lane - xl * q.xt.gpr;
+  int x_si = 0, x_off = 0;
+  const bool x_lane = xl < q.xt.ppp && xcg * G < p.ctot8;
+  bool x_data = false;
+  {
+    const int c = xcg * G;
+#pragma unroll
+    for (int k = 1; k < CGEN_MAX_SEG; ++k) x_si += (k < p.nseg && c >= p.seg_koff[k]) ? 1 : 0;
+    View sv = p.seg[0];
+    int ko = p.seg_koff[0];
+#pragma unroll
+    for (int k = 1; k < CGEN_MAX_SEG; ++k)
+      if (x_si == k) { sv = p.seg[k]; ko = p.seg_koff[k]; }
+    const int cs = c - ko;
+    x_data = x_lane && cs < sv.c;
+    x_off = (int)(xl * sv.sw) + cs;
+  }
+  const int xpieces = q.xt.rows * q.xt.ppr;
+  // epilogue: this lane owns pixel (row wave*2 + f, column fr) and channels co_base + pr*32 + fg*8 .. +8
+  const int ch0 = co_base + fg * 8;
+  int eo_out[2], eo_aux[2], eo_r1[2], eo_r2[2];  // byte offsets from the tile origin of each tensor
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int ry = wave * 2 + f;
+    eo_out[f] = (int)(ry * p.out.sh + fr * p.out.sw + ch0) * 2;
+    eo_aux[f] = (int)(ry * p.aux.sh + fr * p.aux.sw + ch0) * 2;
+    eo_r1[f] = (int)(ry * p.res1.sh + fr * p.res1.sw + ch0) * 2;
+    eo_r2[f] = (int)(ry * p.res2.sh + fr * p.res2.sw + ch0) * 2;
+  }
+  f32x4 binit[NP][2];
+#pragma unroll
+  for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int co = ch0 + pr * 32 + h * 4;
+      binit[pr][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (p.bias && co + 4 <= p.Co) { const float4 b = *(const float4*)(p.bias + co); binit[pr][h] = (f32x4){b.x, b.y, b.z, b.w}; }
+    }
+  const bool has_aux = p.aux.p != nullptr, has_r1 = p.res1.p != nullptr, has_r2 = p.res2.p != nullptr;
+  const char* a_base = Wsb + (size_t)fr * q.ldw * 2 + fg * 16;
+  const char* x_rows = Xb + (size_t)(wave * 2) * q.xt.rowbytes;
+
+  for (int t = blockIdx.x; t < q.ntiles; t += gridDim.x) {
+    // ---- tile origin: scalar
+    int b = t;
+    const int tx = b % q.tiles_x; b /= q.tiles_x;
+    const int ty = b % q.tiles_y;
+    const int n = b / q.tiles_y;
+    const int y0 = ty * TILE_H, x0 = tx * TILE_W;
+    {  // halo tile DMA (row pieces)
+      const T* my_org = vptr<T>(p.seg[0], n, y0 - HALO, x0 - HALO);
+      int64_t my_sh = p.seg[0].sh, my_swp = p.seg[0].sw * q.xt.ppp;
+      if (p.nseg > 1) {
+        if (x_si == 1) { my_org = vptr<T>(p.seg[1], n, y0 - HALO, x0 - HALO); my_sh = p.seg[1].sh; my_swp = p.seg[1].sw * q.xt.ppp; }
+        if (x_si == 2) { my_org = vptr<T>(p.seg[2], n, y0 - HALO, x0 - HALO); my_sh = p.seg[2].sh; my_swp = p.seg[2].sw * q.xt.ppp; }
+        if (x_si == 3) { my_org = vptr<T>(p.seg[3], n, y0 - HALO, x0 - HALO); my_sh = p.seg[3].sh; my_swp = p.seg[3].sw * q.xt.ppp; }
+      }
+      my_org += x_off;
+      for (int pi = wave; pi < xpieces; pi += 4) {
+        const int pu = __builtin_amdgcn_readfirstlane(pi);
+        const int hy = fdiv(pu, q.xt.d_ppr), pc = pu - hy * q.xt.ppr;
+        if (x_lane) {
+          const int hx = pc * q.xt.ppp + xl;
+          const int yy = y0 - HALO + hy, xx = x0 - HALO + hx;
+          const bool ok = x_data && hx < HW && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+          const T* src = ok ? my_org + (hy * my_sh + pc * my_swp) : (const T*)g_zero16;
+          __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Xb + pu * 1024), 16, 0, 0);  // never an LDS store between DMAs
+        }
+      }
+    }
+    // ---- epilogue operands: requested now, consumed after the MFMA loop
+    const bool colv = x0 + fr < p.W;
+    bool pv[2];
+    uint4 ea[NP][2], er[NP][2];
+    {
+      const char* aux_t = (const char*)vptr<T>(p.aux, n, y0, x0);
+      const char* r1_t = (const char*)vptr<T>(p.res1, n, y0, x0);
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        pv[f] = colv && y0 + wave * 2 + f < p.H;
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) {
+          const bool ok = pv[f] && ch0 + pr * 32 + 8 <= p.Co;
+          ea[pr][f] = make_uint4(0, 0, 0, 0);
+          er[pr][f] = make_uint4(0, 0, 0, 0);
+          if (has_aux) ea[pr][f] = *(const uint4*)(ok ? aux_t + eo_aux[f] + pr * 64 : (const char*)g_zero16);
+          if (has_r1) er[pr][f] = *(const uint4*)(ok ? r1_t + eo_r1[f] + pr * 64 : (const char*)g_zero16);
+        }
+      }
+    }
+    // ---- activation in place on the pieces this wave fetched itself (hipcc waits for the DMAs first), then hand over
+    if (p.act != CGEN_ACT_NONE && x_data) {
+      for (int pi = wave; pi < xpieces; pi += 4) {
+        uint4* ptr = (uint4*)(Xb + pi * 1024 + lane * 16);
+        *ptr = act_group<T>(*ptr, p.act);
+      }
+    }
+    __syncthreads();
+
+    // ---- MFMAs: 2 tile rows x NP*32 channels per wave, bias as the initial value
+    f32x4 acc[NP][2][2];
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[pr][h][f] = binit[pr][h];
+#pragma unroll
+    for (int i = 0; i < PX_MAXKS; ++i) {
+      if (i < q.nks) {
+        const bf16x8 b0 = *(const bf16x8*)(x_rows + koff[i]);
+        const bf16x8 b1 = *(const bf16x8*)(x_rows + q.xt.rowbytes + koff[i]);
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const bf16x8 aq = *(const bf16x8*)(a_base + (size_t)(pr * 32 + h * 16) * q.ldw * 2 + i * 64);
+            acc[pr][h][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, b0, acc[pr][h][0], 0, 0, 0);
+            acc[pr][h][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, b1, acc[pr][h][1], 0, 0, 0);
+          }
+      }
+    }
+
+    // ---- epilogue straight from the accumulators: v = acc * act'(aux) + res1 + res2 -> bf16 -> one 16-byte store
+    {
+      char* out_t = (char*)vptr<T>(p.out, n, y0, x0);
+      const char* r2_t = (const char*)vptr<T>(p.res2, n, y0, x0);
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int pr = 0; pr < NP; ++pr) {
+          if (!(pv[f] && ch0 + pr * 32 + 8 <= p.Co)) continue;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = acc[pr][0][f][e]; v[4 + e] = acc[pr][1][f][e]; }
+          if (has_aux) {
+            const uint32_t w[4] = {ea[pr][f].x, ea[pr][f].y, ea[pr][f].z, ea[pr][f].w};
+            if (p.dact == CGEN_ACT_RELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[2 * e] = bf_lo(w[e]) > 0.f ? v[2 * e] : 0.f;
+                v[2 * e + 1] = bf_hi(w[e]) > 0.f ? v[2 * e + 1] : 0.f;
+              }
+            } else if (p.dact == CGEN_ACT_GELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[2 * e] *= gelu_bwd_slow(bf_lo(w[e]));
+                v[2 * e + 1] *= gelu_bwd_slow(bf_hi(w[e]));
+              }
+            }
+          }
+          if (has_r1) {
+            const uint32_t w[4] = {er[pr][f].x, er[pr][f].y, er[pr][f].z, er[pr][f].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(w[e]); v[2 * e + 1] += bf_hi(w[e]); }
+          }
+          if (has_r2) {
+            const uint4 r = *(const uint4*)(r2_t + eo_r2[f] + pr * 64);
+            const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(w[e]); v[2 * e + 1] += bf_hi(w[e]); }
+          }
+          uint4 o;
+          o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]); o.z = f2bf_pk(v[4], v[5]); o.w = f2bf_pk(v[6], v[7]);
+          *(uint4*)(out_t + eo_out[f] + pr * 64) = o;
+        }
+    }
+    __syncthreads();  // every wave is done reading the tile before the next DMA overwrites it
+  }
+}
+
+template <int NP>
+static void launch_px_inst(const ConvP& p, const PxP& q, dim3 grid, size_t lds, hipStream_t st) {
+  if (p.KS == 3) {
+    static bool once3 = false;
+    if (!once3) { (void)hipFuncSetAttribute((const void*)conv_px_kernel<NP, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once3 = true; }
+    hipLaunchKernelGGL((conv_px_kernel<NP, 3>), grid, dim3(256), lds, st, p, q);
+  } else {
+    static bool once1 = false;
+    if (!once1) { (void)hipFuncSetAttribute((const void*)conv_px_kernel<NP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once1 = true; }
+    hipLaunchKernelGGL((conv_px_kernel<NP, 1>), grid, dim3(256), lds, st, p, q);
+  }
+}
+
+static inline bool fits_i32(const View& v, int n, int h, int w) {
+  if (!v.p) return true;
+  const int64_t ext = (int64_t)n * v.sn + (int64_t)h * v.sh + (int64_t)w * v.sw + v.c;
+  return ext * 2 < ((int64_t)1 << 31);
+}
+
+static bool launch_conv_px(const ConvP& p, hipStream_t st) {
+  const int G = 8, halo = p.KS / 2;
+  PxP q;
+  memset(&q, 0, sizeof(q));
+  q.nks = ceil_div(p.taps * p.ctot8, 32);
+  if (q.nks > PX_MAXKS || p.Co % 8 != 0 || !p.epi_vec16) return false;
+  if (!fits_i32(p.out, 1, TILE_H, TILE_W) || !fits_i32(p.aux, 1, TILE_H, TILE_W) || !fits_i32(p.res1, 1, TILE_H, TILE_W) || !fits_i32(p.res2, 1, TILE_H, TILE_W)) return false;
+  q.xt = mk_pixtile(p.ctot8, 2, TILE_H + 2 * halo, TILE_W + 2 * halo);
+  if (q.xt.ppp < 1) return false;
+  q.ldw = lds_stride(q.nks * 32, 2);  // <= ceil32(K) + 16 <= krow
+  q.rows_pad = pad_to(p.Co, 16);
+  q.tiles_x = ceil_div(p.W, TILE_W); q.tiles_y = ceil_div(p.H, TILE_H);
+  q.ntiles = p.N * q.tiles_x * q.tiles_y;
+  // channel pairs per workgroup: as many as keep three workgroups per CU (LDS) -- fewer re-reads of the input tile --
+  // but small launches are split further so every CU has work
+  const int np_all = ceil_div(p.Co, 32);
+  int np = np_all < 4 ? np_all : 4;
+  auto lds_of = [&](int n_) { return (size_t)ceil_div(n_ * 32 * (q.ldw / G), 64) * 1024 + (size_t)q.xt.bytes; };
+  while (np > 1 && lds_of(np) > 52 * 1024) --np;
+  if (np == 3 && np_all == 4) np = 2;
+  while (np > 1 && (int64_t)q.ntiles * ceil_div(np_all, np) < 512) --np;
+  const size_t lds = lds_of(np);
+  if (lds > 150 * 1024) return false;
+  q.wpieces = ceil_div(np * 32 * (q.ldw / G), 64);
+  q.d_gprw = mk_fastdiv(q.ldw / G); q.d_ctot8 = mk_fastdiv(p.ctot8);
+  const int parts = ceil_div(np_all, np);
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 3) per_cu = 3;
+  if (per_cu < 1) per_cu = 1;
+  int gx = 256 * per_cu / parts;
+  if (gx < 1) gx = 1;
+  if (gx > q.ntiles) gx = q.ntiles;
+  dim3 grid(gx, parts);
+  switch (np) {
+    case 1: launch_px_inst<1>(p, q, grid, lds, st); break;
+    case 2: launch_px_inst<2>(p, q, grid, lds, st); break;
+    case 3: launch_px_inst<3>(p, q, grid, lds, st); break;
+    case 4: launch_px_inst<4>(p, q, grid, lds, st); break;
+    default: return false;
+  }
+  return true;
+}
+
 // ============================================================================= weight-stationary persistent conv (bf16)
 // fwd / dgrad for KS in {1,3} on >= 5x5 images.  The forward kernel above re-stages the weight slab in LDS for every
 // 128-pixel tile (for a 96->24 3x3 conv that is 55 KB of weights per 25 KB of activations).  Here the K axis
@@ -1153,6 +1538,7 @@ struct WsP {
   int tiles_x, tiles_y, ntiles, nk;  // nk = K-steps that carry weights
   int rows_pad, red_bytes, dbg, pad0;
   FastDiv d_ctot8;
+  unsigned long long* stamps;  // optional (CGEN_WS_STAMPS): per-phase cycle stamps of workgroup 0
 };
 
 template <int NTC, int NKW>
@@ -1217,6 +1603,13 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
     x_off = (int)(xl * sv.sw) + cs;
   }
   const int xpieces = q.xt.rows * q.xt.ppr;
+  Bias8 ebias;  // CPP divides 64: a lane's chunk (=> bias) is the same for every k and every tile
+  ebias.b0 = ebias.b1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.epi_vec16 && co_base + (lane % (NTC * 2)) * 8 + 8 <= p.Co) bias8_load(p, co_base + (lane % (NTC * 2)) * 8, ebias);
+  const bool stamp = q.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+  int nst = 0;
+#define WS_STAMP() do { if (stamp && nst < 60) q.stamps[nst++] = __builtin_readcyclecounter(); } while (0)
+  WS_STAMP();
 
   for (int t = blockIdx.x; t < q.ntiles; t += gridDim.x) {
     int b = t;
@@ -1247,7 +1640,22 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
         }
       }
     }
+    // epilogue operands of this tile (see Epi8): in flight with the halo DMA
+    constexpr int COT_ = NTC * 16, CPP_ = COT_ / 8;
+    Epi8 epl[NTC];
+    bool efast[NTC];
+#pragma unroll
+    for (int k = 0; k < NTC; ++k) {
+      const int idx = lane + 64 * k;
+      const int pl = idx / CPP_, ch = idx % CPP_;
+      const int py = y0 + wave * 2 + (pl >> 4), px = x0 + (pl & 15);
+      const int co = co_base + ch * 8;
+      efast[k] = py < p.H && px < p.W && p.epi_vec16 && co + 8 <= p.Co && !(q.dbg & 8);
+      if (efast[k]) epi8_load(p, n, py, px, co, epl[k]);
+    }
+    WS_STAMP();
     __syncthreads();  // hipcc waits vmcnt(0) here: the tile has landed
+    WS_STAMP();
     if (p.act != CGEN_ACT_NONE && !(q.dbg & 2)) {
       if (x_data) {
         for (int pi = wave; pi < xpieces; pi += 4) {
@@ -1257,6 +1665,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
       }
       __syncthreads();
     }
+    WS_STAMP();
     // ---- MFMAs: this wave's K-steps x all 8 tile rows
     f32x4 acc[NTC][TILE_H];
 #pragma unroll
@@ -1276,6 +1685,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
       }
     }
     __syncthreads();  // everyone is done reading the tile: its LDS is reused for the partial sums
+    WS_STAMP();
     {
       f32x4* red = (f32x4*)smem + (size_t)wave * NF * 64 + lane;
 #pragma unroll
@@ -1305,12 +1715,16 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
         const int py = y0 + f, px = x0 + pxl;
         if (py < p.H && px < p.W) {
           float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          conv_epilogue8_bf16(p, v, n, py, px, co_base + ch * 8);
+          if (efast[k]) epi8_finish(p, v, epl[k], ebias, n, py, px, co_base + ch * 8);
+          else conv_epilogue8_bf16(p, v, n, py, px, co_base + ch * 8);
         }
       }
     }
     __syncthreads();  // partial sums consumed before the next tile's DMA overwrites them
+    WS_STAMP();
   }
+  if (stamp) q.stamps[63] = nst;
+#undef WS_STAMP
 }
 
 template <int NTC, int NKW>
@@ -1341,6 +1755,7 @@ static bool launch_conv_ws(const ConvP& p, hipStream_t st) {
   q.rows_pad = pad_to(p.Co, 16);
   q.d_ctot8 = mk_fastdiv(p.ctot8);
   { const char* e = getenv("CGEN_WS_DBG"); q.dbg = e ? atoi(e) : 0; }
+  { const char* e = getenv("CGEN_WS_STAMPS"); q.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
   const int grid_y = ceil_div(p.Co, ntc * 16);
   // measured on MI355X: the register-resident weights pay off when every wave owns >= 3 K-steps and the halo tile is
   // re-staged for at most nkw/2 output-channel tiles; short-K / wide-output (expanding) convs stay on the tile kernel

@@ -10,6 +10,7 @@ sequence with fixed addresses and can be captured in a hipGraph.
 PyTorch supplies device memory, streams and the nn.Module parameter containers only.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -143,6 +144,11 @@ class Engine:
         self.rng = None
         self.launches = 0
         self.prof = None  # {"conv_fwd": [flops, [(ev0, ev1), ...]], ...} when profiling is on
+        # weight-gradient kernels are leaves of the backward graph: they run on a second HIP stream (forked per launch,
+        # joined before the split-K reduction) so they fill the CUs the latency-bound dgrad chain leaves idle
+        self.overlap_wgrad = os.environ.get("CGEN_WGRAD_STREAM", "1") != "0"
+        self.side = None
+        self._side_busy = False
 
     # ------------------------------------------------------------------ memory
     def begin(self):
@@ -154,6 +160,7 @@ class Engine:
         self.pgrad_init = set()
         self._pnhwc, self._pgrad_tmp = {}, {}
         self._adopted = set()
+        self._side_busy = False
         self.passes = 0
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
 
@@ -489,13 +496,27 @@ class Engine:
             out.append((cur, b))
         return out
 
-    def grad_write(self, t):
+    def _join_side(self):
+        """Main stream waits for everything enqueued on the weight-gradient stream."""
+        if self._side_busy:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self._side_busy = False
+
+    def _side_hazard(self, t):
+        """True when accumulating into grad(t) in place could race with a weight-gradient kernel on the side stream:
+        only ADOPTED buffers (see _grad_residual) are ever written after their producer's wgrad was enqueued."""
+        e = self.grads.get(id(t.base))
+        return self._side_busy and e is not None and id(e[0]) in self._adopted
+
+    def grad_write(self, t, defer_hazard=False):
         """Gradient view for `t` plus whether it already holds a value (=> the writer must accumulate)."""
         assert t.rg
         g, ivs, base = self._gentry(t.base)
         a, b = t.coff, t.coff + t.c
         miss = self._missing(ivs, a, b)
         gv = g.chan(a, b)
+        if miss != [(a, b)] and not defer_hazard and self._side_hazard(t):
+            self._join_side()
         if not miss:
             return gv, True
         if miss == [(a, b)]:
@@ -573,7 +594,17 @@ class Engine:
         for k, s in enumerate(segs):
             if not (s.rg and site.seg_rg[k]):
                 continue
-            gv, acc = self.grad_write(s)
+            gv, acc = self.grad_write(s, defer_hazard=True)
+            prev = gv
+            if acc and self._side_hazard(s):
+                # grad(s) lives in an adopted buffer a side-stream wgrad may still be reading: accumulate OUT of place
+                # (same traffic: the kernel reads `prev` as a residual either way) instead of stalling the main stream
+                if s.base is s:
+                    e = self.grads[id(s)]
+                    e[0] = self.new(s.n, s.h, s.w, s.c, rg=False)
+                    gv = e[0].chan(0, s.c)
+                else:
+                    self._join_side()
             a = _lib.ConvArgs()
             a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = self.dt, x0.n, x0.h, x0.w, site.ks, 1, ACT_NONE, act
             a.seg[0] = g.cv()
@@ -581,7 +612,7 @@ class Engine:
             a.bias = None
             a.out = gv.cv()
             a.aux = s.cv() if act != ACT_NONE else NULL_VIEW
-            a.res1 = gv.cv() if acc else NULL_VIEW
+            a.res1 = prev.cv() if acc else NULL_VIEW
             a.res2 = NULL_VIEW
             self._timed("conv_dgrad", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream), ci=s.c)
 
@@ -605,10 +636,19 @@ class Engine:
         a.nsplit = nsplit
         a.partial_w = buf.data_ptr()
         a.partial_b = buf.data_ptr() + 4 * nsplit * nw if site.conv.bias is not None else None
-        self._timed("conv_wgrad", site, x0, lambda: self.lib.conv2d_wgrad(C.byref(a), self.stream))
+        if self.overlap_wgrad and self.prof is None:
+            if self.side is None:
+                self.side = torch.cuda.Stream(self.device)
+            self.side.wait_stream(torch.cuda.current_stream(self.device))  # fork: everything enqueued so far is visible
+            self._side_busy = True
+            self.launches += 1
+            self.lib.conv2d_wgrad(C.byref(a), self.side.cuda_stream)
+        else:
+            self._timed("conv_wgrad", site, x0, lambda: self.lib.conv2d_wgrad(C.byref(a), self.stream))
         self._wg_events.append((site, key, nsplit))
 
     def _reduce_wgrads(self):
+        self._join_side()
         if not self._wg_events:
             return
         sig = tuple(k for _, k, _ in self._wg_events)

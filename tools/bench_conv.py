@@ -27,6 +27,7 @@ def main():
     iters = int(os.environ.get("ITERS", "20"))
     convs = [torch.nn.Conv2d(sum(s[2]), s[3], s[4], padding=s[4] // 2) for s in SHAPES]
     eng = Engine("cuda", dtype)
+    eng.overlap_wgrad = False  # single launches are timed here; no fork/join
     holder = torch.nn.ModuleList(convs).cuda()
     sites = [ConvSite(f"c{i}", c, s[2], [True] * len(s[2]), i) for i, (c, s) in enumerate(zip(holder, SHAPES))]
     eng.bind(holder, sites)
@@ -66,6 +67,18 @@ def main():
         if kind in ("fwd", "all"):
             y = eng.conv(site, xs, 1)
             res["fwd"] = timed(lambda: eng.conv(site, xs, 1, out=y))
+            if os.environ.get("STAMPS"):
+                st = torch.zeros(64, dtype=torch.int64, device="cuda")
+                os.environ["CGEN_WS_STAMPS"] = hex(st.data_ptr())
+                eng.conv(site, xs, 1, out=y)
+                torch.cuda.synchronize()
+                del os.environ["CGEN_WS_STAMPS"]
+                v = st.cpu().tolist()
+                n = v[63]
+                d = [v[i + 1] - v[i] for i in range(n - 1)]
+                if n:
+                    print("   ws stamps(cycles) per tile [issue, wait, act, mfma, reduce+epilogue]: %s" % (
+                        [d[k * 5:k * 5 + 5] for k in range((n - 1) // 5)]))
         if kind in ("wgrad", "all"):
             g = eng.new(N, R, R, Co)
             eng.fill(g, 0.25)
