@@ -75,7 +75,9 @@ static inline bool vec16_ok(const cgen_view& v, int esz) {
 static inline bool dma_clean(const cgen_view& v, int esz) {
   const int G = 16 / esz;
   const int cg = (v.c + G - 1) / G * G;
-  return vec16_ok(v, esz) && (v.c % G == 0 || v.cpad >= cg);
+  // the tiled kernels form per-lane offsets inside a tile with 24-bit multiplies (row stride, 64-pixel stride)
+  const bool small_strides = v.sh >= 0 && v.sw >= 0 && v.sh < (1 << 24) && v.sw * 64 < (1 << 24);
+  return vec16_ok(v, esz) && (v.c % G == 0 || v.cpad >= cg) && small_strides;
 }
 
 // ----------------------------------------------------------------------------- activations (vae.py:50,59)

@@ -32,8 +32,7 @@ static inline FastDiv mk_fastdiv(uint32_t d) {
   return f;
 }
 // q = (umulhi(n, mul) + n) >> shift   (the "add" variant keeps mul in 32 bits)
-__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
-  if (f.d == 1) return n;
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {  // d == 1: mul = shift = 0 -> n (no branch)
   return (int)(((uint64_t)__umulhi((uint32_t)n, f.mul) + (uint32_t)n) >> f.shift);
 }
 
@@ -398,18 +397,32 @@ struct TileP {
 __device__ uint4 g_zero16[4];  // 64 bytes of zeros: DMA source for out-of-image / padding groups
 
 // in-register activation of one 16-byte group
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 template <typename T>
 __device__ __forceinline__ uint4 act_group(uint4 v, int act) {
   constexpr int G = 16 / sizeof(T);
   Pack<T, G> tv;
   tv.v4 = v;
   if constexpr (sizeof(T) == 2) {
-    if (act == CGEN_ACT_RELU) {  // bf16 ReLU on packed pairs: clear every half whose sign bit is set
+    if (act == CGEN_ACT_RELU) {
+      // bf16 ReLU == signed 16-bit max(x, 0) on the raw bits (negative floats have the sign bit set): one v_pk_max_i16
+      // per channel pair.  (-0.0 -> +0.0; a NaN with the sign bit set becomes 0, torch keeps it -- not reachable here)
+      union { uint32_t u; s16x2 s; } c;
       uint32_t* w = (uint32_t*)&tv.v4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] &= ~(((w[e] >> 15) & 0x00010001u) * 0xFFFFu);
+      for (int e = 0; e < 4; ++e) {
+        c.u = w[e];
+        c.s = __builtin_elementwise_max(c.s, (s16x2){0, 0});
+        w[e] = c.u;
+      }
       return tv.v4;
     }
+    if (act == CGEN_ACT_GELU) {
+#pragma unroll
+      for (int e = 0; e < G; ++e) tv.e[e] = Elem<T>::to(gelu_fwd_slow(Elem<T>::ld(&tv.e[e])));
+      return tv.v4;
+    }
+    return v;
   }
 #pragma unroll
   for (int e = 0; e < G; ++e) tv.e[e] = Elem<T>::to(act_fwd(act, Elem<T>::ld(&tv.e[e])));
@@ -654,21 +667,29 @@ static bool launch_conv_ws(const ConvP& p, hipStream_t st);  // weight-stationar
 static bool launch_conv_px(const ConvP& p, hipStream_t st);  // lean persistent kernel for short-K convs (bf16), defined below
 #define PX_MAXKS 16
 
+static void conv_trace(const ConvP& p, const char* which) {  // CGEN_CONV_TRACE=1: which kernel served which shape
+  static const bool on = getenv("CGEN_CONV_TRACE") != nullptr;
+  if (on) fprintf(stderr, "conv %-5s ks%d ci8 %-4d co %-4d res %-3d nseg %d act %d aux %d res %d%d\n", which, p.KS, p.ctot8, p.Co, p.H, p.nseg, p.act,
+                  p.aux.p != nullptr, p.res1.p != nullptr, p.res2.p != nullptr);
+}
+
 template <typename T>
 static int launch_conv(const ConvP& p, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     if ((p.KS == 1 || p.KS == 3) && p.H >= 5 && p.W >= 5 && p.dma_ok && !p.force_generic && !getenv("CGEN_CONV_NO_PX")) {
       const int nks = ceil_div(p.taps * p.ctot8, 32);
       const bool expanding = nks <= PX_MAXKS && p.Co >= 2 * p.ctot8;  // short K, wide output
-      if ((expanding || getenv("CGEN_CONV_FORCE_PX")) && launch_conv_px(p, st)) return check_launch("cgen_conv2d(px)");
+      static const int px_mode = [] { const char* e = getenv("CGEN_PX_MODE"); return e ? atoi(e) : 2; }();  // 0: expanding only, 1: +1x1, 2: everything with a short K
+      const bool take = expanding || (px_mode >= 1 && p.KS == 1 && nks <= PX_MAXKS) || (px_mode >= 2 && nks <= PX_MAXKS);
+      if (take && launch_conv_px(p, st)) { conv_trace(p, "px"); return check_launch("cgen_conv2d(px)"); }
     }
     if ((p.KS == 1 || p.KS == 3) && p.H >= 5 && p.W >= 5 && p.dma_ok && !p.force_generic && !getenv("CGEN_CONV_NO_WS")) {
-      if (launch_conv_ws(p, st)) return check_launch("cgen_conv2d(ws)");
+      if (launch_conv_ws(p, st)) { conv_trace(p, "ws"); return check_launch("cgen_conv2d(ws)"); }
     }
   }
   if ((p.KS == 1 || p.KS == 3) && p.H >= 5 && p.W >= 5 && !p.force_generic && p.dma_ok) {
     const bool ok = p.KS == 3 ? launch_conv_tile<T, 3>(p, st) : launch_conv_tile<T, 1>(p, st);
-    if (ok) return check_launch("cgen_conv2d(tile)");
+    if (ok) { conv_trace(p, "tile"); return check_launch("cgen_conv2d(tile)"); }
   }
   dim3 block(256);
   const int px_tiles = ceil_div(p.P, CONV_PT);
@@ -679,6 +700,7 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   } else {
     hipLaunchKernelGGL((conv_kernel<T, 4>), dim3(px_tiles, ceil_div(p.Co, 64)), block, 0, st, p);
   }
+  conv_trace(p, "gen");
   return check_launch("cgen_conv2d");
 }
 
@@ -893,6 +915,37 @@ __device__ __forceinline__ int pix_off(const PixTile& t, int row, int x) {
   return row * t.rowbytes + pc * 1024 + (x - pc * t.ppp) * t.gpr * 16;
 }
 
+// ---- lean row-piece DMA of one tile (shared by the persistent kernels).  Everything tile-invariant about a lane lives in
+// LaneTile (built once per kernel); per piece the wave spends ~10 VALU + ~12 SALU: the piece walk (hy, pc) is scalar and
+// incremental, offsets are 24-bit multiplies, the image box is given in TILE coordinates.
+struct LaneTile {
+  int xl;       // pixel of this lane inside a piece
+  int sh, swp;  // element strides of this lane's source per tile row / per piece (ppp pixels); < 2^24 (dma_clean)
+  bool lane;    // lane maps to a slot of the piece
+  bool data;    // ... and the slot carries real channels
+};
+// `org`: this lane's source for (tile row 0, piece 0), lane pixel / channel offset included.  Rows [ry0, ry1) and columns
+// [cx0, cx1) of the tile lie inside the image (and inside the tile's own pixel extent); everything else reads zeros.
+// `wave` must be wave-uniform (readfirstlane).  No LDS store may sit between two DMAs (hipcc would drain vmcnt).
+template <typename T>
+__device__ __forceinline__ void dma_tile(const PixTile& xt, const LaneTile& L, const T* org, char* buf, int wave, int ry0, int ry1,
+                                         int cx0, int cx1) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  const int npieces = xt.rows * xt.ppr;
+  int hy = fdiv(wave, xt.d_ppr), pc = wave - hy * xt.ppr;
+  for (int pi = wave; pi < npieces; pi += 4) {
+    if (L.lane) {
+      const int hx = pc * xt.ppp + L.xl;
+      const bool ok = L.data && hy >= ry0 && hy < ry1 && hx >= cx0 && hx < cx1;
+      const T* src = ok ? org + (int)(__umul24(hy, L.sh) + __umul24(pc, L.swp)) : (const T*)g_zero16;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(buf + pi * 1024), 16, 0, 0);
+    }
+    pc += 4;
+    while (pc >= xt.ppr) { pc -= xt.ppr; ++hy; }
+  }
+}
+
 struct Wg2P {
   int N, H, W, KS, nseg, act, Co, taps, ci_total, ctot8;
   View seg[CGEN_MAX_SEG];
@@ -931,7 +984,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
   char* Xb = smem;
   char* Gb = smem + p.xt.bytes;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int sp = blockIdx.x;
   const int cA = blockIdx.y * p.cwin;
   const int cw = min(p.cwin, p.ctot8 - cA);      // multiple of 8
@@ -977,47 +1030,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
   const int g_off = (int)(gl * p.gout.sw) + co_base + gcg * G;
   const int xpieces = p.xt.rows * p.xt.ppr, gpieces = p.gt.rows * p.gt.ppr;
 
+  LaneTile LX, LG;
+  {
+    LX.xl = xl; LX.lane = x_lane; LX.data = x_data;
+    LX.sh = (int)p.seg[0].sh; LX.swp = (int)(p.seg[0].sw * p.xt.ppp);
+#pragma unroll
+    for (int k = 1; k < CGEN_MAX_SEG; ++k)
+      if (x_si == k) { LX.sh = (int)p.seg[k].sh; LX.swp = (int)(p.seg[k].sw * p.xt.ppp); }
+    LG.xl = gl; LG.lane = g_lane; LG.data = g_data;
+    LG.sh = (int)p.gout.sh; LG.swp = (int)(p.gout.sw * p.gt.ppp);
+  }
   auto issue_tile = [&](int t) {
     int b = t;
     const int tx = b % p.tiles_x; b /= p.tiles_x;
     const int ty = b % p.tiles_y;
     const int n = b / p.tiles_y;
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
-    const T* org0 = vptr<T>(p.seg[0], n, y0 - HALO, x0 - HALO);
-    const T* org1 = p.nseg > 1 ? vptr<T>(p.seg[1], n, y0 - HALO, x0 - HALO) : org0;
-    const T* org2 = p.nseg > 2 ? vptr<T>(p.seg[2], n, y0 - HALO, x0 - HALO) : org0;
-    const T* org3 = p.nseg > 3 ? vptr<T>(p.seg[3], n, y0 - HALO, x0 - HALO) : org0;
-    const T* my_org = org0;  // this lane's segment
-    int64_t my_sh = p.seg[0].sh, my_swp = p.seg[0].sw * p.xt.ppp;
+    const T* my_org = vptr<T>(p.seg[0], n, y0 - HALO, x0 - HALO);  // this lane's segment
     if (p.nseg > 1) {
-      if (x_si == 1) { my_org = org1; my_sh = p.seg[1].sh; my_swp = p.seg[1].sw * p.xt.ppp; }
-      if (x_si == 2) { my_org = org2; my_sh = p.seg[2].sh; my_swp = p.seg[2].sw * p.xt.ppp; }
-      if (x_si == 3) { my_org = org3; my_sh = p.seg[3].sh; my_swp = p.seg[3].sw * p.xt.ppp; }
+      if (x_si == 1) my_org = vptr<T>(p.seg[1], n, y0 - HALO, x0 - HALO);
+      if (x_si == 2) my_org = vptr<T>(p.seg[2], n, y0 - HALO, x0 - HALO);
+      if (x_si == 3) my_org = vptr<T>(p.seg[3], n, y0 - HALO, x0 - HALO);
     }
-    my_org += x_off;
-    for (int pi = wave; pi < xpieces; pi += 4) {
-      const int pu = __builtin_amdgcn_readfirstlane(pi);
-      const int hy = fdiv(pu, p.xt.d_ppr), pc = pu - hy * p.xt.ppr;
-      if (x_lane) {
-        const int hx = pc * p.xt.ppp + xl;
-        const int yy = y0 - HALO + hy, xx = x0 - HALO + hx;
-        const bool ok = x_data && hx < HW && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-        const T* src = ok ? my_org + (hy * my_sh + pc * my_swp) : (const T*)g_zero16;
-        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Xb + pu * 1024), 16, 0, 0);  // never an LDS store between DMAs
-      }
-    }
-    const T* orgg = vptr<T>(p.gout, n, y0, x0) + g_off;
-    const int64_t g_swp = p.gout.sw * p.gt.ppp;
-    for (int pi = wave; pi < gpieces; pi += 4) {
-      const int pu = __builtin_amdgcn_readfirstlane(pi);
-      const int py = fdiv(pu, p.gt.d_ppr), pc = pu - py * p.gt.ppr;
-      if (g_lane) {
-        const int pxx = pc * p.gt.ppp + gl;
-        const bool ok = g_data && pxx < TILE_W && y0 + py < p.H && x0 + pxx < p.W;
-        const T* src = ok ? orgg + (py * p.gout.sh + pc * g_swp) : (const T*)g_zero16;
-        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Gb + pu * 1024), 16, 0, 0);
-      }
-    }
+    dma_tile<T>(p.xt, LX, my_org + x_off, Xb, wave, max(0, HALO - y0), min(HH, p.H + HALO - y0), max(0, HALO - x0), min(HW, p.W + HALO - x0));
+    dma_tile<T>(p.gt, LG, vptr<T>(p.gout, n, y0, x0) + g_off, Gb, wave, 0, min(TILE_H, p.H - y0), 0, min(TILE_W, p.W - x0));
   };
   // in-place activation of the staged halo tile: every lane re-visits the groups it DMA'd (same piece mapping)
   auto act_pass = [&]() {
@@ -1033,13 +1069,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
   const int krow = g >> 1, kx = (g & 1) * 8 + r;  // this lane's FIRST read inside a 2-row K-step: pixel (row, x); second: x + 4
   // tile-independent LDS byte offsets of this lane's two reads per (tap, channel group) fragment
   int xo0[NJW], xo1[NJW];
+  int jtap[NJW], jcb[NJW];  // (tap, first channel of the 16-channel group) of fragment j of this wave; wave-uniform
+  {
+    int tapw = wave / cgrp, gw = wave - tapw * cgrp;  // fragment jf = wave + 4j  ->  (tap, group), walked incrementally
 #pragma unroll
-  for (int j = 0; j < NJW; ++j) {
-    const int jf = min(wave + 4 * j, njf - 1);  // waves short of a fragment compute a duplicate that is never written out
-    const int tap = jf / cgrp, cb = (jf - tap * cgrp) * 16;
-    const int dy = tap / KS, dx = tap % KS;
-    xo0[j] = pix_off(p.xt, krow + dy, kx + dx) + (cb + qd * 4) * 2;
-    xo1[j] = pix_off(p.xt, krow + dy, kx + dx + 4) + (cb + qd * 4) * 2;
+    for (int j = 0; j < NJW; ++j) {
+      const int tap = tapw < TAPS ? tapw : TAPS - 1;  // waves short of a fragment compute a duplicate that is never written out
+      const int cb = tapw < TAPS ? gw * 16 : 0;
+      jtap[j] = tap; jcb[j] = cb;
+      const int dy = tap / KS, dx = tap % KS;
+      xo0[j] = pix_off(p.xt, krow + dy, kx + dx) + (cb + qd * 4) * 2;
+      xo1[j] = pix_off(p.xt, krow + dy, kx + dx + 4) + (cb + qd * 4) * 2;
+      gw += 4;
+      while (gw >= cgrp) { gw -= cgrp; ++tapw; }
+    }
   }
   const int nj_eff = (njf + 3) >> 2;  // fragments per wave, the same for all four waves
   const int go0 = pix_off(p.gt, krow, kx) + qd * 8, go1 = pix_off(p.gt, krow, kx + 4) + qd * 8;
@@ -1096,51 +1139,34 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
     WG2_STAMP();
   }
 
-  // ---- write the partial slab through LDS so the stores are coalesced (rows of `cw` consecutive f32 per (co, tap));
-  // straight from the MFMA layout this tail cost more cycles than a whole tile (432 scattered 4-byte stores per wave).
+  // ---- write the partial slab straight from the accumulators.  Lane (g, t16) of fragment (a, j) holds
+  // D[co = a*16 + 4g + e][ci = cb_j + t16]: 16 consecutive input channels = one 64-byte run per (co, tap).  Everything
+  // but a per-lane constant is wave-uniform, so a store costs no address arithmetic: what made this tail expensive
+  // before was 64-bit index math per store, not the stores.
   {
-    float* stage = (float*)smem;  // [16 co][TAPS][cw16] per co-fragment
-    const int q4 = cw16 >> 2;     // float4 groups per row
-    const int ngroups = 16 * TAPS * q4;
-    const bool one_seg_vec = p.nseg == 1 && (p.ci_total & 3) == 0 && (cA & 3) == 0;
+    // this lane's real input-channel index for fragment j (8-granular concat index -> segment -> OIHW channel), -1: padding
+    const int cl = cA + t16;
+    float* pw_lane = p.pw + ((size_t)sp * p.Co + co_base + g * 4) * TAPS * p.ci_total;
 #pragma unroll
-    for (int a = 0; a < NCF; ++a) {
-      __syncthreads();  // previous users of the LDS region are done
+    for (int j = 0; j < NJW; ++j) {
+      const int jf = wave + 4 * j;
+      if (jf < njf) {
+        const int c = cl + jcb[j];
+        int sidx = 0;
 #pragma unroll
-      for (int j = 0; j < NJW; ++j) {
-        const int jf = wave + 4 * j;
-        if (jf < njf) {
-          const int tap = jf / cgrp, cb = (jf - tap * cgrp) * 16;
+        for (int k = 1; k < CGEN_MAX_SEG; ++k) sidx += (k < p.nseg && c >= p.seg_koff[k]) ? 1 : 0;
+        int koff = p.seg_koff[0], segc = p.seg[0].c, soff = p.seg_off[0];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) stage[(((lane >> 4) * 4 + e) * TAPS + tap) * cw16 + cb + (lane & 15)] = acc[a][j][e];
-        }
-      }
-      __syncthreads();
-      for (int idx = tid; idx < ngroups; idx += 256) {
-        const int r = idx / q4, c4 = (idx - r * q4) * 4;
-        const int col = r / TAPS, tap = r - col * TAPS;
-        const int co = co_base + a * 16 + col;
-        if (co >= p.Co || c4 >= cw) continue;
-        const float4 v = *(const float4*)(stage + r * cw16 + c4);
-        float* row = p.pw + (((size_t)sp * p.Co + co) * TAPS + tap) * p.ci_total;
-        if (one_seg_vec && cA + c4 + 4 <= p.seg[0].c) {
-          *(float4*)(row + cA + c4) = v;
-        } else {
-          const float vv[4] = {v.x, v.y, v.z, v.w};
+        for (int k = 1; k < CGEN_MAX_SEG; ++k)
+          if (sidx == k) { koff = p.seg_koff[k]; segc = p.seg[k].c; soff = p.seg_off[k]; }
+        const int cs = c - koff;
+        const bool cv = jcb[j] + t16 < cw && cs < segc;
+        float* col = pw_lane + jtap[j] * p.ci_total + soff + cs;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int c = cA + c4 + e;
-            int sidx = 0;
+        for (int a = 0; a < NCF; ++a)
 #pragma unroll
-            for (int k = 1; k < CGEN_MAX_SEG; ++k) sidx += (k < p.nseg && c >= p.seg_koff[k]) ? 1 : 0;
-            int koff = p.seg_koff[0], segc = p.seg[0].c, soff = p.seg_off[0];
-#pragma unroll
-            for (int k = 1; k < CGEN_MAX_SEG; ++k)
-              if (sidx == k) { koff = p.seg_koff[k]; segc = p.seg[k].c; soff = p.seg_off[k]; }
-            const int cs = c - koff;
-            if (c4 + e < cw && cs < segc) row[soff + cs] = vv[e];
-          }
-        }
+          for (int e = 0; e < 4; ++e)
+            if (cv && co_base + a * 16 + g * 4 + e < p.Co) col[(size_t)(a * 16 + e) * TAPS * p.ci_total] = acc[a][j][e];
       }
     }
   }
@@ -1181,16 +1207,12 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
   }
   if (g.gt.ppp < 1) return false;
   g.lds = (size_t)g.xt.bytes + g.gt.bytes;
-  {
-    const size_t stage = (size_t)16 * taps * pad_to(cwin, 16) * 4;  // coalesced partial write-out (one co-fragment at a time)
-    if (stage > g.lds) g.lds = stage;
-    if (g.lds > 80 * 1024) return false;
-  }
   g.cwin = cwin;
   g.n_cwin = ceil_div(ctot8, cwin);
   g.tiles_x = ceil_div(W, TILE_W); g.tiles_y = ceil_div(H, TILE_H);
   g.ntiles = N * g.tiles_x * g.tiles_y;
-  int want = ceil_div(512, g.n_cwin * g.n_co);  // two persistent workgroups per CU
+  static const int want_total = [] { const char* e = getenv("CGEN_WG2_WANT"); return e ? atoi(e) : 512; }();
+  int want = ceil_div(want_total, g.n_cwin * g.n_co);  // two persistent workgroups per CU
   {  // bound the split-K partials of one conv (they are written and re-read by cgen_wgrad_reduce)
     const char* e = getenv("CGEN_WG2_PARTIAL_MB");
     const long cap = (e ? atol(e) : 4096) << 20;  // off by default: capping costs more wgrad time than it saves in the reduce
@@ -1255,7 +1277,7 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
   char* Wsb = smem;
   char* Xb = smem + (size_t)q.wpieces * 1024;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
   const int co_base = blockIdx.y * (NP * 32);
 
@@ -1284,7 +1306,9 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
     for (int dx = 0; dx < 3; ++dx) pxo[dx] = pix_off(q.xt, 0, fr + (dx < KS ? dx : 0));
 #pragma unroll
     for (int i = 0; i < PX_MAXKS; ++i) {
-      const int kidx = min(i, q.nks - 1) * 32 + fg * 8;
+      koff[i] = 0;
+      if (i >= q.nks) continue;
+      const int kidx = i * 32 + fg * 8;
       int tap = fdiv(kidx, q.d_ctot8);
       const int c = kidx - tap * p.ctot8;
       tap = tap < TAPS ? tap : TAPS - 1;  // columns past the last tap carry zero weights; keep the address legal
@@ -1311,6 +1335,14 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
     x_off = (int)(xl * sv.sw) + cs;
   }
   const int xpieces = q.xt.rows * q.xt.ppr;
+  LaneTile LX;
+  {
+    LX.xl = xl; LX.lane = x_lane; LX.data = x_data;
+    LX.sh = (int)p.seg[0].sh; LX.swp = (int)(p.seg[0].sw * q.xt.ppp);
+#pragma unroll
+    for (int k = 1; k < CGEN_MAX_SEG; ++k)
+      if (x_si == k) { LX.sh = (int)p.seg[k].sh; LX.swp = (int)(p.seg[k].sw * q.xt.ppp); }
+  }
   // epilogue: this lane owns pixel (row wave*2 + f, column fr) and channels co_base + pr*32 + fg*8 .. +8
   const int ch0 = co_base + fg * 8;
   int eo_out[2], eo_aux[2], eo_r1[2], eo_r2[2];  // byte offsets from the tile origin of each tensor
@@ -1344,24 +1376,12 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
     {  // halo tile DMA (row pieces)
       const T* my_org = vptr<T>(p.seg[0], n, y0 - HALO, x0 - HALO);
-      int64_t my_sh = p.seg[0].sh, my_swp = p.seg[0].sw * q.xt.ppp;
       if (p.nseg > 1) {
-        if (x_si == 1) { my_org = vptr<T>(p.seg[1], n, y0 - HALO, x0 - HALO); my_sh = p.seg[1].sh; my_swp = p.seg[1].sw * q.xt.ppp; }
-        if (x_si == 2) { my_org = vptr<T>(p.seg[2], n, y0 - HALO, x0 - HALO); my_sh = p.seg[2].sh; my_swp = p.seg[2].sw * q.xt.ppp; }
-        if (x_si == 3) { my_org = vptr<T>(p.seg[3], n, y0 - HALO, x0 - HALO); my_sh = p.seg[3].sh; my_swp = p.seg[3].sw * q.xt.ppp; }
+        if (x_si == 1) my_org = vptr<T>(p.seg[1], n, y0 - HALO, x0 - HALO);
+        if (x_si == 2) my_org = vptr<T>(p.seg[2], n, y0 - HALO, x0 - HALO);
+        if (x_si == 3) my_org = vptr<T>(p.seg[3], n, y0 - HALO, x0 - HALO);
       }
-      my_org += x_off;
-      for (int pi = wave; pi < xpieces; pi += 4) {
-        const int pu = __builtin_amdgcn_readfirstlane(pi);
-        const int hy = fdiv(pu, q.xt.d_ppr), pc = pu - hy * q.xt.ppr;
-        if (x_lane) {
-          const int hx = pc * q.xt.ppp + xl;
-          const int yy = y0 - HALO + hy, xx = x0 - HALO + hx;
-          const bool ok = x_data && hx < HW && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-          const T* src = ok ? my_org + (hy * my_sh + pc * my_swp) : (const T*)g_zero16;
-          __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Xb + pu * 1024), 16, 0, 0);  // never an LDS store between DMAs
-        }
-      }
+      dma_tile<T>(q.xt, LX, my_org + x_off, Xb, wave, max(0, HALO - y0), min(TILE_H + 2 * HALO, p.H + HALO - y0), max(0, HALO - x0), min(HW, p.W + HALO - x0));
     }
     // ---- epilogue operands: requested now, consumed after the MFMA loop
     const bool colv = x0 + fr < p.W;
@@ -1552,7 +1572,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
   const int KS = p.KS, HALO = KS / 2, TAPS = p.taps;
   const int HW = TILE_W + 2 * HALO;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
   const int co_base = blockIdx.y * (NTC * 16);
 
@@ -1603,6 +1623,14 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
     x_off = (int)(xl * sv.sw) + cs;
   }
   const int xpieces = q.xt.rows * q.xt.ppr;
+  LaneTile LX;
+  {
+    LX.xl = xl; LX.lane = x_lane; LX.data = x_data;
+    LX.sh = (int)p.seg[0].sh; LX.swp = (int)(p.seg[0].sw * q.xt.ppp);
+#pragma unroll
+    for (int k = 1; k < CGEN_MAX_SEG; ++k)
+      if (x_si == k) { LX.sh = (int)p.seg[k].sh; LX.swp = (int)(p.seg[k].sw * q.xt.ppp); }
+  }
   Bias8 ebias;  // CPP divides 64: a lane's chunk (=> bias) is the same for every k and every tile
   ebias.b0 = ebias.b1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.epi_vec16 && co_base + (lane % (NTC * 2)) * 8 + 8 <= p.Co) bias8_load(p, co_base + (lane % (NTC * 2)) * 8, ebias);
@@ -1617,28 +1645,15 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
     const int ty = b % q.tiles_y;
     const int n = b / q.tiles_y;
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
-    // ---- halo tile DMA (row pieces): a few SALU ops + ~6 VALU per piece
+    // ---- halo tile DMA (row pieces)
     if (!(q.dbg & 1)) {
-      const T* org0 = vptr<T>(p.seg[0], n, y0 - HALO, x0 - HALO);
-      const T* my_org = org0;
-      int64_t my_sh = p.seg[0].sh, my_swp = p.seg[0].sw * q.xt.ppp;
+      const T* my_org = vptr<T>(p.seg[0], n, y0 - HALO, x0 - HALO);
       if (p.nseg > 1) {
-        if (x_si == 1) { my_org = vptr<T>(p.seg[1], n, y0 - HALO, x0 - HALO); my_sh = p.seg[1].sh; my_swp = p.seg[1].sw * q.xt.ppp; }
-        if (x_si == 2) { my_org = vptr<T>(p.seg[2], n, y0 - HALO, x0 - HALO); my_sh = p.seg[2].sh; my_swp = p.seg[2].sw * q.xt.ppp; }
-        if (x_si == 3) { my_org = vptr<T>(p.seg[3], n, y0 - HALO, x0 - HALO); my_sh = p.seg[3].sh; my_swp = p.seg[3].sw * q.xt.ppp; }
+        if (x_si == 1) my_org = vptr<T>(p.seg[1], n, y0 - HALO, x0 - HALO);
+        if (x_si == 2) my_org = vptr<T>(p.seg[2], n, y0 - HALO, x0 - HALO);
+        if (x_si == 3) my_org = vptr<T>(p.seg[3], n, y0 - HALO, x0 - HALO);
       }
-      my_org += x_off;
-      for (int pi = wave; pi < xpieces; pi += 4) {
-        const int pu = __builtin_amdgcn_readfirstlane(pi);
-        const int hy = fdiv(pu, q.xt.d_ppr), pc = pu - hy * q.xt.ppr;
-        if (x_lane) {
-          const int hx = pc * q.xt.ppp + xl;
-          const int yy = y0 - HALO + hy, xx = x0 - HALO + hx;
-          const bool ok = x_data && hx < HW && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-          const T* src = ok ? my_org + (hy * my_sh + pc * my_swp) : (const T*)g_zero16;
-          __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Xb + pu * 1024), 16, 0, 0);  // never an LDS store between DMAs
-        }
-      }
+      dma_tile<T>(q.xt, LX, my_org + x_off, Xb, wave, max(0, HALO - y0), min(TILE_H + 2 * HALO, p.H + HALO - y0), max(0, HALO - x0), min(HW, p.W + HALO - x0));
     }
     // epilogue operands of this tile (see Epi8): in flight with the halo DMA
     constexpr int COT_ = NTC * 16, CPP_ = COT_ / 8;
