@@ -1523,7 +1523,8 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st) {
   auto lds_of = [&](int n_) { return (size_t)ceil_div(n_ * 32 * (q.ldw / G), 64) * 1024 + (size_t)q.xt.bytes; };
   while (np > 1 && lds_of(np) > 52 * 1024) --np;
   if (np == 3 && np_all == 4) np = 2;
-  while (np > 1 && (int64_t)q.ntiles * ceil_div(np_all, np) < 512) --np;
+  static const int min_wgs = [] { const char* e = getenv("CGEN_PX_MINWG"); return e ? atoi(e) : 512; }();
+  while (np > 1 && (int64_t)q.ntiles * ceil_div(np_all, np) < min_wgs) --np;
   const size_t lds = lds_of(np);
   if (lds > 150 * 1024) return false;
   q.wpieces = ceil_div(np * 32 * (q.ldw / G), 64);
@@ -1631,9 +1632,27 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
     for (int k = 1; k < CGEN_MAX_SEG; ++k)
       if (x_si == k) { LX.sh = (int)p.seg[k].sh; LX.swp = (int)(p.seg[k].sw * q.xt.ppp); }
   }
-  Bias8 ebias;  // CPP divides 64: a lane's chunk (=> bias) is the same for every k and every tile
+  // ---- epilogue lane constants (the host only selects this kernel when every epilogue access is a whole aligned chunk):
+  // chunk k of this lane = pixel (row ef[k], column ex[k]) of the tile, channels co_base + ech*8 .. +8
+  constexpr int CPP = NTC * 2;  // 16-byte chunks per pixel; divides 64, so a lane's chunk column is the same for every k
+  const int ech = lane % CPP;
+  const bool chv = co_base + ech * 8 + 8 <= p.Co;
+  Bias8 ebias;
   ebias.b0 = ebias.b1 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.epi_vec16 && co_base + (lane % (NTC * 2)) * 8 + 8 <= p.Co) bias8_load(p, co_base + (lane % (NTC * 2)) * 8, ebias);
+  if (chv) bias8_load(p, co_base + ech * 8, ebias);
+  int ef[NTC], ex[NTC], erd[NTC], eo_out[NTC], eo_aux[NTC], eo_r1[NTC], eo_r2[NTC];
+#pragma unroll
+  for (int k = 0; k < NTC; ++k) {
+    const int pl = (lane + 64 * k) / CPP;
+    ef[k] = wave * 2 + (pl >> 4); ex[k] = pl & 15;
+    erd[k] = ((ech >> 1) * TILE_H + ef[k]) * 64 + (ech & 1) * 32 + ex[k];  // f32x4 index of the "lo" half in the partial-sum area
+    const int c0 = co_base + ech * 8;
+    eo_out[k] = (int)(ef[k] * p.out.sh + ex[k] * p.out.sw + c0) * 2;
+    eo_aux[k] = (int)(ef[k] * p.aux.sh + ex[k] * p.aux.sw + c0) * 2;
+    eo_r1[k] = (int)(ef[k] * p.res1.sh + ex[k] * p.res1.sw + c0) * 2;
+    eo_r2[k] = (int)(ef[k] * p.res2.sh + ex[k] * p.res2.sw + c0) * 2;
+  }
+  const bool has_aux = p.aux.p != nullptr, has_r1 = p.res1.p != nullptr, has_r2 = p.res2.p != nullptr;
   const bool stamp = q.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
   int nst = 0;
 #define WS_STAMP() do { if (stamp && nst < 60) q.stamps[nst++] = __builtin_readcyclecounter(); } while (0)
@@ -1655,18 +1674,21 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
       }
       dma_tile<T>(q.xt, LX, my_org + x_off, Xb, wave, max(0, HALO - y0), min(TILE_H + 2 * HALO, p.H + HALO - y0), max(0, HALO - x0), min(HW, p.W + HALO - x0));
     }
-    // epilogue operands of this tile (see Epi8): in flight with the halo DMA
-    constexpr int COT_ = NTC * 16, CPP_ = COT_ / 8;
-    Epi8 epl[NTC];
-    bool efast[NTC];
+    // epilogue operands of this tile: requested now (in flight with the halo DMA), consumed after the reduction
+    uint4 ea[NTC], er1[NTC], er2[NTC];
+    bool ev[NTC];
+    {
+      const char* aux_t = (const char*)vptr<T>(p.aux, n, y0, x0);
+      const char* r1_t = (const char*)vptr<T>(p.res1, n, y0, x0);
+      const char* r2_t = (const char*)vptr<T>(p.res2, n, y0, x0);
 #pragma unroll
-    for (int k = 0; k < NTC; ++k) {
-      const int idx = lane + 64 * k;
-      const int pl = idx / CPP_, ch = idx % CPP_;
-      const int py = y0 + wave * 2 + (pl >> 4), px = x0 + (pl & 15);
-      const int co = co_base + ch * 8;
-      efast[k] = py < p.H && px < p.W && p.epi_vec16 && co + 8 <= p.Co && !(q.dbg & 8);
-      if (efast[k]) epi8_load(p, n, py, px, co, epl[k]);
+      for (int k = 0; k < NTC; ++k) {
+        ev[k] = chv && y0 + ef[k] < p.H && x0 + ex[k] < p.W && !(q.dbg & 8);
+        ea[k] = er1[k] = er2[k] = make_uint4(0, 0, 0, 0);
+        if (has_aux) ea[k] = *(const uint4*)(ev[k] ? aux_t + eo_aux[k] : (const char*)g_zero16);
+        if (has_r1) er1[k] = *(const uint4*)(ev[k] ? r1_t + eo_r1[k] : (const char*)g_zero16);
+        if (has_r2) er2[k] = *(const uint4*)(ev[k] ? r2_t + eo_r2[k] : (const char*)g_zero16);
+      }
     }
     WS_STAMP();
     __syncthreads();  // hipcc waits vmcnt(0) here: the tile has landed
@@ -1709,17 +1731,13 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
         for (int f = 0; f < TILE_H; ++f) red[(tt * TILE_H + f) * 64] = acc[tt][f];
     }
     __syncthreads();
-    if (!(q.dbg & 8)) {
+    {
       // each wave finalises 2 tile rows; a lane owns an 8-channel (16-byte) chunk of one pixel so that consecutive lanes
       // cover consecutive chunks of a pixel row (coalesced epilogue I/O).  Fixed summation order: deterministic.
-      constexpr int COT = NTC * 16, CPP = COT / 8;
+      char* out_t = (char*)vptr<T>(p.out, n, y0, x0);
 #pragma unroll
       for (int k = 0; k < NTC; ++k) {
-        const int idx = lane + 64 * k;
-        const int pl = idx / CPP, ch = idx % CPP;      // pixel 0..31 of this wave's two rows, chunk inside the pixel
-        const int f = wave * 2 + (pl >> 4), pxl = pl & 15;
-        const int tt = ch >> 1, cg = (ch & 1) * 2;     // MFMA fragment and lane group pair that hold channels ch*8..+8
-        const f32x4* rd = (const f32x4*)smem + (size_t)(tt * TILE_H + f) * 64 + cg * 16 + pxl;
+        const f32x4* rd = (const f32x4*)smem + erd[k];
         f32x4 lo = rd[0], hi = rd[16];
 #pragma unroll
         for (int wv = 1; wv < 4; ++wv) {
@@ -1727,11 +1745,38 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
           lo[0] += a[0]; lo[1] += a[1]; lo[2] += a[2]; lo[3] += a[3];
           hi[0] += bq2[0]; hi[1] += bq2[1]; hi[2] += bq2[2]; hi[3] += bq2[3];
         }
-        const int py = y0 + f, px = x0 + pxl;
-        if (py < p.H && px < p.W) {
-          float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          if (efast[k]) epi8_finish(p, v, epl[k], ebias, n, py, px, co_base + ch * 8);
-          else conv_epilogue8_bf16(p, v, n, py, px, co_base + ch * 8);
+        if (ev[k]) {
+          float v[8] = {lo[0] + ebias.b0.x, lo[1] + ebias.b0.y, lo[2] + ebias.b0.z, lo[3] + ebias.b0.w,
+                        hi[0] + ebias.b1.x, hi[1] + ebias.b1.y, hi[2] + ebias.b1.z, hi[3] + ebias.b1.w};
+          if (has_aux) {
+            const uint32_t w[4] = {ea[k].x, ea[k].y, ea[k].z, ea[k].w};
+            if (p.dact == CGEN_ACT_RELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[2 * e] = bf_lo(w[e]) > 0.f ? v[2 * e] : 0.f;
+                v[2 * e + 1] = bf_hi(w[e]) > 0.f ? v[2 * e + 1] : 0.f;
+              }
+            } else if (p.dact == CGEN_ACT_GELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                v[2 * e] *= gelu_bwd_slow(bf_lo(w[e]));
+                v[2 * e + 1] *= gelu_bwd_slow(bf_hi(w[e]));
+              }
+            }
+          }
+          if (has_r1) {
+            const uint32_t w[4] = {er1[k].x, er1[k].y, er1[k].z, er1[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(w[e]); v[2 * e + 1] += bf_hi(w[e]); }
+          }
+          if (has_r2) {
+            const uint32_t w[4] = {er2[k].x, er2[k].y, er2[k].z, er2[k].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(w[e]); v[2 * e + 1] += bf_hi(w[e]); }
+          }
+          uint4 o;
+          o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]); o.z = f2bf_pk(v[4], v[5]); o.w = f2bf_pk(v[6], v[7]);
+          *(uint4*)(out_t + eo_out[k]) = o;
         }
       }
     }
@@ -1762,6 +1807,7 @@ static bool launch_conv_ws(const ConvP& p, hipStream_t st) {
   if (bk < 0) return false;                      // K too long for the register-resident weights: multi-pass kernel
   q.xt = mk_pixtile(p.ctot8, 2, TILE_H + 2 * halo, TILE_W + 2 * halo);
   if (q.xt.ppp < 1) return false;
+  if (!p.epi_vec16 || p.Co % 8 != 0) return false;  // the kernel only has the whole-chunk epilogue
   q.red_bytes = 4 * ntc * TILE_H * 1024;
   const size_t lds = (size_t)(q.xt.bytes > q.red_bytes ? q.xt.bytes : q.red_bytes);
   if (lds > 78 * 1024) return false;             // keep two workgroups per CU

@@ -144,11 +144,14 @@ class Engine:
         self.rng = None
         self.launches = 0
         self.prof = None  # {"conv_fwd": [flops, [(ev0, ev1), ...]], ...} when profiling is on
-        # weight-gradient kernels are leaves of the backward graph: they run on a second HIP stream (forked per launch,
-        # joined before the split-K reduction) so they fill the CUs the latency-bound dgrad chain leaves idle
-        self.overlap_wgrad = os.environ.get("CGEN_WGRAD_STREAM", "1") != "0"
-        self.side = None
-        self._side_busy = False
+        # weight-gradient kernels are leaves of the backward graph and independent of each other: they are DEFERRED to the
+        # end of the backward pass and issued round-robin on a few HIP streams (one fork, one join before the split-K
+        # reduction).  The low-resolution ones are latency chains on a fraction of the CUs; several at a time fill the chip.
+        self.wgrad_streams = int(os.environ.get("CGEN_WGRAD_STREAMS", "2"))
+        self.wgrad_flush = int(os.environ.get("CGEN_WGRAD_FLUSH", "0"))  # > 0: also issue them every N launches while the dgrad chain runs
+        self._wg_forked = False
+        self._wg_pool = []
+        self._wg_deferred = []
 
     # ------------------------------------------------------------------ memory
     def begin(self):
@@ -160,7 +163,8 @@ class Engine:
         self.pgrad_init = set()
         self._pnhwc, self._pgrad_tmp = {}, {}
         self._adopted = set()
-        self._side_busy = False
+        self._wg_deferred = []
+        self._wg_forked = False
         self.passes = 0
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
 
@@ -496,17 +500,24 @@ class Engine:
             out.append((cur, b))
         return out
 
-    def _join_side(self):
-        """Main stream waits for everything enqueued on the weight-gradient stream."""
-        if self._side_busy:
-            torch.cuda.current_stream(self.device).wait_stream(self.side)
-            self._side_busy = False
+    def _defer_wgrad(self):
+        return self.wgrad_streams > 1 and self.prof is None
 
-    def _side_hazard(self, t):
-        """True when accumulating into grad(t) in place could race with a weight-gradient kernel on the side stream:
-        only ADOPTED buffers (see _grad_residual) are ever written after their producer's wgrad was enqueued."""
+    def _frozen(self, t):
+        """True when grad(t) lives in a buffer a deferred weight-gradient kernel will still read: only ADOPTED buffers
+        (see _grad_residual) are ever written after their producer's backward ran.  Such a buffer must not be
+        accumulated into in place."""
         e = self.grads.get(id(t.base))
-        return self._side_busy and e is not None and id(e[0]) in self._adopted
+        return self._defer_wgrad() and e is not None and id(e[0]) in self._adopted
+
+    def _cow(self, t):
+        """Copy-on-write of a frozen gradient buffer (rare: only non-conv ops accumulating into an adopted buffer)."""
+        e = self.grads[id(t.base)]
+        old, base = e[0], e[2]
+        new = self.new(base.n, base.h, base.w, base.c, rg=False)
+        self.lib.axpby(self.dt, old.n, old.h, old.w, old.cv(), new.cv(), 1.0, 1.0, 1 << 30, 0, self.stream)
+        self.launches += 1
+        e[0] = new
 
     def grad_write(self, t, defer_hazard=False):
         """Gradient view for `t` plus whether it already holds a value (=> the writer must accumulate)."""
@@ -514,9 +525,10 @@ class Engine:
         g, ivs, base = self._gentry(t.base)
         a, b = t.coff, t.coff + t.c
         miss = self._missing(ivs, a, b)
+        if miss != [(a, b)] and not defer_hazard and self._frozen(t):
+            self._cow(t)
+            g = self.grads[id(t.base)][0]
         gv = g.chan(a, b)
-        if miss != [(a, b)] and not defer_hazard and self._side_hazard(t):
-            self._join_side()
         if not miss:
             return gv, True
         if miss == [(a, b)]:
@@ -596,15 +608,16 @@ class Engine:
                 continue
             gv, acc = self.grad_write(s, defer_hazard=True)
             prev = gv
-            if acc and self._side_hazard(s):
-                # grad(s) lives in an adopted buffer a side-stream wgrad may still be reading: accumulate OUT of place
-                # (same traffic: the kernel reads `prev` as a residual either way) instead of stalling the main stream
+            if acc and self._frozen(s):
+                # grad(s) lives in an adopted buffer a deferred wgrad will still read: accumulate OUT of place (same
+                # traffic: the kernel reads `prev` as a residual either way)
                 if s.base is s:
                     e = self.grads[id(s)]
                     e[0] = self.new(s.n, s.h, s.w, s.c, rg=False)
                     gv = e[0].chan(0, s.c)
                 else:
-                    self._join_side()
+                    self._cow(s)
+                    gv = prev = self.grads[id(s.base)][0].chan(s.coff, s.coff + s.c)
             a = _lib.ConvArgs()
             a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = self.dt, x0.n, x0.h, x0.w, site.ks, 1, ACT_NONE, act
             a.seg[0] = g.cv()
@@ -636,19 +649,38 @@ class Engine:
         a.nsplit = nsplit
         a.partial_w = buf.data_ptr()
         a.partial_b = buf.data_ptr() + 4 * nsplit * nw if site.conv.bias is not None else None
-        if self.overlap_wgrad and self.prof is None:
-            if self.side is None:
-                self.side = torch.cuda.Stream(self.device)
-            self.side.wait_stream(torch.cuda.current_stream(self.device))  # fork: everything enqueued so far is visible
-            self._side_busy = True
-            self.launches += 1
-            self.lib.conv2d_wgrad(C.byref(a), self.side.cuda_stream)
+        if self._defer_wgrad():
+            self._wg_deferred.append((a, 2.0 * site.ci * site.taps * site.co * x0.n * x0.h * x0.w))
+            if self.wgrad_flush > 0 and len(self._wg_deferred) >= self.wgrad_flush:
+                self._launch_deferred_wgrads(final=False)
         else:
             self._timed("conv_wgrad", site, x0, lambda: self.lib.conv2d_wgrad(C.byref(a), self.stream))
         self._wg_events.append((site, key, nsplit))
 
+    def _launch_deferred_wgrads(self, final=True):
+        main = torch.cuda.current_stream(self.device)
+        if self._wg_deferred:
+            k = min(self.wgrad_streams, len(self._wg_deferred))
+            while len(self._wg_pool) < k:
+                self._wg_pool.append(torch.cuda.Stream(self.device))
+            streams = self._wg_pool[:k]
+            for st in streams:
+                st.wait_stream(main)  # fork: everything enqueued so far is visible
+            self._wg_forked = True
+            load = [0.0] * k
+            for a, cost in sorted(self._wg_deferred, key=lambda e: -e[1]):  # longest first onto the least loaded stream
+                i = load.index(min(load))
+                load[i] += cost + 2.0e8  # + a fixed per-launch cost
+                self.lib.conv2d_wgrad(C.byref(a), streams[i].cuda_stream)
+                self.launches += 1
+            self._wg_deferred = []
+        if final and self._wg_forked:
+            for st in self._wg_pool:
+                main.wait_stream(st)
+            self._wg_forked = False
+
     def _reduce_wgrads(self):
-        self._join_side()
+        self._launch_deferred_wgrads()
         if not self._wg_events:
             return
         sig = tuple(k for _, k, _ in self._wg_events)
