@@ -1521,7 +1521,8 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st) {
   const int np_all = ceil_div(p.Co, 32);
   int np = np_all < 4 ? np_all : 4;
   auto lds_of = [&](int n_) { return (size_t)ceil_div(n_ * 32 * (q.ldw / G), 64) * 1024 + (size_t)q.xt.bytes; };
-  while (np > 1 && lds_of(np) > 52 * 1024) --np;
+  static const int lds_budget = [] { const char* e = getenv("CGEN_PX_LDS"); return (e ? atoi(e) : 52) * 1024; }();
+  while (np > 1 && lds_of(np) > (size_t)lds_budget) --np;
   if (np == 3 && np_all == 4) np = 2;
   static const int min_wgs = [] { const char* e = getenv("CGEN_PX_MINWG"); return e ? atoi(e) : 512; }();
   while (np > 1 && (int64_t)q.ntiles * ceil_div(np_all, np) < min_wgs) --np;
@@ -1897,26 +1898,53 @@ __global__ __launch_bounds__(256) void wprep_kernel(const cgen_wprep_desc* descs
 }
 
 __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, const int* csite, const int* cidx) {
+  // Threads walk the PARTIAL layout [co][tap][ci] (what the wgrad kernels wrote), 4 consecutive ci per thread, so the
+  // nsplit-deep reads are coalesced 16-byte streams; the sum is scattered into the OIHW gradient (1/nsplit of the bytes).
   const cgen_wred_desc d = descs[csite[blockIdx.x]];
   const int taps = d.ks * d.ks;
-  const int64_t nw = (int64_t)d.co * d.ci_total * taps;
-  const int64_t base = (int64_t)cidx[blockIdx.x] * MT_CHUNK;
-  for (int i = threadIdx.x; i < MT_CHUNK; i += 256) {
-    const int64_t o = base + i;
-    if (o >= d.numel) break;
-    if (o < nw) {  // o indexes the OIHW gradient
-      const int tap = (int)(o % taps);
-      const int ci = (int)((o / taps) % d.ci_total);
-      const int co = (int)(o / ((int64_t)taps * d.ci_total));
-      const int64_t src = ((int64_t)co * taps + tap) * d.ci_total + ci;
-      float a = 0.f;
-      for (int sp = 0; sp < d.nsplit; ++sp) a += d.partial_w[(int64_t)sp * nw + src];
-      d.grad_w[o] = d.accumulate ? d.grad_w[o] + a : a;
-    } else if (d.grad_b) {
-      const int co = (int)(o - nw);
-      float a = 0.f;
-      for (int sp = 0; sp < d.nsplit; ++sp) a += d.partial_b[(int64_t)sp * d.co + co];
-      d.grad_b[co] = d.accumulate ? d.grad_b[co] + a : a;
+  const int nw = d.co * d.ci_total * taps;  // < 2^31 (checked on the host)
+  const int s0 = cidx[blockIdx.x] * MT_CHUNK + threadIdx.x * 4;
+  if (s0 >= d.numel) return;
+  if (s0 < nw) {
+    const bool vec = (d.ci_total & 3) == 0 && (((uintptr_t)d.partial_w) & 15) == 0;  // nw % 4 == 0 follows
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    const int cnt = min(4, nw - s0);
+    if (vec) {
+      const float4* src = (const float4*)(d.partial_w + s0);
+      const size_t stride = (size_t)nw / 4;
+      float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+      int sp = 0;
+      for (; sp + 2 <= d.nsplit; sp += 2) {  // two independent chains; fixed order => deterministic
+        const float4 v0 = src[(size_t)sp * stride], v1 = src[(size_t)(sp + 1) * stride];
+        b0.x += v0.x; b0.y += v0.y; b0.z += v0.z; b0.w += v0.w;
+        b1.x += v1.x; b1.y += v1.y; b1.z += v1.z; b1.w += v1.w;
+      }
+      if (sp < d.nsplit) { const float4 v0 = src[(size_t)sp * stride]; b0.x += v0.x; b0.y += v0.y; b0.z += v0.z; b0.w += v0.w; }
+      a[0] = b0.x + b1.x; a[1] = b0.y + b1.y; a[2] = b0.z + b1.z; a[3] = b0.w + b1.w;
+    } else {
+      for (int e = 0; e < cnt; ++e) {
+        float acc = 0.f;
+        for (int sp = 0; sp < d.nsplit; ++sp) acc += d.partial_w[(size_t)sp * nw + s0 + e];
+        a[e] = acc;
+      }
+    }
+    for (int e = 0; e < cnt; ++e) {
+      const unsigned sidx = (unsigned)(s0 + e);
+      const unsigned r = sidx / (unsigned)d.ci_total, ci = sidx - r * d.ci_total;
+      const unsigned co = r / (unsigned)taps, tap = r - co * taps;
+      const size_t o = ((size_t)co * d.ci_total + ci) * taps + tap;
+      d.grad_w[o] = d.accumulate ? d.grad_w[o] + a[e] : a[e];
+    }
+  }
+  if (d.grad_b) {  // elements nw .. numel-1 are the bias gradient
+    for (int e = 0; e < 4; ++e) {
+      const int o = s0 + e;
+      if (o >= nw && o < d.numel) {
+        const int co = o - nw;
+        float acc = 0.f;
+        for (int sp = 0; sp < d.nsplit; ++sp) acc += d.partial_b[(size_t)sp * d.co + co];
+        d.grad_b[co] = d.accumulate ? d.grad_b[co] + acc : acc;
+      }
     }
   }
 }

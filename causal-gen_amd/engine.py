@@ -152,6 +152,9 @@ class Engine:
         self._wg_forked = False
         self._wg_pool = []
         self._wg_deferred = []
+        # independent sub-graphs of the forward pass (prior / posterior Block of a decoder layer) run on two streams
+        self.fwd_branch = os.environ.get("CGEN_FWD_BRANCH", "1") != "0"
+        self._fwd_side = None
 
     # ------------------------------------------------------------------ memory
     def begin(self):
@@ -499,6 +502,28 @@ class Engine:
         if cur < b:
             out.append((cur, b))
         return out
+
+    # ------------------------------------------------------------------ two-stream sections of the forward pass
+    def fork_side(self):
+        """Returns True when a side stream is available; everything enqueued so far is visible to it."""
+        if not self.fwd_branch or self.prof is not None:
+            return False
+        if self._fwd_side is None:
+            self._fwd_side = torch.cuda.Stream(self.device)
+        self._fwd_side.wait_stream(torch.cuda.current_stream(self.device))
+        return True
+
+    def on_side(self, fn):
+        """Run `fn()` with every launch going to the side stream."""
+        old = self.stream
+        self.stream = self._fwd_side.cuda_stream
+        try:
+            return fn()
+        finally:
+            self.stream = old
+
+    def join_side(self):
+        torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)
 
     def _defer_wgrad(self):
         return self.wgrad_streams > 1 and self.prof is None

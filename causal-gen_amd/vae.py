@@ -372,13 +372,18 @@ class HVAE(nn.Module):
                 if not blk.q_correction:
                     z = h if same else eng.upsample(z, res, bp)
             p_in = h if blk.q_correction else z
-            pout = self._run_block(eng, blk.prior, [p_in, pa_sto] if blk.cond_prior else [p_in])
+            run_prior = lambda: self._run_block(eng, blk.prior, [p_in, pa_sto] if blk.cond_prior else [p_in])
+            # the prior and the posterior Block of a layer are independent: two streams (one fork / join per layer)
+            two = blk.stochastic and acts is not None and eng.recording and eng.fork_side()
+            pout = eng.on_side(run_prior) if two else run_prior()
             zd = blk.z_dim
             p_loc, p_ls, p_feat = pout.chan(0, zd), pout.chan(zd, 2 * zd), pout.chan(2 * zd, pout.c)
             if blk.stochastic:
                 sid += 1
                 if acts is not None:
                     qout = self._run_block(eng, blk.posterior, [h, pa, acts[res]])
+                    if two:
+                        eng.join_side()
                     q_loc, q_ls = qout.chan(0, zd), qout.chan(zd, 2 * zd)
                     eps = self._next_eps(eng, q_loc.shape)
                     kptr = kl[0] + 4 * kl[2][i] if kl is not None else self._scratch_kl(eng, B, res, zd)
