@@ -77,11 +77,12 @@ PROTOTYPES = {
     "cgen_reparam_kl_bwd": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, View, vp, i32, View, View, View,
                             View, i32, i32, vp],
     "cgen_sample_gaussian": [i32, i32, i32, i32, i32, View, View, View, vp, u32, f32, View, vp],
+    "cgen_gaussian_kl_map": [i64, vp, vp, vp, vp, vp, vp],
     "cgen_mediator_mix": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, f32, f32, View, vp],
     "cgen_like_chunks": [i32, i32],
     "cgen_dgauss_nll_fwd": [i32, i32, i32, i32, i32, View, View, vp, vp],
     "cgen_dgauss_nll_bwd": [i32, i32, i32, i32, i32, View, View, vp, i32, View, vp],
-    "cgen_dgauss_sample": [i32, i32, i32, i32, i32, View, f32, vp, vp, vp],
+    "cgen_dgauss_sample": [i32, i32, i32, i32, i32, View, f32, vp, u32, vp, vp, vp],
     "cgen_dmol_nll_fwd": [i32, i32, i32, i32, View, View, vp, vp],
     "cgen_dmol_nll_bwd": [i32, i32, i32, i32, View, View, vp, i32, View, vp],
     "cgen_dmol_decode": [i32, i32, i32, i32, View, i32, vp, u32, f32, vp, vp, vp],

@@ -138,6 +138,16 @@ __global__ __launch_bounds__(256) void mediator_kernel(int n, int h, int w, int 
   }
 }
 
+// element-wise KL(q || p) of diagonal Gaussians on flat f32 arrays (vae.py:14-25), no reduction
+__global__ __launch_bounds__(256) void gaussian_kl_map_kernel(int64_t total, const float* q_loc, const float* q_ls, const float* p_loc,
+                                                              const float* p_ls, float* out) {
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+    const float ql = q_loc[g], qs = q_ls[g], pl = p_loc[g], ps = p_ls[g];
+    const float eq = expf(qs), ep = expf(ps), d = ql - pl;
+    out[g] = -0.5f + ps - qs + 0.5f * (eq * eq + d * d) / (ep * ep);
+  }
+}
+
 static inline int lat_grid(int64_t total) {
   int64_t b = (total + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -210,4 +220,12 @@ extern "C" int cgen_mediator_mix(int32_t dtype, int32_t n, int32_t h, int32_t w,
   else
     hipLaunchKernelGGL(mediator_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(z), mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), alpha, t, logt, mk(out));
   return check_launch("cgen_mediator_mix");
+}
+
+extern "C" int cgen_gaussian_kl_map(int64_t count, const float* q_loc, const float* q_ls, const float* p_loc, const float* p_ls,
+                                    float* out, cgen_stream_t stream) {
+  CGEN_REQUIRE(count >= 0 && q_loc && q_ls && p_loc && p_ls && out, "cgen_gaussian_kl_map: bad args");
+  if (count == 0) return CGEN_OK;
+  hipLaunchKernelGGL(cgen::gaussian_kl_map_kernel, dim3(cgen::lat_grid(count)), dim3(256), 0, (hipStream_t)stream, count, q_loc, q_ls, p_loc, p_ls, out);
+  return cgen::check_launch("cgen_gaussian_kl_map");
 }

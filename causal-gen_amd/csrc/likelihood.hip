@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void dgauss_nll_bwd_kernel(DgP p) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void dgauss_sample_kernel(int n, int h, int w, int c, View params, float logt, float* xo, float* so) {
+__global__ __launch_bounds__(256) void dgauss_sample_kernel(int n, int h, int w, int c, View params, float logt, const uint64_t* rng, uint32_t stream_id, float* xo, float* so) {
   const int npix = h * w;
   const int64_t total = (int64_t)n * npix;
   for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * 256) {
@@ -134,8 +134,11 @@ __global__ __launch_bounds__(256) void dgauss_sample_kernel(int n, int h, int w,
     }
     for (int ch = 0; ch < c; ++ch) {
       const int64_t o = ((int64_t)b * c + ch) * npix + px;
-      xo[o] = fminf(fmaxf(loc[ch], -1.f), 1.f);
-      so[o] = expf(fmaxf(Elem<T>::ld(pp + c + ch), DG_MIN_LS) + logt);
+      const float sc = expf(fmaxf(Elem<T>::ld(pp + c + ch), DG_MIN_LS) + logt);
+      // return_loc=False (vae.py:418-420): x = loc + scale * N(0,1), then the same clamp
+      const float noise = rng ? sc * Philox::normal1(rng[0], rng[1], stream_id, (uint64_t)o) : 0.f;
+      xo[o] = fminf(fmaxf(loc[ch] + noise, -1.f), 1.f);
+      so[o] = sc;
     }
   }
 }
@@ -432,12 +435,12 @@ extern "C" int cgen_dgauss_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t 
 }
 
 extern "C" int cgen_dgauss_sample(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, float logt,
-                                  float* x_nchw, float* scale_nchw, cgen_stream_t stream) {
+                                  const uint64_t* rng, uint32_t stream_id, float* x_nchw, float* scale_nchw, cgen_stream_t stream) {
   CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dgauss_sample: bad dtype");
   CGEN_REQUIRE((c == 1 || c == 3) && params.p && x_nchw && scale_nchw, "cgen_dgauss_sample: bad args");
   const int grid = like_grid((int64_t)n * h * w);
-  if (dtype == CGEN_F32) hipLaunchKernelGGL(dgauss_sample_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), logt, x_nchw, scale_nchw);
-  else hipLaunchKernelGGL(dgauss_sample_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), logt, x_nchw, scale_nchw);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(dgauss_sample_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
+  else hipLaunchKernelGGL(dgauss_sample_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
   return check_launch("cgen_dgauss_sample");
 }
 

@@ -24,14 +24,49 @@ from .engine import ConvSite, Engine
 EPS = -9  # minimum logscale (vae.py:11)
 
 
-def gaussian_kl(q_loc, q_logscale, p_loc, p_logscale):
-    """Import-compatible name (vae.py:14-25).  The model itself uses the fused cgen_reparam_kl kernels; this
-    helper runs that kernel's KL branch on NCHW tensors for callers that want the map."""
-    raise NotImplementedError("use HVAE.forward; the per-element KL map is not materialised on the GPU path")
+def _flat_f32(name, *ts):
+    lib = _lib.load()
+    _lib.require_gpu()
+    out = []
+    shape, dev = ts[0].shape, ts[0].device
+    for t in ts:
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device == dev and t.shape == shape):
+            raise _lib.CgenError(f"{name}: expects same-shaped tensors on one GPU (there is no CPU path)")
+        out.append(t.detach().to(torch.float32).contiguous())
+    return lib, out
 
 
-def sample_gaussian(loc, logscale):
-    raise NotImplementedError("use HVAE.sample / forward_latents; sampling is fused into cgen_reparam_kl_fwd")
+def gaussian_kl(q_loc: Tensor, q_logscale: Tensor, p_loc: Tensor, p_logscale: Tensor) -> Tensor:
+    """Element-wise KL(q || p) map, import-compatible with vae.py:14-25 (no clamps, no reduction).  The model itself uses
+    the fused cgen_reparam_kl kernels; this is the stand-alone op for callers of the module-level name.  HIP only."""
+    lib, (ql, qs, pl, ps) = _flat_f32("gaussian_kl", q_loc, q_logscale, p_loc, p_logscale)
+    out = torch.empty_like(ql)
+    lib.gaussian_kl_map(ql.numel(), ql.data_ptr(), qs.data_ptr(), pl.data_ptr(), ps.data_ptr(), out.data_ptr(),
+                        torch.cuda.current_stream(ql.device).cuda_stream)
+    return out
+
+
+_FREE_RNG = {}
+
+
+def sample_gaussian(loc: Tensor, logscale: Tensor) -> Tensor:
+    """loc + exp(logscale) * N(0, 1) (vae.py:28-30) with the device Philox generator, seeded from torch.initial_seed();
+    every call advances the counter.  HIP only."""
+    lib, (l, s) = _flat_f32("sample_gaussian", loc, logscale)
+    dev = l.device
+    rng = _FREE_RNG.get(dev)
+    if rng is None:
+        rng = _FREE_RNG[dev] = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=dev)
+    out = torch.empty_like(l)
+    n = l.numel()
+    st = torch.cuda.current_stream(dev).cuda_stream
+
+    def view(t):
+        return _lib.View(t.data_ptr(), n, n, 1, 1, 0)
+
+    lib.sample_gaussian(_lib.F32, 1, 1, n, 1, view(l), view(s), NULL_VIEW, rng.data_ptr(), 0x5A17, 0.0, view(out), st)
+    lib.rng_advance(rng.data_ptr(), (n + 3) // 4 + 1, st)
+    return out
 
 
 class Block(nn.Module):
@@ -527,9 +562,13 @@ class HVAE(nn.Module):
         xo = torch.empty((B, Cx, R, R), dtype=torch.float32, device=eng.device)
         so = torch.empty_like(xo)
         if lk.kind == "dgauss":
-            if not return_loc:
-                raise NotImplementedError("DGaussNet.sample(return_loc=False) is unused by the reference's callers")
-            eng.lib.dgauss_sample(eng.dt, B, R, R, Cx, params.cv(), 0.0, xo.data_ptr(), so.data_ptr(), eng.stream)
+            if not return_loc and t is not None and Cx == 3:
+                # vae.py:418 passes t in the position of x: the reference indexes a float here and raises
+                raise TypeError("'float' object is not subscriptable")
+            # vae.py:416-420: neither branch applies the temperature (return_loc=True calls forward(h); return_loc=False
+            # hands t over as `x`, which the grayscale path never reads)
+            eng.lib.dgauss_sample(eng.dt, B, R, R, Cx, params.cv(), 0.0, None if return_loc else eng.rng_ptr(), 978,
+                                  xo.data_ptr(), so.data_ptr(), eng.stream)
         else:
             mode = {"soft": 0, "hard": 1}[lk.mask] if return_loc else 2
             logt = 0.0 if t is None else float(torch.tensor(t).log())

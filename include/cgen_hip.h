@@ -154,6 +154,10 @@ int cgen_reparam_kl_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t 
                         cgen_view p_loc, cgen_view p_ls, cgen_view z, float logt, cgen_view gz,
                         const float* kl_coef_dev, int32_t coef_stride, cgen_view g_q_loc, cgen_view g_q_ls,
                         cgen_view g_p_loc, cgen_view g_p_ls, int32_t acc_q, int32_t acc_p, cgen_stream_t);
+/* element-wise KL(q || p) map on flat contiguous f32 arrays, no reduction: the module-level gaussian_kl of vae.py:14-25
+ * (-0.5 + p_ls - q_ls + 0.5 * (exp(q_ls)^2 + (q_loc - p_loc)^2) / exp(p_ls)^2; no clamps) */
+int cgen_gaussian_kl_map(int64_t count, const float* q_loc, const float* q_ls, const float* p_loc, const float* p_ls,
+                         float* out, cgen_stream_t);
 /* z = loc + exp(ls + logt) * eps (prior sampling, vae.py:283-286); eps as above */
 int cgen_sample_gaussian(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view loc, cgen_view ls,
                          cgen_view eps_in, const uint64_t* rng, uint32_t stream_id, float logt, cgen_view z,
@@ -173,9 +177,11 @@ int cgen_dgauss_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t 
 /* g_params = coef_dev[b*coef_stride] * d(sum -log p)/d params */
 int cgen_dgauss_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x,
                         const float* coef_dev, int32_t coef_stride, cgen_view g_params, cgen_stream_t);
-/* DGaussNet.sample(return_loc=True) (vae.py:413-422): loc (RGB autoregressive, clamped) and exp(logscale)+log t, NCHW f32 out */
+/* DGaussNet.sample (vae.py:413-422): loc (RGB autoregressive on the clamped predicted channels) and exp(logscale + log t),
+ * NCHW f32 out.  rng == NULL: return_loc=True (x = clamp(loc)); rng = device (seed, offset): return_loc=False,
+ * x = clamp(loc + scale * N(0,1)) with Philox noise of stream `stream_id` */
 int cgen_dgauss_sample(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, float logt,
-                       float* x_nchw, float* scale_nchw, cgen_stream_t);
+                       const uint64_t* rng, uint32_t stream_id, float* x_nchw, float* scale_nchw, cgen_stream_t);
 /* Discretised mixture of logistics, 10 mixtures, 3 channels (dmol.py:24-118, 164-215, 121-161). logits: [.,100] */
 int cgen_dmol_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, cgen_view x, float* nll_part,
                       cgen_stream_t);

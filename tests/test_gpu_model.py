@@ -168,3 +168,27 @@ def test_bf16_path_close_to_fixture():
     g = dict(m.named_parameters())["likelihood.x_loc.weight"].grad.cpu()
     ref = f["grads"]["likelihood.x_loc.weight"]
     assert (g - ref).abs().max() / ref.abs().max() < 0.1
+
+
+def test_sample_return_loc_false_adds_scaled_noise():
+    """DGaussNet.sample(return_loc=False) (vae.py:416-421): x = clamp(loc + scale * N(0,1)); latents replayed so that the
+    only randomness is the pixel noise."""
+    fx = load_golden("tiny_light_c1.pt")
+    m, _ = build(fx)
+    x, pa = fx["x"].cuda(), fx["pa"].cuda()
+    zs = m.abduct(x, pa)
+    loc, scale = m.forward_latents(zs, pa)
+    eng = m.engine()
+    eng.begin()
+    eng.recording = False
+    eng.prepare_weights()
+    pnt = eng.from_nchw(pa.float())
+    lat = [eng.from_nchw(z.float()) for z in zs]
+    h, _ = m._decode(eng, pnt, latents=lat)
+    xs, ss = m._sample_likelihood(eng, h, return_loc=False)
+    torch.testing.assert_close(ss, scale)
+    assert float(xs.abs().max()) <= 1.0 and not torch.equal(xs, loc)
+    inside = (loc.abs() + 4 * scale) < 1.0  # pixels the clamp cannot touch
+    if int(inside.sum()) > 200:
+        u = ((xs - loc) / scale)[inside]
+        assert abs(float(u.mean())) < 0.2 and abs(float(u.std()) - 1.0) < 0.2

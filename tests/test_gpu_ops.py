@@ -237,7 +237,7 @@ def test_dgauss_nll_golden(C):
     eng.lib.dgauss_nll_bwd(eng.dt, N, H, W, C, pt.cv(), xt.cv(), coef.data_ptr(), 0, gp.cv(), eng.stream)
     torch.testing.assert_close(nhwc_to_torch(eng, gp), g_ref, rtol=2e-3, atol=1e-5 * g_ref.abs().max().item() + 1e-7)
     xo, so = torch.empty(N, C, H, W, device="cuda"), torch.empty(N, C, H, W, device="cuda")
-    eng.lib.dgauss_sample(eng.dt, N, H, W, C, pt.cv(), 0.0, xo.data_ptr(), so.data_ptr(), eng.stream)
+    eng.lib.dgauss_sample(eng.dt, N, H, W, C, pt.cv(), 0.0, None, 0, xo.data_ptr(), so.data_ptr(), eng.stream)
     torch.testing.assert_close(xo.cpu(), d["sample_x"], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(so.cpu(), d["sample_scale"], rtol=1e-5, atol=1e-7)
 
@@ -288,3 +288,25 @@ def test_cf_pixels_and_particles():
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(sx.cpu(), 2 * ref, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(sx2.cpu(), 2 * ref ** 2, rtol=1e-6, atol=1e-6)
+
+
+def test_module_level_gaussian_kl_and_sample_gaussian():
+    """The import-compatible module functions (vae.py:14-30) run as HIP kernels: KL map vs the reference's own values
+    (golden fixture), sampling statistics + determinism of the device Philox stream."""
+    from causal_gen_amd import vae
+
+    fx = load_golden("ops.pt")["gaussian_kl"]
+    ql, qs, pl, ps = (fx[k].cuda() for k in ("q_loc", "q_logscale", "p_loc", "p_logscale"))
+    kl = vae.gaussian_kl(ql, qs, pl, ps)
+    assert kl.shape == ql.shape and kl.is_cuda
+    torch.testing.assert_close(kl.cpu(), fx["kl"], rtol=1e-5, atol=1e-5)  # tolerance: expf vs torch.exp, f32
+    with pytest.raises(Exception):
+        vae.gaussian_kl(ql.cpu(), qs.cpu(), pl.cpu(), ps.cpu())  # no CPU path
+
+    loc = torch.full((64, 4, 32, 32), 0.25, device="cuda")
+    ls = torch.full_like(loc, math.log(0.5))
+    a, b = vae.sample_gaussian(loc, ls), vae.sample_gaussian(loc, ls)
+    assert a.shape == loc.shape and not torch.equal(a, b)  # the counter advances between calls
+    for s in (a, b):
+        assert abs(float(s.mean()) - 0.25) < 5e-3 and abs(float(s.std()) - 0.5) < 5e-3
+    assert abs(float(((a - 0.25) / 0.5).pow(4).mean()) - 3.0) < 0.1  # Gaussian kurtosis
