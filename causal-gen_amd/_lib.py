@@ -74,8 +74,10 @@ PROTOTYPES = {
     "cgen_im2col": [i32, i32, i32, i32, i32, View, View, vp],
     "cgen_reparam_kl_chunks": [i32, i32, i32],
     "cgen_reparam_kl_fwd": [i32, i32, i32, i32, i32, View, View, View, View, View, vp, u32, f32, View, View, vp, i32, vp],
-    "cgen_reparam_kl_bwd": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, View, vp, i32, View, View, View,
+    "cgen_reparam_kl_bwd": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, View, vp, i32, vp, View, View, View,
                             View, i32, i32, vp],
+    "cgen_kl_channel_sums": [i32, i32, i32, i32, i32, View, View, View, View, f32, vp, i32, vp],
+    "cgen_elbo_finalize_fb": [i32, vp, i32, f32, vp, i32, f32, f32, f32, vp, vp, vp],
     "cgen_sample_gaussian": [i32, i32, i32, i32, i32, View, View, View, vp, u32, f32, View, vp],
     "cgen_gaussian_kl_map": [i64, vp, vp, vp, vp, vp, vp],
     "cgen_mediator_mix": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, f32, f32, View, vp],

@@ -61,6 +61,7 @@ struct LatBwdP {
   int n, h, w, c;
   View q_loc, q_ls, p_loc, p_ls, z, gz, g_q_loc, g_q_ls, g_p_loc, g_p_ls;
   const float* coef;
+  const float* chan_scale;  // optional [c]: per-channel multiplier of the KL gradient (free-bits mask)
   int coef_stride, acc_q, acc_p;
   float logt;
 };
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(LatBwdP p) {
     const float qs = Elem<T>::ld(vptr<T>(p.q_ls, b, y, x) + ch) + p.logt;
     const float pl = Elem<T>::ld(vptr<T>(p.p_loc, b, y, x) + ch);
     const float ps = Elem<T>::ld(vptr<T>(p.p_ls, b, y, x) + ch) + p.logt;
-    const float k = p.coef[(int64_t)b * p.coef_stride];
+    const float k = p.coef[(int64_t)b * p.coef_stride] * (p.chan_scale ? p.chan_scale[ch] : 1.f);
     const float e2q = expf(2.f * qs), ie2p = expf(-2.f * ps);
     const float d = ql - pl;
     float gql = k * d * ie2p;
@@ -138,6 +139,33 @@ __global__ __launch_bounds__(256) void mediator_kernel(int n, int h, int w, int 
   }
 }
 
+// free bits (vae.py:443-449): S[b][c] = sum_{h,w} KL(q || p)[b,h,w,c] of one stochastic layer.  One workgroup per sample;
+// a thread owns channel (tid % c) of pixels tid / c, tid / c + 256 / c, ... (c divides 256), fixed-order LDS tree.
+template <typename T>
+__global__ __launch_bounds__(256) void kl_channel_sums_kernel(int h, int w, int c, View q_loc, View q_ls, View p_loc, View p_ls, float logt,
+                                                              float* out, int out_stride) {
+  __shared__ float red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int ch = tid % c, lanes = 256 / c, slot = tid / c;
+  float acc = 0.f;
+  for (int px = slot; px < h * w; px += lanes) {
+    const int y = px / w, x = px - y * w;
+    const float ql = Elem<T>::ld(vptr<T>(q_loc, b, y, x) + ch);
+    const float qs = Elem<T>::ld(vptr<T>(q_ls, b, y, x) + ch) + logt;
+    const float pl = Elem<T>::ld(vptr<T>(p_loc, b, y, x) + ch);
+    const float ps = Elem<T>::ld(vptr<T>(p_ls, b, y, x) + ch) + logt;
+    const float d = ql - pl;
+    acc += -0.5f + ps - qs + 0.5f * (expf(2.f * qs) + d * d) * expf(-2.f * ps);
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int s = lanes >> 1; s > 0; s >>= 1) {
+    if (slot < s) red[tid] += red[tid + s * c];
+    __syncthreads();
+  }
+  if (slot == 0) out[(int64_t)b * out_stride + ch] = red[tid];
+}
+
 // element-wise KL(q || p) of diagonal Gaussians on flat f32 arrays (vae.py:14-25), no reduction
 __global__ __launch_bounds__(256) void gaussian_kl_map_kernel(int64_t total, const float* q_loc, const float* q_ls, const float* p_loc,
                                                               const float* p_ls, float* out) {
@@ -179,8 +207,9 @@ extern "C" int cgen_reparam_kl_fwd(int32_t dtype, int32_t n, int32_t h, int32_t 
 
 extern "C" int cgen_reparam_kl_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls,
                                    cgen_view p_loc, cgen_view p_ls, cgen_view z, float logt, cgen_view gz,
-                                   const float* kl_coef_dev, int32_t coef_stride, cgen_view g_q_loc, cgen_view g_q_ls,
-                                   cgen_view g_p_loc, cgen_view g_p_ls, int32_t acc_q, int32_t acc_p, cgen_stream_t stream) {
+                                   const float* kl_coef_dev, int32_t coef_stride, const float* kl_chan_scale, cgen_view g_q_loc,
+                                   cgen_view g_q_ls, cgen_view g_p_loc, cgen_view g_p_ls, int32_t acc_q, int32_t acc_p,
+                                   cgen_stream_t stream) {
   CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_reparam_kl_bwd: bad dtype");
   CGEN_REQUIRE(q_loc.p && q_ls.p && p_loc.p && p_ls.p && kl_coef_dev && g_q_loc.p && g_q_ls.p && g_p_loc.p && g_p_ls.p,
                "cgen_reparam_kl_bwd: null view");
@@ -189,7 +218,7 @@ extern "C" int cgen_reparam_kl_bwd(int32_t dtype, int32_t n, int32_t h, int32_t 
   p.n = n; p.h = h; p.w = w; p.c = c;
   p.q_loc = mk(q_loc); p.q_ls = mk(q_ls); p.p_loc = mk(p_loc); p.p_ls = mk(p_ls); p.z = mk(z); p.gz = mk(gz);
   p.g_q_loc = mk(g_q_loc); p.g_q_ls = mk(g_q_ls); p.g_p_loc = mk(g_p_loc); p.g_p_ls = mk(g_p_ls);
-  p.coef = kl_coef_dev; p.coef_stride = coef_stride; p.acc_q = acc_q; p.acc_p = acc_p; p.logt = logt;
+  p.coef = kl_coef_dev; p.chan_scale = kl_chan_scale; p.coef_stride = coef_stride; p.acc_q = acc_q; p.acc_p = acc_p; p.logt = logt;
   const int grid = lat_grid((int64_t)n * h * w * c);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(reparam_kl_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(reparam_kl_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
@@ -228,4 +257,15 @@ extern "C" int cgen_gaussian_kl_map(int64_t count, const float* q_loc, const flo
   if (count == 0) return CGEN_OK;
   hipLaunchKernelGGL(cgen::gaussian_kl_map_kernel, dim3(cgen::lat_grid(count)), dim3(256), 0, (hipStream_t)stream, count, q_loc, q_ls, p_loc, p_ls, out);
   return cgen::check_launch("cgen_gaussian_kl_map");
+}
+
+extern "C" int cgen_kl_channel_sums(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls,
+                                    cgen_view p_loc, cgen_view p_ls, float logt, float* out, int32_t out_stride, cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_kl_channel_sums: bad dtype");
+  CGEN_REQUIRE(q_loc.p && q_ls.p && p_loc.p && p_ls.p && out && out_stride >= c, "cgen_kl_channel_sums: bad args");
+  CGEN_REQUIRE(c >= 1 && c <= 256 && 256 % c == 0, "cgen_kl_channel_sums: the latent width must divide 256 (got %d)", c);
+  using namespace cgen;
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(kl_channel_sums_kernel<float>, dim3(n), dim3(256), 0, (hipStream_t)stream, h, w, c, mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), logt, out, out_stride);
+  else hipLaunchKernelGGL(kl_channel_sums_kernel<bf16_t>, dim3(n), dim3(256), 0, (hipStream_t)stream, h, w, c, mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), logt, out, out_stride);
+  return check_launch("cgen_kl_channel_sums");
 }

@@ -385,6 +385,38 @@ __global__ __launch_bounds__(256) void elbo_finalize_kernel(int n, const float* 
   }
 }
 
+// free-bits ELBO (vae.py:443-457): kl = sum_j max(fb, mean_b S[b][j]) / kl_div over all (layer, channel) columns j;
+// chan_mask[j] = d max(fb, m_j) / d m_j  (1 above the threshold, 0 below, 1/2 on a tie as torch.maximum).
+// The NLL is assembled exactly as in elbo_finalize_kernel.
+__global__ __launch_bounds__(256) void elbo_finalize_fb_kernel(int n, const float* nll_part, int nll_count, float nll_div,
+                                                               const float* kl_bc, int ncol, float kl_div, float free_bits,
+                                                               float beta, float* out3, float* chan_mask) {
+  extern __shared__ float per[];  // [n + 256]
+  float* colsum = per + n;
+  for (int b = threadIdx.x; b < n; b += 256) {
+    float a = 0.f;
+    for (int j = 0; j < nll_count; ++j) a += nll_part[(int64_t)b * nll_count + j];
+    per[b] = a / nll_div;
+  }
+  float k = 0.f;
+  for (int j = threadIdx.x; j < ncol; j += 256) {
+    float m = 0.f;
+    for (int b = 0; b < n; ++b) m += kl_bc[(int64_t)b * ncol + j];
+    m /= (float)n;
+    k += fmaxf(free_bits, m);
+    chan_mask[j] = m > free_bits ? 1.f : (m == free_bits ? 0.5f : 0.f);
+  }
+  colsum[threadIdx.x] = k;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, kk = 0.f;
+    for (int b = 0; b < n; ++b) a += per[b];
+    for (int t = 0; t < 256; ++t) kk += colsum[t];
+    a /= (float)n; kk /= kl_div;
+    out3[0] = a + beta * kk; out3[1] = a; out3[2] = kk;
+  }
+}
+
 __global__ __launch_bounds__(256) void cf_pixels_kernel(int64_t count, const float* x, const float* rec_loc, const float* rec_scale,
                                                         const float* cf_loc, const float* cf_scale, float* cf_x, float* sum_x,
                                                         float* sum_x2) {
@@ -496,4 +528,12 @@ extern "C" int cgen_cf_pixels(int64_t count, const float* x, const float* rec_lo
   hipLaunchKernelGGL(cf_pixels_kernel, dim3(like_grid(count)), dim3(256), 0, (hipStream_t)stream, count, x, rec_loc, rec_scale,
                      cf_loc, cf_scale, cf_x, sum_x, sum_x2);
   return check_launch("cgen_cf_pixels");
+}
+
+extern "C" int cgen_elbo_finalize_fb(int32_t n, const float* nll_part, int32_t nll_count, float nll_div, const float* kl_bc, int32_t ncol,
+                                     float kl_div, float free_bits, float beta, float* out3, float* chan_mask, cgen_stream_t stream) {
+  CGEN_REQUIRE(n > 0 && n <= 8192 && nll_part && nll_count > 0 && kl_bc && ncol > 0 && out3 && chan_mask, "cgen_elbo_finalize_fb: bad args");
+  hipLaunchKernelGGL(elbo_finalize_fb_kernel, dim3(1), dim3(256), (n + 256) * sizeof(float), (hipStream_t)stream, n, nll_part, nll_count,
+                     nll_div, kl_bc, ncol, kl_div, free_bits, beta, out3, chan_mask);
+  return check_launch("cgen_elbo_finalize_fb");
 }

@@ -451,14 +451,20 @@ class Engine:
         self.launches += 1
         return out
 
-    def reparam_kl(self, q_loc, q_ls, p_loc, p_ls, eps, stream_id, logt, kl_ptr, kl_stride):
+    def reparam_kl(self, q_loc, q_ls, p_loc, p_ls, eps, stream_id, logt, kl_ptr, kl_stride, fb=None):
+        """`fb` = (S_ptr, S_stride, column offset) when free bits are on: per-(sample, channel) KL sums of this layer go to
+        S[b*S_stride + col + ch], and the backward pass scales this layer's KL gradient by kl_chan_ptr[col + ch]."""
         z = self.new(q_loc.n, q_loc.h, q_loc.w, q_loc.c)
+        if fb is not None:
+            self.lib.kl_channel_sums(self.dt, z.n, z.h, z.w, z.c, q_loc.cv(), q_ls.cv(), p_loc.cv(), p_ls.cv(), logt,
+                                     fb[0] + 4 * fb[2], fb[1], self.stream)
+            self.launches += 1
         self.lib.reparam_kl_fwd(self.dt, z.n, z.h, z.w, z.c, q_loc.cv(), q_ls.cv(), p_loc.cv(), p_ls.cv(),
                                 eps.cv() if eps is not None else NULL_VIEW, self.rng_ptr(), stream_id, logt, z.cv(), NULL_VIEW,
                                 kl_ptr, kl_stride, self.stream)
         self.launches += 1
         if self.recording:
-            self.tape.append((self._bw_reparam, (q_loc, q_ls, p_loc, p_ls, z, logt)))
+            self.tape.append((self._bw_reparam, (q_loc, q_ls, p_loc, p_ls, z, logt, None if fb is None else fb[2])))
         return z
 
     def sample_gaussian(self, loc, ls, eps, stream_id, logt):
@@ -788,7 +794,7 @@ class Engine:
         inner = NT(g.ptr, x.n, x.h, x.w, x.c, g.sn, g.sh, g.sw, g.es, rg=False)
         self.grad_add(x, inner)
 
-    def _bw_reparam(self, q_loc, q_ls, p_loc, p_ls, z, logt):
+    def _bw_reparam(self, q_loc, q_ls, p_loc, p_ls, z, logt, fb_col=None):
         gz = self.grad_read(z)
         gql, a1 = self.grad_write(q_loc)
         gqs, a2 = self.grad_write(q_ls)
@@ -796,6 +802,7 @@ class Engine:
         gps, a4 = self.grad_write(p_ls)
         assert a1 == a2 and a3 == a4
         self.lib.reparam_kl_bwd(self.dt, z.n, z.h, z.w, z.c, q_loc.cv(), q_ls.cv(), p_loc.cv(), p_ls.cv(), z.cv(), logt,
-                                gz.cv() if gz is not None else NULL_VIEW, self.kl_coef_ptr, 0, gql.cv(), gqs.cv(), gpl.cv(),
+                                gz.cv() if gz is not None else NULL_VIEW, self.kl_coef_ptr, 0,
+                                None if fb_col is None else self.kl_chan_ptr + 4 * fb_col, gql.cv(), gqs.cv(), gpl.cv(),
                                 gps.cv(), 1 if a1 else 0, 1 if a3 else 0, self.stream)
         self.launches += 1

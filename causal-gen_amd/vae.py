@@ -258,7 +258,7 @@ class HVAE(nn.Module):
         self.q_correction = args.q_correction
         self._reset_runtime()
 
-    _RUNTIME_KEYS = ("_eng", "_trigger", "noise", "_saved", "_coef")
+    _RUNTIME_KEYS = ("_eng", "_trigger", "noise", "_saved", "_coef", "_fb_buf")
 
     def _reset_runtime(self):
         for k in self._RUNTIME_KEYS:
@@ -380,7 +380,7 @@ class HVAE(nn.Module):
         assert tuple(e.shape) == (n, c, h, w), (tuple(e.shape), shape_nhwc)
         return eng.from_nchw(e.to(eng.device, torch.float32))
 
-    def _decode(self, eng, parents, acts=None, t=None, latents=None, collect=None, drop=(1, 1), kl=None):
+    def _decode(self, eng, parents, acts=None, t=None, latents=None, collect=None, drop=(1, 1), kl=None, fb=None):
         """Decoder.forward (vae.py:222-301).  `collect`: None | "z" | "q" (q stats for cond-prior abduction) |
         "p" (prior stats).  `kl` = (ptr, stride, offsets) when the KL is wanted."""
         dec = self.decoder
@@ -423,7 +423,8 @@ class HVAE(nn.Module):
                     eps = self._next_eps(eng, q_loc.shape)
                     kptr = kl[0] + 4 * kl[2][i] if kl is not None else self._scratch_kl(eng, B, res, zd)
                     kstride = kl[1] if kl is not None else _lib.load().reparam_kl_chunks(res, res, zd)
-                    z = eng.reparam_kl(q_loc, q_ls, p_loc, p_ls, eps, sid, logt, kptr, kstride)
+                    fbl = None if fb is None else (fb[0], fb[1], fb[2][i])
+                    z = eng.reparam_kl(q_loc, q_ls, p_loc, p_ls, eps, sid, logt, kptr, kstride, fb=fbl)
                     if collect == "z":
                         out.append(z)
                     elif collect == "q":
@@ -477,8 +478,6 @@ class HVAE(nn.Module):
 
     # ------------------------------------------------------------------ training forward / backward
     def _run_forward(self, x, parents, beta, record):
-        if self.free_bits > 0:
-            raise NotImplementedError("kl_free_bits > 0 needs per-channel batch means; not on the HIP path yet")
         eng = self.engine()
         eng.begin()
         eng.recording = record
@@ -494,7 +493,20 @@ class HVAE(nn.Module):
         offs, kl_total = self._kl_layout(eng)
         kl_ptr = eng.new_f32(B * max(kl_total, 1))
         acts = self._encode(eng, xin)
-        h, _ = self._decode(eng, pa, acts=acts, drop=drop, kl=(kl_ptr, kl_total, offs))
+        fb = None
+        if self.free_bits > 0:
+            # vae.py:443-449: per-layer, per-channel batch means of the KL, floored at free_bits.  Needs a cross-rank mean of
+            # S under data parallelism, which this single-process path does not have.
+            if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                raise NotImplementedError("kl_free_bits > 0 under data parallelism needs an all-reduce inside the forward pass")
+            cols, ncol = {}, 0
+            for i, blk in enumerate(self.decoder.blocks):
+                if blk.stochastic:
+                    cols[i] = ncol
+                    ncol += blk.z_dim
+            s_buf = torch.empty(B * ncol + ncol, dtype=torch.float32, device=eng.device)  # S[B][ncol] then chan_mask[ncol]
+            fb = (s_buf.data_ptr(), ncol, cols)
+        h, _ = self._decode(eng, pa, acts=acts, drop=drop, kl=(kl_ptr, kl_total, offs), fb=fb)
         params = self._likelihood_params(eng, h)
         nchunk = lib.like_chunks(R, R)
         nll_ptr = eng.new_f32(B * nchunk)
@@ -505,7 +517,14 @@ class HVAE(nn.Module):
             lib.dmol_nll_fwd(eng.dt, B, R, R, params.cv(), xin.cv(), nll_ptr, eng.stream)
         out3 = torch.empty(3, dtype=torch.float32, device=eng.device)
         dims = float(Cx * R * R)
-        lib.elbo_finalize(B, nll_ptr, nchunk, dims, kl_ptr, kl_total, dims, float(beta), out3.data_ptr(), eng.stream)
+        if fb is None:
+            lib.elbo_finalize(B, nll_ptr, nchunk, dims, kl_ptr, kl_total, dims, float(beta), out3.data_ptr(), eng.stream)
+        else:
+            mask_ptr = fb[0] + 4 * B * fb[1]
+            lib.elbo_finalize_fb(B, nll_ptr, nchunk, dims, fb[0], fb[1], dims, float(self.free_bits), float(beta),
+                                 out3.data_ptr(), mask_ptr, eng.stream)
+            eng.kl_chan_ptr = mask_ptr
+            self.__dict__["_fb_buf"] = s_buf  # keep alive until the backward pass
         eng.launches += 2
         eng.recording = False
         self.__dict__["_saved"] = (params, xin, B, R, Cx, dims)

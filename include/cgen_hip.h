@@ -152,8 +152,14 @@ int cgen_reparam_kl_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t 
  * Writes (or accumulates into) the four gradients. */
 int cgen_reparam_kl_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls,
                         cgen_view p_loc, cgen_view p_ls, cgen_view z, float logt, cgen_view gz,
-                        const float* kl_coef_dev, int32_t coef_stride, cgen_view g_q_loc, cgen_view g_q_ls,
-                        cgen_view g_p_loc, cgen_view g_p_ls, int32_t acc_q, int32_t acc_p, cgen_stream_t);
+                        const float* kl_coef_dev, int32_t coef_stride, const float* kl_chan_scale, cgen_view g_q_loc,
+                        cgen_view g_q_ls, cgen_view g_p_loc, cgen_view g_p_ls, int32_t acc_q, int32_t acc_p, cgen_stream_t);
+/* kl_chan_scale (optional, [c]): per-channel multiplier of the KL gradient -- the free-bits mask of this layer.
+ *
+ * Free bits (kl_free_bits > 0, vae.py:443-449).  S[b*out_stride + ch] = sum_{h,w} KL(q||p)[b,h,w,ch] of one layer
+ * (c must divide 256; one deterministic workgroup per sample).  The caller lays the layers' channels side by side. */
+int cgen_kl_channel_sums(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls,
+                         cgen_view p_loc, cgen_view p_ls, float logt, float* out, int32_t out_stride, cgen_stream_t);
 /* element-wise KL(q || p) map on flat contiguous f32 arrays, no reduction: the module-level gaussian_kl of vae.py:14-25
  * (-0.5 + p_ls - q_ls + 0.5 * (exp(q_ls)^2 + (q_loc - p_loc)^2) / exp(p_ls)^2; no clamps) */
 int cgen_gaussian_kl_map(int64_t count, const float* q_loc, const float* q_ls, const float* p_loc, const float* p_ls,
@@ -195,6 +201,10 @@ int cgen_dmol_decode(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view l
  * layout: kl_part[b*kl_stride + j], j < kl_count. */
 int cgen_elbo_finalize(int32_t n, const float* nll_part, int32_t nll_count, float nll_div, const float* kl_part,
                        int32_t kl_count, float kl_div, float beta, float* out3, cgen_stream_t);
+/* free-bits variant: kl = sum_j max(free_bits, mean_b kl_bc[b*ncol + j]) / kl_div; out3 as above;
+ * chan_mask[j] = d max/d mean (1 / 0 / 0.5 on a tie) for cgen_reparam_kl_bwd's kl_chan_scale */
+int cgen_elbo_finalize_fb(int32_t n, const float* nll_part, int32_t nll_count, float nll_div, const float* kl_bc, int32_t ncol,
+                          float kl_div, float free_bits, float beta, float* out3, float* chan_mask, cgen_stream_t);
 /* Counterfactual pixel step (dscm.py:55-63): u=(x-rec_loc)/max(rec_scale,1e-12); cf=clamp(cf_loc+cf_scale*u,-1,1);
  * optional running sums sum_x += cf, sum_x2 += cf^2.  All NCHW f32 contiguous, `count` elements. */
 int cgen_cf_pixels(int64_t count, const float* x, const float* rec_loc, const float* rec_scale, const float* cf_loc,
