@@ -606,6 +606,26 @@ class Engine:
             return
         self.grad_add(r, g)
 
+    def flat_axpy(self, src_ptr, dst_ptr, count, alpha=1.0, accumulate=True):
+        """dst (+)= alpha * src over `count` contiguous f32 (gradient accumulation across backward passes; fill with
+        `alpha` when src_ptr is None)."""
+        cols = 1024
+        rows = count // cols
+
+        def v(ptr, w, c):
+            return NULL_VIEW if ptr is None else View(ptr, w * c, w * c, c, c, 0)
+
+        if rows:
+            self.lib.axpby(F32, 1, 1, rows, v(src_ptr, rows, cols), v(dst_ptr, rows, cols), alpha, 1.0, 1 << 30,
+                           1 if accumulate else 0, self.stream)
+            self.launches += 1
+        rem = count - rows * cols
+        if rem:
+            off = 4 * rows * cols
+            self.lib.axpby(F32, 1, 1, 1, v(None if src_ptr is None else src_ptr + off, 1, rem), v(dst_ptr + off, 1, rem), alpha, 1.0,
+                           1 << 30, 1 if accumulate else 0, self.stream)
+            self.launches += 1
+
     def seed_grad(self, t):
         """Gradient buffer of an output tensor, to be written by a loss kernel."""
         gv, acc = self.grad_write(t)

@@ -56,6 +56,10 @@ class TrainStep:
         self.out3 = None
         self.beta = float(args.beta)
         self.it = 0
+        # gradient accumulation (trainer.py:64-67): elbo / accu_steps per iteration, summed in a second flat buffer; the
+        # optimiser tail runs on iterations with (it - 1) % accu_steps == 0 and reads that buffer
+        self.accu = max(1, int(getattr(args, "accu_steps", 1) or 1))
+        self.acc_g = torch.zeros(n, device=dev) if self.accu > 1 else None
 
     # -- pieces -----------------------------------------------------------------------------------------
     def _fwd_bwd(self, x, pa, beta):
@@ -63,7 +67,7 @@ class TrainStep:
         out3 = m._run_forward(x, pa, beta, record=True)
         params, xin, B, R, Cx, dims = m.__dict__["_saved"]
         if self.coef is None or self.coef_key != (B, dims, beta):
-            self.coef = torch.tensor([1.0 / (B * dims), beta / (B * dims)], device=eng.device)
+            self.coef = torch.tensor([1.0 / (B * dims * self.accu), beta / (B * dims * self.accu)], device=eng.device)
             self.coef_key = (B, dims, beta)
         eng.kl_coef_ptr = self.coef.data_ptr() + 4
         gparams = eng.seed_grad(params)
@@ -72,13 +76,18 @@ class TrainStep:
         else:
             self.lib.dmol_nll_bwd(eng.dt, B, R, R, params.cv(), xin.cv(), self.coef.data_ptr(), 0, gparams.cv(), eng.stream)
         eng.backward()
+        if self.acc_g is not None:
+            eng.flat_axpy(eng.flat_g.data_ptr(), self.acc_g.data_ptr(), eng.flat_g.numel())
         return out3
+
+    def _gbuf(self):
+        return self.eng.flat_g if self.acc_g is None else self.acc_g
 
     def _allreduce(self, out3):
         """Average the flat gradient (and the reported scalars, whose NaN-ness feeds the skip predicate) over the
         data-parallel ranks: a few large buckets, not 800 small tensors (xGMI rings are per-link bound)."""
         if self.world > 1:
-            dp.bucketed_allreduce_mean(self.eng.flat_g, self.bucket_elems, self.pg, extra=(out3,))
+            dp.bucketed_allreduce_mean(self._gbuf(), self.bucket_elems, self.pg, extra=(out3,))
 
     def _used_ranges(self):
         eng = self.eng
@@ -99,7 +108,8 @@ class TrainStep:
     def _optim(self, out3):
         eng, a = self.eng, self.args
         st = eng.stream
-        self.lib.sumsq_partial(eng.flat_g.data_ptr(), eng.flat_g.numel(), self.partial.data_ptr(), self.NORM_BLOCKS, st)
+        gbuf = self._gbuf()
+        self.lib.sumsq_partial(gbuf.data_ptr(), gbuf.numel(), self.partial.data_ptr(), self.NORM_BLOCKS, st)
         self.lib.clip_decide(self.partial.data_ptr(), self.NORM_BLOCKS, out3.data_ptr(), float(a.grad_clip), float(a.grad_skip),
                              self.state.data_ptr(), st)
         if self.ranges is None:
@@ -107,7 +117,7 @@ class TrainStep:
         for (lo, hi) in self.ranges:
             q = _lib.AdamwArgs()
             q.p = eng.flat_p.data_ptr() + 4 * lo
-            q.g = eng.flat_g.data_ptr() + 4 * lo
+            q.g = gbuf.data_ptr() + 4 * lo
             q.m = self.m.data_ptr() + 4 * lo
             q.v = self.v.data_ptr() + 4 * lo
             q.ema = self.ema_flat.data_ptr() + 4 * lo if self.ema_model is not None else None
@@ -117,12 +127,15 @@ class TrainStep:
             q.state_dev = self.state.data_ptr()
             self.lib.adamw_ema(C.byref(q), st)
         self.lib.step_commit(self.state.data_ptr(), st)
+        if self.acc_g is not None:  # model.zero_grad() of trainer.py:87
+            eng.flat_axpy(None, self.acc_g.data_ptr(), self.acc_g.numel(), alpha=0.0, accumulate=False)
 
-    def _eager(self, x, pa, beta):
+    def _eager(self, x, pa, beta, do_step=True):
         out3 = self._fwd_bwd(x, pa, beta)
         self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
-        self._allreduce(out3)
-        self._optim(out3)
+        if do_step:
+            self._allreduce(out3)
+            self._optim(out3)
         return out3
 
     # -- public -------------------------------------------------------------------------------------------
@@ -133,28 +146,29 @@ class TrainStep:
         beta = self.beta
         if getattr(a, "beta_warmup_steps", 0) > 0:
             beta = self.beta * linear_warmup(a.beta_warmup_steps)(self.it)
+        do_step = (self.it - 1) % self.accu == 0
         if not self.use_graph:
-            return self._eager(x, pa, beta)
+            return self._eager(x, pa, beta, do_step)
         m = self.model
         drop = (1, 1)
         if m.cond_prior:  # host draw (shared across DP ranks through the common seed), one graph per outcome
             drop = type(m.decoder).drop_cond(m.decoder)
             m.decoder.__dict__["drop_cond"] = lambda d=drop: d
-        key = (tuple(x.shape), x.dtype, beta, drop)
+        key = (tuple(x.shape), x.dtype, beta, drop, do_step)
         ent = self.graphs.get(key)
         if ent is None:
-            out = self._eager(x, pa, beta)  # eager warm-up: sizes the arena, builds the tables
+            out = self._eager(x, pa, beta, do_step)  # eager warm-up: sizes the arena, builds the tables
             sx, sp = x.clone(), pa.clone()
             torch.cuda.synchronize()
             # NCCL inside a captured graph is avoided: under DP the step is two graphs around an eager all-reduce
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 so = self._fwd_bwd(sx, sp, beta)
-                if self.world == 1:
+                if self.world == 1 and do_step:
                     self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
                     self._optim(so)
             g2 = None
-            if self.world > 1:
+            if self.world > 1 and do_step:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2):
                     self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream

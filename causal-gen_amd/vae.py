@@ -258,7 +258,7 @@ class HVAE(nn.Module):
         self.q_correction = args.q_correction
         self._reset_runtime()
 
-    _RUNTIME_KEYS = ("_eng", "_trigger", "noise", "_saved", "_coef", "_fb_buf")
+    _RUNTIME_KEYS = ("_eng", "_trigger", "noise", "_saved", "_coef", "_fb_buf", "_grad_prev")
 
     def _reset_runtime(self):
         for k in self._RUNTIME_KEYS:
@@ -549,15 +549,29 @@ class HVAE(nn.Module):
         else:
             lib.dmol_nll_bwd(eng.dt, B, R, R, params.cv(), xin.cv(), coef.data_ptr(), 0, gparams.cv(), eng.stream)
         eng.launches += 1
+        # torch semantics: a backward pass ACCUMULATES into existing .grad (trainer.py:64-67, accu_steps > 1).  The engine
+        # overwrites its flat gradient buffer, so when gradients are already attached they are parked and added back.
+        live = [p for p in self.parameters() if p.grad is not None]
+        for p in live:
+            if p.grad.data_ptr() != eng.param_grad_view(p).data_ptr():
+                raise RuntimeError("HVAE parameters' .grad must stay the engine's views (use zero_grad() to reset them)")
+        prev = None
+        if live:
+            prev = self.__dict__.get("_grad_prev")
+            if prev is None or prev.numel() != eng.flat_g.numel():
+                prev = self.__dict__["_grad_prev"] = torch.empty_like(eng.flat_g)
+            eng.flat_axpy(eng.flat_g.data_ptr(), prev.data_ptr(), prev.numel(), accumulate=False)
         eng.backward()
+        if prev is not None:
+            had = {id(p) for p in live}
+            for p in self.parameters():  # .grad is None means zero: nothing to add back for those
+                if id(p) not in had and id(p) in eng.pgrad_init:
+                    o = eng.p_off[id(p)]
+                    eng.flat_axpy(None, prev.data_ptr() + 4 * o, p.numel(), alpha=0.0, accumulate=False)
+            eng.flat_axpy(prev.data_ptr(), eng.flat_g.data_ptr(), prev.numel())
         for p in self.parameters():
-            if id(p) in eng.pgrad_init:
-                g = eng.param_grad_view(p)
-                if p.grad is None:
-                    p.grad = g
-                elif p.grad.data_ptr() != g.data_ptr():
-                    raise NotImplementedError("gradient accumulation over several backward passes (accu_steps > 1) "
-                                              "is not supported by the HIP path yet")
+            if id(p) in eng.pgrad_init and p.grad is None:
+                p.grad = eng.param_grad_view(p)
 
     def forward(self, x: Tensor, parents: Tensor, beta: int = 1) -> Dict[str, Tensor]:
         """vae.py:439-458 -> {elbo, nll, kl} as 0-dim tensors in nats/dim; ``elbo`` is differentiable."""

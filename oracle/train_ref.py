@@ -105,3 +105,23 @@ class RefTrainer:
         grads = {k: g for (k, v), g in zip([(k, v) for k, v in self.sd.items() if v.requires_grad], gs)}
         gn = self.apply_grads(grads, out["nll"].item(), out["kl"].item())
         return {k: float(v) for k, v in out.items()}, gn
+
+    def iteration(self, i, x, pa, beta=None, noise=None, drop=(1, 1)):
+        """One loader iteration of trainer.py:62-87 with gradient accumulation: backward of elbo / accu_steps into the
+        running .grad; the optimiser runs when ``i % accu_steps == 0`` (i is the 0-based enumerate index, so iteration 0
+        steps on a single micro-batch), tested on the LAST micro-batch's nll / kl; then zero_grad.  Returns
+        (out, grad_norm or None)."""
+        beta = self.hp.beta if beta is None else beta
+        out = hvae_ref.hvae_forward(self.sd, self.hp, x, pa, beta=beta, noise=noise, drop=drop)
+        named = [(k, v) for k, v in self.sd.items() if v.requires_grad]
+        gs = torch.autograd.grad(out["elbo"] / self.hp.accu_steps, [v for _, v in named], allow_unused=True)
+        acc = getattr(self, "_acc", None) or {}
+        for (k, _), g in zip(named, gs):
+            if g is not None:
+                acc[k] = g.detach() if acc.get(k) is None else acc[k] + g.detach()
+        self._acc = acc
+        gn = None
+        if i % self.hp.accu_steps == 0:
+            gn = self.apply_grads(acc, out["nll"].item(), out["kl"].item())
+            self._acc = {}
+        return {k: float(v) for k, v in out.items()}, gn

@@ -114,3 +114,77 @@ def test_counterfactual_api_and_dscm_forward():
     assert out["cfs"]["x"].shape == x.shape and out["var_cf_x"].shape == x.shape
     assert torch.isfinite(out["cfs"]["x"]).all() and (out["var_cf_x"] >= -1e-6).all()
     assert dscm.vae_preprocess(args, {"a": torch.ones(2, 1), "b": torch.ones(2, 1), "c": torch.ones(2, 1)}).shape == (2, 3, 16, 16)
+
+
+def test_backward_accumulates_into_existing_grads():
+    """torch semantics on the drop-in surface: a second backward without zero_grad() adds to .grad (what
+    trainer.py:64-67 relies on for accu_steps > 1)."""
+    fx, hpd, m = setup()
+    m.eval()
+    x, pa = fx["x"].cuda(), fx["pa"].cuda()
+    g = torch.Generator().manual_seed(3)
+    eps = [[torch.randn(e.shape, generator=g) for e in fx["fwd"]["eps"]] for _ in range(2)]
+    singles = []
+    for k in range(2):
+        m.zero_grad(set_to_none=True)
+        m.noise = [e.clone() for e in eps[k]]
+        (m(x, pa, beta=1.5)["elbo"] / 2).backward()
+        singles.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    m.zero_grad(set_to_none=True)
+    for k in range(2):
+        m.noise = [e.clone() for e in eps[k]]
+        (m(x, pa, beta=1.5)["elbo"] / 2).backward()
+    for n, p in m.named_parameters():
+        if n in singles[0]:
+            want = singles[0][n] + singles[1][n]
+            torch.testing.assert_close(p.grad, want, rtol=1e-5, atol=1e-7, msg=lambda s: f"{n}: {s}")
+
+
+def test_gradient_accumulation_matches_oracle():
+    """accu_steps = 2 (trainer.py:62-87): optimiser on iterations 0, 2, 4 over the summed elbo/2 gradients."""
+    from causal_gen_amd.train import TrainStep
+    from oracle import train_ref
+
+    fx, hpd, m = setup(accu_steps=2)
+    hp = SimpleNamespace(**hpd)
+    ref = train_ref.RefTrainer(fx["state_dict"], hp)
+    ts = TrainStep(m, hp, ema=True, use_graph=False)
+    x, pa = fx["x"], fx["pa"]
+    g = torch.Generator().manual_seed(0)
+    for i in range(5):
+        eps = [torch.randn(e.shape, generator=g) for e in fx["fwd"]["eps"]]
+        r_out, r_gn = ref.iteration(i, x, pa, noise=[e.clone() for e in eps])
+        m.noise = [e.clone() for e in eps]
+        out = ts.step(x.cuda(), pa.cuda())
+        got = [float(v) for v in out.cpu()]
+        for a, b in zip(got, (r_out["elbo"], r_out["nll"], r_out["kl"])):
+            assert abs(a - b) / abs(b) < 2e-4, (i, got, r_out)
+        st = ts.stats()
+        assert st["opt_steps"] == ref.opt_steps, (i, st, ref.opt_steps)
+        if r_gn is not None:
+            assert abs(st["grad_norm"] - r_gn) / r_gn < 2e-3, (i, st, r_gn)
+    assert ref.opt_steps == 3
+    sd = m.state_dict()
+    for k, v in ref.sd.items():
+        torch.testing.assert_close(sd[k].cpu(), v.detach(), rtol=2e-3, atol=2e-5, msg=lambda s: f"{k}: {s}")
+
+
+def test_gradient_accumulation_graph_equals_eager():
+    """The accumulate-only and the stepping iteration are two hipGraphs; replaying them must equal eager execution."""
+    from causal_gen_amd.train import TrainStep
+
+    outs = []
+    for use_graph in (False, True):
+        fx, hpd, m = setup(accu_steps=2)
+        torch.manual_seed(321)
+        ts = TrainStep(m, SimpleNamespace(**hpd), ema=True, use_graph=use_graph)
+        x, pa = fx["x"].cuda(), fx["pa"].cuda()
+        for _ in range(7):
+            o = ts.step(x, pa)
+        torch.cuda.synchronize()
+        outs.append(([float(v) for v in o.cpu()], {k: v.clone() for k, v in m.state_dict().items()}, ts.stats()))
+    (o0, s0, t0), (o1, s1, t1) = outs
+    assert t0["opt_steps"] == t1["opt_steps"] == 4  # iterations 0, 2, 4, 6
+    assert o0 == o1, (o0, o1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
