@@ -301,7 +301,23 @@ __global__ __launch_bounds__(256) void dmol_decode_kernel(int n, int h, int w, V
     dm_load<T>(vptr<T>(logits, b, px / w, px % w), l);
     float sel[DM_NMIX];
     uint32_t r[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0}, r3[4] = {0, 0, 0, 0};
-    if (mode == 0) {  // soft: softmax weights (dmol.py:170-172)
+    if (mode >= 10) {  // top-k (dmol.py:178-188): logits below the k-th largest are switched off, then renormalised
+      const int k = mode - 10;
+      float srt[DM_NMIX];
+#pragma unroll
+      for (int m = 0; m < DM_NMIX; ++m) srt[m] = l[m];
+#pragma unroll
+      for (int a = 1; a < DM_NMIX; ++a)  // insertion sort, descending
+#pragma unroll
+        for (int b2 = a; b2 > 0; --b2)
+          if (srt[b2] > srt[b2 - 1]) { const float tmp = srt[b2]; srt[b2] = srt[b2 - 1]; srt[b2 - 1] = tmp; }
+      float thr = srt[0];
+#pragma unroll
+      for (int m = 0; m < DM_NMIX; ++m) if (m == k - 1) thr = srt[m];
+#pragma unroll
+      for (int m = 0; m < DM_NMIX; ++m) if (l[m] < thr) l[m] = -INFINITY;
+    }
+    if (mode == 0 || mode >= 10) {  // soft: softmax weights (dmol.py:170-172)
       float mx = -INFINITY, se = 0.f;
 #pragma unroll
       for (int m = 0; m < DM_NMIX; ++m) mx = fmaxf(mx, l[m]);
@@ -506,7 +522,7 @@ extern "C" int cgen_dmol_decode(int32_t dtype, int32_t n, int32_t h, int32_t w, 
                                 const uint64_t* rng, uint32_t stream_id, float logt, float* x_nchw, float* scale_nchw,
                                 cgen_stream_t stream) {
   CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dmol_decode: bad dtype");
-  CGEN_REQUIRE(logits.p && logits.c == 100 && x_nchw && scale_nchw && mode >= 0 && mode <= 2 && (mode != 2 || rng), "cgen_dmol_decode: bad args");
+  CGEN_REQUIRE(logits.p && logits.c == 100 && x_nchw && scale_nchw && ((mode >= 0 && mode <= 2) || (mode >= 11 && mode <= 19)) && (mode != 2 || rng), "cgen_dmol_decode: bad args");
   const int grid = like_grid((int64_t)n * h * w);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(dmol_decode_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, mk(logits), mode, rng, stream_id, logt, x_nchw, scale_nchw);
   else hipLaunchKernelGGL(dmol_decode_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, mk(logits), mode, rng, stream_id, logt, x_nchw, scale_nchw);

@@ -3,7 +3,7 @@
 ``DmolNet`` has the same ``nll(h, x)`` / ``sample(h, return_loc, t)`` role as ``DGaussNet`` (dmol.py:218-245) and is
 swapped into ``HVAE.likelihood`` exactly as in the reference (SURVEY probe C.6): ``m.likelihood = DmolNet(args)``.
 The 1x1 conv (w0 -> 100 logits) runs through the MFMA conv kernel; the log-prob / mean / sample math is the fused
-kernels cgen_dmol_nll_fwd/bwd and cgen_dmol_decode (10 mixtures, RGB only; ``mask`` in {"soft","hard"}).
+kernels cgen_dmol_nll_fwd/bwd and cgen_dmol_decode (10 mixtures, RGB only; ``mask`` in {"soft","hard","top<k>"}).
 """
 from torch import nn
 

@@ -603,7 +603,13 @@ class HVAE(nn.Module):
             eng.lib.dgauss_sample(eng.dt, B, R, R, Cx, params.cv(), 0.0, None if return_loc else eng.rng_ptr(), 978,
                                   xo.data_ptr(), so.data_ptr(), eng.stream)
         else:
-            mode = {"soft": 0, "hard": 1}[lk.mask] if return_loc else 2
+            if not return_loc:
+                mode = 2
+            elif "top" in lk.mask:  # dmol.py:178-180: "top3" -> int(mask[-1]), must be < 10
+                mode = 10 + int(lk.mask[-1])
+                assert 1 <= mode - 10 < 10, "invalid top_k"
+            else:
+                mode = {"soft": 0, "hard": 1}[lk.mask]
             logt = 0.0 if t is None else float(torch.tensor(t).log())
             eng.lib.dmol_decode(eng.dt, B, R, R, params.cv(), mode, eng.rng_ptr(), 977, logt, xo.data_ptr(), so.data_ptr(),
                                 eng.stream)

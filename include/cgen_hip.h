@@ -193,7 +193,8 @@ int cgen_dmol_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view 
                       cgen_stream_t);
 int cgen_dmol_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, cgen_view x,
                       const float* coef_dev, int32_t coef_stride, cgen_view g_logits, cgen_stream_t);
-/* mode 0 soft mean, 1 hard (argmax) mean, 2 sample (Gumbel argmax + logistic noise from rng, temperature logt) */
+/* mode 0 soft mean, 1 hard (argmax) mean, 2 sample (Gumbel argmax + logistic noise from rng, temperature logt),
+ * 10 + k (k = 1..9): top-k mean -- mixtures below the k-th largest logit are switched off and the rest renormalised */
 int cgen_dmol_decode(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, int32_t mode,
                      const uint64_t* rng, uint32_t stream_id, float logt, float* x_nchw, float* scale_nchw, cgen_stream_t);
 /* elbo/nll/kl (vae.py:450-457): nll = mean_b( sum(nll_part[b]) / nll_div ), kl = mean_b( sum(kl_part[b]) / kl_div ),

@@ -259,7 +259,7 @@ def test_dmol_golden():
     eng.lib.dmol_nll_bwd(eng.dt, N, H, W, lt.cv(), xt.cv(), coef.data_ptr(), 0, gl.cv(), eng.stream)
     g = nhwc_to_torch(eng, gl).permute(0, 2, 3, 1)
     torch.testing.assert_close(g, d["grad_l"], rtol=2e-3, atol=2e-6)
-    for mode, mask in ((0, "soft"), (1, "hard")):
+    for mode, mask in ((0, "soft"), (1, "hard"), (13, "top3")):
         xo, so = torch.empty(N, 3, H, W, device="cuda"), torch.empty(N, 3, H, W, device="cuda")
         eng.lib.dmol_decode(eng.dt, N, H, W, lt.cv(), mode, None, 0, 0.0, xo.data_ptr(), so.data_ptr(), eng.stream)
         torch.testing.assert_close(xo.cpu().permute(0, 2, 3, 1), d[f"mean_{mask}"], rtol=1e-4, atol=1e-5)
