@@ -157,3 +157,41 @@ def test_train_steps_adamw_ema():
                 torch.testing.assert_close(tr.ema[k], snap["ema"][k], rtol=1e-5, atol=1e-7)
             assert abs(tr.lr() - snap["lr"]) < 1e-12
     assert tr.skipped == 1
+
+
+def test_simple_vae_config1():
+    """Config 1: the oracle's restatement of simple_vae.py against the reference's own outputs."""
+    from oracle import simple_ref
+
+    fx = load_golden("simple_vae_c1.pt")
+    assert fx["n_params"] == 234690
+    hp = SimpleNamespace(**fx["hp"])
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in fx["state_dict"].items()}
+    x, pa, cf_pa, eps = fx["x"], fx["pa"], fx["cf_pa"], fx["eps"]
+    f = fx["fwd"]
+    out = simple_ref.forward(sd, hp, x, pa, beta=f["beta"], eps=eps)
+    for k in ("elbo", "nll", "kl"):
+        torch.testing.assert_close(out[k].detach(), f[k], **TOL)
+    out["elbo"].backward()
+    for n, g in f["grads"].items():
+        torch.testing.assert_close(sd[n].grad, g, rtol=1e-4, atol=1e-6, msg=lambda m: f"{n}: {m}")
+    with torch.no_grad():
+        d = fx["fwd_drop"]
+        o = simple_ref.forward(sd, hp, x, pa, beta=1.0, eps=eps, drop=d["drop"])
+        for k in ("elbo", "nll", "kl"):
+            torch.testing.assert_close(o[k], d[k], **TOL)
+        ab = fx["abduct"]
+        q = simple_ref.abduct(sd, hp, x, pa, t=ab["t"], eps=eps)[0]
+        torch.testing.assert_close(q["z"], ab["z"], **TOL)
+        zs = simple_ref.abduct(sd, hp, x, pa, cf_parents=cf_pa, alpha=ab["alpha"], t=ab["t"], eps=eps)[0]
+        torch.testing.assert_close(zs, ab["zstar"], **TOL)
+        rl, rs = simple_ref.forward_latents(sd, hp, [q["z"]], pa, t=ab["t"])
+        cl, cs = simple_ref.forward_latents(sd, hp, [zs], cf_pa, t=ab["t"])
+        torch.testing.assert_close(rl, ab["rec_loc"], **TOL)
+        torch.testing.assert_close(cs, ab["cf_scale"], **TOL)
+        cf = torch.clamp(cl + cs * ((x - rl) / rs.clamp(min=1e-12)), min=-1, max=1)
+        torch.testing.assert_close(cf, ab["cf_x"], rtol=1e-4, atol=1e-4)
+        s = fx["sample"]
+        sx, ss = simple_ref.sample(sd, hp, pa, t=s["t"], eps=eps)
+        torch.testing.assert_close(sx, s["x"], **TOL)
+        torch.testing.assert_close(ss, s["scale"], **TOL)
