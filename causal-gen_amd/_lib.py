@@ -7,6 +7,7 @@ LIB_PATH = os.path.join(_HERE, "libcgen_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+UNARY_LEAKY_RELU, UNARY_CLAMP_MIN, UNARY_ADD = 3, 4, 5
 MAX_SEG = 4
 
 
@@ -78,9 +79,13 @@ PROTOTYPES = {
                             View, i32, i32, vp],
     "cgen_kl_channel_sums": [i32, i32, i32, i32, i32, View, View, View, View, f32, vp, i32, vp],
     "cgen_elbo_finalize_fb": [i32, vp, i32, f32, vp, i32, f32, f32, f32, vp, vp, vp],
+    "cgen_im2col_strided": [i32, i32, i32, i32, i32, i32, i32, i32, i32, View, View, vp],
+    "cgen_col2im_strided": [i32, i32, i32, i32, i32, i32, i32, i32, i32, View, View, i32, vp],
+    "cgen_unary_fwd": [i32, i32, f32, i32, i32, i32, i32, View, View, vp],
+    "cgen_unary_bwd": [i32, i32, f32, i32, i32, i32, i32, View, View, View, i32, vp],
     "cgen_sample_gaussian": [i32, i32, i32, i32, i32, View, View, View, vp, u32, f32, View, vp],
     "cgen_gaussian_kl_map": [i64, vp, vp, vp, vp, vp, vp],
-    "cgen_mediator_mix": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, f32, f32, View, vp],
+    "cgen_mediator_mix": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, f32, f32, i32, View, vp],
     "cgen_like_chunks": [i32, i32],
     "cgen_dgauss_nll_fwd": [i32, i32, i32, i32, i32, View, View, vp, vp],
     "cgen_dgauss_nll_bwd": [i32, i32, i32, i32, i32, View, View, vp, i32, View, vp],

@@ -287,6 +287,97 @@ static inline bool vec4_ok(int esz, int c, std::initializer_list<const cgen_view
     }                                                                                                         \
   } while (0)
 
+
+// ----------------------------------------------------------------------------- strided im2col / col2im, unary ops
+// (config 1, simple_vae.py: 5x5/s2/p1 and 3x3/s2/p1 convolutions run as im2col + a 1x1 conv; LeakyReLU; clamp(min))
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_strided_kernel(Shape4 so, int hi, int wi, int ks, int stride, int pad, int cin, View in, View out,
+                                                             int cphys) {
+  const int taps = ks * ks;
+  const int64_t total = (int64_t)so.n * so.h * so.w * cphys;
+  GRID_STRIDE(g) {
+    if (g >= total) return;
+    const int oc = (int)(g % cphys);
+    int64_t r = g / cphys;
+    const int ox = (int)(r % so.w); r /= so.w;
+    const int oy = (int)(r % so.h);
+    const int n = (int)(r / so.h);
+    T v = (T)0;
+    if (oc < cin * taps) {
+      const int c = oc / taps, tap = oc - c * taps;
+      const int yy = oy * stride - pad + tap / ks, xx = ox * stride - pad + tap % ks;
+      if (yy >= 0 && yy < hi && xx >= 0 && xx < wi) v = *(vptr<T>(in, n, yy, xx) + c);
+    }
+    *(vptr<T>(out, n, oy, ox) + oc) = v;
+  }
+}
+
+// gin[n,y,x,c] (+)= sum over (oy, ox, tap) that read this input pixel of gcol[n,oy,ox, c*taps + tap]   (gather form)
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_strided_kernel(Shape4 si, int ho, int wo, int ks, int stride, int pad, View gcol, View gin,
+                                                             int accumulate) {
+  const int taps = ks * ks;
+  const int64_t total = (int64_t)si.n * si.h * si.w * si.c;
+  GRID_STRIDE(g) {
+    if (g >= total) return;
+    const int c = (int)(g % si.c);
+    int64_t r = g / si.c;
+    const int x = (int)(r % si.w); r /= si.w;
+    const int y = (int)(r % si.h);
+    const int n = (int)(r / si.h);
+    float a = 0.f;
+    for (int tap = 0; tap < taps; ++tap) {
+      const int ny = y + pad - tap / ks, nx = x + pad - tap % ks;
+      if (ny < 0 || nx < 0 || ny % stride || nx % stride) continue;
+      const int oy = ny / stride, ox = nx / stride;
+      if (oy < ho && ox < wo) a += Elem<T>::ld(vptr<T>(gcol, n, oy, ox) + c * taps + tap);
+    }
+    T* o = vptr<T>(gin, n, y, x) + c;
+    Elem<T>::st(o, accumulate ? Elem<T>::ld(o) + a : a);
+  }
+}
+
+__device__ __forceinline__ float unary_f(int op, float p, float x) {
+  if (op == CGEN_UNARY_LEAKY_RELU) return x > 0.f ? x : p * x;
+  if (op == CGEN_UNARY_CLAMP_MIN) return x < p ? p : x;  // NaN stays NaN, as torch.clamp
+  if (op == CGEN_UNARY_ADD) return x + p;
+  return act_fwd(op, x);
+}
+__device__ __forceinline__ float unary_df(int op, float p, float x) {
+  if (op == CGEN_UNARY_LEAKY_RELU) return x > 0.f ? 1.f : p;
+  if (op == CGEN_UNARY_CLAMP_MIN) return x < p ? 0.f : 1.f;  // torch: gradient passes where x >= min
+  if (op == CGEN_UNARY_ADD) return 1.f;
+  return act_bwd(op, x);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void unary_fwd_kernel(Shape4 s, int op, float p, View in, View out) {
+  const int64_t total = (int64_t)s.n * s.h * s.w * s.c;
+  GRID_STRIDE(g) {
+    if (g >= total) return;
+    const int c = (int)(g % s.c);
+    int64_t r = g / s.c;
+    const int x = (int)(r % s.w); r /= s.w;
+    const int y = (int)(r % s.h);
+    const int n = (int)(r / s.h);
+    Elem<T>::st(vptr<T>(out, n, y, x) + c, unary_f(op, p, Elem<T>::ld(vptr<T>(in, n, y, x) + c)));
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void unary_bwd_kernel(Shape4 s, int op, float p, View xin, View gout, View gin, int accumulate) {
+  const int64_t total = (int64_t)s.n * s.h * s.w * s.c;
+  GRID_STRIDE(g) {
+    if (g >= total) return;
+    const int c = (int)(g % s.c);
+    int64_t r = g / s.c;
+    const int x = (int)(r % s.w); r /= s.w;
+    const int y = (int)(r % s.h);
+    const int n = (int)(r / s.h);
+    const float v = Elem<T>::ld(vptr<T>(gout, n, y, x) + c) * unary_df(op, p, Elem<T>::ld(vptr<T>(xin, n, y, x) + c));
+    T* o = vptr<T>(gin, n, y, x) + c;
+    Elem<T>::st(o, accumulate ? Elem<T>::ld(o) + v : v);
+  }
+}
+
 }  // namespace cgen
 
 using namespace cgen;
@@ -413,4 +504,50 @@ extern "C" int cgen_nhwc_to_nchw(int32_t dtype, int32_t n, int32_t c, int32_t h,
   if (dtype == CGEN_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, mk(in), dst);
   else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, mk(in), dst);
   return check_launch("cgen_nhwc_to_nchw");
+}
+
+extern "C" int cgen_im2col_strided(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t ks, int32_t stride, int32_t pad, int32_t ho,
+                                   int32_t wo, cgen_view in, cgen_view out, cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_im2col_strided");
+  CGEN_REQUIRE(in.p && out.p && ks >= 1 && stride >= 1 && pad >= 0 && out.c == in.c * ks * ks, "cgen_im2col_strided: bad args");
+  CGEN_REQUIRE(ho == (h + 2 * pad - ks) / stride + 1 && wo == (w + 2 * pad - ks) / stride + 1, "cgen_im2col_strided: bad output size");
+  const int cphys = out.cpad > out.c ? out.cpad : out.c;
+  Shape4 so{n, ho, wo, out.c};
+  const int64_t items = (int64_t)n * ho * wo * cphys;
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(im2col_strided_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, so, h, w, ks, stride, pad, in.c, mk(in), mk(out), cphys);
+  else hipLaunchKernelGGL(im2col_strided_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, so, h, w, ks, stride, pad, in.c, mk(in), mk(out), cphys);
+  return check_launch("cgen_im2col_strided");
+}
+
+extern "C" int cgen_col2im_strided(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t ks, int32_t stride, int32_t pad, int32_t ho,
+                                   int32_t wo, cgen_view gcol, cgen_view gin, int32_t accumulate, cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_col2im_strided");
+  CGEN_REQUIRE(gcol.p && gin.p && ks >= 1 && stride >= 1 && pad >= 0 && gcol.c == gin.c * ks * ks, "cgen_col2im_strided: bad args");
+  Shape4 si{n, h, w, gin.c};
+  const int64_t items = (int64_t)n * h * w * gin.c;
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(col2im_strided_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, si, ho, wo, ks, stride, pad, mk(gcol), mk(gin), accumulate);
+  else hipLaunchKernelGGL(col2im_strided_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, si, ho, wo, ks, stride, pad, mk(gcol), mk(gin), accumulate);
+  return check_launch("cgen_col2im_strided");
+}
+
+extern "C" int cgen_unary_fwd(int32_t dtype, int32_t op, float param, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view in, cgen_view out,
+                              cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_unary_fwd");
+  CGEN_REQUIRE(in.p && out.p && op >= 0 && op <= CGEN_UNARY_ADD, "cgen_unary_fwd: bad args");
+  Shape4 s{n, h, w, c};
+  const int64_t items = (int64_t)n * h * w * c;
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(unary_fwd_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, op, param, mk(in), mk(out));
+  else hipLaunchKernelGGL(unary_fwd_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, op, param, mk(in), mk(out));
+  return check_launch("cgen_unary_fwd");
+}
+
+extern "C" int cgen_unary_bwd(int32_t dtype, int32_t op, float param, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view x, cgen_view gout,
+                              cgen_view gin, int32_t accumulate, cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_unary_bwd");
+  CGEN_REQUIRE(x.p && gout.p && gin.p && op >= 0 && op <= CGEN_UNARY_ADD, "cgen_unary_bwd: bad args");
+  Shape4 s{n, h, w, c};
+  const int64_t items = (int64_t)n * h * w * c;
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(unary_bwd_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, op, param, mk(x), mk(gout), mk(gin), accumulate);
+  else hipLaunchKernelGGL(unary_bwd_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, op, param, mk(x), mk(gout), mk(gin), accumulate);
+  return check_launch("cgen_unary_bwd");
 }

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void sample_gaussian_kernel(int n, int h, int 
 
 template <typename T>
 __global__ __launch_bounds__(256) void mediator_kernel(int n, int h, int w, int c, View z, View q_loc, View q_ls, View p_loc,
-                                                       View p_ls, float alpha, float t, float logt, View out) {
+                                                       View p_ls, float alpha, float t, float logt, int linear_var, View out) {
   const int per = h * w * c;
   const int64_t total = (int64_t)n * per;
   for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256) void mediator_kernel(int n, int h, int w, int 
     const float psc = expf(Elem<T>::ld(vptr<T>(p_ls, b, y, x) + ch) + logt);
     const float u = (zv - ql) / qsc;
     const float r_loc = alpha * ql + (1.f - alpha) * pl;
-    float r_scale = sqrtf(alpha * alpha * qsc * qsc + (1.f - alpha) * (1.f - alpha) * psc * psc);
+    // vae.py:505 weights the variances by a^2 / (1-a)^2; simple_vae.py:385 by a / (1-a)
+    const float wq = linear_var ? alpha : alpha * alpha, wp = linear_var ? (1.f - alpha) : (1.f - alpha) * (1.f - alpha);
+    float r_scale = sqrtf(wq * qsc * qsc + wp * psc * psc);
     if (t > 0.f) r_scale *= t;
     Elem<T>::st(vptr<T>(out, b, y, x) + ch, r_loc + r_scale * u);
   }
@@ -240,14 +242,14 @@ extern "C" int cgen_sample_gaussian(int32_t dtype, int32_t n, int32_t h, int32_t
 
 extern "C" int cgen_mediator_mix(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view z, cgen_view q_loc,
                                  cgen_view q_ls, cgen_view p_loc, cgen_view p_ls, float alpha, float t, float logt,
-                                 cgen_view out, cgen_stream_t stream) {
+                                 int32_t linear_var, cgen_view out, cgen_stream_t stream) {
   CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_mediator_mix: bad dtype");
   CGEN_REQUIRE(z.p && q_loc.p && q_ls.p && p_loc.p && p_ls.p && out.p, "cgen_mediator_mix: null view");
   const int grid = lat_grid((int64_t)n * h * w * c);
   if (dtype == CGEN_F32)
-    hipLaunchKernelGGL(mediator_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(z), mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), alpha, t, logt, mk(out));
+    hipLaunchKernelGGL(mediator_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(z), mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), alpha, t, logt, linear_var, mk(out));
   else
-    hipLaunchKernelGGL(mediator_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(z), mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), alpha, t, logt, mk(out));
+    hipLaunchKernelGGL(mediator_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(z), mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), alpha, t, logt, linear_var, mk(out));
   return check_launch("cgen_mediator_mix");
 }
 

@@ -16,7 +16,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, NULL_VIEW, View
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, NULL_VIEW, UNARY_CLAMP_MIN, UNARY_LEAKY_RELU, View
 
 _ALIGN = 256
 
@@ -508,6 +508,84 @@ class Engine:
         if cur < b:
             out.append((cur, b))
         return out
+
+    # ------------------------------------------------------------------ ops used only by the config-1 model (simple_vae)
+    def unary(self, x, op, param=0.0):
+        """Stand-alone activation / clamp (ACT_* or UNARY_*), differentiable."""
+        out = self.new(x.n, x.h, x.w, x.c, rg=x.rg)
+        self.lib.unary_fwd(self.dt, op, float(param), x.n, x.h, x.w, x.c, x.cv(), out.cv(), self.stream)
+        self.launches += 1
+        if self.recording and x.rg:
+            self.tape.append((self._bw_unary, (x, out, op, float(param))))
+        return out
+
+    def _bw_unary(self, x, out, op, param):
+        g = self.grad_read(out)
+        if g is None:
+            return
+        gv, acc = self.grad_write(x)
+        self.lib.unary_bwd(self.dt, op, param, x.n, x.h, x.w, x.c, x.cv(), g.cv(), gv.cv(), 1 if acc else 0, self.stream)
+        self.launches += 1
+
+    def im2col_strided(self, x, ks, stride, pad):
+        """[N,H,W,C] -> [N,Ho,Wo,C*ks*ks] patches (channel = c*ks*ks + tap); differentiable (col2im)."""
+        ho, wo = (x.h + 2 * pad - ks) // stride + 1, (x.w + 2 * pad - ks) // stride + 1
+        out = self.new(x.n, ho, wo, x.c * ks * ks, rg=x.rg)
+        out.cpad = _ceil(out.c, 8)  # the kernel zeroes the padding channels of every pixel
+        self.lib.im2col_strided(self.dt, x.n, x.h, x.w, ks, stride, pad, ho, wo, x.cv(), out.cv(), self.stream)
+        self.launches += 1
+        if self.recording and x.rg:
+            self.tape.append((self._bw_im2col_strided, (x, out, ks, stride, pad)))
+        return out
+
+    def _bw_im2col_strided(self, x, out, ks, stride, pad):
+        g = self.grad_read(out)
+        if g is None:
+            return
+        gv, acc = self.grad_write(x)
+        self.lib.col2im_strided(self.dt, x.n, x.h, x.w, ks, stride, pad, out.h, out.w, g.cv(), gv.cv(), 1 if acc else 0, self.stream)
+        self.launches += 1
+
+    def flatten_chw(self, x):
+        """[N,H,W,C] -> [N,1,1,C*H*W] in (c, y, x) order: what ``t.reshape(N, -1)`` does to an NCHW tensor
+        (simple_vae.py:62).  f32 engines only (the layout kernels convert to / from f32 NCHW)."""
+        assert self.dt == F32, "flatten_chw: f32 engine only"
+        k = x.c * x.h * x.w
+        out = self.new(x.n, 1, 1, k, rg=x.rg)
+        assert out.sn == k, "flatten_chw needs an unpadded vector (C*H*W multiple of 8)"
+        self.lib.nhwc_to_nchw(self.dt, x.n, x.c, x.h, x.w, x.cv(), out.ptr, self.stream)
+        self.launches += 1
+        if self.recording and x.rg:
+            self.tape.append((self._bw_flatten_chw, (x, out)))
+        return out
+
+    def _bw_flatten_chw(self, x, out):
+        g = self.grad_read(out)
+        if g is None:
+            return
+        gv, acc = self.grad_write(x)
+        assert not acc and g.sn == x.c * x.h * x.w and gv.coff == 0 and gv.c == x.c
+        self.lib.nchw_to_nhwc(0, self.dt, x.n, x.c, x.h, x.w, g.ptr, gv.cv(), 0.0, 1.0, self.stream)
+        self.launches += 1
+
+    def unflatten_chw(self, v, c, h, w):
+        """[N,1,1,C*H*W] -> [N,H,W,C], the inverse of flatten_chw (``t.reshape(N, -1, 4, 4)``, simple_vae.py:310)."""
+        assert self.dt == F32 and v.c == c * h * w and v.sn == v.c
+        out = self.new(v.n, h, w, c, rg=v.rg)
+        self.lib.nchw_to_nhwc(0, self.dt, v.n, c, h, w, v.ptr, out.cv(), 0.0, 1.0, self.stream)
+        self.launches += 1
+        if self.recording and v.rg:
+            self.tape.append((self._bw_unflatten_chw, (v, out)))
+        return out
+
+    def _bw_unflatten_chw(self, v, out):
+        g = self.grad_read(out)
+        if g is None:
+            return
+        gv, acc = self.grad_write(v)
+        assert not acc and gv.sn == v.c and gv.coff == 0 and gv.c == v.c
+        self.lib.nhwc_to_nchw(self.dt, out.n, out.c, out.h, out.w, g.cv(), gv.ptr, self.stream)
+        self.launches += 1
 
     # ------------------------------------------------------------------ two-stream sections of the forward pass
     def fork_side(self):

@@ -661,7 +661,7 @@ class HVAE(nn.Module):
         for (z, ql, qs_), (pl, pls) in zip(qs, ps):
             o = eng.new(z.n, z.h, z.w, z.c, rg=False)
             eng.lib.mediator_mix(eng.dt, z.n, z.h, z.w, z.c, z.cv(), ql.cv(), qs_.cv(), pl.cv(), pls.cv(), float(alpha),
-                                 float(t) if t is not None else -1.0, logt, o.cv(), eng.stream)
+                                 float(t) if t is not None else -1.0, logt, 0, o.cv(), eng.stream)
             eng.launches += 1
             outs.append(eng.to_torch_cl(o))
         return outs

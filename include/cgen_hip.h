@@ -133,6 +133,24 @@ int cgen_nchw_to_nhwc(int32_t src_is_u8, int32_t dtype, int32_t n, int32_t c, in
  * image and in out's padding channels (out.c = in.c*ks*ks, out.cpad = ceil8(out.c)).  The 7x7 stem then runs as a 1x1
  * conv over 49*Ci channels on the MFMA kernels, with the OIHW weight used as the [Co][49*Ci] matrix unchanged. */
 int cgen_im2col(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t ks, cgen_view in, cgen_view out, cgen_stream_t);
+/* General im2col / col2im (config 1, simple_vae.py:38-49: the 5x5/s2/p1 and 3x3/s2/p1 convolutions run as im2col + a
+ * 1x1 conv with the OIHW weight used as the [Co][Ci*ks*ks] matrix).  out[n,oy,ox, c*ks*ks + tap] =
+ * in[n, oy*stride - pad + dy, ox*stride - pad + dx, c] (zeros outside; channels [out.c, out.cpad) zeroed);
+ * col2im is its transpose: gin (+)= scatter of gcol. */
+int cgen_im2col_strided(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t ks, int32_t stride, int32_t pad, int32_t ho,
+                        int32_t wo, cgen_view in, cgen_view out, cgen_stream_t);
+int cgen_col2im_strided(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t ks, int32_t stride, int32_t pad, int32_t ho,
+                        int32_t wo, cgen_view gcol, cgen_view gin, int32_t accumulate, cgen_stream_t);
+/* Stand-alone unary ops where an activation cannot be fused into a consumer (simple_vae.py:13 LeakyReLU applied to one
+ * segment of a concatenation only; .clamp(min=EPS) on log-scales, :68,97): op = CGEN_ACT_* or CGEN_UNARY_*;
+ * bwd: gin (+)= gout * f'(x) */
+#define CGEN_UNARY_LEAKY_RELU 3 /* param = negative slope */
+#define CGEN_UNARY_CLAMP_MIN 4  /* param = minimum; gradient passes where x >= min */
+#define CGEN_UNARY_ADD 5        /* x + param (temperature: logscale + log t) */
+int cgen_unary_fwd(int32_t dtype, int32_t op, float param, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view in, cgen_view out,
+                   cgen_stream_t);
+int cgen_unary_bwd(int32_t dtype, int32_t op, float param, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view x, cgen_view gout,
+                   cgen_view gin, int32_t accumulate, cgen_stream_t);
 /* NHWC view -> contiguous NCHW f32 */
 int cgen_nhwc_to_nchw(int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, cgen_view in, float* dst, cgen_stream_t);
 
@@ -169,9 +187,10 @@ int cgen_sample_gaussian(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t
                          cgen_view eps_in, const uint64_t* rng, uint32_t stream_id, float logt, cgen_view z,
                          cgen_stream_t);
 /* Mediator latent z* (vae.py:485-513), q = q_ls+logt, p = p_ls+logt: u=(z-q_loc)/e^{q}; r_loc=a q_loc+(1-a)p_loc;
- * r_var=a^2 e^{2q}+(1-a)^2 e^{2p}; z* = r_loc + sqrt(r_var)*t*u   (t<=0 => no temperature factor) */
+ * r_var=a^2 e^{2q}+(1-a)^2 e^{2p}; z* = r_loc + sqrt(r_var)*t*u   (t<=0 => no temperature factor).
+ * linear_var != 0: r_var = a e^{2q} + (1-a) e^{2p}, the config-1 model's variant (simple_vae.py:383-386) */
 int cgen_mediator_mix(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view z, cgen_view q_loc,
-                      cgen_view q_ls, cgen_view p_loc, cgen_view p_ls, float alpha, float t, float logt, cgen_view out,
+                      cgen_view q_ls, cgen_view p_loc, cgen_view p_ls, float alpha, float t, float logt, int32_t linear_var, cgen_view out,
                       cgen_stream_t);
 
 /* ------------------------------------------------------------------ likelihoods (K11-K14) and ELBO

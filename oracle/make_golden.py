@@ -294,6 +294,7 @@ def simple_vae_fixture(B=6, seed=11):
     torch.manual_seed(seed)
     m = ref_simple.VAE(a).eval()
     n_params = sum(p.numel() for p in m.parameters())
+    init_abs_sum = float(sum(p.detach().double().abs().sum() for p in m.parameters()))  # default init under manual_seed(seed)
     with torch.no_grad():  # the prior heads are zero-initialised: perturb so every path is alive
         for n, p in m.named_parameters():
             if "prior.z_" in n or "likelihood.x_logscale" in n:
@@ -318,7 +319,7 @@ def simple_vae_fixture(B=6, seed=11):
         grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
         fx = dict(hp=dict(hps="morphomnist", input_res=32, input_channels=1, z_dim=16, context_dim=12, cond_prior=True,
                           widths=[16, 32, 64, 128, 256], x_like="diag_dgauss", std_init=0.0, hidden_dim=128),
-                  n_params=n_params, state_dict={k: v.detach().clone() for k, v in m.state_dict().items()},
+                  n_params=n_params, init_seed=seed, init_abs_sum=init_abs_sum, state_dict={k: v.detach().clone() for k, v in m.state_dict().items()},
                   x=x, pa=pa, cf_pa=cf_pa, eps=eps,
                   fwd=dict(beta=2.0, grads=grads, **{k: v.detach() for k, v in out.items()}))
         with torch.no_grad():

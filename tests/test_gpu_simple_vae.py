@@ -1,0 +1,89 @@
+"""Config 1: simple_vae.VAE on the HIP path against the golden fixture made from the imported reference.
+Tolerances as for the HVAE f32 path: ELBO / NLL / KL 1e-4 relative, gradients 2e-3 of the tensor's max, counterfactual
+pixels 1e-3 absolute."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def build():
+    from causal_gen_amd import simple_vae
+    from causal_gen_amd.hps import Hparams
+
+    fx = load_golden("simple_vae_c1.pt")
+    hp = {k: v for k, v in fx["hp"].items() if k != "hidden_dim"}
+    m = simple_vae.VAE(Hparams(**hp))
+    m.load_state_dict(fx["state_dict"])
+    return fx, m.cuda().eval()
+
+
+def rel(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+
+
+def test_forward_and_grads():
+    fx, m = build()
+    f = fx["fwd"]
+    m.noise = [fx["eps"].clone()]
+    out = m(fx["x"].cuda(), fx["pa"].cuda(), beta=f["beta"])
+    for k in ("elbo", "nll", "kl"):
+        assert rel(out[k].detach(), f[k]) < 1e-4, (k, float(out[k]), float(f[k]))
+    out["elbo"].backward()
+    torch.cuda.synchronize()
+    got = {n: p.grad for n, p in m.named_parameters()}
+    worst = 0.0
+    for n, g in f["grads"].items():
+        assert got[n] is not None, n
+        err = (got[n].cpu() - g).abs().max().item() / (g.abs().max().item() + 1e-8)
+        worst = max(worst, err)
+        assert err < 2e-3, (n, err)
+    print("simple_vae worst grad rel-to-max err", worst)
+    # 4-D parents take [:, :, 0, 0] (simple_vae.py:64-65)
+    m.noise = [fx["eps"].clone()]
+    with torch.no_grad():
+        o2 = m(fx["x"].cuda(), fx["pa"].cuda()[..., None, None].repeat(1, 1, 32, 32), beta=f["beta"])
+    assert rel(o2["elbo"], f["elbo"]) < 1e-4
+
+
+def test_train_mode_drop_cond():
+    fx, m = build()
+    d = fx["fwd_drop"]
+    m.train()
+    m.decoder.drop_cond = lambda: d["drop"]
+    m.noise = [fx["eps"].clone()]
+    with torch.no_grad():
+        out = m(fx["x"].cuda(), fx["pa"].cuda(), beta=1.0)
+    for k in ("elbo", "nll", "kl"):
+        assert rel(out[k], d[k]) < 1e-4, (k, float(out[k]), float(d[k]))
+
+
+def test_abduct_mediator_replay_counterfactual_and_sample():
+    fx, m = build()
+    ab = fx["abduct"]
+    x, pa, cf_pa = fx["x"].cuda(), fx["pa"].cuda(), fx["cf_pa"].cuda()
+    m.noise = [fx["eps"].clone()]
+    q = m.abduct(x, pa, t=ab["t"])[0]
+    torch.testing.assert_close(q["z"].cpu(), ab["z"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(q["q_logscale"].cpu(), ab["q_logscale"], rtol=1e-4, atol=1e-5)
+    m.noise = [fx["eps"].clone()]
+    zs = m.abduct(x, pa, cf_parents=cf_pa, alpha=ab["alpha"], t=ab["t"])[0]
+    torch.testing.assert_close(zs.cpu(), ab["zstar"], rtol=1e-4, atol=1e-5)
+    rec_loc, rec_scale = m.forward_latents([q["z"]], pa, t=ab["t"])
+    cf_loc, cf_scale = m.forward_latents([zs], cf_pa, t=ab["t"])
+    torch.testing.assert_close(rec_loc.cpu(), ab["rec_loc"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(cf_scale.cpu(), ab["cf_scale"], rtol=1e-4, atol=1e-5)
+    from causal_gen_amd import dscm
+
+    cf = dscm.cf_pixels(x, rec_loc, rec_scale, cf_loc, cf_scale)
+    assert (cf.cpu() - ab["cf_x"]).abs().max().item() < 1e-3
+    s = fx["sample"]
+    m.noise = [fx["eps"].clone()]
+    sx, ss = m.sample(pa, t=s["t"])
+    torch.testing.assert_close(sx.cpu(), s["x"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ss.cpu(), s["scale"], rtol=1e-4, atol=1e-5)
+    # return_loc=False adds pixel noise at temperature t and stays in range
+    xs, _ = m.forward_latents([zs], cf_pa, return_loc=False, t=0.7)
+    assert float(xs.abs().max()) <= 1.0 and not torch.equal(xs, cf_loc)
