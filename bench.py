@@ -104,6 +104,11 @@ def profile_step(ts, x, pa, dtype):
     """One eager step with HIP events around every conv launch (on the launch stream) -> per-class totals."""
     eng = ts.eng
     eng.prof = {}
+    # Park the stream behind a spin kernel while the host enqueues the whole eager step: otherwise the host (one ctypes call
+    # per launch) is slower than the GPU and every event pair would also time the idle gap before its kernel is enqueued.
+    torch.cuda.synchronize()
+    if hasattr(torch.cuda, "_sleep"):
+        torch.cuda._sleep(int(0.4 * 2.4e9))
     ts._eager(x, pa, ts.beta)
     torch.cuda.synchronize()
     classes = {}

@@ -1211,7 +1211,7 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
   g.n_cwin = ceil_div(ctot8, cwin);
   g.tiles_x = ceil_div(W, TILE_W); g.tiles_y = ceil_div(H, TILE_H);
   g.ntiles = N * g.tiles_x * g.tiles_y;
-  static const int want_total = [] { const char* e = getenv("CGEN_WG2_WANT"); return e ? atoi(e) : 512; }();
+  static const int want_total = [] { const char* e = getenv("CGEN_WG2_WANT"); return e ? atoi(e) : 384; }();
   int want = ceil_div(want_total, g.n_cwin * g.n_co);  // two persistent workgroups per CU
   {  // bound the split-K partials of one conv (they are written and re-read by cgen_wgrad_reduce)
     const char* e = getenv("CGEN_WG2_PARTIAL_MB");
