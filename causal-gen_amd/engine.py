@@ -148,7 +148,6 @@ class Engine:
         # end of the backward pass and issued round-robin on a few HIP streams (one fork, one join before the split-K
         # reduction).  The low-resolution ones are latency chains on a fraction of the CUs; several at a time fill the chip.
         self.wgrad_streams = int(os.environ.get("CGEN_WGRAD_STREAMS", "2"))
-        self.wgrad_flush = int(os.environ.get("CGEN_WGRAD_FLUSH", "0"))  # > 0: also issue them every N launches while the dgrad chain runs
         self._wg_forked = False
         self._wg_pool = []
         self._wg_deferred = []
@@ -780,8 +779,6 @@ class Engine:
         a.partial_b = buf.data_ptr() + 4 * nsplit * nw if site.conv.bias is not None else None
         if self._defer_wgrad():
             self._wg_deferred.append((a, 2.0 * site.ci * site.taps * site.co * x0.n * x0.h * x0.w))
-            if self.wgrad_flush > 0 and len(self._wg_deferred) >= self.wgrad_flush:
-                self._launch_deferred_wgrads(final=False)
         else:
             self._timed("conv_wgrad", site, x0, lambda: self.lib.conv2d_wgrad(C.byref(a), self.stream))
         self._wg_events.append((site, key, nsplit))
