@@ -1222,7 +1222,8 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
   }
   if (want < 1) want = 1;
   g.tps = ceil_div(g.ntiles, want);
-  if (g.tps < 2 && g.ntiles >= 2) g.tps = 2;
+  static const int min_tps = [] { const char* e = getenv("CGEN_WG2_MINTPS"); return e ? atoi(e) : 2; }();
+  if (g.tps < min_tps && g.ntiles >= min_tps) g.tps = min_tps;
   g.nsplit = ceil_div(g.ntiles, g.tps);
   return true;
 }
