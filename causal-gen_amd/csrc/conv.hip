@@ -667,6 +667,126 @@ static bool launch_conv_ws(const ConvP& p, hipStream_t st);  // weight-stationar
 static bool launch_conv_px(const ConvP& p, hipStream_t st);  // lean persistent kernel for short-K convs (bf16), defined below
 #define PX_MAXKS 16
 
+// ============================================================================= small-image conv with the K axis split (bf16)
+// Layers on 1x1 ... 4x4 images (the top of both hierarchies; 32 to a few hundred pixels in a batch) have long K
+// (512 channels x 9 taps = 144 K-steps) and almost no pixels: the generic kernel walks K serially in a handful of
+// workgroups, one exposed global-memory round trip per step (measured 40-270 us per launch).  Here the K-steps are
+// dealt round-robin to the 4 waves of a workgroup; each wave loads its MFMA operands straight from global memory (16 B per
+// lane: a weight-image row slice and an im2col slice of one pixel) with four K-steps in flight, and the four partial sums
+// are added through LDS in a fixed order (deterministic).  One workgroup = 16*SP_NCO output channels x 32 pixels.
+#define SP_NCO 2
+template <int KS>
+__global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, FastDiv d_ctot8, FastDiv d_hw, FastDiv d_w) {
+  typedef bf16_t T;
+  constexpr int HALO = KS / 2, TAPS = KS * KS, KU = 4;  // K-steps issued together per wave
+  __shared__ __attribute__((aligned(16))) float red[4 * SP_NCO * 2 * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int co_base = blockIdx.y * (SP_NCO * 16);
+  const int HWp = p.H * p.W;
+  int pn[2], py[2], px[2];
+  bool pv[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int m = blockIdx.x * 32 + f * 16 + fr;
+    pv[f] = m < p.P;
+    const int mm = pv[f] ? m : p.P - 1;
+    pn[f] = fdiv(mm, d_hw);
+    const int r = mm - pn[f] * HWp;
+    py[f] = fdiv(r, d_w);
+    px[f] = r - py[f] * p.W;
+  }
+  const int rows_pad = (p.Co + 15) & ~15;
+  f32x4 acc[SP_NCO][2];
+#pragma unroll
+  for (int t = 0; t < SP_NCO; ++t)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) acc[t][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // K-step ks = k0 + wave + 4*j ; image column = tap0*ctot8 + ks*32 + fg*8 (1x1 images only ever see their centre tap)
+  const int kcol0 = p.tap0 * p.ctot8;
+  for (int kb = wave; kb < nks; kb += 4 * KU) {
+    uint4 aq[KU][SP_NCO], bq[KU][2];
+#pragma unroll
+    for (int j = 0; j < KU; ++j) {
+      const int ks = kb + 4 * j;
+      const bool kin = ks < nks;
+      const int k = kcol0 + ks * 32 + fg * 8;
+      const int tap = fdiv(k, d_ctot8), c = k - tap * p.ctot8;
+      const int dy = tap / KS - HALO, dx = tap % KS - HALO;
+      int sidx = 0;
+#pragma unroll
+      for (int u = 1; u < CGEN_MAX_SEG; ++u) sidx += (u < p.nseg && c >= p.seg_koff[u]) ? 1 : 0;
+      View sv = p.seg[0];
+      int koff = p.seg_koff[0];
+#pragma unroll
+      for (int u = 1; u < CGEN_MAX_SEG; ++u)
+        if (sidx == u) { sv = p.seg[u]; koff = p.seg_koff[u]; }
+      const int cs = c - koff;
+      const bool kv = kin && tap < TAPS && cs < sv.c;
+#pragma unroll
+      for (int t = 0; t < SP_NCO; ++t) {
+        const int row = co_base + t * 16 + fr;
+        const uint4* src = (kin && row < rows_pad) ? (const uint4*)((const T*)p.w + (size_t)row * p.krow + k) : (const uint4*)g_zero16;
+        aq[j][t] = *src;
+      }
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int yy = py[f] + dy, xx = px[f] + dx;
+        const bool ok = kv && pv[f] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        const uint4* src = ok ? (const uint4*)(vptr<T>(sv, pn[f], yy, xx) + cs) : (const uint4*)g_zero16;
+        bq[j][f] = *src;  // unconditional load from a selected address (no branch, no early wait)
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KU; ++j) {
+      union { uint4 u; bf16x8 v; } a0, b0;
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        b0.u = p.act != CGEN_ACT_NONE ? act_group<T>(bq[j][f], p.act) : bq[j][f];
+#pragma unroll
+        for (int t = 0; t < SP_NCO; ++t) {
+          a0.u = aq[j][t];
+          acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v, b0.v, acc[t][f], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- fixed-order reduction over the four waves, then the generic fused epilogue
+#pragma unroll
+  for (int t = 0; t < SP_NCO; ++t)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) *(f32x4*)(red + ((wave * SP_NCO + t) * 2 + f) * 256 + lane * 4) = acc[t][f];
+  __syncthreads();
+  // wave w finalises fragment pair (t, f) = (w >> 1, w & 1)  (SP_NCO * 2 == 4 fragments)
+  {
+    const int t = wave >> 1, f = wave & 1;
+    f32x4 v = *(const f32x4*)(red + ((0 * SP_NCO + t) * 2 + f) * 256 + lane * 4);
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) {
+      const f32x4 o = *(const f32x4*)(red + ((w2 * SP_NCO + t) * 2 + f) * 256 + lane * 4);
+      v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+    }
+    // the pixel of fragment f owned by this lane (all lanes hold identical pn/py/px tables for both f)
+    const int n2 = f == 0 ? pn[0] : pn[1], y2 = f == 0 ? py[0] : py[1], x2 = f == 0 ? px[0] : px[1];
+    const bool v2 = f == 0 ? pv[0] : pv[1];
+    if (v2) conv_epilogue<T>(p, v, n2, y2, x2, co_base + t * 16 + fg * 4);
+  }
+}
+
+static bool launch_conv_smallp(const ConvP& p, hipStream_t st) {
+  for (int s = 0; s < p.nseg; ++s)
+    if (!p.seg_vec[s]) return false;  // 16-byte fragment loads
+  if (!p.dma_ok) return false;        // ragged channel counts must be zero padded to 8 (cpad), as for the tiled kernels
+  const int ntap = p.tap1 - p.tap0;
+  const int nks = ceil_div(ntap * p.ctot8, 32);
+  dim3 grid(ceil_div(p.P, 32), ceil_div(p.Co, SP_NCO * 16));
+  const FastDiv d1 = mk_fastdiv(p.ctot8), d2 = mk_fastdiv(p.H * p.W), d3 = mk_fastdiv(p.W);
+  if (p.KS == 1) hipLaunchKernelGGL((conv_smallp_kernel<1>), grid, dim3(256), 0, st, p, nks, d1, d2, d3);
+  else if (p.KS == 3) hipLaunchKernelGGL((conv_smallp_kernel<3>), grid, dim3(256), 0, st, p, nks, d1, d2, d3);
+  else return false;
+  return true;
+}
+
 static void conv_trace(const ConvP& p, const char* which) {  // CGEN_CONV_TRACE=1: which kernel served which shape
   static const bool on = getenv("CGEN_CONV_TRACE") != nullptr;
   if (on) fprintf(stderr, "conv %-5s ks%d ci8 %-4d co %-4d res %-3d nseg %d act %d aux %d res %d%d\n", which, p.KS, p.ctot8, p.Co, p.H, p.nseg, p.act,
@@ -690,6 +810,12 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   if ((p.KS == 1 || p.KS == 3) && p.H >= 5 && p.W >= 5 && !p.force_generic && p.dma_ok) {
     const bool ok = p.KS == 3 ? launch_conv_tile<T, 3>(p, st) : launch_conv_tile<T, 1>(p, st);
     if (ok) { conv_trace(p, "tile"); return check_launch("cgen_conv2d(tile)"); }
+  }
+  if constexpr (sizeof(T) == 2) {
+    if ((p.H < 5 || p.W < 5) && !p.force_generic && !getenv("CGEN_CONV_NO_SMALLP") && launch_conv_smallp(p, st)) {
+      conv_trace(p, "smlp");
+      return check_launch("cgen_conv2d(smallp)");
+    }
   }
   dim3 block(256);
   const int px_tiles = ceil_div(p.P, CONV_PT);
