@@ -668,17 +668,16 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st);  // lean persistent 
 #define PX_MAXKS 16
 
 // ============================================================================= small-image conv with the K axis split (bf16)
-// Layers on 1x1 ... 4x4 images (the top of both hierarchies; 32 to a few hundred pixels in a batch) have long K
+// Layers with few pixels in the batch (1x1 ... 12x12 images at batch 32: the top of both hierarchies) have long K
 // (512 channels x 9 taps = 144 K-steps) and almost no pixels: the generic kernel walks K serially in a handful of
 // workgroups, one exposed global-memory round trip per step (measured 40-270 us per launch).  Here the K-steps are
 // dealt round-robin to the 4 waves of a workgroup; each wave loads its MFMA operands straight from global memory (16 B per
 // lane: a weight-image row slice and an im2col slice of one pixel) with four K-steps in flight, and the four partial sums
 // are added through LDS in a fixed order (deterministic).  One workgroup = 16*SP_NCO output channels x 32 pixels.
-#define SP_NCO 2
-template <int KS>
+template <int KS, int SP_NCO, int KU>
 __global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, FastDiv d_ctot8, FastDiv d_hw, FastDiv d_w) {
   typedef bf16_t T;
-  constexpr int HALO = KS / 2, TAPS = KS * KS, KU = 4;  // K-steps issued together per wave
+  constexpr int HALO = KS / 2, TAPS = KS * KS;  // KU K-steps are issued together per wave
   __shared__ __attribute__((aligned(16))) float red[4 * SP_NCO * 2 * 256];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
@@ -757,9 +756,9 @@ __global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, Fast
 #pragma unroll
     for (int f = 0; f < 2; ++f) *(f32x4*)(red + ((wave * SP_NCO + t) * 2 + f) * 256 + lane * 4) = acc[t][f];
   __syncthreads();
-  // wave w finalises fragment pair (t, f) = (w >> 1, w & 1)  (SP_NCO * 2 == 4 fragments)
-  {
-    const int t = wave >> 1, f = wave & 1;
+  // the SP_NCO * 2 fragments are finalised round-robin by the four waves
+  for (int fi = wave; fi < SP_NCO * 2; fi += 4) {
+    const int t = fi >> 1, f = fi & 1;
     f32x4 v = *(const f32x4*)(red + ((0 * SP_NCO + t) * 2 + f) * 256 + lane * 4);
 #pragma unroll
     for (int w2 = 1; w2 < 4; ++w2) {
@@ -779,10 +778,11 @@ static bool launch_conv_smallp(const ConvP& p, hipStream_t st) {
   if (!p.dma_ok) return false;        // ragged channel counts must be zero padded to 8 (cpad), as for the tiled kernels
   const int ntap = p.tap1 - p.tap0;
   const int nks = ceil_div(ntap * p.ctot8, 32);
-  dim3 grid(ceil_div(p.P, 32), ceil_div(p.Co, SP_NCO * 16));
+  constexpr int NCO = 2, KU = 4;  // measured on MI355X: 1 / 2 output fragments and 2 / 4 K-steps in flight are equivalent, more is slower
+  dim3 grid(ceil_div(p.P, 32), ceil_div(p.Co, NCO * 16));
   const FastDiv d1 = mk_fastdiv(p.ctot8), d2 = mk_fastdiv(p.H * p.W), d3 = mk_fastdiv(p.W);
-  if (p.KS == 1) hipLaunchKernelGGL((conv_smallp_kernel<1>), grid, dim3(256), 0, st, p, nks, d1, d2, d3);
-  else if (p.KS == 3) hipLaunchKernelGGL((conv_smallp_kernel<3>), grid, dim3(256), 0, st, p, nks, d1, d2, d3);
+  if (p.KS == 1) hipLaunchKernelGGL((conv_smallp_kernel<1, NCO, KU>), grid, dim3(256), 0, st, p, nks, d1, d2, d3);
+  else if (p.KS == 3) hipLaunchKernelGGL((conv_smallp_kernel<3, NCO, KU>), grid, dim3(256), 0, st, p, nks, d1, d2, d3);
   else return false;
   return true;
 }
@@ -795,6 +795,13 @@ static void conv_trace(const ConvP& p, const char* which) {  // CGEN_CONV_TRACE=
 
 template <typename T>
 static int launch_conv(const ConvP& p, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    static const int smallp_maxp = [] { const char* e = getenv("CGEN_SMALLP_MAXP"); return e ? atoi(e) : 6000; }();
+    if (p.P <= smallp_maxp && (p.KS == 1 || p.KS == 3) && !p.force_generic && launch_conv_smallp(p, st)) {
+      conv_trace(p, "smlp");
+      return check_launch("cgen_conv2d(smallp)");
+    }
+  }
   if constexpr (sizeof(T) == 2) {
     if ((p.KS == 1 || p.KS == 3) && p.H >= 5 && p.W >= 5 && p.dma_ok && !p.force_generic && !getenv("CGEN_CONV_NO_PX")) {
       const int nks = ceil_div(p.taps * p.ctot8, 32);
