@@ -797,7 +797,10 @@ template <typename T>
 static int launch_conv(const ConvP& p, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
     static const int smallp_maxp = [] { const char* e = getenv("CGEN_SMALLP_MAXP"); return e ? atoi(e) : 6000; }();
-    if (p.P <= smallp_maxp && (p.KS == 1 || p.KS == 3) && !p.force_generic && launch_conv_smallp(p, st)) {
+    static const int smallp_maxp_longk = [] { const char* e = getenv("CGEN_SMALLP_MAXP_LONGK"); return e ? atoi(e) : 19000; }();
+    static const int smallp_longk = [] { const char* e = getenv("CGEN_SMALLP_LONGK"); return e ? atoi(e) : 60; }();  // K-steps: the 3-segment cat[h,pa,acts] convs at 24x24
+    const bool longk = ceil_div(p.taps * p.ctot8, 32) >= smallp_longk;
+    if ((p.P <= smallp_maxp || (longk && p.P <= smallp_maxp_longk)) && (p.KS == 1 || p.KS == 3) && !p.force_generic && launch_conv_smallp(p, st)) {
       conv_trace(p, "smlp");
       return check_launch("cgen_conv2d(smallp)");
     }
