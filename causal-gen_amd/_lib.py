@@ -60,6 +60,8 @@ PROTOTYPES = {
     "cgen_last_error": [],
     "cgen_conv2d": [C.POINTER(ConvArgs), vp],
     "cgen_conv2d_wgrad_plan": [C.POINTER(WgradArgs), C.POINTER(i32)],
+    "cgen_conv2d_wgrad_batch_plan": [vp, i32, vp, i64, vp, vp, i32, vp, vp],
+    "cgen_conv2d_wgrad_batch_run": [vp, vp, i32, vp],
     "cgen_conv2d_wgrad": [C.POINTER(WgradArgs), vp],
     "cgen_weight_prep": [vp, vp, vp, i32, vp],
     "cgen_wgrad_reduce": [vp, vp, vp, i32, vp],
@@ -104,6 +106,10 @@ PROTOTYPES = {
 }
 _RESTYPES = {"cgen_last_error": C.c_char_p}
 _NOCHECK = {"cgen_version", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks"}
+
+
+class WgradBatchLaunch(C.Structure):
+    _fields_ = [("ncf", C.c_int32), ("ks", C.c_int32), ("lds_bytes", C.c_int32), ("nblocks", C.c_int32), ("blocks_offset", C.c_int64)]
 
 
 class CgenError(RuntimeError):

@@ -9,6 +9,9 @@
 // Global -> register -> LDS staging with the next K-step's loads issued before the current MFMAs.
 #include <stdlib.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "common.h"
 
 namespace cgen {
@@ -1109,7 +1112,7 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
 }
 
 template <int NCF, int NJW, int KS>
-__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
+__device__ __forceinline__ void wgrad_tile_body(const Wg2P& p, const int bid_x, const int bid_y, const int bid_z) {
   typedef bf16_t T;
   constexpr int G = 8;
   constexpr int HALO = KS / 2, HH = TILE_H + 2 * HALO, HW = TILE_W + 2 * HALO;
@@ -1121,13 +1124,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
   char* Gb = smem + p.xt.bytes;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int sp = blockIdx.x;
-  const int cA = blockIdx.y * p.cwin;
+  const int sp = bid_x;
+  const int cA = bid_y * p.cwin;
   const int cw = min(p.cwin, p.ctot8 - cA);      // multiple of 8
   const int cw16 = (cw + 15) & ~15;
   const int cgrp = cw16 >> 4;
   const int njf = TAPS * cgrp;                   // (tap, 16-channel group) fragments of this window
-  const int co_base = blockIdx.z * (NCF * 16);
+  const int co_base = bid_z * (NCF * 16);
   const int t_begin = sp * p.tiles_per_split, t_end = min(p.ntiles, t_begin + p.tiles_per_split);
 
   f32x4 acc[NCF][NJW];
@@ -1138,7 +1141,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
 #pragma unroll
     for (int j = 0; j < NJW; ++j) acc[a][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const bool do_bias = p.pb != nullptr && blockIdx.y == 0 && wave == 0;
+  const bool do_bias = p.pb != nullptr && bid_y == 0 && wave == 0;
   const unsigned long long t_entry = __builtin_readcyclecounter();
 
   // ---- per-lane DMA constants (identical for every piece of every tile)
@@ -1226,7 +1229,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
-  const bool stamp = p.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+  const bool stamp = p.stamps != nullptr && bid_x == 0 && bid_y == 0 && bid_z == 0 && tid == 0;
   int nst = 0;
 #define WG2_STAMP() do { if (stamp && nst < 60) p.stamps[nst++] = __builtin_readcyclecounter(); } while (0)
   if (stamp) p.stamps[nst++] = t_entry;
@@ -1320,6 +1323,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
 #undef WG2_STAMP
 }
 
+template <int NCF, int NJW, int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
+  wgrad_tile_body<NCF, NJW, KS>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Horizontally batched form: ONE launch runs the workgroups of many independent weight-gradient problems of the same
+// kernel variant.  The engine defers all weight gradients of a step to the end of the backward pass, where they are
+// independent; most of them (everything below 48x48) fill a fraction of the CUs with one or two tiles per workgroup,
+// i.e. they are latency chains.  Packed into one grid, every CU always holds workgroups of *some* problem.
+// blocks[b] = {problem, split, channel window, co range}; problems are read through a uniform pointer (scalar loads).
+template <int NCF, int NJW, int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_tile_batched_kernel(const Wg2P* __restrict__ probs, const int4* __restrict__ blocks) {
+  const int4 bi = blocks[blockIdx.x];
+  const int prob = __builtin_amdgcn_readfirstlane(bi.x);
+  wgrad_tile_body<NCF, NJW, KS>(probs[prob], __builtin_amdgcn_readfirstlane(bi.y), __builtin_amdgcn_readfirstlane(bi.z),
+                                __builtin_amdgcn_readfirstlane(bi.w));
+}
+
 struct Wg2Geom { int ncf, njw, cwin, nsplit, tps, ntiles, tiles_x, tiles_y, n_cwin, n_co; PixTile xt, gt; size_t lds; };
 
 // returns false when the shape is not served by the tiled kernel
@@ -1347,8 +1368,10 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
   g.n_cwin = ceil_div(ctot8, cwin);
   g.tiles_x = ceil_div(W, TILE_W); g.tiles_y = ceil_div(H, TILE_H);
   g.ntiles = N * g.tiles_x * g.tiles_y;
-  static const int want_total = [] { const char* e = getenv("CGEN_WG2_WANT"); return e ? atoi(e) : 384; }();
-  int want = ceil_div(want_total, g.n_cwin * g.n_co);  // two persistent workgroups per CU
+  static const int want_total = [] { const char* e = getenv("CGEN_WG2_WANT"); return e ? atoi(e) : 160; }();
+  // workgroups per problem: the batched launch packs all problems of a step into one grid, so a problem need not fill
+  // the chip by itself -- fewer, longer workgroups mean fewer split-K partials (measured optimum on MI355X: ~160 / >= 4 tiles)
+  int want = ceil_div(want_total, g.n_cwin * g.n_co);
   {  // bound the split-K partials of one conv (they are written and re-read by cgen_wgrad_reduce)
     const char* e = getenv("CGEN_WG2_PARTIAL_MB");
     const long cap = (e ? atol(e) : 4096) << 20;  // off by default: capping costs more wgrad time than it saves in the reduce
@@ -1358,7 +1381,7 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
   }
   if (want < 1) want = 1;
   g.tps = ceil_div(g.ntiles, want);
-  static const int min_tps = [] { const char* e = getenv("CGEN_WG2_MINTPS"); return e ? atoi(e) : 2; }();
+  static const int min_tps = [] { const char* e = getenv("CGEN_WG2_MINTPS"); return e ? atoi(e) : 4; }();
   if (g.tps < min_tps && g.ntiles >= min_tps) g.tps = min_tps;
   g.nsplit = ceil_div(g.ntiles, g.tps);
   return true;
@@ -2172,6 +2195,110 @@ extern "C" int cgen_conv2d_wgrad_plan(const cgen_wgrad_args* a, int32_t* tiled_o
   return nsplit;
 }
 
+// Wg2P + geometry of one problem for the tiled bf16 kernel (false: not eligible, the caller uses the generic kernel)
+static bool build_wg2(const cgen_wgrad_args* a, Wg2P& q, Wg2Geom& g) {
+  if (!wgrad_tiled_ok(a, g)) return false;
+  memset(&q, 0, sizeof(q));
+  q.N = a->n; q.H = a->h; q.W = a->w; q.KS = a->ks; q.nseg = a->nseg; q.act = a->act; q.Co = a->gout.c; q.taps = a->ks * a->ks;
+  int k8 = 0, o2 = 0;
+  for (int s = 0; s < a->nseg; ++s) {
+    q.seg[s] = mk(a->seg[s]); q.seg_koff[s] = k8; q.seg_off[s] = o2;
+    k8 += pad_to(a->seg[s].c, 8); o2 += a->seg[s].c;
+  }
+  for (int s = a->nseg; s < CGEN_MAX_SEG; ++s) q.seg_koff[s] = 1 << 30;
+  q.ci_total = o2;
+  q.ctot8 = k8;
+  q.gout = mk(a->gout);
+  q.pw = a->partial_w; q.pb = a->partial_b;
+  q.tiles_x = g.tiles_x; q.tiles_y = g.tiles_y; q.ntiles = g.ntiles; q.nsplit = g.nsplit; q.tiles_per_split = g.tps;
+  q.cwin = g.cwin; q.cog = g.ncf * 16; q.xt = g.xt; q.gt = g.gt;
+  return true;
+}
+
+template <int NCF, int NJW>
+static void launch_wgrad2_batched(int ks, const Wg2P* probs, const int4* blocks, int nblocks, size_t lds, hipStream_t st) {
+  if (ks == 3) {
+    static bool once3 = false;
+    if (!once3) { (void)hipFuncSetAttribute((const void*)wgrad_tile_batched_kernel<NCF, NJW, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once3 = true; }
+    hipLaunchKernelGGL((wgrad_tile_batched_kernel<NCF, NJW, 3>), dim3(nblocks), dim3(256), lds, st, probs, blocks);
+  } else {
+    static bool once1 = false;
+    if (!once1) { (void)hipFuncSetAttribute((const void*)wgrad_tile_batched_kernel<NCF, NJW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once1 = true; }
+    hipLaunchKernelGGL((wgrad_tile_batched_kernel<NCF, NJW, 1>), dim3(nblocks), dim3(256), lds, st, probs, blocks);
+  }
+}
+
+extern "C" int cgen_conv2d_wgrad_batch_plan(const cgen_wgrad_args* args, int32_t count, void* blob_host, int64_t capacity, int64_t* blob_bytes,
+                                            cgen_wgrad_batch_launch* launches, int32_t max_launches, int32_t* n_launches, int32_t* eligible) {
+  CGEN_REQUIRE(args && count >= 0 && blob_bytes && n_launches && eligible, "cgen_conv2d_wgrad_batch_plan: null args");
+  struct Item { int idx; Wg2P q; Wg2Geom g; int key; long cost; };
+  std::vector<Item> items;
+  for (int i = 0; i < count; ++i) {
+    Item it;
+    it.idx = i;
+    eligible[i] = 0;
+    if (args[i].dtype != CGEN_BF16 || !args[i].partial_w) continue;
+    if (!build_wg2(&args[i], it.q, it.g)) continue;
+    if (it.g.nsplit != args[i].nsplit) continue;
+    eligible[i] = 1;
+    // one launch per (variant, kernel size, LDS class): a big-LDS problem must not lower everyone's occupancy
+    it.key = (it.g.ncf * 4 + (args[i].ks == 3 ? 1 : 0)) * 2 + (it.g.lds > 40 * 1024 ? 1 : 0);
+    it.cost = (long)it.g.nsplit * it.g.n_cwin * it.g.n_co * it.g.tps;
+    items.push_back(it);
+  }
+  std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.key != b.key ? a.key < b.key : a.cost > b.cost; });
+  const int64_t probs_bytes = pad_to((int)(items.size() * sizeof(Wg2P)), 256);
+  int64_t nblocks_total = 0;
+  for (auto& it : items) nblocks_total += (int64_t)it.g.nsplit * it.g.n_cwin * it.g.n_co;
+  *blob_bytes = probs_bytes + nblocks_total * (int64_t)sizeof(int4);
+  int nl = 0;
+  for (size_t i = 0; i < items.size(); ++i)
+    if (i == 0 || items[i].key != items[i - 1].key) ++nl;
+  *n_launches = nl;
+  if (!blob_host) return CGEN_OK;  // size query
+  CGEN_REQUIRE(capacity >= *blob_bytes && launches && max_launches >= nl, "cgen_conv2d_wgrad_batch_plan: buffers too small");
+  memset(blob_host, 0, (size_t)*blob_bytes);
+  Wg2P* probs = (Wg2P*)blob_host;
+  int4* blocks = (int4*)((char*)blob_host + probs_bytes);
+  int64_t b = 0;
+  int li = -1;
+  for (size_t i = 0; i < items.size(); ++i) {
+    const Item& it = items[i];
+    probs[i] = it.q;
+    if (i == 0 || it.key != items[i - 1].key) {
+      ++li;
+      launches[li].ncf = it.g.ncf; launches[li].ks = args[it.idx].ks; launches[li].lds_bytes = 0; launches[li].nblocks = 0;
+      launches[li].blocks_offset = probs_bytes + b * (int64_t)sizeof(int4);
+    }
+    if ((int32_t)it.g.lds > launches[li].lds_bytes) launches[li].lds_bytes = (int32_t)it.g.lds;
+    for (int z = 0; z < it.g.n_co; ++z)
+      for (int y = 0; y < it.g.n_cwin; ++y)
+        for (int x = 0; x < it.g.nsplit; ++x) { blocks[b] = make_int4((int)i, x, y, z); ++b; }
+    launches[li].nblocks += it.g.nsplit * it.g.n_cwin * it.g.n_co;
+  }
+  return CGEN_OK;
+}
+
+extern "C" int cgen_conv2d_wgrad_batch_run(const void* blob_dev, const cgen_wgrad_batch_launch* launches, int32_t n_launches, cgen_stream_t stream) {
+  CGEN_REQUIRE(blob_dev && (launches || n_launches == 0) && n_launches >= 0, "cgen_conv2d_wgrad_batch_run: null args");
+  hipStream_t st = (hipStream_t)stream;
+  const Wg2P* probs = (const Wg2P*)blob_dev;
+  for (int i = 0; i < n_launches; ++i) {
+    const cgen_wgrad_batch_launch& l = launches[i];
+    if (l.nblocks <= 0) continue;
+    const int4* blocks = (const int4*)((const char*)blob_dev + l.blocks_offset);
+    switch (l.ncf) {
+      case 1: launch_wgrad2_batched<1, 16>(l.ks, probs, blocks, l.nblocks, (size_t)l.lds_bytes, st); break;
+      case 2: launch_wgrad2_batched<2, 12>(l.ks, probs, blocks, l.nblocks, (size_t)l.lds_bytes, st); break;
+      case 4: launch_wgrad2_batched<4, 6>(l.ks, probs, blocks, l.nblocks, (size_t)l.lds_bytes, st); break;
+      case 6: launch_wgrad2_batched<6, 4>(l.ks, probs, blocks, l.nblocks, (size_t)l.lds_bytes, st); break;
+      case 8: launch_wgrad2_batched<8, 3>(l.ks, probs, blocks, l.nblocks, (size_t)l.lds_bytes, st); break;
+      default: return cgen::fail(CGEN_EINVAL, "cgen_conv2d_wgrad_batch_run: bad variant %d", l.ncf);
+    }
+  }
+  return check_launch("cgen_conv2d_wgrad_batch_run");
+}
+
 extern "C" int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream) {
   CGEN_REQUIRE(a && a->partial_w, "cgen_conv2d_wgrad: null args");
   CGEN_REQUIRE(a->dtype == CGEN_F32 || a->dtype == CGEN_BF16, "cgen_conv2d_wgrad: bad dtype");
@@ -2198,23 +2325,9 @@ extern "C" int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream)
     int segc[CGEN_MAX_SEG];
     for (int s = 0; s < a->nseg; ++s) segc[s] = a->seg[s].c;
     Wg2Geom g;
-    if (wgrad_tiled_ok(a, g)) {
+    Wg2P q;
+    if (build_wg2(a, q, g)) {
       CGEN_REQUIRE(g.nsplit == a->nsplit, "cgen_conv2d_wgrad: nsplit %d != expected %d", a->nsplit, g.nsplit);
-      Wg2P q;
-      memset(&q, 0, sizeof(q));
-      q.N = a->n; q.H = a->h; q.W = a->w; q.KS = a->ks; q.nseg = a->nseg; q.act = a->act; q.Co = a->gout.c; q.taps = p.taps;
-      q.ci_total = off;
-      int k8 = 0, o2 = 0;
-      for (int s = 0; s < a->nseg; ++s) {
-        q.seg[s] = mk(a->seg[s]); q.seg_koff[s] = k8; q.seg_off[s] = o2;
-        k8 += pad_to(a->seg[s].c, 8); o2 += a->seg[s].c;
-      }
-      for (int s = a->nseg; s < CGEN_MAX_SEG; ++s) q.seg_koff[s] = 1 << 30;
-      q.ctot8 = k8;
-      q.gout = mk(a->gout);
-      q.pw = a->partial_w; q.pb = a->partial_b;
-      q.tiles_x = g.tiles_x; q.tiles_y = g.tiles_y; q.ntiles = g.ntiles; q.nsplit = g.nsplit; q.tiles_per_split = g.tps;
-      q.cwin = g.cwin; q.cog = g.ncf * 16; q.xt = g.xt; q.gt = g.gt;
       { const char* e = getenv("CGEN_WG2_DBG"); q.dbg = e ? atoi(e) : 0; }
       { const char* e = getenv("CGEN_WG2_STAMPS"); q.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
       hipStream_t st = (hipStream_t)stream;

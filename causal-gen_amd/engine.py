@@ -148,6 +148,9 @@ class Engine:
         # end of the backward pass and issued round-robin on a few HIP streams (one fork, one join before the split-K
         # reduction).  The low-resolution ones are latency chains on a fraction of the CUs; several at a time fill the chip.
         self.wgrad_streams = int(os.environ.get("CGEN_WGRAD_STREAMS", "2"))
+        # ... or, better, packed: ONE launch per kernel variant runs the workgroups of all deferred problems (cgen_conv2d_wgrad_batch_*)
+        self.wgrad_batch = os.environ.get("CGEN_WGRAD_BATCH", "1") != "0"
+        self._wg_batches = {}
         self._wg_forked = False
         self._wg_pool = []
         self._wg_deferred = []
@@ -609,7 +612,7 @@ class Engine:
         torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)
 
     def _defer_wgrad(self):
-        return self.wgrad_streams > 1 and self.prof is None
+        return self.wgrad_batch or (self.wgrad_streams > 1 and self.prof is None)
 
     def _frozen(self, t):
         """True when grad(t) lives in a buffer a deferred weight-gradient kernel will still read: only ADOPTED buffers
@@ -785,6 +788,9 @@ class Engine:
 
     def _launch_deferred_wgrads(self, final=True):
         main = torch.cuda.current_stream(self.device)
+        if self._wg_deferred and self.wgrad_batch:
+            self._launch_batched_wgrads()
+            return
         if self._wg_deferred:
             k = min(self.wgrad_streams, len(self._wg_deferred))
             while len(self._wg_pool) < k:
@@ -804,6 +810,46 @@ class Engine:
             for st in self._wg_pool:
                 main.wait_stream(st)
             self._wg_forked = False
+
+    def _launch_batched_wgrads(self):
+        """All deferred weight-gradient problems in a handful of launches.  The packed problem table is planned once per
+        distinct set of launch arguments (addresses are stable: the arena is deterministic) and kept on the device."""
+        args = [a for a, _ in self._wg_deferred]
+        n = len(args)
+        arr = (_lib.WgradArgs * n)(*args)
+        key = bytes(arr)
+        ent = self._wg_batches.get(key)
+        if ent is None:
+            lib = self.lib
+            nbytes, nl = C.c_int64(0), C.c_int32(0)
+            elig = (C.c_int32 * n)()
+            lib.conv2d_wgrad_batch_plan(arr, n, None, 0, C.byref(nbytes), None, 0, C.byref(nl), elig)
+            host = (C.c_char * max(nbytes.value, 1))()
+            launches = (_lib.WgradBatchLaunch * max(nl.value, 1))()
+            lib.conv2d_wgrad_batch_plan(arr, n, host, nbytes.value, C.byref(nbytes), launches, nl.value, C.byref(nl), elig)
+            blob = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.device) if nbytes.value else None
+            rest = [i for i in range(n) if not elig[i]]
+            if len(self._wg_batches) > 8:
+                self._wg_batches.clear()
+            ent = self._wg_batches[key] = (blob, launches, nl.value, rest)
+        blob, launches, nl, rest = ent
+        ev = None
+        if self.prof is not None:  # the packed launches are timed as ONE class entry (per-problem times do not exist)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        if blob is not None and nl:
+            self.lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl, self.stream)
+            self.launches += nl
+        for i in rest:
+            self.lib.conv2d_wgrad(C.byref(args[i]), self.stream)
+            self.launches += 1
+        if ev is not None:
+            ev[1].record()
+            ent2 = self.prof.setdefault(("conv_wgrad", 0, 0, 0, 0), [0.0, [], 0])
+            ent2[0] += sum(c for _, c in self._wg_deferred)
+            ent2[1].append(ev)
+            ent2[2] += nl + len(rest)
+        self._wg_deferred = []
 
     def _reduce_wgrads(self):
         self._launch_deferred_wgrads()

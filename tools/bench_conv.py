@@ -27,7 +27,7 @@ def main():
     iters = int(os.environ.get("ITERS", "20"))
     convs = [torch.nn.Conv2d(sum(s[2]), s[3], s[4], padding=s[4] // 2) for s in SHAPES]
     eng = Engine("cuda", dtype)
-    eng.wgrad_streams = 0  # single launches are timed here; no fork/join
+    eng.wgrad_streams, eng.wgrad_batch = 0, False  # single launches are timed here
     holder = torch.nn.ModuleList(convs).cuda()
     sites = [ConvSite(f"c{i}", c, s[2], [True] * len(s[2]), i) for i, (c, s) in enumerate(zip(holder, SHAPES))]
     eng.bind(holder, sites)
