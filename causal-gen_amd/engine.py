@@ -840,9 +840,27 @@ class Engine:
         if blob is not None and nl:
             self.lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl, self.stream)
             self.launches += nl
-        for i in rest:
-            self.lib.conv2d_wgrad(C.byref(args[i]), self.stream)
-            self.launches += 1
+        if len(rest) >= 4 and self.wgrad_streams > 1 and ev is None:
+            # problems the packed kernel does not serve (f32, < 5x5 images): independent launches on the stream pool
+            main = torch.cuda.current_stream(self.device)
+            k = min(self.wgrad_streams, len(rest))
+            while len(self._wg_pool) < k:
+                self._wg_pool.append(torch.cuda.Stream(self.device))
+            costs = [c for _, c in self._wg_deferred]
+            load = [0.0] * k
+            for st in self._wg_pool[:k]:
+                st.wait_stream(main)
+            for i in sorted(rest, key=lambda i: -costs[i]):
+                j = load.index(min(load))
+                load[j] += costs[i] + 2.0e8
+                self.lib.conv2d_wgrad(C.byref(args[i]), self._wg_pool[j].cuda_stream)
+                self.launches += 1
+            for st in self._wg_pool[:k]:
+                main.wait_stream(st)
+        else:
+            for i in rest:
+                self.lib.conv2d_wgrad(C.byref(args[i]), self.stream)
+                self.launches += 1
         if ev is not None:
             ev[1].record()
             ent2 = self.prof.setdefault(("conv_wgrad", 0, 0, 0, 0), [0.0, [], 0])
