@@ -100,7 +100,7 @@ def pmc_traffic(kernel_class, dtype):
         return None
 
 
-def profile_step(ts, x, pa, dtype):
+def profile_step(ts, x, pa, dtype, workload_key=None):
     """One eager step with HIP events around every conv launch (on the launch stream) -> per-class totals."""
     eng = ts.eng
     eng.prof = {}
@@ -136,7 +136,7 @@ def profile_step(ts, x, pa, dtype):
     top = top[:8]
     return dict(
         bound="mfma", kernel=dom, achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_PEAK_TF[dtype], unit="TFLOP/s",
-        frac=flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dtype], traffic=pmc_traffic(dom, dtype), launches=n, avg_launch_us=1e3 * ms / n,
+        frac=flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dtype], traffic=pmc_traffic(dom, dtype) if workload_key == ("ukbb192", 32) else None, launches=n, avg_launch_us=1e3 * ms / n,
         algorithmic_flops_per_launch=flops / n,
         classes={k: dict(tflops=v[0] / (v[1] * 1e-3) / 1e12, ms=v[1], launches=v[2]) for k, v in classes.items()},
         top_shapes=[dict(kind=k[0], ks=k[1], ci=k[2], co=k[3], res=k[4], ms=v[1], tflops=v[0] / (v[1] * 1e-3) / 1e12, n=v[2])
@@ -218,7 +218,7 @@ def main():
             "model_tflops": img_s * gf * 1e9 / 1e12,
             "model_mfma_frac": img_s * gf * 1e9 / 1e12 / (MFMA_PEAK_TF[a.dtype] * world),
         }
-        res["roofline"] = profile_step(ts, x, pa, a.dtype)
+        res["roofline"] = profile_step(ts, x, pa, a.dtype, (a.config, B))
         if not a.no_cf:
             from causal_gen_amd.dscm import counterfactual
 
