@@ -162,13 +162,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    local = local % max(torch.cuda.device_count(), 1)  # (a 1-GPU box can host a 2-rank gloo dry run of the DP path)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        backend = os.environ.get("CGEN_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         pg = dist.group.WORLD
 
     from causal_gen_amd.train import TrainStep
@@ -201,6 +206,8 @@ def main():
     elbo, nll, kl = [float(v) for v in out.cpu()]
     stats = ts.stats()
     img_s = B * world * a.steps / dt
+    # the profiled eager step contains the gradient all-reduce: every rank takes part (rank 0 reports)
+    roof = profile_step(ts, x, pa, a.dtype, (a.config, B))
 
     if rank == 0:
         gf = TRAIN_GFLOP_PER_IMG[a.config]
@@ -218,7 +225,7 @@ def main():
             "model_tflops": img_s * gf * 1e9 / 1e12,
             "model_mfma_frac": img_s * gf * 1e9 / 1e12 / (MFMA_PEAK_TF[a.dtype] * world),
         }
-        res["roofline"] = profile_step(ts, x, pa, a.dtype, (a.config, B))
+        res["roofline"] = roof
         if not a.no_cf:
             from causal_gen_amd.dscm import counterfactual
 

@@ -188,3 +188,26 @@ def test_gradient_accumulation_graph_equals_eager():
     assert o0 == o1, (o0, o1)
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k
+
+
+def test_dp_bench_path_two_gloo_ranks_on_one_gpu():
+    """The data-parallel step (hipGraph fwd+bwd -> bucketed gradient all-reduce -> hipGraph step tail) end to end: two
+    ranks share this GPU over gloo (RCCL wants one device per rank; the code path is the same).  Both ranks must finish
+    and rank 0 must print one JSON line with n_gpus = 2 and a finite ELBO."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CGEN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--config", "morphomnist", "--batch", "16",
+           "--steps", "2", "--warmup", "1", "--prep-steps", "1", "--no-cf"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["elbo_nats_per_dim"] == d["elbo_nats_per_dim"]
+    assert d["opt_steps"] == 4 and "roofline" in d
