@@ -1,12 +1,23 @@
-// Implicit-GEMM convolution for gfx950: forward / data-gradient (one kernel) and weight-gradient.
+// Implicit-GEMM convolution for gfx950 (MI355X): forward / data-gradient (cgen_conv2d) and weight-gradient
+// (cgen_conv2d_wgrad, cgen_conv2d_wgrad_batch_*), plus the multi-tensor weight-image prep and split-K reduction.
 //
-// GEMM view (operands swapped so every lane owns 4 consecutive output channels of one pixel):
-//   D[co][px] = sum_k  Wimg[co][k] * A[k][px],   k = (tap, segment, channel)
+// GEMM view (operands swapped so a lane owns consecutive output channels of one pixel):
+//   D[co][px] = sum_k  Wimg[co][k] * A[k][px],   k = (tap, segment, channel) with channels 8-granular
 //   A[k][px]  = act( seg_s[n, y+dy, x+dx, c] )   (zero outside the image; act(0) == 0)
 // f32 path : v_mfma_f32_16x16x4_f32  (exact f32 fmaf chains -> the 1e-4 ELBO parity path)
 // bf16 path: v_mfma_f32_16x16x32_bf16 (f32 accumulate)
-// Workgroup = 256 threads (4 waves) -> 128 pixels x (16*NTC) output channels; K advances 32 channels per step.
-// Global -> register -> LDS staging with the next K-step's loads issued before the current MFMAs.
+//
+// Kernels in this file (DESIGN.md section 3 has the when/why and the measurements):
+//   conv_kernel<T,NTC>            generic gather kernel (any view, f32 on tiny images)
+//   conv_tile_kernel<T,NTC,KS>    one 8x16 halo tile + weight slab in LDS per workgroup (f32; bf16 multi-window shapes)
+//   conv_px_kernel<NP,KS>         lean persistent kernel for short-K convs: slab in LDS once, 16-byte epilogue from registers
+//   conv_ws_kernel<NTC,NKW>       weight-stationary persistent kernel for long-K / narrow-output convs (weights in registers)
+//   conv_smallp_kernel<KS,..>     K split over the waves, operands straight from global memory (<= ~6000 pixels per batch)
+//   wgrad_kernel<T,NTC>           generic weight gradient (f32 MFMA)
+//   wgrad_tile_kernel / wgrad_tile_batched_kernel<NCF,NJW,KS>   bf16 weight gradient with LDS transpose reads;
+//                                 the batched form runs the workgroups of many problems in one launch
+//   wprep_kernel / wred_kernel    OIHW f32 -> weight images; split-K partials -> flat OIHW gradient
+// What bounds them on MI355X is instruction issue (VALU/SALU per MFMA), not MFMA or HBM: see DESIGN.md 3.4.
 #include <stdlib.h>
 
 #include <algorithm>
