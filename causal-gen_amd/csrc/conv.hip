@@ -1585,14 +1585,20 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
 
     // ---- MFMAs: 2 tile rows x NP*32 channels per wave, bias as the initial value
     f32x4 acc[NP][2][2];
+    {  // K-step 0 always exists: the bias registers are its C operand (no accumulator initialisation moves)
+      const bf16x8 b0 = *(const bf16x8*)(x_rows + koff[0]);
+      const bf16x8 b1 = *(const bf16x8*)(x_rows + q.xt.rowbytes + koff[0]);
 #pragma unroll
-    for (int pr = 0; pr < NP; ++pr)
+      for (int pr = 0; pr < NP; ++pr)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h) {
+          const bf16x8 aq = *(const bf16x8*)(a_base + (size_t)(pr * 32 + h * 16) * q.ldw * 2);
+          acc[pr][h][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, b0, binit[pr][h], 0, 0, 0);
+          acc[pr][h][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, b1, binit[pr][h], 0, 0, 0);
+        }
+    }
 #pragma unroll
-        for (int f = 0; f < 2; ++f) acc[pr][h][f] = binit[pr][h];
-#pragma unroll
-    for (int i = 0; i < PX_MAXKS; ++i) {
+    for (int i = 1; i < PX_MAXKS; ++i) {
       if (i < q.nks) {
         const bf16x8 b0 = *(const bf16x8*)(x_rows + koff[i]);
         const bf16x8 b1 = *(const bf16x8*)(x_rows + q.xt.rowbytes + koff[i]);
