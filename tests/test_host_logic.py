@@ -116,3 +116,28 @@ def test_simple_vae_module_tree_and_init_rng():
     assert abs(got - fx["init_abs_sum"]) < 1e-6 * fx["init_abs_sum"], (got, fx["init_abs_sum"])
     with pytest.raises(Exception):
         m(fx["x"], fx["pa"])  # parameter holders on the CPU: the product path needs the GPU
+
+
+def test_reference_checkpoint_wire_format(tmp_path):
+    """A checkpoint in the reference's format (trainer.py:154-165) round-trips through the loader of train_cf.py:357-364,
+    including the free_bits -> kl_free_bits rename and the cond_prior default."""
+    from causal_gen_amd import checkpoint, vae
+    from causal_gen_amd.hps import Hparams
+
+    fx = load_golden("tiny_light_c1.pt")
+    hp = dict(fx["hp"])
+    m = vae.HVAE(Hparams(**hp))
+    m.load_state_dict(fx["state_dict"])
+    legacy = dict(hp)
+    legacy["free_bits"] = legacy.pop("kl_free_bits", 0.0)
+    legacy.pop("cond_prior", None)
+    path = str(tmp_path / "checkpoint.pt")
+    torch.save({"epoch": 3, "step": 30, "best_loss": 1.0, "model_state_dict": m.state_dict(),
+                "ema_model_state_dict": m.state_dict(), "optimizer_state_dict": None, "scheduler_state_dict": None,
+                "hparams": legacy}, path)
+    m2, args = checkpoint.load_checkpoint(path, device=None)
+    assert args.kl_free_bits == legacy["free_bits"] and args.cond_prior is False
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    checkpoint.save_checkpoint(path, m2, m2, args, epoch=4)
+    assert set(torch.load(path, weights_only=False)) >= {"model_state_dict", "ema_model_state_dict", "hparams", "epoch"}
