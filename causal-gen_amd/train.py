@@ -19,6 +19,29 @@ import torch
 from . import _lib, dp
 
 
+def preprocess_batch(args, batch, expand_pa=False):
+    """trainer.py:16-21 on the device: u8 pixels -> [-1, 1] f32 (one HIP launch, no ATen arithmetic), parents to f32 and,
+    for the HVAE's parent concatenation, broadcast to [B, ctx, R, R].  ``HVAE.forward`` also accepts the raw u8 batch
+    directly and fuses the normalisation into its NCHW -> NHWC load, which skips this pass altogether."""
+    lib = _lib.require_gpu()
+    dev = torch.device(getattr(args, "device", "cuda"))
+    x = batch["x"].to(dev)
+    if x.dtype == torch.uint8:
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        out = torch.empty((n, h, w, c), dtype=torch.float32, device=dev)  # channels-last memory, NCHW shape below
+        lib.nchw_to_nhwc(1, _lib.F32, n, c, h, w, x.data_ptr(), _lib.View(out.data_ptr(), h * w * c, w * c, c, c, 0), 127.5,
+                         1.0 / 127.5, torch.cuda.current_stream(dev).cuda_stream)
+        x = out.permute(0, 3, 1, 2)
+    else:
+        x = (x.float() - 127.5) / 127.5
+    batch["x"] = x
+    batch["pa"] = batch["pa"].to(dev).float()
+    if expand_pa:
+        batch["pa"] = batch["pa"][..., None, None].repeat(1, 1, *(args.input_res,) * 2)
+    return batch
+
+
 def linear_warmup(warmup_iters):
     """utils.py:32-36."""
     return lambda it: 1.0 if it > warmup_iters else it / warmup_iters

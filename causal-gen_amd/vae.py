@@ -472,7 +472,11 @@ class HVAE(nn.Module):
 
     def _prep_inputs(self, eng, x, parents):
         assert x.dim() == 4 and parents.dim() == 4 and parents.shape[1] == self.context_dim
-        xin = eng.from_nchw(x.to(eng.device), rg=False) if x is not None else None
+        xin = None
+        if x is not None:
+            x = x.to(eng.device)
+            # raw u8 pixels: trainer.py:17's (x - 127.5) / 127.5 is fused into the layout kernel
+            xin = eng.from_nchw(x, rg=False, sub=127.5, mul=1.0 / 127.5) if x.dtype == torch.uint8 else eng.from_nchw(x, rg=False)
         pa = eng.from_nchw(parents.to(eng.device, torch.float32), rg=False)
         return xin, pa
 

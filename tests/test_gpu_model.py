@@ -226,3 +226,25 @@ def test_free_bits_forward_and_grads(name):
         worst = max(worst, err)
         assert err < 2e-3, (n, err)
     print(name, "free-bits worst grad rel-to-max err", worst)
+
+
+def test_u8_pixels_are_normalised_on_the_device():
+    """trainer.py:17 fused into the load: feeding the raw u8 batch equals feeding (x - 127.5) / 127.5."""
+    from causal_gen_amd.train import preprocess_batch
+
+    fx = load_golden("tiny_default_c3.pt")
+    m, args = build(fx)
+    g = torch.Generator().manual_seed(9)
+    xu = torch.randint(0, 256, tuple(fx["x"].shape), generator=g, dtype=torch.uint8)
+    xf = (xu.float() - 127.5) / 127.5
+    pa = fx["pa"].cuda()
+    outs = []
+    for x in (xf.cuda(), xu.cuda()):
+        m.noise = [e.clone() for e in fx["fwd"]["eps"]]
+        with torch.no_grad():
+            outs.append(m(x, pa, beta=1.0))
+    for k in ("elbo", "nll", "kl"):
+        assert rel(outs[1][k], outs[0][k]) < 1e-5, (k, float(outs[1][k]), float(outs[0][k]))
+    b = preprocess_batch(SimpleNamespace(device="cuda", input_res=xu.shape[-1]), {"x": xu, "pa": fx["pa"][:, :, 0, 0]}, expand_pa=True)
+    torch.testing.assert_close(b["x"].cpu(), xf, rtol=0, atol=2e-7)
+    assert tuple(b["pa"].shape) == tuple(fx["pa"].shape) and b["x"].shape == xf.shape
