@@ -93,7 +93,15 @@ template <typename T, int N> union Pack {
 // (bias + acc) * act'(aux) + res1 + res2 for 4 consecutive output channels of one pixel
 template <typename T>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4& a, int pn, int py, int px, int co) {
-  if (co >= p.Co) return;
+  if (co >= p.Co) {  // padding channels [Co, out.cpad) are written as zeros so that consumers may fetch whole 16-byte groups
+    if (co < p.out.cpad) {
+      T* z = vptr<T>(p.out, pn, py, px);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (co + e < p.out.cpad) z[co + e] = (T)0;
+    }
+    return;
+  }
   T* optr = vptr<T>(p.out, pn, py, px);
   const T* aptr = p.aux.p ? vptr<T>(p.aux, pn, py, px) : nullptr;
   const T* r1 = p.res1.p ? vptr<T>(p.res1, pn, py, px) : nullptr;
@@ -130,6 +138,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4& a, in
         if (r1) u += Elem<T>::ld(r1 + co + e);
         if (r2) u += Elem<T>::ld(r2 + co + e);
         Elem<T>::st(optr + co + e, u);
+      } else if (co + e < p.out.cpad) {
+        optr[co + e] = (T)0;
       }
     }
   }
@@ -190,7 +200,15 @@ __device__ __forceinline__ void epi8_finish(const ConvP& p, float (&v)[8], const
 // epilogues where consecutive lanes own consecutive 16-byte chunks of a pixel row (fully coalesced stores / loads)
 __device__ __forceinline__ void conv_epilogue8_bf16(const ConvP& p, float (&v)[8], int pn, int py, int px, int co) {
   typedef bf16_t T;
-  if (co >= p.Co) return;
+  if (co >= p.Co) {
+    if (co < p.out.cpad) {
+      T* z = vptr<T>(p.out, pn, py, px);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (co + e < p.out.cpad) z[co + e] = 0;
+    }
+    return;
+  }
   T* optr = vptr<T>(p.out, pn, py, px) + co;
   const T* aptr = p.aux.p ? vptr<T>(p.aux, pn, py, px) + co : nullptr;
   const T* r1 = p.res1.p ? vptr<T>(p.res1, pn, py, px) + co : nullptr;
@@ -228,6 +246,8 @@ __device__ __forceinline__ void conv_epilogue8_bf16(const ConvP& p, float (&v)[8
         if (r1) u += bf2f(r1[e]);
         if (r2) u += bf2f(r2[e]);
         optr[e] = f2bf(u);
+      } else if (co + e < p.out.cpad) {
+        optr[e] = 0;
       }
     }
   }

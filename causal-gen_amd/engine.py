@@ -43,8 +43,11 @@ class NT:
 
     def chan(self, a, b):
         assert 0 <= a < b <= self.c
-        return NT(self.ptr + a * self.es, self.n, self.h, self.w, b - a, self.sn, self.sh, self.sw, self.es,
-                  base=self.base, coff=self.coff + a, rg=self.rg, keep=self.keep)
+        v = NT(self.ptr + a * self.es, self.n, self.h, self.w, b - a, self.sn, self.sh, self.sw, self.es,
+               base=self.base, coff=self.coff + a, rg=self.rg, keep=self.keep)
+        if b == self.c and self.cpad:  # a view that ends where the tensor ends keeps its zero padding
+            v.cpad = self.cpad - a
+        return v
 
     def crop(self, r):
         """[:, :r, :r, :] -- only used on tensors that need no gradient (parents)."""
@@ -351,6 +354,8 @@ class Engine:
         x0 = segs[0]
         if out is None:
             out = self.new(x0.n, x0.h, x0.w, site.co)
+            if site.co % 8:  # ragged width (e.g. the 4-channel bottleneck of a 16-wide Block): the kernel zero-fills the
+                out.cpad = _ceil(site.co, 8)  # padding channels, which keeps the tensor DMA-clean for its consumers
         assert out.c == site.co and len(segs) == len(site.seg_c)
         a = _lib.ConvArgs()
         a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = self.dt, x0.n, x0.h, x0.w, site.ks, len(segs), act, 0
@@ -486,10 +491,17 @@ class Engine:
         self.launches += 1
 
     # ------------------------------------------------------------------ gradient bookkeeping
+    def _new_grad(self, n, h, w, c):
+        g = self.new(n, h, w, c, rg=False)
+        if c % 8:  # ragged width: zero the padding once (writers only touch [0, c)) so gradient consumers can DMA it
+            self.fill(self._padded(g), 0.0)
+            g.cpad = _ceil(c, 8)
+        return g
+
     def _gentry(self, base):
         e = self.grads.get(id(base))
         if e is None:
-            g = self.new(base.n, base.h, base.w, base.c, rg=False)
+            g = self._new_grad(base.n, base.h, base.w, base.c)
             e = [g, [], base]
             self.grads[id(base)] = e
         return e
@@ -625,7 +637,7 @@ class Engine:
         """Copy-on-write of a frozen gradient buffer (rare: only non-conv ops accumulating into an adopted buffer)."""
         e = self.grads[id(t.base)]
         old, base = e[0], e[2]
-        new = self.new(base.n, base.h, base.w, base.c, rg=False)
+        new = self._new_grad(base.n, base.h, base.w, base.c)
         self.lib.axpby(self.dt, old.n, old.h, old.w, old.cv(), new.cv(), 1.0, 1.0, 1 << 30, 0, self.stream)
         self.launches += 1
         e[0] = new
@@ -744,7 +756,7 @@ class Engine:
                 # traffic: the kernel reads `prev` as a residual either way)
                 if s.base is s:
                     e = self.grads[id(s)]
-                    e[0] = self.new(s.n, s.h, s.w, s.c, rg=False)
+                    e[0] = self._new_grad(s.n, s.h, s.w, s.c)
                     gv = e[0].chan(0, s.c)
                 else:
                     self._cow(s)

@@ -34,7 +34,9 @@ enum cgen_act { CGEN_ACT_NONE = 0, CGEN_ACT_RELU = 1, CGEN_ACT_GELU = 2 };
 
 /* NHWC strided view; strides in elements; p == NULL means "absent".
  * cpad (optional, 0 = none): the caller guarantees that channels [c, cpad) of every pixel are readable and hold
- * finite values (zeros); lets the tiled kernels fetch whole 16-byte groups of a ragged-width tensor by LDS-DMA. */
+ * finite values (zeros); lets the tiled kernels fetch whole 16-byte groups of a ragged-width tensor by LDS-DMA.
+ * On an OUTPUT view of cgen_conv2d, cpad > c asks the kernel to write zeros into channels [c, cpad) as well, so that a
+ * ragged-width result (e.g. the 4-channel bottleneck of a 16-wide Block) is itself DMA-clean for its consumers. */
 typedef struct cgen_view {
   void* p;
   int64_t sn, sh, sw;
