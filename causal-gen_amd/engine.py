@@ -358,17 +358,18 @@ class Engine:
                 out.cpad = _ceil(site.co, 8)  # padding channels, which keeps the tensor DMA-clean for its consumers
         assert out.c == site.co and len(segs) == len(site.seg_c)
         a = _lib.ConvArgs()
-        a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = self.dt, x0.n, x0.h, x0.w, site.ks, len(segs), act, 0
+        gn, gh, gw, vw = self._geom(site.ks, list(segs) + [out, res1, res2])
+        a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = self.dt, gn, gh, gw, site.ks, len(segs), act, 0
         for k, s in enumerate(segs):
             assert s.c == site.seg_c[k] and (s.n, s.h, s.w) == (x0.n, x0.h, x0.w), (site.name, k, s.shape, site.seg_c)
-            a.seg[k] = s.cv()
+            a.seg[k] = vw(s)
         a.weight = site.img_fwd
         b = site.conv.bias
         a.bias = b.data_ptr() if b is not None else None
-        a.out = out.cv()
+        a.out = vw(out)
         a.aux = NULL_VIEW
-        a.res1 = res1.cv() if res1 is not None else NULL_VIEW
-        a.res2 = res2.cv() if res2 is not None else NULL_VIEW
+        a.res1 = vw(res1)
+        a.res2 = vw(res2)
         self._timed("conv_fwd", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream))
         if self.recording:
             self.tape.append((self._bw_conv, (site, segs, act, out, res1, res2)))
@@ -491,6 +492,20 @@ class Engine:
         self.launches += 1
 
     # ------------------------------------------------------------------ gradient bookkeeping
+    @staticmethod
+    def _geom(ks, ts):
+        """Launch geometry (n, h, w) and the view constructor for a conv over tensors `ts` (None entries allowed).
+        A 1x1 conv does not care about the spatial structure: on tiny images (< 5x5, where the tiled kernels do not apply)
+        pixel-contiguous tensors are presented as ONE image of 16-pixel rows, [1, P/16, 16, C], which the tiled /
+        persistent kernels (and the packed weight-gradient launch) serve."""
+        t0 = next(t for t in ts if t is not None)
+        n, h, w = t0.n, t0.h, t0.w
+        P = n * h * w
+        if ks == 1 and h * w < 25 and P % 16 == 0 and P >= 256 and all(
+                t is None or (t.sh == t.w * t.sw and t.sn == t.h * t.sh) for t in ts):
+            return 1, P // 16, 16, (lambda t: NULL_VIEW if t is None else View(t.ptr, P * t.sw, 16 * t.sw, t.sw, t.c, t.cpad))
+        return n, h, w, (lambda t: NULL_VIEW if t is None else t.cv())
+
     def _new_grad(self, n, h, w, c):
         g = self.new(n, h, w, c, rg=False)
         if c % 8:  # ragged width: zero the padding once (writers only touch [0, c)) so gradient consumers can DMA it
@@ -762,23 +777,25 @@ class Engine:
                     self._cow(s)
                     gv = prev = self.grads[id(s.base)][0].chan(s.coff, s.coff + s.c)
             a = _lib.ConvArgs()
-            a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = self.dt, x0.n, x0.h, x0.w, site.ks, 1, ACT_NONE, act
-            a.seg[0] = g.cv()
+            gn, gh, gw, vw = self._geom(site.ks, [g, gv, s, prev])
+            a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = self.dt, gn, gh, gw, site.ks, 1, ACT_NONE, act
+            a.seg[0] = vw(g)
             a.weight = site.img_dg[k]
             a.bias = None
-            a.out = gv.cv()
-            a.aux = s.cv() if act != ACT_NONE else NULL_VIEW
-            a.res1 = prev.cv() if acc else NULL_VIEW
+            a.out = vw(gv)
+            a.aux = vw(s) if act != ACT_NONE else NULL_VIEW
+            a.res1 = vw(prev) if acc else NULL_VIEW
             a.res2 = NULL_VIEW
             self._timed("conv_dgrad", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream), ci=s.c)
 
     def _wgrad(self, site, segs, act, g):
         x0 = segs[0]
         a = _lib.WgradArgs()
-        a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act = self.dt, x0.n, x0.h, x0.w, site.ks, len(segs), act
+        gn, gh, gw, vw = self._geom(site.ks, list(segs) + [g])
+        a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act = self.dt, gn, gh, gw, site.ks, len(segs), act
         for k, s in enumerate(segs):
-            a.seg[k] = s.cv()
-        a.gout = g.cv()
+            a.seg[k] = vw(s)
+        a.gout = vw(g)
         use = sum(1 for e in self._wg_events if e[0] is site)
         key = (site.index, use, x0.n, x0.h, x0.w)
         ent = self._partials.get(key)
