@@ -1376,7 +1376,8 @@ struct Wg2Geom { int ncf, njw, cwin, nsplit, tps, ntiles, tiles_x, tiles_y, n_cw
 
 // returns false when the shape is not served by the tiled kernel
 static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2Geom& g) {
-  if (!(ks == 1 || ks == 3) || H < 5 || W < 5) return false;
+  static const int min_hw = [] { const char* e = getenv("CGEN_WG2_MINHW"); return e ? atoi(e) : 3; }();  // tiny images waste most of a tile, but the packed launch still beats the generic kernel
+  if (!(ks == 1 || ks == 3) || H < min_hw || W < min_hw) return false;
   const int taps = ks * ks;
   const int halo = ks / 2;
   g.ncf = co <= 16 ? 1 : (co <= 32 ? 2 : (co <= 64 ? 4 : (co <= 96 ? 6 : 8)));
