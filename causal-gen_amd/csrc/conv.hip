@@ -1451,7 +1451,7 @@ static void launch_wgrad2_ks(const Wg2P& p, const Wg2Geom& g, hipStream_t st) {
 struct PxP {
   PixTile xt;
   int tiles_x, tiles_y, ntiles, nks;
-  int ldw, wpieces, rows_pad, pad0;
+  int ldw, wpieces, rows_pad, co8;  // co8: output channels incl. zero padding to 8 (== Co unless the output view carries cpad)
   FastDiv d_gprw, d_ctot8;
 };
 
@@ -1553,7 +1553,7 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
     for (int h = 0; h < 2; ++h) {
       const int co = ch0 + pr * 32 + h * 4;
       binit[pr][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (p.bias && co + 4 <= p.Co) { const float4 b = *(const float4*)(p.bias + co); binit[pr][h] = (f32x4){b.x, b.y, b.z, b.w}; }
+      if (p.bias && co + 4 <= p.Co) { const float4 b = *(const float4*)(p.bias + co); binit[pr][h] = (f32x4){b.x, b.y, b.z, b.w}; }  // (Co % 4 == 0: checked on the host)
     }
   const bool has_aux = p.aux.p != nullptr, has_r1 = p.res1.p != nullptr, has_r2 = p.res2.p != nullptr;
   const char* a_base = Wsb + (size_t)fr * q.ldw * 2 + fg * 16;
@@ -1587,7 +1587,7 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
         pv[f] = colv && y0 + wave * 2 + f < p.H;
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) {
-          const bool ok = pv[f] && ch0 + pr * 32 + 8 <= p.Co;
+          const bool ok = pv[f] && ch0 + pr * 32 + 8 <= q.co8;
           ea[pr][f] = make_uint4(0, 0, 0, 0);
           er[pr][f] = make_uint4(0, 0, 0, 0);
           if (has_aux) ea[pr][f] = *(const uint4*)(ok ? aux_t + eo_aux[f] + pr * 64 : (const char*)g_zero16);
@@ -1642,7 +1642,7 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
       for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) {
-          if (!(pv[f] && ch0 + pr * 32 + 8 <= p.Co)) continue;
+          if (!(pv[f] && ch0 + pr * 32 + 8 <= q.co8)) continue;
           float v[8];
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[e] = acc[pr][0][f][e]; v[4 + e] = acc[pr][1][f][e]; }
@@ -1706,7 +1706,16 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st) {
   PxP q;
   memset(&q, 0, sizeof(q));
   q.nks = ceil_div(p.taps * p.ctot8, 32);
-  if (q.nks > PX_MAXKS || p.Co % 8 != 0 || !p.epi_vec16) return false;
+  if (q.nks > PX_MAXKS || !p.epi_vec16) return false;
+  q.co8 = p.Co;
+  if (p.Co % 8 != 0) {
+    // ragged output width: the rows past Co of the weight image are zero, so the kernel may write whole 8-channel chunks
+    // if the output asks for zero padding (out.cpad) and every epilogue operand is zero-padded as well
+    const int c8 = pad_to(p.Co, 8);
+    auto padded = [&](const View& v) { return !v.p || v.cpad >= c8; };
+    if (p.Co % 4 != 0 || p.out.cpad < c8 || !padded(p.aux) || !padded(p.res1) || !padded(p.res2)) return false;
+    q.co8 = c8;
+  }
   if (!fits_i32(p.out, 1, TILE_H, TILE_W) || !fits_i32(p.aux, 1, TILE_H, TILE_W) || !fits_i32(p.res1, 1, TILE_H, TILE_W) || !fits_i32(p.res2, 1, TILE_H, TILE_W)) return false;
   q.xt = mk_pixtile(p.ctot8, 2, TILE_H + 2 * halo, TILE_W + 2 * halo);
   if (q.xt.ppp < 1) return false;
