@@ -227,17 +227,18 @@ def main():
         }
         res["roofline"] = roof
         if not a.no_cf:
-            from causal_gen_amd.dscm import counterfactual
+            from causal_gen_amd.dscm import GraphedCounterfactual
 
             ema = ts.ema_model
             cfp = pa.roll(1, 0)  # train_cf.py:149 feeds a permutation of the batch's parents as `do`
-            for _ in range(2):
-                counterfactual(ema, x, pa, cfp)
+            counterfactual = GraphedCounterfactual(ema)  # abduct -> act -> predict as one hipGraph replay per batch
+            for _ in range(3):
+                counterfactual(x, pa, cfp)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            n_cf = 5
+            n_cf = 10
             for _ in range(n_cf):
-                counterfactual(ema, x, pa, cfp)
+                counterfactual(x, pa, cfp)
             torch.cuda.synchronize()
             cf_s = B * n_cf / (time.perf_counter() - t1)
             res["counterfactuals_per_s"] = cf_s

@@ -211,3 +211,33 @@ def test_dp_bench_path_two_gloo_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["elbo_nats_per_dim"] == d["elbo_nats_per_dim"]
     assert d["opt_steps"] == 4 and "roofline" in d
+
+
+def test_graphed_counterfactual_matches_eager_and_follows_weight_updates():
+    from causal_gen_amd import dscm
+
+    fx, hpd, m = setup("tiny_condprior_morpho_c1.pt")
+    m.eval()
+    x, pa, cf = fx["x"].cuda(), fx["pa"].cuda(), fx["cf_pa"].cuda()
+    gcf = dscm.GraphedCounterfactual(m)
+
+    def reset():
+        eng = m.engine()
+        eng.rng_ptr()
+        eng.rng.copy_(torch.tensor([123, 0], dtype=torch.int64, device=eng.rng.device))  # in place: the graph holds its address
+
+    def both():
+        reset()
+        a = dscm.counterfactual(m, x, pa, cf).clone()
+        reset()
+        b = gcf(x, pa, cf).clone()
+        return a, b
+
+    a0, b0 = both()      # first graphed call = eager warm-up + capture
+    a1, b1 = both()      # replay
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.05)
+    a2, b2 = both()
+    assert torch.equal(a2, b2) and not torch.equal(a2, a1)
