@@ -310,3 +310,49 @@ def test_module_level_gaussian_kl_and_sample_gaussian():
     for s in (a, b):
         assert abs(float(s.mean()) - 0.25) < 5e-3 and abs(float(s.std()) - 0.5) < 5e-3
     assert abs(float(((a - 0.25) / 0.5).pow(4).mean()) - 3.0) < 0.1  # Gaussian kurtosis
+
+
+def test_reparam_kl_bf16_vec8_path_matches_scalar_formula():
+    """The 8-channels-per-thread bf16 kernels (z_dim = 16 in every preset) against the f32 formula on the bf16-rounded
+    inputs: z, per-sample KL and all four gradients; plus the Philox branch (same noise as the scalar kernel's mapping)."""
+    from oracle import hvae_ref
+
+    g = torch.Generator().manual_seed(4)
+    N, Cc, H, W = 3, 16, 5, 7
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    ql, pl = bf(torch.randn(N, Cc, H, W, generator=g)), bf(torch.randn(N, Cc, H, W, generator=g))
+    qs, ps = bf(torch.randn(N, Cc, H, W, generator=g) * 0.3 - 0.5), bf(torch.randn(N, Cc, H, W, generator=g) * 0.3)
+    eps, gz = bf(torch.randn(N, Cc, H, W, generator=g)), bf(torch.randn(N, Cc, H, W, generator=g))
+    leaves = [t.clone().requires_grad_(True) for t in (ql, qs, pl, ps)]
+    z_ref = leaves[0] + leaves[1].exp() * eps
+    kl_ref = hvae_ref.gaussian_kl(*leaves)
+    coef = 0.21
+    ((z_ref * gz).sum() + coef * kl_ref.sum()).backward()
+    eng, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]], dtype="bf16")
+    eng.recording = True
+    ts = [eng.from_nchw(t.cuda(), rg=True) for t in (ql, qs, pl, ps)]
+    for t in ts:
+        t.rg = True
+    nch = eng.lib.reparam_kl_chunks(H, W, Cc)
+    klp = torch.zeros(N * nch, device="cuda")
+    z = eng.reparam_kl(ts[0], ts[1], ts[2], ts[3], eng.from_nchw(eps.cuda()), 1, 0.0, klp.data_ptr(), nch)
+    torch.testing.assert_close(nhwc_to_torch(eng, z), z_ref.detach(), rtol=1e-2, atol=1e-2)  # bf16 storage of z
+    torch.testing.assert_close(klp.view(N, nch).sum(1).cpu(), kl_ref.detach().sum(dim=(1, 2, 3)), rtol=1e-4, atol=1e-3)
+    gzv = eng.seed_grad(z)
+    eng.lib.axpby(eng.dt, N, H, W, eng.from_nchw(gz.cuda()).cv(), gzv.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
+    cf = torch.tensor([0.0, coef], device="cuda")
+    eng.kl_coef_ptr = cf.data_ptr() + 4
+    eng.backward()
+    for t, leaf in zip(ts, leaves):
+        got = nhwc_to_torch(eng, eng.grad_read(t))
+        assert (got - leaf.grad).abs().max().item() < 2e-2 * leaf.grad.abs().max().item()  # bf16 z and bf16 gradient storage
+    # Philox branch: z - q_loc = exp(q_ls) * N(0,1) with the generator's statistics, deterministic per (seed, offset)
+    eng2, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]], dtype="bf16")
+    big = [eng2.from_nchw(torch.zeros(8, 16, 32, 32, device="cuda")) for _ in range(4)]
+    nch2 = eng2.lib.reparam_kl_chunks(32, 32, 16)
+    k2 = torch.zeros(8 * nch2, device="cuda")
+    eng2.rng_ptr()
+    eng2.rng.copy_(torch.tensor([99, 0], dtype=torch.int64, device="cuda"))
+    za = nhwc_to_torch(eng2, eng2.reparam_kl(big[0], big[1], big[2], big[3], None, 7, 0.0, k2.data_ptr(), nch2))
+    zb = nhwc_to_torch(eng2, eng2.reparam_kl(big[0], big[1], big[2], big[3], None, 7, 0.0, k2.data_ptr(), nch2))
+    assert torch.equal(za, zb) and abs(za.mean().item()) < 1e-2 and abs(za.std().item() - 1.0) < 1e-2
