@@ -153,15 +153,27 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(Shape4 si, int ho, in
 
 template <typename T>
 __global__ __launch_bounds__(256) void batch_reduce_kernel(Shape4 s, View in, float* out, int accumulate) {
+  // a workgroup owns 64 consecutive (y, x, c) elements; its 4 waves split the batch and are combined in a fixed order
+  __shared__ float part[4][64];
   const int64_t per = (int64_t)s.h * s.w * s.c;
-  GRID_STRIDE(g) {
-    if (g >= per) return;
-    const int c = (int)(g % s.c);
-    const int x = (int)((g / s.c) % s.w);
-    const int y = (int)(g / ((int64_t)s.c * s.w));
+  const int lane = threadIdx.x & 63, phase = threadIdx.x >> 6;
+  for (int64_t g0 = (int64_t)blockIdx.x * 64; g0 < per; g0 += (int64_t)gridDim.x * 64) {
+    const int64_t g = g0 + lane;
     float a = 0.f;
-    for (int n = 0; n < s.n; ++n) a += Elem<T>::ld(vptr<T>(in, n, y, x) + c);
-    out[g] = accumulate ? out[g] + a : a;
+    if (g < per) {
+      const int c = (int)(g % s.c);
+      const int x = (int)((g / s.c) % s.w);
+      const int y = (int)(g / ((int64_t)s.c * s.w));
+      const T* p0 = vptr<T>(in, 0, y, x) + c;
+      for (int n = phase; n < s.n; n += 4) a += Elem<T>::ld(p0 + (int64_t)n * in.sn);
+    }
+    part[phase][lane] = a;
+    __syncthreads();
+    if (phase == 0 && g < per) {
+      const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+      out[g] = accumulate ? out[g] + t : t;
+    }
+    __syncthreads();
   }
 }
 
@@ -464,8 +476,8 @@ extern "C" int cgen_batch_reduce(int32_t dtype, int32_t n, int32_t h, int32_t w,
   CGEN_REQUIRE(in.p && out, "cgen_batch_reduce: bad args");
   Shape4 s{n, h, w, in.c};
   const int64_t items = (int64_t)h * w * in.c;
-  if (dtype == CGEN_F32) hipLaunchKernelGGL(batch_reduce_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, mk(in), out, accumulate);
-  else hipLaunchKernelGGL(batch_reduce_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, mk(in), out, accumulate);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(batch_reduce_kernel<float>, dim3(grid_for(items * 4)), dim3(256), 0, (hipStream_t)stream, s, mk(in), out, accumulate);
+  else hipLaunchKernelGGL(batch_reduce_kernel<bf16_t>, dim3(grid_for(items * 4)), dim3(256), 0, (hipStream_t)stream, s, mk(in), out, accumulate);
   return check_launch("cgen_batch_reduce");
 }
 
