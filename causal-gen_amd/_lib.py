@@ -61,7 +61,7 @@ PROTOTYPES = {
     "cgen_conv2d": [C.POINTER(ConvArgs), vp],
     "cgen_conv2d_wgrad_plan": [C.POINTER(WgradArgs), C.POINTER(i32)],
     "cgen_conv2d_wgrad_batch_plan": [vp, i32, vp, i64, vp, vp, i32, vp, vp],
-    "cgen_conv2d_wgrad_batch_run": [vp, vp, i32, vp],
+    "cgen_conv2d_wgrad_batch_run": [vp, vp, i32, i32, vp],
     "cgen_conv2d_wgrad": [C.POINTER(WgradArgs), vp],
     "cgen_weight_prep": [vp, vp, vp, i32, vp],
     "cgen_wgrad_reduce": [vp, vp, vp, i32, vp],

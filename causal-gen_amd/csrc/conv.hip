@@ -465,6 +465,7 @@ __device__ __forceinline__ uint4 act_group(uint4 v, int act) {
 
 template <typename T, int NTC, int KS>
 __global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP p, TileP q) {
+  __builtin_amdgcn_s_setprio(3);  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   constexpr int G = 16 / sizeof(T);
   constexpr int HALO = KS / 2, HH = TILE_H + 2 * HALO, HW = TILE_W + 2 * HALO, HPX = HH * HW;
   constexpr int TAPS = KS * KS;
@@ -710,6 +711,7 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st);  // lean persistent 
 // are added through LDS in a fixed order (deterministic).  One workgroup = 16*SP_NCO output channels x 32 pixels.
 template <int KS, int SP_NCO, int KU>
 __global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, FastDiv d_ctot8, FastDiv d_hw, FastDiv d_w) {
+  __builtin_amdgcn_s_setprio(3);  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   typedef bf16_t T;
   constexpr int HALO = KS / 2, TAPS = KS * KS;  // KU K-steps are issued together per wave
   __shared__ __attribute__((aligned(16))) float red[4 * SP_NCO * 2 * 256];
@@ -1365,11 +1367,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_kernel(Wg2P p) {
 // i.e. they are latency chains.  Packed into one grid, every CU always holds workgroups of *some* problem.
 // blocks[b] = {problem, split, channel window, co range}; problems are read through a uniform pointer (scalar loads).
 template <int NCF, int NJW, int KS>
-__global__ __launch_bounds__(256, 2) void wgrad_tile_batched_kernel(const Wg2P* __restrict__ probs, const int4* __restrict__ blocks) {
-  const int4 bi = blocks[blockIdx.x];
-  const int prob = __builtin_amdgcn_readfirstlane(bi.x);
-  wgrad_tile_body<NCF, NJW, KS>(probs[prob], __builtin_amdgcn_readfirstlane(bi.y), __builtin_amdgcn_readfirstlane(bi.z),
-                                __builtin_amdgcn_readfirstlane(bi.w));
+__global__ __launch_bounds__(256, 2) void wgrad_tile_batched_kernel(const Wg2P* __restrict__ probs, const int4* __restrict__ blocks, const int nblocks) {
+  // gridDim.x < nblocks: a resident set of workgroups walks the block list (the engine caps the grid when the launch
+  // runs in the background of the backward chain, so that the chain's kernels always find free CUs)
+  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const int4 bi = blocks[b];
+    const int prob = __builtin_amdgcn_readfirstlane(bi.x);
+    wgrad_tile_body<NCF, NJW, KS>(probs[prob], __builtin_amdgcn_readfirstlane(bi.y), __builtin_amdgcn_readfirstlane(bi.z),
+                                  __builtin_amdgcn_readfirstlane(bi.w));
+    __syncthreads();
+  }
 }
 
 struct Wg2Geom { int ncf, njw, cwin, nsplit, tps, ntiles, tiles_x, tiles_y, n_cwin, n_co; PixTile xt, gt; size_t lds; };
@@ -1461,6 +1468,7 @@ __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 
 
 template <int NP, int KS>
 __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
+  __builtin_amdgcn_s_setprio(3);  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   typedef bf16_t T;
   constexpr int G = 8, HALO = KS / 2, HW = TILE_W + 2 * HALO, TAPS = KS * KS;
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -1772,6 +1780,7 @@ struct WsP {
 
 template <int NTC, int NKW>
 __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
+  __builtin_amdgcn_s_setprio(3);  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   typedef bf16_t T;
   constexpr int G = 8, NF = NTC * TILE_H;
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -2263,15 +2272,15 @@ static bool build_wg2(const cgen_wgrad_args* a, Wg2P& q, Wg2Geom& g) {
 }
 
 template <int NCF, int NJW>
-static void launch_wgrad2_batched(int ks, const Wg2P* probs, const int4* blocks, int nblocks, size_t lds, hipStream_t st) {
+static void launch_wgrad2_batched(int ks, const Wg2P* probs, const int4* blocks, int nblocks, int grid, size_t lds, hipStream_t st) {
   if (ks == 3) {
     static bool once3 = false;
     if (!once3) { (void)hipFuncSetAttribute((const void*)wgrad_tile_batched_kernel<NCF, NJW, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once3 = true; }
-    hipLaunchKernelGGL((wgrad_tile_batched_kernel<NCF, NJW, 3>), dim3(nblocks), dim3(256), lds, st, probs, blocks);
+    hipLaunchKernelGGL((wgrad_tile_batched_kernel<NCF, NJW, 3>), dim3(grid), dim3(256), lds, st, probs, blocks, nblocks);
   } else {
     static bool once1 = false;
     if (!once1) { (void)hipFuncSetAttribute((const void*)wgrad_tile_batched_kernel<NCF, NJW, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once1 = true; }
-    hipLaunchKernelGGL((wgrad_tile_batched_kernel<NCF, NJW, 1>), dim3(nblocks), dim3(256), lds, st, probs, blocks);
+    hipLaunchKernelGGL((wgrad_tile_batched_kernel<NCF, NJW, 1>), dim3(grid), dim3(256), lds, st, probs, blocks, nblocks);
   }
 }
 
@@ -2326,7 +2335,8 @@ extern "C" int cgen_conv2d_wgrad_batch_plan(const cgen_wgrad_args* args, int32_t
   return CGEN_OK;
 }
 
-extern "C" int cgen_conv2d_wgrad_batch_run(const void* blob_dev, const cgen_wgrad_batch_launch* launches, int32_t n_launches, cgen_stream_t stream) {
+extern "C" int cgen_conv2d_wgrad_batch_run(const void* blob_dev, const cgen_wgrad_batch_launch* launches, int32_t n_launches, int32_t max_workgroups,
+                                           cgen_stream_t stream) {
   CGEN_REQUIRE(blob_dev && (launches || n_launches == 0) && n_launches >= 0, "cgen_conv2d_wgrad_batch_run: null args");
   hipStream_t st = (hipStream_t)stream;
   const Wg2P* probs = (const Wg2P*)blob_dev;
@@ -2334,12 +2344,13 @@ extern "C" int cgen_conv2d_wgrad_batch_run(const void* blob_dev, const cgen_wgra
     const cgen_wgrad_batch_launch& l = launches[i];
     if (l.nblocks <= 0) continue;
     const int4* blocks = (const int4*)((const char*)blob_dev + l.blocks_offset);
+    const int grid = max_workgroups > 0 ? std::min(l.nblocks, max_workgroups) : l.nblocks;
     switch (l.ncf) {
-      case 1: launch_wgrad2_batched<1, 16>(l.ks, probs, blocks, l.nblocks, (size_t)l.lds_bytes, st); break;
-      case 2: launch_wgrad2_batched<2, 12>(l.ks, probs, blocks, l.nblocks, (size_t)l.lds_bytes, st); break;
-      case 4: launch_wgrad2_batched<4, 6>(l.ks, probs, blocks, l.nblocks, (size_t)l.lds_bytes, st); break;
-      case 6: launch_wgrad2_batched<6, 4>(l.ks, probs, blocks, l.nblocks, (size_t)l.lds_bytes, st); break;
-      case 8: launch_wgrad2_batched<8, 3>(l.ks, probs, blocks, l.nblocks, (size_t)l.lds_bytes, st); break;
+      case 1: launch_wgrad2_batched<1, 16>(l.ks, probs, blocks, l.nblocks, grid, (size_t)l.lds_bytes, st); break;
+      case 2: launch_wgrad2_batched<2, 12>(l.ks, probs, blocks, l.nblocks, grid, (size_t)l.lds_bytes, st); break;
+      case 4: launch_wgrad2_batched<4, 6>(l.ks, probs, blocks, l.nblocks, grid, (size_t)l.lds_bytes, st); break;
+      case 6: launch_wgrad2_batched<6, 4>(l.ks, probs, blocks, l.nblocks, grid, (size_t)l.lds_bytes, st); break;
+      case 8: launch_wgrad2_batched<8, 3>(l.ks, probs, blocks, l.nblocks, grid, (size_t)l.lds_bytes, st); break;
       default: return cgen::fail(CGEN_EINVAL, "cgen_conv2d_wgrad_batch_run: bad variant %d", l.ncf);
     }
   }

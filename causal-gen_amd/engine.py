@@ -153,6 +153,11 @@ class Engine:
         self.wgrad_streams = int(os.environ.get("CGEN_WGRAD_STREAMS", "2"))
         # ... or, better, packed: ONE launch per kernel variant runs the workgroups of all deferred problems (cgen_conv2d_wgrad_batch_*)
         self.wgrad_batch = os.environ.get("CGEN_WGRAD_BATCH", "1") != "0"
+        # background flushes: once this many GFLOP of weight gradients are pending they are issued on a side stream with a
+        # capped grid, so that they fill the CUs the latency-bound backward chain leaves idle (0: one batch at the end)
+        self.wgrad_flush_frac = [float(v) for v in os.environ.get("CGEN_WGRAD_FLUSH_FRAC", "0.55").split(",") if v]
+        self.wgrad_bg_wgs = int(os.environ.get("CGEN_WGRAD_BG_WGS", "256"))
+        self._wg_cum, self._wg_total, self._wg_nflush = 0.0, 0.0, 0
         self._wg_batches = {}
         self._wg_forked = False
         self._wg_pool = []
@@ -172,6 +177,7 @@ class Engine:
         self._pnhwc, self._pgrad_tmp = {}, {}
         self._adopted = set()
         self._wg_deferred = []
+        self._wg_cum, self._wg_nflush = 0.0, 0
         self._wg_forked = False
         self.passes = 0
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -741,6 +747,9 @@ class Engine:
 
     # ------------------------------------------------------------------ backward
     def backward(self):
+        if self.wgrad_flush_frac:  # total weight-gradient work of this pass: the background-flush marks are fractions of it
+            self._wg_total = sum(2.0 * a[0].ci * a[0].taps * a[0].co * a[1][0].n * a[1][0].h * a[1][0].w
+                                 for fn, a in self.tape if fn == self._bw_conv and a[0].conv.weight.requires_grad)
         for fn, args in reversed(self.tape):
             fn(*args)
         self._reduce_wgrads()
@@ -810,15 +819,27 @@ class Engine:
         a.partial_w = buf.data_ptr()
         a.partial_b = buf.data_ptr() + 4 * nsplit * nw if site.conv.bias is not None else None
         if self._defer_wgrad():
-            self._wg_deferred.append((a, 2.0 * site.ci * site.taps * site.co * x0.n * x0.h * x0.w))
+            cost = 2.0 * site.ci * site.taps * site.co * x0.n * x0.h * x0.w
+            self._wg_deferred.append((a, cost))
+            self._wg_cum += cost
+            k = self._wg_nflush  # cumulative-cost marks, fractions of the pass's total
+            if (self.wgrad_batch and self.prof is None and k < len(self.wgrad_flush_frac) and self._wg_total > 0
+                    and self._wg_cum >= self.wgrad_flush_frac[k] * self._wg_total):
+                self._wg_nflush += 1
+                self._launch_batched_wgrads(background=True)
         else:
             self._timed("conv_wgrad", site, x0, lambda: self.lib.conv2d_wgrad(C.byref(a), self.stream))
         self._wg_events.append((site, key, nsplit))
 
     def _launch_deferred_wgrads(self, final=True):
         main = torch.cuda.current_stream(self.device)
-        if self._wg_deferred and self.wgrad_batch:
-            self._launch_batched_wgrads()
+        if self.wgrad_batch:
+            if self._wg_deferred:
+                self._launch_batched_wgrads()
+            if final and self._wg_forked:
+                for st in self._wg_pool:
+                    main.wait_stream(st)
+                self._wg_forked = False
             return
         if self._wg_deferred:
             k = min(self.wgrad_streams, len(self._wg_deferred))
@@ -840,11 +861,17 @@ class Engine:
                 main.wait_stream(st)
             self._wg_forked = False
 
-    def _launch_batched_wgrads(self):
+    def _launch_batched_wgrads(self, background=False):
         """All deferred weight-gradient problems in a handful of launches.  The packed problem table is planned once per
         distinct set of launch arguments (addresses are stable: the arena is deterministic) and kept on the device."""
         args = [a for a, _ in self._wg_deferred]
         n = len(args)
+        if os.environ.get("CGEN_WG_DEBUG"):
+            tot, line = 0.0, []
+            for a, c in self._wg_deferred:
+                tot += c
+                line.append("%dx%d:%.0f" % (a.h, a.ks, tot / 1e9))
+            print("wgrad batch (bg=%s): %d problems, %.0f GF: %s" % (background, n, tot / 1e9, " ".join(line)), flush=True)
         arr = (_lib.WgradArgs * n)(*args)
         key = bytes(arr)
         ent = self._wg_batches.get(key)
@@ -858,7 +885,7 @@ class Engine:
             lib.conv2d_wgrad_batch_plan(arr, n, host, nbytes.value, C.byref(nbytes), launches, nl.value, C.byref(nl), elig)
             blob = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.device) if nbytes.value else None
             rest = [i for i in range(n) if not elig[i]]
-            if len(self._wg_batches) > 8:
+            if len(self._wg_batches) > 64:
                 self._wg_batches.clear()
             ent = self._wg_batches[key] = (blob, launches, nl.value, rest)
         blob, launches, nl, rest = ent
@@ -866,8 +893,23 @@ class Engine:
         if self.prof is not None:  # the packed launches are timed as ONE class entry (per-problem times do not exist)
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        if background:
+            main = torch.cuda.current_stream(self.device)
+            if not self._wg_pool:
+                self._wg_pool.append(torch.cuda.Stream(self.device))
+            side = self._wg_pool[0]
+            side.wait_stream(main)
+            self._wg_forked = True
+            if blob is not None and nl:
+                self.lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl, self.wgrad_bg_wgs, side.cuda_stream)
+                self.launches += nl
+            for i in rest:
+                self.lib.conv2d_wgrad(C.byref(args[i]), side.cuda_stream)
+                self.launches += 1
+            self._wg_deferred = []
+            return
         if blob is not None and nl:
-            self.lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl, self.stream)
+            self.lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl, 0, self.stream)
             self.launches += nl
         if len(rest) >= 4 and self.wgrad_streams > 1 and ev is None:
             # problems the packed kernel does not serve (f32, < 5x5 images): independent launches on the stream pool

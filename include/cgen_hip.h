@@ -86,14 +86,17 @@ int cgen_conv2d_wgrad_plan(const cgen_wgrad_args* a, int32_t* tiled_out);
  * go through cgen_conv2d_wgrad) into a host blob: a table of problems followed by one {problem, split, window, co range}
  * record per workgroup, and describes one launch per kernel variant.  Call it with blob_host = NULL to get the sizes.
  * The caller copies the blob to the device ONCE (addresses are stable across steps: the arena is deterministic) and
- * `run` then issues n_launches kernels instead of `count`.  nsplit / partial buffers exactly as cgen_conv2d_wgrad. */
+ * `run` then issues n_launches kernels instead of `count`.  nsplit / partial buffers exactly as cgen_conv2d_wgrad.
+ * max_workgroups > 0 caps each launch's grid (a resident set of workgroups walks the records): a batch issued on a side
+ * stream in the background of the backward chain must leave CUs free for the chain's kernels; 0 = one workgroup per record. */
 typedef struct {
   int32_t ncf, ks, lds_bytes, nblocks;
   int64_t blocks_offset; /* byte offset of this launch's workgroup records inside the blob */
 } cgen_wgrad_batch_launch;
 int cgen_conv2d_wgrad_batch_plan(const cgen_wgrad_args* args, int32_t count, void* blob_host, int64_t capacity, int64_t* blob_bytes,
                                  cgen_wgrad_batch_launch* launches, int32_t max_launches, int32_t* n_launches, int32_t* eligible);
-int cgen_conv2d_wgrad_batch_run(const void* blob_dev, const cgen_wgrad_batch_launch* launches, int32_t n_launches, cgen_stream_t);
+int cgen_conv2d_wgrad_batch_run(const void* blob_dev, const cgen_wgrad_batch_launch* launches, int32_t n_launches, int32_t max_workgroups,
+                               cgen_stream_t);
 int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream);
 
 /* Multi-tensor descriptor tables (device memory, built once by the host).  One launch serves every conv site. */
