@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
 
 struct PixTile {
   int gpr, ppp, ppr, rows, npx, rowbytes, bytes, pad;
-  FastDiv d_gpr, d_ppr;
+  FastDiv d_gpr, d_ppr, d_ppp;
 };
 static inline PixTile mk_pixtile(int width_elems, int esz, int rows, int npx) {
   PixTile t;
@@ -1073,17 +1073,17 @@ static inline PixTile mk_pixtile(int width_elems, int esz, int rows, int npx) {
   t.gpr = gpr; t.ppp = 64 / gpr; t.rows = rows; t.npx = npx;
   if (t.ppp < 1) {  // pixel wider than one 1-KiB piece: caller must fall back (checks ppp < 1)
     t.ppr = 0; t.rowbytes = 0; t.bytes = 0; t.pad = 0;
-    t.d_gpr = mk_fastdiv(1); t.d_ppr = mk_fastdiv(1);
+    t.d_gpr = mk_fastdiv(1); t.d_ppr = mk_fastdiv(1); t.d_ppp = mk_fastdiv(1);
     return t;
   }
   t.ppr = (npx + t.ppp - 1) / t.ppp;
   t.rowbytes = t.ppr * 1024; t.bytes = rows * t.rowbytes; t.pad = 0;
-  t.d_gpr = mk_fastdiv(gpr); t.d_ppr = mk_fastdiv(t.ppr);
+  t.d_gpr = mk_fastdiv(gpr); t.d_ppr = mk_fastdiv(t.ppr); t.d_ppp = mk_fastdiv(t.ppp);
   return t;
 }
 // byte offset of pixel (row, x) inside a PixTile
 __device__ __forceinline__ int pix_off(const PixTile& t, int row, int x) {
-  const int pc = x / t.ppp;
+  const int pc = fdiv(x, t.d_ppp);
   return row * t.rowbytes + pc * 1024 + (x - pc * t.ppp) * t.gpr * 16;
 }
 
@@ -1459,14 +1459,16 @@ struct PxP {
   PixTile xt;
   int tiles_x, tiles_y, ntiles, nks;
   int ldw, wpieces, rows_pad, co8;  // co8: output channels incl. zero padding to 8 (== Co unless the output view carries cpad)
-  FastDiv d_gprw, d_ctot8;
+  FastDiv d_gprw, d_ctot8, d_tx, d_ty;
+  int ktab[PX_MAXKS * 4];  // [K-step][lane group fg]: ((tap row * rowbytes + channel * 2) << 3) | (tap column == 2) << 2 | tap column -- read with VECTOR loads from the kernarg segment
+  unsigned long long* stamps;  // optional (CGEN_PX_STAMPS): 100 MHz wall-clock stamps {entry, tile landed, MFMAs done, exit} of every workgroup
 };
 
 // bf16 pair -> two floats
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-template <int NP, int KS>
+template <int NP, int KS, bool ONESEG>
 __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
   __builtin_amdgcn_s_setprio(3);  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   typedef bf16_t T;
@@ -1480,48 +1482,52 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
   const int co_base = blockIdx.y * (NP * 32);
+  unsigned long long* stamp = (q.stamps != nullptr && tid == 0) ? q.stamps + 8 * (blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
+  if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
 
   // ---- weight slab, once.  LDS row (pr*32 + h*16 + j) holds output channel pr*32 + (j>>2)*8 + h*4 + (j&3): MFMA "h" of
   // pair pr then leaves channels 8*fg + 4*h + {0..3} of the pair in lane group fg
   {
-    const int gpr_w = q.ldw / G, wgroups = NP * 32 * gpr_w;
+    // branch-free: a lane past the slab's last group re-copies the last group into its own (padding) slot, rows past the
+    // weight image are clamped to its last row (their outputs are never stored); columns never leave the row (ldw <= krow)
+    const int gpr_w = q.ldw / G, last = NP * 32 * gpr_w - 1;
     for (int piece = wave; piece < q.wpieces; piece += 4) {
       const int pu = __builtin_amdgcn_readfirstlane(piece);
-      const int gi = pu * 64 + lane;
+      const int gi = min(pu * 64 + lane, last);
       const int r = fdiv(gi, q.d_gprw), k = (gi - r * gpr_w) * G;
-      if (gi < wgroups) {
-        const int j = r & 15, h = (r >> 4) & 1, pr = r >> 5;
-        const int row = co_base + pr * 32 + (j >> 2) * 8 + h * 4 + (j & 3);
-        const T* src = (row < q.rows_pad && k < p.krow) ? (const T*)p.w + (size_t)row * p.krow + k : (const T*)g_zero16;
-        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Wsb + (size_t)pu * 1024), 16, 0, 0);
-      }
+      const int j = r & 15, h = (r >> 4) & 1, pr = r >> 5;
+      const int row = min(co_base + pr * 32 + (j >> 2) * 8 + h * 4 + (j & 3), q.rows_pad - 1);
+      const T* src = (const T*)p.w + (__umul24(row, p.krow) + k);
+      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Wsb + (size_t)pu * 1024), 16, 0, 0);
     }
   }
-
+  if (stamp) stamp[4] = __builtin_amdgcn_s_memrealtime();
   // ---- lane constants
-  int koff[PX_MAXKS];  // K-step -> byte offset of this lane's 8 input channels inside a tile row (tap shift included)
+  // K-step -> byte offset of this lane's 8 input channels inside a tile row (tap shift included).  The (K-step, lane group)
+  // -> (tap, channel) decoding is done on the host: q.ktab sits in the kernarg segment, which is ordinary memory -- every
+  // lane fetches its entries with vector loads that are all in flight together.  They are CONSUMED only after the first
+  // tile's DMA has been issued (vmcnt is in order: consuming them here would expose the weight-slab latency).
+  int koff[PX_MAXKS], kt[PX_MAXKS];
   {
-    int pxo[3];
+    constexpr size_t q_off = (sizeof(ConvP) + alignof(PxP) - 1) / alignof(PxP) * alignof(PxP);
+    const int* ktab = (const int*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + q_off + offsetof(PxP, ktab)) + fg;
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) pxo[dx] = pix_off(q.xt, 0, fr + (dx < KS ? dx : 0));
-#pragma unroll
-    for (int i = 0; i < PX_MAXKS; ++i) {
-      koff[i] = 0;
-      if (i >= q.nks) continue;
-      const int kidx = i * 32 + fg * 8;
-      int tap = fdiv(kidx, q.d_ctot8);
-      const int c = kidx - tap * p.ctot8;
-      tap = tap < TAPS ? tap : TAPS - 1;  // columns past the last tap carry zero weights; keep the address legal
-      const int dy = tap / KS, dx = tap - dy * KS;
-      koff[i] = dy * q.xt.rowbytes + (dx == 0 ? pxo[0] : (dx == 1 ? pxo[1] : pxo[2])) + c * 2;
-    }
+    for (int i = 0; i < PX_MAXKS; ++i) { kt[i] = ktab[i * 4]; koff[i] = 0; }
   }
+  bool koff_pending = true;
   // halo DMA: lane -> (pixel inside a piece, 16-byte channel group) -> segment, element offset (see wgrad_tile_kernel)
   const int xl = fdiv(lane, q.xt.d_gpr), xcg = lane - xl * q.xt.gpr;
   int x_si = 0, x_off = 0;
   const bool x_lane = xl < q.xt.ppp && xcg * G < p.ctot8;
   bool x_data = false;
-  {
+  LaneTile LX;
+  LX.xl = xl; LX.lane = x_lane;
+  if (ONESEG) {
+    const int c = xcg * G;
+    x_data = x_lane && c < p.seg[0].c;
+    x_off = (int)__umul24(xl, (int)p.seg[0].sw) + c;
+    LX.sh = (int)p.seg[0].sh; LX.swp = (int)(p.seg[0].sw * q.xt.ppp);
+  } else {
     const int c = xcg * G;
 #pragma unroll
     for (int k = 1; k < CGEN_MAX_SEG; ++k) x_si += (k < p.nseg && c >= p.seg_koff[k]) ? 1 : 0;
@@ -1533,26 +1539,24 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
     const int cs = c - ko;
     x_data = x_lane && cs < sv.c;
     x_off = (int)(xl * sv.sw) + cs;
-  }
-  const int xpieces = q.xt.rows * q.xt.ppr;
-  LaneTile LX;
-  {
-    LX.xl = xl; LX.lane = x_lane; LX.data = x_data;
     LX.sh = (int)p.seg[0].sh; LX.swp = (int)(p.seg[0].sw * q.xt.ppp);
 #pragma unroll
     for (int k = 1; k < CGEN_MAX_SEG; ++k)
       if (x_si == k) { LX.sh = (int)p.seg[k].sh; LX.swp = (int)(p.seg[k].sw * q.xt.ppp); }
   }
+  LX.data = x_data;
+  const int xpieces = q.xt.rows * q.xt.ppr;
   // epilogue: this lane owns pixel (row wave*2 + f, column fr) and channels co_base + pr*32 + fg*8 .. +8
   const int ch0 = co_base + fg * 8;
-  int eo_out[2], eo_aux[2], eo_r1[2], eo_r2[2];  // byte offsets from the tile origin of each tensor
+  const bool has_aux = p.aux.p != nullptr, has_r1 = p.res1.p != nullptr, has_r2 = p.res2.p != nullptr;
+  int eo_out[2], eo_aux[2], eo_r1[2], eo_r2[2];  // byte offsets from the tile origin of each tensor (strides < 2^24)
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const int ry = wave * 2 + f;
-    eo_out[f] = (int)(ry * p.out.sh + fr * p.out.sw + ch0) * 2;
-    eo_aux[f] = (int)(ry * p.aux.sh + fr * p.aux.sw + ch0) * 2;
-    eo_r1[f] = (int)(ry * p.res1.sh + fr * p.res1.sw + ch0) * 2;
-    eo_r2[f] = (int)(ry * p.res2.sh + fr * p.res2.sw + ch0) * 2;
+    eo_out[f] = (int)(__umul24(ry, (int)p.out.sh) + __umul24(fr, (int)p.out.sw) + ch0) * 2;
+    eo_aux[f] = (int)(__umul24(ry, (int)p.aux.sh) + __umul24(fr, (int)p.aux.sw) + ch0) * 2;  // (absent operands: strides are 0)
+    eo_r1[f] = (int)(__umul24(ry, (int)p.res1.sh) + __umul24(fr, (int)p.res1.sw) + ch0) * 2;
+    eo_r2[f] = (int)(__umul24(ry, (int)p.res2.sh) + __umul24(fr, (int)p.res2.sw) + ch0) * 2;
   }
   f32x4 binit[NP][2];
 #pragma unroll
@@ -1560,26 +1564,25 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int co = ch0 + pr * 32 + h * 4;
-      binit[pr][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (p.bias && co + 4 <= p.Co) { const float4 b = *(const float4*)(p.bias + co); binit[pr][h] = (f32x4){b.x, b.y, b.z, b.w}; }  // (Co % 4 == 0: checked on the host)
+      // (Co % 4 == 0: checked on the host); no bias / channels past Co: an unconditional load of zeros, no branch
+      const float4 b = *(const float4*)((p.bias && co + 4 <= p.Co) ? (const void*)(p.bias + co) : (const void*)g_zero16);
+      binit[pr][h] = (f32x4){b.x, b.y, b.z, b.w};
     }
-  const bool has_aux = p.aux.p != nullptr, has_r1 = p.res1.p != nullptr, has_r2 = p.res2.p != nullptr;
   const char* a_base = Wsb + (size_t)fr * q.ldw * 2 + fg * 16;
   const char* x_rows = Xb + (size_t)(wave * 2) * q.xt.rowbytes;
 
+  if (stamp) stamp[5] = __builtin_amdgcn_s_memrealtime();
   for (int t = blockIdx.x; t < q.ntiles; t += gridDim.x) {
     // ---- tile origin: scalar
-    int b = t;
-    const int tx = b % q.tiles_x; b /= q.tiles_x;
-    const int ty = b % q.tiles_y;
-    const int n = b / q.tiles_y;
+    const int b1 = fdiv(t, q.d_tx), tx = t - b1 * q.tiles_x;
+    const int n = fdiv(b1, q.d_ty), ty = b1 - n * q.tiles_y;
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
     {  // halo tile DMA (row pieces)
-      const T* my_org = vptr<T>(p.seg[0], n, y0 - HALO, x0 - HALO);
-      if (p.nseg > 1) {
-        if (x_si == 1) my_org = vptr<T>(p.seg[1], n, y0 - HALO, x0 - HALO);
-        if (x_si == 2) my_org = vptr<T>(p.seg[2], n, y0 - HALO, x0 - HALO);
-        if (x_si == 3) my_org = vptr<T>(p.seg[3], n, y0 - HALO, x0 - HALO);
+      const T* my_org = vptr32<T>(p.seg[0], n, y0 - HALO, x0 - HALO);
+      if (!ONESEG && p.nseg > 1) {
+        if (x_si == 1) my_org = vptr32<T>(p.seg[1], n, y0 - HALO, x0 - HALO);
+        if (x_si == 2) my_org = vptr32<T>(p.seg[2], n, y0 - HALO, x0 - HALO);
+        if (x_si == 3) my_org = vptr32<T>(p.seg[3], n, y0 - HALO, x0 - HALO);
       }
       dma_tile<T>(q.xt, LX, my_org + x_off, Xb, wave, max(0, HALO - y0), min(TILE_H + 2 * HALO, p.H + HALO - y0), max(0, HALO - x0), min(HW, p.W + HALO - x0));
     }
@@ -1588,8 +1591,8 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
     bool pv[2];
     uint4 ea[NP][2], er[NP][2];
     {
-      const char* aux_t = (const char*)vptr<T>(p.aux, n, y0, x0);
-      const char* r1_t = (const char*)vptr<T>(p.res1, n, y0, x0);
+      const char* aux_t = has_aux ? (const char*)vptr32<T>(p.aux, n, y0, x0) : nullptr;
+      const char* r1_t = has_r1 ? (const char*)vptr32<T>(p.res1, n, y0, x0) : nullptr;
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
         pv[f] = colv && y0 + wave * 2 + f < p.H;
@@ -1603,6 +1606,20 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
         }
       }
     }
+    if (koff_pending) {
+      koff_pending = false;
+#pragma unroll
+      for (int i = 0; i < PX_MAXKS; ++i) asm volatile("" : "+v"(kt[i]));  // pins the consumption (and its vmcnt wait) below the DMA issue
+      const int px0 = pix_off(q.xt, 0, fr);
+      const int d01 = KS > 1 ? pix_off(q.xt, 0, fr + 1) - px0 : 0, d02 = KS > 1 ? pix_off(q.xt, 0, fr + 2) - px0 : 0;
+      const int e02 = d02 - 2 * d01;  // offset(dx) = dx * d01 + (dx == 2) * e02: two multiply-adds, no compare/select chain
+#pragma unroll
+      for (int i = 0; i < PX_MAXKS; ++i) {
+        if (KS > 1) koff[i] = (int)__umul24(kt[i] & 3, d01) + (int)__umul24((kt[i] >> 2) & 1, e02) + ((kt[i] >> 3) + px0);
+        else koff[i] = (kt[i] >> 3) + px0;
+      }
+    }
+    if (stamp) stamp[6] = __builtin_amdgcn_s_memrealtime();
     // ---- activation in place on the pieces this wave fetched itself (hipcc waits for the DMAs first), then hand over
     if (p.act != CGEN_ACT_NONE && x_data) {
       for (int pi = wave; pi < xpieces; pi += 4) {
@@ -1610,7 +1627,9 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
         *ptr = act_group<T>(*ptr, p.act);
       }
     }
+    if (stamp) stamp[7] = __builtin_amdgcn_s_memrealtime();
     __syncthreads();
+    if (stamp) stamp[1] = __builtin_amdgcn_s_memrealtime();
 
     // ---- MFMAs: 2 tile rows x NP*32 channels per wave, bias as the initial value
     f32x4 acc[NP][2][2];
@@ -1628,24 +1647,24 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
     }
 #pragma unroll
     for (int i = 1; i < PX_MAXKS; ++i) {
-      if (i < q.nks) {
-        const bf16x8 b0 = *(const bf16x8*)(x_rows + koff[i]);
-        const bf16x8 b1 = *(const bf16x8*)(x_rows + q.xt.rowbytes + koff[i]);
+      if (i >= q.nks) break;  // (a break, not a guard: one scalar compare-and-branch per K-step instead of 15 precomputed masks)
+      const bf16x8 b0 = *(const bf16x8*)(x_rows + koff[i]);
+      const bf16x8 b1 = *(const bf16x8*)(x_rows + q.xt.rowbytes + koff[i]);
 #pragma unroll
-        for (int pr = 0; pr < NP; ++pr)
+      for (int pr = 0; pr < NP; ++pr)
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const bf16x8 aq = *(const bf16x8*)(a_base + (size_t)(pr * 32 + h * 16) * q.ldw * 2 + i * 64);
-            acc[pr][h][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, b0, acc[pr][h][0], 0, 0, 0);
-            acc[pr][h][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, b1, acc[pr][h][1], 0, 0, 0);
-          }
-      }
+        for (int h = 0; h < 2; ++h) {
+          const bf16x8 aq = *(const bf16x8*)(a_base + (size_t)(pr * 32 + h * 16) * q.ldw * 2 + i * 64);
+          acc[pr][h][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, b0, acc[pr][h][0], 0, 0, 0);
+          acc[pr][h][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, b1, acc[pr][h][1], 0, 0, 0);
+        }
     }
 
+    if (stamp) stamp[2] = __builtin_amdgcn_s_memrealtime();
     // ---- epilogue straight from the accumulators: v = acc * act'(aux) + res1 + res2 -> bf16 -> one 16-byte store
     {
-      char* out_t = (char*)vptr<T>(p.out, n, y0, x0);
-      const char* r2_t = (const char*)vptr<T>(p.res2, n, y0, x0);
+      char* out_t = (char*)vptr32<T>(p.out, n, y0, x0);
+      const char* r2_t = has_r2 ? (const char*)vptr32<T>(p.res2, n, y0, x0) : nullptr;
 #pragma unroll
       for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -1687,19 +1706,24 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
         }
     }
     __syncthreads();  // every wave is done reading the tile before the next DMA overwrites it
+    if (stamp) stamp[3] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
+template <int NP, int KS, bool ONESEG>
+static void launch_px_inst2(const ConvP& p, const PxP& q, dim3 grid, size_t lds, hipStream_t st) {
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)conv_px_kernel<NP, KS, ONESEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  hipLaunchKernelGGL((conv_px_kernel<NP, KS, ONESEG>), grid, dim3(256), lds, st, p, q);
+}
 template <int NP>
 static void launch_px_inst(const ConvP& p, const PxP& q, dim3 grid, size_t lds, hipStream_t st) {
   if (p.KS == 3) {
-    static bool once3 = false;
-    if (!once3) { (void)hipFuncSetAttribute((const void*)conv_px_kernel<NP, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once3 = true; }
-    hipLaunchKernelGGL((conv_px_kernel<NP, 3>), grid, dim3(256), lds, st, p, q);
+    if (p.nseg == 1) launch_px_inst2<NP, 3, true>(p, q, grid, lds, st);
+    else launch_px_inst2<NP, 3, false>(p, q, grid, lds, st);
   } else {
-    static bool once1 = false;
-    if (!once1) { (void)hipFuncSetAttribute((const void*)conv_px_kernel<NP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once1 = true; }
-    hipLaunchKernelGGL((conv_px_kernel<NP, 1>), grid, dim3(256), lds, st, p, q);
+    if (p.nseg == 1) launch_px_inst2<NP, 1, true>(p, q, grid, lds, st);
+    else launch_px_inst2<NP, 1, false>(p, q, grid, lds, st);
   }
 }
 
@@ -1724,7 +1748,11 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st) {
     if (p.Co % 4 != 0 || p.out.cpad < c8 || !padded(p.aux) || !padded(p.res1) || !padded(p.res2)) return false;
     q.co8 = c8;
   }
-  if (!fits_i32(p.out, 1, TILE_H, TILE_W) || !fits_i32(p.aux, 1, TILE_H, TILE_W) || !fits_i32(p.res1, 1, TILE_H, TILE_W) || !fits_i32(p.res2, 1, TILE_H, TILE_W)) return false;
+  // the kernel does all its address arithmetic in 32 bits: every view must span less than 2^31 bytes (tile overhang included)
+  for (int sg = 0; sg < p.nseg; ++sg)
+    if (!fits_i32(p.seg[sg], p.N, p.H + TILE_H + 2, p.W + TILE_W + 2)) return false;
+  if (!fits_i32(p.out, p.N, p.H + TILE_H, p.W + TILE_W) || !fits_i32(p.aux, p.N, p.H + TILE_H, p.W + TILE_W) ||
+      !fits_i32(p.res1, p.N, p.H + TILE_H, p.W + TILE_W) || !fits_i32(p.res2, p.N, p.H + TILE_H, p.W + TILE_W)) return false;
   q.xt = mk_pixtile(p.ctot8, 2, TILE_H + 2 * halo, TILE_W + 2 * halo);
   if (q.xt.ppp < 1) return false;
   q.ldw = lds_stride(q.nks * 32, 2);  // <= ceil32(K) + 16 <= krow
@@ -1745,6 +1773,17 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st) {
   if (lds > 150 * 1024) return false;
   q.wpieces = ceil_div(np * 32 * (q.ldw / G), 64);
   q.d_gprw = mk_fastdiv(q.ldw / G); q.d_ctot8 = mk_fastdiv(p.ctot8);
+  q.d_tx = mk_fastdiv(q.tiles_x); q.d_ty = mk_fastdiv(q.tiles_y);
+  for (int i = 0; i < q.nks; ++i)
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const int kidx = i * 32 + g4 * 8;
+      int tap = kidx / p.ctot8;
+      const int c = kidx - tap * p.ctot8;
+      if (tap >= p.taps) tap = p.taps - 1;  // columns past the last tap carry zero weights; keep the address legal
+      const int dy = tap / p.KS, dx = tap - dy * p.KS;
+      q.ktab[i * 4 + g4] = ((dy * q.xt.rowbytes + c * 2) << 3) | ((dx == 2) << 2) | dx;
+    }
+  { const char* e = getenv("CGEN_PX_STAMPS"); q.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
   const int parts = ceil_div(np_all, np);
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 3) per_cu = 3;
@@ -1823,11 +1862,19 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
   }
 
   // ---- per-lane DMA constants (see wgrad_tile_kernel)
+  constexpr bool ONESEG = false;  // (the block below is shared text with conv_px_kernel, which specialises on it)
   const int xl = fdiv(lane, q.xt.d_gpr), xcg = lane - xl * q.xt.gpr;
   int x_si = 0, x_off = 0;
   const bool x_lane = xl < q.xt.ppp && xcg * G < p.ctot8;
   bool x_data = false;
-  {
+  LaneTile LX;
+  LX.xl = xl; LX.lane = x_lane;
+  if (ONESEG) {
+    const int c = xcg * G;
+    x_data = x_lane && c < p.seg[0].c;
+    x_off = (int)__umul24(xl, (int)p.seg[0].sw) + c;
+    LX.sh = (int)p.seg[0].sh; LX.swp = (int)(p.seg[0].sw * q.xt.ppp);
+  } else {
     const int c = xcg * G;
 #pragma unroll
     for (int k = 1; k < CGEN_MAX_SEG; ++k) x_si += (k < p.nseg && c >= p.seg_koff[k]) ? 1 : 0;
@@ -1839,16 +1886,13 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
     const int cs = c - ko;
     x_data = x_lane && cs < sv.c;
     x_off = (int)(xl * sv.sw) + cs;
-  }
-  const int xpieces = q.xt.rows * q.xt.ppr;
-  LaneTile LX;
-  {
-    LX.xl = xl; LX.lane = x_lane; LX.data = x_data;
     LX.sh = (int)p.seg[0].sh; LX.swp = (int)(p.seg[0].sw * q.xt.ppp);
 #pragma unroll
     for (int k = 1; k < CGEN_MAX_SEG; ++k)
       if (x_si == k) { LX.sh = (int)p.seg[k].sh; LX.swp = (int)(p.seg[k].sw * q.xt.ppp); }
   }
+  LX.data = x_data;
+  const int xpieces = q.xt.rows * q.xt.ppr;
   // ---- epilogue lane constants (the host only selects this kernel when every epilogue access is a whole aligned chunk):
   // chunk k of this lane = pixel (row ef[k], column ex[k]) of the tile, channels co_base + ech*8 .. +8
   constexpr int CPP = NTC * 2;  // 16-byte chunks per pixel; divides 64, so a lane's chunk column is the same for every k

@@ -79,6 +79,28 @@ def main():
                 if n:
                     print("   ws stamps(cycles) per tile [issue, wait, act, mfma, reduce+epilogue]: %s" % (
                         [d[k * 5:k * 5 + 5] for k in range((n - 1) // 5)]))
+            if os.environ.get("PXSTAMPS"):
+                # three back-to-back launches, each stamping {entry, tile landed, MFMAs done, exit} per workgroup (100 MHz clock)
+                bufs = [torch.zeros(8 * 8192, dtype=torch.int64, device="cuda") for _ in range(3)]
+                for b in bufs:
+                    os.environ["CGEN_PX_STAMPS"] = hex(b.data_ptr())
+                    eng.conv(site, xs, 1, out=y)
+                del os.environ["CGEN_PX_STAMPS"]
+                torch.cuda.synchronize()
+                vs = [b.view(-1, 8).cpu() for b in bufs]
+                vs = [v[v[:, 0] > 0] for v in vs]
+                if len(vs[0]):
+                    t0 = int(vs[1][:, 0].min())
+                    us = lambda t: (float(t) - t0) / 100.0
+                    v = vs[1]
+                    print("   px stamps (us, launch 2 of 3; %d WGs): prev kernel last exit %.2f | first entry 0 last entry %.2f | landed median %.2f | "
+                          "mfma done median %.2f | exit median %.2f last %.2f | next kernel first entry %.2f ; per-WG median: wait %.2f mfma %.2f epi %.2f"
+                          % (len(v), us(vs[0][:, 3].max()), us(v[:, 0].max()), us(v[:, 1].median()), us(v[:, 2].median()), us(v[:, 3].median()),
+                             us(v[:, 3].max()), us(vs[2][:, 0].min()), float((v[:, 1] - v[:, 0]).median()) / 100, float((v[:, 2] - v[:, 1]).median()) / 100,
+                             float((v[:, 3] - v[:, 2]).median()) / 100))
+                    md = lambda a, b: float((v[:, a] - v[:, b]).median()) / 100
+                    print("      entry->weights issued %.2f ->lane consts %.2f ->tile+epilogue requests issued %.2f ->own DMAs landed+act %.2f ->barrier %.2f"
+                          % (md(4, 0), md(5, 4), md(6, 5), md(7, 6), md(1, 7)))
         if kind in ("wgrad", "all"):
             g = eng.new(N, R, R, Co)
             eng.fill(g, 0.25)
