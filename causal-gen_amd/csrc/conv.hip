@@ -1813,11 +1813,11 @@ struct WsP {
   PixTile xt;
   int tiles_x, tiles_y, ntiles, nk;  // nk = K-steps that carry weights
   int rows_pad, red_bytes, dbg, pad0;
-  FastDiv d_ctot8;
+  FastDiv d_ctot8, d_tx, d_ty;
   unsigned long long* stamps;  // optional (CGEN_WS_STAMPS): per-phase cycle stamps of workgroup 0
 };
 
-template <int NTC, int NKW>
+template <int NTC, int NKW, bool ONESEG>
 __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
   __builtin_amdgcn_s_setprio(3);  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   typedef bf16_t T;
@@ -1845,24 +1845,21 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
       const int ks = wave + 4 * i;
 #pragma unroll
       for (int t = 0; t < NTC; ++t) {
-        const int row = co_base + t * 16 + fr;
-        bf16x8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (__bf16)0.0f;
-        if (ks < q.nk && row < q.rows_pad) v = *(const bf16x8*)((const T*)p.w + (size_t)row * p.krow + ks * 32 + fg * 8);
-        aw[t][i] = v;
+        // unconditional: rows past the image are clamped to its last row (never stored), K-steps past nk read the 32 zero
+        // columns that close every weight row (krow = ceil32(K) + 32)
+        const int row = min(co_base + t * 16 + fr, q.rows_pad - 1);
+        aw[t][i] = *(const bf16x8*)((const T*)p.w + (__umul24(row, p.krow) + min(ks, q.nk) * 32 + fg * 8));
       }
       const int kidx = min(ks, q.nk - 1) * 32 + fg * 8;
       int tap = fdiv(kidx, q.d_ctot8);
       const int c = kidx - tap * p.ctot8;
       tap = tap < TAPS ? tap : TAPS - 1;  // columns past the last tap carry zero weights; keep the address legal
-      const int dy = tap / KS, dx = tap - dy * KS;
+      const int dy = KS == 3 ? (tap * 11) >> 5 : 0, dx = tap - dy * KS;  // (KS in {1, 3}: tap < 9)
       koff[i] = dy * q.xt.rowbytes + (dx == 0 ? pxo[0] : (dx == 1 ? pxo[1] : pxo[2])) + c * 2;
     }
   }
 
   // ---- per-lane DMA constants (see wgrad_tile_kernel)
-  constexpr bool ONESEG = false;  // (the block below is shared text with conv_px_kernel, which specialises on it)
   const int xl = fdiv(lane, q.xt.d_gpr), xcg = lane - xl * q.xt.gpr;
   int x_si = 0, x_off = 0;
   const bool x_lane = xl < q.xt.ppp && xcg * G < p.ctot8;
@@ -1908,10 +1905,10 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
     ef[k] = wave * 2 + (pl >> 4); ex[k] = pl & 15;
     erd[k] = ((ech >> 1) * TILE_H + ef[k]) * 64 + (ech & 1) * 32 + ex[k];  // f32x4 index of the "lo" half in the partial-sum area
     const int c0 = co_base + ech * 8;
-    eo_out[k] = (int)(ef[k] * p.out.sh + ex[k] * p.out.sw + c0) * 2;
-    eo_aux[k] = (int)(ef[k] * p.aux.sh + ex[k] * p.aux.sw + c0) * 2;
-    eo_r1[k] = (int)(ef[k] * p.res1.sh + ex[k] * p.res1.sw + c0) * 2;
-    eo_r2[k] = (int)(ef[k] * p.res2.sh + ex[k] * p.res2.sw + c0) * 2;
+    eo_out[k] = (int)(__umul24(ef[k], (int)p.out.sh) + __umul24(ex[k], (int)p.out.sw) + c0) * 2;  // strides < 2^24
+    eo_aux[k] = (int)(__umul24(ef[k], (int)p.aux.sh) + __umul24(ex[k], (int)p.aux.sw) + c0) * 2;
+    eo_r1[k] = (int)(__umul24(ef[k], (int)p.res1.sh) + __umul24(ex[k], (int)p.res1.sw) + c0) * 2;
+    eo_r2[k] = (int)(__umul24(ef[k], (int)p.res2.sh) + __umul24(ex[k], (int)p.res2.sw) + c0) * 2;
   }
   const bool has_aux = p.aux.p != nullptr, has_r1 = p.res1.p != nullptr, has_r2 = p.res2.p != nullptr;
   const bool stamp = q.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
@@ -1920,18 +1917,16 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
   WS_STAMP();
 
   for (int t = blockIdx.x; t < q.ntiles; t += gridDim.x) {
-    int b = t;
-    const int tx = b % q.tiles_x; b /= q.tiles_x;
-    const int ty = b % q.tiles_y;
-    const int n = b / q.tiles_y;
+    const int b1 = fdiv(t, q.d_tx), tx = t - b1 * q.tiles_x;
+    const int n = fdiv(b1, q.d_ty), ty = b1 - n * q.tiles_y;
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
     // ---- halo tile DMA (row pieces)
     if (!(q.dbg & 1)) {
-      const T* my_org = vptr<T>(p.seg[0], n, y0 - HALO, x0 - HALO);
-      if (p.nseg > 1) {
-        if (x_si == 1) my_org = vptr<T>(p.seg[1], n, y0 - HALO, x0 - HALO);
-        if (x_si == 2) my_org = vptr<T>(p.seg[2], n, y0 - HALO, x0 - HALO);
-        if (x_si == 3) my_org = vptr<T>(p.seg[3], n, y0 - HALO, x0 - HALO);
+      const T* my_org = vptr32<T>(p.seg[0], n, y0 - HALO, x0 - HALO);
+      if (!ONESEG && p.nseg > 1) {
+        if (x_si == 1) my_org = vptr32<T>(p.seg[1], n, y0 - HALO, x0 - HALO);
+        if (x_si == 2) my_org = vptr32<T>(p.seg[2], n, y0 - HALO, x0 - HALO);
+        if (x_si == 3) my_org = vptr32<T>(p.seg[3], n, y0 - HALO, x0 - HALO);
       }
       dma_tile<T>(q.xt, LX, my_org + x_off, Xb, wave, max(0, HALO - y0), min(TILE_H + 2 * HALO, p.H + HALO - y0), max(0, HALO - x0), min(HW, p.W + HALO - x0));
     }
@@ -1939,9 +1934,9 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
     uint4 ea[NTC], er1[NTC], er2[NTC];
     bool ev[NTC];
     {
-      const char* aux_t = (const char*)vptr<T>(p.aux, n, y0, x0);
-      const char* r1_t = (const char*)vptr<T>(p.res1, n, y0, x0);
-      const char* r2_t = (const char*)vptr<T>(p.res2, n, y0, x0);
+      const char* aux_t = (const char*)vptr32<T>(p.aux, n, y0, x0);
+      const char* r1_t = (const char*)vptr32<T>(p.res1, n, y0, x0);
+      const char* r2_t = (const char*)vptr32<T>(p.res2, n, y0, x0);
 #pragma unroll
       for (int k = 0; k < NTC; ++k) {
         ev[k] = chv && y0 + ef[k] < p.H && x0 + ex[k] < p.W && !(q.dbg & 8);
@@ -1995,7 +1990,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
     {
       // each wave finalises 2 tile rows; a lane owns an 8-channel (16-byte) chunk of one pixel so that consecutive lanes
       // cover consecutive chunks of a pixel row (coalesced epilogue I/O).  Fixed summation order: deterministic.
-      char* out_t = (char*)vptr<T>(p.out, n, y0, x0);
+      char* out_t = (char*)vptr32<T>(p.out, n, y0, x0);
 #pragma unroll
       for (int k = 0; k < NTC; ++k) {
         const f32x4* rd = (const f32x4*)smem + erd[k];
@@ -2048,11 +2043,16 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
 #undef WS_STAMP
 }
 
+template <int NTC, int NKW, bool ONESEG>
+static void launch_ws_inst2(const ConvP& p, const WsP& q, int grid_x, int grid_y, size_t lds, hipStream_t st) {
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)conv_ws_kernel<NTC, NKW, ONESEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  hipLaunchKernelGGL((conv_ws_kernel<NTC, NKW, ONESEG>), dim3(grid_x, grid_y), dim3(256), lds, st, p, q);
+}
 template <int NTC, int NKW>
 static void launch_ws_inst(const ConvP& p, const WsP& q, int grid_x, int grid_y, size_t lds, hipStream_t st) {
-  static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)conv_ws_kernel<NTC, NKW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-  hipLaunchKernelGGL((conv_ws_kernel<NTC, NKW>), dim3(grid_x, grid_y), dim3(256), lds, st, p, q);
+  if (p.nseg == 1) launch_ws_inst2<NTC, NKW, true>(p, q, grid_x, grid_y, lds, st);
+  else launch_ws_inst2<NTC, NKW, false>(p, q, grid_x, grid_y, lds, st);
 }
 
 static bool launch_conv_ws(const ConvP& p, hipStream_t st) {
@@ -2069,19 +2069,24 @@ static bool launch_conv_ws(const ConvP& p, hipStream_t st) {
   q.xt = mk_pixtile(p.ctot8, 2, TILE_H + 2 * halo, TILE_W + 2 * halo);
   if (q.xt.ppp < 1) return false;
   if (!p.epi_vec16 || p.Co % 8 != 0) return false;  // the kernel only has the whole-chunk epilogue
+  // 32-bit address arithmetic in the kernel: every view must span less than 2^31 bytes (tile overhang included)
+  for (int sg = 0; sg < p.nseg; ++sg)
+    if (!fits_i32(p.seg[sg], p.N, p.H + TILE_H + 2, p.W + TILE_W + 2)) return false;
+  if (!fits_i32(p.out, p.N, p.H + TILE_H, p.W + TILE_W) || !fits_i32(p.aux, p.N, p.H + TILE_H, p.W + TILE_W) ||
+      !fits_i32(p.res1, p.N, p.H + TILE_H, p.W + TILE_W) || !fits_i32(p.res2, p.N, p.H + TILE_H, p.W + TILE_W)) return false;
   q.red_bytes = 4 * ntc * TILE_H * 1024;
   const size_t lds = (size_t)(q.xt.bytes > q.red_bytes ? q.xt.bytes : q.red_bytes);
   if (lds > 78 * 1024) return false;             // keep two workgroups per CU
   q.tiles_x = ceil_div(p.W, TILE_W); q.tiles_y = ceil_div(p.H, TILE_H);
   q.ntiles = p.N * q.tiles_x * q.tiles_y;
   q.rows_pad = pad_to(p.Co, 16);
-  q.d_ctot8 = mk_fastdiv(p.ctot8);
+  q.d_ctot8 = mk_fastdiv(p.ctot8); q.d_tx = mk_fastdiv(q.tiles_x); q.d_ty = mk_fastdiv(q.tiles_y);
   { const char* e = getenv("CGEN_WS_DBG"); q.dbg = e ? atoi(e) : 0; }
   { const char* e = getenv("CGEN_WS_STAMPS"); q.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
   const int grid_y = ceil_div(p.Co, ntc * 16);
   // measured on MI355X: the register-resident weights pay off when every wave owns >= 3 K-steps and the halo tile is
   // re-staged for at most nkw/2 output-channel tiles; short-K / wide-output (expanding) convs stay on the tile kernel
-  if (!getenv("CGEN_CONV_FORCE_WS") && (nkw < 3 || nkw < 2 * grid_y)) return false;
+  if (nkw < 3 || (!getenv("CGEN_CONV_FORCE_WS") && nkw < 2 * grid_y)) return false;
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 4) per_cu = 4;
   if (per_cu < 1) per_cu = 1;
@@ -2090,7 +2095,7 @@ static bool launch_conv_ws(const ConvP& p, hipStream_t st) {
   if (grid_x > q.ntiles) grid_x = q.ntiles;
 #define WS_CASE(NKW) case NKW: if (ntc == 1) launch_ws_inst<1, NKW>(p, q, grid_x, grid_y, lds, st); else launch_ws_inst<2, NKW>(p, q, grid_x, grid_y, lds, st); break;
   switch (bk) {
-    WS_CASE(1) WS_CASE(2) WS_CASE(3) WS_CASE(4) WS_CASE(5) WS_CASE(6) WS_CASE(8) WS_CASE(10) WS_CASE(12)
+    WS_CASE(3) WS_CASE(4) WS_CASE(5) WS_CASE(6) WS_CASE(8) WS_CASE(10) WS_CASE(12)
     default: return false;
   }
 #undef WS_CASE
