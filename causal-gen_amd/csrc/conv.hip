@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -29,6 +30,7 @@ namespace cgen {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // Division by a run-time constant without v_rcp/loops: q = umulhi(n, mul) >> shift, exact for 0 <= n < 2^31
 // (round-up method: mul = ceil(2^(32+shift) / d)).  Built on the host, used in the per-lane address generation.
@@ -709,9 +711,11 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st);  // lean persistent 
 // dealt round-robin to the 4 waves of a workgroup; each wave loads its MFMA operands straight from global memory (16 B per
 // lane: a weight-image row slice and an im2col slice of one pixel) with four K-steps in flight, and the four partial sums
 // are added through LDS in a fixed order (deterministic).  One workgroup = 16*SP_NCO output channels x 32 pixels.
-template <int KS, int SP_NCO, int KU>
-__global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, FastDiv d_ctot8, FastDiv d_hw, FastDiv d_w) {
-  __builtin_amdgcn_s_setprio(3);  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
+template <int KS, int SP_NCO, int KU, bool ONESEG>
+__global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, FastDiv d_ctot8, FastDiv d_hw, FastDiv d_w, unsigned long long* stamps) {
+  __builtin_amdgcn_s_setprio(3);
+  unsigned long long* stamp = (stamps != nullptr && threadIdx.x == 0) ? stamps + 8 * (blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
+  if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   typedef bf16_t T;
   constexpr int HALO = KS / 2, TAPS = KS * KS;  // KU K-steps are issued together per wave
   __shared__ __attribute__((aligned(16))) float red[4 * SP_NCO * 2 * 256];
@@ -731,67 +735,103 @@ __global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, Fast
     py[f] = fdiv(r, d_w);
     px[f] = r - py[f] * p.W;
   }
+  // 32-bit element offsets (the host checked that every view spans < 2^31 bytes): this lane's two pixels in every segment,
+  // and its weight rows (rows past the image are clamped: their outputs are never stored)
+  int poff[CGEN_MAX_SEG][2];
+#pragma unroll
+  for (int u = 0; u < CGEN_MAX_SEG; ++u)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+      poff[u][f] = (ONESEG && u > 0) ? 0 : pn[f] * (int)p.seg[u].sn + py[f] * (int)p.seg[u].sh + px[f] * (int)p.seg[u].sw;
   const int rows_pad = (p.Co + 15) & ~15;
+  int woff[SP_NCO];
+#pragma unroll
+  for (int t = 0; t < SP_NCO; ++t) woff[t] = __umul24(min(co_base + t * 16 + fr, rows_pad - 1), p.krow) + fg * 8;
   f32x4 acc[SP_NCO][2];
 #pragma unroll
   for (int t = 0; t < SP_NCO; ++t)
 #pragma unroll
     for (int f = 0; f < 2; ++f) acc[t][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // K-step ks = k0 + wave + 4*j ; image column = tap0*ctot8 + ks*32 + fg*8 (1x1 images only ever see their centre tap)
+  // K-step ks = k0 + wave + 4*j ; image column = tap0*ctot8 + ks*32 + fg*8 (1x1 images only ever see their centre tap).
+  // The loop is instruction-issue bound (~150 instructions per K-step for 4 MFMAs before this form), so:
+  //   * it is instantiated per activation (the dispatch on p.act happens once, outside);
+  //   * operands come through BUFFER loads: the weight address is (per-lane row offset) + (scalar column offset) with no
+  //     vector arithmetic at all, and an out-of-image / out-of-range activation group is a lane whose offset lies past
+  //     num_records -- the hardware returns zeros, no pointer select, no branch (one-segment inputs; concatenated inputs
+  //     pick their segment per lane and keep the pointer form).
   const int kcol0 = p.tap0 * p.ctot8;
-  for (int kb = wave; kb < nks; kb += 4 * KU) {
-    uint4 aq[KU][SP_NCO], bq[KU][2];
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.seg[0].p, 0, 0x7ffffff0, 0x00020000);
+  if (stamp) stamp[4] = __builtin_amdgcn_s_memrealtime();
+  auto kloop = [&](auto act_c) {
+    constexpr int ACT = decltype(act_c)::value;
+    for (int kb = wave; kb < nks; kb += 4 * KU) {
+      u32x4 aq[KU][SP_NCO], bq[KU][2];
 #pragma unroll
-    for (int j = 0; j < KU; ++j) {
-      const int ks = kb + 4 * j;
-      const bool kin = ks < nks;
-      const int k = kcol0 + ks * 32 + fg * 8;
-      const int tap = fdiv(k, d_ctot8), c = k - tap * p.ctot8;
-      const int dy = tap / KS - HALO, dx = tap % KS - HALO;
-      int sidx = 0;
+      for (int j = 0; j < KU; ++j) {
+        const int ks = min(kb + 4 * j, nks);  // K-steps past the end read the 32 zero columns that close every weight row
+        const int kc = kcol0 + ks * 32;
 #pragma unroll
-      for (int u = 1; u < CGEN_MAX_SEG; ++u) sidx += (u < p.nseg && c >= p.seg_koff[u]) ? 1 : 0;
-      View sv = p.seg[0];
-      int koff = p.seg_koff[0];
+        for (int t = 0; t < SP_NCO; ++t) aq[j][t] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, woff[t] * 2, kc * 2, 0);
+        const int k = kc + fg * 8;
+        const int tap = fdiv(k, d_ctot8), c = k - tap * p.ctot8;
+        const int dy = (KS == 3 ? (min(tap, 8) * 11) >> 5 : 0), dx = (KS == 3 ? min(tap, 8) - dy * 3 : 0);
+        if (ONESEG) {
+          const bool kv = tap < TAPS && c < p.seg[0].c;
+          const int delta = __mul24(dy - HALO, (int)p.seg[0].sh) + __mul24(dx - HALO, (int)p.seg[0].sw) + c;  // strides < 2^24 (dma_clean)
 #pragma unroll
-      for (int u = 1; u < CGEN_MAX_SEG; ++u)
-        if (sidx == u) { sv = p.seg[u]; koff = p.seg_koff[u]; }
-      const int cs = c - koff;
-      const bool kv = kin && tap < TAPS && cs < sv.c;
+          for (int f = 0; f < 2; ++f) {
+            const int yy = py[f] + dy - HALO, xx = px[f] + dx - HALO;
+            const bool ok = kv && pv[f] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            bq[j][f] = __builtin_amdgcn_raw_buffer_load_b128(x_rs, ok ? (poff[0][f] + delta) * 2 : 0x7fffffff, 0, 0);
+          }
+        } else {
+          const T* sbase = (const T*)p.seg[0].p;
+          int cs = c, segc = p.seg[0].c, sh = (int)p.seg[0].sh, sw = (int)p.seg[0].sw, o0 = poff[0][0], o1 = poff[0][1];
 #pragma unroll
-      for (int t = 0; t < SP_NCO; ++t) {
-        const int row = co_base + t * 16 + fr;
-        const uint4* src = (kin && row < rows_pad) ? (const uint4*)((const T*)p.w + (size_t)row * p.krow + k) : (const uint4*)g_zero16;
-        aq[j][t] = *src;
+          for (int u = 1; u < CGEN_MAX_SEG; ++u)
+            if (u < p.nseg && c >= p.seg_koff[u]) {
+              sbase = (const T*)p.seg[u].p; cs = c - p.seg_koff[u]; segc = p.seg[u].c; sh = (int)p.seg[u].sh; sw = (int)p.seg[u].sw;
+              o0 = poff[u][0]; o1 = poff[u][1];
+            }
+          const bool kv = tap < TAPS && cs < segc;
+          const int delta = __mul24(dy - HALO, sh) + __mul24(dx - HALO, sw) + cs;
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            const int yy = py[f] + dy - HALO, xx = px[f] + dx - HALO;
+            const bool ok = kv && pv[f] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            const u32x4* src = ok ? (const u32x4*)(sbase + ((f == 0 ? o0 : o1) + delta)) : (const u32x4*)g_zero16;
+            bq[j][f] = *src;  // unconditional load from a selected address (no early wait)
+          }
+        }
       }
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        const int yy = py[f] + dy, xx = px[f] + dx;
-        const bool ok = kv && pv[f] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-        const uint4* src = ok ? (const uint4*)(vptr<T>(sv, pn[f], yy, xx) + cs) : (const uint4*)g_zero16;
-        bq[j][f] = *src;  // unconditional load from a selected address (no branch, no early wait)
-      }
-    }
+      for (int j = 0; j < KU; ++j) {
+        union { u32x4 u; uint4 q; bf16x8 v; } a0, b0;
 #pragma unroll
-    for (int j = 0; j < KU; ++j) {
-      union { uint4 u; bf16x8 v; } a0, b0;
+        for (int f = 0; f < 2; ++f) {
+          b0.u = bq[j][f];
+          if (ACT != CGEN_ACT_NONE) b0.q = act_group<T>(b0.q, ACT);
 #pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        b0.u = p.act != CGEN_ACT_NONE ? act_group<T>(bq[j][f], p.act) : bq[j][f];
-#pragma unroll
-        for (int t = 0; t < SP_NCO; ++t) {
-          a0.u = aq[j][t];
-          acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v, b0.v, acc[t][f], 0, 0, 0);
+          for (int t = 0; t < SP_NCO; ++t) {
+            a0.u = aq[j][t];
+            acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v, b0.v, acc[t][f], 0, 0, 0);
+          }
         }
       }
     }
-  }
+  };
+  if (p.act == CGEN_ACT_NONE) kloop(std::integral_constant<int, CGEN_ACT_NONE>{});
+  else if (p.act == CGEN_ACT_RELU) kloop(std::integral_constant<int, CGEN_ACT_RELU>{});
+  else kloop(std::integral_constant<int, CGEN_ACT_GELU>{});
+  if (stamp) stamp[1] = __builtin_amdgcn_s_memrealtime();
   // ---- fixed-order reduction over the four waves, then the generic fused epilogue
 #pragma unroll
   for (int t = 0; t < SP_NCO; ++t)
 #pragma unroll
     for (int f = 0; f < 2; ++f) *(f32x4*)(red + ((wave * SP_NCO + t) * 2 + f) * 256 + lane * 4) = acc[t][f];
   __syncthreads();
+  if (stamp) stamp[2] = __builtin_amdgcn_s_memrealtime();
   // the SP_NCO * 2 fragments are finalised round-robin by the four waves
   for (int fi = wave; fi < SP_NCO * 2; fi += 4) {
     const int t = fi >> 1, f = fi & 1;
@@ -806,6 +846,14 @@ __global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, Fast
     const bool v2 = f == 0 ? pv[0] : pv[1];
     if (v2) conv_epilogue<T>(p, v, n2, y2, x2, co_base + t * 16 + fg * 4);
   }
+  if (stamp) stamp[3] = __builtin_amdgcn_s_memrealtime();
+}
+
+// every element offset of the view (extent n x h x w) fits 32-bit byte arithmetic
+static inline bool fits_i32(const View& v, int n, int h, int w) {
+  if (!v.p) return true;
+  const int64_t ext = (int64_t)n * v.sn + (int64_t)h * v.sh + (int64_t)w * v.sw + v.c;
+  return ext * 2 < ((int64_t)1 << 31);
 }
 
 static bool launch_conv_smallp(const ConvP& p, hipStream_t st) {
@@ -814,12 +862,24 @@ static bool launch_conv_smallp(const ConvP& p, hipStream_t st) {
   if (!p.dma_ok) return false;        // ragged channel counts must be zero padded to 8 (cpad), as for the tiled kernels
   const int ntap = p.tap1 - p.tap0;
   const int nks = ceil_div(ntap * p.ctot8, 32);
-  constexpr int NCO = 2, KU = 4;  // measured on MI355X: 1 / 2 output fragments and 2 / 4 K-steps in flight are equivalent, more is slower
+  // measured on MI355X: 1 / 2 output fragments and 2 / 4 K-steps in flight are equivalent, 6 / 8 are slower.  The K loop's time
+  // does not depend on the number of workgroups (4.2 us for 12 K-steps per wave from batch 4 to 32) nor on its instruction
+  // count (150 -> 60 per K-step changed nothing): it is ~22 ns per 1-KiB load instruction per CU -- every load touches 16
+  // half-used cache lines -- plus ~0.6 us latency per round of KU K-steps
+  constexpr int NCO = 2, KU = 4;
   dim3 grid(ceil_div(p.P, 32), ceil_div(p.Co, NCO * 16));
   const FastDiv d1 = mk_fastdiv(p.ctot8), d2 = mk_fastdiv(p.H * p.W), d3 = mk_fastdiv(p.W);
-  if (p.KS == 1) hipLaunchKernelGGL((conv_smallp_kernel<1, NCO, KU>), grid, dim3(256), 0, st, p, nks, d1, d2, d3);
-  else if (p.KS == 3) hipLaunchKernelGGL((conv_smallp_kernel<3, NCO, KU>), grid, dim3(256), 0, st, p, nks, d1, d2, d3);
+  // 32-bit address arithmetic in the kernel
+  for (int sg = 0; sg < p.nseg; ++sg)
+    if (!fits_i32(p.seg[sg], p.N, p.H + 2, p.W + 2)) return false;
+  unsigned long long* stamps = nullptr;
+  { const char* e = getenv("CGEN_PX_STAMPS"); stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+#define SP_LAUNCH(KS_, KU_) do { if (p.nseg == 1) hipLaunchKernelGGL((conv_smallp_kernel<KS_, NCO, KU_, true>), grid, dim3(256), 0, st, p, nks, d1, d2, d3, stamps); \
+    else hipLaunchKernelGGL((conv_smallp_kernel<KS_, NCO, KU_, false>), grid, dim3(256), 0, st, p, nks, d1, d2, d3, stamps); } while (0)
+  if (p.KS == 1) SP_LAUNCH(1, KU);
+  else if (p.KS == 3) SP_LAUNCH(3, KU);
   else return false;
+#undef SP_LAUNCH
   return true;
 }
 
@@ -1727,11 +1787,6 @@ static void launch_px_inst(const ConvP& p, const PxP& q, dim3 grid, size_t lds, 
   }
 }
 
-static inline bool fits_i32(const View& v, int n, int h, int w) {
-  if (!v.p) return true;
-  const int64_t ext = (int64_t)n * v.sn + (int64_t)h * v.sh + (int64_t)w * v.sw + v.c;
-  return ext * 2 < ((int64_t)1 << 31);
-}
 
 static bool launch_conv_px(const ConvP& p, hipStream_t st) {
   const int G = 8, halo = p.KS / 2;

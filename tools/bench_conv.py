@@ -22,6 +22,9 @@ SHAPES = [  # (N, res, seg channels, Co, ks)   ukbb192 trunk shapes at batch 32
 
 
 def main():
+    global SHAPES
+    if os.environ.get("NB"):
+        SHAPES = [(int(os.environ["NB"]),) + sh[1:] for sh in SHAPES]
     dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
     kind = sys.argv[2] if len(sys.argv) > 2 else "fwd"
     iters = int(os.environ.get("ITERS", "20"))
@@ -99,8 +102,11 @@ def main():
                              us(v[:, 3].max()), us(vs[2][:, 0].min()), float((v[:, 1] - v[:, 0]).median()) / 100, float((v[:, 2] - v[:, 1]).median()) / 100,
                              float((v[:, 3] - v[:, 2]).median()) / 100))
                     md = lambda a, b: float((v[:, a] - v[:, b]).median()) / 100
-                    print("      entry->weights issued %.2f ->lane consts %.2f ->tile+epilogue requests issued %.2f ->own DMAs landed+act %.2f ->barrier %.2f"
-                          % (md(4, 0), md(5, 4), md(6, 5), md(7, 6), md(1, 7)))
+                    if int(v[0, 5]) == 0:
+                        print("      (smallp) entry->K loop %.2f K loop %.2f barrier %.2f reduce+epilogue %.2f" % (md(4, 0), md(1, 4), md(2, 1), md(3, 2)))
+                    else:
+                        print("      entry->weights issued %.2f ->lane consts %.2f ->tile+epilogue requests issued %.2f ->own DMAs landed+act %.2f ->barrier %.2f"
+                              % (md(4, 0), md(5, 4), md(6, 5), md(7, 6), md(1, 7)))
         if kind in ("wgrad", "all"):
             g = eng.new(N, R, R, Co)
             eng.fill(g, 0.25)
