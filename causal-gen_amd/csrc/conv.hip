@@ -176,8 +176,9 @@ __device__ __forceinline__ void epi8_finish(const ConvP& p, float (&v)[8], const
   if (p.aux.p) {
     t.v4 = l.a;
     if (p.dact == CGEN_ACT_GELU) {
+      const F8 gp = gelu8_bwd_bf16(l.a);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= gelu_bwd_slow(bf2f(t.e[e]));
+      for (int e = 0; e < 8; ++e) v[e] *= gp.v[e];
     } else if (p.dact == CGEN_ACT_RELU) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = bf2f(t.e[e]) > 0.f ? v[e] : 0.f;
@@ -223,8 +224,14 @@ __device__ __forceinline__ void conv_epilogue8_bf16(const ConvP& p, float (&v)[8
     Pack<T, 8> t;
     if (aptr) {
       t.v4 = *(const uint4*)aptr;
+      if (p.dact == CGEN_ACT_GELU) {
+        const F8 gp = gelu8_bwd_bf16(t.v4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] *= act_bwd(p.dact, bf2f(t.e[e]));
+        for (int e = 0; e < 8; ++e) v[e] *= gp.v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= act_bwd(p.dact, bf2f(t.e[e]));
+      }
     }
     if (r1) {
       t.v4 = *(const uint4*)r1;
@@ -454,9 +461,7 @@ __device__ __forceinline__ uint4 act_group(uint4 v, int act) {
       return tv.v4;
     }
     if (act == CGEN_ACT_GELU) {
-#pragma unroll
-      for (int e = 0; e < G; ++e) tv.e[e] = Elem<T>::to(gelu_fwd_slow(Elem<T>::ld(&tv.e[e])));
-      return tv.v4;
+      return gelu8_fwd_bf16(v);
     }
     return v;
   }
@@ -1742,11 +1747,9 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
                 v[2 * e + 1] = bf_hi(w[e]) > 0.f ? v[2 * e + 1] : 0.f;
               }
             } else if (p.dact == CGEN_ACT_GELU) {
+              const F8 gp = gelu8_bwd_bf16(make_uint4(w[0], w[1], w[2], w[3]));
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v[2 * e] *= gelu_bwd_slow(bf_lo(w[e]));
-                v[2 * e + 1] *= gelu_bwd_slow(bf_hi(w[e]));
-              }
+              for (int e = 0; e < 8; ++e) v[e] *= gp.v[e];
             }
           }
           if (has_r1) {
@@ -2068,11 +2071,9 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
                 v[2 * e + 1] = bf_hi(w[e]) > 0.f ? v[2 * e + 1] : 0.f;
               }
             } else if (p.dact == CGEN_ACT_GELU) {
+              const F8 gp = gelu8_bwd_bf16(make_uint4(w[0], w[1], w[2], w[3]));
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                v[2 * e] *= gelu_bwd_slow(bf_lo(w[e]));
-                v[2 * e + 1] *= gelu_bwd_slow(bf_hi(w[e]));
-              }
+              for (int e = 0; e < 8; ++e) v[e] *= gp.v[e];
             }
           }
           if (has_r1) {
