@@ -1196,6 +1196,7 @@ struct Wg2P {
   int dbg;        // ablation mask (CGEN_WG2_DBG): 1 skip DMA, 2 skip activation pass, 4 skip MFMA loop
   unsigned long long* stamps;  // optional (CGEN_WG2_STAMPS): per-phase cycle stamps of workgroup 0
   PixTile xt, gt;
+  FastDiv d_tx, d_ty;
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -1278,19 +1279,17 @@ __device__ __forceinline__ void wgrad_tile_body(const Wg2P& p, const int bid_x, 
     LG.sh = (int)p.gout.sh; LG.swp = (int)(p.gout.sw * p.gt.ppp);
   }
   auto issue_tile = [&](int t) {
-    int b = t;
-    const int tx = b % p.tiles_x; b /= p.tiles_x;
-    const int ty = b % p.tiles_y;
-    const int n = b / p.tiles_y;
+    const int b1 = fdiv(t, p.d_tx), tx = t - b1 * p.tiles_x;
+    const int n = fdiv(b1, p.d_ty), ty = b1 - n * p.tiles_y;
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
-    const T* my_org = vptr<T>(p.seg[0], n, y0 - HALO, x0 - HALO);  // this lane's segment
+    const T* my_org = vptr32<T>(p.seg[0], n, y0 - HALO, x0 - HALO);  // this lane's segment
     if (p.nseg > 1) {
-      if (x_si == 1) my_org = vptr<T>(p.seg[1], n, y0 - HALO, x0 - HALO);
-      if (x_si == 2) my_org = vptr<T>(p.seg[2], n, y0 - HALO, x0 - HALO);
-      if (x_si == 3) my_org = vptr<T>(p.seg[3], n, y0 - HALO, x0 - HALO);
+      if (x_si == 1) my_org = vptr32<T>(p.seg[1], n, y0 - HALO, x0 - HALO);
+      if (x_si == 2) my_org = vptr32<T>(p.seg[2], n, y0 - HALO, x0 - HALO);
+      if (x_si == 3) my_org = vptr32<T>(p.seg[3], n, y0 - HALO, x0 - HALO);
     }
     dma_tile<T>(p.xt, LX, my_org + x_off, Xb, wave, max(0, HALO - y0), min(HH, p.H + HALO - y0), max(0, HALO - x0), min(HW, p.W + HALO - x0));
-    dma_tile<T>(p.gt, LG, vptr<T>(p.gout, n, y0, x0) + g_off, Gb, wave, 0, min(TILE_H, p.H - y0), 0, min(TILE_W, p.W - x0));
+    dma_tile<T>(p.gt, LG, vptr32<T>(p.gout, n, y0, x0) + g_off, Gb, wave, 0, min(TILE_H, p.H - y0), 0, min(TILE_W, p.W - x0));
   };
   // in-place activation of the staged halo tile: every lane re-visits the groups it DMA'd (same piece mapping)
   auto act_pass = [&]() {
@@ -2338,6 +2337,14 @@ static bool wgrad_tiled_ok(const cgen_wgrad_args* a, Wg2Geom& g) {
     if (!dma_clean(a->seg[s], 2)) return false;
     segc[s] = a->seg[s].c;
   }
+  // the kernel does its address arithmetic in 32 bits: every view must span less than 2^31 bytes (tile overhang included)
+  auto fits = [&](const cgen_view& v) {
+    const int64_t ext = (int64_t)a->n * v.sn + (int64_t)(a->h + TILE_H + 2) * v.sh + (int64_t)(a->w + TILE_W + 2) * v.sw + v.c;
+    return ext * 2 < ((int64_t)1 << 31);
+  };
+  if (!fits(a->gout)) return false;
+  for (int s = 0; s < a->nseg; ++s)
+    if (!fits(a->seg[s])) return false;
   return wgrad2_geometry(a->n, a->h, a->w, a->gout.c, ctot8_of(segc, a->nseg), a->ks, g);
 }
 
@@ -2373,6 +2380,7 @@ static bool build_wg2(const cgen_wgrad_args* a, Wg2P& q, Wg2Geom& g) {
   q.pw = a->partial_w; q.pb = a->partial_b;
   q.tiles_x = g.tiles_x; q.tiles_y = g.tiles_y; q.ntiles = g.ntiles; q.nsplit = g.nsplit; q.tiles_per_split = g.tps;
   q.cwin = g.cwin; q.cog = g.ncf * 16; q.xt = g.xt; q.gt = g.gt;
+  q.d_tx = mk_fastdiv(g.tiles_x); q.d_ty = mk_fastdiv(g.tiles_y);
   return true;
 }
 
