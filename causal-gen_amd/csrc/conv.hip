@@ -2117,7 +2117,7 @@ static bool launch_conv_ws(const ConvP& p, hipStream_t st) {
   const int ntc = p.Co <= 16 ? 1 : 2;
   q.nk = ceil_div(p.taps * p.ctot8, 32);
   const int nkw = ceil_div(q.nk, 4);
-  static const int buckets[] = {1, 2, 3, 4, 5, 6, 8, 10, 12};
+  static const int buckets[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
   int bk = -1;
   for (int b : buckets) if (b >= nkw) { bk = b; break; }
   if (bk < 0) return false;                      // K too long for the register-resident weights: multi-pass kernel
@@ -2150,7 +2150,7 @@ static bool launch_conv_ws(const ConvP& p, hipStream_t st) {
   if (grid_x > q.ntiles) grid_x = q.ntiles;
 #define WS_CASE(NKW) case NKW: if (ntc == 1) launch_ws_inst<1, NKW>(p, q, grid_x, grid_y, lds, st); else launch_ws_inst<2, NKW>(p, q, grid_x, grid_y, lds, st); break;
   switch (bk) {
-    WS_CASE(3) WS_CASE(4) WS_CASE(5) WS_CASE(6) WS_CASE(8) WS_CASE(10) WS_CASE(12)
+    WS_CASE(3) WS_CASE(4) WS_CASE(5) WS_CASE(6) WS_CASE(8) WS_CASE(10) WS_CASE(12) WS_CASE(16)
     default: return false;
   }
 #undef WS_CASE
