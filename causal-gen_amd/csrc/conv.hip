@@ -2114,9 +2114,9 @@ static bool launch_conv_ws(const ConvP& p, hipStream_t st) {
   WsP q;
   memset(&q, 0, sizeof(q));
   const int halo = p.KS / 2;
-  const int ntc = p.Co <= 16 ? 1 : 2;
   q.nk = ceil_div(p.taps * p.ctot8, 32);
   const int nkw = ceil_div(q.nk, 4);
+  const int ntc = p.Co <= 16 ? 1 : 2;
   static const int buckets[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
   int bk = -1;
   for (int b : buckets) if (b >= nkw) { bk = b; break; }
@@ -2131,7 +2131,8 @@ static bool launch_conv_ws(const ConvP& p, hipStream_t st) {
       !fits_i32(p.res1, p.N, p.H + TILE_H, p.W + TILE_W) || !fits_i32(p.res2, p.N, p.H + TILE_H, p.W + TILE_W)) return false;
   q.red_bytes = 4 * ntc * TILE_H * 1024;
   const size_t lds = (size_t)(q.xt.bytes > q.red_bytes ? q.xt.bytes : q.red_bytes);
-  if (lds > 78 * 1024) return false;             // keep two workgroups per CU
+  static const int ws_maxlds = [] { const char* e = getenv("CGEN_WS_MAXLDS"); return (e ? atoi(e) : 100) * 1024; }();
+  if (lds > (size_t)ws_maxlds) return false;     // (<= 78 KB keeps two workgroups per CU; the 196->24 posterior-in conv at 48x48 needs 90 KB and still beats the tile kernel 47 vs 70 us)
   q.tiles_x = ceil_div(p.W, TILE_W); q.tiles_y = ceil_div(p.H, TILE_H);
   q.ntiles = p.N * q.tiles_x * q.tiles_y;
   q.rows_pad = pad_to(p.Co, 16);

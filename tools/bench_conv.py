@@ -17,7 +17,7 @@ SHAPES = [  # (N, res, seg channels, Co, ks)   ukbb192 trunk shapes at batch 32
     (32, 192, [32], 8, 3), (32, 192, [8], 32, 3), (32, 96, [64], 16, 3), (32, 96, [16], 64, 3),
     (32, 48, [96], 24, 3), (32, 48, [24], 96, 3), (32, 24, [128], 32, 3), (32, 24, [32], 128, 3),
     (32, 12, [160], 40, 3), (32, 12, [40], 160, 3), (32, 6, [192], 48, 3), (32, 48, [96, 4, 96], 24, 3),
-    (32, 48, [16, 96], 96, 1), (32, 96, [16, 4], 64, 1),
+    (32, 48, [16, 96], 96, 1), (32, 96, [16, 4], 64, 1), (32, 24, [128, 4, 128], 32, 3), (32, 12, [160, 4, 160], 40, 3),
 ]
 
 
@@ -43,6 +43,10 @@ def main():
         xs = [eng.new(N, R, R, c) for c in segc]
         for x in xs:
             eng.lib.philox_normal  # noqa
+            if x.c % 8:  # ragged width: zero padding to 8 channels, as Engine.input does for the parents
+                eng.fill(eng._padded(x), 0.0)
+                x.cpad = (x.c + 7) // 8 * 8
+                x._cv = None
             eng.fill(x, 0.5)
         torch.cuda.synchronize()
         flops = 2.0 * sum(segc) * ks * ks * Co * N * R * R
