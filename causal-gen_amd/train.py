@@ -57,6 +57,8 @@ class TrainStep:
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
+        if self.world > 1 and getattr(model, "free_bits", 0) > 0:
+            self.use_graph = False  # free bits exchange per-channel KL sums inside the forward pass (vae.py): not capturable
         model.train()
         eng = model.engine()
         self.eng = eng

@@ -499,10 +499,8 @@ class HVAE(nn.Module):
         acts = self._encode(eng, xin)
         fb = None
         if self.free_bits > 0:
-            # vae.py:443-449: per-layer, per-channel batch means of the KL, floored at free_bits.  Needs a cross-rank mean of
-            # S under data parallelism, which this single-process path does not have.
-            if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-                raise NotImplementedError("kl_free_bits > 0 under data parallelism needs an all-reduce inside the forward pass")
+            # vae.py:443-449: per-layer, per-channel batch means of the KL, floored at free_bits.  Under data parallelism the
+            # batch is the GLOBAL batch: the per-channel sums are all-reduced before the floor (below).
             cols, ncol = {}, 0
             for i, blk in enumerate(self.decoder.blocks):
                 if blk.stochastic:
@@ -511,6 +509,16 @@ class HVAE(nn.Module):
             s_buf = torch.empty(B * ncol + ncol, dtype=torch.float32, device=eng.device)  # S[B][ncol] then chan_mask[ncol]
             fb = (s_buf.data_ptr(), ncol, cols)
         h, _ = self._decode(eng, pa, acts=acts, drop=drop, kl=(kl_ptr, kl_total, offs), fb=fb)
+        if fb is not None and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            # one small exchange: every row of S is replaced by the global per-channel mean, so that the finalize kernel
+            # floors (and masks the gradient of) the same batch statistic on every rank; the per-sample gradient weight
+            # stays 1/B_local because the gradient all-reduce averages over ranks (equal per-rank batches).  Not
+            # capturable: the trainer runs this configuration without a hipGraph.
+            world = torch.distributed.get_world_size()
+            S = s_buf[:B * ncol].view(B, ncol)
+            col = S.sum(0)
+            torch.distributed.all_reduce(col)
+            S.copy_((col / float(B * world)).expand(B, ncol))
         params = self._likelihood_params(eng, h)
         nchunk = lib.like_chunks(R, R)
         nll_ptr = eng.new_f32(B * nchunk)

@@ -213,6 +213,22 @@ def test_dp_bench_path_two_gloo_ranks_on_one_gpu():
     assert d["opt_steps"] == 4 and "roofline" in d
 
 
+def test_free_bits_under_data_parallelism():
+    """kl_free_bits > 0 with two ranks: the per-channel KL sums are all-reduced inside the forward pass, so the
+    floored KL and the rank-averaged gradients equal the single-process result on the concatenated batch."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(root, "tests", "dp_free_bits_worker.py")]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    assert "DP_FREE_BITS_OK" in r.stdout, r.stdout[-1500:]
+
+
 def test_graphed_counterfactual_matches_eager_and_follows_weight_updates():
     from causal_gen_amd import dscm
 
