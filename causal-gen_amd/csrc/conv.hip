@@ -1484,7 +1484,11 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
   }
   if (want < 1) want = 1;
   g.tps = ceil_div(g.ntiles, want);
-  static const int min_tps = [] { const char* e = getenv("CGEN_WG2_MINTPS"); return e ? atoi(e) : 4; }();
+  // long workgroups: the packed launch fills the chip whatever a single problem does, and every split costs a partial slab
+  // (12 tiles per workgroup halves the split-K partials of ukbb192, 1.8 -> 0.94 GB per step, +1.7 %); the batch-256 32x32
+  // models measured 1-2 % better with 4
+  static const int min_tps_env = [] { const char* e = getenv("CGEN_WG2_MINTPS"); return e ? atoi(e) : 0; }();
+  const int min_tps = min_tps_env > 0 ? min_tps_env : (N <= 64 ? 12 : 4);
   if (g.tps < min_tps && g.ntiles >= min_tps) g.tps = min_tps;
   g.nsplit = ceil_div(g.ntiles, g.tps);
   return true;
