@@ -1197,6 +1197,7 @@ struct Wg2P {
   unsigned long long* stamps;  // optional (CGEN_WG2_STAMPS): per-phase cycle stamps of workgroup 0
   PixTile xt, gt;
   FastDiv d_tx, d_ty;
+  int variant, pad1;  // ncf * 2 + (KS == 3): which body the all-variant kernel runs for this problem
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -1439,6 +1440,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_batched_kernel(const Wg2P* 
     const int prob = __builtin_amdgcn_readfirstlane(bi.x);
     wgrad_tile_body<NCF, NJW, KS>(probs[prob], __builtin_amdgcn_readfirstlane(bi.y), __builtin_amdgcn_readfirstlane(bi.z),
                                   __builtin_amdgcn_readfirstlane(bi.w));
+    __syncthreads();
+  }
+}
+
+// All variants in ONE launch: a flush of the deferred weight gradients used to be up to 14 dependent launches (one per
+// variant and LDS class), each with its own tail and, in the background of the backward chain, each a barrier packet on
+// the side queue -- the rocprofv3 timeline showed the chain being dispatched only every ~60 us while those packets waited
+// on each other.  Here every workgroup walks the common block list and runs the body its problem asks for.
+__global__ __launch_bounds__(256, 2) void wgrad_tile_mega_kernel(const Wg2P* __restrict__ probs, const int4* __restrict__ blocks, const int nblocks) {
+  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const int4 bi = blocks[b];
+    const Wg2P& p = probs[__builtin_amdgcn_readfirstlane(bi.x)];
+    const int bx = __builtin_amdgcn_readfirstlane(bi.y), by = __builtin_amdgcn_readfirstlane(bi.z), bz = __builtin_amdgcn_readfirstlane(bi.w);
+    switch (p.variant) {
+      case 2: wgrad_tile_body<1, 16, 1>(p, bx, by, bz); break;
+      case 3: wgrad_tile_body<1, 16, 3>(p, bx, by, bz); break;
+      case 4: wgrad_tile_body<2, 12, 1>(p, bx, by, bz); break;
+      case 5: wgrad_tile_body<2, 12, 3>(p, bx, by, bz); break;
+      case 8: wgrad_tile_body<4, 6, 1>(p, bx, by, bz); break;
+      case 9: wgrad_tile_body<4, 6, 3>(p, bx, by, bz); break;
+      case 12: wgrad_tile_body<6, 4, 1>(p, bx, by, bz); break;
+      case 13: wgrad_tile_body<6, 4, 3>(p, bx, by, bz); break;
+      case 16: wgrad_tile_body<8, 3, 1>(p, bx, by, bz); break;
+      default: wgrad_tile_body<8, 3, 3>(p, bx, by, bz); break;
+    }
     __syncthreads();
   }
 }
@@ -2386,6 +2412,7 @@ static bool build_wg2(const cgen_wgrad_args* a, Wg2P& q, Wg2Geom& g) {
   q.tiles_x = g.tiles_x; q.tiles_y = g.tiles_y; q.ntiles = g.ntiles; q.nsplit = g.nsplit; q.tiles_per_split = g.tps;
   q.cwin = g.cwin; q.cog = g.ncf * 16; q.xt = g.xt; q.gt = g.gt;
   q.d_tx = mk_fastdiv(g.tiles_x); q.d_ty = mk_fastdiv(g.tiles_y);
+  q.variant = g.ncf * 2 + (a->ks == 3 ? 1 : 0);
   return true;
 }
 
@@ -2420,6 +2447,13 @@ extern "C" int cgen_conv2d_wgrad_batch_plan(const cgen_wgrad_args* args, int32_t
     it.cost = (long)it.g.nsplit * it.g.n_cwin * it.g.n_co * it.g.tps;
     items.push_back(it);
   }
+  static const bool mega = [] { const char* e = getenv("CGEN_WGRAD_MEGA"); return !e || atoi(e) != 0; }();
+  if (mega) {  // one launch for everything: longest blocks first (the resident workgroups take them round robin)
+    for (auto& it : items) {
+      it.key = 0;
+      it.cost = (long)it.g.tps * it.g.ncf * std::min(it.g.cwin, it.q.ctot8) * it.q.taps;
+    }
+  }
   std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.key != b.key ? a.key < b.key : a.cost > b.cost; });
   const int64_t probs_bytes = pad_to((int)(items.size() * sizeof(Wg2P)), 256);
   int64_t nblocks_total = 0;
@@ -2441,7 +2475,7 @@ extern "C" int cgen_conv2d_wgrad_batch_plan(const cgen_wgrad_args* args, int32_t
     probs[i] = it.q;
     if (i == 0 || it.key != items[i - 1].key) {
       ++li;
-      launches[li].ncf = it.g.ncf; launches[li].ks = args[it.idx].ks; launches[li].lds_bytes = 0; launches[li].nblocks = 0;
+      launches[li].ncf = mega ? 0 : it.g.ncf; launches[li].ks = args[it.idx].ks; launches[li].lds_bytes = 0; launches[li].nblocks = 0;
       launches[li].blocks_offset = probs_bytes + b * (int64_t)sizeof(int4);
     }
     if ((int32_t)it.g.lds > launches[li].lds_bytes) launches[li].lds_bytes = (int32_t)it.g.lds;
@@ -2464,6 +2498,12 @@ extern "C" int cgen_conv2d_wgrad_batch_run(const void* blob_dev, const cgen_wgra
     const int4* blocks = (const int4*)((const char*)blob_dev + l.blocks_offset);
     const int grid = max_workgroups > 0 ? std::min(l.nblocks, max_workgroups) : l.nblocks;
     switch (l.ncf) {
+      case 0: {
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_tile_mega_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+        hipLaunchKernelGGL(wgrad_tile_mega_kernel, dim3(grid), dim3(256), (size_t)l.lds_bytes, st, probs, blocks, l.nblocks);
+        break;
+      }
       case 1: launch_wgrad2_batched<1, 16>(l.ks, probs, blocks, l.nblocks, grid, (size_t)l.lds_bytes, st); break;
       case 2: launch_wgrad2_batched<2, 12>(l.ks, probs, blocks, l.nblocks, grid, (size_t)l.lds_bytes, st); break;
       case 4: launch_wgrad2_batched<4, 6>(l.ks, probs, blocks, l.nblocks, grid, (size_t)l.lds_bytes, st); break;

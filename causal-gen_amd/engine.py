@@ -888,6 +888,8 @@ class Engine:
             if len(self._wg_batches) > 64:
                 self._wg_batches.clear()
             ent = self._wg_batches[key] = (blob, launches, nl.value, rest)
+            if os.environ.get("CGEN_WG_DEBUG"):
+                print("  launches: " + " ".join("<%d,ks%d>lds%dK:%dblk" % (launches[i].ncf, launches[i].ks, launches[i].lds_bytes // 1024, launches[i].nblocks) for i in range(nl.value)), flush=True)
         blob, launches, nl, rest = ent
         ev = None
         if self.prof is not None:  # the packed launches are timed as ONE class entry (per-problem times do not exist)
