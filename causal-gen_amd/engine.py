@@ -138,6 +138,7 @@ class Engine:
         self._img_buf = None
         self._prep_tab = None
         self._wg_events = []
+        self._wg_reduced, self._wg_seen = 0, set()
         self._partials = {}
         self._red_tabs = {}
         self.params = None          # list of nn.Parameter in model.parameters() order
@@ -157,6 +158,7 @@ class Engine:
         # capped grid, so that they fill the CUs the latency-bound backward chain leaves idle (0: one batch at the end)
         self.wgrad_flush_frac = [float(v) for v in os.environ.get("CGEN_WGRAD_FLUSH_FRAC", "0.55").split(",") if v]
         self.wgrad_bg_wgs = int(os.environ.get("CGEN_WGRAD_BG_WGS", "304"))
+        self.wgrad_bg_reduce = os.environ.get("CGEN_WGRAD_BG_REDUCE", "1") != "0"
         self._wg_cum, self._wg_total, self._wg_nflush = 0.0, 0.0, 0
         self._wg_batches = {}
         self._wg_forked = False
@@ -173,6 +175,7 @@ class Engine:
         self.tape.clear()
         self.grads.clear()
         self._wg_events = []
+        self._wg_reduced, self._wg_seen = 0, set()
         self.pgrad_init = set()
         self._pnhwc, self._pgrad_tmp = {}, {}
         self._adopted = set()
@@ -812,8 +815,7 @@ class Engine:
         if ent is None:
             nsplit = self.lib.conv2d_wgrad_plan(C.byref(a), None)
             ent = (torch.empty(nsplit * (nw + site.co), dtype=torch.float32, device=self.device), nsplit)
-            self._partials[key] = ent
-            self._red_tabs = {}
+            self._partials[key] = ent  # (reduce tables are keyed by these keys: a new key cannot invalidate an existing table)
         buf, nsplit = ent
         a.nsplit = nsplit
         a.partial_w = buf.data_ptr()
@@ -909,6 +911,8 @@ class Engine:
                 self.lib.conv2d_wgrad(C.byref(args[i]), side.cuda_stream)
                 self.launches += 1
             self._wg_deferred = []
+            if self.wgrad_bg_reduce:
+                self._reduce_events(side.cuda_stream)  # these partials are final: their reduction leaves the critical path too
             return
         if blob is not None and nl:
             self.lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl, 0, self.stream)
@@ -944,13 +948,24 @@ class Engine:
 
     def _reduce_wgrads(self):
         self._launch_deferred_wgrads()
-        if not self._wg_events:
+        self._reduce_events(self.stream)
+
+    def _reduce_events(self, stream):
+        """Split-K partials -> flat OIHW gradients for every weight-gradient event not reduced yet (one multi-tensor launch).
+        Called on the side stream right after a background flush (those partials are final) and at the end of the pass."""
+        events = self._wg_events[self._wg_reduced:]
+        if not events:
             return
-        sig = tuple(k for _, k, _ in self._wg_events)
+        self._wg_reduced = len(self._wg_events)
+        flags = []
+        for site, _, _ in events:  # a site used twice in one pass accumulates its second use
+            flags.append(site.index in self._wg_seen)
+            self._wg_seen.add(site.index)
+        sig = (tuple(k for _, k, _ in events), tuple(flags))
         tab = self._red_tabs.get(sig)
         if tab is None:
-            descs, csite, cidx, seen = [], [], [], set()
-            for site, key, nsplit in self._wg_events:
+            descs, csite, cidx = [], [], []
+            for (site, key, nsplit), acc in zip(events, flags):
                 buf = self._partials[key][0]
                 nw = site.co * site.taps * site.ci
                 d = _lib.WredDesc()
@@ -959,8 +974,7 @@ class Engine:
                 d.grad_w = self.param_grad_ptr(site.conv.weight)
                 d.grad_b = self.param_grad_ptr(site.conv.bias) if site.conv.bias is not None else None
                 d.co, d.ci_total, d.ks, d.nsplit = site.co, site.ci, site.ks, nsplit
-                d.accumulate = 1 if site.index in seen else 0
-                seen.add(site.index)
+                d.accumulate = 1 if acc else 0
                 d.numel = nw + (site.co if site.conv.bias is not None else 0)
                 descs.append(d)
             for i, d in enumerate(descs):
@@ -972,9 +986,9 @@ class Engine:
                    torch.tensor(cidx, dtype=torch.int32, device=self.device), len(csite))
             self._red_tabs[sig] = tab
         d, cs, ci, n = tab
-        self.lib.wgrad_reduce(d.data_ptr(), cs.data_ptr(), ci.data_ptr(), n, self.stream)
+        self.lib.wgrad_reduce(d.data_ptr(), cs.data_ptr(), ci.data_ptr(), n, stream)
         self.launches += 1
-        for site, _, _ in self._wg_events:
+        for site, _, _ in events:
             self.pgrad_init.add(id(site.conv.weight))
             if site.conv.bias is not None:
                 self.pgrad_init.add(id(site.conv.bias))
