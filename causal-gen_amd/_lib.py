@@ -79,6 +79,8 @@ PROTOTYPES = {
     "cgen_reparam_kl_fwd": [i32, i32, i32, i32, i32, View, View, View, View, View, vp, u32, f32, View, View, vp, i32, vp],
     "cgen_reparam_kl_bwd": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, View, vp, i32, vp, View, View, View,
                             View, i32, i32, vp],
+    "cgen_reparam_kl_bwd_rider": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, View, vp, i32, vp, View, View, View,
+                                  View, i32, i32, View, View, i32, vp],
     "cgen_kl_channel_sums": [i32, i32, i32, i32, i32, View, View, View, View, f32, vp, i32, vp],
     "cgen_elbo_finalize_fb": [i32, vp, i32, f32, vp, i32, f32, f32, f32, vp, vp, vp],
     "cgen_im2col_strided": [i32, i32, i32, i32, i32, i32, i32, i32, i32, View, View, vp],

@@ -1,8 +1,13 @@
 #!/bin/bash
 # Build libcgen_hip.so for gfx950 (MI355X) in-tree.  hipcc cross-compiles without a GPU.
+# NOPK: no packed-f32 VALU instructions (v_pk_mul/add/fma_f32) in any kernel.  Measured on MI355X (tools/coexec_probe.py):
+# a wave executing them returns corrupted results when a wave of ANOTHER kernel on the same SIMD is executing
+# v_mfma_f32_16x16x32_bf16 -- exactly what the background weight-gradient kernel does next to the backward chain.
+# (The feature name is unknown to the host pass, which says so and ignores it.)
 set -e
 cd "$(dirname "$0")"
 OUT=libcgen_hip.so
+NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"
 SRCS="csrc/runtime.hip csrc/conv.hip csrc/elementwise.hip csrc/latent.hip csrc/likelihood.hip csrc/optim.hip"
 mkdir -p build
 OBJS=""
@@ -11,7 +16,7 @@ for s in $SRCS; do
   o=build/$(basename ${s%.hip}).o
   OBJS="$OBJS $o"
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ csrc/common.h -nt "$o" ] || [ ../include/cgen_hip.h -nt "$o" ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -c "$s" -o "$o" &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $NOPK ${CGEN_EXTRA_FLAGS} -Wno-unused-result -c "$s" -o "$o" &
     pids="$pids $!"
   fi
 done

@@ -26,6 +26,12 @@
 
 #include "common.h"
 
+#ifdef CGEN_NO_SETPRIO
+#define CGEN_SETPRIO() do {} while (0)
+#else
+#define CGEN_SETPRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+
 namespace cgen {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -472,7 +478,7 @@ __device__ __forceinline__ uint4 act_group(uint4 v, int act) {
 
 template <typename T, int NTC, int KS>
 __global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP p, TileP q) {
-  __builtin_amdgcn_s_setprio(3);  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
+  CGEN_SETPRIO();  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   constexpr int G = 16 / sizeof(T);
   constexpr int HALO = KS / 2, HH = TILE_H + 2 * HALO, HW = TILE_W + 2 * HALO, HPX = HH * HW;
   constexpr int TAPS = KS * KS;
@@ -718,7 +724,7 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st);  // lean persistent 
 // are added through LDS in a fixed order (deterministic).  One workgroup = 16*SP_NCO output channels x 32 pixels.
 template <int KS, int SP_NCO, int KU, bool ONESEG>
 __global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, FastDiv d_ctot8, FastDiv d_hw, FastDiv d_w, unsigned long long* stamps) {
-  __builtin_amdgcn_s_setprio(3);
+  CGEN_SETPRIO();
   unsigned long long* stamp = (stamps != nullptr && threadIdx.x == 0) ? stamps + 8 * (blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
   if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   typedef bf16_t T;
@@ -1202,8 +1208,13 @@ struct Wg2P {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
+__device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1, const bool plain = false) {
   typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+  if (plain) {  // ablation (CGEN_WG2_DBG & 8): ordinary 8-byte LDS reads instead of the transposing ones (wrong math, same traffic)
+    union { s16x4 h[2]; bf16x8 v; } u;
+    u.h[0] = *(const s16x4*)p0; u.h[1] = *(const s16x4*)p1;
+    return u.v;
+  }
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p0);
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p1);
   union { s16x4 h[2]; bf16x8 v; } u;
@@ -1328,6 +1339,11 @@ __device__ __forceinline__ void wgrad_tile_body(const Wg2P& p, const int bid_x, 
   for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
   const bool stamp = p.stamps != nullptr && bid_x == 0 && bid_y == 0 && bid_z == 0 && tid == 0;
+#ifdef CGEN_WG2_ABLATE
+  const bool plain_rd = (p.dbg & 8) != 0, no_mfma = (p.dbg & 16) != 0;
+#else
+  constexpr bool plain_rd = false;
+#endif
   int nst = 0;
 #define WG2_STAMP() do { if (stamp && nst < 60) p.stamps[nst++] = __builtin_readcyclecounter(); } while (0)
   if (stamp) p.stamps[nst++] = t_entry;
@@ -1351,7 +1367,7 @@ __device__ __forceinline__ void wgrad_tile_body(const Wg2P& p, const int bid_x, 
         bf16x8 af[NCF];
         const char* gk = Gb + ks * 2 * p.gt.rowbytes;
 #pragma unroll
-        for (int a = 0; a < NCF; ++a) af[a] = tr_pair(gk + go0 + a * 32, gk + go1 + a * 32);
+        for (int a = 0; a < NCF; ++a) af[a] = tr_pair(gk + go0 + a * 32, gk + go1 + a * 32, plain_rd);
         if (do_bias) {
 #pragma unroll
           for (int a = 0; a < NCF; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, accb[a], 0, 0, 0);
@@ -1362,11 +1378,22 @@ __device__ __forceinline__ void wgrad_tile_body(const Wg2P& p, const int bid_x, 
           if (j0 < nj_eff) {
             bf16x8 bfv[CH];
 #pragma unroll
-            for (int u = 0; u < CH; ++u) bfv[u] = tr_pair(xk + xo0[j0 + u], xk + xo1[j0 + u]);
+            for (int u = 0; u < CH; ++u) bfv[u] = tr_pair(xk + xo0[j0 + u], xk + xo1[j0 + u], plain_rd);
 #pragma unroll
             for (int u = 0; u < CH; ++u)
 #pragma unroll
-              for (int a = 0; a < NCF; ++a) acc[a][j0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfv[u], acc[a][j0 + u], 0, 0, 0);
+              for (int a = 0; a < NCF; ++a) {
+#ifdef CGEN_WG2_ABLATE  // (tools/coexec_probe.py, CGEN_WG2_DBG & 16): keep the LDS reads alive without the matrix instruction
+                if (no_mfma) {
+                  union { bf16x8 v; float f[4]; } ua, ub;
+                  ua.v = af[a]; ub.v = bfv[u];
+                  acc[a][j0 + u][0] += ua.f[0] + ub.f[0]; acc[a][j0 + u][1] += ua.f[1] + ub.f[1];
+                  acc[a][j0 + u][2] += ua.f[2] + ub.f[2]; acc[a][j0 + u][3] += ua.f[3] + ub.f[3];
+                  continue;
+                }
+#endif
+                acc[a][j0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfv[u], acc[a][j0 + u], 0, 0, 0);
+              }
           }
         }
       }
@@ -1564,7 +1591,7 @@ __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 
 
 template <int NP, int KS, bool ONESEG>
 __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
-  __builtin_amdgcn_s_setprio(3);  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
+  CGEN_SETPRIO();  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   typedef bf16_t T;
   constexpr int G = 8, HALO = KS / 2, HW = TILE_W + 2 * HALO, TAPS = KS * KS;
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -1906,7 +1933,7 @@ struct WsP {
 
 template <int NTC, int NKW, bool ONESEG>
 __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
-  __builtin_amdgcn_s_setprio(3);  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
+  CGEN_SETPRIO();  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   typedef bf16_t T;
   constexpr int G = 8, NF = NTC * TILE_H;
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -2413,6 +2440,7 @@ static bool build_wg2(const cgen_wgrad_args* a, Wg2P& q, Wg2Geom& g) {
   q.cwin = g.cwin; q.cog = g.ncf * 16; q.xt = g.xt; q.gt = g.gt;
   q.d_tx = mk_fastdiv(g.tiles_x); q.d_ty = mk_fastdiv(g.tiles_y);
   q.variant = g.ncf * 2 + (a->ks == 3 ? 1 : 0);
+  { const char* e = getenv("CGEN_WG2_DBG"); q.dbg = e ? atoi(e) : 0; }
   return true;
 }
 

@@ -66,6 +66,10 @@ struct LatBwdP {
   const float* chan_scale;  // optional [c]: per-channel multiplier of the KL gradient (free-bits mask)
   int coef_stride, acc_q, acc_p;
   float logt;
+  // optional rider (vec8 kernel only): blocks past `main_blocks` copy / accumulate the [n,h,w,ride_c] view ride_src into
+  // ride_dst -- the residual's share of grad(prior output), which would otherwise be a launch of its own
+  View ride_src, ride_dst;
+  int main_blocks, ride_c, ride_acc;
 };
 
 template <typename T>
@@ -161,10 +165,51 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_vec8_kernel(LatP p) {
   if (threadIdx.x == 0) p.kl_part[(int64_t)b * p.kl_stride + chunk] = tot;
 }
 
+#ifdef CGEN_SOFT_EXP
+#define CGEN_EXP exp_valu
+#else
+#define CGEN_EXP expf
+#endif
+// exp without the transcendental unit (experiment): 2^(x log2 e) with a degree-6 polynomial on [-0.5, 0.5] and an exponent add
+__device__ __forceinline__ float exp_valu(float x) {
+  const float t = fminf(fmaxf(x * 1.44269504088896341f, -125.f), 125.f);
+  const float n = rintf(t), f = t - n;
+  float pl = 1.53533619e-4f;
+  pl = fmaf(pl, f, 1.33335581e-3f);
+  pl = fmaf(pl, f, 9.61812911e-3f);
+  pl = fmaf(pl, f, 5.55041087e-2f);
+  pl = fmaf(pl, f, 2.40226507e-1f);
+  pl = fmaf(pl, f, 6.93147181e-1f);
+  pl = fmaf(pl, f, 1.f);
+  return __int_as_float(__float_as_int(pl) + ((int)n << 23));
+}
+
 __global__ __launch_bounds__(256) void reparam_kl_bwd_vec8_kernel(LatBwdP p) {
+  if ((int)blockIdx.x >= p.main_blocks) {  // rider blocks
+    const int rg = p.ride_c >> 3, per = p.h * p.w * rg;
+    const int64_t tot = (int64_t)p.n * per;
+    const int nb = gridDim.x - p.main_blocks;
+    for (int64_t g = (int64_t)(blockIdx.x - p.main_blocks) * 256 + threadIdx.x; g < tot; g += (int64_t)nb * 256) {
+      const int b = (int)(g / per), g8 = (int)(g - (int64_t)b * per);
+      const int pix = g8 / rg, ch = (g8 - pix * rg) * 8;
+      const int y = pix / p.w, x = pix - y * p.w;
+      uint4 v = ld8(p.ride_src, off8(p.ride_src, b, y, x, ch));
+      const int o = off8(p.ride_dst, b, y, x, ch);
+      if (p.ride_acc) {
+        float a[8], t[8];
+        unpack8(v, a);
+        unpack8(ld8(p.ride_dst, o), t);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] += t[k];
+        v = pack8(a);
+      }
+      st8(p.ride_dst, o, v);
+    }
+    return;
+  }
   const int per8 = (p.h * p.w * p.c) >> 3, cg = p.c >> 3;
   const int64_t total = (int64_t)p.n * per8;
-  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)p.main_blocks * 256) {
     const int b = (int)(g / per8), g8 = (int)(g - (int64_t)b * per8);
     const int pix = g8 / cg, ch = (g8 - pix * cg) * 8;
     const int y = pix / p.w, x = pix - y * p.w;
@@ -183,7 +228,7 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_vec8_kernel(LatBwdP p) {
     for (int k = 0; k < 8; ++k) {
       const float kk = k0 * (p.chan_scale ? p.chan_scale[ch + k] : 1.f);
       const float q = qs[k] + p.logt, pp = ps[k] + p.logt;
-      const float e2q = expf(2.f * q), ie2p = expf(-2.f * pp), d = ql[k] - pl[k];
+      const float e2q = CGEN_EXP(2.f * q), ie2p = CGEN_EXP(-2.f * pp), d = ql[k] - pl[k];
       float gql = kk * d * ie2p, gqs = kk * (e2q * ie2p - 1.f);
       o3[k] = -kk * d * ie2p;
       o4[k] = kk * (1.f - (e2q + d * d) * ie2p);
@@ -333,26 +378,53 @@ extern "C" int cgen_reparam_kl_fwd(int32_t dtype, int32_t n, int32_t h, int32_t 
   return check_launch("cgen_reparam_kl_fwd");
 }
 
-extern "C" int cgen_reparam_kl_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls,
-                                   cgen_view p_loc, cgen_view p_ls, cgen_view z, float logt, cgen_view gz,
-                                   const float* kl_coef_dev, int32_t coef_stride, const float* kl_chan_scale, cgen_view g_q_loc,
-                                   cgen_view g_q_ls, cgen_view g_p_loc, cgen_view g_p_ls, int32_t acc_q, int32_t acc_p,
-                                   cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_reparam_kl_bwd: bad dtype");
-  CGEN_REQUIRE(q_loc.p && q_ls.p && p_loc.p && p_ls.p && kl_coef_dev && g_q_loc.p && g_q_ls.p && g_p_loc.p && g_p_ls.p,
-               "cgen_reparam_kl_bwd: null view");
-  CGEN_REQUIRE(!gz.p || z.p, "cgen_reparam_kl_bwd: gz given without z");
+static int reparam_kl_bwd_impl(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls, cgen_view p_loc,
+                               cgen_view p_ls, cgen_view z, float logt, cgen_view gz, const float* kl_coef_dev, int32_t coef_stride,
+                               const float* kl_chan_scale, cgen_view g_q_loc, cgen_view g_q_ls, cgen_view g_p_loc, cgen_view g_p_ls,
+                               int32_t acc_q, int32_t acc_p, const cgen_view* ride_src, const cgen_view* ride_dst, int32_t ride_acc,
+                               cgen_stream_t stream, const char* who) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "%s: bad dtype", who);
+  CGEN_REQUIRE(q_loc.p && q_ls.p && p_loc.p && p_ls.p && kl_coef_dev && g_q_loc.p && g_q_ls.p && g_p_loc.p && g_p_ls.p, "%s: null view", who);
+  CGEN_REQUIRE(!gz.p || z.p, "%s: gz given without z", who);
   LatBwdP p;
+  memset(&p, 0, sizeof(p));
   p.n = n; p.h = h; p.w = w; p.c = c;
   p.q_loc = mk(q_loc); p.q_ls = mk(q_ls); p.p_loc = mk(p_loc); p.p_ls = mk(p_ls); p.z = mk(z); p.gz = mk(gz);
   p.g_q_loc = mk(g_q_loc); p.g_q_ls = mk(g_q_ls); p.g_p_loc = mk(g_p_loc); p.g_p_ls = mk(g_p_ls);
   p.coef = kl_coef_dev; p.chan_scale = kl_chan_scale; p.coef_stride = coef_stride; p.acc_q = acc_q; p.acc_p = acc_p; p.logt = logt;
   const int grid = lat_grid((int64_t)n * h * w * c);
+  const bool vec8 = dtype == CGEN_BF16 && lat_vec8_ok(n, c, {q_loc, q_ls, p_loc, p_ls, z, gz, g_q_loc, g_q_ls, g_p_loc, g_p_ls});
+  if (ride_src) {
+    CGEN_REQUIRE(vec8 && ride_dst && ride_src->p && ride_dst->p && ride_src->c == ride_dst->c && ride_src->c % 8 == 0 &&
+                     lat_vec8_ok(n, ride_src->c, {*ride_src, *ride_dst}),
+                 "%s: the rider needs the 16-byte bf16 path (8-channel multiples, 16-byte aligned views)", who);
+    p.ride_src = mk(*ride_src); p.ride_dst = mk(*ride_dst); p.ride_c = ride_src->c; p.ride_acc = ride_acc;
+  }
   if (dtype == CGEN_F32) hipLaunchKernelGGL(reparam_kl_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-  else if (lat_vec8_ok(n, c, {q_loc, q_ls, p_loc, p_ls, z, gz, g_q_loc, g_q_ls, g_p_loc, g_p_ls}))
-    hipLaunchKernelGGL(reparam_kl_bwd_vec8_kernel, dim3(lat_grid((int64_t)n * h * w * c / 8)), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(reparam_kl_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-  return check_launch("cgen_reparam_kl_bwd");
+  else if (vec8) {
+    p.main_blocks = lat_grid((int64_t)n * h * w * c / 8);
+    const int ride_blocks = ride_src ? lat_grid((int64_t)n * h * w * ride_src->c / 8) : 0;
+    hipLaunchKernelGGL(reparam_kl_bwd_vec8_kernel, dim3(p.main_blocks + ride_blocks), dim3(256), 0, (hipStream_t)stream, p);
+  } else hipLaunchKernelGGL(reparam_kl_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch(who);
+}
+
+extern "C" int cgen_reparam_kl_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls,
+                                   cgen_view p_loc, cgen_view p_ls, cgen_view z, float logt, cgen_view gz,
+                                   const float* kl_coef_dev, int32_t coef_stride, const float* kl_chan_scale, cgen_view g_q_loc,
+                                   cgen_view g_q_ls, cgen_view g_p_loc, cgen_view g_p_ls, int32_t acc_q, int32_t acc_p,
+                                   cgen_stream_t stream) {
+  return reparam_kl_bwd_impl(dtype, n, h, w, c, q_loc, q_ls, p_loc, p_ls, z, logt, gz, kl_coef_dev, coef_stride, kl_chan_scale, g_q_loc, g_q_ls,
+                             g_p_loc, g_p_ls, acc_q, acc_p, nullptr, nullptr, 0, stream, "cgen_reparam_kl_bwd");
+}
+
+extern "C" int cgen_reparam_kl_bwd_rider(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls,
+                                         cgen_view p_loc, cgen_view p_ls, cgen_view z, float logt, cgen_view gz,
+                                         const float* kl_coef_dev, int32_t coef_stride, const float* kl_chan_scale, cgen_view g_q_loc,
+                                         cgen_view g_q_ls, cgen_view g_p_loc, cgen_view g_p_ls, int32_t acc_q, int32_t acc_p,
+                                         cgen_view ride_src, cgen_view ride_dst, int32_t ride_acc, cgen_stream_t stream) {
+  return reparam_kl_bwd_impl(dtype, n, h, w, c, q_loc, q_ls, p_loc, p_ls, z, logt, gz, kl_coef_dev, coef_stride, kl_chan_scale, g_q_loc, g_q_ls,
+                             g_p_loc, g_p_ls, acc_q, acc_p, &ride_src, &ride_dst, ride_acc, stream, "cgen_reparam_kl_bwd_rider");
 }
 
 extern "C" int cgen_sample_gaussian(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view loc, cgen_view ls,

@@ -139,6 +139,9 @@ class Engine:
         self._prep_tab = None
         self._wg_events = []
         self._wg_reduced, self._wg_seen = 0, set()
+        self._dbg_names = {} if os.environ.get("CGEN_DEBUG_NAMES") else None  # id(tensor) -> producing conv (tools/ab_grads.py)
+        self._riders = {}
+        self.ride = os.environ.get("CGEN_RIDER", "1") != "0"
         self._partials = {}
         self._red_tabs = {}
         self.params = None          # list of nn.Parameter in model.parameters() order
@@ -176,6 +179,7 @@ class Engine:
         self.grads.clear()
         self._wg_events = []
         self._wg_reduced, self._wg_seen = 0, set()
+        self._riders = {}
         self.pgrad_init = set()
         self._pnhwc, self._pgrad_tmp = {}, {}
         self._adopted = set()
@@ -381,6 +385,8 @@ class Engine:
         a.res2 = vw(res2)
         self._timed("conv_fwd", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream))
         if self.recording:
+            if self._dbg_names is not None:
+                self._dbg_names[id(out.base)] = site.name
             self.tape.append((self._bw_conv, (site, segs, act, out, res1, res2)))
         return out
 
@@ -666,9 +672,19 @@ class Engine:
         self.launches += 1
         e[0] = new
 
+    def _land_rider(self, base):
+        """A copy parked for the next reparam backward (see _grad_residual) must land before anyone else touches grad(base)."""
+        job = self._riders.pop(id(base), None)
+        if job is not None:
+            gv, g, acc = job
+            self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
+            self.launches += 1
+
     def grad_write(self, t, defer_hazard=False):
         """Gradient view for `t` plus whether it already holds a value (=> the writer must accumulate)."""
         assert t.rg
+        if self._riders:
+            self._land_rider(t.base)
         g, ivs, base = self._gentry(t.base)
         a, b = t.coff, t.coff + t.c
         miss = self._missing(ivs, a, b)
@@ -688,6 +704,8 @@ class Engine:
 
     def grad_read(self, t):
         """Gradient of `t` for reading (zero-filling channels nobody wrote); None when nothing flowed into it."""
+        if self._riders:
+            self._land_rider(t.base)
         e = self.grads.get(id(t.base))
         if e is None:
             return None
@@ -701,10 +719,21 @@ class Engine:
             ivs.append((s, e2))
         return g.chan(a, b)
 
-    def grad_add(self, t, g):
+    def grad_add(self, t, g, may_ride=False):
         gv, acc = self.grad_write(t)
+        if (may_ride and self.ride and self.dt == BF16 and self._defer_wgrad() and t.base is not t and id(t.base) not in self._riders
+                and t.c % 8 == 0 and self._v16(gv) and self._v16(g) and id(self.grads[id(t.base)][0]) not in self._adopted):
+            # channel slice of a wider gradient buffer (the prior Block's output): the copy rides on the reparam backward
+            # that writes the neighbouring channels (grad buffers are immutable under deferral, so `g` can wait)
+            self._riders[id(t.base)] = (gv, g, acc)
+            return
         self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
         self.launches += 1
+
+    @staticmethod
+    def _v16(v):
+        """16-byte vector access is legal on this bf16 view."""
+        return v.es == 2 and v.ptr % 16 == 0 and v.sn % 8 == 0 and v.sh % 8 == 0 and v.sw % 8 == 0 and v.n * v.sn * 2 < (1 << 31)
 
     def _grad_residual(self, r, g, out, segs):
         """d(out)/d(residual) = identity.  When `r` is a whole tensor that has no gradient yet and `out`'s gradient is a
@@ -720,7 +749,7 @@ class Engine:
             self.grads[id(r)] = [gbuf, [(0, r.c)], r]
             self._adopted.add(id(gbuf))
             return
-        self.grad_add(r, g)
+        self.grad_add(r, g, may_ride=True)
 
     def flat_axpy(self, src_ptr, dst_ptr, count, alpha=1.0, accumulate=True):
         """dst (+)= alpha * src over `count` contiguous f32 (gradient accumulation across backward passes; fill with
@@ -755,6 +784,10 @@ class Engine:
                                  for fn, a in self.tape if fn == self._bw_conv and a[0].conv.weight.requires_grad)
         for fn, args in reversed(self.tape):
             fn(*args)
+        for bid in list(self._riders):
+            gv, g, acc = self._riders.pop(bid)
+            self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
+            self.launches += 1
         self._reduce_wgrads()
         for p, ptr in self._pgrad_tmp.values():  # NHWC-accumulated gradients of [1,C,h,w] parameters -> NCHW
             _, c, h, w = p.shape
@@ -902,8 +935,15 @@ class Engine:
             if not self._wg_pool:
                 self._wg_pool.append(torch.cuda.Stream(self.device))
             side = self._wg_pool[0]
-            side.wait_stream(main)
-            self._wg_forked = True
+            snap = None
+            if os.environ.get("CGEN_WG_STRAYCHECK"):  # debugging: does the flushed batch write anywhere inside the arena?
+                torch.cuda.synchronize()
+                snap = [c.clone() for c in self.arena.chunks]
+            if os.environ.get("CGEN_WGRAD_BG_SERIAL"):  # debugging: same launches, but in line on the main stream
+                side = main
+            else:
+                side.wait_stream(main)
+                self._wg_forked = True
             if blob is not None and nl:
                 self.lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl, self.wgrad_bg_wgs, side.cuda_stream)
                 self.launches += nl
@@ -913,6 +953,12 @@ class Engine:
             self._wg_deferred = []
             if self.wgrad_bg_reduce:
                 self._reduce_events(side.cuda_stream)  # these partials are final: their reduction leaves the critical path too
+            if snap is not None:
+                torch.cuda.synchronize()
+                for k, (c0, c1) in enumerate(zip(snap, self.arena.chunks)):
+                    d = (c0 != c1).nonzero().flatten()
+                    print("straycheck chunk %d: %d arena bytes changed by the flushed batch (arena offset now %d of chunk %d)%s" % (
+                        k, d.numel(), self.arena.off, self.arena.ci, "" if not d.numel() else " first %d last %d" % (int(d[0]), int(d[-1]))), flush=True)
             return
         if blob is not None and nl:
             self.lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl, 0, self.stream)
@@ -1042,13 +1088,26 @@ class Engine:
 
     def _bw_reparam(self, q_loc, q_ls, p_loc, p_ls, z, logt, fb_col=None):
         gz = self.grad_read(z)
+        job = self._riders.pop(id(p_loc.base), None)  # (taken before grad_write would land it as a launch of its own)
         gql, a1 = self.grad_write(q_loc)
         gqs, a2 = self.grad_write(q_ls)
         gpl, a3 = self.grad_write(p_loc)
         gps, a4 = self.grad_write(p_ls)
         assert a1 == a2 and a3 == a4
-        self.lib.reparam_kl_bwd(self.dt, z.n, z.h, z.w, z.c, q_loc.cv(), q_ls.cv(), p_loc.cv(), p_ls.cv(), z.cv(), logt,
-                                gz.cv() if gz is not None else NULL_VIEW, self.kl_coef_ptr, 0,
-                                None if fb_col is None else self.kl_chan_ptr + 4 * fb_col, gql.cv(), gqs.cv(), gpl.cv(),
-                                gps.cv(), 1 if a1 else 0, 1 if a3 else 0, self.stream)
+        views = [q_loc, q_ls, p_loc, p_ls, z, gql, gqs, gpl, gps] + ([gz] if gz is not None else [])
+        if job is not None and not (z.c % 8 == 0 and all(self._v16(v) for v in views)
+                                    and (job[1].n, job[1].h, job[1].w) == (z.n, z.h, z.w)):
+            gv, g, acc = job  # not the 16-byte bf16 path after all: the copy is its own launch
+            self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
+            self.launches += 1
+            job = None
+        args = (self.dt, z.n, z.h, z.w, z.c, q_loc.cv(), q_ls.cv(), p_loc.cv(), p_ls.cv(), z.cv(), logt,
+                gz.cv() if gz is not None else NULL_VIEW, self.kl_coef_ptr, 0,
+                None if fb_col is None else self.kl_chan_ptr + 4 * fb_col, gql.cv(), gqs.cv(), gpl.cv(),
+                gps.cv(), 1 if a1 else 0, 1 if a3 else 0)
+        if job is None:
+            self.lib.reparam_kl_bwd(*args, self.stream)
+        else:
+            gv, g, acc = job
+            self.lib.reparam_kl_bwd_rider(*args, g.cv(), gv.cv(), 1 if acc else 0, self.stream)
         self.launches += 1

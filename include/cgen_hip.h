@@ -190,6 +190,16 @@ int cgen_reparam_kl_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t 
                         cgen_view p_loc, cgen_view p_ls, cgen_view z, float logt, cgen_view gz,
                         const float* kl_coef_dev, int32_t coef_stride, const float* kl_chan_scale, cgen_view g_q_loc,
                         cgen_view g_q_ls, cgen_view g_p_loc, cgen_view g_p_ls, int32_t acc_q, int32_t acc_p, cgen_stream_t);
+/* The same launch carrying a RIDER: extra workgroups copy (ride_acc = 0) or accumulate (1) the [n,h,w,ride_src.c] view
+ * ride_src into ride_dst.  In the decoder block  h = z_proj(z, pa) + h + p_feat  (vae.py:279-287) the gradient of the
+ * residual p_feat -- a channel slice of the prior Block's output -- is the gradient of h verbatim; it has to land in the
+ * prior output's gradient buffer next to the g_p_loc / g_p_ls this kernel writes, and used to be a launch of its own per
+ * decoder block.  bf16, every view 16-byte aligned with channel counts in multiples of 8 (CGEN_EINVAL otherwise). */
+int cgen_reparam_kl_bwd_rider(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls,
+                              cgen_view p_loc, cgen_view p_ls, cgen_view z, float logt, cgen_view gz,
+                              const float* kl_coef_dev, int32_t coef_stride, const float* kl_chan_scale, cgen_view g_q_loc,
+                              cgen_view g_q_ls, cgen_view g_p_loc, cgen_view g_p_ls, int32_t acc_q, int32_t acc_p,
+                              cgen_view ride_src, cgen_view ride_dst, int32_t ride_acc, cgen_stream_t);
 /* kl_chan_scale (optional, [c]): per-channel multiplier of the KL gradient -- the free-bits mask of this layer.
  *
  * Free bits (kl_free_bits > 0, vae.py:443-449).  S[b*out_stride + ch] = sum_{h,w} KL(q||p)[b,h,w,ch] of one layer

@@ -213,6 +213,40 @@ def test_dp_bench_path_two_gloo_ranks_on_one_gpu():
     assert d["opt_steps"] == 4 and "roofline" in d
 
 
+def test_backward_is_bit_reproducible_next_to_the_background_weight_gradient_kernel():
+    """Three backward passes of the ukbb192 model (bf16, background flush on) from identical state must give bit-identical
+    gradients.  They did not while packed-f32 instructions were in the kernels: a co-resident MFMA wave of the background
+    weight-gradient kernel corrupts them (tools/coexec_probe.py); build.sh keeps them out of every kernel."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    m, hp = bench.build_model("ukbb192", "bf16")
+    m = m.cuda().train()
+    x, pa = bench.synth_batch("ukbb192", hp, 8, "cuda", 1)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(torch.randn(p.shape, generator=g).cuda() * 0.02)
+    eng = m.engine()
+    eng.rng_ptr()
+    assert eng.wgrad_flush_frac, "the background flush is the default"
+    runs = []
+    for _ in range(3):
+        m.zero_grad()
+        eng.rng.copy_(torch.tensor([11, 0], dtype=torch.int64, device=eng.rng.device))
+        out = m(x, pa, beta=1.0)
+        out["elbo"].backward()
+        torch.cuda.synchronize()
+        runs.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    for r in runs[1:]:
+        bad = [n for n in runs[0] if not torch.equal(runs[0][n], r[n])]
+        assert not bad, (len(bad), bad[:4])
+
+
 def test_free_bits_under_data_parallelism():
     """kl_free_bits > 0 with two ranks: the per-channel KL sums are all-reduced inside the forward pass, so the
     floored KL and the rank-averaged gradients equal the single-process result on the concatenated batch."""

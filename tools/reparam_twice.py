@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Run every reparam_kl_bwd of a real backward pass twice (second time into a shadow buffer) and compare: is the kernel's
+result stable while the background weight-gradient kernel is running?"""
+import copy
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import bench
+from causal_gen_amd import _lib
+
+m, hp = bench.build_model("ukbb192", "bf16")
+m = m.cuda().train()
+x, pa = bench.synth_batch("ukbb192", hp, 8, "cuda", 1)
+eng = m.engine()
+out = m(x, pa, beta=1.0)
+out["elbo"].backward()
+torch.cuda.synchronize()
+orig = eng.lib.reparam_kl_bwd
+log = []
+
+
+def chunk_of(ptr):
+    for ch in eng.arena.chunks:
+        if ch.data_ptr() <= ptr < ch.data_ptr() + ch.numel():
+            return ch
+    return None
+
+
+zlog = []
+zlast = []
+
+
+def snap_view(v, n):
+    ch = chunk_of(v.p)
+    off = v.p - ch.data_ptr()
+    return ch[off:off + n * v.sn * 2].clone()
+
+
+def twice(*a):
+    z0 = [snap_view(a[i], a[1]) for i in (5, 6, 7, 8, 9, 11)]
+    r = orig(*a)
+    z1 = [snap_view(a[i], a[1]) for i in (5, 6, 7, 8, 9, 11)]
+    zlog.append((z0, z1))
+    zlast.append(z0)
+    a = list(a)
+    # outputs: g_q_loc (15), g_q_ls (16), g_p_loc (17), g_p_ls (18); acc flags 19, 20
+    gq = a[15]
+    n, h, w, c = a[1], a[2], a[3], a[4]
+    base = min(a[15].p, a[16].p)
+    nbytes = n * gq.sn * 2
+    ch = chunk_of(base)
+    if ch is None or a[19] or a[20]:
+        return r
+    shadow = torch.zeros(nbytes + 64, dtype=torch.uint8, device="cuda")
+    sbase = (shadow.data_ptr() + 15) // 16 * 16
+    delta = sbase - base
+    b2 = list(a)
+    for i in (15, 16):
+        v = a[i]
+        b2[i] = _lib.View(v.p + delta, v.sn, v.sh, v.sw, v.c, v.cpad)
+    # prior outputs go to a throw-away buffer too
+    pb = min(a[17].p, a[18].p)
+    pshadow = torch.zeros(n * a[17].sn * 2 + 64, dtype=torch.uint8, device="cuda")
+    pd = (pshadow.data_ptr() + 15) // 16 * 16 - pb
+    for i in (17, 18):
+        v = a[i]
+        b2[i] = _lib.View(v.p + pd, v.sn, v.sh, v.sw, v.c, v.cpad)
+    orig(*b2)
+    off = base - ch.data_ptr()
+    log.append((len(log), (n, h, w, c), ch[off:off + nbytes].clone(), shadow, sbase - shadow.data_ptr(), nbytes))
+    return r
+
+
+eng.lib.reparam_kl_bwd = twice
+os.environ.setdefault("CGEN_RIDER", "0")
+eng.ride = False
+for it in range(4):
+    log.clear()
+    zlast.clear()
+    m.zero_grad()
+    out = m(x, pa, beta=1.0)
+    out["elbo"].backward()
+    torch.cuda.synchronize()
+    bad = []
+    for k, shape, first, shadow, so, nb in log:
+        second = shadow[so:so + nb]
+        # compare only the two 16-channel slices the kernel writes (the rest of the buffer is other tensors' business)
+        if not torch.equal(first, second):
+            d = (first.view(torch.int16) != second.view(torch.int16)).nonzero().flatten()
+            bad.append((k, shape, int(d.numel()), d[:8].tolist()))
+            f16, s16 = first.view(torch.bfloat16).float(), second.view(torch.bfloat16).float()
+            i0 = int(d[0])
+            print("   call %d idx %d: first-run values %s | second-run values %s (8-channel group around it: first %s second %s)" % (
+                k, i0, f16[d[:4]].tolist(), s16[d[:4]].tolist(), f16[i0 // 8 * 8: i0 // 8 * 8 + 8].tolist(), s16[i0 // 8 * 8: i0 // 8 * 8 + 8].tolist()))
+            # third opinion: torch recomputation of g_q_ls at that element
+            zin = zlast[k]
+            names = ["q_loc", "q_ls", "p_loc", "p_ls", "z", "gz"]
+            t = {nm: v.view(torch.bfloat16).float() for nm, v in zip(names, zin)}
+            pix, chn = i0 // 32, i0 % 32 - 16
+            j = pix * 16 + chn
+            e2q, ie2p = torch.exp(2 * t["q_ls"][j]), torch.exp(-2 * t["p_ls"][j])
+            print("      inputs at that element: q_ls %.6g p_ls %.6g q_loc %.6g z %.6g gz %.6g -> (e2q*ie2p-1) %.6g, gz*(z-q_loc) %.6g" % (
+                float(t["q_ls"][j]), float(t["p_ls"][j]), float(t["q_loc"][j]), float(t["z"][j]), float(t["gz"][j]), float(e2q * ie2p - 1), float(t["gz"][j] * (t["z"][j] - t["q_loc"][j]))))
+    names = ["q_loc", "q_ls", "p_loc", "p_ls", "z", "gz"]
+    for k, (z0, z1) in enumerate(zlog):
+        for nm, u, v in zip(names, z0, z1):
+            if not torch.equal(u, v):
+                d = (u.view(torch.int16) != v.view(torch.int16)).nonzero().flatten()
+                print("   call %d: INPUT %s changed between the snapshots around the kernel: %d elements, first %s" % (k, nm, d.numel(), d[:6].tolist()))
+    zlog.clear()
+    print("iter %d: %d reparam backward calls, %d gave different results on the second run: %s" % (it, len(log), len(bad), bad[:4]))
