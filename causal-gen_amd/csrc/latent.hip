@@ -165,25 +165,6 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_vec8_kernel(LatP p) {
   if (threadIdx.x == 0) p.kl_part[(int64_t)b * p.kl_stride + chunk] = tot;
 }
 
-#ifdef CGEN_SOFT_EXP
-#define CGEN_EXP exp_valu
-#else
-#define CGEN_EXP expf
-#endif
-// exp without the transcendental unit (experiment): 2^(x log2 e) with a degree-6 polynomial on [-0.5, 0.5] and an exponent add
-__device__ __forceinline__ float exp_valu(float x) {
-  const float t = fminf(fmaxf(x * 1.44269504088896341f, -125.f), 125.f);
-  const float n = rintf(t), f = t - n;
-  float pl = 1.53533619e-4f;
-  pl = fmaf(pl, f, 1.33335581e-3f);
-  pl = fmaf(pl, f, 9.61812911e-3f);
-  pl = fmaf(pl, f, 5.55041087e-2f);
-  pl = fmaf(pl, f, 2.40226507e-1f);
-  pl = fmaf(pl, f, 6.93147181e-1f);
-  pl = fmaf(pl, f, 1.f);
-  return __int_as_float(__float_as_int(pl) + ((int)n << 23));
-}
-
 __global__ __launch_bounds__(256) void reparam_kl_bwd_vec8_kernel(LatBwdP p) {
   if ((int)blockIdx.x >= p.main_blocks) {  // rider blocks
     const int rg = p.ride_c >> 3, per = p.h * p.w * rg;
@@ -228,7 +209,7 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_vec8_kernel(LatBwdP p) {
     for (int k = 0; k < 8; ++k) {
       const float kk = k0 * (p.chan_scale ? p.chan_scale[ch + k] : 1.f);
       const float q = qs[k] + p.logt, pp = ps[k] + p.logt;
-      const float e2q = CGEN_EXP(2.f * q), ie2p = CGEN_EXP(-2.f * pp), d = ql[k] - pl[k];
+      const float e2q = expf(2.f * q), ie2p = expf(-2.f * pp), d = ql[k] - pl[k];
       float gql = kk * d * ie2p, gqs = kk * (e2q * ie2p - 1.f);
       o3[k] = -kk * d * ie2p;
       o4[k] = kk * (1.f - (e2q + d * d) * ie2p);
