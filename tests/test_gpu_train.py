@@ -245,6 +245,16 @@ def test_backward_is_bit_reproducible_next_to_the_background_weight_gradient_ker
     for r in runs[1:]:
         bad = [n for n in runs[0] if not torch.equal(runs[0][n], r[n])]
         assert not bad, (len(bad), bad[:4])
+    # the launch-structure features change WHERE and WHEN work is launched, never the arithmetic: switching the background
+    # flush, the reparam rider and the side-stream reduce off gives the same bits
+    eng.wgrad_flush_frac, eng.ride, eng.wgrad_bg_reduce = [], False, False
+    m.zero_grad()
+    eng.rng.copy_(torch.tensor([11, 0], dtype=torch.int64, device=eng.rng.device))
+    out = m(x, pa, beta=1.0)
+    out["elbo"].backward()
+    torch.cuda.synchronize()
+    bad = [n for n, p in m.named_parameters() if p.grad is not None and not torch.equal(runs[0][n], p.grad)]
+    assert not bad, (len(bad), bad[:4])
 
 
 def test_free_bits_under_data_parallelism():
