@@ -9,6 +9,8 @@ the two latent replays, the pixel-noise step and the particle statistics -- runs
 """
 from typing import Dict, Optional
 
+import os
+
 import torch
 from torch import Tensor, nn
 
@@ -59,11 +61,15 @@ def counterfactual(vae, x, parents, cf_parents, t_abduct=1.0, te_cf=False, alpha
     zs = vae.abduct(x, parents, t=t_abduct)
     if vae.cond_prior:
         zs = [z["z"] for z in zs]
-    rec_loc, rec_scale = vae.forward_latents(zs, parents)
-    cf_zs = zs
-    if te_cf and vae.cond_prior:
-        cf_zs = vae.abduct(x, parents, cf_parents=cf_parents, alpha=alpha, t=t_abduct)
-    cf_loc, cf_scale = vae.forward_latents(cf_zs, cf_parents)
+    if not (te_cf and vae.cond_prior) and os.environ.get("CGEN_CF_PAIR", "1") != "0" and hasattr(vae, "forward_latents_pair"):
+        # the two replays share their latents: two concurrent streams
+        (rec_loc, rec_scale), (cf_loc, cf_scale) = vae.forward_latents_pair(zs, parents, cf_parents)
+    else:
+        rec_loc, rec_scale = vae.forward_latents(zs, parents)
+        cf_zs = zs
+        if te_cf and vae.cond_prior:
+            cf_zs = vae.abduct(x, parents, cf_parents=cf_parents, alpha=alpha, t=t_abduct)
+        cf_loc, cf_scale = vae.forward_latents(cf_zs, cf_parents)
     if t_u is not None:
         cf_scale = cf_scale * t_u
     return cf_pixels(x.to(rec_loc.device), rec_loc, rec_scale, cf_loc, cf_scale)

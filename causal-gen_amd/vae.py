@@ -694,6 +694,28 @@ class HVAE(nn.Module):
         return ins
 
     @torch.no_grad()
+    def forward_latents_pair(self, latents: List[Tensor], parents_a: Tensor, parents_b: Tensor, t: Optional[float] = None):
+        """Two replays of the SAME latents under two parent settings (dscm.py:53-54: reconstruction and counterfactual), as
+        two concurrent streams: each replay is a ~400-kernel latency chain that fills a fraction of the chip, and the two
+        share nothing but read-only inputs.  Returns ((loc_a, scale_a), (loc_b, scale_b)) == (forward_latents(l, a),
+        forward_latents(l, b))."""
+        eng = self._begin_inference()
+        pa_a = eng.from_nchw(parents_a.to(eng.device, torch.float32))
+        pa_b = eng.from_nchw(parents_b.to(eng.device, torch.float32))
+        lat = self._latents_in(eng, latents)
+
+        def replay(pa):
+            h, _ = self._decode(eng, pa, latents=lat, t=t)
+            return self._sample_likelihood(eng, h, True, t)
+
+        if not eng.fork_side():
+            return replay(pa_a), replay(pa_b)
+        ra = eng.on_side(lambda: replay(pa_a))
+        rb = replay(pa_b)
+        eng.join_side()
+        return ra, rb
+
+    @torch.no_grad()
     def forward_latents(self, latents: List[Tensor], parents: Tensor, t: Optional[float] = None):
         """vae.py:516-522: replay (possibly partial) latents under `parents`; returns (loc in [-1,1], scale)."""
         eng = self._begin_inference()
