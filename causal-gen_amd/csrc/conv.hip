@@ -1736,7 +1736,7 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
       const int e02 = d02 - 2 * d01;  // offset(dx) = dx * d01 + (dx == 2) * e02: two multiply-adds, no compare/select chain
 #pragma unroll
       for (int i = 0; i < PX_MAXKS; ++i) {
-        if (KS > 1) koff[i] = (int)__umul24(kt[i] & 3, d01) + (int)__umul24((kt[i] >> 2) & 1, e02) + ((kt[i] >> 3) + px0);
+        if (KS > 1) koff[i] = (int)__umul24(kt[i] & 3, d01) + __mul24((kt[i] >> 2) & 1, e02) + ((kt[i] >> 3) + px0);  // e02 < 0 when only x+1 crosses a piece
         else koff[i] = (kt[i] >> 3) + px0;
       }
     }

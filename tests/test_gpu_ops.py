@@ -42,6 +42,16 @@ CONV_CASES = [
     (2, 16, 32, [16], 96, 3, 2, True),
     (3, 40, 24, [8], 64, 3, 1, False),
     (2, 16, 16, [200], 16, 1, 0, False),
+    # model-size shapes (px / ws / packed-wgrad kernels; > 6000 pixels so the small-image kernel does not take them).
+    # [32] x 3x3 has 12 pixels per LDS piece: column 11 of a tile reads its x+1 / x+2 neighbours across a piece boundary
+    (8, 32, 32, [32], 64, 3, 1, True),
+    (1, 96, 96, [32], 8, 3, 1, False),
+    (8, 32, 32, [48], 192, 3, 0, False),
+    (8, 32, 32, [64], 16, 3, 2, True),
+    (2, 64, 64, [56], 24, 3, 1, False),
+    (4, 48, 48, [96, 4, 96], 24, 3, 1, False),
+    (8, 32, 32, [16, 96], 96, 1, 0, True),
+    (8, 32, 32, [24], 160, 3, 1, False),
 ]
 
 
