@@ -257,6 +257,49 @@ def test_backward_is_bit_reproducible_next_to_the_background_weight_gradient_ker
     assert not bad, (len(bad), bad[:4])
 
 
+def test_full_size_bf16_path_agrees_with_the_f32_parity_path():
+    """ukbb192 at full size (the shapes the lean bf16 kernels are selected for; the golden fixtures are tiny models):
+    the throughput path and the f32 parity path must agree on the ELBO and on every parameter gradient's direction."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    res = {}
+    for dt in ("f32", "bf16"):
+        m, hp = bench.build_model("ukbb192", dt)
+        m = m.cuda().train()
+        g = torch.Generator().manual_seed(3)
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(torch.randn(p.shape, generator=g).cuda() * 0.02)
+        x, pa = bench.synth_batch("ukbb192", hp, 2, "cuda", 1)
+        eng = m.engine()
+        eng.rng_ptr()
+        eng.rng.copy_(torch.tensor([11, 0], dtype=torch.int64, device=eng.rng.device))
+        out = m(x, pa, beta=1.0)
+        out["elbo"].backward()
+        torch.cuda.synchronize()
+        res[dt] = ({k: float(out[k]) for k in ("elbo", "nll", "kl")},
+                   {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
+        del m, eng
+    for k in ("elbo", "nll", "kl"):
+        a, b = res["f32"][0][k], res["bf16"][0][k]
+        assert abs(a - b) <= 3e-3 * abs(a), (k, a, b)
+    errs, cosines = [], []
+    for n, gf in res["f32"][1].items():
+        gb = res["bf16"][1][n]
+        den = float(gf.norm())
+        if den == 0:
+            continue
+        errs.append(float((gb - gf).norm()) / den)
+        cosines.append(float((gb * gf).sum()) / (den * float(gb.norm()) + 1e-30))
+    errs.sort()
+    assert errs[len(errs) // 2] < 0.02 and errs[-1] < 0.2 and min(cosines) > 0.985, (errs[len(errs) // 2], errs[-1], min(cosines))
+
+
 def test_free_bits_under_data_parallelism():
     """kl_free_bits > 0 with two ranks: the per-channel KL sums are all-reduced inside the forward pass, so the
     floored KL and the rank-averaged gradients equal the single-process result on the concatenated batch."""

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Full-size model through the bf16 throughput path and the f32 parity path: ELBO and per-parameter gradient agreement."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import bench
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "ukbb192"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+res = {}
+for dt in ("f32", "bf16"):
+    m, hp = bench.build_model(cfg, dt)
+    m = m.cuda().train()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(torch.randn(p.shape, generator=g).cuda() * 0.02)
+    x, pa = bench.synth_batch(cfg, hp, B, "cuda", 1)
+    eng = m.engine()
+    eng.rng_ptr()
+    eng.rng.copy_(torch.tensor([11, 0], dtype=torch.int64, device=eng.rng.device))
+    out = m(x, pa, beta=1.0)
+    out["elbo"].backward()
+    torch.cuda.synchronize()
+    res[dt] = ({k: float(out[k]) for k in ("elbo", "nll", "kl")}, {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
+    del m
+print("f32 ", res["f32"][0])
+print("bf16", res["bf16"][0])
+errs = []
+for n, gf in res["f32"][1].items():
+    gb = res["bf16"][1][n]
+    den = float(gf.norm())
+    if den == 0:
+        continue
+    errs.append((float((gb - gf).norm()) / den, float((gb * gf).sum()) / (den * float(gb.norm()) + 1e-30), n, gf.numel()))
+errs.sort(reverse=True)
+print("params %d; relative L2 error of the bf16 gradient: max %.4f median %.4f; min cosine %.5f" % (len(errs), errs[0][0], errs[len(errs) // 2][0], min(e[1] for e in errs)))
+for e in errs[:8]:
+    print("   %.4f cos %.5f %s (%d)" % e)
