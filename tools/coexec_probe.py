@@ -95,3 +95,43 @@ blob = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
 torch.cuda.synchronize()
 for cap in (304,):
     trial("wgrad neighbour, cap %d" % cap, lambda: [lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl.value, cap, side.cuda_stream) for _ in range(3)])
+
+# ---- conv kernels as victims next to the weight-gradient neighbour (address arithmetic, epilogue, MFMA of their own)
+def conv_trial(name, N, R, ci, co, ks, reps=600):
+    cv = torch.nn.ModuleList([torch.nn.Conv2d(ci, co, ks, padding=ks // 2)]).cuda()
+    e2 = Engine("cuda", "bf16")
+    st = [ConvSite("v0", cv[0], [ci], [True], 0)]
+    e2.bind(cv, st)
+    e2.begin()
+    e2.prepare_weights(force=True)
+    xin = e2.new(N, R, R, ci)
+    e2.fill(xin, 0.37)
+    gg = torch.Generator().manual_seed(1)
+    xt = torch.randn(N, ci, R, R, generator=gg).cuda()
+    xin = e2.from_nchw(xt)
+    outs = [e2.conv(st[0], [xin], 1) for _ in range(8)]
+    torch.cuda.synchronize()
+    nb = outs[0].n * outs[0].sn * outs[0].es
+
+    def snap(y):
+        for ch in e2.arena.chunks:
+            off = y.ptr - ch.data_ptr()
+            if 0 <= off and off + nb <= ch.numel():
+                return ch[off:off + nb]
+    ref = snap(outs[0]).clone()
+    bad = 0
+    neighbour = lambda: [lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl.value, 304, side.cuda_stream) for _ in range(3)]
+    for i in range(reps):
+        if i % 10 == 0:
+            neighbour()
+        y = outs[i % 8]
+        e2.conv(st[0], [xin], 1, out=y)
+        if i % 8 == 7:
+            torch.cuda.synchronize()
+            bad += sum(1 for o in outs if not torch.equal(snap(o), ref))
+    print("%-28s: %d of %d conv executions differ next to the wgrad neighbour" % (name, bad, reps), flush=True)
+
+
+conv_trial("px 32->128 3x3 @24x24 N32", 32, 24, 32, 128, 3)
+conv_trial("ws 128->32 3x3 @24x24 N32", 32, 24, 128, 32, 3)
+conv_trial("smallp 160->40 3x3 @12x12", 32, 12, 160, 40, 3)

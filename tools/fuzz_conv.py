@@ -17,8 +17,8 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 widths = [8, 16, 24, 32, 40, 48, 64, 96, 128, 160, 192, 256]
 fails = 0
 for i in range(n_cases):
-    res = rng.choice([1, 2, 4, 6, 12, 24, 48, 96])
-    N = rng.choice([1, 2, 8, 32]) if res <= 48 else rng.choice([1, 2, 4])
+    res = rng.choice([1, 2, 4, 6, 8, 12, 16, 24, 32, 48, 96])
+    N = rng.choice([1, 2, 8, 32, 64, 256]) if res <= 16 else (rng.choice([1, 2, 8, 32]) if res <= 48 else rng.choice([1, 2, 4]))
     kind = rng.random()
     if kind < 0.35:       # bottleneck in: C -> C/4
         c = rng.choice(widths[3:]); segc, Co = [c], max(4, c // 4)
@@ -37,6 +37,7 @@ for i in range(n_cases):
         H, W = res, res if rng.random() < 0.8 else max(1, res - rng.choice([1, 3]))
     case = (N, H, W, segc, Co, ks, act, with_res)
     for dtype in (["bf16"] if rng.random() < 0.8 else ["bf16", "f32"]):
+        print("run  %s %s" % (dtype, case), flush=True)
         try:
             test_conv_fwd_bwd(case, dtype)
             print("ok   %s %s" % (dtype, case), flush=True)
