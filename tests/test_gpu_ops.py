@@ -366,3 +366,44 @@ def test_reparam_kl_bf16_vec8_path_matches_scalar_formula():
     za = nhwc_to_torch(eng2, eng2.reparam_kl(big[0], big[1], big[2], big[3], None, 7, 0.0, k2.data_ptr(), nch2))
     zb = nhwc_to_torch(eng2, eng2.reparam_kl(big[0], big[1], big[2], big[3], None, 7, 0.0, k2.data_ptr(), nch2))
     assert torch.equal(za, zb) and abs(za.mean().item()) < 1e-2 and abs(za.std().item() - 1.0) < 1e-2
+
+
+def test_reparam_kl_bf16_vec8_on_channel_slices_at_model_size():
+    """As the model calls it: q_loc | q_ls and p_loc | p_ls are channel slices of 32- and (32+C)-channel conv outputs
+    (pixel stride != 16), 4 x 24 x 24 pixels; forward z / KL and all four gradients against the f32 formula."""
+    from oracle import hvae_ref
+
+    g = torch.Generator().manual_seed(8)
+    N, Cc, H, W, Cf = 4, 16, 24, 24, 40
+    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    q = bf(torch.randn(N, 2 * Cc, H, W, generator=g) * 0.5)
+    p = bf(torch.randn(N, 2 * Cc + Cf, H, W, generator=g) * 0.5)
+    eps, gz = bf(torch.randn(N, Cc, H, W, generator=g)), bf(torch.randn(N, Cc, H, W, generator=g))
+    leaves = [t.clone().requires_grad_(True) for t in (q[:, :Cc], q[:, Cc:] - 0.5, p[:, :Cc], p[:, Cc:2 * Cc])]
+    q = torch.cat([leaves[0].detach(), leaves[1].detach()], 1)  # (the shifted logscale is what the kernel sees too)
+    q = bf(q)
+    leaves[1] = q[:, Cc:].clone().requires_grad_(True)
+    z_ref = leaves[0] + leaves[1].exp() * eps
+    kl_ref = hvae_ref.gaussian_kl(*leaves)
+    coef = 0.37
+    ((z_ref * gz).sum() + coef * kl_ref.sum()).backward()
+    eng, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]], dtype="bf16")
+    eng.recording = True
+    tq, tp = eng.from_nchw(q.cuda(), rg=True), eng.from_nchw(p.cuda(), rg=True)
+    tq.rg = tp.rg = True
+    ts = [tq.chan(0, Cc), tq.chan(Cc, 2 * Cc), tp.chan(0, Cc), tp.chan(Cc, 2 * Cc)]
+    nch = eng.lib.reparam_kl_chunks(H, W, Cc)
+    klp = torch.zeros(N * nch, device="cuda")
+    z = eng.reparam_kl(ts[0], ts[1], ts[2], ts[3], eng.from_nchw(eps.cuda()), 1, 0.0, klp.data_ptr(), nch)
+    torch.testing.assert_close(nhwc_to_torch(eng, z), z_ref.detach(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(klp.view(N, nch).sum(1).cpu(), kl_ref.detach().sum(dim=(1, 2, 3)), rtol=2e-4, atol=1e-2)
+    gzv = eng.seed_grad(z)
+    eng.lib.axpby(eng.dt, N, H, W, eng.from_nchw(gz.cuda()).cv(), gzv.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
+    cf = torch.tensor([0.0, coef], device="cuda")
+    eng.kl_coef_ptr = cf.data_ptr() + 4
+    eng.backward()
+    torch.cuda.synchronize()
+    gq, gp = nhwc_to_torch(eng, eng.grad_read(tq)), nhwc_to_torch(eng, eng.grad_read(tp))
+    for got, leaf in ((gq[:, :Cc], leaves[0]), (gq[:, Cc:], leaves[1]), (gp[:, :Cc], leaves[2]), (gp[:, Cc:2 * Cc], leaves[3])):
+        assert (got - leaf.grad).abs().max().item() < 2e-2 * leaf.grad.abs().max().item()
+    assert gp[:, 2 * Cc:].abs().max().item() == 0.0  # the feature channels of the prior output received no gradient here
