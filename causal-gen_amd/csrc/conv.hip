@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvP p) {
       const int gi = tid + i * 256;
       if (gi < WGROUPS) {
         const int r = gi / (CONV_BK / G), kg = gi % (CONV_BK / G);
-        wr[i] = *(const uint4*)(wbase + (size_t)(co_base + r) * p.krow + kg * G);
+        wr[i] = *(const uint4*)(wbase + (size_t)min(co_base + r, ((p.Co + 15) & ~15) - 1) * p.krow + kg * G);  // rows past the image: clamped (never stored)
       }
     }
   };
@@ -543,7 +543,9 @@ __global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP 
       const int gi = pu * 64 + lane;
       const int r = fdiv(gi, q.d_gprw), k = (gi - r * gpr_w) * G;
       if (gi < wgroups && k < kreal) {
-        const T* row = (const T*)p.w + (size_t)(co_base + r) * p.krow;
+        // rows past the image (the last output-channel tile of a ragged Co) are clamped: their outputs are never stored, and
+        // reading past the LAST image of the buffer faulted once in ~2 500 fuzz cases (tools/fuzz_conv.py 150 24)
+        const T* row = (const T*)p.w + (size_t)min(co_base + r, ((p.Co + 15) & ~15) - 1) * p.krow;
         const T* src;
         if (single) {
           src = row + k;

@@ -907,6 +907,12 @@ class Engine:
                 tot += c
                 line.append("%dx%d:%.0f" % (a.h, a.ks, tot / 1e9))
             print("wgrad batch (bg=%s): %d problems, %.0f GF: %s" % (background, n, tot / 1e9, " ".join(line)), flush=True)
+            print("   arena chunks %s; partial buffers %s; flat_g %s" % (
+                ["%x-%x" % (c.data_ptr(), c.data_ptr() + c.numel()) for c in self.arena.chunks],
+                ["%x-%x" % (a.partial_w, a.partial_w + 1) for a in args][:4],
+                "%x-%x" % (self.flat_g.data_ptr(), self.flat_g.data_ptr() + 4 * self.flat_g.numel())), flush=True)
+            for key, (buf, ns) in list(self._partials.items())[-4:]:
+                print("   partial %s: %x-%x nsplit %d" % (key, buf.data_ptr(), buf.data_ptr() + 4 * buf.numel(), ns), flush=True)
         arr = (_lib.WgradArgs * n)(*args)
         key = bytes(arr)
         ent = self._wg_batches.get(key)
@@ -939,6 +945,12 @@ class Engine:
             if os.environ.get("CGEN_WG_STRAYCHECK"):  # debugging: does the flushed batch write anywhere inside the arena?
                 torch.cuda.synchronize()
                 snap = [c.clone() for c in self.arena.chunks]
+            # problems the packed kernel does not serve (f32, < 3x3 images) stay in line on the main stream: only the
+            # packed launch goes to the background (the generic kernel on the side stream was the one configuration in
+            # which tools/fuzz_conv.py produced a GPU memory fault; it is also a negligible share of the bf16 work)
+            for i in rest:
+                self.lib.conv2d_wgrad(C.byref(args[i]), self.stream)
+                self.launches += 1
             if os.environ.get("CGEN_WGRAD_BG_SERIAL"):  # debugging: same launches, but in line on the main stream
                 side = main
             else:
@@ -947,9 +959,6 @@ class Engine:
             if blob is not None and nl:
                 self.lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl, self.wgrad_bg_wgs, side.cuda_stream)
                 self.launches += nl
-            for i in rest:
-                self.lib.conv2d_wgrad(C.byref(args[i]), side.cuda_stream)
-                self.launches += 1
             self._wg_deferred = []
             if self.wgrad_bg_reduce:
                 self._reduce_events(side.cuda_stream)  # these partials are final: their reduction leaves the critical path too

@@ -14,6 +14,7 @@ from test_gpu_ops import test_conv_fwd_bwd  # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # generate the same sequence but execute only cases >= skip
 widths = [8, 16, 24, 32, 40, 48, 64, 96, 128, 160, 192, 256]
 fails = 0
 for i in range(n_cases):
@@ -37,6 +38,8 @@ for i in range(n_cases):
         H, W = res, res if rng.random() < 0.8 else max(1, res - rng.choice([1, 3]))
     case = (N, H, W, segc, Co, ks, act, with_res)
     for dtype in (["bf16"] if rng.random() < 0.8 else ["bf16", "f32"]):
+        if i < skip:
+            continue
         print("run  %s %s" % (dtype, case), flush=True)
         try:
             test_conv_fwd_bwd(case, dtype)
