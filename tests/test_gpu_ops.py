@@ -407,3 +407,36 @@ def test_reparam_kl_bf16_vec8_on_channel_slices_at_model_size():
     for got, leaf in ((gq[:, :Cc], leaves[0]), (gq[:, Cc:], leaves[1]), (gp[:, :Cc], leaves[2]), (gp[:, Cc:2 * Cc], leaves[3])):
         assert (got - leaf.grad).abs().max().item() < 2e-2 * leaf.grad.abs().max().item()
     assert gp[:, 2 * Cc:].abs().max().item() == 0.0  # the feature channels of the prior output received no gradient here
+
+
+def _model_like_cases(n, seed):
+    """Random conv cases at model-like sizes (the generator of tools/fuzz_conv.py): bottleneck in / out, cat[h, pa, acts],
+    z_proj-like; resolutions 1 .. 96, batch up to 256 at low resolution; they sweep the kernel-selection space."""
+    import random
+
+    rng = random.Random(seed)
+    widths = [8, 16, 24, 32, 40, 48, 64, 96, 128, 160, 192, 256]
+    out = []
+    for _ in range(n):
+        res = rng.choice([1, 2, 4, 6, 8, 12, 16, 24, 32, 48, 96])
+        N = rng.choice([1, 2, 8, 32, 64, 256]) if res <= 16 else (rng.choice([1, 2, 8, 32]) if res <= 48 else rng.choice([1, 2, 4]))
+        kind = rng.random()
+        if kind < 0.35:
+            c = rng.choice(widths[3:]); segc, Co = [c], max(4, c // 4)
+        elif kind < 0.65:
+            c = rng.choice(widths[3:]); segc, Co = [max(4, c // 4)], c
+        elif kind < 0.85:
+            c = rng.choice(widths[3:10]); segc, Co = [c, rng.choice([4, 6, 12]), c], max(8, c // 4)
+        else:
+            c = rng.choice(widths[3:]); segc, Co = [16, rng.choice([4, c])], c
+        ks = 1 if (res <= 2 or rng.random() < 0.3) else 3
+        act = rng.choice([0, 1, 1, 2])
+        with_res = rng.random() < 0.4
+        H, W = (1, 1) if res == 1 else (res, res if rng.random() < 0.8 else max(1, res - rng.choice([1, 3])))
+        out.append(((N, H, W, segc, Co, ks, act, with_res), "bf16" if rng.random() < 0.8 else "f32"))
+    return out
+
+
+@pytest.mark.parametrize("case,dtype", _model_like_cases(28, 5))
+def test_conv_fwd_bwd_model_like_shapes(case, dtype):
+    test_conv_fwd_bwd(case, dtype)
