@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Random HVAE architectures through the bf16 throughput path and the f32 parity path (same weights, same noise): ELBO and
+per-parameter gradient agreement.  The graph shape changes with every case (block counts, widths, z_dim, light / default
+blocks, cond_prior, q_correction, free bits, RGB, DMoL), which exercises the engine's gradient bookkeeping (adoption,
+out-of-place accumulation, riders, background flush) beyond the presets.  usage: python tools/fuzz_model.py [n] [seed]"""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from causal_gen_amd import dmol, vae
+from causal_gen_amd.hps import setup_hparams
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+fails = 0
+for case in range(n):
+    R = rng.choice([32, 48, 64])
+    res, r = [R], R
+    while r > 4 and len(res) < 4:
+        r //= 2
+        res.append(r)
+    res.append(1)
+    widths = sorted(rng.choice([16, 24, 32]) * (k + 1) for k in range(len(res)))  # non-decreasing with depth, as every preset
+    nb = [rng.choice([1, 2, 3]) for _ in res]
+    enc = ",".join("%db%dd%d" % (rr, b, (res[i] // res[i + 1]) if i + 1 < len(res) else 1) for i, (rr, b) in enumerate(zip(res, nb)))
+    enc = ",".join(enc.split(",")[:-1] + ["1b%d" % nb[-1]])
+    dec = ",".join("%db%d" % (rr, rng.choice([1, 2, 3])) for rr in reversed(res))
+    light = rng.random() < 0.5
+    C = rng.choice([1, 3])
+    ov = dict(input_res=R, enc_arch=enc, dec_arch=dec, widths=widths, z_dim=rng.choice([8, 16]), z_max_res=rng.choice([R, R // 2]),
+              bias_max_res=R, input_channels=C, context_dim=rng.choice([4, 6, 12]), cond_prior=rng.random() < 0.5,
+              q_correction=rng.random() < 0.3, kl_free_bits=rng.choice([0.0, 0.0, 0.05]))
+    name = "ukbb192" if light else "morphomnist"
+    use_dmol = C == 3 and rng.random() < 0.5
+    B = rng.choice([2, 8, 16])
+    outs = {}
+    try:
+        for dt in ("f32", "bf16"):
+            hp = setup_hparams(name, **ov)
+            torch.manual_seed(case)
+            m = vae.HVAE(hp)
+            if use_dmol:
+                m.likelihood = dmol.DmolNet(hp)
+            g = torch.Generator().manual_seed(100 + case)
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.add_(torch.randn(p.shape, generator=g) * 0.02)
+            m.compute_dtype = dt
+            m = m.cuda().eval() if rng.random() < 0 else m.cuda().train()
+            type(m.decoder).drop_cond  # noqa: B018
+            if hp.cond_prior:
+                m.decoder.__dict__["drop_cond"] = lambda: (1, 1)  # no conditioning dropout: both runs must see the same graph
+            x = ((torch.randint(0, 256, (B, C, R, R), generator=g).float() - 127.5) / 127.5).cuda()
+            pa = torch.randn(B, hp.context_dim, generator=g)[..., None, None].repeat(1, 1, R, R).cuda()
+            eng = m.engine()
+            eng.rng_ptr()
+            eng.rng.copy_(torch.tensor([5, 0], dtype=torch.int64, device=eng.rng.device))
+            out = m(x, pa, beta=2.0)
+            out["elbo"].backward()
+            torch.cuda.synchronize()
+            outs[dt] = ({k: float(out[k]) for k in ("elbo", "nll", "kl")}, {nm: p.grad.detach().float().cpu() for nm, p in m.named_parameters() if p.grad is not None})
+            del m, eng
+        a, b = outs["f32"], outs["bf16"]
+        rel = max(abs(a[0][k] - b[0][k]) / max(abs(a[0][k]), 1e-6) for k in ("elbo", "nll"))
+        errs, cos = [], []
+        for nm, gf in a[1].items():
+            den = float(gf.norm())
+            if den == 0:
+                continue
+            gb = b[1][nm]
+            errs.append(float((gb - gf).norm()) / den)
+            cos.append(float((gb * gf).sum()) / (den * float(gb.norm()) + 1e-30))
+        errs.sort()
+        ok = rel < 1e-2 and errs[len(errs) // 2] < 0.03 and min(cos) > 0.97
+        fails += 0 if ok else 1
+        print("%s case %d: R%d C%d %s z%d cond%d qc%d fb%.2f dmol%d B%d enc %s dec %s | elbo f32 %.5f bf16 %.5f; grad err median %.4f max %.4f min cos %.4f" % (
+            "ok  " if ok else "FAIL", case, R, C, "light" if light else "default", ov["z_dim"], ov["cond_prior"], ov["q_correction"], ov["kl_free_bits"], use_dmol, B,
+            enc, dec, a[0]["elbo"], b[0]["elbo"], errs[len(errs) // 2], errs[-1], min(cos)), flush=True)
+    except Exception as e:  # noqa: BLE001
+        fails += 1
+        import traceback
+        print("EXC  case %d (%s, %s): %s" % (case, enc, dec, "".join(traceback.format_exception_only(type(e), e)).strip()[:300]), flush=True)
+print("%d failures" % fails)
