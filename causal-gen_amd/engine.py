@@ -139,6 +139,7 @@ class Engine:
         self._prep_tab = None
         self._wg_events = []
         self._wg_reduced, self._wg_seen = 0, set()
+        self._in_side = False
         self._dbg_names = {} if os.environ.get("CGEN_DEBUG_NAMES") else None  # id(tensor) -> producing conv (tools/ab_grads.py)
         self._riders = {}
         self.ride = os.environ.get("CGEN_RIDER", "1") != "0"
@@ -353,6 +354,10 @@ class Engine:
             self.lib.nchw_to_nhwc(0, F32, 1, c, h, w, p.data_ptr(), v.cv(), 0.0, 1.0, self.stream)
             self.launches += 1
             self._pnhwc[id(p)] = ptr
+            if self._in_side:
+                # created lazily inside a side-stream section, cached for everybody: the main stream must not read it before
+                # this conversion has run (found by tools/fuzz_model.py: two concurrent replays sharing the decoder biases)
+                torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)
         return ptr
 
     def param_grad_ptr(self, p):
@@ -645,10 +650,12 @@ class Engine:
         """Run `fn()` with every launch going to the side stream."""
         old = self.stream
         self.stream = self._fwd_side.cuda_stream
+        self._in_side = True
         try:
             return fn()
         finally:
             self.stream = old
+            self._in_side = False
 
     def join_side(self):
         torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)

@@ -248,3 +248,35 @@ def test_u8_pixels_are_normalised_on_the_device():
     b = preprocess_batch(SimpleNamespace(device="cuda", input_res=xu.shape[-1]), {"x": xu, "pa": fx["pa"][:, :, 0, 0]}, expand_pa=True)
     torch.testing.assert_close(b["x"].cpu(), xf, rtol=0, atol=2e-7)
     assert tuple(b["pa"].shape) == tuple(fx["pa"].shape) and b["x"].shape == xf.shape
+
+
+def test_concurrent_replays_equal_sequential_replays_on_first_use(monkeypatch):
+    """dscm.counterfactual runs its two replays as two concurrent streams (HVAE.forward_latents_pair).  On a FRESH engine the
+    decoder biases' NHWC images are created lazily inside the side-stream section and cached for everybody: the main
+    stream once read them before the conversion had run (tools/fuzz_model.py).  Sequential and concurrent replays must give
+    the same pixels bit for bit, first call included."""
+    from causal_gen_amd import dscm
+
+    name = "tiny_light_c1.pt"
+    if name not in TINY:
+        pytest.skip("fixture not generated")
+    fx = load_golden(name)
+    outs = []
+    for pair in ("0", "1", "1"):
+        monkeypatch.setenv("CGEN_CF_PAIR", pair)
+        m, _ = build(fx, "bf16")  # fresh model => fresh engine => empty caches
+        x, pa = fx["x"].cuda(), fx["pa"].cuda()
+        eng = m.engine()
+        eng.rng_ptr()
+        eng.rng.copy_(torch.tensor([21, 0], dtype=torch.int64, device=eng.rng.device))
+        with torch.no_grad():
+            zs = m.abduct(x, pa)
+            if pair == "0":
+                a, b = m.forward_latents(zs, pa), m.forward_latents(zs, pa.roll(1, 0))
+            else:
+                a, b = m.forward_latents_pair(zs, pa, pa.roll(1, 0))
+        torch.cuda.synchronize()
+        outs.append((a[0].clone(), a[1].clone(), b[0].clone(), b[1].clone()))
+    for o in outs[1:]:
+        for u, v in zip(outs[0], o):
+            assert torch.equal(u, v)
