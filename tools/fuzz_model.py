@@ -39,7 +39,7 @@ for case in range(n):
     B = rng.choice([2, 8, 16])
     outs = {}
     try:
-        for dt in ("f32", "bf16"):
+        for dt in ("f32", "bf16", "bf16#2"):
             hp = setup_hparams(name, **ov)
             torch.manual_seed(case)
             m = vae.HVAE(hp)
@@ -49,7 +49,7 @@ for case in range(n):
             with torch.no_grad():
                 for p in m.parameters():
                     p.add_(torch.randn(p.shape, generator=g) * 0.02)
-            m.compute_dtype = dt
+            m.compute_dtype = dt.split("#")[0]
             m = m.cuda().eval() if rng.random() < 0 else m.cuda().train()
             type(m.decoder).drop_cond  # noqa: B018
             if hp.cond_prior:
@@ -73,6 +73,8 @@ for case in range(n):
             outs[dt] = outs[dt] + (cf.float().cpu(),)
             del m, eng
         a, b = outs["f32"], outs["bf16"]
+        rep = [nm for nm in b[1] if not torch.equal(b[1][nm], outs["bf16#2"][1][nm])]
+        rep_cf = not torch.equal(b[2], outs["bf16#2"][2])
         rel = max(abs(a[0][k] - b[0][k]) / max(abs(a[0][k]), 1e-6) for k in ("elbo", "nll"))
         errs, cos = [], []
         for nm, gf in a[1].items():
@@ -85,11 +87,11 @@ for case in range(n):
         errs.sort()
         cfd = float((a[2] - b[2]).abs().max()) if not use_dmol else 0.0  # (DMoL decodes by arg-max over mixtures: ties flip)
         cff = float(((a[2] - b[2]).abs() > 0.05).float().mean())
-        ok = rel < 1e-2 and errs[len(errs) // 2] < 0.03 and min(cos) > 0.97 and cfd < 0.1
+        ok = rel < 1e-2 and errs[len(errs) // 2] < 0.03 and min(cos) > 0.97 and cfd < 0.1 and not rep and not rep_cf
         fails += 0 if ok else 1
-        print("%s case %d: R%d C%d %s z%d cond%d qc%d fb%.2f dmol%d B%d enc %s dec %s | elbo f32 %.5f bf16 %.5f; grad err median %.4f max %.4f min cos %.4f; cf max|d| %.4f frac>0.05 %.5f" % (
+        print("%s case %d: R%d C%d %s z%d cond%d qc%d fb%.2f dmol%d B%d enc %s dec %s | elbo f32 %.5f bf16 %.5f; grad err median %.4f max %.4f min cos %.4f; cf max|d| %.4f frac>0.05 %.5f; non-reproducible grads %d cf %d" % (
             "ok  " if ok else "FAIL", case, R, C, "light" if light else "default", ov["z_dim"], ov["cond_prior"], ov["q_correction"], ov["kl_free_bits"], use_dmol, B,
-            enc, dec, a[0]["elbo"], b[0]["elbo"], errs[len(errs) // 2], errs[-1], min(cos), cfd, cff), flush=True)
+            enc, dec, a[0]["elbo"], b[0]["elbo"], errs[len(errs) // 2], errs[-1], min(cos), cfd, cff, len(rep), rep_cf), flush=True)
     except Exception as e:  # noqa: BLE001
         fails += 1
         import traceback
