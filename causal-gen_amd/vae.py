@@ -708,6 +708,8 @@ class HVAE(nn.Module):
             h, _ = self._decode(eng, pa, latents=lat, t=t)
             return self._sample_likelihood(eng, h, True, t)
 
+        for p in self.decoder.bias:  # shared, lazily built, rebuilt every pass: build them BEFORE the streams fork
+            eng.param_nhwc(p)
         if not eng.fork_side():
             return replay(pa_a), replay(pa_b)
         ra = eng.on_side(lambda: replay(pa_a))

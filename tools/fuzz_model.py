@@ -84,6 +84,7 @@ for case in range(n):
             gb = b[1][nm]
             errs.append(float((gb - gf).norm()) / den)
             cos.append(float((gb * gf).sum()) / (den * float(gb.norm()) + 1e-30))
+        worst = sorted(((float((b[1][nm] - gf).norm()) / max(float(gf.norm()), 1e-30), nm, tuple(gf.shape)) for nm, gf in a[1].items() if float(gf.norm()) > 0), reverse=True)[:4]
         errs.sort()
         cfd = float((a[2] - b[2]).abs().max()) if not use_dmol else 0.0  # (DMoL decodes by arg-max over mixtures: ties flip)
         cff = float(((a[2] - b[2]).abs() > 0.05).float().mean())
@@ -92,6 +93,8 @@ for case in range(n):
         print("%s case %d: R%d C%d %s z%d cond%d qc%d fb%.2f dmol%d B%d enc %s dec %s | elbo f32 %.5f bf16 %.5f; grad err median %.4f max %.4f min cos %.4f; cf max|d| %.4f frac>0.05 %.5f; non-reproducible grads %d cf %d" % (
             "ok  " if ok else "FAIL", case, R, C, "light" if light else "default", ov["z_dim"], ov["cond_prior"], ov["q_correction"], ov["kl_free_bits"], use_dmol, B,
             enc, dec, a[0]["elbo"], b[0]["elbo"], errs[len(errs) // 2], errs[-1], min(cos), cfd, cff, len(rep), rep_cf), flush=True)
+        if not ok:
+            print("     worst:", worst, flush=True)
     except Exception as e:  # noqa: BLE001
         fails += 1
         import traceback
