@@ -140,6 +140,7 @@ class Engine:
         self._wg_events = []
         self._wg_reduced, self._wg_seen = 0, set()
         self._in_side = False
+        self._rng_override = None
         self._dbg_names = {} if os.environ.get("CGEN_DEBUG_NAMES") else None  # id(tensor) -> producing conv (tools/ab_grads.py)
         self._riders = {}
         self.ride = os.environ.get("CGEN_RIDER", "1") != "0"
@@ -505,7 +506,16 @@ class Engine:
     def rng_ptr(self):
         if self.rng is None:
             self.rng = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=self.device)
-        return self.rng.data_ptr()
+            self._rng_next = torch.empty_like(self.rng)
+            self._rng_one = torch.tensor([0, 1], dtype=torch.int64, device=self.device)
+        return self._rng_override if self._rng_override is not None else self.rng.data_ptr()
+
+    def rng_next_ptr(self):
+        """Pointer to a copy of the Philox state one pass ahead ([seed, offset + 1]): the second of two passes that run
+        concurrently draws what it would have drawn had it run after the first (HVAE.forward_latents_pair)."""
+        self.rng_ptr()
+        torch.add(self.rng, self._rng_one, out=self._rng_next)
+        return self._rng_next.data_ptr()
 
     def rng_advance(self, inc=1):
         self.lib.rng_advance(self.rng_ptr(), inc, self.stream)

@@ -710,11 +710,24 @@ class HVAE(nn.Module):
 
         for p in self.decoder.bias:  # shared, lazily built, rebuilt every pass: build them BEFORE the streams fork
             eng.param_nhwc(p)
+        philox = self.__dict__["noise"] is None
         if not eng.fork_side():
-            return replay(pa_a), replay(pa_b)
+            ra = replay(pa_a)
+            if philox:
+                eng.rng_advance(1)  # what the second forward_latents call's _begin_inference would have done
+            eng.passes = 0          # ... and its Philox stream ids start over
+            return ra, replay(pa_b)
+        nxt = eng.rng_next_ptr() if philox else None
         ra = eng.on_side(lambda: replay(pa_a))
-        rb = replay(pa_b)
+        eng._rng_override = nxt
+        eng.passes = 0  # the second replay numbers its Philox streams as a pass of its own
+        try:
+            rb = replay(pa_b)
+        finally:
+            eng._rng_override = None
         eng.join_side()
+        if philox:
+            eng.rng_advance(1)
         return ra, rb
 
     @torch.no_grad()
