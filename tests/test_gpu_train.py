@@ -300,6 +300,35 @@ def test_full_size_bf16_path_agrees_with_the_f32_parity_path():
     assert errs[len(errs) // 2] < 0.02 and errs[-1] < 0.2 and min(cosines) > 0.985, (errs[len(errs) // 2], errs[-1], min(cosines))
 
 
+def test_full_size_graph_replay_equals_eager_bf16():
+    """ukbb192, bf16, four optimiser steps: the captured step (background flush on a side stream, reparam riders, the
+    two-stream forward, step tail) replays bit for bit what the eager step computes."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from causal_gen_amd.train import TrainStep
+
+    outs = []
+    for use_graph in (False, True):
+        m, hp = bench.build_model("ukbb192", "bf16")
+        m = m.cuda()
+        torch.manual_seed(123)
+        ts = TrainStep(m, hp, ema=True, use_graph=use_graph)
+        x, pa = bench.synth_batch("ukbb192", hp, 4, "cuda", 1)
+        for _ in range(4):
+            o = ts.step(x, pa)
+        torch.cuda.synchronize()
+        outs.append(([float(v) for v in o.cpu()], {k: v.detach().clone() for k, v in m.state_dict().items()}, ts.stats()))
+        del m, ts
+    (o0, s0, t0), (o1, s1, t1) = outs
+    assert t0["opt_steps"] == t1["opt_steps"] == 4 and o0 == o1, (o0, o1)
+    bad = [k for k in s0 if not torch.equal(s0[k], s1[k])]
+    assert not bad, (len(bad), bad[:4])
+
+
 def test_free_bits_under_data_parallelism():
     """kl_free_bits > 0 with two ranks: the per-channel KL sums are all-reduced inside the forward pass, so the
     floored KL and the rank-averaged gradients equal the single-process result on the concatenated batch."""
