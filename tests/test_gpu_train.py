@@ -329,6 +329,31 @@ def test_full_size_graph_replay_equals_eager_bf16():
     assert not bad, (len(bad), bad[:4])
 
 
+def test_full_size_null_intervention_returns_the_observation():
+    """Size-independent property of abduct -> replay x2 -> dscm.py:55-56: with cf_parents == parents the counterfactual is the
+    observation itself, here on ukbb192 in bf16; a real intervention changes the image."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from causal_gen_amd import dscm
+
+    m, hp = bench.build_model("ukbb192", "bf16")
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(torch.randn(p.shape, generator=g).cuda() * 0.02)
+    x, pa = bench.synth_batch("ukbb192", hp, 2, "cuda", 1)
+    with torch.no_grad():
+        same = dscm.counterfactual(m, x, pa, pa)
+        diff = dscm.counterfactual(m, x, pa, pa.roll(1, 0))
+    assert float((same - x).abs().max()) < 1e-5
+    assert float((diff - x).abs().mean()) > 1e-3
+
+
 def test_free_bits_under_data_parallelism():
     """kl_free_bits > 0 with two ranks: the per-channel KL sums are all-reduced inside the forward pass, so the
     floored KL and the rank-averaged gradients equal the single-process result on the concatenated batch."""
