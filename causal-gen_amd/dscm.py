@@ -58,6 +58,16 @@ def cf_pixels(x, rec_loc, rec_scale, cf_loc, cf_scale, sum_x=None, sum_x2=None):
 @torch.no_grad()
 def counterfactual(vae, x, parents, cf_parents, t_abduct=1.0, te_cf=False, alpha=0.65, t_u=None):
     """Abduction -> action -> prediction for one batch (dscm.py:52-56; notebook cell 9 for cond_prior / total effect)."""
+    if not (te_cf and vae.cond_prior) and os.environ.get("CGEN_CF_REUSE", "1") != "0" and hasattr(vae, "abduct_with_reconstruction"):
+        # the reconstruction replay would rebuild, from the same latents and parents, the hidden state the abduction pass
+        # already holds: one decoder pass less per counterfactual, same bits
+        zs, (rec_loc, rec_scale) = vae.abduct_with_reconstruction(x, parents, t=t_abduct)
+        if vae.cond_prior:
+            zs = [z["z"] for z in zs]
+        cf_loc, cf_scale = vae.forward_latents(zs, cf_parents)
+        if t_u is not None:
+            cf_scale = cf_scale * t_u
+        return cf_pixels(x.to(rec_loc.device), rec_loc, rec_scale, cf_loc, cf_scale)
     zs = vae.abduct(x, parents, t=t_abduct)
     if vae.cond_prior:
         zs = [z["z"] for z in zs]

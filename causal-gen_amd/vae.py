@@ -650,14 +650,29 @@ class HVAE(nn.Module):
                t: Optional[float] = None):
         """vae.py:466-514.  Returns the exogenous z list, the list of {z,q_loc,q_logscale} dicts (cond. prior), or the
         mediator z* list when ``cf_parents`` is given."""
+        return self._abduct(x, parents, cf_parents, alpha, t, False)
+
+    @torch.no_grad()
+    def abduct_with_reconstruction(self, x: Tensor, parents: Tensor, t: Optional[float] = None):
+        """``abduct(x, parents, t=t)`` plus ``forward_latents(that, parents)`` without running the decoder twice: the
+        posterior pass that produces the latents already holds the hidden state the replay would rebuild (same latents, same
+        parents, same kernels), so the reconstruction is the likelihood head on it.  Returns (abduct's result, (loc, scale))
+        -- bit-identical to the two calls (tests/test_gpu_model.py)."""
+        out = self._abduct(x, parents, None, 0.5, t, True)
+        if self.__dict__["noise"] is None:
+            self.engine().rng_advance(1)  # the Philox state moves on as if forward_latents had been a call of its own
+        return out
+
+    def _abduct(self, x, parents, cf_parents, alpha, t, with_rec):
         eng = self._begin_inference()
         xin, pa = self._prep_inputs(eng, x, parents)
         acts = self._encode(eng, xin)
         logt = 0.0 if t is None else float(torch.tensor(t).log())
         if not self.cond_prior:
-            _, zs = self._decode(eng, pa, acts=acts, t=t, collect="z")
-            return [eng.to_torch_cl(z) for z in zs]
-        _, qs = self._decode(eng, pa, acts=acts, t=t, collect="q")
+            h, zs = self._decode(eng, pa, acts=acts, t=t, collect="z")
+            zs = [eng.to_torch_cl(z) for z in zs]
+            return (zs, self._sample_likelihood(eng, h, True, None)) if with_rec else zs
+        h, qs = self._decode(eng, pa, acts=acts, t=t, collect="q")
         if cf_parents is None:
             out = []
             for z, ql, qs_ in qs:
@@ -665,7 +680,8 @@ class HVAE(nn.Module):
                 if logt != 0.0:
                     d["q_logscale"] = d["q_logscale"] + logt  # the reference stores q_logscale + log t
                 out.append(d)
-            return out
+            return (out, self._sample_likelihood(eng, h, True, None)) if with_rec else out
+        assert not with_rec
         cfp = eng.from_nchw(cf_parents.to(eng.device, torch.float32))
         _, ps = self._decode(eng, cfp, t=t, collect="p")
         assert len(ps) == len(qs)

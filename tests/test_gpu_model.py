@@ -282,3 +282,31 @@ def test_concurrent_replays_equal_sequential_replays_on_first_use(monkeypatch):
     for o in outs[1:]:
         for u, v in zip(outs[0], o):
             assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("name", ["tiny_light_c1.pt", "tiny_condprior_morpho_c1.pt", "tiny_default_c3.pt"])
+def test_counterfactual_reusing_the_abduction_pass_gives_the_same_bits(name, monkeypatch):
+    """dscm.counterfactual takes the reconstruction from the abduction pass (HVAE.abduct_with_reconstruction) instead of
+    replaying the latents under the observed parents: same pixels and same Philox state afterwards as the reference's
+    three-call sequence abduct -> forward_latents(parents) -> forward_latents(cf_parents), bit for bit."""
+    from causal_gen_amd import dscm
+
+    if name not in TINY:
+        pytest.skip("fixture not generated")
+    fx = load_golden(name)
+    outs = []
+    for reuse in ("0", "1"):
+        monkeypatch.setenv("CGEN_CF_REUSE", reuse)
+        monkeypatch.setenv("CGEN_CF_PAIR", "0")
+        for dt in ("f32", "bf16"):
+            m, _ = build(fx, dt)
+            x, pa = fx["x"].cuda(), fx["pa"].cuda()
+            eng = m.engine()
+            eng.rng_ptr()
+            eng.rng.copy_(torch.tensor([33, 0], dtype=torch.int64, device=eng.rng.device))
+            with torch.no_grad():
+                cf = dscm.counterfactual(m, x, pa, pa.roll(1, 0), t_abduct=0.7)
+            torch.cuda.synchronize()
+            outs.append((reuse, dt, cf.clone(), eng.rng.clone()))
+    for (r0, d0, c0, g0), (r1, d1, c1, g1) in zip(outs[:2], outs[2:]):
+        assert d0 == d1 and torch.equal(c0, c1) and torch.equal(g0, g1), (d0,)
