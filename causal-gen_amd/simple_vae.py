@@ -305,6 +305,15 @@ class VAE(HVAE):
         eng.launches += 1
         return [to2d(o)]
 
+    def abduct_with_reconstruction(self, x: Tensor, parents: Tensor, t: Optional[float] = None):
+        """What dscm.counterfactual asks of an image mechanism (see HVAE.abduct_with_reconstruction); with one latent and
+        a three-conv decoder there is nothing worth sharing between the passes, so this is the two calls."""
+        zs = self.abduct(x, parents, t=t)
+        return zs, self.forward_latents([z["z"] if isinstance(z, dict) else z for z in zs], parents)
+
+    def forward_latents_pair(self, latents: List[Tensor], parents_a: Tensor, parents_b: Tensor, t: Optional[float] = None):
+        return self.forward_latents(latents, parents_a, t=t), self.forward_latents(latents, parents_b, t=t)
+
     @torch.no_grad()
     def forward_latents(self, latents: List[Tensor], parents: Tensor, return_loc: bool = True, t: Optional[float] = None):
         """simple_vae.py:406-415."""

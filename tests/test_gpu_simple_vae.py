@@ -1,6 +1,8 @@
 """Config 1: simple_vae.VAE on the HIP path against the golden fixture made from the imported reference.
 Tolerances as for the HVAE f32 path: ELBO / NLL / KL 1e-4 relative, gradients 2e-3 of the tensor's max, counterfactual
 pixels 1e-3 absolute."""
+import os
+
 import pytest
 import torch
 
@@ -79,6 +81,21 @@ def test_abduct_mediator_replay_counterfactual_and_sample():
 
     cf = dscm.cf_pixels(x, rec_loc, rec_scale, cf_loc, cf_scale)
     assert (cf.cpu() - ab["cf_x"]).abs().max().item() < 1e-3
+    # the same through dscm.counterfactual: total-effect form (mediator latents) against the golden pixels, and the
+    # default form (reconstruction from the abduction call, or the paired replays) against the three calls above
+    m.noise = [fx["eps"].clone(), fx["eps"].clone()]
+    cf_te = dscm.counterfactual(m, x, pa, cf_pa, t_abduct=ab["t"], te_cf=True, alpha=ab["alpha"])
+    assert (cf_te.cpu() - ab["cf_x"]).abs().max().item() < 1e-3
+    d_loc, d_scale = m.forward_latents([q["z"]], cf_pa)
+    want = dscm.cf_pixels(x, rec_loc, rec_scale, d_loc, d_scale)
+    for reuse, pair in (("1", "1"), ("0", "1"), ("0", "0")):
+        os.environ["CGEN_CF_REUSE"], os.environ["CGEN_CF_PAIR"] = reuse, pair
+        try:
+            m.noise = [fx["eps"].clone()]
+            got = dscm.counterfactual(m, x, pa, cf_pa, t_abduct=ab["t"])
+        finally:
+            del os.environ["CGEN_CF_REUSE"], os.environ["CGEN_CF_PAIR"]
+        assert torch.equal(got, want), (reuse, pair)
     s = fx["sample"]
     m.noise = [fx["eps"].clone()]
     sx, ss = m.sample(pa, t=s["t"])
