@@ -112,6 +112,8 @@ class VAE(HVAE):
         self.decoder = Decoder(args)
         x_dist = args.x_like.split("_")[1]
         if x_dist != "dgauss" or args.input_channels != 1:
+            # (simple_vae.py's DGaussNet treats RGB channels independently, unlike vae.py's: the likelihood kernels
+            # implement the latter's channel_coeffs form for three channels)
             raise NotImplementedError(f"simple_vae on the HIP path: x_like=*_dgauss with one input channel (got {args.x_like}, "
                                       f"{args.input_channels} channels)")
         self.likelihood = DGaussNet(args)
@@ -201,8 +203,9 @@ class VAE(HVAE):
         if self.cond_prior:
             return self._prior(eng, y1, t)
         d = self.decoder
-        p_loc = eng.from_nchw(d.p_loc.repeat(B, 1)[:, :, None, None].contiguous(), rg=False)
-        p_ls = eng.from_nchw(d.p_scale.log().repeat(B, 1)[:, :, None, None].contiguous(), rg=False)
+        # (rg=True although the N(0,I) prior is a buffer: the fused KL backward writes all four gradients, these two unread)
+        p_loc = eng.from_nchw(d.p_loc.repeat(B, 1)[:, :, None, None].contiguous(), rg=True)
+        p_ls = eng.from_nchw(d.p_scale.log().repeat(B, 1)[:, :, None, None].contiguous(), rg=True)
         if t is not None:
             p_ls = eng.unary(p_ls, UNARY_ADD, float(np.log(t)))
         return p_loc, p_ls, None

@@ -282,14 +282,15 @@ def train_steps():
     print("train_steps: norms[5]=%.1f norms[9]=%.1f" % (norms[5], norms[9]))
 
 
-def simple_vae_fixture(B=6, seed=11):
+def simple_vae_fixture(B=6, seed=11, tag="c1", C=1, cond_prior=True):
     """Config 1: the reference's ``simple_vae.VAE`` at the morphomnist preset with --cond_prior
-    --context_dim 12 (234 690 parameters), parents [B,12] = two uniform(-1,1) scalars + one-hot(10)."""
+    --context_dim 12 (234 690 parameters), parents [B,12] = two uniform(-1,1) scalars + one-hot(10).
+    tag "c1x": the same with the exogenous N(0,I) prior (no --cond_prior)."""
     import simple_vae as ref_simple  # noqa: E402  (reference)
 
     gen = torch.Generator().manual_seed(seed)
     a = Hparams()
-    a.update(dict(hps="morphomnist", input_res=32, input_channels=1, z_dim=16, context_dim=12, cond_prior=True,
+    a.update(dict(hps="morphomnist", input_res=32, input_channels=C, z_dim=16, context_dim=12, cond_prior=cond_prior,
                   widths=[16, 32, 64, 128, 256], x_like="diag_dgauss", std_init=0.0, kl_free_bits=0.0))
     torch.manual_seed(seed)
     m = ref_simple.VAE(a).eval()
@@ -299,7 +300,7 @@ def simple_vae_fixture(B=6, seed=11):
         for n, p in m.named_parameters():
             if "prior.z_" in n or "likelihood.x_logscale" in n:
                 p.copy_(torch.randn(p.shape, generator=gen) * 0.05)
-    x = (torch.randint(0, 256, (B, 1, 32, 32), generator=gen).float() - 127.5) / 127.5
+    x = (torch.randint(0, 256, (B, C, 32, 32), generator=gen).float() - 127.5) / 127.5
     x[0, 0, 0, 0], x[0, 0, 0, 1] = -1.0, 1.0
 
     def parents():
@@ -317,25 +318,28 @@ def simple_vae_fixture(B=6, seed=11):
         out = m(x, pa, beta=2.0)
         out["elbo"].backward()
         grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
-        fx = dict(hp=dict(hps="morphomnist", input_res=32, input_channels=1, z_dim=16, context_dim=12, cond_prior=True,
+        fx = dict(hp=dict(hps="morphomnist", input_res=32, input_channels=C, z_dim=16, context_dim=12, cond_prior=cond_prior,
                           widths=[16, 32, 64, 128, 256], x_like="diag_dgauss", std_init=0.0, hidden_dim=128),
                   n_params=n_params, init_seed=seed, init_abs_sum=init_abs_sum, state_dict={k: v.detach().clone() for k, v in m.state_dict().items()},
                   x=x, pa=pa, cf_pa=cf_pa, eps=eps,
                   fwd=dict(beta=2.0, grads=grads, **{k: v.detach() for k, v in out.items()}))
         with torch.no_grad():
             # training-mode forward with a fixed conditioning-dropout draw (simple_vae.py:286-293)
-            m.train()
-            m.decoder.drop_cond = lambda: (0, 1)
-            o2 = m(x, pa, beta=1.0)
-            fx["fwd_drop"] = dict(drop=(0, 1), **{k: v.detach() for k, v in o2.items()})
-            m.eval()
-            del m.decoder.drop_cond
+            if cond_prior:
+                m.train()
+                m.decoder.drop_cond = lambda: (0, 1)
+                o2 = m(x, pa, beta=1.0)
+                fx["fwd_drop"] = dict(drop=(0, 1), **{k: v.detach() for k, v in o2.items()})
+                m.eval()
+                del m.decoder.drop_cond
             # 4-D parents are accepted too (takes [:, :, 0, 0]; simple_vae.py:64-65)
             o3 = m(x, pa[..., None, None].repeat(1, 1, 32, 32), beta=2.0)
             assert torch.allclose(o3["elbo"], out["elbo"])
             # abduct (t = 0.9) -> mediator z* -> forward_latents x2 -> dscm.py:55-56
             q = m.abduct(x, pa, t=0.9)[0]
             zstar = m.abduct(x, pa, cf_parents=cf_pa, alpha=0.3, t=0.9)[0]
+            if not cond_prior:  # exogenous prior: abduct returns the latent itself, with or without cf_parents
+                q = dict(z=q, q_loc=None, q_logscale=None)
             rec_loc, rec_scale = m.forward_latents([q["z"]], pa, t=0.9)
             cf_loc, cf_scale = m.forward_latents([zstar], cf_pa, t=0.9)
             u = (x - rec_loc) / rec_scale.clamp(min=1e-12)
@@ -347,7 +351,7 @@ def simple_vae_fixture(B=6, seed=11):
             fx["sample"] = dict(t=0.8, x=s_loc, scale=s_scale)
     finally:
         ref_simple.sample_gaussian = orig
-    path = os.path.join(OUT, "simple_vae_c1.pt")
+    path = os.path.join(OUT, "simple_vae_%s.pt" % tag)
     torch.save(fx, path)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB;", n_params, "parameters")
 
@@ -355,6 +359,9 @@ def simple_vae_fixture(B=6, seed=11):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "simple":
         simple_vae_fixture()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "simple_c1x":
+        simple_vae_fixture(seed=12, tag="c1x", C=1, cond_prior=False)
         sys.exit(0)
     T = ohp.tiny_hparams
     tiny_fixture("default_c1", T(hps="tiny"))
@@ -369,3 +376,4 @@ if __name__ == "__main__":
     anchors()
     train_steps()
     simple_vae_fixture()
+    simple_vae_fixture(seed=12, tag="c1x", C=1, cond_prior=False)

@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's config-1 model, ``src/simple_vae.py`` (VAE with a
 strided-conv encoder, linear bottleneck and upsample+conv decoder, 234 690 parameters at the morphomnist preset).
 Functional and ``state_dict``-driven like hvae_ref.py; every function cites the reference lines it follows.  Only
-``tests/`` may import this module.  Pinned by tests/golden/simple_vae_c1.pt (made from the imported reference by
+``tests/`` may import this module.  Pinned by tests/golden/simple_vae_c1.pt and simple_vae_c1x.pt (made from the imported reference by
 oracle/make_golden.py).  Likelihood: the discretised Gaussian of simple_vae.py:103-171 (``x_like = *_dgauss``).
 """
 import math

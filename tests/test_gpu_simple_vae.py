@@ -11,11 +11,14 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-def build():
+NAMES = ["simple_vae_c1.pt", "simple_vae_c1x.pt"]  # conditional-prior preset; the same with the exogenous prior
+
+
+def build(name="simple_vae_c1.pt"):
     from causal_gen_amd import simple_vae
     from causal_gen_amd.hps import Hparams
 
-    fx = load_golden("simple_vae_c1.pt")
+    fx = load_golden(name)
     hp = {k: v for k, v in fx["hp"].items() if k != "hidden_dim"}
     m = simple_vae.VAE(Hparams(**hp))
     m.load_state_dict(fx["state_dict"])
@@ -26,8 +29,9 @@ def rel(a, b):
     return abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
 
 
-def test_forward_and_grads():
-    fx, m = build()
+@pytest.mark.parametrize("name", NAMES)
+def test_forward_and_grads(name):
+    fx, m = build(name)
     f = fx["fwd"]
     m.noise = [fx["eps"].clone()]
     out = m(fx["x"].cuda(), fx["pa"].cuda(), beta=f["beta"])
@@ -62,14 +66,18 @@ def test_train_mode_drop_cond():
         assert rel(out[k], d[k]) < 1e-4, (k, float(out[k]), float(d[k]))
 
 
-def test_abduct_mediator_replay_counterfactual_and_sample():
-    fx, m = build()
+@pytest.mark.parametrize("name", NAMES)
+def test_abduct_mediator_replay_counterfactual_and_sample(name):
+    fx, m = build(name)
     ab = fx["abduct"]
     x, pa, cf_pa = fx["x"].cuda(), fx["pa"].cuda(), fx["cf_pa"].cuda()
     m.noise = [fx["eps"].clone()]
     q = m.abduct(x, pa, t=ab["t"])[0]
+    if m.cond_prior:
+        torch.testing.assert_close(q["q_logscale"].cpu(), ab["q_logscale"], rtol=1e-4, atol=1e-5)
+    else:
+        q = dict(z=q)  # exogenous prior: the latent itself (simple_vae.py:403-404)
     torch.testing.assert_close(q["z"].cpu(), ab["z"], rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(q["q_logscale"].cpu(), ab["q_logscale"], rtol=1e-4, atol=1e-5)
     m.noise = [fx["eps"].clone()]
     zs = m.abduct(x, pa, cf_parents=cf_pa, alpha=ab["alpha"], t=ab["t"])[0]
     torch.testing.assert_close(zs.cpu(), ab["zstar"], rtol=1e-4, atol=1e-5)
