@@ -1578,9 +1578,18 @@ static void launch_wgrad2_ks(const Wg2P& p, const Wg2Geom& g, hipStream_t st) {
 //     its pixel (two MFMA results): the epilogue is a 16-byte load / store per lane straight from the accumulators --
 //     no LDS staging, no extra barrier; bias is the accumulators' initial value; bf16 rounding is v_cvt_pk_bf16_f32;
 //   * epilogue operands (aux, residual) are requested before the halo DMA wait and consumed after the MFMA loop.
+// Measured on MI355X (ukbb192, B=32): grouping neighbouring tiles on one XCD is 2 % SLOWER than the round-robin order
+// (1750 vs 1786 img/s) -- these launches are issue / latency bound, halo re-reads are served by the Infinity Cache either
+// way, and neighbours on one XCD queue on the same L2 channels at the same moment.  Off by default; kept as a knob.
+static bool xcd_remap_on() {
+  static const int on = [] { const char* e = getenv("CGEN_XCD_REMAP"); return e ? atoi(e) : 0; }();
+  return on != 0;
+}
+
 struct PxP {
   PixTile xt;
   int tiles_x, tiles_y, ntiles, nks;
+  int xcd_chunk, pad_x;  // > 0: gridDim.x / 8 -- workgroup b starts at tile (b % 8) * xcd_chunk + b / 8, so that the tiles an XCD works on (workgroups go round-robin over the 8 XCDs) are neighbours and share halo rows in that XCD's L2
   int ldw, wpieces, rows_pad, co8;  // co8: output channels incl. zero padding to 8 (== Co unless the output view carries cpad)
   FastDiv d_gprw, d_ctot8, d_tx, d_ty;
   int ktab[PX_MAXKS * 4];  // [K-step][lane group fg]: ((tap row * rowbytes + channel * 2) << 3) | (tap column == 2) << 2 | tap column -- read with VECTOR loads from the kernarg segment
@@ -1695,7 +1704,7 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
   const char* x_rows = Xb + (size_t)(wave * 2) * q.xt.rowbytes;
 
   if (stamp) stamp[5] = __builtin_amdgcn_s_memrealtime();
-  for (int t = blockIdx.x; t < q.ntiles; t += gridDim.x) {
+  for (int t = q.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * q.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x; t < q.ntiles; t += gridDim.x) {
     // ---- tile origin: scalar
     const int b1 = fdiv(t, q.d_tx), tx = t - b1 * q.tiles_x;
     const int n = fdiv(b1, q.d_ty), ty = b1 - n * q.tiles_y;
@@ -1907,6 +1916,8 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st) {
   int gx = 256 * per_cu / parts;
   if (gx < 1) gx = 1;
   if (gx > q.ntiles) gx = q.ntiles;
+  q.xcd_chunk = (xcd_remap_on() && gx % 8 == 0 && gx >= 64) ? gx / 8 : 0;
+  q.pad_x = 0;
   dim3 grid(gx, parts);
   switch (np) {
     case 1: launch_px_inst<1>(p, q, grid, lds, st); break;
@@ -1928,7 +1939,7 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st) {
 struct WsP {
   PixTile xt;
   int tiles_x, tiles_y, ntiles, nk;  // nk = K-steps that carry weights
-  int rows_pad, red_bytes, dbg, pad0;
+  int rows_pad, red_bytes, dbg, xcd_chunk;  // xcd_chunk: as in PxP
   FastDiv d_ctot8, d_tx, d_ty;
   unsigned long long* stamps;  // optional (CGEN_WS_STAMPS): per-phase cycle stamps of workgroup 0
 };
@@ -2032,7 +2043,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
 #define WS_STAMP() do { if (stamp && nst < 60) q.stamps[nst++] = __builtin_readcyclecounter(); } while (0)
   WS_STAMP();
 
-  for (int t = blockIdx.x; t < q.ntiles; t += gridDim.x) {
+  for (int t = q.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * q.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x; t < q.ntiles; t += gridDim.x) {
     const int b1 = fdiv(t, q.d_tx), tx = t - b1 * q.tiles_x;
     const int n = fdiv(b1, q.d_ty), ty = b1 - n * q.tiles_y;
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
@@ -2208,6 +2219,7 @@ static bool launch_conv_ws(const ConvP& p, hipStream_t st) {
   int grid_x = 256 * per_cu / grid_y;
   if (grid_x < 1) grid_x = 1;
   if (grid_x > q.ntiles) grid_x = q.ntiles;
+  q.xcd_chunk = (xcd_remap_on() && grid_x % 8 == 0 && grid_x >= 64) ? grid_x / 8 : 0;
 #define WS_CASE(NKW) case NKW: if (ntc == 1) launch_ws_inst<1, NKW>(p, q, grid_x, grid_y, lds, st); else launch_ws_inst<2, NKW>(p, q, grid_x, grid_y, lds, st); break;
   switch (bk) {
     WS_CASE(3) WS_CASE(4) WS_CASE(5) WS_CASE(6) WS_CASE(8) WS_CASE(10) WS_CASE(12) WS_CASE(16)
