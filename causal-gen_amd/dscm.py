@@ -58,12 +58,15 @@ def cf_pixels(x, rec_loc, rec_scale, cf_loc, cf_scale, sum_x=None, sum_x2=None):
 @torch.no_grad()
 def counterfactual(vae, x, parents, cf_parents, t_abduct=1.0, te_cf=False, alpha=0.65, t_u=None):
     """Abduction -> action -> prediction for one batch (dscm.py:52-56; notebook cell 9 for cond_prior / total effect)."""
-    if not (te_cf and vae.cond_prior) and os.environ.get("CGEN_CF_REUSE", "1") != "0" and hasattr(vae, "abduct_with_reconstruction"):
+    te = bool(te_cf and vae.cond_prior)
+    if os.environ.get("CGEN_CF_REUSE", "1") != "0" and hasattr(vae, "abduct_with_reconstruction"):
         # the reconstruction replay would rebuild, from the same latents and parents, the hidden state the abduction pass
         # already holds: one decoder pass less per counterfactual, same bits
         zs, (rec_loc, rec_scale) = vae.abduct_with_reconstruction(x, parents, t=t_abduct)
         if vae.cond_prior:
             zs = [z["z"] for z in zs]
+        if te:  # total effect: mediator latents from a second abduction under the counterfactual parents
+            zs = vae.abduct(x, parents, cf_parents=cf_parents, alpha=alpha, t=t_abduct)
         cf_loc, cf_scale = vae.forward_latents(zs, cf_parents)
         if t_u is not None:
             cf_scale = cf_scale * t_u
@@ -71,13 +74,13 @@ def counterfactual(vae, x, parents, cf_parents, t_abduct=1.0, te_cf=False, alpha
     zs = vae.abduct(x, parents, t=t_abduct)
     if vae.cond_prior:
         zs = [z["z"] for z in zs]
-    if not (te_cf and vae.cond_prior) and os.environ.get("CGEN_CF_PAIR", "1") != "0" and hasattr(vae, "forward_latents_pair"):
+    if not te and os.environ.get("CGEN_CF_PAIR", "1") != "0" and hasattr(vae, "forward_latents_pair"):
         # the two replays share their latents: two concurrent streams
         (rec_loc, rec_scale), (cf_loc, cf_scale) = vae.forward_latents_pair(zs, parents, cf_parents)
     else:
         rec_loc, rec_scale = vae.forward_latents(zs, parents)
         cf_zs = zs
-        if te_cf and vae.cond_prior:
+        if te:
             cf_zs = vae.abduct(x, parents, cf_parents=cf_parents, alpha=alpha, t=t_abduct)
         cf_loc, cf_scale = vae.forward_latents(cf_zs, cf_parents)
     if t_u is not None:

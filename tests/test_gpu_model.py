@@ -284,8 +284,9 @@ def test_concurrent_replays_equal_sequential_replays_on_first_use(monkeypatch):
             assert torch.equal(u, v)
 
 
-@pytest.mark.parametrize("name", ["tiny_light_c1.pt", "tiny_condprior_morpho_c1.pt", "tiny_default_c3.pt"])
-def test_counterfactual_reusing_the_abduction_pass_gives_the_same_bits(name, monkeypatch):
+@pytest.mark.parametrize("name,te", [("tiny_light_c1.pt", False), ("tiny_condprior_morpho_c1.pt", False),
+                                     ("tiny_condprior_morpho_c1.pt", True), ("tiny_default_c3.pt", False)])
+def test_counterfactual_reusing_the_abduction_pass_gives_the_same_bits(name, te, monkeypatch):
     """dscm.counterfactual takes the reconstruction from the abduction pass (HVAE.abduct_with_reconstruction) instead of
     replaying the latents under the observed parents: same pixels and same Philox state afterwards as the reference's
     three-call sequence abduct -> forward_latents(parents) -> forward_latents(cf_parents), bit for bit."""
@@ -305,7 +306,7 @@ def test_counterfactual_reusing_the_abduction_pass_gives_the_same_bits(name, mon
             eng.rng_ptr()
             eng.rng.copy_(torch.tensor([33, 0], dtype=torch.int64, device=eng.rng.device))
             with torch.no_grad():
-                cf = dscm.counterfactual(m, x, pa, pa.roll(1, 0), t_abduct=0.7)
+                cf = dscm.counterfactual(m, x, pa, pa.roll(1, 0), t_abduct=0.7, te_cf=te, alpha=0.4)
             torch.cuda.synchronize()
             outs.append((reuse, dt, cf.clone(), eng.rng.clone()))
     for (r0, d0, c0, g0), (r1, d1, c1, g1) in zip(outs[:2], outs[2:]):
