@@ -19,6 +19,7 @@ __device__ __forceinline__ float dg_cdf_grad(float u) {
 
 struct DgP {
   int n, h, w, c;
+  int ar, pad0;  // ar: three channels in vae.py's autoregressive form (params = [loc | logscale | coeffs], 9 channels); 0: independent channels
   View params, x, g;
   float* part;
   const float* coef;
@@ -36,7 +37,7 @@ __device__ __forceinline__ void dg_load(const DgP& p, int b, int y, int x, float
     ls_raw[c] = Elem<T>::ld(pp + p.c + c);
     xv[c] = Elem<T>::ld(xp + c);
   }
-  if (p.c == 3) {
+  if (p.ar) {
     for (int j = 0; j < 3; ++j) k[j] = tanhf(Elem<T>::ld(pp + 6 + j));
   }
 }
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void dgauss_nll_fwd_kernel(DgP p) {
       const int y = px / p.w, x = px % p.w;
       float loc[3], lsr[3], k[3], xv[3];
       dg_load<T>(p, b, y, x, loc, lsr, k, xv);
-      if (p.c == 3) {  // training-time autoregressive means use the true x (vae.py:370-377)
+      if (p.ar) {  // training-time autoregressive means use the true x (vae.py:370-377)
         loc[2] = loc[2] + k[1] * xv[0] + k[2] * xv[1];
         loc[1] = loc[1] + k[0] * xv[0];
       }
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void dgauss_nll_bwd_kernel(DgP p) {
     const int y = px / p.w, x = px % p.w;
     float loc[3], lsr[3], k[3], xv[3];
     dg_load<T>(p, b, y, x, loc, lsr, k, xv);
-    if (p.c == 3) {
+    if (p.ar) {
       loc[2] = loc[2] + k[1] * xv[0] + k[2] * xv[1];
       loc[1] = loc[1] + k[0] * xv[0];
     }
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(256) void dgauss_nll_bwd_kernel(DgP p) {
       Elem<T>::st(go + c, gloc[c]);
       Elem<T>::st(go + p.c + c, gls[c]);
     }
-    if (p.c == 3) {  // coeff_raw -> tanh -> k0 (g<-r), k1 (b<-r), k2 (b<-g)
+    if (p.ar) {  // coeff_raw -> tanh -> k0 (g<-r), k1 (b<-r), k2 (b<-g)
       Elem<T>::st(go + 6, gloc[1] * xv[0] * (1.f - k[0] * k[0]));
       Elem<T>::st(go + 7, gloc[2] * xv[0] * (1.f - k[1] * k[1]));
       Elem<T>::st(go + 8, gloc[2] * xv[1] * (1.f - k[2] * k[2]));
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void dgauss_nll_bwd_kernel(DgP p) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void dgauss_sample_kernel(int n, int h, int w, int c, View params, float logt, const uint64_t* rng, uint32_t stream_id, float* xo, float* so) {
+__global__ __launch_bounds__(256) void dgauss_sample_kernel(int n, int h, int w, int c, int ar, View params, float logt, const uint64_t* rng, uint32_t stream_id, float* xo, float* so) {
   const int npix = h * w;
   const int64_t total = (int64_t)n * npix;
   for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * 256) {
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void dgauss_sample_kernel(int n, int h, int w,
     const T* pp = vptr<T>(params, b, px / w, px % w);
     float loc[3];
     for (int ch = 0; ch < c; ++ch) loc[ch] = Elem<T>::ld(pp + ch);
-    if (c == 3) {  // inference: autoregressive on the clamped predicted channels (vae.py:360-369)
+    if (ar) {  // inference: autoregressive on the clamped predicted channels (vae.py:360-369)
       const float k0 = tanhf(Elem<T>::ld(pp + 6)), k1 = tanhf(Elem<T>::ld(pp + 7)), k2 = tanhf(Elem<T>::ld(pp + 8));
       const float r = fminf(fmaxf(loc[0], -1.f), 1.f);
       const float g = fminf(fmaxf(loc[1] + k0 * r, -1.f), 1.f);
@@ -459,10 +460,10 @@ extern "C" int cgen_like_chunks(int32_t h, int32_t w) { return ceil_div((int64_t
 extern "C" int cgen_dgauss_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x,
                                    float* nll_part, cgen_stream_t stream) {
   CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dgauss_nll_fwd: bad dtype");
-  CGEN_REQUIRE((c == 1 || c == 3) && params.p && x.p && nll_part && params.c >= 2 * c + (c == 3 ? 3 : 0), "cgen_dgauss_nll_fwd: bad args");
+  CGEN_REQUIRE((c == 1 || c == 3) && params.p && x.p && nll_part && params.c >= 2 * c, "cgen_dgauss_nll_fwd: bad args");
   DgP p;
   memset(&p, 0, sizeof(p));
-  p.n = n; p.h = h; p.w = w; p.c = c; p.params = mk(params); p.x = mk(x); p.part = nll_part;
+  p.n = n; p.h = h; p.w = w; p.c = c; p.ar = (c == 3 && params.c >= 9); p.params = mk(params); p.x = mk(x); p.part = nll_part;
   dim3 grid(cgen_like_chunks(h, w), n);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(dgauss_nll_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(dgauss_nll_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -472,10 +473,10 @@ extern "C" int cgen_dgauss_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t 
 extern "C" int cgen_dgauss_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x,
                                    const float* coef_dev, int32_t coef_stride, cgen_view g_params, cgen_stream_t stream) {
   CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dgauss_nll_bwd: bad dtype");
-  CGEN_REQUIRE((c == 1 || c == 3) && params.p && x.p && coef_dev && g_params.p, "cgen_dgauss_nll_bwd: bad args");
+  CGEN_REQUIRE((c == 1 || c == 3) && params.p && x.p && coef_dev && g_params.p && params.c >= 2 * c && g_params.c >= (c == 3 && params.c >= 9 ? 9 : 2 * c), "cgen_dgauss_nll_bwd: bad args");
   DgP p;
   memset(&p, 0, sizeof(p));
-  p.n = n; p.h = h; p.w = w; p.c = c; p.params = mk(params); p.x = mk(x); p.g = mk(g_params); p.coef = coef_dev; p.coef_stride = coef_stride;
+  p.n = n; p.h = h; p.w = w; p.c = c; p.ar = (c == 3 && params.c >= 9); p.params = mk(params); p.x = mk(x); p.g = mk(g_params); p.coef = coef_dev; p.coef_stride = coef_stride;
   const int grid = like_grid((int64_t)n * h * w);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(dgauss_nll_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(dgauss_nll_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
@@ -485,10 +486,11 @@ extern "C" int cgen_dgauss_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t 
 extern "C" int cgen_dgauss_sample(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, float logt,
                                   const uint64_t* rng, uint32_t stream_id, float* x_nchw, float* scale_nchw, cgen_stream_t stream) {
   CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dgauss_sample: bad dtype");
-  CGEN_REQUIRE((c == 1 || c == 3) && params.p && x_nchw && scale_nchw, "cgen_dgauss_sample: bad args");
+  CGEN_REQUIRE((c == 1 || c == 3) && params.p && x_nchw && scale_nchw && params.c >= 2 * c, "cgen_dgauss_sample: bad args");
+  const int ar = (c == 3 && params.c >= 9);
   const int grid = like_grid((int64_t)n * h * w);
-  if (dtype == CGEN_F32) hipLaunchKernelGGL(dgauss_sample_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
-  else hipLaunchKernelGGL(dgauss_sample_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(dgauss_sample_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, ar, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
+  else hipLaunchKernelGGL(dgauss_sample_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, ar, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
   return check_launch("cgen_dgauss_sample");
 }
 

@@ -17,7 +17,7 @@ from torch import Tensor, nn
 from . import _lib
 from ._lib import ACT_NONE, ACT_RELU, NULL_VIEW, UNARY_ADD, UNARY_CLAMP_MIN, UNARY_LEAKY_RELU
 from .engine import ConvSite
-from .vae import DGaussNet, HVAE, _HVAEFunction  # noqa: F401  (the autograd bridge and the likelihood holder are shared)
+from .vae import DGaussNet as _HvaeDGaussNet, HVAE, _HVAEFunction  # noqa: F401  (the autograd bridge is shared)
 
 EPS = -9
 EPS_z = -9
@@ -101,6 +101,33 @@ class _LinearSite:
         self.kernel_size, self.out_channels, self.in_channels = (1, 1), lin.out_features, lin.in_features
 
 
+class DGaussNet(_HvaeDGaussNet):
+    """simple_vae.py:103-171: as vae.py's head but RGB channels are independent (no ``channel_coeffs``): the likelihood
+    kernels see a [loc(C) | logscale(C)] view."""
+
+    def __init__(self, args):
+        nn.Module.__init__(self)
+        self.x_loc = nn.Conv2d(args.widths[0], args.input_channels, kernel_size=1, stride=1)
+        self.x_logscale = nn.Conv2d(args.widths[0], args.input_channels, kernel_size=1, stride=1)
+        self.channels = args.input_channels
+        if args.std_init > 0:
+            nn.init.zeros_(self.x_logscale.weight)
+            nn.init.constant_(self.x_logscale.bias, np.log(args.std_init))
+            covariance = args.x_like.split("_")[0]
+            if covariance == "fixed":
+                self.x_logscale.weight.requires_grad = False
+                self.x_logscale.bias.requires_grad = False
+            elif covariance == "shared":
+                self.x_logscale.weight.requires_grad = False
+                self.x_logscale.bias.requires_grad = True
+
+    def heads(self):
+        return [self.x_loc, self.x_logscale]
+
+    def out_channels(self):
+        return 2 * self.channels
+
+
 class VAE(HVAE):
     compute_dtype = "f32"
 
@@ -111,11 +138,9 @@ class VAE(HVAE):
         self.encoder = Encoder(args)
         self.decoder = Decoder(args)
         x_dist = args.x_like.split("_")[1]
-        if x_dist != "dgauss" or args.input_channels != 1:
-            # (simple_vae.py's DGaussNet treats RGB channels independently, unlike vae.py's: the likelihood kernels
-            # implement the latter's channel_coeffs form for three channels)
-            raise NotImplementedError(f"simple_vae on the HIP path: x_like=*_dgauss with one input channel (got {args.x_like}, "
-                                      f"{args.input_channels} channels)")
+        if x_dist != "dgauss" or args.input_channels not in (1, 3):
+            raise NotImplementedError(f"simple_vae on the HIP path: x_like=*_dgauss with one or three input channels (got "
+                                      f"{args.x_like}, {args.input_channels} channels)")
         self.likelihood = DGaussNet(args)
         self.free_bits = 0.0
         self.z_dim, self.context_dim, self.input_channels = args.z_dim, args.context_dim, args.input_channels

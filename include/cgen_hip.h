@@ -223,7 +223,8 @@ int cgen_mediator_mix(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c,
 
 /* ------------------------------------------------------------------ likelihoods (K11-K14) and ELBO
  * Discretised Gaussian (vae.py:352-411).  params view holds [loc(C) | logscale(C) | coeff(3, only C==3)] per pixel
- * (the raw 1x1-conv outputs); x is NHWC.  nll_part[b*nchunk+chunk] = partial sums of -log p over (C,H,W). */
+ * (the raw 1x1-conv outputs); x is NHWC.  For C == 3 a params view of >= 9 channels selects vae.py's autoregressive
+ * RGB form; a 6-channel view [loc(3) | logscale(3)] selects independent channels (simple_vae.py:103-171, no coeffs).  nll_part[b*nchunk+chunk] = partial sums of -log p over (C,H,W). */
 int cgen_like_chunks(int32_t h, int32_t w);
 int cgen_dgauss_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x,
                         float* nll_part, cgen_stream_t);

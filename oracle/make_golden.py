@@ -285,7 +285,7 @@ def train_steps():
 def simple_vae_fixture(B=6, seed=11, tag="c1", C=1, cond_prior=True):
     """Config 1: the reference's ``simple_vae.VAE`` at the morphomnist preset with --cond_prior
     --context_dim 12 (234 690 parameters), parents [B,12] = two uniform(-1,1) scalars + one-hot(10).
-    tag "c1x": the same with the exogenous N(0,I) prior (no --cond_prior)."""
+    tag "c1x": the same with the exogenous N(0,I) prior (no --cond_prior); tag "c3": RGB input (independent channels)."""
     import simple_vae as ref_simple  # noqa: E402  (reference)
 
     gen = torch.Generator().manual_seed(seed)
@@ -360,6 +360,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "simple":
         simple_vae_fixture()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "simple_c3":
+        simple_vae_fixture(seed=13, tag="c3", C=3, cond_prior=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "simple_c1x":
         simple_vae_fixture(seed=12, tag="c1x", C=1, cond_prior=False)
         sys.exit(0)
@@ -377,3 +380,4 @@ if __name__ == "__main__":
     train_steps()
     simple_vae_fixture()
     simple_vae_fixture(seed=12, tag="c1x", C=1, cond_prior=False)
+    simple_vae_fixture(seed=13, tag="c3", C=3, cond_prior=True)

@@ -11,7 +11,7 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-NAMES = ["simple_vae_c1.pt", "simple_vae_c1x.pt"]  # conditional-prior preset; the same with the exogenous prior
+NAMES = ["simple_vae_c1.pt", "simple_vae_c1x.pt", "simple_vae_c3.pt"]  # conditional-prior preset; exogenous prior; RGB input
 
 
 def build(name="simple_vae_c1.pt"):
