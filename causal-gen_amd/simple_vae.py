@@ -138,10 +138,15 @@ class VAE(HVAE):
         self.encoder = Encoder(args)
         self.decoder = Decoder(args)
         x_dist = args.x_like.split("_")[1]
-        if x_dist != "dgauss" or args.input_channels not in (1, 3):
-            raise NotImplementedError(f"simple_vae on the HIP path: x_like=*_dgauss with one or three input channels (got "
-                                      f"{args.x_like}, {args.input_channels} channels)")
-        self.likelihood = DGaussNet(args)
+        if x_dist == "dgauss" and args.input_channels in (1, 3):
+            self.likelihood = DGaussNet(args)
+        elif x_dist == "dmol" and args.input_channels == 3:  # simple_vae.py:336-339
+            from .dmol import DmolNet
+
+            self.likelihood = DmolNet(args)
+        else:
+            raise NotImplementedError(f"simple_vae on the HIP path: x_like=*_dgauss (one or three channels) or *_dmol (three) "
+                                      f"(got {args.x_like}, {args.input_channels} channels)")
         self.free_bits = 0.0
         self.z_dim, self.context_dim, self.input_channels = args.z_dim, args.context_dim, args.input_channels
         self.hidden_dim = args.hidden_dim
@@ -183,8 +188,11 @@ class VAE(HVAE):
         add("decoder.conv.1", d.conv[1], [n], [True])
         add("decoder.conv.4", d.conv[4], [n], [True])
         add("decoder.conv.7", d.conv[7], [n * 25], [True], as_1x1=True)  # 5x5/p2 as im2col + 1x1 as well
-        for nme, cv in zip(("x_loc", "x_logscale"), self.likelihood.heads()):
-            add("likelihood." + nme, cv, [cv.in_channels], [True])
+        if self.likelihood.kind == "dgauss":
+            for nme, cv in zip(("x_loc", "x_logscale"), self.likelihood.heads()):
+                add("likelihood." + nme, cv, [cv.in_channels], [True])
+        else:
+            add("likelihood.conv", self.likelihood.conv, [self.likelihood.conv.in_channels], [True])
         return sites
 
     def _s(self, mod):
@@ -281,7 +289,10 @@ class VAE(HVAE):
         params = self._likelihood_params(eng, h)
         nchunk = lib.like_chunks(R, R)
         nll_ptr = eng.new_f32(B * nchunk)
-        lib.dgauss_nll_fwd(eng.dt, B, R, R, Cx, params.cv(), xin.cv(), nll_ptr, eng.stream)
+        if self.likelihood.kind == "dgauss":
+            lib.dgauss_nll_fwd(eng.dt, B, R, R, Cx, params.cv(), xin.cv(), nll_ptr, eng.stream)
+        else:
+            lib.dmol_nll_fwd(eng.dt, B, R, R, params.cv(), xin.cv(), nll_ptr, eng.stream)
         out3 = torch.empty(3, dtype=torch.float32, device=eng.device)
         dims = float(Cx * R * R)
         lib.elbo_finalize(B, nll_ptr, nchunk, dims, kl_ptr, nch, dims, float(beta), out3.data_ptr(), eng.stream)
@@ -292,7 +303,10 @@ class VAE(HVAE):
 
     # ------------------------------------------------------------------ inference API
     def _like_sample(self, eng, h, return_loc, t):
-        """DGaussNet.sample of simple_vae.py:162-171 (the temperature IS applied when return_loc=False)."""
+        """DGaussNet.sample of simple_vae.py:162-171 (the temperature IS applied when return_loc=False); DmolNet.sample is
+        the one HVAE uses (dmol.py:234-245)."""
+        if self.likelihood.kind != "dgauss":
+            return self._sample_likelihood(eng, h, return_loc, t)
         params = self._likelihood_params(eng, h)
         B, R, Cx = h.n, h.h, self.input_channels
         xo = torch.empty((B, Cx, R, R), dtype=torch.float32, device=eng.device)

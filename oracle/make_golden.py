@@ -282,16 +282,16 @@ def train_steps():
     print("train_steps: norms[5]=%.1f norms[9]=%.1f" % (norms[5], norms[9]))
 
 
-def simple_vae_fixture(B=6, seed=11, tag="c1", C=1, cond_prior=True):
+def simple_vae_fixture(B=6, seed=11, tag="c1", C=1, cond_prior=True, x_like="diag_dgauss"):
     """Config 1: the reference's ``simple_vae.VAE`` at the morphomnist preset with --cond_prior
     --context_dim 12 (234 690 parameters), parents [B,12] = two uniform(-1,1) scalars + one-hot(10).
-    tag "c1x": the same with the exogenous N(0,I) prior (no --cond_prior); tag "c3": RGB input (independent channels)."""
+    tag "c1x": the same with the exogenous N(0,I) prior (no --cond_prior); tag "c3": RGB input (independent channels); tag "dmol3": RGB with dmol.DmolNet."""
     import simple_vae as ref_simple  # noqa: E402  (reference)
 
     gen = torch.Generator().manual_seed(seed)
     a = Hparams()
     a.update(dict(hps="morphomnist", input_res=32, input_channels=C, z_dim=16, context_dim=12, cond_prior=cond_prior,
-                  widths=[16, 32, 64, 128, 256], x_like="diag_dgauss", std_init=0.0, kl_free_bits=0.0))
+                  widths=[16, 32, 64, 128, 256], x_like=x_like, std_init=0.0, kl_free_bits=0.0))
     torch.manual_seed(seed)
     m = ref_simple.VAE(a).eval()
     n_params = sum(p.numel() for p in m.parameters())
@@ -319,7 +319,7 @@ def simple_vae_fixture(B=6, seed=11, tag="c1", C=1, cond_prior=True):
         out["elbo"].backward()
         grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
         fx = dict(hp=dict(hps="morphomnist", input_res=32, input_channels=C, z_dim=16, context_dim=12, cond_prior=cond_prior,
-                          widths=[16, 32, 64, 128, 256], x_like="diag_dgauss", std_init=0.0, hidden_dim=128),
+                          widths=[16, 32, 64, 128, 256], x_like=x_like, std_init=0.0, hidden_dim=128),
                   n_params=n_params, init_seed=seed, init_abs_sum=init_abs_sum, state_dict={k: v.detach().clone() for k, v in m.state_dict().items()},
                   x=x, pa=pa, cf_pa=cf_pa, eps=eps,
                   fwd=dict(beta=2.0, grads=grads, **{k: v.detach() for k, v in out.items()}))
@@ -360,6 +360,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "simple":
         simple_vae_fixture()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "simple_dmol3":
+        simple_vae_fixture(seed=14, tag="dmol3", C=3, cond_prior=True, x_like="diag_dmol")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "simple_c3":
         simple_vae_fixture(seed=13, tag="c3", C=3, cond_prior=True)
         sys.exit(0)
@@ -381,3 +384,4 @@ if __name__ == "__main__":
     simple_vae_fixture()
     simple_vae_fixture(seed=12, tag="c1x", C=1, cond_prior=False)
     simple_vae_fixture(seed=13, tag="c3", C=3, cond_prior=True)
+    simple_vae_fixture(seed=14, tag="dmol3", C=3, cond_prior=True, x_like="diag_dmol")

@@ -2,7 +2,8 @@
 strided-conv encoder, linear bottleneck and upsample+conv decoder, 234 690 parameters at the morphomnist preset).
 Functional and ``state_dict``-driven like hvae_ref.py; every function cites the reference lines it follows.  Only
 ``tests/`` may import this module.  Pinned by tests/golden/simple_vae_c1.pt and simple_vae_c1x.pt (made from the imported reference by
-oracle/make_golden.py).  Likelihood: the discretised Gaussian of simple_vae.py:103-171 (``x_like = *_dgauss``).
+oracle/make_golden.py).  Likelihood: the discretised Gaussian of simple_vae.py:103-171 (``x_like = *_dgauss``), or dmol.DmolNet via dmol_ref.py
+(``*_dmol``, simple_vae.py:336-339).
 """
 import math
 
@@ -91,8 +92,15 @@ def like_params(sd, h, t=None):
     return loc, ls
 
 
+def _is_dmol(sd):
+    return "likelihood.conv.weight" in sd  # x_like = *_dmol: dmol.DmolNet (simple_vae.py:336-339)
+
+
 def nll(sd, h, x):
-    """DGaussNet.nll, simple_vae.py:141-160."""
+    """DGaussNet.nll, simple_vae.py:141-160 (or DmolNet.nll, dmol.py:229-232)."""
+    if _is_dmol(sd):
+        from . import dmol_ref
+        return dmol_ref.dmolnet_nll(sd, h, x)
     loc, ls = like_params(sd, h)
     c, inv = x - loc, torch.exp(-ls)
     cp, cm = _approx_cdf(inv * (c + 1.0 / 255.0)), _approx_cdf(inv * (c - 1.0 / 255.0))
@@ -102,7 +110,10 @@ def nll(sd, h, x):
 
 
 def like_sample(sd, h, return_loc=True, t=None, eps=None):
-    """DGaussNet.sample, simple_vae.py:162-171 (here t IS applied when return_loc=False)."""
+    """DGaussNet.sample, simple_vae.py:162-171 (here t IS applied when return_loc=False); DmolNet.sample, dmol.py:234-245."""
+    if _is_dmol(sd):
+        from . import dmol_ref
+        return dmol_ref.dmolnet_sample(sd, h, return_loc=return_loc, t=t)
     if return_loc:
         x, ls = like_params(sd, h)
     else:

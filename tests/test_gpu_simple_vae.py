@@ -11,7 +11,7 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-NAMES = ["simple_vae_c1.pt", "simple_vae_c1x.pt", "simple_vae_c3.pt"]  # conditional-prior preset; exogenous prior; RGB input
+NAMES = ["simple_vae_c1.pt", "simple_vae_c1x.pt", "simple_vae_c3.pt", "simple_vae_dmol3.pt"]  # preset; exogenous prior; RGB; RGB + DMoL
 
 
 def build(name="simple_vae_c1.pt"):

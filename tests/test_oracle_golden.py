@@ -159,7 +159,8 @@ def test_train_steps_adamw_ema():
     assert tr.skipped == 1
 
 
-@pytest.mark.parametrize("name,n_params", [("simple_vae_c1.pt", 234690), ("simple_vae_c1x.pt", 208274), ("simple_vae_c3.pt", 236358)])
+@pytest.mark.parametrize("name,n_params", [("simple_vae_c1.pt", 234690), ("simple_vae_c1x.pt", 208274), ("simple_vae_c3.pt", 236358),
+                                           ("simple_vae_dmol3.pt", 237956)])
 def test_simple_vae_config1(name, n_params):
     """Config 1: the oracle's restatement of simple_vae.py against the reference's own outputs (conditional-prior
     preset; the same with the exogenous prior; RGB input)."""
