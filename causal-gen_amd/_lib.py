@@ -94,6 +94,9 @@ PROTOTYPES = {
     "cgen_dgauss_nll_fwd": [i32, i32, i32, i32, i32, View, View, vp, vp],
     "cgen_dgauss_nll_bwd": [i32, i32, i32, i32, i32, View, View, vp, i32, View, vp],
     "cgen_dgauss_sample": [i32, i32, i32, i32, i32, View, f32, vp, u32, vp, vp, vp],
+    "cgen_gauss_nll_fwd": [i32, i32, i32, i32, i32, View, View, View, vp, u32, vp, vp],
+    "cgen_gauss_nll_bwd": [i32, i32, i32, i32, i32, View, View, View, vp, u32, vp, i32, View, vp],
+    "cgen_gauss_sample": [i32, i32, i32, i32, i32, View, f32, vp, u32, vp, vp, vp],
     "cgen_dmol_nll_fwd": [i32, i32, i32, i32, View, View, vp, vp],
     "cgen_dmol_nll_bwd": [i32, i32, i32, i32, View, View, vp, i32, View, vp],
     "cgen_dmol_decode": [i32, i32, i32, i32, View, i32, vp, u32, f32, vp, vp, vp],

@@ -144,6 +144,97 @@ __global__ __launch_bounds__(256) void dgauss_sample_kernel(int n, int h, int w,
   }
 }
 
+// ----------------------------------------------------------------------------- logit-space Gaussian (simple_vae.py GaussNet)
+// nll (simple_vae.py:215-229): x in [-1,1] -> [0,255] + u, u ~ U[0,1) (dequantisation) -> logit(x / 256) (torch's
+// SigmoidTransform.inv: the argument clamped to [tiny, 1 - eps]) -> -log N(. ; loc, exp(max(logscale, -9))), summed; no
+// log-determinant term (the reference has none).  u is an injected NHWC view, or Philox uniforms indexed by element.
+struct GsP {
+  int n, h, w, c;
+  View params, x, u, g;
+  const uint64_t* rng;
+  uint32_t stream_id, pad0;
+  float* part;
+  const float* coef;
+  int coef_stride, pad1;
+};
+
+template <typename T>
+__device__ __forceinline__ float gs_target(const GsP& p, int b, int y, int x, int c, float xv) {
+  float u;
+  if (p.u.p != nullptr) u = Elem<T>::ld(vptr<T>(p.u, b, y, x) + c);
+  else {
+    uint32_t r[4];
+    Philox::gen(p.rng[0], p.rng[1], p.stream_id, ((uint64_t)((int64_t)b * p.h + y) * p.w + x) * p.c + c, r);
+    u = Philox::u01(r[0]);
+  }
+  float v = ((xv + 1.0f) * 127.5f + u) * (1.0f / 256.0f);
+  v = fminf(fmaxf(v, 1.17549435e-38f), 1.0f - 1.1920929e-07f);
+  return logf(v) - log1pf(-v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gauss_nll_fwd_kernel(GsP p) {
+  __shared__ float sm[4];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int npix = p.h * p.w;
+  float acc = 0.f;
+  for (int i = 0; i < LIKE_PIX / 256; ++i) {
+    const int px = chunk * LIKE_PIX + i * 256 + threadIdx.x;
+    if (px < npix) {
+      const int y = px / p.w, x = px % p.w;
+      const T* pp = vptr<T>(p.params, b, y, x);
+      const T* xp = vptr<T>(p.x, b, y, x);
+      for (int c = 0; c < p.c; ++c) {
+        const float loc = Elem<T>::ld(pp + c), ls = fmaxf(Elem<T>::ld(pp + p.c + c), DG_MIN_LS);
+        const float d = (gs_target<T>(p, b, y, x, c, Elem<T>::ld(xp + c)) - loc) * expf(-ls);
+        acc += 0.5f * d * d + ls + 0.9189385332046727f;  // -log N: 0.5 d^2 + log sigma + 0.5 log(2 pi)
+      }
+    }
+  }
+  const float tot = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) p.part[(int64_t)b * gridDim.x + chunk] = tot;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gauss_nll_bwd_kernel(GsP p) {
+  const int npix = p.h * p.w;
+  const int64_t total = (int64_t)p.n * npix;
+  for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * 256) {
+    const int b = (int)(gi / npix), px = (int)(gi % npix);
+    const int y = px / p.w, x = px % p.w;
+    const T* pp = vptr<T>(p.params, b, y, x);
+    const T* xp = vptr<T>(p.x, b, y, x);
+    T* go = vptr<T>(p.g, b, y, x);
+    const float coef = p.coef[(int64_t)b * p.coef_stride];
+    for (int c = 0; c < p.c; ++c) {
+      const float loc = Elem<T>::ld(pp + c), lsr = Elem<T>::ld(pp + p.c + c), ls = fmaxf(lsr, DG_MIN_LS);
+      const float inv = expf(-ls), d = (gs_target<T>(p, b, y, x, c, Elem<T>::ld(xp + c)) - loc) * inv;
+      Elem<T>::st(go + c, -coef * d * inv);
+      Elem<T>::st(go + p.c + c, lsr >= DG_MIN_LS ? coef * (1.f - d * d) : 0.f);
+    }
+  }
+}
+
+// GaussNet.sample (simple_vae.py:231-238): scale = exp(logscale + log t) in BOTH modes; x = loc (+ scale * N(0,1)) ->
+// sigmoid * 256 -> clamp((. - 128) / 128, -1, 1)
+template <typename T>
+__global__ __launch_bounds__(256) void gauss_sample_kernel(int n, int h, int w, int c, View params, float logt, const uint64_t* rng, uint32_t stream_id, float* xo, float* so) {
+  const int npix = h * w;
+  const int64_t total = (int64_t)n * npix;
+  for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * 256) {
+    const int b = (int)(gi / npix), px = (int)(gi % npix);
+    const T* pp = vptr<T>(params, b, px / w, px % w);
+    for (int ch = 0; ch < c; ++ch) {
+      const int64_t o = ((int64_t)b * c + ch) * npix + px;
+      const float sc = expf(fmaxf(Elem<T>::ld(pp + c + ch), DG_MIN_LS) + logt);
+      const float noise = rng ? sc * Philox::normal1(rng[0], rng[1], stream_id, (uint64_t)o) : 0.f;
+      const float v = 256.0f / (1.0f + expf(-(Elem<T>::ld(pp + ch) + noise)));
+      xo[o] = fminf(fmaxf((v - 128.0f) * (1.0f / 128.0f), -1.f), 1.f);
+      so[o] = sc;
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------- discretised mixture of logistics
 #define DM_NMIX 10
 #define DM_MIN_LS (-7.0f)
@@ -554,4 +645,43 @@ extern "C" int cgen_elbo_finalize_fb(int32_t n, const float* nll_part, int32_t n
   hipLaunchKernelGGL(elbo_finalize_fb_kernel, dim3(1), dim3(256), (n + 256) * sizeof(float), (hipStream_t)stream, n, nll_part, nll_count,
                      nll_div, kl_bc, ncol, kl_div, free_bits, beta, out3, chan_mask);
   return check_launch("cgen_elbo_finalize_fb");
+}
+
+extern "C" int cgen_gauss_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x, cgen_view u,
+                                  const uint64_t* rng, uint32_t stream_id, float* nll_part, cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_gauss_nll_fwd: bad dtype");
+  CGEN_REQUIRE((c == 1 || c == 3) && params.p && x.p && nll_part && params.c >= 2 * c && (u.p || rng), "cgen_gauss_nll_fwd: bad args");
+  GsP p;
+  memset(&p, 0, sizeof(p));
+  p.n = n; p.h = h; p.w = w; p.c = c; p.params = mk(params); p.x = mk(x); p.u = mk(u); p.rng = rng; p.stream_id = stream_id; p.part = nll_part;
+  dim3 grid(cgen_like_chunks(h, w), n);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(gauss_nll_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gauss_nll_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("cgen_gauss_nll_fwd");
+}
+
+extern "C" int cgen_gauss_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x, cgen_view u,
+                                  const uint64_t* rng, uint32_t stream_id, const float* coef_dev, int32_t coef_stride,
+                                  cgen_view g_params, cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_gauss_nll_bwd: bad dtype");
+  CGEN_REQUIRE((c == 1 || c == 3) && params.p && x.p && coef_dev && g_params.p && params.c >= 2 * c && g_params.c >= 2 * c && (u.p || rng),
+               "cgen_gauss_nll_bwd: bad args");
+  GsP p;
+  memset(&p, 0, sizeof(p));
+  p.n = n; p.h = h; p.w = w; p.c = c; p.params = mk(params); p.x = mk(x); p.u = mk(u); p.g = mk(g_params); p.rng = rng; p.stream_id = stream_id;
+  p.coef = coef_dev; p.coef_stride = coef_stride;
+  const int grid = like_grid((int64_t)n * h * w);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(gauss_nll_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gauss_nll_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("cgen_gauss_nll_bwd");
+}
+
+extern "C" int cgen_gauss_sample(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, float logt,
+                                 const uint64_t* rng, uint32_t stream_id, float* x_nchw, float* scale_nchw, cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_gauss_sample: bad dtype");
+  CGEN_REQUIRE((c == 1 || c == 3) && params.p && x_nchw && scale_nchw && params.c >= 2 * c, "cgen_gauss_sample: bad args");
+  const int grid = like_grid((int64_t)n * h * w);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(gauss_sample_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
+  else hipLaunchKernelGGL(gauss_sample_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
+  return check_launch("cgen_gauss_sample");
 }

@@ -128,6 +128,11 @@ class DGaussNet(_HvaeDGaussNet):
         return 2 * self.channels
 
 
+class GaussNet(DGaussNet):
+    """simple_vae.py:173-248: Gaussian in logit space on dequantised pixels (x_like = *_gauss); same two heads."""
+    logit_space = True
+
+
 class VAE(HVAE):
     compute_dtype = "f32"
 
@@ -140,12 +145,14 @@ class VAE(HVAE):
         x_dist = args.x_like.split("_")[1]
         if x_dist == "dgauss" and args.input_channels in (1, 3):
             self.likelihood = DGaussNet(args)
+        elif x_dist == "gauss" and args.input_channels in (1, 3):
+            self.likelihood = GaussNet(args)
         elif x_dist == "dmol" and args.input_channels == 3:  # simple_vae.py:336-339
             from .dmol import DmolNet
 
             self.likelihood = DmolNet(args)
         else:
-            raise NotImplementedError(f"simple_vae on the HIP path: x_like=*_dgauss (one or three channels) or *_dmol (three) "
+            raise NotImplementedError(f"simple_vae on the HIP path: x_like=*_dgauss / *_gauss (one or three channels) or *_dmol (three) "
                                       f"(got {args.x_like}, {args.input_channels} channels)")
         self.free_bits = 0.0
         self.z_dim, self.context_dim, self.input_channels = args.z_dim, args.context_dim, args.input_channels
@@ -289,7 +296,17 @@ class VAE(HVAE):
         params = self._likelihood_params(eng, h)
         nchunk = lib.like_chunks(R, R)
         nll_ptr = eng.new_f32(B * nchunk)
-        if self.likelihood.kind == "dgauss":
+        if getattr(self.likelihood, "logit_space", False):
+            # dequantisation noise (simple_vae.py:222): injected for tests (`dequant_noise`, NCHW in [0,1)), else Philox
+            # uniforms keyed by a snapshot of this pass's state, which the backward pass reads again
+            un = self.__dict__.get("dequant_noise")
+            u_nt = None if un is None else eng.from_nchw(un.to(eng.device, torch.float32).contiguous(), rg=False)
+            u = NULL_VIEW if u_nt is None else u_nt.cv()
+            eng.rng_ptr()
+            snap = eng.rng.clone()
+            self.__dict__["_gauss_noise"] = (u, snap, u_nt)  # (u_nt keeps the injected tensor alive until the backward pass)
+            lib.gauss_nll_fwd(eng.dt, B, R, R, Cx, params.cv(), xin.cv(), u, snap.data_ptr(), 977, nll_ptr, eng.stream)
+        elif self.likelihood.kind == "dgauss":
             lib.dgauss_nll_fwd(eng.dt, B, R, R, Cx, params.cv(), xin.cv(), nll_ptr, eng.stream)
         else:
             lib.dmol_nll_fwd(eng.dt, B, R, R, params.cv(), xin.cv(), nll_ptr, eng.stream)
@@ -312,8 +329,12 @@ class VAE(HVAE):
         xo = torch.empty((B, Cx, R, R), dtype=torch.float32, device=eng.device)
         so = torch.empty_like(xo)
         logt = 0.0 if (return_loc or t is None) else float(np.log(t))
-        eng.lib.dgauss_sample(eng.dt, B, R, R, Cx, params.cv(), logt, None if return_loc else eng.rng_ptr(), 979,
-                              xo.data_ptr(), so.data_ptr(), eng.stream)
+        if getattr(self.likelihood, "logit_space", False):  # GaussNet.sample: the temperature scales `scale` in both modes
+            eng.lib.gauss_sample(eng.dt, B, R, R, Cx, params.cv(), 0.0 if t is None else float(np.log(t)),
+                                 None if return_loc else eng.rng_ptr(), 979, xo.data_ptr(), so.data_ptr(), eng.stream)
+        else:
+            eng.lib.dgauss_sample(eng.dt, B, R, R, Cx, params.cv(), logt, None if return_loc else eng.rng_ptr(), 979,
+                                  xo.data_ptr(), so.data_ptr(), eng.stream)
         eng.launches += 1
         return xo, so
 

@@ -96,7 +96,11 @@ class TrainStep:
             self.coef_key = (B, dims, beta)
         eng.kl_coef_ptr = self.coef.data_ptr() + 4
         gparams = eng.seed_grad(params)
-        if m.likelihood.kind == "dgauss":
+        if getattr(m.likelihood, "logit_space", False):
+            u, snap = m.__dict__["_gauss_noise"][:2]
+            self.lib.gauss_nll_bwd(eng.dt, B, R, R, Cx, params.cv(), xin.cv(), u, snap.data_ptr(), 977, self.coef.data_ptr(), 0,
+                                   gparams.cv(), eng.stream)
+        elif m.likelihood.kind == "dgauss":
             self.lib.dgauss_nll_bwd(eng.dt, B, R, R, Cx, params.cv(), xin.cv(), self.coef.data_ptr(), 0, gparams.cv(), eng.stream)
         else:
             self.lib.dmol_nll_bwd(eng.dt, B, R, R, params.cv(), xin.cv(), self.coef.data_ptr(), 0, gparams.cv(), eng.stream)

@@ -556,7 +556,11 @@ class HVAE(nn.Module):
         eng.stream = torch.cuda.current_stream(eng.device).cuda_stream
         eng.kl_coef_ptr = coef.data_ptr() + 4
         gparams = eng.seed_grad(params)
-        if self.likelihood.kind == "dgauss":
+        if getattr(self.likelihood, "logit_space", False):  # simple_vae's GaussNet: same dequantisation noise as the forward pass
+            u, snap = self.__dict__["_gauss_noise"][:2]
+            lib.gauss_nll_bwd(eng.dt, B, R, R, Cx, params.cv(), xin.cv(), u, snap.data_ptr(), 977, coef.data_ptr(), 0, gparams.cv(),
+                              eng.stream)
+        elif self.likelihood.kind == "dgauss":
             lib.dgauss_nll_bwd(eng.dt, B, R, R, Cx, params.cv(), xin.cv(), coef.data_ptr(), 0, gparams.cv(), eng.stream)
         else:
             lib.dmol_nll_bwd(eng.dt, B, R, R, params.cv(), xin.cv(), coef.data_ptr(), 0, gparams.cv(), eng.stream)

@@ -236,6 +236,19 @@ int cgen_dgauss_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t 
  * x = clamp(loc + scale * N(0,1)) with Philox noise of stream `stream_id` */
 int cgen_dgauss_sample(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, float logt,
                        const uint64_t* rng, uint32_t stream_id, float* x_nchw, float* scale_nchw, cgen_stream_t);
+/* Logit-space Gaussian of the config-1 model (simple_vae.py:173-248, GaussNet; x_like = *_gauss).  params = [loc(C) |
+ * logscale(C)].  nll: x in [-1,1] -> (x+1)*127.5 + u, u ~ U[0,1) -> logit(./256) -> -log N(.; loc, exp(max(logscale,-9)))
+ * (simple_vae.py:215-229; no log-determinant, as the reference).  u: NHWC view of injected uniforms (u.p != NULL), else
+ * Philox uniforms from the device (seed, offset) pair `rng`, stream `stream_id`; bwd must be given the same u / rng state.
+ * sample (simple_vae.py:231-238): scale = exp(logscale + logt) in both modes, x = loc (+ scale*N(0,1) when rng != NULL)
+ * -> sigmoid*256 -> clamp((.-128)/128, -1, 1); NCHW f32 out. */
+int cgen_gauss_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x, cgen_view u,
+                       const uint64_t* rng, uint32_t stream_id, float* nll_part, cgen_stream_t);
+int cgen_gauss_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x, cgen_view u,
+                       const uint64_t* rng, uint32_t stream_id, const float* coef_dev, int32_t coef_stride,
+                       cgen_view g_params, cgen_stream_t);
+int cgen_gauss_sample(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, float logt,
+                      const uint64_t* rng, uint32_t stream_id, float* x_nchw, float* scale_nchw, cgen_stream_t);
 /* Discretised mixture of logistics, 10 mixtures, 3 channels (dmol.py:24-118, 164-215, 121-161). logits: [.,100] */
 int cgen_dmol_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, cgen_view x, float* nll_part,
                       cgen_stream_t);

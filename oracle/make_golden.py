@@ -285,7 +285,7 @@ def train_steps():
 def simple_vae_fixture(B=6, seed=11, tag="c1", C=1, cond_prior=True, x_like="diag_dgauss"):
     """Config 1: the reference's ``simple_vae.VAE`` at the morphomnist preset with --cond_prior
     --context_dim 12 (234 690 parameters), parents [B,12] = two uniform(-1,1) scalars + one-hot(10).
-    tag "c1x": the same with the exogenous N(0,I) prior (no --cond_prior); tag "c3": RGB input (independent channels); tag "dmol3": RGB with dmol.DmolNet."""
+    tag "c1x": the same with the exogenous N(0,I) prior (no --cond_prior); tag "c3": RGB input (independent channels); tag "dmol3": RGB with dmol.DmolNet; tag "gauss1": the logit-space GaussNet (dequantisation noise pinned)."""
     import simple_vae as ref_simple  # noqa: E402  (reference)
 
     gen = torch.Generator().manual_seed(seed)
@@ -312,6 +312,10 @@ def simple_vae_fixture(B=6, seed=11, tag="c1", C=1, cond_prior=True, x_like="dia
     eps = torch.randn(B, 16, generator=gen)
     orig = ref_simple.sample_gaussian
     ref_simple.sample_gaussian = lambda loc, ls: loc + ls.exp() * eps
+    u_deq = torch.rand(B, C, 32, 32, generator=gen) if x_like.endswith("_gauss") else None
+    orig_rand = torch.rand_like
+    if u_deq is not None:  # GaussNet.nll dequantises with torch.rand_like(x) (simple_vae.py:222): pin it
+        torch.rand_like = lambda t_, **k: u_deq.clone()
     try:
         for p in m.parameters():
             p.grad = None
@@ -351,6 +355,9 @@ def simple_vae_fixture(B=6, seed=11, tag="c1", C=1, cond_prior=True, x_like="dia
             fx["sample"] = dict(t=0.8, x=s_loc, scale=s_scale)
     finally:
         ref_simple.sample_gaussian = orig
+        torch.rand_like = orig_rand
+    if u_deq is not None:
+        fx["u"] = u_deq
     path = os.path.join(OUT, "simple_vae_%s.pt" % tag)
     torch.save(fx, path)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB;", n_params, "parameters")
@@ -362,6 +369,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "simple_dmol3":
         simple_vae_fixture(seed=14, tag="dmol3", C=3, cond_prior=True, x_like="diag_dmol")
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "simple_gauss1":
+        simple_vae_fixture(seed=15, tag="gauss1", C=1, cond_prior=True, x_like="diag_gauss")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "simple_c3":
         simple_vae_fixture(seed=13, tag="c3", C=3, cond_prior=True)
@@ -385,3 +395,4 @@ if __name__ == "__main__":
     simple_vae_fixture(seed=12, tag="c1x", C=1, cond_prior=False)
     simple_vae_fixture(seed=13, tag="c3", C=3, cond_prior=True)
     simple_vae_fixture(seed=14, tag="dmol3", C=3, cond_prior=True, x_like="diag_dmol")
+    simple_vae_fixture(seed=15, tag="gauss1", C=1, cond_prior=True, x_like="diag_gauss")

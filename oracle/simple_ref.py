@@ -96,11 +96,37 @@ def _is_dmol(sd):
     return "likelihood.conv.weight" in sd  # x_like = *_dmol: dmol.DmolNet (simple_vae.py:336-339)
 
 
-def nll(sd, h, x):
-    """DGaussNet.nll, simple_vae.py:141-160 (or DmolNet.nll, dmol.py:229-232)."""
+def _is_logit(hp):
+    return hp is not None and getattr(hp, "x_like", "diag_dgauss").split("_")[1] == "gauss"  # GaussNet, simple_vae.py:332-333
+
+
+def gauss_nll(sd, h, x, u=None):
+    """GaussNet.nll, simple_vae.py:215-229: dequantise with u ~ U[0,1), logit(x / 256) (torch's SigmoidTransform.inv clamps
+    its argument to [tiny, 1 - eps]), Normal log-density summed over (C,H,W) / D.  No log-determinant term."""
+    loc, ls = like_params(sd, h)
+    v = ((x + 1.0) * 127.5 + (torch.rand_like(x) if u is None else u)) / 256.0
+    fi = torch.finfo(v.dtype)
+    v = v.clamp(min=fi.tiny, max=1.0 - fi.eps)
+    tgt = v.log() - (-v).log1p()
+    lp = -0.5 * ((tgt - loc) / ls.exp()) ** 2 - ls - 0.5 * math.log(2 * math.pi)
+    return -1.0 * lp.sum(dim=(1, 2, 3)) / np.prod(x.shape[1:])
+
+
+def gauss_sample(sd, h, return_loc=True, t=None, eps=None):
+    """GaussNet.sample, simple_vae.py:231-238 (the temperature enters the returned scale in both modes)."""
+    loc, ls = like_params(sd, h, t)
+    x = loc if return_loc else loc + ls.exp() * (torch.randn_like(loc) if eps is None else eps)
+    x = torch.sigmoid(x) * 256.0
+    return torch.clamp((x - 128) / 128, min=-1.0, max=1.0), ls.exp()
+
+
+def nll(sd, h, x, hp=None, u=None):
+    """DGaussNet.nll, simple_vae.py:141-160 (or DmolNet.nll, dmol.py:229-232; or GaussNet.nll)."""
     if _is_dmol(sd):
         from . import dmol_ref
         return dmol_ref.dmolnet_nll(sd, h, x)
+    if _is_logit(hp):
+        return gauss_nll(sd, h, x, u)
     loc, ls = like_params(sd, h)
     c, inv = x - loc, torch.exp(-ls)
     cp, cm = _approx_cdf(inv * (c + 1.0 / 255.0)), _approx_cdf(inv * (c - 1.0 / 255.0))
@@ -109,11 +135,13 @@ def nll(sd, h, x):
     return -1.0 * lp.mean(dim=(1, 2, 3))
 
 
-def like_sample(sd, h, return_loc=True, t=None, eps=None):
+def like_sample(sd, h, return_loc=True, t=None, eps=None, hp=None):
     """DGaussNet.sample, simple_vae.py:162-171 (here t IS applied when return_loc=False); DmolNet.sample, dmol.py:234-245."""
     if _is_dmol(sd):
         from . import dmol_ref
         return dmol_ref.dmolnet_sample(sd, h, return_loc=return_loc, t=t)
+    if _is_logit(hp):
+        return gauss_sample(sd, h, return_loc, t, eps)
     if return_loc:
         x, ls = like_params(sd, h)
     else:
@@ -122,13 +150,13 @@ def like_sample(sd, h, return_loc=True, t=None, eps=None):
     return torch.clamp(x, min=-1.0, max=1.0), ls.exp()
 
 
-def forward(sd, hp, x, parents, beta=1, eps=None, drop=(1, 1)):
+def forward(sd, hp, x, parents, beta=1, eps=None, drop=(1, 1), u=None):
     """VAE.forward, simple_vae.py:343-352."""
     q_loc, q_ls = encode(sd, x, parents)
     e = torch.randn_like(q_loc) if eps is None else eps
     z = q_loc + q_ls.exp() * e
     h, (p_loc, p_ls) = decode(sd, hp, parents, z=z, drop=drop)
-    nll_pp = nll(sd, h, x)
+    nll_pp = nll(sd, h, x, hp, u)
     kl_pp = gaussian_kl(q_loc, q_ls, p_loc, p_ls).sum(dim=-1) / np.prod(x.shape[1:])
     return dict(elbo=nll_pp.mean() + beta * kl_pp.mean(), nll=nll_pp.mean(), kl=kl_pp.mean())
 
@@ -136,7 +164,7 @@ def forward(sd, hp, x, parents, beta=1, eps=None, drop=(1, 1)):
 def sample(sd, hp, parents, return_loc=True, t=None, eps=None):
     """VAE.sample, simple_vae.py:354-358."""
     h, _ = decode(sd, hp, parents, t=t, eps=eps)
-    return like_sample(sd, h, return_loc, t=t)
+    return like_sample(sd, h, return_loc, t=t, hp=hp)
 
 
 def abduct(sd, hp, x, parents, cf_parents=None, alpha=0.5, t=None, eps=None):
@@ -161,4 +189,4 @@ def abduct(sd, hp, x, parents, cf_parents=None, alpha=0.5, t=None, eps=None):
 def forward_latents(sd, hp, latents, parents, return_loc=True, t=None):
     """VAE.forward_latents, simple_vae.py:406-415."""
     h, _ = decode(sd, hp, parents, z=latents[0], t=t)
-    return like_sample(sd, h, return_loc, t=t)
+    return like_sample(sd, h, return_loc, t=t, hp=hp)

@@ -2,6 +2,7 @@
 import math
 
 import pytest
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -250,6 +251,65 @@ def test_dgauss_nll_golden(C):
     eng.lib.dgauss_sample(eng.dt, N, H, W, C, pt.cv(), 0.0, None, 0, xo.data_ptr(), so.data_ptr(), eng.stream)
     torch.testing.assert_close(xo.cpu(), d["sample_x"], rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(so.cpu(), d["sample_scale"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("C", [1, 3])
+def test_logit_gaussian_nll_injected_and_philox_noise(C):
+    """simple_vae's GaussNet likelihood (cgen_gauss_nll_fwd/bwd): against the oracle with injected dequantisation noise,
+    then with device-side Philox uniforms -- the backward pass must see the uniforms the forward pass saw: with loc = 0
+    and logscale = 0 its loc-gradient IS minus the logit target, from which the uniforms are recovered, injected, and
+    the forward pass repeated."""
+    from oracle import simple_ref
+
+    N, H, W = 3, 20, 24
+    g = torch.Generator().manual_seed(5 + C)
+    raw = torch.randn(N, 2 * C, H, W, generator=g) * 0.5
+    raw.requires_grad_(True)
+    x = (torch.randint(0, 256, (N, C, H, W), generator=g).float() - 127.5) / 127.5
+    u = torch.rand(N, C, H, W, generator=g)
+    D = C * H * W
+    # oracle: gauss_nll reads loc / logscale through like_params -> identity 1x1 heads over the raw parameters
+    eye = torch.eye(2 * C).view(2 * C, 2 * C, 1, 1)
+    sd = {"likelihood.x_loc.weight": eye[:C], "likelihood.x_loc.bias": torch.zeros(C),
+          "likelihood.x_logscale.weight": eye[C:], "likelihood.x_logscale.bias": torch.zeros(C)}
+    nll_ref = simple_ref.gauss_nll(sd, raw, x, u)
+    (g_ref,) = torch.autograd.grad(nll_ref.sum(), raw)
+    eng, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]])
+    pt, xt, ut = eng.from_nchw(raw.detach().cuda()), eng.from_nchw(x.cuda()), eng.from_nchw(u.cuda())
+    nch = eng.lib.like_chunks(H, W)
+    part = torch.zeros(N * nch, device="cuda")
+    eng.lib.gauss_nll_fwd(eng.dt, N, H, W, C, pt.cv(), xt.cv(), ut.cv(), None, 0, part.data_ptr(), eng.stream)
+    torch.testing.assert_close(part.view(N, nch).sum(1).cpu() / D, nll_ref.detach(), rtol=2e-5, atol=1e-6)
+    gp = eng.new(N, H, W, 2 * C)
+    coef = torch.tensor([1.0 / D], device="cuda")
+    eng.lib.gauss_nll_bwd(eng.dt, N, H, W, C, pt.cv(), xt.cv(), ut.cv(), None, 0, coef.data_ptr(), 0, gp.cv(), eng.stream)
+    torch.testing.assert_close(nhwc_to_torch(eng, gp), g_ref, rtol=2e-3, atol=1e-5 * g_ref.abs().max().item() + 1e-7)
+    # Philox uniforms
+    from causal_gen_amd._lib import NULL_VIEW
+
+    rng = torch.tensor([1234, 3], dtype=torch.int64, device="cuda")
+    zt = eng.from_nchw(torch.zeros(N, 2 * C, H, W).cuda())
+    one = torch.tensor([1.0], device="cuda")
+    eng.lib.gauss_nll_bwd(eng.dt, N, H, W, C, zt.cv(), xt.cv(), NULL_VIEW, rng.data_ptr(), 977, one.data_ptr(), 0, gp.cv(), eng.stream)
+    tgt = -nhwc_to_torch(eng, gp)[:, :C].double()
+    u_rec = torch.sigmoid(tgt) * 256.0 - (x.double() + 1.0) * 127.5
+    assert float(u_rec.min()) > -1e-3 and float(u_rec.max()) < 1 + 1e-3 and abs(float(u_rec.mean()) - 0.5) < 0.02
+    part2 = torch.zeros_like(part)
+    eng.lib.gauss_nll_fwd(eng.dt, N, H, W, C, pt.cv(), xt.cv(), NULL_VIEW, rng.data_ptr(), 977, part2.data_ptr(), eng.stream)
+    want = simple_ref.gauss_nll({k: v.double() for k, v in sd.items()}, raw.detach().double(), x.double(), u_rec.clamp(0, 1)).float()
+    torch.testing.assert_close(part2.view(N, nch).sum(1).cpu() / D, want, rtol=1e-3, atol=1e-4)
+    # a different Philox offset gives different uniforms
+    rng2 = torch.tensor([1234, 4], dtype=torch.int64, device="cuda")
+    part3 = torch.zeros_like(part)
+    eng.lib.gauss_nll_fwd(eng.dt, N, H, W, C, pt.cv(), xt.cv(), NULL_VIEW, rng2.data_ptr(), 977, part3.data_ptr(), eng.stream)
+    torch.cuda.synchronize()
+    assert not torch.equal(part2, part3)
+    # sample: sigmoid * 256 -> [-1, 1], scale carries the temperature in both modes
+    xo, so = torch.empty(N, C, H, W, device="cuda"), torch.empty(N, C, H, W, device="cuda")
+    eng.lib.gauss_sample(eng.dt, N, H, W, C, pt.cv(), float(np.log(0.8)), None, 0, xo.data_ptr(), so.data_ptr(), eng.stream)
+    wx, ws = simple_ref.gauss_sample(sd, raw.detach(), True, 0.8)
+    torch.testing.assert_close(xo.cpu(), wx, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(so.cpu(), ws, rtol=1e-5, atol=1e-7)
 
 
 def test_dmol_golden():

@@ -11,7 +11,8 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 
 
-NAMES = ["simple_vae_c1.pt", "simple_vae_c1x.pt", "simple_vae_c3.pt", "simple_vae_dmol3.pt"]  # preset; exogenous prior; RGB; RGB + DMoL
+NAMES = ["simple_vae_c1.pt", "simple_vae_c1x.pt", "simple_vae_c3.pt", "simple_vae_dmol3.pt", "simple_vae_gauss1.pt"]
+# preset; exogenous prior; RGB; RGB + DMoL; logit-space GaussNet (dequantisation noise injected)
 
 
 def build(name="simple_vae_c1.pt"):
@@ -22,6 +23,8 @@ def build(name="simple_vae_c1.pt"):
     hp = {k: v for k, v in fx["hp"].items() if k != "hidden_dim"}
     m = simple_vae.VAE(Hparams(**hp))
     m.load_state_dict(fx["state_dict"])
+    if "u" in fx:
+        m.dequant_noise = fx["u"]
     return fx, m.cuda().eval()
 
 
@@ -94,8 +97,9 @@ def test_abduct_mediator_replay_counterfactual_and_sample(name):
     m.noise = [fx["eps"].clone(), fx["eps"].clone()]
     cf_te = dscm.counterfactual(m, x, pa, cf_pa, t_abduct=ab["t"], te_cf=True, alpha=ab["alpha"])
     assert (cf_te.cpu() - ab["cf_x"]).abs().max().item() < 1e-3
+    r_loc, r_scale = m.forward_latents([q["z"]], pa)  # (no temperature, as dscm.counterfactual: GaussNet's scale carries t)
     d_loc, d_scale = m.forward_latents([q["z"]], cf_pa)
-    want = dscm.cf_pixels(x, rec_loc, rec_scale, d_loc, d_scale)
+    want = dscm.cf_pixels(x, r_loc, r_scale, d_loc, d_scale)
     for reuse, pair in (("1", "1"), ("0", "1"), ("0", "0")):
         os.environ["CGEN_CF_REUSE"], os.environ["CGEN_CF_PAIR"] = reuse, pair
         try:
@@ -112,3 +116,31 @@ def test_abduct_mediator_replay_counterfactual_and_sample(name):
     # return_loc=False adds pixel noise at temperature t and stays in range
     xs, _ = m.forward_latents([zs], cf_pa, return_loc=False, t=0.7)
     assert float(xs.abs().max()) <= 1.0 and not torch.equal(xs, cf_loc)
+
+
+def test_gaussnet_device_side_dequantisation_noise():
+    """Without injected uniforms the GaussNet likelihood draws its dequantisation noise from the engine's Philox state:
+    same state -> same bits (forward and gradients), next state -> different noise, and the NLL stays where the
+    reference's is for these weights (the noise moves it by well under a percent)."""
+    fx, m = build("simple_vae_gauss1.pt")
+    m.dequant_noise = None
+    x, pa = fx["x"].cuda(), fx["pa"].cuda()
+    eng = m.engine()
+    eng.rng_ptr()
+
+    def run(off):
+        eng.rng.copy_(torch.tensor([77, off], dtype=torch.int64, device=eng.rng.device))
+        m.noise = [fx["eps"].clone()]
+        m.zero_grad()
+        out = m(x, pa, beta=fx["fwd"]["beta"])
+        out["elbo"].backward()
+        torch.cuda.synchronize()
+        return float(out["nll"]), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    n0, g0 = run(0)
+    n1, g1 = run(0)
+    n2, _ = run(5)
+    assert n0 == n1 and all(torch.equal(g0[k], g1[k]) for k in g0)
+    assert n2 != n0 and rel(n0, fx["fwd"]["nll"]) < 1e-2 and rel(n2, fx["fwd"]["nll"]) < 1e-2
+    assert all(torch.isfinite(v).all() for v in g0.values())
+

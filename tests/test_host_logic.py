@@ -100,7 +100,7 @@ def test_dp_gloo_world2():
     assert torch.equal(torch.cat([sh0, sh1]), torch.arange(12.0).view(6, 2)[:6])
 
 
-@pytest.mark.parametrize("name", ["simple_vae_c1.pt", "simple_vae_c1x.pt", "simple_vae_c3.pt", "simple_vae_dmol3.pt"])
+@pytest.mark.parametrize("name", ["simple_vae_c1.pt", "simple_vae_c1x.pt", "simple_vae_c3.pt", "simple_vae_dmol3.pt", "simple_vae_gauss1.pt"])
 def test_simple_vae_module_tree_and_init_rng(name):
     """Config 1: same state_dict keys / parameter count as the reference's simple_vae.VAE and the same default-init RNG
     consumption (sum |theta| under the fixture's seed), checked without a GPU."""

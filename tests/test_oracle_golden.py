@@ -160,7 +160,7 @@ def test_train_steps_adamw_ema():
 
 
 @pytest.mark.parametrize("name,n_params", [("simple_vae_c1.pt", 234690), ("simple_vae_c1x.pt", 208274), ("simple_vae_c3.pt", 236358),
-                                           ("simple_vae_dmol3.pt", 237956)])
+                                           ("simple_vae_dmol3.pt", 237956), ("simple_vae_gauss1.pt", 234690)])
 def test_simple_vae_config1(name, n_params):
     """Config 1: the oracle's restatement of simple_vae.py against the reference's own outputs (conditional-prior
     preset; the same with the exogenous prior; RGB input)."""
@@ -172,7 +172,8 @@ def test_simple_vae_config1(name, n_params):
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in fx["state_dict"].items()}
     x, pa, cf_pa, eps = fx["x"], fx["pa"], fx["cf_pa"], fx["eps"]
     f = fx["fwd"]
-    out = simple_ref.forward(sd, hp, x, pa, beta=f["beta"], eps=eps)
+    u = fx.get("u")  # pinned dequantisation noise (GaussNet only)
+    out = simple_ref.forward(sd, hp, x, pa, beta=f["beta"], eps=eps, u=u)
     for k in ("elbo", "nll", "kl"):
         torch.testing.assert_close(out[k].detach(), f[k], **TOL)
     out["elbo"].backward()
@@ -181,7 +182,7 @@ def test_simple_vae_config1(name, n_params):
     with torch.no_grad():
         if "fwd_drop" in fx:
             d = fx["fwd_drop"]
-            o = simple_ref.forward(sd, hp, x, pa, beta=1.0, eps=eps, drop=d["drop"])
+            o = simple_ref.forward(sd, hp, x, pa, beta=1.0, eps=eps, drop=d["drop"], u=u)
             for k in ("elbo", "nll", "kl"):
                 torch.testing.assert_close(o[k], d[k], **TOL)
         ab = fx["abduct"]
