@@ -3,7 +3,9 @@
 per-parameter gradient agreement.  The graph shape changes with every case (block counts, widths, z_dim, light / default
 blocks, cond_prior, q_correction, free bits, RGB, DMoL), which exercises the engine's gradient bookkeeping (adoption,
 out-of-place accumulation, riders, background flush) beyond the presets.  usage: python tools/fuzz_model.py [n] [seed]
-(FUZZ_ONLY=<case> runs one case of the sequence, FUZZ_XSEED=<k> changes its weights and data)"""
+(FUZZ_ONLY=<case> runs one case of the sequence, FUZZ_XSEED=<k> changes its weights and data -- a case with free bits
+and a tiny batch can sit on the free-bits threshold, where bf16 and f32 pick different channel masks: a failure that
+vanishes with another XSEED and is unchanged by CGEN_WGRAD_FLUSH_FRAC=2 CGEN_RIDER=0 is that, not bookkeeping)"""
 import os
 import random
 import sys
