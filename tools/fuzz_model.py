@@ -3,9 +3,10 @@
 per-parameter gradient agreement.  The graph shape changes with every case (block counts, widths, z_dim, light / default
 blocks, cond_prior, q_correction, free bits, RGB, DMoL), which exercises the engine's gradient bookkeeping (adoption,
 out-of-place accumulation, riders, background flush) beyond the presets.  usage: python tools/fuzz_model.py [n] [seed]
-(FUZZ_ONLY=<case> runs one case of the sequence, FUZZ_XSEED=<k> changes its weights and data -- a case with free bits
-and a tiny batch can sit on the free-bits threshold, where bf16 and f32 pick different channel masks: a failure that
-vanishes with another XSEED and is unchanged by CGEN_WGRAD_FLUSH_FRAC=2 CGEN_RIDER=0 is that, not bookkeeping)"""
+(FUZZ_ONLY=<case> runs one case of the sequence, FUZZ_XSEED=<k> changes its weights and data, FUZZ_FB=<v> overrides the
+free-bits draw.  With a tiny batch at 1x1 resolution a single ReLU unit whose pre-activation is ~0 can be gated differently
+in bf16 and f32; the failure print localises the error by output row -- all of it in ONE row, gone with another XSEED and
+unchanged by CGEN_WGRAD_FLUSH_FRAC=2 CGEN_RIDER=0 is that discontinuity (seed 321 case 17), not bookkeeping)"""
 import os
 import random
 import sys
@@ -37,6 +38,8 @@ for case in range(n):
     ov = dict(input_res=R, enc_arch=enc, dec_arch=dec, widths=widths, z_dim=rng.choice([8, 16]), z_max_res=rng.choice([R, R // 2]),
               bias_max_res=R, input_channels=C, context_dim=rng.choice([4, 6, 12]), cond_prior=rng.random() < 0.5,
               q_correction=rng.random() < 0.3, kl_free_bits=rng.choice([0.0, 0.0, 0.05]))
+    if os.environ.get("FUZZ_FB"):  # override the free-bits draw of every case (diagnosis)
+        ov["kl_free_bits"] = float(os.environ["FUZZ_FB"])
     name = "ukbb192" if light else "morphomnist"
     use_dmol = C == 3 and rng.random() < 0.5
     B = rng.choice([2, 8, 16])
@@ -103,6 +106,10 @@ for case in range(n):
             enc, dec, a[0]["elbo"], b[0]["elbo"], errs[len(errs) // 2], errs[-1], min(cos), cfd, cff, len(rep), rep_cf), flush=True)
         if not ok:
             print("     worst:", worst, flush=True)
+            w0 = worst[0][1]
+            if a[1][w0].dim() >= 2:  # where the error sits: one output row = one unit's gate (ReLU / clamp) decided differently in bf16
+                rowe = (b[1][w0] - a[1][w0]).flatten(1).norm(dim=1)
+                print("     rows of %s by error: %s of total %.3e" % (w0, [(int(i), "%.3e" % float(rowe[i])) for i in rowe.argsort(descending=True)[:3]], float(rowe.norm())), flush=True)
             print("     |g| f32 of those:", ["%.3e" % float(a[1][w[1]].norm()) for w in worst], "median |g| %.3e" % sorted(float(v.norm()) for v in a[1].values())[len(a[1]) // 2], flush=True)
     except Exception as e:  # noqa: BLE001
         fails += 1
