@@ -86,6 +86,44 @@ def test_graph_replay_equals_eager():
         assert torch.equal(s0[k], s1[k]), k
 
 
+@pytest.mark.parametrize("name", ["simple_vae_c1.pt", "simple_vae_gauss1.pt", "simple_vae_dmol3.pt"])
+def test_fused_train_step_on_the_config1_model(name):
+    """TrainStep drives simple_vae.VAE like the HVAE (same engine): the first step reports the autograd path's ELBO, the
+    parameters move, and hipGraph replay equals eager execution bit for bit -- including GaussNet's device-side
+    dequantisation noise, whose Philox snapshot the captured backward pass reads again."""
+    from causal_gen_amd import simple_vae
+    from causal_gen_amd.hps import Hparams
+    from causal_gen_amd.train import TrainStep
+
+    fx = load_golden(name)
+    hpd = {k: v for k, v in fx["hp"].items() if k != "hidden_dim"}
+    hpd.update(lr=1e-3, betas=(0.9, 0.9), wd=0.01, grad_clip=350.0, grad_skip=5000.0, ema_rate=0.99, lr_warmup_steps=2, beta=1.0,
+               accu_steps=1, kl_free_bits=0.0)
+    x, pa = fx["x"].cuda(), fx["pa"].cuda()
+    outs = []
+    for use_graph in (False, True):
+        m = simple_vae.VAE(Hparams(**hpd))
+        m.load_state_dict(fx["state_dict"])
+        m = m.cuda().train()
+        torch.manual_seed(123)
+        ts = TrainStep(m, SimpleNamespace(**hpd), ema=True, use_graph=use_graph)
+        first = None
+        for _ in range(4):
+            o = ts.step(x, pa)
+            first = o.clone() if first is None else first
+        torch.cuda.synchronize()
+        outs.append(([float(v) for v in o.cpu()], [float(v) for v in first.cpu()], {k: v.clone() for k, v in m.state_dict().items()}, ts.stats()))
+    (o0, f0, s0, t0), (o1, f1, s1, t1) = outs
+    assert t0["opt_steps"] == t1["opt_steps"] == 4 and t0["n_skipped"] == 0
+    assert o0 == o1 and f0 == f1, (o0, o1)
+    assert all(torch.isfinite(torch.tensor(o0))) and o0[0] < f0[0]  # four steps on one batch lower its ELBO
+    moved = 0
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+        moved += int(not torch.equal(s0[k].cpu(), fx["state_dict"][k]))
+    assert moved > 10
+
+
 def test_counterfactual_api_and_dscm_forward():
     from causal_gen_amd import dscm
 
