@@ -82,7 +82,7 @@ PROTOTYPES = {
     "cgen_reparam_kl_bwd_rider": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, View, vp, i32, vp, View, View, View,
                                   View, i32, i32, View, View, i32, vp],
     "cgen_kl_channel_sums": [i32, i32, i32, i32, i32, View, View, View, View, f32, vp, i32, vp],
-    "cgen_elbo_finalize_fb": [i32, vp, i32, f32, vp, i32, f32, f32, f32, vp, vp, vp],
+    "cgen_elbo_finalize_fb": [i32, vp, i32, f32, vp, i32, f32, f32, f32, vp, vp, vp, vp],
     "cgen_im2col_strided": [i32, i32, i32, i32, i32, i32, i32, i32, i32, View, View, vp],
     "cgen_col2im_strided": [i32, i32, i32, i32, i32, i32, i32, i32, i32, View, View, i32, vp],
     "cgen_unary_fwd": [i32, i32, f32, i32, i32, i32, i32, View, View, vp],
@@ -100,7 +100,8 @@ PROTOTYPES = {
     "cgen_dmol_nll_fwd": [i32, i32, i32, i32, View, View, vp, vp],
     "cgen_dmol_nll_bwd": [i32, i32, i32, i32, View, View, vp, i32, View, vp],
     "cgen_dmol_decode": [i32, i32, i32, i32, View, i32, vp, u32, f32, vp, vp, vp],
-    "cgen_elbo_finalize": [i32, vp, i32, f32, vp, i32, f32, f32, vp, vp],
+    "cgen_elbo_finalize": [i32, vp, i32, f32, vp, i32, f32, f32, vp, vp, vp],
+    "cgen_cf_dgauss_bwd": [i32, i32, i32, i32, i32, View, View, View, vp, f32, View, View, vp],
     "cgen_cf_pixels": [i64, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "cgen_sumsq_partial": [vp, i64, vp, i32, vp],
     "cgen_clip_decide": [vp, i32, vp, f32, f32, vp, vp],

@@ -138,31 +138,52 @@ class DSCM(nn.Module):
 
     def forward(self, obs: Dict[str, Tensor], do: Dict[str, Tensor], elbo_fn=None, cf_particles: int = 1,
                 t_abduct: float = 1.0) -> Dict[str, Tensor]:
-        """dscm.py:30-95.  The counterfactual image branch is evaluated without building an autograd graph through
-        the three decoder replays (inference-time DSCM); the factual ELBO stays differentiable."""
+        """dscm.py:30-95.  With autograd on and a trainable HVAE the image half runs as ONE recorded engine step
+        (``HVAE._run_dscm_forward``): factual ELBO, abduction, reconstruction and counterfactual replay share a tape, so
+        ``out["loss"].backward()`` reaches the HVAE weights through ``cf_x`` and through the ELBO constraint exactly as the
+        reference's autograd graph does (train_cf.py:159-183).  Under ``torch.no_grad()`` (or with a frozen HVAE) the same
+        numbers come from the inference calls."""
         pa = {k: v for k, v in obs.items() if k != "x"}
         _pa = vae_preprocess(self.args, {k: v.clone() for k, v in pa.items()})
-        vae_out = self.vae(obs["x"], _pa, beta=self.args.beta)
-        x = obs["x"].cuda().float()
-        sx = torch.zeros_like(x) if cf_particles > 1 else None
-        sx2 = torch.zeros_like(x) if cf_particles > 1 else None
-        cf_pa, cf_x = None, None
+        cf_pa, cf_list = None, []
         for _ in range(cf_particles):
             cf_pa = self.pgm.counterfactual(obs=pa, intervention=do, num_particles=1)
-            _cf_pa = vae_preprocess(self.args, {k: v.clone() for k, v in cf_pa.items()})
-            with torch.no_grad():
-                zs = self.vae.abduct(x, parents=_pa, t=t_abduct)
-                if self.vae.cond_prior:
-                    zs = [z["z"] for z in zs]
-                cf_loc, cf_scale = self.vae.forward_latents(zs, parents=_cf_pa)
-                rec_loc, rec_scale = self.vae.forward_latents(zs, parents=_pa)
-                cf_x = cf_pixels(x, rec_loc, rec_scale, cf_loc, cf_scale, sx, sx2)
-        if cf_particles > 1:
-            var_cf_x = (sx2 - sx ** 2 / cf_particles) / cf_particles
-            cfs = {"x": sx / cf_particles}
-        else:
-            var_cf_x = None
+            cf_list.append(vae_preprocess(self.args, {k: v.clone() for k, v in cf_pa.items()}))
+        vae = self.vae
+        if torch.is_grad_enabled() and any(p.requires_grad for p in vae.parameters()):
+            if not getattr(vae, "_dscm_differentiable", False):
+                raise NotImplementedError("DSCM.forward with autograd needs the HVAE image mechanism (its counterfactual passes are "
+                                          "recorded on the engine tape); call under torch.no_grad() for inference")
+            from .vae import _DSCMFunction
+
+            trig = vae.__dict__.get("_trigger")
+            dev = next(vae.parameters()).device
+            if trig is None or trig.device != dev:
+                trig = vae.__dict__["_trigger"] = torch.zeros(1, device=dev, requires_grad=True)
+            elbo, nll, kl, cf_x, var = _DSCMFunction.apply(trig, vae, obs["x"], _pa, tuple(cf_list), self.args.beta, t_abduct)
+            vae_out = dict(elbo=elbo, nll=nll, kl=kl)
+            var_cf_x = var if cf_particles > 1 else None
             cfs = {"x": cf_x}
+        else:
+            vae_out = vae(obs["x"], _pa, beta=self.args.beta)
+            x = obs["x"].cuda().float()
+            sx = torch.zeros_like(x) if cf_particles > 1 else None
+            sx2 = torch.zeros_like(x) if cf_particles > 1 else None
+            cf_x = None
+            with torch.no_grad():
+                for _cf_pa in cf_list:
+                    zs = vae.abduct(x, parents=_pa, t=t_abduct)
+                    if vae.cond_prior:
+                        zs = [z["z"] for z in zs]
+                    cf_loc, cf_scale = vae.forward_latents(zs, parents=_cf_pa)
+                    rec_loc, rec_scale = vae.forward_latents(zs, parents=_pa)
+                    cf_x = cf_pixels(x, rec_loc, rec_scale, cf_loc, cf_scale, sx, sx2)
+            if cf_particles > 1:
+                var_cf_x = (sx2 - sx ** 2 / cf_particles) / cf_particles
+                cfs = {"x": sx / cf_particles}
+            else:
+                var_cf_x = None
+                cfs = {"x": cf_x}
         cfs.update(cf_pa)
         nan = sum(int(torch.isnan(v).sum()) for v in list(vae_out.values()) + [cfs["x"]])
         if nan > 0:

@@ -176,6 +176,8 @@ class Engine:
     # ------------------------------------------------------------------ memory
     def begin(self):
         """Start a new step/pass: recycle the arena, clear the tape and gradient bookkeeping."""
+        self.generation = getattr(self, "generation", 0) + 1  # a recorded pass is only valid within its generation
+        self.kl_coef_override = None
         self.arena.reset()
         self.tape.clear()
         self.grads.clear()
@@ -269,6 +271,9 @@ class Engine:
                 s.img_dg[k] = base + o if s.dg_numel[k] else None
         self._build_prep_table()
         self._weights_version = None
+        # set by whoever writes the flat parameter buffer through raw pointers (the fused AdamW / EMA kernel, which
+        # torch's version counters cannot see): the next prepare_weights() re-images even when no _version moved
+        self.weights_dirty = True
 
     def _flatten(self):
         ps = self.params
@@ -336,8 +341,9 @@ class Engine:
         """OIHW f32 parameters -> forward/dgrad weight images (one multi-tensor launch).  Skipped when no
         parameter changed since the last call (inference)."""
         ver = sum(p._version for p in self.params)
-        if not force and ver == self._weights_version:
+        if not force and ver == self._weights_version and not self.weights_dirty:
             return
+        self.weights_dirty = False
         d, cs, ci, n = self._prep_tab
         self.lib.weight_prep(d.data_ptr(), cs.data_ptr(), ci.data_ptr(), n, self.stream)
         self.launches += 1
@@ -493,7 +499,7 @@ class Engine:
                                 kl_ptr, kl_stride, self.stream)
         self.launches += 1
         if self.recording:
-            self.tape.append((self._bw_reparam, (q_loc, q_ls, p_loc, p_ls, z, logt, None if fb is None else fb[2])))
+            self.tape.append((self._bw_reparam, (q_loc, q_ls, p_loc, p_ls, z, logt, None if fb is None else fb[2], self.kl_coef_override)))
         return z
 
     def sample_gaussian(self, loc, ls, eps, stream_id, logt):
@@ -798,7 +804,7 @@ class Engine:
     def backward(self):
         if self.wgrad_flush_frac:  # total weight-gradient work of this pass: the background-flush marks are fractions of it
             self._wg_total = sum(2.0 * a[0].ci * a[0].taps * a[0].co * a[1][0].n * a[1][0].h * a[1][0].w
-                                 for fn, a in self.tape if fn == self._bw_conv and a[0].conv.weight.requires_grad)
+                                 for fn, a in self.tape if fn == self._bw_conv and self._needs_wgrad(a[0]))
         for fn, args in reversed(self.tape):
             fn(*args)
         for bid in list(self._riders):
@@ -821,7 +827,7 @@ class Engine:
             if r is not None and r.rg:
                 self._grad_residual(r, g, out, segs)
         x0 = segs[0]
-        if site.conv.weight.requires_grad:
+        if self._needs_wgrad(site):
             self._wgrad(site, segs, act, g)
         for k, s in enumerate(segs):
             if not (s.rg and site.seg_rg[k]):
@@ -849,6 +855,13 @@ class Engine:
             a.res1 = vw(prev) if acc else NULL_VIEW
             a.res2 = NULL_VIEW
             self._timed("conv_dgrad", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream), ci=s.c)
+
+    @staticmethod
+    def _needs_wgrad(site):
+        """The weight-and-bias gradient kernel runs when EITHER needs a gradient (x_like='shared_*' freezes the weight of
+        likelihood.x_logscale but trains its bias, vae.py:342-344); only the parts that require grad become visible."""
+        b = site.conv.bias
+        return site.conv.weight.requires_grad or (b is not None and b.requires_grad)
 
     def _wgrad(self, site, segs, act, g):
         x0 = segs[0]
@@ -1061,8 +1074,9 @@ class Engine:
         self.lib.wgrad_reduce(d.data_ptr(), cs.data_ptr(), ci.data_ptr(), n, stream)
         self.launches += 1
         for site, _, _ in events:
-            self.pgrad_init.add(id(site.conv.weight))
-            if site.conv.bias is not None:
+            if site.conv.weight.requires_grad:
+                self.pgrad_init.add(id(site.conv.weight))
+            if site.conv.bias is not None and site.conv.bias.requires_grad:
                 self.pgrad_init.add(id(site.conv.bias))
 
     def _bw_pool(self, x, out, d):
@@ -1112,7 +1126,9 @@ class Engine:
         inner = NT(g.ptr, x.n, x.h, x.w, x.c, g.sn, g.sh, g.sw, g.es, rg=False)
         self.grad_add(x, inner)
 
-    def _bw_reparam(self, q_loc, q_ls, p_loc, p_ls, z, logt, fb_col=None):
+    def _bw_reparam(self, q_loc, q_ls, p_loc, p_ls, z, logt, fb_col=None, coef_ptr=None):
+        """`coef_ptr`: device address of d(loss)/d(sum kl) for this layer when it is not the engine-wide one (the abduction
+        passes of DSCM.forward draw z from q but contribute no KL term: their coefficient is a device-side zero)."""
         gz = self.grad_read(z)
         job = self._riders.pop(id(p_loc.base), None)  # (taken before grad_write would land it as a launch of its own)
         gql, a1 = self.grad_write(q_loc)
@@ -1128,7 +1144,7 @@ class Engine:
             self.launches += 1
             job = None
         args = (self.dt, z.n, z.h, z.w, z.c, q_loc.cv(), q_ls.cv(), p_loc.cv(), p_ls.cv(), z.cv(), logt,
-                gz.cv() if gz is not None else NULL_VIEW, self.kl_coef_ptr, 0,
+                gz.cv() if gz is not None else NULL_VIEW, self.kl_coef_ptr if coef_ptr is None else coef_ptr, 0,
                 None if fb_col is None else self.kl_chan_ptr + 4 * fb_col, gql.cv(), gqs.cv(), gpl.cv(),
                 gps.cv(), 1 if a1 else 0, 1 if a3 else 0)
         if job is None:

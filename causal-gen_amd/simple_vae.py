@@ -134,6 +134,7 @@ class GaussNet(DGaussNet):
 
 
 class VAE(HVAE):
+    _dscm_differentiable = False  # (the counterfactual fine-tuning of train_cf.py is run with the HVAE)
     compute_dtype = "f32"
 
     def __init__(self, args):
@@ -312,10 +313,12 @@ class VAE(HVAE):
             lib.dmol_nll_fwd(eng.dt, B, R, R, params.cv(), xin.cv(), nll_ptr, eng.stream)
         out3 = torch.empty(3, dtype=torch.float32, device=eng.device)
         dims = float(Cx * R * R)
-        lib.elbo_finalize(B, nll_ptr, nchunk, dims, kl_ptr, nch, dims, float(beta), out3.data_ptr(), eng.stream)
+        lib.elbo_finalize(B, nll_ptr, nchunk, dims, kl_ptr, nch, dims, float(beta), self.__dict__.get("_beta_dev"),
+                          out3.data_ptr(), eng.stream)
         eng.launches += 2
         eng.recording = False
         self.__dict__["_saved"] = (params, xin, B, R, Cx, dims)
+        self.__dict__["_saved_gen"] = eng.generation
         return out3
 
     # ------------------------------------------------------------------ inference API

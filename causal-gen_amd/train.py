@@ -74,6 +74,7 @@ class TrainStep:
             self.ema_flat = self.ema_model.engine().flat_p
         self.state = torch.zeros(8, device=dev)
         self.partial = torch.zeros(self.NORM_BLOCKS, device=dev)
+        self.coefs = {}   # (B, dims) -> [device tensor (1/(B dims accu), beta/(B dims accu), beta), beta last written]
         self.coef = None
         self.ranges = None
         self.graphs = {}
@@ -87,13 +88,29 @@ class TrainStep:
         self.acc_g = torch.zeros(n, device=dev) if self.accu > 1 else None
 
     # -- pieces -----------------------------------------------------------------------------------------
+    def _coef_for(self, x, beta):
+        """Per-(batch, dims) device constants of a step: gradient seeds d(elbo)/d(sum nll), d(elbo)/d(sum kl) and beta itself.
+        They live in device memory so that a captured step follows the beta warm-up (trainer.py:57) without re-capture:
+        the host rewrites the three floats (outside any capture) only when beta moved.  One tensor per key, kept alive as
+        long as the TrainStep: captured graphs hold its address."""
+        B, dims = int(x.shape[0]), float(x[0].numel())
+        ent = self.coefs.get((B, dims))
+        if ent is None:
+            ent = self.coefs[(B, dims)] = [torch.zeros(3, device=self.eng.device), None]
+        if ent[1] != beta:
+            ent[0].copy_(torch.tensor([1.0 / (B * dims * self.accu), beta / (B * dims * self.accu), beta], dtype=torch.float32))
+            ent[1] = beta
+        return ent[0]
+
     def _fwd_bwd(self, x, pa, beta):
         m, eng = self.model, self.eng
-        out3 = m._run_forward(x, pa, beta, record=True)
+        self.coef = self.coefs[(int(x.shape[0]), float(x[0].numel()))][0]  # written by step() before any capture / replay
+        m.__dict__["_beta_dev"] = self.coef.data_ptr() + 8
+        try:
+            out3 = m._run_forward(x, pa, beta, record=True)
+        finally:
+            m.__dict__["_beta_dev"] = None
         params, xin, B, R, Cx, dims = m.__dict__["_saved"]
-        if self.coef is None or self.coef_key != (B, dims, beta):
-            self.coef = torch.tensor([1.0 / (B * dims * self.accu), beta / (B * dims * self.accu)], device=eng.device)
-            self.coef_key = (B, dims, beta)
         eng.kl_coef_ptr = self.coef.data_ptr() + 4
         gparams = eng.seed_grad(params)
         if getattr(m.likelihood, "logit_space", False):
@@ -160,12 +177,23 @@ class TrainStep:
             eng.flat_axpy(None, self.acc_g.data_ptr(), self.acc_g.numel(), alpha=0.0, accumulate=False)
 
     def _eager(self, x, pa, beta, do_step=True):
+        self._coef_for(x, beta)
         out3 = self._fwd_bwd(x, pa, beta)
         self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
         if do_step:
             self._allreduce(out3)
             self._optim(out3)
+            self._mark_weights_written()
         return out3
+
+    def _mark_weights_written(self):
+        """The fused AdamW / EMA kernel writes both flat parameter buffers through raw pointers, which torch's version
+        counters do not see: tell the engines (model and EMA copy) that their weight images are stale, so the next
+        inference call (validation on ``ema_model``, sampling, counterfactuals) re-images before it runs."""
+        for mod in (self.model, self.ema_model):
+            eng = None if mod is None else mod.__dict__.get("_eng")
+            if eng is not None:
+                eng.weights_dirty = True
 
     # -- public -------------------------------------------------------------------------------------------
     def step(self, x, pa):
@@ -183,8 +211,9 @@ class TrainStep:
         if m.cond_prior:  # host draw (shared across DP ranks through the common seed), one graph per outcome
             drop = type(m.decoder).drop_cond(m.decoder)
             m.decoder.__dict__["drop_cond"] = lambda d=drop: d
-        key = (tuple(x.shape), x.dtype, beta, drop, do_step)
+        key = (tuple(x.shape), x.dtype, drop, do_step)  # (beta is device data: the warm-up schedule replays the same graph)
         ent = self.graphs.get(key)
+        self._coef_for(x, beta)
         if ent is None:
             out = self._eager(x, pa, beta, do_step)  # eager warm-up: sizes the arena, builds the tables
             sx, sp = x.clone(), pa.clone()
@@ -212,7 +241,62 @@ class TrainStep:
         if g2 is not None:
             self._allreduce(so)
             g2.replay()
+        if do_step:
+            self._mark_weights_written()
         return so
+
+    # -- checkpoint / resume (trainer.py:154-165, main.py:75-90) -----------------------------------------------
+    def state_dict(self):
+        """Optimiser state in ``torch.optim.AdamW.state_dict()`` layout (per-parameter ``step`` / ``exp_avg`` /
+        ``exp_avg_sq`` in ``model.parameters()`` order, one param group) so that a reference-side resume can load it,
+        plus this harness's own counters under ``"cgen"``."""
+        eng, a = self.eng, self.args
+        st = self.state.cpu()
+        steps = float(st[5])
+        state = {}
+        for i, p in enumerate(eng.params):
+            o, k = eng.p_off[id(p)], p.numel()
+            state[i] = {"step": torch.tensor(steps), "exp_avg": self.m[o:o + k].view(p.shape).clone(),
+                        "exp_avg_sq": self.v[o:o + k].view(p.shape).clone()}
+        group = {"lr": float(a.lr) * linear_warmup(int(a.lr_warmup_steps))(int(steps)), "betas": tuple(float(b) for b in a.betas),
+                 "eps": 1e-8, "weight_decay": float(a.wd), "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                 "differentiable": False, "fused": None, "initial_lr": float(a.lr), "params": list(range(len(eng.params)))}
+        return {"state": state, "param_groups": [group],
+                "cgen": {"it": self.it, "opt_steps": int(steps), "n_skipped": int(st[4]),
+                         "acc_g": None if self.acc_g is None else self.acc_g.clone()}}
+
+    def scheduler_state_dict(self):
+        """``LambdaLR.state_dict()`` of the reference's warm-up scheduler (train_setup.py:49-51): one step per successful
+        optimiser step."""
+        steps = int(self.state[5].item())
+        a = self.args
+        lr = float(a.lr) * linear_warmup(int(a.lr_warmup_steps))(steps)
+        return {"base_lrs": [float(a.lr)], "last_epoch": steps, "_step_count": steps + 1, "_get_lr_called_within_step": False,
+                "_last_lr": [lr], "lr_lambdas": [None]}
+
+    def load_state_dict(self, sd):
+        """Inverse of :meth:`state_dict`; also accepts a plain ``torch.optim.AdamW`` state dict saved by the reference
+        (the step count is then the parameters' common ``step``)."""
+        eng = self.eng
+        steps = None
+        for i, p in enumerate(eng.params):
+            ent = sd["state"].get(i)
+            if ent is None:
+                continue
+            o, k = eng.p_off[id(p)], p.numel()
+            self.m[o:o + k].copy_(ent["exp_avg"].reshape(-1))
+            self.v[o:o + k].copy_(ent["exp_avg_sq"].reshape(-1))
+            steps = float(ent["step"])
+        extra = sd.get("cgen") or {}
+        if "opt_steps" in extra:
+            steps = float(extra["opt_steps"])
+        st = torch.zeros(8)
+        st[5] = 0.0 if steps is None else steps
+        st[4] = float(extra.get("n_skipped", 0))
+        self.state.copy_(st)
+        self.it = int(extra.get("it", st[5]))
+        if self.acc_g is not None and extra.get("acc_g") is not None:
+            self.acc_g.copy_(extra["acc_g"])
 
     def stats(self):
         """Host read of the device-side step state (one sync; call every N steps, not every step)."""

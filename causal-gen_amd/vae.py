@@ -238,6 +238,26 @@ class _HVAEFunction(torch.autograd.Function):
         return None, None, None, None, None
 
 
+class _DSCMFunction(torch.autograd.Function):
+    """``DSCM.forward``'s image half as one differentiable node: outputs (elbo, nll, kl, mean cf_x, var cf_x); the
+    backward pass seeds the factual likelihood / KL gradients and d loss / d cf_x and sweeps the shared tape once."""
+
+    @staticmethod
+    def forward(ctx, trigger, model, x, parents, cf_parents_list, beta, t_abduct):
+        ctx.model = model
+        ctx.beta = float(beta)
+        out3, cf_mean, var = model._run_dscm_forward(x, parents, cf_parents_list, beta, t_abduct)
+        if var is None:
+            var = torch.empty(0, device=cf_mean.device)
+        ctx.mark_non_differentiable(var)
+        return out3[0], out3[1], out3[2], cf_mean, var
+
+    @staticmethod
+    def backward(ctx, g_elbo, g_nll, g_kl, g_cf, g_var):
+        ctx.model._run_dscm_backward(g_elbo, g_nll, g_kl, g_cf, ctx.beta)
+        return None, None, None, None, None, None, None
+
+
 class HVAE(nn.Module):
     compute_dtype = "f32"
 
@@ -258,7 +278,8 @@ class HVAE(nn.Module):
         self.q_correction = args.q_correction
         self._reset_runtime()
 
-    _RUNTIME_KEYS = ("_eng", "_trigger", "noise", "_saved", "_coef", "_fb_buf", "_grad_prev")
+    _RUNTIME_KEYS = ("_eng", "_trigger", "noise", "_saved", "_coef", "_fb_buf", "_grad_prev", "_beta_dev", "_saved_gen", "_saved_cf",
+                     "_coef_keep")
 
     def _reset_runtime(self):
         for k in self._RUNTIME_KEYS:
@@ -489,6 +510,12 @@ class HVAE(nn.Module):
         if self.__dict__["noise"] is None:
             eng.rng_advance(1)
         xin, pa = self._prep_inputs(eng, x, parents)
+        out3 = self._elbo_pass(eng, xin, pa, beta)
+        eng.recording = False
+        return out3
+
+    def _elbo_pass(self, eng, xin, pa, beta):
+        """HVAE.forward (vae.py:439-458) on prepared inputs; records the tape when eng.recording."""
         drop = (1, 1)
         if self.training and self.cond_prior:
             drop = self.decoder.drop_cond()
@@ -530,20 +557,99 @@ class HVAE(nn.Module):
         out3 = torch.empty(3, dtype=torch.float32, device=eng.device)
         dims = float(Cx * R * R)
         if fb is None:
-            lib.elbo_finalize(B, nll_ptr, nchunk, dims, kl_ptr, kl_total, dims, float(beta), out3.data_ptr(), eng.stream)
+            lib.elbo_finalize(B, nll_ptr, nchunk, dims, kl_ptr, kl_total, dims, float(beta), self.__dict__.get("_beta_dev"),
+                              out3.data_ptr(), eng.stream)
         else:
             mask_ptr = fb[0] + 4 * B * fb[1]
             lib.elbo_finalize_fb(B, nll_ptr, nchunk, dims, fb[0], fb[1], dims, float(self.free_bits), float(beta),
-                                 out3.data_ptr(), mask_ptr, eng.stream)
+                                 self.__dict__.get("_beta_dev"), out3.data_ptr(), mask_ptr, eng.stream)
             eng.kl_chan_ptr = mask_ptr
             self.__dict__["_fb_buf"] = s_buf  # keep alive until the backward pass
         eng.launches += 2
-        eng.recording = False
         self.__dict__["_saved"] = (params, xin, B, R, Cx, dims)
+        self.__dict__["_saved_gen"] = eng.generation
         return out3
+
+    # ------------------------------------------------------------------ DSCM.forward with a differentiable counterfactual branch
+    _dscm_differentiable = True
+
+    def _run_dscm_forward(self, x, parents, cf_parents_list, beta, t_abduct):
+        """dscm.py:40-72 as ONE recorded engine step: the factual ELBO pass, then per particle an abduction pass (encoder +
+        posterior decoder pass drawing z ~ q at temperature t_abduct; it contributes no KL term) whose final hidden state is
+        also the reconstruction replay's (same latents, same parents, same kernels -- HVAE.abduct_with_reconstruction) and a
+        replay of those latents under the counterfactual parents.  All passes share the arena and the tape, so one reverse
+        sweep delivers d loss / d theta through cf_x as train_cf.py:159-183 needs.
+        Returns (out3 = [elbo, nll, kl], mean cf_x [B,C,R,R], var cf_x or None)."""
+        from .dscm import cf_pixels
+
+        if self.likelihood.kind != "dgauss" or getattr(self.likelihood, "logit_space", False):
+            raise NotImplementedError("the differentiable counterfactual branch is built for the DGaussNet head")
+        eng = self.engine()
+        eng.begin()
+        eng.recording = True
+        eng.prepare_weights(force=True)
+        if self.__dict__["noise"] is None:
+            eng.rng_advance(1)
+        xin, pa = self._prep_inputs(eng, x, parents)
+        out3 = self._elbo_pass(eng, xin, pa, beta)
+        if getattr(eng, "_zero4", None) is None:
+            eng._zero4 = torch.zeros(4, dtype=torch.float32, device=eng.device)
+        P = len(cf_parents_list)
+        x_nchw = eng.to_nchw(xin)
+        sx = torch.zeros_like(x_nchw) if P > 1 else None
+        sx2 = torch.zeros_like(x_nchw) if P > 1 else None
+        passes, cf_x = [], None
+        for cfp_t in cf_parents_list:
+            cfp = eng.from_nchw(cfp_t.to(eng.device, torch.float32))
+            eng.kl_coef_override = eng._zero4.data_ptr()
+            acts = self._encode(eng, xin)
+            h_ab, qs = self._decode(eng, pa, acts=acts, t=t_abduct, collect="q" if self.cond_prior else "z")
+            eng.kl_coef_override = None
+            zs = [q[0] for q in qs] if self.cond_prior else qs
+            rec_params = self._likelihood_params(eng, h_ab)
+            h_cf, _ = self._decode(eng, cfp, latents=zs)
+            cf_params = self._likelihood_params(eng, h_cf)
+            (rl, rs), (cl, cs) = self._decode_params(eng, rec_params), self._decode_params(eng, cf_params)
+            cf_x = cf_pixels(x_nchw, rl, rs, cl, cs, sx, sx2)
+            passes.append((rec_params, cf_params))
+        eng.recording = False
+        self.__dict__["_saved_cf"] = (passes, xin)
+        if P > 1:
+            return out3, sx / P, (sx2 - sx ** 2 / P) / P
+        return out3, cf_x, None
+
+    def _decode_params(self, eng, params):
+        """DGaussNet.sample(h) with return_loc=True on ready-made head outputs -> (loc, scale) as NCHW f32."""
+        B, R, Cx = params.n, params.h, self.input_channels
+        xo = torch.empty((B, Cx, R, R), dtype=torch.float32, device=eng.device)
+        so = torch.empty_like(xo)
+        eng.lib.dgauss_sample(eng.dt, B, R, R, Cx, params.cv(), 0.0, None, 978, xo.data_ptr(), so.data_ptr(), eng.stream)
+        eng.launches += 1
+        return xo, so
+
+    def _run_dscm_backward(self, g_elbo, g_nll, g_kl, g_cf, beta):
+        eng = self.__dict__["_eng"]
+        passes, xin = self.__dict__["_saved_cf"]
+        if g_cf is not None:
+            g = g_cf.to(eng.device, torch.float32).contiguous()
+            eng.stream = torch.cuda.current_stream(eng.device).cuda_stream
+            B, R, Cx = xin.n, xin.h, xin.c
+            for rec_params, cf_params in passes:
+                g_rec, g_cfp = eng.seed_grad(rec_params), eng.seed_grad(cf_params)
+                eng.lib.cf_dgauss_bwd(eng.dt, B, R, R, Cx, rec_params.cv(), cf_params.cv(), xin.cv(), g.data_ptr(), 1.0 / len(passes),
+                                      g_rec.cv(), g_cfp.cv(), eng.stream)
+                eng.launches += 1
+            self.__dict__["_coef_keep"] = g
+        self._run_backward(g_elbo, g_nll, g_kl, beta)
 
     def _run_backward(self, g_elbo, g_nll, g_kl, beta):
         eng = self.__dict__["_eng"]
+        if eng is None or eng.generation != self.__dict__.get("_saved_gen"):
+            # a later pass (abduct / forward_latents / sample / another forward) recycled the arena and the tape this
+            # result was recorded on: its activations are gone.  Fail loudly instead of returning no gradients.
+            raise RuntimeError("HVAE backward: the engine state of this forward pass has been recycled by a later HVAE call; "
+                               "call backward() before running another pass on the same model (DSCM.forward records its "
+                               "counterfactual passes on the same tape for exactly this reason)")
         params, xin, B, R, Cx, dims = self.__dict__["_saved"]
         lib = eng.lib
         z = torch.zeros((), device=eng.device)

@@ -260,13 +260,22 @@ int cgen_dmol_decode(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view l
                      const uint64_t* rng, uint32_t stream_id, float logt, float* x_nchw, float* scale_nchw, cgen_stream_t);
 /* elbo/nll/kl (vae.py:450-457): nll = mean_b( sum(nll_part[b]) / nll_div ), kl = mean_b( sum(kl_part[b]) / kl_div ),
  * out3 = {nll + beta*kl, nll, kl}.  kl_part: [nkl][B] per-sample sums already reduced per layer by the caller's
- * layout: kl_part[b*kl_stride + j], j < kl_count. */
+ * layout: kl_part[b*kl_stride + j], j < kl_count.  beta_dev (optional, device memory) overrides beta, so a captured
+ * launch follows trainer.py's beta warm-up without re-capture. */
 int cgen_elbo_finalize(int32_t n, const float* nll_part, int32_t nll_count, float nll_div, const float* kl_part,
-                       int32_t kl_count, float kl_div, float beta, float* out3, cgen_stream_t);
+                       int32_t kl_count, float kl_div, float beta, const float* beta_dev, float* out3, cgen_stream_t);
 /* free-bits variant: kl = sum_j max(free_bits, mean_b kl_bc[b*ncol + j]) / kl_div; out3 as above;
  * chan_mask[j] = d max/d mean (1 / 0 / 0.5 on a tie) for cgen_reparam_kl_bwd's kl_chan_scale */
 int cgen_elbo_finalize_fb(int32_t n, const float* nll_part, int32_t nll_count, float nll_div, const float* kl_bc, int32_t ncol,
-                          float kl_div, float free_bits, float beta, float* out3, float* chan_mask, cgen_stream_t);
+                          float kl_div, float free_bits, float beta, const float* beta_dev, float* out3, float* chan_mask,
+                          cgen_stream_t);
+/* Backward of the counterfactual pixel step composed with both heads' DGaussNet.sample(h) decodes (dscm.py:52-56 over
+ * vae.py:352-385,413-422), for the differentiable counterfactual branch of DSCM.forward (train_cf.py:159-183 fine-tunes the
+ * HVAE through it): g_cfx_nchw = d loss / d cf_x (f32 NCHW), gscale = 1 / cf_particles; writes d/d params of the
+ * reconstruction head and of the counterfactual head ([loc | logscale | coeffs] NHWC, same layout as the inputs). */
+int cgen_cf_dgauss_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view rec_params, cgen_view cf_params,
+                       cgen_view x, const float* g_cfx_nchw, float gscale, cgen_view g_rec_params, cgen_view g_cf_params,
+                       cgen_stream_t);
 /* Counterfactual pixel step (dscm.py:55-63): u=(x-rec_loc)/max(rec_scale,1e-12); cf=clamp(cf_loc+cf_scale*u,-1,1);
  * optional running sums sum_x += cf, sum_x2 += cf^2.  All NCHW f32 contiguous, `count` elements. */
 int cgen_cf_pixels(int64_t count, const float* x, const float* rec_loc, const float* rec_scale, const float* cf_loc,

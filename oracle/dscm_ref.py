@@ -80,3 +80,39 @@ def lagrangian(aux_loss, elbo, lmbda, eps, damping):
     """dscm.py:85-88."""
     sg = (eps - elbo).detach()
     return aux_loss - (lmbda - damping * sg) * (eps - elbo)
+
+
+def dscm_forward(sd, hp, x, parents, cf_parents_list, beta, t_abduct=1.0, noise=None, aux_fn=None, lmbda=None, eps=None,
+                 damping=0.0):
+    """Image half of DSCM.forward (dscm.py:40-95) as ONE differentiable torch graph over the state dict ``sd``: factual
+    ELBO (vae.py:439-458), then per particle abduct -> replay under cf parents -> replay under the observed parents ->
+    dscm.py:55-56, particle mean / variance (dscm.py:58-72), and -- when ``aux_fn(cf_x)`` (standing in for the predictor's
+    ``elbo_fn.differentiable_loss / B``, pyro-side) and the multiplier are given -- the Lagrangian of dscm.py:85-88.
+    ``noise``: a single hvae_ref._Noise shared by all passes in the reference's draw order (factual first)."""
+    out = hvae_ref.hvae_forward(sd, hp, x, parents, beta=beta, noise=noise)
+    P = len(cf_parents_list)
+    sx, sx2, cf_x = torch.zeros_like(x), torch.zeros_like(x), None
+    for cfp in cf_parents_list:
+        zs = hvae_ref.hvae_abduct(sd, hp, x, parents, t=t_abduct, noise=noise)
+        if hp.cond_prior:
+            zs = [z["z"] for z in zs]
+        cf_loc, cf_scale = hvae_ref.hvae_forward_latents(sd, hp, zs, cfp)
+        rec_loc, rec_scale = hvae_ref.hvae_forward_latents(sd, hp, zs, parents)
+        u = (x - rec_loc) / rec_scale.clamp(min=1e-12)
+        cf_x = torch.clamp(cf_loc + cf_scale * u, min=-1, max=1)
+        if P > 1:
+            sx = sx + cf_x
+            with torch.no_grad():
+                sx2 = sx2 + cf_x ** 2
+    res = dict(out)
+    if P > 1:
+        with torch.no_grad():
+            res["var_cf_x"] = (sx2 - sx ** 2 / P) / P
+        res["cf_x"] = sx / P
+    else:
+        res["var_cf_x"] = None
+        res["cf_x"] = cf_x
+    if aux_fn is not None:
+        res["aux_loss"] = aux_fn(res["cf_x"])
+        res["loss"] = lagrangian(res["aux_loss"], out["elbo"], lmbda, eps, damping)
+    return res

@@ -1,0 +1,173 @@
+"""DSCM.forward on the HIP path against oracle/dscm_ref.py (a differentiable torch-CPU restatement of dscm.py:40-95 over
+the oracle HVAE): particle mean / variance of the counterfactual, ELBO, Lagrangian loss -- and d loss / d theta through the
+counterfactual branch (train_cf.py:159-183 fine-tunes the HVAE through abduct -> two replays -> dscm.py:55-56), which the
+reference gets from autograd and this build from one reverse sweep over a tape shared by all passes."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+class StubPGM(torch.nn.Module):
+    """pgm.counterfactual is pyro-side (outside the hot path): returns the observed parents with `do` applied."""
+
+    def counterfactual(self, obs, intervention, num_particles=1):
+        return {k: intervention.get(k, v) for k, v in obs.items()}
+
+
+class StubPredictor(torch.nn.Module):
+    model_anticausal = None
+    guide_pass = None
+
+
+class StubELBO:
+    """Stands in for TraceStorage_ELBO.differentiable_loss(model, guide, **cfs): a fixed smooth functional of cf_x, summed
+    over the batch (DSCM.forward divides by B)."""
+
+    def __init__(self, w):
+        self.w = w
+
+    def differentiable_loss(self, model, guide, **cfs):
+        x = cfs["x"]
+        return ((x * self.w.to(x.device)).sum() + 0.5 * (x ** 2).sum())
+
+
+def _build(name, dtype="f32"):
+    from causal_gen_amd import vae
+    from causal_gen_amd.hps import Hparams
+
+    fx = load_golden(name)
+    hpd = dict(fx["hp"])
+    m = vae.HVAE(Hparams(**hpd))
+    m.load_state_dict(fx["state_dict"])
+    m.compute_dtype = dtype
+    return fx, hpd, m.cuda().eval()
+
+
+@pytest.mark.parametrize("name,particles", [("tiny_default_c1.pt", 3), ("tiny_light_c1.pt", 1), ("tiny_default_c3.pt", 2)])
+def test_dscm_forward_matches_oracle_values_and_gradients(name, particles):
+    from causal_gen_amd import dscm
+    from oracle import dscm_ref, hvae_ref
+
+    fx, hpd, m = _build(name)
+    hp = SimpleNamespace(**hpd)
+    x, pa, cf = fx["x"], fx["pa"], fx["cf_pa"]
+    B, ctx = x.shape[0], pa.shape[1]
+    names = [f"p{i}" for i in range(ctx)]
+    beta, t_ab, lmbda0, eps_c, damping = 1.7, 0.9, 0.8, 2.0, 10.0
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(x.shape, generator=g) * 0.3
+
+    # ---- oracle: one differentiable graph, noise drawn once and recorded
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in fx["state_dict"].items()}
+    lm = torch.tensor([lmbda0], requires_grad=True)
+    noise = hvae_ref._Noise(None)
+    torch.manual_seed(17)
+    # particle p intervenes on parent 0 with a different value each time (the stub PGM is deterministic: emulate by lists)
+    cf_list = [torch.cat([cf[:, :1] * (1.0 + 0.5 * p), pa[:, 1:]], 1) for p in range(particles)]
+    ref = dscm_ref.dscm_forward(sd, hp, x, pa, cf_list, beta, t_abduct=t_ab, noise=noise,
+                                aux_fn=lambda c: ((c * w).sum() + 0.5 * (c ** 2).sum()) / B, lmbda=lm, eps=torch.tensor([eps_c]),
+                                damping=damping)
+    ref["loss"].sum().backward()
+
+    # ---- HIP path through the reference's DSCM surface
+    class SeqPGM(StubPGM):
+        def __init__(self):
+            super().__init__()
+            self.i = 0
+
+        def counterfactual(self, obs, intervention, num_particles=1):
+            out = dict(obs)
+            out["p0"] = cf[:, 0, 0, 0].cuda() * (1.0 + 0.5 * self.i)
+            self.i += 1
+            return out
+
+    args = SimpleNamespace(**hpd, parents_x=names, dataset="none", lmbda_init=lmbda0, elbo_constraint=eps_c, damping=damping)
+    args.beta = beta
+    model = dscm.DSCM(args, SeqPGM(), StubPredictor(), m).cuda()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    obs = {"x": x.cuda()}
+    obs.update({n: pa[:, i, 0, 0].cuda() for i, n in enumerate(names)})
+    m.noise = [e.clone() for e in noise.drawn]
+    out = model(obs, {"p0": None}, StubELBO(w), cf_particles=particles, t_abduct=t_ab)
+    assert not m.noise, "every recorded draw must have been consumed, in the reference's order"
+    for k in ("elbo", "nll", "kl"):
+        assert abs(float(out[k]) - float(ref[k])) <= 1e-4 * abs(float(ref[k])), (k, float(out[k]), float(ref[k]))
+    ok = torch.ones_like(x, dtype=torch.bool)
+    assert (out["cfs"]["x"].detach().cpu() - ref["cf_x"].detach())[ok].abs().max() < 1e-3
+    if particles > 1:
+        assert (out["var_cf_x"].cpu() - ref["var_cf_x"]).abs().max() < 1e-3
+    else:
+        assert out["var_cf_x"] is None
+    assert abs(float(out["aux_loss"]) - float(ref["aux_loss"])) <= 2e-4 * abs(float(ref["aux_loss"])) + 1e-5
+    assert abs(float(out["loss"]) - float(ref["loss"])) <= 2e-4 * abs(float(ref["loss"])) + 1e-5
+    out["loss"].sum().backward()
+    torch.cuda.synchronize()
+    assert abs(float(model.lmbda.grad) - float(lm.grad)) <= 1e-4 * abs(float(lm.grad)) + 1e-6
+    worst, n_checked = 0.0, 0
+    for n_, p in m.named_parameters():
+        rg = sd[n_].grad
+        if rg is None or float(rg.abs().max()) == 0.0:
+            continue
+        assert p.grad is not None, n_
+        d = float((p.grad.cpu() - rg).abs().max()) / float(rg.abs().max())
+        worst = max(worst, d)
+        n_checked += 1
+        assert d < 2e-3, (n_, d)
+    assert n_checked > 20
+    print(name, "particles", particles, "worst grad err rel-to-max", worst, "over", n_checked, "tensors")
+
+
+def test_cf_branch_alone_reaches_the_weights():
+    """loss = aux(cf_x) only (no ELBO term): the gradient that arrives in the encoder / posterior / decoder weights is the
+    one that flowed through abduction and both replays."""
+    from causal_gen_amd import vae as hvae_mod
+    from oracle import dscm_ref, hvae_ref
+
+    fx, hpd, m = _build("tiny_default_c1.pt")
+    hp = SimpleNamespace(**hpd)
+    x, pa, cf = fx["x"], fx["pa"], fx["cf_pa"]
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in fx["state_dict"].items()}
+    noise = hvae_ref._Noise(None)
+    torch.manual_seed(3)
+    ref = dscm_ref.dscm_forward(sd, hp, x, pa, [cf], 1.0, noise=noise)
+    (ref["cf_x"] ** 2).sum().backward()
+    m.noise = [e.clone() for e in noise.drawn]
+    trig = torch.zeros(1, device="cuda", requires_grad=True)
+    elbo, nll, kl, cf_x, _ = hvae_mod._DSCMFunction.apply(trig, m, x.cuda(), pa.cuda(), (cf.cuda(),), 1.0, 1.0)
+    (cf_x ** 2).sum().backward()
+    torch.cuda.synchronize()
+    for n_ in ("encoder.stem.weight", "decoder.blocks.0.posterior.conv.1.weight", "decoder.blocks.1.z_proj.weight",
+               "likelihood.x_logscale.weight"):
+        rg = sd[n_].grad
+        got = dict(m.named_parameters())[n_].grad.cpu()
+        assert float((got - rg).abs().max()) < 2e-3 * float(rg.abs().max()), n_
+
+
+def test_backward_after_a_later_pass_fails_loudly():
+    """A forward pass whose tape was recycled by a later inference call must not return silently empty gradients."""
+    fx, hpd, m = _build("tiny_light_c1.pt")
+    for p in m.parameters():
+        p.requires_grad_(True)
+    out = m(fx["x"].cuda(), fx["pa"].cuda(), beta=1.0)
+    m.abduct(fx["x"].cuda(), fx["pa"].cuda())
+    with pytest.raises(RuntimeError, match="recycled"):
+        out["elbo"].backward()
+
+
+def test_dscm_forward_without_grad_keeps_the_inference_path():
+    from causal_gen_amd import dscm
+
+    fx, hpd, m = _build("tiny_default_c1.pt")
+    x, pa, cf = fx["x"].cuda(), fx["pa"].cuda(), fx["cf_pa"].cuda()
+    args = SimpleNamespace(**hpd, parents_x=["a", "b", "c"], dataset="none", lmbda_init=1.0, elbo_constraint=2.0, damping=10.0)
+    model = dscm.DSCM(args, StubPGM(), None, m)
+    obs = {"x": x, "a": pa[:, 0, 0, 0], "b": pa[:, 1, 0, 0], "c": pa[:, 2:3, 0, 0]}
+    with torch.no_grad():
+        out = model(obs, {"a": cf[:, 0, 0, 0]}, None, cf_particles=2)
+    assert out["cfs"]["x"].shape == x.shape and torch.isfinite(out["cfs"]["x"]).all()

@@ -1,0 +1,152 @@
+"""Full-size parity on every BASELINE preset (morphomnist, cmnist + DmolNet, ukbb192, mimic-shape 224^2), HIP f32 path:
+
+* against tests/golden/fullsize.pt -- outputs of the REFERENCE itself (oracle/make_fullsize.py) on weights rebuilt here
+  from the same seeded recipe (oracle/fullsize_recipe.py): ELBO / NLL / KL within 1e-4 relative, sampled gradients of a
+  dozen named parameters, counterfactual pixels within 1e-3 absolute;
+* against the oracle run live on this host's CPU (every parameter gradient);
+* and the bf16 throughput path's measured deviation from those reference values, with the bound it is held to.
+
+The tiny golden models are served by other kernels than these shapes, hence this file."""
+import os
+import sys
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+pytestmark = pytest.mark.gpu
+
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import fullsize_recipe as R  # noqa: E402
+
+ELBO_TOL = 1e-4       # north_star: ELBO and DMoL nats/dim within 1e-4 relative
+CF_TOL = 1e-3         # north_star: counterfactual pixels within 1e-3 absolute
+GRAD_TOL = 2e-3       # of the tensor's max |gradient|
+# bf16 storage of activations / weight images (f32 accumulate, f32 KL / NLL / reductions): measured deviation of the ELBO
+# from the reference at full size is 1e-4 .. 8e-4 relative depending on the preset (printed below); it is held to this bound.
+BF16_ELBO_TOL = 2e-3
+
+
+def _model(name, dmol, dtype):
+    import bench
+
+    m, hp = bench.build_model(name, dtype, dmol)
+    R.perturb(m)
+    return m.cuda().eval(), hp
+
+
+def _rel(a, b):
+    return abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+
+
+@pytest.mark.parametrize("name,B,dmol", R.CASES, ids=[R.key(n, d) for n, _, d in R.CASES])
+def test_fullsize_forward_backward_counterfactual(name, B, dmol):
+    from causal_gen_amd import dscm
+    from oracle import hparams as ohp
+    from oracle import hvae_ref
+
+    row = load_golden("fullsize.pt")[R.key(name, dmol)]
+    m, hp = _model(name, dmol, "f32")
+    abs_sum = float(sum(p.detach().abs().double().sum() for p in m.parameters()))
+    assert abs(abs_sum - row["abs_sum"]) < 1e-6 * row["abs_sum"], "the seeded recipe did not rebuild the reference's weights"
+    x, pa = R.inputs(hp, B)
+    eps = R.eps_sequence(11, row["eps_shapes"])
+
+    # ---- reference-made values
+    for p in m.parameters():
+        p.requires_grad_(True)
+    m.noise = [e.clone() for e in eps]
+    out = m(x.cuda(), pa.cuda(), beta=row["beta"])
+    assert not m.noise
+    got = {k: float(out[k]) for k in ("elbo", "nll", "kl")}
+    for k in got:
+        assert _rel(got[k], row[k]) < ELBO_TOL, (k, got[k], row[k])
+    out["elbo"].backward()
+    torch.cuda.synchronize()
+    named = dict(m.named_parameters())
+    worst_fx = 0.0
+    for n_, ref in row["grads"].items():
+        g = named[n_].grad
+        assert g is not None, n_
+        s = R.sample(g).cpu()
+        scale = float(ref["sample"].abs().max()) + 1e-12
+        d = float((s - ref["sample"]).abs().max()) / scale
+        worst_fx = max(worst_fx, d)
+        assert d < GRAD_TOL, (n_, d)
+        assert abs(float(g.double().norm()) - ref["norm"]) <= 5e-3 * ref["norm"] + 1e-9, (n_, float(g.double().norm()), ref["norm"])
+
+    # ---- the oracle, live on this host (all parameters)
+    ohp_ = ohp.make_hparams(name)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    ref = hvae_ref.hvae_forward(sd, ohp_, x, pa, beta=row["beta"], noise=hvae_ref._Noise([e.clone() for e in eps]))
+    for k in got:
+        assert _rel(ref[k], row[k]) < 2e-5, ("oracle vs reference", k, float(ref[k]), row[k])
+        assert _rel(got[k], ref[k]) < ELBO_TOL, (k, got[k], float(ref[k]))
+    ref["elbo"].backward()
+    worst, n_checked = 0.0, 0
+    for n_, p in m.named_parameters():
+        rg = sd[n_].grad
+        if rg is None or float(rg.abs().max()) == 0.0:
+            continue
+        assert p.grad is not None, n_
+        d = float((p.grad.cpu() - rg).abs().max()) / float(rg.abs().max())
+        worst = max(worst, d)
+        n_checked += 1
+        assert d < GRAD_TOL, (n_, d)
+    assert n_checked >= 10
+
+    # ---- counterfactual pixels (abduct -> replay x2 -> dscm.py:55-56) against the reference-made sample
+    cf_pa = pa.roll(1, 0) if B > 1 else pa.flip(1)
+    m.noise = R.eps_sequence(21, row["cf"]["eps_shapes"])
+    with torch.no_grad():
+        cf_x = dscm.counterfactual(m, x.cuda(), pa.cuda(), cf_pa.cuda(), t_abduct=1.0)
+    assert not m.noise
+    ok = row["cf"]["rec_scale"] > 1e-3
+    d_cf = (R.sample_img(cf_x).cpu() - row["cf"]["cf_x"]).abs()
+    assert float(d_cf[ok].max()) < CF_TOL, float(d_cf[ok].max())
+    assert abs(float((cf_x.cpu() - x).abs().mean()) - row["cf"]["moved"]) < 1e-3
+
+    # ---- bf16 throughput path: measured deviation from the reference's values on the same inputs
+    del m
+    torch.cuda.empty_cache()
+    mb, _ = _model(name, dmol, "bf16")
+    mb.noise = [e.clone() for e in eps]
+    with torch.no_grad():
+        ob = mb(x.cuda(), pa.cuda(), beta=row["beta"])
+    dev = {k: _rel(ob[k], row[k]) for k in ("elbo", "nll", "kl")}
+    mb.noise = R.eps_sequence(21, row["cf"]["eps_shapes"])
+    with torch.no_grad():
+        cf_b = dscm.counterfactual(mb, x.cuda(), pa.cuda(), cf_pa.cuda(), t_abduct=1.0)
+    d_cfb = float((R.sample_img(cf_b).cpu() - row["cf"]["cf_x"]).abs()[ok].max())
+    print("FULLSIZE %s: f32 vs reference elbo %.2e nll %.2e kl %.2e | grads: worst %.2e (fixture sample) %.2e (oracle, %d tensors) | "
+          "cf %.2e || bf16 vs reference elbo %.2e nll %.2e kl %.2e cf %.2e" % (
+              R.key(name, dmol), _rel(got["elbo"], row["elbo"]), _rel(got["nll"], row["nll"]), _rel(got["kl"], row["kl"]), worst_fx,
+              worst, n_checked, float(d_cf[ok].max()), dev["elbo"], dev["nll"], dev["kl"], d_cfb))
+    assert dev["elbo"] < BF16_ELBO_TOL and dev["nll"] < BF16_ELBO_TOL, dev
+    assert dev["kl"] < 2e-2, dev
+
+
+@pytest.mark.parametrize("name", ["morphomnist", "cmnist", "ukbb192"])
+def test_reference_init_anchor_reproduced_on_the_gpu(name):
+    """anchors.pt (made by the reference): seed-7 default init + bias zeroing, seeded input, the eps sequence of
+    torch.manual_seed(11) -> (elbo, nll, kl).  Hits the reference's numbers directly with the model built HERE."""
+    import bench
+
+    row = load_golden("anchors.pt")[name]
+    m, hp = bench.build_model(name, "f32")
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(123)
+    Rr, C = hp.input_res, hp.input_channels
+    x = (torch.randint(0, 256, (2, C, Rr, Rr), generator=g).float() - 127.5) / 127.5
+    pa = torch.randn(2, hp.context_dim, generator=g)[..., None, None].repeat(1, 1, Rr, Rr)
+    shapes = [(2, b.z_dim, b.res, b.res) for b in m.decoder.blocks if b.stochastic]
+    m.noise = R.eps_sequence(11, shapes)
+    with torch.no_grad():
+        o = m(x.cuda(), pa.cuda(), beta=hp.beta)
+    for k in ("elbo", "nll"):
+        assert _rel(o[k], row[k]) < ELBO_TOL, (k, float(o[k]), row[k])
+    assert abs(float(o["kl"]) - row["kl"]) <= ELBO_TOL * abs(row["kl"]) + 1e-7, (float(o["kl"]), row["kl"])

@@ -436,3 +436,153 @@ def test_graphed_counterfactual_matches_eager_and_follows_weight_updates():
             p.mul_(1.05)
     a2, b2 = both()
     assert torch.equal(a2, b2) and not torch.equal(a2, a1)
+
+
+def test_inference_after_train_steps_sees_the_updated_weights():
+    """The fused AdamW / EMA kernel writes the flat parameter buffers through raw pointers (no torch version bump): an
+    inference call after TrainStep.step() -- validation on ema_model (trainer.py:39-40,94), sampling, counterfactuals --
+    must re-image the weights.  ema_model(x) after N steps == a fresh model loaded from ema_model.state_dict()."""
+    from causal_gen_amd import vae
+    from causal_gen_amd.hps import Hparams
+    from causal_gen_amd.train import TrainStep
+
+    for use_graph in (False, True):
+        fx, hpd, m = setup()
+        hp = SimpleNamespace(**hpd)
+        ts = TrainStep(m, hp, ema=True, use_graph=use_graph)
+        x, pa = fx["x"].cuda(), fx["pa"].cuda()
+        eps = [e.clone() for e in fx["fwd"]["eps"]]
+
+        def evaluate(model):
+            model.noise = [e.clone() for e in eps]
+            with torch.no_grad():
+                o = model(x, pa, beta=1.0)
+            return [float(o[k]) for k in ("elbo", "nll", "kl")]
+
+        seen = []
+        for rounds in range(2):  # train -> eval -> train -> eval
+            for _ in range(3):
+                ts.step(x, pa)
+            for live in (ts.ema_model, m):
+                was = live.training
+                live.eval()
+                got = evaluate(live)
+                fresh = vae.HVAE(Hparams(**hpd))
+                fresh.load_state_dict({k: v.clone() for k, v in live.state_dict().items()})
+                want = evaluate(fresh.cuda().eval())
+                live.train(was)
+                assert got == want, (use_graph, rounds, got, want)
+                seen.append(got[0])
+        assert len(set(seen)) == len(seen), seen  # and the numbers do move from round to round
+
+
+def test_beta_warmup_replays_one_graph_and_matches_eager():
+    """beta warm-up (trainer.py:57): beta is device data of the captured step, so the schedule replays ONE graph instead of
+    capturing (and leaking) a graph per distinct beta; results equal the eager path's bit for bit."""
+    from causal_gen_amd.train import TrainStep
+
+    res = []
+    for use_graph in (False, True):
+        fx, hpd, m = setup(beta_warmup_steps=4)
+        hp = SimpleNamespace(**hpd)
+        torch.manual_seed(5)
+        ts = TrainStep(m, hp, ema=True, use_graph=use_graph)
+        x, pa = fx["x"].cuda(), fx["pa"].cuda()
+        outs = []
+        for _ in range(7):
+            outs.append([float(v) for v in ts.step(x, pa).cpu()])
+        if use_graph:
+            assert len(ts.graphs) == 1, list(ts.graphs)
+        res.append((outs, {k: v.clone() for k, v in m.state_dict().items()}))
+    assert res[0][0] == res[1][0], (res[0][0], res[1][0])
+    assert all(torch.equal(res[0][1][k], res[1][1][k]) for k in res[0][1])
+    elbos = [o[0] - o[1] for o in res[0][0]]  # beta * kl grows with the schedule while kl itself stays O(1)
+    assert elbos[0] < elbos[3]
+
+
+def test_two_batch_shapes_keep_their_own_step_constants():
+    """Alternating batch shapes replays graphs that each hold the address of THEIR gradient-seed constants."""
+    from causal_gen_amd.train import TrainStep
+
+    res = []
+    for use_graph in (False, True):
+        fx, hpd, m = setup()
+        hp = SimpleNamespace(**hpd)
+        torch.manual_seed(5)
+        ts = TrainStep(m, hp, ema=False, use_graph=use_graph)
+        x, pa = fx["x"].cuda(), fx["pa"].cuda()
+        outs = []
+        for i in range(6):
+            n = 3 if i % 2 == 0 else 2
+            outs.append([float(v) for v in ts.step(x[:n].contiguous(), pa[:n].contiguous()).cpu()])
+        res.append((outs, {k: v.clone() for k, v in m.state_dict().items()}))
+    assert res[0][0] == res[1][0]
+    assert all(torch.equal(res[0][1][k], res[1][1][k]) for k in res[0][1])
+
+
+def test_train_step_state_dict_resumes_moments_and_schedules(tmp_path):
+    """main.py:75-90: a resumed run continues Adam's moments, the LR warm-up and the EMA warm-up.  5 steps == 3 steps ->
+    checkpoint (reference wire format, AdamW-layout optimiser state) -> fresh process state -> 2 steps."""
+    from causal_gen_amd import checkpoint, vae
+    from causal_gen_amd.hps import Hparams
+    from causal_gen_amd.train import TrainStep
+
+    fx, hpd, m = setup(lr_warmup_steps=4)
+    hp = SimpleNamespace(**hpd)
+    x, pa = fx["x"].cuda(), fx["pa"].cuda()
+    g = torch.Generator().manual_seed(0)
+    eps = [[torch.randn(e.shape, generator=g) for e in fx["fwd"]["eps"]] for _ in range(5)]
+    ts = TrainStep(m, hp, ema=True, use_graph=False)
+    for s in range(3):
+        m.noise = [e.clone() for e in eps[s]]
+        ts.step(x, pa)
+    path = str(tmp_path / "checkpoint.pt")
+    checkpoint.save_checkpoint(path, m, ts.ema_model, Hparams(**hpd), epoch=1, step=3, train_step=ts)
+    ck = torch.load(path, weights_only=False)
+    opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros_like(p)) for p in m.parameters()], lr=hp.lr, betas=tuple(hp.betas),
+                            weight_decay=hp.wd)
+    opt.load_state_dict({k: v for k, v in ck["optimizer_state_dict"].items() if k != "cgen"})  # a stock AdamW accepts the layout
+    for s in range(3, 5):
+        m.noise = [e.clone() for e in eps[s]]
+        ts.step(x, pa)
+    want = ({k: v.clone() for k, v in m.state_dict().items()}, {k: v.clone() for k, v in ts.ema_model.state_dict().items()})
+    m2 = vae.HVAE(Hparams(**hpd)).cuda()
+    ts2 = TrainStep(m2, hp, ema=True, use_graph=False)
+    info = checkpoint.resume_train_step(path, ts2)
+    assert info["step"] == 3 and ts2.stats()["opt_steps"] == 3
+    for s in range(3, 5):
+        m2.noise = [e.clone() for e in eps[s]]
+        ts2.step(x, pa)
+    for k, v in want[0].items():
+        assert torch.equal(m2.state_dict()[k], v), k
+    for k, v in want[1].items():
+        assert torch.equal(ts2.ema_model.state_dict()[k], v), k
+
+
+def test_shared_covariance_bias_gets_its_gradient():
+    """x_like='shared_dgauss' with std_init > 0 (vae.py:335-345): likelihood.x_logscale.weight is frozen, its bias trains."""
+    from causal_gen_amd import vae
+    from causal_gen_amd.hps import Hparams
+    from oracle import hvae_ref
+
+    fx = load_golden("tiny_light_c1.pt")
+    hpd = dict(fx["hp"])
+    hpd.update(x_like="shared_dgauss", std_init=0.3)
+    m = vae.HVAE(Hparams(**hpd))
+    sd0 = {k: v.clone() for k, v in fx["state_dict"].items()}
+    sd0["likelihood.x_logscale.weight"] = torch.zeros_like(sd0["likelihood.x_logscale.weight"])
+    sd0["likelihood.x_logscale.bias"] = torch.full_like(sd0["likelihood.x_logscale.bias"], float(torch.tensor(0.3).log()))
+    m.load_state_dict(sd0)
+    m = m.cuda().eval()
+    assert not m.likelihood.x_logscale.weight.requires_grad and m.likelihood.x_logscale.bias.requires_grad
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+    eps = fx["fwd"]["eps"]
+    ref = hvae_ref.hvae_forward(sd, SimpleNamespace(**hpd), fx["x"], fx["pa"], beta=1.0, noise=hvae_ref._Noise([e.clone() for e in eps]))
+    ref["elbo"].backward()
+    m.noise = [e.clone() for e in eps]
+    out = m(fx["x"].cuda(), fx["pa"].cuda(), beta=1.0)
+    out["elbo"].backward()
+    torch.cuda.synchronize()
+    gb, rb = m.likelihood.x_logscale.bias.grad, sd["likelihood.x_logscale.bias"].grad
+    assert gb is not None and float((gb.cpu() - rb).abs().max()) < 2e-3 * float(rb.abs().max())
+    assert m.likelihood.x_logscale.weight.grad is None

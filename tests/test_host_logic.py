@@ -142,3 +142,20 @@ def test_reference_checkpoint_wire_format(tmp_path):
         assert k1 == k2 and torch.equal(v1, v2)
     checkpoint.save_checkpoint(path, m2, m2, args, epoch=4)
     assert set(torch.load(path, weights_only=False)) >= {"model_state_dict", "ema_model_state_dict", "hparams", "epoch"}
+
+
+def test_dmol_hvae_checkpoint_loads(tmp_path):
+    """A hierarchical checkpoint whose hparams say x_like='diag_dmol' (HVAE + DmolNet head, SURVEY probe C.6) loads."""
+    from causal_gen_amd import checkpoint, dmol, vae
+    from causal_gen_amd.hps import Hparams
+
+    fx = load_golden("tiny_dmol_c3.pt")
+    hp = dict(fx["hp"])
+    hp["x_like"] = "diag_dmol"
+    path = str(tmp_path / "checkpoint.pt")
+    torch.save({"epoch": 1, "step": 1, "best_loss": 1.0, "model_state_dict": fx["state_dict"], "ema_model_state_dict": fx["state_dict"],
+                "optimizer_state_dict": None, "scheduler_state_dict": None, "hparams": hp}, path)
+    m, args = checkpoint.load_checkpoint(path, device=None)
+    assert isinstance(m.likelihood, dmol.DmolNet) and args.x_like == "diag_dmol"
+    for k, v in fx["state_dict"].items():
+        assert torch.equal(m.state_dict()[k], v), k
