@@ -1042,8 +1042,22 @@ class Engine:
         if not events:
             return
         self._wg_reduced = len(self._wg_events)
+        # One multi-tensor launch must not hold two events of the SAME site (DSCM.forward's tape runs every conv up to three
+        # times): their blocks would overwrite / accumulate the same gradient tensor concurrently.  Events are dealt into
+        # rounds with at most one event per site; the rounds run back to back on the stream.
+        rounds, nth = [], {}
+        for ev in events:
+            k = nth.get(ev[0].index, 0)
+            nth[ev[0].index] = k + 1
+            while len(rounds) <= k:
+                rounds.append([])
+            rounds[k].append(ev)
+        for evs in rounds:
+            self._reduce_round(evs, stream)
+
+    def _reduce_round(self, events, stream):
         flags = []
-        for site, _, _ in events:  # a site used twice in one pass accumulates its second use
+        for site, _, _ in events:  # a site used before in this pass accumulates
             flags.append(site.index in self._wg_seen)
             self._wg_seen.add(site.index)
         sig = (tuple(k for _, k, _ in events), tuple(flags))

@@ -457,6 +457,7 @@ def test_inference_after_train_steps_sees_the_updated_weights():
             model.noise = [e.clone() for e in eps]
             with torch.no_grad():
                 o = model(x, pa, beta=1.0)
+            model.noise = None
             return [float(o[k]) for k in ("elbo", "nll", "kl")]
 
         seen = []
@@ -473,7 +474,7 @@ def test_inference_after_train_steps_sees_the_updated_weights():
                 live.train(was)
                 assert got == want, (use_graph, rounds, got, want)
                 seen.append(got[0])
-        assert len(set(seen)) == len(seen), seen  # and the numbers do move from round to round
+        assert seen[0] != seen[2] and seen[1] != seen[3], seen  # the numbers move from round to round (EMA == model during its warm-up)
 
 
 def test_beta_warmup_replays_one_graph_and_matches_eager():
