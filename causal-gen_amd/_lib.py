@@ -25,6 +25,13 @@ class ConvArgs(C.Structure):
                 ("weight", C.c_void_p), ("bias", C.c_void_p), ("out", View), ("aux", View), ("res1", View), ("res2", View)]
 
 
+class BlockArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("mode", C.c_int32),
+                ("nseg", C.c_int32), ("pre_act", C.c_int32), ("reserved", C.c_int32), ("seg", View * MAX_SEG),
+                ("w_a", C.c_void_p), ("bias_a", C.c_void_p), ("w_b", C.c_void_p), ("bias_b", C.c_void_p),
+                ("mid", View), ("mid_aux", View), ("out", View), ("aux", View), ("res1", View)]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("ks", C.c_int32),
                 ("nseg", C.c_int32), ("act", C.c_int32), ("nsplit", C.c_int32), ("seg", View * MAX_SEG), ("gout", View),
@@ -59,6 +66,8 @@ PROTOTYPES = {
     "cgen_version": [],
     "cgen_last_error": [],
     "cgen_conv2d": [C.POINTER(ConvArgs), vp],
+    "cgen_block2_supported": [C.POINTER(BlockArgs)],
+    "cgen_block2": [C.POINTER(BlockArgs), vp],
     "cgen_conv2d_wgrad_plan": [C.POINTER(WgradArgs), C.POINTER(i32)],
     "cgen_conv2d_wgrad_batch_plan": [vp, i32, vp, i64, vp, vp, i32, vp, vp],
     "cgen_conv2d_wgrad_batch_run": [vp, vp, i32, i32, vp],
@@ -111,7 +120,8 @@ PROTOTYPES = {
     "cgen_rng_advance": [vp, u64, vp],
 }
 _RESTYPES = {"cgen_last_error": C.c_char_p}
-_NOCHECK = {"cgen_version", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks"}
+_NOCHECK = {"cgen_version", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks",
+            "cgen_block2_supported"}
 
 
 class WgradBatchLaunch(C.Structure):

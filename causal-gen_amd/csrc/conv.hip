@@ -2341,9 +2341,52 @@ __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, 
   }
 }
 
+#include "block_fused.inc"
+
 }  // namespace cgen
 
 using namespace cgen;
+
+// ----------------------------------------------------------------------------- fused light Block (block_fused.inc)
+static int blk_fill(const cgen_block_args* a, BlkP& p) {
+  if (!a || a->dtype != CGEN_BF16 || a->nseg < 1 || a->nseg > 3 || a->n <= 0 || a->h <= 0 || a->w <= 0) return 0;
+  memset(&p, 0, sizeof(p));
+  p.N = a->n; p.H = a->h; p.W = a->w; p.mode = a->mode; p.nseg = a->nseg; p.pre_act = a->pre_act;
+  int koff = 0;
+  for (int s = 0; s < a->nseg; ++s) {
+    if (!a->seg[s].p || a->seg[s].c <= 0 || !dma_clean(a->seg[s], 2)) return 0;
+    p.seg[s] = mk(a->seg[s]);
+    p.seg_koff[s] = koff;
+    koff += pad_to(a->seg[s].c, 8);
+    if (!fits_i32(p.seg[s], 1, a->h + BLK_TH + 4, a->w + BLK_TW + 4)) return 0;
+  }
+  for (int s = a->nseg; s < 3; ++s) p.seg_koff[s] = 1 << 30;
+  p.CU = koff; p.CT = a->mid.c; p.CV = a->out.c;
+  if (!a->mid.p || !a->out.p || !a->w_a || !a->w_b) return 0;
+  if (a->mode != 0 && !a->mid_aux.p) return 0;
+  // every epilogue access is an 8-byte vector: 8-byte aligned views
+  auto v8 = [](const cgen_view& v) { return !v.p || (((uintptr_t)v.p % 8 == 0) && v.sn % 4 == 0 && v.sh % 4 == 0 && v.sw % 4 == 0); };
+  if (!v8(a->mid) || !v8(a->mid_aux) || !v8(a->out) || !v8(a->aux) || !v8(a->res1)) return 0;
+  if (((uintptr_t)a->w_a % 16) || ((uintptr_t)a->w_b % 16) || (a->bias_a && (uintptr_t)a->bias_a % 16) || (a->bias_b && (uintptr_t)a->bias_b % 16)) return 0;
+  p.wA = (const bf16_t*)a->w_a; p.wB = (const bf16_t*)a->w_b; p.biasA = a->bias_a; p.biasB = a->bias_b;
+  p.krowA = pad_to(9 * p.CU, 32) + 32; p.krowB = pad_to(9 * pad_to(p.CT, 8), 32) + 32;
+  p.rowsA = pad_to(p.CT, 16); p.rowsB = pad_to(p.CV, 16);
+  p.t = mk(a->mid); p.taux = mk(a->mid_aux); p.out = mk(a->out); p.aux = mk(a->aux); p.res1 = mk(a->res1);
+  return blk_geometry(p) ? 1 : 0;
+}
+
+extern "C" int cgen_block2_supported(const cgen_block_args* a) {
+  BlkP p;
+  return blk_fill(a, p);
+}
+
+extern "C" int cgen_block2(const cgen_block_args* a, cgen_stream_t stream) {
+  BlkP p;
+  CGEN_REQUIRE(blk_fill(a, p), "cgen_block2: shape / layout not served by the fused Block kernel (ask cgen_block2_supported first)");
+  CGEN_REQUIRE(launch_blk(p, (hipStream_t)stream), "cgen_block2: no kernel instance for K = %d", p.nksA);
+  if (getenv("CGEN_CONV_TRACE")) fprintf(stderr, "blk2[%s] %dx%dx%d CU %d CT %d CV %d nseg %d\n", a->mode ? "bwd" : "fwd", a->n, a->h, a->w, p.CU, p.CT, p.CV, a->nseg);
+  return check_launch("cgen_block2");
+}
 
 extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
   CGEN_REQUIRE(a, "cgen_conv2d: null args");

@@ -172,6 +172,9 @@ class Engine:
         # independent sub-graphs of the forward pass (prior / posterior Block of a decoder layer) run on two streams
         self.fwd_branch = os.environ.get("CGEN_FWD_BRANCH", "1") != "0"
         self._fwd_side = None
+        # fused light-Block kernel (two 3x3 convs per launch, csrc/block_fused.inc): 0 off, 1 forward only, 2 forward + data gradient
+        self.blk_fuse = int(os.environ.get("CGEN_BLK_FUSE", "2"))
+        self.blk_minres = int(os.environ.get("CGEN_BLK_MINRES", "24"))
 
     # ------------------------------------------------------------------ memory
     def begin(self):
@@ -402,6 +405,41 @@ class Engine:
             self.tape.append((self._bw_conv, (site, segs, act, out, res1, res2)))
         return out
 
+    def block2(self, site1, site2, segs, act, res1=None):
+        """A whole light Block -- conv3x3(act(cat segs)) -> conv3x3(act(.)) (+ res1), vae.py:60-71,73-84 -- as ONE launch when
+        the fused kernel serves the shape (bf16, >= blk_minres pixels wide, concat width a multiple of 32, bottleneck <= 32),
+        else as the two conv launches.  The bottleneck tensor is written either way (weight gradients, backward mask), so
+        the tape is the same."""
+        x0 = segs[0]
+        a = None
+        if (self.blk_fuse and self.dt == BF16 and act == ACT_RELU and site1.ks == 3 and site2.ks == 3 and len(segs) <= 3
+                and min(x0.h, x0.w) >= self.blk_minres):
+            a = _lib.BlockArgs()
+            a.dtype, a.n, a.h, a.w, a.mode, a.nseg, a.pre_act = self.dt, x0.n, x0.h, x0.w, 0, len(segs), 1
+            for k, sg in enumerate(segs):
+                a.seg[k] = sg.cv()
+            a.w_a, a.w_b = site1.img_fwd, site2.img_fwd
+            b1, b2 = site1.conv.bias, site2.conv.bias
+            a.bias_a = b1.data_ptr() if b1 is not None else None
+            a.bias_b = b2.data_ptr() if b2 is not None else None
+        if a is not None:
+            t = self.new(x0.n, x0.h, x0.w, site1.co)
+            out = self.new(x0.n, x0.h, x0.w, site2.co)
+            a.mid, a.mid_aux, a.out, a.aux = t.cv(), NULL_VIEW, out.cv(), NULL_VIEW
+            a.res1 = res1.cv() if res1 is not None else NULL_VIEW
+            if site1.co % 8 == 0 and site2.co % 8 == 0 and self.lib.block2_supported(C.byref(a)):
+                self._timed_blk("conv_fwd", site1, site2, x0, lambda: self.lib.block2(C.byref(a), self.stream))
+                if self.recording:
+                    if self.blk_fuse >= 2:
+                        self.tape.append((self._bw_block2, (site1, site2, segs, act, t, out, res1)))
+                    else:
+                        self.tape.append((self._bw_conv, (site1, segs, act, t, None, None)))
+                        self.tape.append((self._bw_conv, (site2, [t], act, out, res1, None)))
+                return out
+            # (the two tensors just allocated are simply not used: the arena is reset per step)
+        t = self.conv(site1, segs, act)
+        return self.conv(site2, [t], act, res1=res1)
+
     def _timed(self, kind, site, x0, fn, ci=None):
         """Launch `fn`; when profiling, bracket it with events on the launch stream and tally algorithmic FLOPs
         (2 * Ci * k*k * Co per output pixel) under (kind, shape)."""
@@ -416,6 +454,21 @@ class Engine:
         flops = 2.0 * ci * site.taps * site.co * x0.n * x0.h * x0.w
         key = (kind, site.ks, ci, site.co, x0.h)
         ent = self.prof.setdefault(key, [0.0, [], 0])
+        ent[0] += flops
+        ent[1].append((e0, e1))
+        ent[2] += 1
+
+    def _timed_blk(self, kind, site1, site2, x0, fn):
+        """A fused Block launch, tallied (when profiling) with the algorithmic FLOPs of BOTH convs it executes."""
+        self.launches += 1
+        if self.prof is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        flops = 2.0 * (site1.ci * site1.taps * site1.co + site2.ci * site2.taps * site2.co) * x0.n * x0.h * x0.w
+        ent = self.prof.setdefault((kind + "_blk", 3, site1.ci, site2.co, x0.h), [0.0, [], 0])
         ent[0] += flops
         ent[1].append((e0, e1))
         ent[2] += 1
@@ -832,18 +885,7 @@ class Engine:
         for k, s in enumerate(segs):
             if not (s.rg and site.seg_rg[k]):
                 continue
-            gv, acc = self.grad_write(s, defer_hazard=True)
-            prev = gv
-            if acc and self._frozen(s):
-                # grad(s) lives in an adopted buffer a deferred wgrad will still read: accumulate OUT of place (same
-                # traffic: the kernel reads `prev` as a residual either way)
-                if s.base is s:
-                    e = self.grads[id(s)]
-                    e[0] = self._new_grad(s.n, s.h, s.w, s.c)
-                    gv = e[0].chan(0, s.c)
-                else:
-                    self._cow(s)
-                    gv = prev = self.grads[id(s.base)][0].chan(s.coff, s.coff + s.c)
+            gv, prev, acc = self._dgrad_target(s)
             a = _lib.ConvArgs()
             gn, gh, gw, vw = self._geom(site.ks, [g, gv, s, prev])
             a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = self.dt, gn, gh, gw, site.ks, 1, ACT_NONE, act
@@ -855,6 +897,59 @@ class Engine:
             a.res1 = vw(prev) if acc else NULL_VIEW
             a.res2 = NULL_VIEW
             self._timed("conv_dgrad", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream), ci=s.c)
+
+    def _dgrad_target(self, s):
+        """Where the data gradient of input tensor `s` goes: (view to write, view to add when accumulating, accumulate?)."""
+        gv, acc = self.grad_write(s, defer_hazard=True)
+        prev = gv
+        if acc and self._frozen(s):
+            # grad(s) lives in an adopted buffer a deferred wgrad will still read: accumulate OUT of place (same
+            # traffic: the kernel reads `prev` as a residual either way)
+            if s.base is s:
+                e = self.grads[id(s)]
+                e[0] = self._new_grad(s.n, s.h, s.w, s.c)
+                gv = e[0].chan(0, s.c)
+            else:
+                self._cow(s)
+                gv = prev = self.grads[id(s.base)][0].chan(s.coff, s.coff + s.c)
+        return gv, prev, acc
+
+    def _bw_block2(self, site1, site2, segs, act, t, out, res1):
+        """Backward of a fused light Block.  Weight gradients as for the two convs (deferred, batched); the two data-gradient
+        convs run as ONE launch of the fused kernel (mode 1) when conv1 has a single differentiable segment and the shape is
+        served, else as the two conv launches."""
+        g = self.grad_read(out)
+        if g is None:
+            return
+        s0 = segs[0]
+        fused = len(segs) == 1 and s0.rg and site1.seg_rg[0] and site1.img_dg[0] is not None and site2.img_dg[0] is not None
+        a = None
+        if fused:
+            a = _lib.BlockArgs()
+            a.dtype, a.n, a.h, a.w, a.mode, a.nseg, a.pre_act = self.dt, s0.n, s0.h, s0.w, 1, 1, 0
+            a.seg[0] = g.cv()
+            a.w_a, a.w_b, a.bias_a, a.bias_b = site2.img_dg[0], site1.img_dg[0], None, None
+            a.mid = View(t.ptr, t.sn, t.sh, t.sw, t.c, 0)      # shape stand-ins for the query; the real views are set below
+            a.mid_aux = t.cv()
+            a.out = View(s0.ptr, s0.sn, s0.sh, s0.sw, s0.c, 0)
+            a.aux, a.res1 = s0.cv(), NULL_VIEW
+            fused = bool(g.c % 8 == 0 and self.lib.block2_supported(C.byref(a)))
+        if not fused:
+            self._bw_conv(site2, [t], act, out, res1, None)
+            self._bw_conv(site1, segs, act, t, None, None)
+            return
+        if res1 is not None and res1.rg:
+            self._grad_residual(res1, g, out, [t])
+        if self._needs_wgrad(site2):
+            self._wgrad(site2, [t], act, g)
+        gt, acc_t = self.grad_write(t)
+        assert not acc_t
+        gv, prev, acc = self._dgrad_target(s0)
+        a.mid, a.out = gt.cv(), gv.cv()
+        a.res1 = prev.cv() if acc else NULL_VIEW
+        self._timed_blk("conv_dgrad", site1, site2, s0, lambda: self.lib.block2(C.byref(a), self.stream))
+        if self._needs_wgrad(site1):
+            self._wgrad(site1, segs, act, gt)
 
     @staticmethod
     def _needs_wgrad(site):

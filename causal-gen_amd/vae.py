@@ -371,10 +371,13 @@ class HVAE(nn.Module):
                 res = eng.conv(self._site(eng, blk.width_proj), segs, ACT_NONE)
             else:
                 res = x
-        h = eng.conv(self._site(eng, cs[0]), segs, act, res1=res if len(cs) == 1 else None)
-        for j, c in enumerate(cs[1:]):
-            last = j == len(cs) - 2
-            h = eng.conv(self._site(eng, c), [h], act, res1=res if last else None)
+        if blk.light and len(cs) == 2:  # the two 3x3 convs of a light Block: one fused launch where the kernel serves the shape
+            h = eng.block2(self._site(eng, cs[0]), self._site(eng, cs[1]), segs, act, res1=res)
+        else:
+            h = eng.conv(self._site(eng, cs[0]), segs, act, res1=res if len(cs) == 1 else None)
+            for j, c in enumerate(cs[1:]):
+                last = j == len(cs) - 2
+                h = eng.conv(self._site(eng, c), [h], act, res1=res if last else None)
         if blk.d:
             if isinstance(blk.d, float):
                 raise NotImplementedError("adaptive_avg_pool2d down-rates are not used by any preset")

@@ -68,6 +68,29 @@ typedef struct cgen_conv_args {
 } cgen_conv_args;
 int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream);
 
+/* ------------------------------------------------------------------ fused "light" Block: two 3x3 convs in one launch (bf16)
+ * Block.forward with version == "light" (vae.py:60-71,73-84):
+ *   mode 0:  mid = bias_a + conv3x3(relu(cat_C(seg)))            (pre-activation bottleneck tensor, written once)
+ *            out = bias_b + conv3x3(relu(mid)) + res1            (w_a / w_b: forward weight images of the two convs)
+ * and its data gradient (aten::convolution_backward x2 + threshold_backward x2, the input part):
+ *   mode 1:  mid = conv3x3(seg[0] = grad_out; w_a = dgrad image of conv2) * relu'(mid_aux)       (= grad of the bottleneck)
+ *            out = conv3x3(mid; w_b = dgrad image of conv1's segment) * relu'(aux) + res1         (= grad of the input)
+ * The bottleneck tensor stays in LDS between the two convs (halo recomputed); `mid` is written for the weight gradients
+ * and the backward mask.  pre_act: apply ReLU to the phase-A input (1 in mode 0, 0 in mode 1).
+ * Served shapes: sum_s ceil8(seg[s].c) a multiple of 32 (<= 160), mid.c in {8,16,24,32}, out.c a multiple of 8;
+ * cgen_block2_supported() answers without launching (1 = served). */
+typedef struct cgen_block_args {
+  int32_t dtype, n, h, w, mode, nseg, pre_act, reserved;
+  cgen_view seg[CGEN_MAX_SEG];
+  const void* w_a;
+  const float* bias_a;
+  const void* w_b;
+  const float* bias_b;
+  cgen_view mid, mid_aux, out, aux, res1;
+} cgen_block_args;
+int cgen_block2_supported(const cgen_block_args* a);
+int cgen_block2(const cgen_block_args* a, cgen_stream_t stream);
+
 /* Weight gradient (aten::convolution_backward, weight/bias part) as split-K partials:
  *   partial_w[split][Co][KS*KS][Ci_total] (f32), partial_b[split][Co] (f32, may be NULL)
  * with Ci_total = sum_s seg[s].c and nsplit = cgen_conv2d_wgrad_plan(args) (call it with the views filled in; it also
