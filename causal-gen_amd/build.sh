@@ -15,7 +15,11 @@ pids=""
 for s in $SRCS; do
   o=build/$(basename ${s%.hip}).o
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ csrc/common.h -nt "$o" ] || [ ../include/cgen_hip.h -nt "$o" ]; then
+  stale=0
+  for dep in "$s" csrc/common.h csrc/*.inc ../include/cgen_hip.h; do
+    if [ "$dep" -nt "$o" ]; then stale=1; fi
+  done
+  if [ ! -f "$o" ] || [ $stale = 1 ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $NOPK ${CGEN_EXTRA_FLAGS} -Wno-unused-result -c "$s" -o "$o" &
     pids="$pids $!"
   fi

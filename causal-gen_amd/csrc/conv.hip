@@ -2348,6 +2348,15 @@ __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, 
 using namespace cgen;
 
 // ----------------------------------------------------------------------------- fused light Block (block_fused.inc)
+static bool blk_bv(const cgen_view& v, int n, int h, int w, BV& o) {  // 64-bit element strides -> 32-bit byte strides (checked)
+  o.p = (const char*)v.p; o.sn = o.sh = o.sw = 0; o.c = v.c;
+  if (!v.p) return true;
+  const int64_t ext = ((int64_t)n * v.sn + (int64_t)(h + BLK_TH + 4) * v.sh + (int64_t)(w + BLK_TW + 4) * v.sw + v.c) * 2;
+  if (ext >= ((int64_t)1 << 31) || v.sn < 0 || v.sh < 0 || v.sw < 0) return false;
+  o.sn = (int)(v.sn * 2); o.sh = (int)(v.sh * 2); o.sw = (int)(v.sw * 2);
+  return true;
+}
+
 static int blk_fill(const cgen_block_args* a, BlkP& p) {
   if (!a || a->dtype != CGEN_BF16 || a->nseg < 1 || a->nseg > 3 || a->n <= 0 || a->h <= 0 || a->w <= 0) return 0;
   memset(&p, 0, sizeof(p));
@@ -2355,15 +2364,14 @@ static int blk_fill(const cgen_block_args* a, BlkP& p) {
   int koff = 0;
   for (int s = 0; s < a->nseg; ++s) {
     if (!a->seg[s].p || a->seg[s].c <= 0 || !dma_clean(a->seg[s], 2)) return 0;
-    p.seg[s] = mk(a->seg[s]);
+    if (!blk_bv(a->seg[s], a->n, a->h, a->w, p.seg[s])) return 0;
     p.seg_koff[s] = koff;
     koff += pad_to(a->seg[s].c, 8);
-    if (!fits_i32(p.seg[s], 1, a->h + BLK_TH + 4, a->w + BLK_TW + 4)) return 0;
   }
   for (int s = a->nseg; s < 3; ++s) p.seg_koff[s] = 1 << 30;
   p.CU = koff; p.CT = a->mid.c; p.CV = a->out.c;
   if (!a->mid.p || !a->out.p || !a->w_a || !a->w_b) return 0;
-  if (a->mode != 0 && !a->mid_aux.p) return 0;
+  if (a->mode != 0 && (!a->mid_aux.p || !a->aux.p)) return 0;
   // every epilogue access is an 8-byte vector: 8-byte aligned views
   auto v8 = [](const cgen_view& v) { return !v.p || (((uintptr_t)v.p % 8 == 0) && v.sn % 4 == 0 && v.sh % 4 == 0 && v.sw % 4 == 0); };
   if (!v8(a->mid) || !v8(a->mid_aux) || !v8(a->out) || !v8(a->aux) || !v8(a->res1)) return 0;
@@ -2371,8 +2379,9 @@ static int blk_fill(const cgen_block_args* a, BlkP& p) {
   p.wA = (const bf16_t*)a->w_a; p.wB = (const bf16_t*)a->w_b; p.biasA = a->bias_a; p.biasB = a->bias_b;
   p.krowA = pad_to(9 * p.CU, 32) + 32; p.krowB = pad_to(9 * pad_to(p.CT, 8), 32) + 32;
   p.rowsA = pad_to(p.CT, 16); p.rowsB = pad_to(p.CV, 16);
-  p.t = mk(a->mid); p.taux = mk(a->mid_aux); p.out = mk(a->out); p.aux = mk(a->aux); p.res1 = mk(a->res1);
-  return blk_geometry(p) ? 1 : 0;
+  if (!blk_bv(a->mid, a->n, a->h, a->w, p.t) || !blk_bv(a->mid_aux, a->n, a->h, a->w, p.taux) || !blk_bv(a->out, a->n, a->h, a->w, p.out) ||
+      !blk_bv(a->aux, a->n, a->h, a->w, p.aux) || !blk_bv(a->res1, a->n, a->h, a->w, p.res1)) return 0;
+  return launch_blk(p, nullptr, true) ? 1 : 0;
 }
 
 extern "C" int cgen_block2_supported(const cgen_block_args* a) {

@@ -172,8 +172,10 @@ class Engine:
         # independent sub-graphs of the forward pass (prior / posterior Block of a decoder layer) run on two streams
         self.fwd_branch = os.environ.get("CGEN_FWD_BRANCH", "1") != "0"
         self._fwd_side = None
-        # fused light-Block kernel (two 3x3 convs per launch, csrc/block_fused.inc): 0 off, 1 forward only, 2 forward + data gradient
-        self.blk_fuse = int(os.environ.get("CGEN_BLK_FUSE", "2"))
+        # fused light-Block kernel (two 3x3 convs per launch, csrc/block_fused.inc): 0 off, 1 forward only, 2 forward + data gradient.
+        # OFF by default: correct (tests/test_gpu_block.py) but, at one wave per SIMD, still slower than the two launches it
+        # replaces on MI355X (DESIGN.md section 3.6 has the per-phase cycle stamps and what bounds it)
+        self.blk_fuse = int(os.environ.get("CGEN_BLK_FUSE", "0"))
         self.blk_minres = int(os.environ.get("CGEN_BLK_MINRES", "24"))
 
     # ------------------------------------------------------------------ memory
