@@ -291,11 +291,14 @@ def main():
         torch.cuda.synchronize()
 
     sync()
+    ts.time_comm = world > 1
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = ts.step(x, pa)
     sync()
     dt = time.perf_counter() - t0
+    ts.time_comm = False
+    exposed_comm = ts.exposed_comm_ms() if world > 1 else None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -321,7 +324,14 @@ def main():
             "arena_bytes": ts.eng.arena.high_water, "launches_per_step": roof.get("launches_per_step"),
             "model_tflops": img_s * gf * 1e9 / 1e12,
             "model_mfma_frac": img_s * gf * 1e9 / 1e12 / (MFMA_PEAK_TF[a.dtype] * world),
+            "param_abs_sum": float(sum(p.detach().double().abs().sum() for p in m.parameters())),
         }
+        if world > 1:
+            res["dp"] = {"allreduce_overlapped_with_backward": bool(ts.dp_overlap and ts.early_ranges),
+                         "exposed_comm_ms_per_step": exposed_comm,
+                         "early_bytes": 4 * sum(hi - lo for lo, hi in (ts.early_ranges or [])),
+                         "late_bytes": 4 * sum(hi - lo for lo, hi in (ts.late_ranges or [(0, ts._gbuf().numel())])),
+                         "backend": os.environ.get("CGEN_DIST_BACKEND", "nccl")}
         res["roofline"] = roof
         if not a.no_cf:
             from causal_gen_amd.dscm import GraphedCounterfactual

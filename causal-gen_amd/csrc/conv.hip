@@ -1526,7 +1526,7 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
   g.n_cwin = ceil_div(ctot8, cwin);
   g.tiles_x = ceil_div(W, TILE_W); g.tiles_y = ceil_div(H, TILE_H);
   g.ntiles = N * g.tiles_x * g.tiles_y;
-  static const int want_total = [] { const char* e = getenv("CGEN_WG2_WANT"); return e ? atoi(e) : 160; }();
+  static const int want_total = [] { const char* e = getenv("CGEN_WG2_WANT"); return e ? atoi(e) : 64; }();  // (round 2: 160 -> 64 workgroups per problem: -25 % split-K partial bytes, +2.8 % step throughput)
   // workgroups per problem: the batched launch packs all problems of a step into one grid, so a problem need not fill
   // the chip by itself -- fewer, longer workgroups mean fewer split-K partials (measured optimum on MI355X: ~160 / >= 4 tiles)
   int want = ceil_div(want_total, g.n_cwin * g.n_co);
@@ -2304,15 +2304,28 @@ __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, 
     if (vec) {
       const float4* src = (const float4*)(d.partial_w + s0);
       const size_t stride = (size_t)nw / 4;
-      float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+      // four independent chains of streaming (non-temporal) 16-byte loads: the partials are read exactly once; the sum order
+      // ((c0 + c1) + (c2 + c3)) over splits dealt round-robin is fixed => deterministic
+      float4 b[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b[c] = make_float4(0.f, 0.f, 0.f, 0.f);
       int sp = 0;
-      for (; sp + 2 <= d.nsplit; sp += 2) {  // two independent chains; fixed order => deterministic
-        const float4 v0 = src[(size_t)sp * stride], v1 = src[(size_t)(sp + 1) * stride];
-        b0.x += v0.x; b0.y += v0.y; b0.z += v0.z; b0.w += v0.w;
-        b1.x += v1.x; b1.y += v1.y; b1.z += v1.z; b1.w += v1.w;
+      for (; sp + 4 <= d.nsplit; sp += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 t = __builtin_nontemporal_load((const f32x4*)(src + (size_t)(sp + c) * stride));  // one global_load_dwordx4 nt
+          v[c] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { b[c].x += v[c].x; b[c].y += v[c].y; b[c].z += v[c].z; b[c].w += v[c].w; }
       }
-      if (sp < d.nsplit) { const float4 v0 = src[(size_t)sp * stride]; b0.x += v0.x; b0.y += v0.y; b0.z += v0.z; b0.w += v0.w; }
-      a[0] = b0.x + b1.x; a[1] = b0.y + b1.y; a[2] = b0.z + b1.z; a[3] = b0.w + b1.w;
+      for (int c = 0; sp < d.nsplit; ++sp, ++c) {
+        const float4 v0 = src[(size_t)sp * stride];
+        b[c].x += v0.x; b[c].y += v0.y; b[c].z += v0.z; b[c].w += v0.w;
+      }
+      a[0] = (b[0].x + b[1].x) + (b[2].x + b[3].x); a[1] = (b[0].y + b[1].y) + (b[2].y + b[3].y);
+      a[2] = (b[0].z + b[1].z) + (b[2].z + b[3].z); a[3] = (b[0].w + b[1].w) + (b[2].w + b[3].w);
     } else {
       for (int e = 0; e < cnt; ++e) {
         float acc = 0.f;

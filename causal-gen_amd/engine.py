@@ -177,6 +177,12 @@ class Engine:
         # replaces on MI355X (DESIGN.md section 3.6 has the per-phase cycle stamps and what bounds it)
         self.blk_fuse = int(os.environ.get("CGEN_BLK_FUSE", "0"))
         self.blk_minres = int(os.environ.get("CGEN_BLK_MINRES", "24"))
+        # data parallelism: once this fraction of the pass's weight-gradient work has been issued (and the background flush is
+        # out), `on_split` is called with the side stream joined -- the gradients of every conv reduced so far are FINAL
+        # (`early_final`), so their all-reduce can travel under the rest of the backward pass (train.TrainStep)
+        self.split_frac = float(os.environ.get("CGEN_DP_SPLIT_FRAC", "0.8"))
+        self.on_split = None
+        self.early_final = None
 
     # ------------------------------------------------------------------ memory
     def begin(self):
@@ -195,6 +201,7 @@ class Engine:
         self._wg_deferred = []
         self._wg_cum, self._wg_nflush = 0.0, 0
         self._wg_forked = False
+        self._split_done = False
         self.passes = 0
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
 
@@ -989,6 +996,21 @@ class Engine:
                     and self._wg_cum >= self.wgrad_flush_frac[k] * self._wg_total):
                 self._wg_nflush += 1
                 self._launch_batched_wgrads(background=True)
+            if (self.on_split is not None and not self._split_done and self._wg_nflush >= 1 and self._wg_total > 0
+                    and self._wg_cum >= self.split_frac * self._wg_total):
+                self._split_done = True
+                if self._wg_forked:  # join the background flush + its reduction: by now it has long finished (no stall)
+                    main = torch.cuda.current_stream(self.device)
+                    for st in self._wg_pool:
+                        main.wait_stream(st)
+                    self._wg_forked = False
+                final = set()
+                for st_, _, _ in self._wg_events[:self._wg_reduced]:
+                    final.add(id(st_.conv.weight))
+                    if st_.conv.bias is not None:
+                        final.add(id(st_.conv.bias))
+                self.early_final = final
+                self.on_split()
         else:
             self._timed("conv_wgrad", site, x0, lambda: self.lib.conv2d_wgrad(C.byref(a), self.stream))
         self._wg_events.append((site, key, nsplit))

@@ -42,6 +42,22 @@ def preprocess_batch(args, batch, expand_pa=False):
     return batch
 
 
+def _subtract_ranges(whole, holes):
+    """[lo, hi) ranges of `whole` not covered by `holes` (both sorted, non-overlapping)."""
+    out = []
+    for lo, hi in whole:
+        cur = lo
+        for a, b in holes:
+            if b <= cur or a >= hi:
+                continue
+            if a > cur:
+                out.append((cur, a))
+            cur = max(cur, b)
+        if cur < hi:
+            out.append((cur, hi))
+    return out
+
+
 def linear_warmup(warmup_iters):
     """utils.py:32-36."""
     return lambda it: 1.0 if it > warmup_iters else it / warmup_iters
@@ -82,6 +98,14 @@ class TrainStep:
         self.out3 = None
         self.beta = float(args.beta)
         self.it = 0
+        # DP: all-reduce of the already-final half of the gradient under the rest of the backward pass (CGEN_DP_OVERLAP=0: the
+        # serialized round-1 form, kept for A/B and as the bit-equality reference)
+        import os as _os
+        self.dp_overlap = self.world > 1 and _os.environ.get("CGEN_DP_OVERLAP", "1") != "0"
+        self.comm_stream = None
+        self.early_ranges = self.late_ranges = None
+        self.time_comm = False
+        self._comm_events = []
         # gradient accumulation (trainer.py:64-67): elbo / accu_steps per iteration, summed in a second flat buffer; the
         # optimiser tail runs on iterations with (it - 1) % accu_steps == 0 and reads that buffer
         self.accu = max(1, int(getattr(args, "accu_steps", 1) or 1))
@@ -135,6 +159,67 @@ class TrainStep:
         if self.world > 1:
             dp.bucketed_allreduce_mean(self._gbuf(), self.bucket_elems, self.pg, extra=(out3,))
 
+    # -- gradient all-reduce overlapped with the backward pass (north_star) -------------------------
+    def _ranges_of(self, ids):
+        """Contiguous [lo, hi) ranges of the flat gradient covered by the parameters with these ids."""
+        eng = self.eng
+        rs, cur = [], None
+        for p in eng.params:
+            o, k = eng.p_off[id(p)], p.numel()
+            if id(p) in ids:
+                if cur is not None and cur[1] == o:
+                    cur[1] = o + k
+                else:
+                    cur = [o, o + k]
+                    rs.append(cur)
+            else:
+                cur = None
+        return [(a, b) for a, b in rs]
+
+    def _early_launch(self):
+        """Issue the all-reduce of the gradients that are already final (the decoder half, reduced by the background flush) on
+        the communication stream, behind everything the main stream has done so far.  Returns the pending work handles."""
+        main = torch.cuda.current_stream(self.eng.device)
+        if self.comm_stream is None:
+            self.comm_stream = torch.cuda.Stream(self.eng.device)
+        self.comm_stream.wait_stream(main)
+        works = []
+        g = self._gbuf()
+        with torch.cuda.stream(self.comm_stream):
+            for lo, hi in self.early_ranges:
+                for o in range(lo, hi, self.bucket_elems):
+                    works.append(torch.distributed.all_reduce(g[o:min(hi, o + self.bucket_elems)], group=self.pg, async_op=True))
+        return works
+
+    def _late_finish(self, out3, works):
+        """All-reduce what the rest of the backward pass produced (plus the reported scalars), wait for both halves, average."""
+        g = self._gbuf()
+        t0 = None
+        if self.time_comm:
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+        for lo, hi in self.late_ranges:
+            for o in range(lo, hi, self.bucket_elems):
+                works.append(torch.distributed.all_reduce(g[o:min(hi, o + self.bucket_elems)], group=self.pg, async_op=True))
+        works.append(torch.distributed.all_reduce(out3, group=self.pg, async_op=True))
+        for w in works:
+            w.wait()
+        g.mul_(1.0 / self.world)
+        out3.mul_(1.0 / self.world)
+        if t0 is not None:
+            t1.record()
+            self._comm_events.append((t0, t1))
+
+    def exposed_comm_ms(self):
+        """Mean time per step between the end of the backward pass and the end of the gradient exchange (what the all-reduce
+        adds to the step; needs ``time_comm = True`` before the steps of interest)."""
+        if not self._comm_events:
+            return None
+        torch.cuda.synchronize()
+        v = [a.elapsed_time(b) for a, b in self._comm_events]
+        self._comm_events = []
+        return sum(v) / len(v)
+
     def _used_ranges(self):
         eng = self.eng
         rs, cur = [], None
@@ -178,13 +263,38 @@ class TrainStep:
 
     def _eager(self, x, pa, beta, do_step=True):
         self._coef_for(x, beta)
-        out3 = self._fwd_bwd(x, pa, beta)
+        overlap = self.dp_overlap and do_step and self.acc_g is None
+        works, fired = [], []
+        if overlap:
+            def at_split():
+                if self.early_ranges is None:  # first step: which flat ranges are final here, and which come later
+                    self.early_ranges = self._ranges_of(self.eng.early_final)
+                works.extend(self._early_launch())
+                fired.append(True)
+            self.eng.on_split = at_split
+        try:
+            out3 = self._fwd_bwd(x, pa, beta)
+        finally:
+            self.eng.on_split = None
         self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
         if do_step:
-            self._allreduce(out3)
+            if overlap:
+                if self.early_ranges is None:
+                    self.early_ranges = []  # (the split mark was never reached: tiny model) -> everything is "late"
+                elif not fired:
+                    works.extend(self._early_launch())  # (a step without the background flush, e.g. the profiled one: exchange that half now)
+                if self.late_ranges is None:
+                    used = self._used_or_all_ranges()
+                    self.late_ranges = _subtract_ranges(used, self.early_ranges)
+                self._late_finish(out3, works)
+            else:
+                self._allreduce(out3)
             self._optim(out3)
             self._mark_weights_written()
         return out3
+
+    def _used_or_all_ranges(self):
+        return [(0, self._gbuf().numel())]
 
     def _mark_weights_written(self):
         """The fused AdamW / EMA kernel writes both flat parameter buffers through raw pointers, which torch's version
@@ -218,27 +328,58 @@ class TrainStep:
             out = self._eager(x, pa, beta, do_step)  # eager warm-up: sizes the arena, builds the tables
             sx, sp = x.clone(), pa.clone()
             torch.cuda.synchronize()
-            # NCCL inside a captured graph is avoided: under DP the step is two graphs around an eager all-reduce
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                so = self._fwd_bwd(sx, sp, beta)
-                if self.world == 1 and do_step:
-                    self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
-                    self._optim(so)
+            # NCCL inside a captured graph is avoided: under DP the step is graphs around eager all-reduces.  With overlap the
+            # backward graph is cut where the decoder half of the gradient is final (engine.on_split): graph A | all-reduce of
+            # that half on the communication stream | graph B (rest of the backward pass) | all-reduce of the rest | graph C.
+            overlap = self.dp_overlap and do_step and self.acc_g is None and bool(self.early_ranges)
+            g1, g1b = torch.cuda.CUDAGraph(), None
+            if overlap:
+                g1b = torch.cuda.CUDAGraph()
+                cap = torch.cuda.Stream(self.eng.device)
+                cap.wait_stream(torch.cuda.current_stream(self.eng.device))
+                fired = []
+
+                def at_split():
+                    g1.capture_end()
+                    g1b.capture_begin(pool=g1.pool())
+                    fired.append(True)
+
+                with torch.cuda.stream(cap):
+                    g1.capture_begin()
+                    self.eng.on_split = at_split
+                    try:
+                        so = self._fwd_bwd(sx, sp, beta)
+                    finally:
+                        self.eng.on_split = None
+                    (g1b if fired else g1).capture_end()
+                torch.cuda.current_stream(self.eng.device).wait_stream(cap)
+                if not fired:
+                    g1b = None
+            else:
+                with torch.cuda.graph(g1):
+                    so = self._fwd_bwd(sx, sp, beta)
+                    if self.world == 1 and do_step:
+                        self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
+                        self._optim(so)
             g2 = None
             if self.world > 1 and do_step:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2):
                     self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
                     self._optim(so)
-            self.graphs[key] = (g1, g2, sx, sp, so)
+            self.graphs[key] = (g1, g2, sx, sp, so, g1b)
             return out
-        g1, g2, sx, sp, so = ent
+        g1, g2, sx, sp, so, g1b = ent
         if sx.data_ptr() != x.data_ptr():
             sx.copy_(x, non_blocking=True)
             sp.copy_(pa, non_blocking=True)
         g1.replay()
-        if g2 is not None:
+        if g1b is not None:
+            works = self._early_launch()
+            g1b.replay()
+            self._late_finish(so, works)
+            g2.replay()
+        elif g2 is not None:
             self._allreduce(so)
             g2.replay()
         if do_step:

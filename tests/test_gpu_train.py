@@ -251,6 +251,33 @@ def test_dp_bench_path_two_gloo_ranks_on_one_gpu():
     assert d["opt_steps"] == 4 and "roofline" in d
 
 
+def test_dp_allreduce_overlapped_with_backward_equals_the_serialized_exchange():
+    """north_star: gradient all-reduce overlapped with backward.  The backward graph is cut where the decoder half of the
+    flat gradient is final; that half travels on the communication stream under the encoder half.  Two gloo ranks on this
+    GPU: parameters after four steps are bit-equal to the serialized exchange (a two-rank sum is order independent), the
+    overlapped path really ran (early bytes > 0), and the exposed communication time is reported."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for overlap, port in (("0", "29521"), ("1", "29523")):
+        env = dict(os.environ, CGEN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", CGEN_DP_OVERLAP=overlap)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "ukbb192", "--batch", "2",
+               "--steps", "2", "--warmup", "1", "--prep-steps", "1", "--no-cf", "--no-cpu"]
+        r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[overlap] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    a, b = outs["0"], outs["1"]
+    assert not a["dp"]["allreduce_overlapped_with_backward"] and b["dp"]["allreduce_overlapped_with_backward"]
+    assert b["dp"]["early_bytes"] > 0 and b["dp"]["late_bytes"] > 0 and b["dp"]["exposed_comm_ms_per_step"] is not None
+    assert a["param_abs_sum"] == b["param_abs_sum"], (a["param_abs_sum"], b["param_abs_sum"])
+    assert a["elbo_nats_per_dim"] == b["elbo_nats_per_dim"] and a["opt_steps"] == b["opt_steps"] == 4
+
+
 def test_backward_is_bit_reproducible_next_to_the_background_weight_gradient_kernel():
     """Three backward passes of the ukbb192 model (bf16, background flush on) from identical state must give bit-identical
     gradients.  They did not while packed-f32 instructions were in the kernels: a co-resident MFMA wave of the background
