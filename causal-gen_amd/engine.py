@@ -996,7 +996,7 @@ class Engine:
                     and self._wg_cum >= self.wgrad_flush_frac[k] * self._wg_total):
                 self._wg_nflush += 1
                 self._launch_batched_wgrads(background=True)
-            if (self.on_split is not None and not self._split_done and self._wg_nflush >= 1 and self._wg_total > 0
+            if (self.on_split is not None and not self._split_done and self._wg_nflush >= max(1, len(self.wgrad_flush_frac)) and self._wg_total > 0
                     and self._wg_cum >= self.split_frac * self._wg_total):
                 self._split_done = True
                 if self._wg_forked:  # join the background flush + its reduction: by now it has long finished (no stall)

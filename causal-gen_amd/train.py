@@ -102,6 +102,14 @@ class TrainStep:
         # serialized round-1 form, kept for A/B and as the bit-equality reference)
         import os as _os
         self.dp_overlap = self.world > 1 and _os.environ.get("CGEN_DP_OVERLAP", "1") != "0"
+        if self.dp_overlap:
+            # a second background flush at the end of the DECODER's backward pass (75.5 % of the weight-gradient work of the
+            # 192^2 presets; costs 0.8 % on one GPU): from there on every decoder / likelihood gradient is final -- 48 of the
+            # 69.5 MB of ukbb192 -- and is exchanged under the encoder's backward pass; the graph is cut at 90 %
+            if "CGEN_WGRAD_FLUSH_FRAC" not in _os.environ:
+                eng.wgrad_flush_frac = [0.55, 0.755]
+            if "CGEN_DP_SPLIT_FRAC" not in _os.environ:
+                eng.split_frac = 0.9
         self.comm_stream = None
         self.early_ranges = self.late_ranges = None
         self.time_comm = False
