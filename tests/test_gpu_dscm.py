@@ -174,3 +174,43 @@ def test_dscm_forward_without_grad_keeps_the_inference_path():
     with torch.no_grad():
         out = model(obs, {"a": cf[:, 0, 0, 0]}, None, cf_particles=2)
     assert out["cfs"]["x"].shape == x.shape and torch.isfinite(out["cfs"]["x"]).all()
+
+
+def test_dscm_forward_with_the_pyro_free_parent_scm():
+    """DSCM.forward end to end on the GPU box with causal-gen_amd/pgm.FlowPGM as `pgm` (no pyro): a null intervention gives the
+    observation back; do(sex) changes brain volume, hence the image; the loss is differentiable into the HVAE."""
+    from causal_gen_amd import dscm, pgm, vae
+    from causal_gen_amd.hps import Hparams
+    from oracle import hparams as ohp
+
+    hp = vars(ohp.tiny_hparams(hps="tiny_ukbb", z_max_res=8, context_dim=4))
+    torch.manual_seed(0)
+    m = vae.HVAE(Hparams(**hp))
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * (0.1 if p.dim() < 4 else 0.5 / (p[0].numel() ** 0.5)))
+    m = m.cuda().eval()
+    scm = pgm.FlowPGM(SimpleNamespace(widths=[8, 8]))
+    with torch.no_grad():
+        for p in scm.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+    scm = scm.cuda()
+    obs = scm.sample(3, torch.Generator().manual_seed(2))
+    x = ((torch.randint(0, 256, (3, 1, 16, 16), generator=g).float() - 127.5) / 127.5).cuda()
+    args = SimpleNamespace(**hp, parents_x=["mri_seq", "brain_volume", "ventricle_volume", "sex"], dataset="ukbb", lmbda_init=1.0,
+                           elbo_constraint=2.0, damping=10.0)
+    model = dscm.DSCM(args, scm, StubPredictor(), m).cuda()
+    o = dict(obs, x=x)
+    with torch.no_grad():
+        same = model(o, {}, None)
+        flip = model(o, {"sex": 1 - obs["sex"]}, None)
+    assert (same["cfs"]["x"] - x).abs().max() < 1e-4
+    assert (flip["cfs"]["x"] - x).abs().mean() > 1e-4
+    assert torch.equal(flip["cfs"]["sex"], 1 - obs["sex"]) and (flip["cfs"]["brain_volume"] - obs["brain_volume"]).abs().max() > 1e-4
+    for p in m.parameters():
+        p.requires_grad_(True)
+    out = model(o, {"sex": 1 - obs["sex"]}, StubELBO(torch.ones(3, 1, 16, 16)), cf_particles=2)
+    out["loss"].sum().backward()
+    torch.cuda.synchronize()
+    assert m.encoder.stem.weight.grad is not None and float(m.encoder.stem.weight.grad.abs().max()) > 0
