@@ -387,7 +387,9 @@ class Engine:
         return self.flat_g[o:o + p.numel()].view(p.shape)
 
     # ------------------------------------------------------------------ forward ops
-    def conv(self, site, segs, act=ACT_NONE, res1=None, res2=None, out=None):
+    def conv(self, site, segs, act=ACT_NONE, res1=None, res2=None, out=None, tape_hold=None):
+        """`tape_hold` (a list): the backward entry goes there instead of onto the tape -- for an op that is LAUNCHED early (on
+        the side stream) but keeps its place in the backward order (the caller extends the tape with the list later)."""
         x0 = segs[0]
         if out is None:
             out = self.new(x0.n, x0.h, x0.w, site.co)
@@ -411,7 +413,7 @@ class Engine:
         if self.recording:
             if self._dbg_names is not None:
                 self._dbg_names[id(out.base)] = site.name
-            self.tape.append((self._bw_conv, (site, segs, act, out, res1, res2)))
+            (self.tape if tape_hold is None else tape_hold).append((self._bw_conv, (site, segs, act, out, res1, res2)))
         return out
 
     def block2(self, site1, site2, segs, act, res1=None):

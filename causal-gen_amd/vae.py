@@ -420,6 +420,14 @@ class HVAE(nn.Module):
         # Philox stream ids: unique per (decoder pass within this engine step, stochastic layer)
         eng.passes = getattr(eng, "passes", 0) + 1
         sid = 1000 * eng.passes
+        # Software pipeline over layers (training / abduction pass): z_feat_proj of layer k, the upsampling of its output and
+        # the prior Block of layer k + 1 form a chain that only needs z_k and p_feat_k -- it runs on the side stream while the
+        # main stream does z_proj, the conv Block and the posterior Block of layer k + 1.  Same kernels, same tape order.
+        pipeline = acts is not None and eng.recording and eng.fwd_branch and eng.prof is None
+        if pipeline:
+            for p_ in dec.bias:  # (lazily built NHWC images: build them before any side-stream section needs one)
+                eng.param_nhwc(p_)
+        side_ahead = False
         for i, blk in enumerate(dec.blocks):
             res = blk.res
             pa = parents.crop(res)
@@ -429,11 +437,20 @@ class HVAE(nn.Module):
                 same = z is h
                 h = eng.upsample(h, res, bp)
                 if not blk.q_correction:
-                    z = h if same else eng.upsample(z, res, bp)
+                    if same:
+                        z = h
+                    elif side_ahead:
+                        z_lo = z
+                        z = eng.on_side(lambda: eng.upsample(z_lo, res, bp))
+                    else:
+                        z = eng.upsample(z, res, bp)
             p_in = h if blk.q_correction else z
             run_prior = lambda: self._run_block(eng, blk.prior, [p_in, pa_sto] if blk.cond_prior else [p_in])
             # the prior and the posterior Block of a layer are independent: two streams (one fork / join per layer)
-            two = blk.stochastic and acts is not None and eng.recording and eng.fork_side()
+            two = blk.stochastic and acts is not None and eng.recording and (side_ahead or eng.fork_side())
+            if side_ahead and not two:
+                eng.join_side()
+                side_ahead = False
             pout = eng.on_side(run_prior) if two else run_prior()
             zd = blk.z_dim
             p_loc, p_ls, p_feat = pout.chan(0, zd), pout.chan(zd, 2 * zd), pout.chan(2 * zd, pout.c)
@@ -443,6 +460,7 @@ class HVAE(nn.Module):
                     qout = self._run_block(eng, blk.posterior, [h, pa, acts[res]])
                     if two:
                         eng.join_side()
+                        side_ahead = False
                     q_loc, q_ls = qout.chan(0, zd), qout.chan(zd, 2 * zd)
                     eps = self._next_eps(eng, q_loc.shape)
                     kptr = kl[0] + 4 * kl[2][i] if kl is not None else self._scratch_kl(eng, B, res, zd)
@@ -464,10 +482,20 @@ class HVAE(nn.Module):
                             out.append((p_loc, p_ls))
             else:
                 z = p_loc
-            h = eng.conv(self._site(eng, blk.z_proj), [z, pa], ACT_NONE, res1=h, res2=p_feat)
+            z_cur = z
+            feat = not blk.q_correction and i + 1 < len(dec.blocks)
+            hold = []
+            if feat and pipeline and two and dec.blocks[i + 1].stochastic and not dec.blocks[i + 1].q_correction and eng.fork_side():
+                z = eng.on_side(lambda: eng.conv(self._site(eng, blk.z_feat_proj), [z_cur, p_feat], ACT_NONE, tape_hold=hold))
+                side_ahead = True
+                feat = False
+            h = eng.conv(self._site(eng, blk.z_proj), [z_cur, pa], ACT_NONE, res1=h, res2=p_feat)
             h = self._run_block(eng, blk.conv, [h])
-            if not blk.q_correction and i + 1 < len(dec.blocks):
-                z = eng.conv(self._site(eng, blk.z_feat_proj), [z, p_feat], ACT_NONE)
+            eng.tape.extend(hold)  # (backward order as before: z_feat_proj after the conv Block)
+            if feat:
+                z = eng.conv(self._site(eng, blk.z_feat_proj), [z_cur, p_feat], ACT_NONE)
+        if side_ahead:
+            eng.join_side()
         return h, out
 
     def _scratch_kl(self, eng, B, res, zd):
