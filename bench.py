@@ -45,8 +45,12 @@ def synth_batch(name, hp, B, device, seed):
                           torch.randn(B, generator=g), torch.randint(0, 2, (B,), generator=g).float()], 1)
     else:
         pa = torch.randn(B, hp.context_dim, generator=g)
-    pa = pa[..., None, None].repeat(1, 1, R, R)
-    return x.to(device), pa.to(device)
+    # the reference's [B,ctx,R,R] parents (trainer.py:16-21) as the stride-0 view the product's own preprocess_batch hands
+    # over; CGEN_BENCH_PA=repeat materialises them (the general, spatially varying path) for an A/B
+    pa = pa.to(device)[..., None, None].expand(-1, -1, R, R)
+    if os.environ.get("CGEN_BENCH_PA") == "repeat":
+        pa = pa.contiguous()
+    return x.to(device), pa
 
 
 def build_model(name, dtype, dmol=False):
@@ -337,7 +341,8 @@ def main():
             from causal_gen_amd.dscm import GraphedCounterfactual
 
             ema = ts.ema_model
-            cfp = pa.roll(1, 0)  # train_cf.py:149 feeds a permutation of the batch's parents as `do`
+            # train_cf.py:149 feeds a permutation of the batch's parents as `do`
+            cfp = pa[:, :, 0, 0].roll(1, 0)[..., None, None].expand_as(pa) if pa.stride(2) == 0 else pa.roll(1, 0)
             counterfactual = GraphedCounterfactual(ema)  # abduct -> act -> predict as one hipGraph replay per batch
             for _ in range(3):
                 counterfactual(x, pa, cfp)

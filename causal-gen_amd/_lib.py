@@ -27,7 +27,7 @@ class ConvArgs(C.Structure):
 
 class BlockArgs(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("mode", C.c_int32),
-                ("nseg", C.c_int32), ("pre_act", C.c_int32), ("reserved", C.c_int32), ("seg", View * MAX_SEG),
+                ("nseg", C.c_int32), ("pre_act", C.c_int32), ("tile_h", C.c_int32), ("seg", View * MAX_SEG),
                 ("w_a", C.c_void_p), ("bias_a", C.c_void_p), ("w_b", C.c_void_p), ("bias_b", C.c_void_p),
                 ("mid", View), ("mid_aux", View), ("out", View), ("aux", View), ("res1", View)]
 

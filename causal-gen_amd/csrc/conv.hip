@@ -1205,7 +1205,7 @@ struct Wg2P {
   unsigned long long* stamps;  // optional (CGEN_WG2_STAMPS): per-phase cycle stamps of workgroup 0
   PixTile xt, gt;
   FastDiv d_tx, d_ty;
-  int variant, pad1;  // ncf * 2 + (KS == 3): which body the all-variant kernel runs for this problem
+  int variant, dbuf;  // ncf * 2 + (KS == 3): which body the all-variant kernel runs for this problem; dbuf: two tile buffers (the next tile's DMA flies under this tile's MFMAs)
 };
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -1233,8 +1233,8 @@ __device__ __forceinline__ void wgrad_tile_body(const Wg2P& p, const int bid_x, 
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Xb = smem;
-  char* Gb = smem + p.xt.bytes;
+  const int bufbytes = p.xt.bytes + p.gt.bytes;  // one tile buffer: activation halo tile, then the gradient tile
+  const bool dbuf = p.dbuf != 0;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int sp = bid_x;
@@ -1292,7 +1292,7 @@ __device__ __forceinline__ void wgrad_tile_body(const Wg2P& p, const int bid_x, 
     LG.xl = gl; LG.lane = g_lane; LG.data = g_data;
     LG.sh = (int)p.gout.sh; LG.swp = (int)(p.gout.sw * p.gt.ppp);
   }
-  auto issue_tile = [&](int t) {
+  auto issue_tile = [&](int t, char* Xb, char* Gb) {
     const int b1 = fdiv(t, p.d_tx), tx = t - b1 * p.tiles_x;
     const int n = fdiv(b1, p.d_ty), ty = b1 - n * p.tiles_y;
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
@@ -1306,7 +1306,7 @@ __device__ __forceinline__ void wgrad_tile_body(const Wg2P& p, const int bid_x, 
     dma_tile<T>(p.gt, LG, vptr32<T>(p.gout, n, y0, x0) + g_off, Gb, wave, 0, min(TILE_H, p.H - y0), 0, min(TILE_W, p.W - x0));
   };
   // in-place activation of the staged halo tile: every lane re-visits the groups it DMA'd (same piece mapping)
-  auto act_pass = [&]() {
+  auto act_pass = [&](char* Xb) {
     if (!x_data) return;
     for (int pi = wave; pi < xpieces; pi += 4) {
       uint4* ptr = (uint4*)(Xb + pi * 1024 + lane * 16);
@@ -1350,14 +1350,18 @@ __device__ __forceinline__ void wgrad_tile_body(const Wg2P& p, const int bid_x, 
 #define WG2_STAMP() do { if (stamp && nst < 60) p.stamps[nst++] = __builtin_readcyclecounter(); } while (0)
   if (stamp) p.stamps[nst++] = t_entry;
   WG2_STAMP();
-  for (int t = t_begin; t < t_end; ++t) {
-    if (!(p.dbg & 1)) issue_tile(t);
+  // One tile: activation pass + MFMAs on the buffer `cur` while (double-buffered problems) the DMA of tile t + 1 fills `nxt`.
+  // Two things keep that DMA in flight: (1) `cur` / `nxt` are __restrict__ -- hipcc tracks an LDS-DMA as a pending LDS write
+  // and, without alias information, puts s_waitcnt vmcnt(0) in front of the next LDS read; (2) the barrier between the
+  // activation pass and the MFMAs is a bare lgkmcnt(0) + s_barrier: __syncthreads() drains vmcnt as well.
+  auto tile_step = [&](char* __restrict__ cur, char* __restrict__ nxt, const int t) {
+    if (dbuf && t + 1 < t_end && !(p.dbg & 1)) issue_tile(t + 1, nxt, nxt + p.xt.bytes);
     WG2_STAMP();
-    __syncthreads();  // hipcc waits vmcnt(0) here: the tile has landed
-    WG2_STAMP();
+    char* Xb = cur;
+    char* Gb = cur + p.xt.bytes;
     if (p.act != CGEN_ACT_NONE && !(p.dbg & 2)) {
-      act_pass();
-      __syncthreads();
+      act_pass(Xb);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     WG2_STAMP();
     if (!(p.dbg & 4)) {
@@ -1401,9 +1405,21 @@ __device__ __forceinline__ void wgrad_tile_body(const Wg2P& p, const int bid_x, 
       }
     }
     WG2_STAMP();
-    __syncthreads();  // everyone is done with the buffers before the next tile's DMA overwrites them
+  };
+  if (!(p.dbg & 1) && t_begin < t_end) issue_tile(t_begin, smem, smem + p.xt.bytes);
+  int cur = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();  // hipcc waits vmcnt(0) here: tile t has landed; and every wave is done reading the other buffer
     WG2_STAMP();
+    tile_step(smem + cur * bufbytes, smem + (cur ^ 1) * bufbytes, t);
+    if (dbuf) {
+      cur ^= 1;
+    } else if (t + 1 < t_end) {  // single buffer (the tile pair is too big for two): fetch the next tile once this one is consumed
+      __syncthreads();
+      if (!(p.dbg & 1)) issue_tile(t + 1, smem, smem + p.xt.bytes);
+    }
   }
+  __syncthreads();  // (the batched kernels start the next problem's DMA right away)
 
   // ---- write the partial slab straight from the accumulators.  Lane (g, t16) of fragment (a, j) holds
   // D[co = a*16 + 4g + e][ci = cb_j + t16]: 16 consecutive input channels = one 64-byte run per (co, tap).  Everything
@@ -1498,7 +1514,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_mega_kernel(const Wg2P* __r
   }
 }
 
-struct Wg2Geom { int ncf, njw, cwin, nsplit, tps, ntiles, tiles_x, tiles_y, n_cwin, n_co; PixTile xt, gt; size_t lds; };
+struct Wg2Geom { int ncf, njw, cwin, nsplit, tps, ntiles, tiles_x, tiles_y, n_cwin, n_co, dbuf; PixTile xt, gt; size_t lds; };
 
 // returns false when the shape is not served by the tiled kernel
 static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2Geom& g) {
@@ -1522,6 +1538,11 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
   }
   if (g.gt.ppp < 1) return false;
   g.lds = (size_t)g.xt.bytes + g.gt.bytes;
+  // two tile buffers where they fit next to a second workgroup on the CU: the next tile's DMA runs under this tile's MFMAs
+  // (ablation on ukbb192: DMA-only 2.1 ms, MFMA-only ~1.6 ms, both 4.6 ms with one buffer -- the two phases did not overlap)
+  static const int dbuf_on = [] { const char* e = getenv("CGEN_WG2_DBUF"); return e ? atoi(e) : 1; }();
+  g.dbuf = (dbuf_on && 2 * g.lds <= 78 * 1024) ? 1 : 0;
+  if (g.dbuf) g.lds *= 2;
   g.cwin = cwin;
   g.n_cwin = ceil_div(ctot8, cwin);
   g.tiles_x = ceil_div(W, TILE_W); g.tiles_y = ceil_div(H, TILE_H);
@@ -2374,6 +2395,7 @@ static int blk_fill(const cgen_block_args* a, BlkP& p) {
   if (!a || a->dtype != CGEN_BF16 || a->nseg < 1 || a->nseg > 3 || a->n <= 0 || a->h <= 0 || a->w <= 0) return 0;
   memset(&p, 0, sizeof(p));
   p.N = a->n; p.H = a->h; p.W = a->w; p.mode = a->mode; p.nseg = a->nseg; p.pre_act = a->pre_act;
+  p.TH = a->tile_h ? a->tile_h : 8;
   int koff = 0;
   for (int s = 0; s < a->nseg; ++s) {
     if (!a->seg[s].p || a->seg[s].c <= 0 || !dma_clean(a->seg[s], 2)) return 0;
@@ -2519,6 +2541,7 @@ static bool build_wg2(const cgen_wgrad_args* a, Wg2P& q, Wg2Geom& g) {
   q.cwin = g.cwin; q.cog = g.ncf * 16; q.xt = g.xt; q.gt = g.gt;
   q.d_tx = mk_fastdiv(g.tiles_x); q.d_ty = mk_fastdiv(g.tiles_y);
   q.variant = g.ncf * 2 + (a->ks == 3 ? 1 : 0);
+  q.dbuf = g.dbuf;
   { const char* e = getenv("CGEN_WG2_DBG"); q.dbg = e ? atoi(e) : 0; }
   return true;
 }
@@ -2552,6 +2575,10 @@ extern "C" int cgen_conv2d_wgrad_batch_plan(const cgen_wgrad_args* args, int32_t
     // one launch per (variant, kernel size, LDS class): a big-LDS problem must not lower everyone's occupancy
     it.key = (it.g.ncf * 4 + (args[i].ks == 3 ? 1 : 0)) * 2 + (it.g.lds > 40 * 1024 ? 1 : 0);
     it.cost = (long)it.g.nsplit * it.g.n_cwin * it.g.n_co * it.g.tps;
+    if (blob_host && getenv("CGEN_WG2_PLAN_DEBUG"))
+      fprintf(stderr, "wg2 plan: %dx%dx%d ks%d ctot8 %3d co %3d | ncf %d cwin %3d n_cwin %d n_co %d | tiles %5d tps %3d nsplit %3d | lds %6zu dbuf %d | tile-visits %ld\n",
+              args[i].n, args[i].h, args[i].w, args[i].ks, it.q.ctot8, it.q.Co, it.g.ncf, it.g.cwin, it.g.n_cwin, it.g.n_co, it.g.ntiles, it.g.tps,
+              it.g.nsplit, it.g.lds, it.g.dbuf, (long)it.g.ntiles * it.g.n_cwin * it.g.n_co);
     items.push_back(it);
   }
   static const bool mega = [] { const char* e = getenv("CGEN_WGRAD_MEGA"); return !e || atoi(e) != 0; }();

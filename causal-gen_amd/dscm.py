@@ -15,6 +15,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib
+from .engine import StaticParents, compact_parents
 
 _UKBB_MIN_MAX = {"age": (73.0, 44.0), "brain_volume": (1629520.0, 841919.0), "ventricle_volume": (157075.0, 7613.27001953125)}
 _UKBB_LOG_STATS = {"age": (4.112339973449707, 0.11769197136163712), "brain_volume": (13.965583801269531, 0.09537758678197861),
@@ -36,12 +37,13 @@ def ukbb_preprocess(pa: Dict[str, Tensor]) -> Dict[str, Tensor]:
 
 
 def vae_preprocess(args, pa: Dict[str, Tensor]) -> Tensor:
-    """Concatenate parents in ``args.parents_x`` order and expand to [B,ctx,R,R] on the GPU (dscm.py:121-132)."""
+    """Concatenate parents in ``args.parents_x`` order and expand to [B,ctx,R,R] on the GPU (dscm.py:121-132).  The
+    expansion is a stride-0 view: the HVAE lays out [B,1,1,ctx] only (engine.from_parents)."""
     if "ukbb" in getattr(args, "dataset", ""):
         pa = ukbb_preprocess(pa)
     cols = [pa[k] if pa[k].dim() > 1 else pa[k][..., None] for k in args.parents_x]
     flat = torch.cat(cols, dim=1).float().cuda()
-    return flat[..., None, None].expand(-1, -1, args.input_res, args.input_res).contiguous()
+    return flat[..., None, None].expand(-1, -1, args.input_res, args.input_res)
 
 
 def cf_pixels(x, rec_loc, rec_scale, cf_loc, cf_scale, sum_x=None, sum_x2=None):
@@ -100,15 +102,16 @@ class GraphedCounterfactual:
     @torch.no_grad()
     def __call__(self, x, parents, cf_parents):
         vae = self.vae
-        key = (tuple(x.shape), x.dtype, tuple(parents.shape), tuple(cf_parents.shape))
+        key = (tuple(x.shape), x.dtype, tuple(parents.shape), tuple(cf_parents.shape), compact_parents(parents) is not None,
+               compact_parents(cf_parents) is not None)
         ent = self.graphs.get(key)
         if ent is None:
             out = counterfactual(vae, x, parents, cf_parents, **self.kw)  # eager warm-up: sizes the arena, builds tables
-            sx, sp, sc = x.clone(), parents.clone(), cf_parents.clone()
+            sx, sp, sc = x.clone(), StaticParents(parents), StaticParents(cf_parents)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                so = counterfactual(vae, sx, sp, sc, **self.kw)
+                so = counterfactual(vae, sx, sp.t, sc.t, **self.kw)
             self.graphs[key] = (g, sx, sp, sc, so)
             return out
         g, sx, sp, sc, so = ent
@@ -116,8 +119,8 @@ class GraphedCounterfactual:
         eng.stream = torch.cuda.current_stream(eng.device).cuda_stream
         eng.prepare_weights()  # no-op unless a parameter changed since the images were last written
         sx.copy_(x, non_blocking=True)
-        sp.copy_(parents, non_blocking=True)
-        sc.copy_(cf_parents, non_blocking=True)
+        sp.load(parents)
+        sc.load(cf_parents)
         g.replay()
         return so
 

@@ -25,9 +25,42 @@ def _ceil(a, m):
     return (a + m - 1) // m * m
 
 
+def compact_parents(t):
+    """[B,ctx] view of a spatially constant parents tensor given as [B,ctx], [B,ctx,1,1] or an expand()-ed [B,ctx,R,R]
+    (strides 0 over H and W); None for a materialised [B,ctx,R,R] (which may vary over space)."""
+    if t.dim() == 2:
+        return t
+    if t.dim() == 4 and ((t.shape[2] == 1 and t.shape[3] == 1) or (t.stride(2) == 0 and t.stride(3) == 0)):
+        return t[:, :, 0, 0]
+    return None
+
+
+def expand_parents(t, h, w=None):
+    """[B,ctx] -> the reference's [B,ctx,H,W] shape as a stride-0 view (no copy)."""
+    return t[:, :, None, None].expand(-1, -1, h, h if w is None else w)
+
+
+class StaticParents:
+    """Stable-address copy of a parents tensor for a captured graph, keeping the stride-0 (virtual) form when it has one."""
+
+    def __init__(self, pa):
+        c = compact_parents(pa)
+        self.virtual = c is not None
+        if self.virtual:
+            self.buf = c.clone()
+            self.t = self.buf if pa.dim() == 2 else self.buf[:, :, None, None].expand(*pa.shape)
+        else:
+            self.buf = self.t = pa.clone()
+
+    def load(self, pa):
+        src = compact_parents(pa) if self.virtual else pa
+        assert src is not None and src.shape == self.buf.shape, "parents changed form (materialised <-> broadcast) between calls"
+        self.buf.copy_(src, non_blocking=True)
+
+
 class NT:
     """NHWC strided view (channel stride 1) -- the Python twin of cgen_view."""
-    __slots__ = ("ptr", "n", "h", "w", "c", "sn", "sh", "sw", "base", "coff", "rg", "keep", "_cv", "es", "cpad")
+    __slots__ = ("ptr", "n", "h", "w", "c", "sn", "sh", "sw", "base", "coff", "rg", "keep", "_cv", "es", "cpad", "bsrc")
 
     def __init__(self, ptr, n, h, w, c, sn, sh, sw, es, base=None, coff=0, rg=True, keep=None):
         self.ptr, self.n, self.h, self.w, self.c = ptr, n, h, w, c
@@ -35,6 +68,18 @@ class NT:
         self.base = base if base is not None else self
         self.coff, self.rg, self.keep, self._cv = coff, rg, keep, None
         self.cpad = 0  # channels [c, cpad) are guaranteed zero (see cgen_view.cpad)
+        self.bsrc = None  # the [n,1,1,c] tensor this one broadcasts over H x W (row / pixel strides 0), else None
+
+    def broadcast(self, h, w):
+        """A [n,1,1,c] tensor seen as [n,h,w,c] with row and pixel stride 0: spatially constant parents without the
+        [B,ctx,R,R] buffer (SURVEY 8f row 2 -- every conv kernel takes arbitrary strides, and a tile's DMA of such a segment
+        re-reads one 16-byte group per sample from cache instead of streaming H*W copies of it from HBM)."""
+        assert self.h == 1 and self.w == 1 and not self.rg
+        if h == 1 and w == 1:
+            return self
+        v = NT(self.ptr, self.n, h, w, self.c, self.sn, 0, 0, self.es, base=None, coff=0, rg=False, keep=self.keep)
+        v.cpad, v.bsrc = self.cpad, self
+        return v
 
     def cv(self):
         if self._cv is None:
@@ -54,6 +99,8 @@ class NT:
         if r == self.h and r == self.w:
             return self
         assert not self.rg
+        if self.bsrc is not None:
+            return self.bsrc.broadcast(r, r)
         v = NT(self.ptr, self.n, r, r, self.c, self.sn, self.sh, self.sw, self.es, base=None, coff=0, rg=False, keep=self.keep)
         v.cpad = self.cpad
         return v
@@ -177,6 +224,7 @@ class Engine:
         # replaces on MI355X (DESIGN.md section 3.6 has the per-phase cycle stamps and what bounds it)
         self.blk_fuse = int(os.environ.get("CGEN_BLK_FUSE", "0"))
         self.blk_minres = int(os.environ.get("CGEN_BLK_MINRES", "24"))
+        self.blk_th4_maxres = int(os.environ.get("CGEN_BLK_TH4_MAXRES", "0"))  # images up to this size use 4-row tiles (experiment: slower)
         # data parallelism: once this fraction of the pass's weight-gradient work has been issued (and the background flush is
         # out), `on_split` is called with the side stream joined -- the gradients of every conv reduced so far are FINAL
         # (`early_final`), so their all-reduce can travel under the rest of the backward pass (train.TrainStep)
@@ -242,6 +290,21 @@ class Engine:
                               self.stream)
         self.launches += 1
         return out
+
+    def from_parents(self, t, h=None, w=None):
+        """Parents -> engine tensor.  The reference hands the HVAE ``pa[..., None, None].repeat(1, 1, R, R)``
+        (trainer.py:16-21, dscm.py:125-131): spatially constant.  When the caller passes that tensor WITHOUT materialising
+        it -- an ``expand``-ed view (strides 0 over H and W), or [B,ctx] / [B,ctx,1,1] with the target size -- only the
+        [B,1,1,ctx] vector is laid out and every consumer sees a stride-0 broadcast of it.  Any other 4-D tensor takes the
+        general path (arbitrary spatially varying parents stay supported)."""
+        c = compact_parents(t)
+        if c is None:
+            return self.from_nchw(t.to(self.device, torch.float32))
+        if t.dim() == 4 and t.shape[2] > 1:
+            h, w = int(t.shape[2]), int(t.shape[3])
+        assert h is not None and w is not None
+        small = self.from_nchw(c.to(self.device, torch.float32).contiguous()[:, :, None, None])
+        return small.broadcast(h, w)
 
     def to_nchw(self, x):
         """engine NHWC tensor -> fresh torch f32 NCHW tensor."""
@@ -427,6 +490,7 @@ class Engine:
                 and min(x0.h, x0.w) >= self.blk_minres):
             a = _lib.BlockArgs()
             a.dtype, a.n, a.h, a.w, a.mode, a.nseg, a.pre_act = self.dt, x0.n, x0.h, x0.w, 0, len(segs), 1
+            a.tile_h = 4 if max(x0.h, x0.w) <= self.blk_th4_maxres else 8
             for k, sg in enumerate(segs):
                 a.seg[k] = sg.cv()
             a.w_a, a.w_b = site1.img_fwd, site2.img_fwd
@@ -541,6 +605,8 @@ class Engine:
 
     def scale_channels(self, x, c_from, factor):
         """out = x with channels >= c_from multiplied by factor (pa_sto, vae.py:244-247)."""
+        if x.bsrc is not None:  # spatially constant: scale the [n,1,1,c] source, broadcast again
+            return self.scale_channels(x.bsrc, c_from, factor).broadcast(x.h, x.w)
         out = self.new(x.n, x.h, x.w, x.c, rg=False)
         src, dst = x, out
         if x.cpad:  # carry the zero padding along
@@ -938,6 +1004,7 @@ class Engine:
         if fused:
             a = _lib.BlockArgs()
             a.dtype, a.n, a.h, a.w, a.mode, a.nseg, a.pre_act = self.dt, s0.n, s0.h, s0.w, 1, 1, 0
+            a.tile_h = 4 if max(s0.h, s0.w) <= self.blk_th4_maxres else 8
             a.seg[0] = g.cv()
             a.w_a, a.w_b, a.bias_a, a.bias_b = site2.img_dg[0], site1.img_dg[0], None, None
             a.mid = View(t.ptr, t.sn, t.sh, t.sw, t.c, 0)      # shape stand-ins for the query; the real views are set below

@@ -17,12 +17,15 @@ import ctypes as C
 import torch
 
 from . import _lib, dp
+from .engine import StaticParents, compact_parents
 
 
 def preprocess_batch(args, batch, expand_pa=False):
     """trainer.py:16-21 on the device: u8 pixels -> [-1, 1] f32 (one HIP launch, no ATen arithmetic), parents to f32 and,
-    for the HVAE's parent concatenation, broadcast to [B, ctx, R, R].  ``HVAE.forward`` also accepts the raw u8 batch
-    directly and fuses the normalisation into its NCHW -> NHWC load, which skips this pass altogether."""
+    for the HVAE's parent concatenation, broadcast to [B, ctx, R, R] -- as a stride-0 ``expand`` view, not a ``repeat``: same
+    shape and values for every consumer, and the HVAE then lays out only the [B,1,1,ctx] vector (engine.from_parents).
+    ``HVAE.forward`` also accepts the raw u8 batch directly and fuses the normalisation into its NCHW -> NHWC load, which
+    skips this pass altogether."""
     lib = _lib.require_gpu()
     dev = torch.device(getattr(args, "device", "cuda"))
     x = batch["x"].to(dev)
@@ -38,7 +41,7 @@ def preprocess_batch(args, batch, expand_pa=False):
     batch["x"] = x
     batch["pa"] = batch["pa"].to(dev).float()
     if expand_pa:
-        batch["pa"] = batch["pa"][..., None, None].repeat(1, 1, *(args.input_res,) * 2)
+        batch["pa"] = batch["pa"][..., None, None].expand(-1, -1, *(args.input_res,) * 2)
     return batch
 
 
@@ -329,12 +332,14 @@ class TrainStep:
         if m.cond_prior:  # host draw (shared across DP ranks through the common seed), one graph per outcome
             drop = type(m.decoder).drop_cond(m.decoder)
             m.decoder.__dict__["drop_cond"] = lambda d=drop: d
-        key = (tuple(x.shape), x.dtype, drop, do_step)  # (beta is device data: the warm-up schedule replays the same graph)
+        # (beta is device data: the warm-up schedule replays the same graph; virtual and materialised parents are different graphs)
+        key = (tuple(x.shape), x.dtype, drop, do_step, tuple(pa.shape), compact_parents(pa) is not None)
         ent = self.graphs.get(key)
         self._coef_for(x, beta)
         if ent is None:
             out = self._eager(x, pa, beta, do_step)  # eager warm-up: sizes the arena, builds the tables
-            sx, sp = x.clone(), pa.clone()
+            sx, spb = x.clone(), StaticParents(pa)
+            sp = spb.t
             torch.cuda.synchronize()
             # NCCL inside a captured graph is avoided: under DP the step is graphs around eager all-reduces.  With overlap the
             # backward graph is cut where the decoder half of the gradient is final (engine.on_split): graph A | all-reduce of
@@ -375,12 +380,12 @@ class TrainStep:
                 with torch.cuda.graph(g2):
                     self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
                     self._optim(so)
-            self.graphs[key] = (g1, g2, sx, sp, so, g1b)
+            self.graphs[key] = (g1, g2, sx, spb, so, g1b)
             return out
-        g1, g2, sx, sp, so, g1b = ent
+        g1, g2, sx, spb, so, g1b = ent
         if sx.data_ptr() != x.data_ptr():
             sx.copy_(x, non_blocking=True)
-            sp.copy_(pa, non_blocking=True)
+            spb.load(pa)
         g1.replay()
         if g1b is not None:
             works = self._early_launch()

@@ -522,14 +522,21 @@ class HVAE(nn.Module):
             return buf
         return eng.conv(self._site(eng, lk.conv), [h], ACT_NONE)
 
+    def _pa_nt(self, eng, parents):
+        """Parents as an engine tensor: a stride-0 broadcast of [B,1,1,ctx] when the caller did not materialise the
+        spatial expansion (engine.from_parents), the general [B,R,R,ctx] layout otherwise."""
+        assert parents.shape[1] == self.context_dim
+        R = max(b.res for b in self.decoder.blocks)  # (only used for [B,ctx] / [B,ctx,1,1] input; crop() sizes each use)
+        return eng.from_parents(parents, R, R)
+
     def _prep_inputs(self, eng, x, parents):
-        assert x.dim() == 4 and parents.dim() == 4 and parents.shape[1] == self.context_dim
+        assert x.dim() == 4 and parents.dim() in (2, 4) and parents.shape[1] == self.context_dim
         xin = None
         if x is not None:
             x = x.to(eng.device)
             # raw u8 pixels: trainer.py:17's (x - 127.5) / 127.5 is fused into the layout kernel (SURVEY 8f row 2)
             xin = eng.from_nchw(x, rg=False, sub=127.5, mul=1.0 / 127.5) if x.dtype == torch.uint8 else eng.from_nchw(x, rg=False)
-        pa = eng.from_nchw(parents.to(eng.device, torch.float32), rg=False)
+        pa = self._pa_nt(eng, parents)
         return xin, pa
 
     # ------------------------------------------------------------------ training forward / backward
@@ -631,7 +638,7 @@ class HVAE(nn.Module):
         sx2 = torch.zeros_like(x_nchw) if P > 1 else None
         passes, cf_x = [], None
         for cfp_t in cf_parents_list:
-            cfp = eng.from_nchw(cfp_t.to(eng.device, torch.float32))
+            cfp = self._pa_nt(eng, cfp_t)
             eng.kl_coef_override = eng._zero4.data_ptr()
             acts = self._encode(eng, xin)
             h_ab, qs = self._decode(eng, pa, acts=acts, t=t_abduct, collect="q" if self.cond_prior else "z")
@@ -782,7 +789,7 @@ class HVAE(nn.Module):
     def sample(self, parents: Tensor, return_loc: bool = True, t: Optional[float] = None):
         """vae.py:460-464."""
         eng = self._begin_inference()
-        pa = eng.from_nchw(parents.to(eng.device, torch.float32))
+        pa = self._pa_nt(eng, parents)
         h, _ = self._decode(eng, pa, t=t)
         return self._sample_likelihood(eng, h, return_loc, t)
 
@@ -823,7 +830,7 @@ class HVAE(nn.Module):
                 out.append(d)
             return (out, self._sample_likelihood(eng, h, True, None)) if with_rec else out
         assert not with_rec
-        cfp = eng.from_nchw(cf_parents.to(eng.device, torch.float32))
+        cfp = self._pa_nt(eng, cf_parents)
         _, ps = self._decode(eng, cfp, t=t, collect="p")
         assert len(ps) == len(qs)
         outs = []
@@ -857,8 +864,8 @@ class HVAE(nn.Module):
         share nothing but read-only inputs.  Returns ((loc_a, scale_a), (loc_b, scale_b)) == (forward_latents(l, a),
         forward_latents(l, b))."""
         eng = self._begin_inference()
-        pa_a = eng.from_nchw(parents_a.to(eng.device, torch.float32))
-        pa_b = eng.from_nchw(parents_b.to(eng.device, torch.float32))
+        pa_a = self._pa_nt(eng, parents_a)
+        pa_b = self._pa_nt(eng, parents_b)
         lat = self._latents_in(eng, latents)
 
         def replay(pa):
@@ -891,6 +898,6 @@ class HVAE(nn.Module):
     def forward_latents(self, latents: List[Tensor], parents: Tensor, t: Optional[float] = None):
         """vae.py:516-522: replay (possibly partial) latents under `parents`; returns (loc in [-1,1], scale)."""
         eng = self._begin_inference()
-        pa = eng.from_nchw(parents.to(eng.device, torch.float32))
+        pa = self._pa_nt(eng, parents)
         h, _ = self._decode(eng, pa, latents=self._latents_in(eng, latents), t=t)
         return self._sample_likelihood(eng, h, True, t)

@@ -80,7 +80,7 @@ int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream);
  * Served shapes: sum_s ceil8(seg[s].c) a multiple of 32 (<= 160), mid.c in {8,16,24,32}, out.c a multiple of 8;
  * cgen_block2_supported() answers without launching (1 = served). */
 typedef struct cgen_block_args {
-  int32_t dtype, n, h, w, mode, nseg, pre_act, reserved;
+  int32_t dtype, n, h, w, mode, nseg, pre_act, tile_h; /* tile_h: output rows per tile, 8 (0 = 8) or 4 */
   cgen_view seg[CGEN_MAX_SEG];
   const void* w_a;
   const float* bias_a;

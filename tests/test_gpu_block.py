@@ -25,7 +25,7 @@ CASES = [
 ]
 
 
-def _run(case, fuse, seed=0):
+def _run(case, fuse, seed=0, th=8):
     from causal_gen_amd.engine import ConvSite, Engine
 
     N, H, W, segc, b, co, with_res = case
@@ -43,6 +43,7 @@ def _run(case, fuse, seed=0):
     gout = torch.randn(N, co, H, W, generator=g).bfloat16().float()
     eng = Engine("cuda", "bf16")
     eng.blk_fuse, eng.blk_minres = fuse, 8
+    eng.blk_th4_maxres = 1 << 20 if th == 4 else 0   # tile height of the fused kernel: 4 rows or 8
     holder = torch.nn.ModuleList([c1, c2]).cuda()
     s1 = ConvSite("c1", holder[0], segc, [True] * len(segc), 0)
     s2 = ConvSite("c2", holder[1], [b], [True], 1)
@@ -68,11 +69,14 @@ def _run(case, fuse, seed=0):
     return dict(y=y_t, gx=gxs, pg=pg, fwd_launches=fwd_launches, xs=xs, res=res, gout=gout, convs=(c1, c2))
 
 
+@pytest.mark.parametrize("th", [8, 4])
 @pytest.mark.parametrize("case", CASES, ids=[f"{c[3]}x{c[4]}x{c[5]}@{c[1]}x{c[2]}" for c in CASES])
-def test_fused_block_matches_two_launch_path_and_torch(case):
+def test_fused_block_matches_two_launch_path_and_torch(case, th):
     N, H, W, segc, b, co, with_res = case
     two = _run(case, 0)
-    one = _run(case, 2)
+    one = _run(case, 2, th=th)
+    if th == 4 and one["fwd_launches"] == 2:
+        pytest.skip("no 4-row instance for this shape (the engine falls back to the two launches)")
     assert two["fwd_launches"] == 2 and one["fwd_launches"] == 1, (two["fwd_launches"], one["fwd_launches"])
     # ---- (a) against the two-launch path: a handful of bf16 flips at most
     scale = float(two["y"].abs().max())

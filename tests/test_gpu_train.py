@@ -614,3 +614,48 @@ def test_shared_covariance_bias_gets_its_gradient():
     gb, rb = m.likelihood.x_logscale.bias.grad, sd["likelihood.x_logscale.bias"].grad
     assert gb is not None and float((gb.cpu() - rb).abs().max()) < 2e-3 * float(rb.abs().max())
     assert m.likelihood.x_logscale.weight.grad is None
+
+
+def test_virtual_parents_equal_materialised():
+    """parents handed over as the stride-0 expand() view (or [B,ctx]) are laid out as [B,1,1,ctx] and
+    broadcast by stride; ELBO, gradients and decoded means must be BIT-identical to the materialised [B,ctx,R,R] tensor
+    (same kernels, same K order, same values), including the drop_cond scaling of a conditional prior."""
+    from causal_gen_amd import vae
+    from causal_gen_amd.hps import setup_hparams
+
+    for name, B, dt in (("ukbb192", 2, "f32"), ("ukbb192", 2, "bf16"), ("morphomnist", 4, "f32"), ("morphomnist", 4, "bf16")):
+        hp = setup_hparams(name)
+        torch.manual_seed(3)
+        m = vae.HVAE(hp).cuda()
+        m.compute_dtype = dt
+        m.train()
+        if m.cond_prior:
+            m.decoder.__dict__["drop_cond"] = lambda: (0, 1)  # the draw that rescales the parents (vae.py:244-247)
+        g = torch.Generator().manual_seed(5)
+        x = ((torch.randint(0, 256, (B, hp.input_channels, hp.input_res, hp.input_res), generator=g).float() - 127.5) / 127.5).cuda()
+        pc = torch.randn(B, hp.context_dim, generator=g).cuda()
+        R = hp.input_res
+        forms = {"repeat": pc[..., None, None].repeat(1, 1, R, R), "expand": pc[..., None, None].expand(-1, -1, R, R), "flat": pc}
+
+        def eps():
+            ge = torch.Generator().manual_seed(100)
+            return [torch.randn(B, b.z_dim, b.res, b.res, generator=ge) for b in m.decoder.blocks if b.stochastic]
+
+        res = {}
+        for k, pa in forms.items():
+            m.zero_grad(set_to_none=True)
+            m.noise = eps()
+            out = m(x, pa, beta=hp.beta)
+            assert not m.noise
+            out["elbo"].backward()
+            grads = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+            m.noise = eps()
+            with torch.no_grad():
+                zs = m.abduct(x, pa)
+                loc, _ = m.forward_latents(zs, pa)
+            m.noise = None
+            res[k] = (out["elbo"].detach().clone(), grads.clone(), loc.clone())
+        assert float(res["repeat"][1].abs().sum()) > 0
+        for k in ("expand", "flat"):
+            for i, what in enumerate(("elbo", "grads", "decoded mean")):
+                assert torch.equal(res[k][i], res["repeat"][i]), (name, dt, k, what)
