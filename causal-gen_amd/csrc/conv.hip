@@ -1482,8 +1482,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_batched_kernel(const Wg2P* 
   // runs in the background of the backward chain, so that the chain's kernels always find free CUs)
   for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
     const int4 bi = blocks[b];
-    const int prob = __builtin_amdgcn_readfirstlane(bi.x);
-    wgrad_tile_body<NCF, NJW, KS>(probs[prob], __builtin_amdgcn_readfirstlane(bi.y), __builtin_amdgcn_readfirstlane(bi.z),
+    // BY VALUE: through a reference into global memory hipcc must re-read every field after each barrier / store (it cannot
+    // prove the table is not written), and every such s_load waits on lgkmcnt, i.e. on all LDS traffic in flight
+    const Wg2P p = probs[__builtin_amdgcn_readfirstlane(bi.x)];
+    wgrad_tile_body<NCF, NJW, KS>(p, __builtin_amdgcn_readfirstlane(bi.y), __builtin_amdgcn_readfirstlane(bi.z),
                                   __builtin_amdgcn_readfirstlane(bi.w));
     __syncthreads();
   }
@@ -1496,7 +1498,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_batched_kernel(const Wg2P* 
 __global__ __launch_bounds__(256, 2) void wgrad_tile_mega_kernel(const Wg2P* __restrict__ probs, const int4* __restrict__ blocks, const int nblocks) {
   for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
     const int4 bi = blocks[b];
-    const Wg2P& p = probs[__builtin_amdgcn_readfirstlane(bi.x)];
+    const Wg2P p = probs[__builtin_amdgcn_readfirstlane(bi.x)];  // by value (see the batched kernel)
     const int bx = __builtin_amdgcn_readfirstlane(bi.y), by = __builtin_amdgcn_readfirstlane(bi.z), bz = __builtin_amdgcn_readfirstlane(bi.w);
     switch (p.variant) {
       case 2: wgrad_tile_body<1, 16, 1>(p, bx, by, bz); break;
