@@ -58,6 +58,17 @@ class StaticParents:
         self.buf.copy_(src, non_blocking=True)
 
 
+class _Tape(list):
+    """The reverse tape: (backward fn, args, recorded on the side stream?).  The tag lets backward() run the z strand of the
+    decoder (prior Blocks, z_feat_proj, the upsampling of z) on the side stream again, next to the h strand."""
+    __slots__ = ("eng",)
+
+    def append(self, item):
+        if len(item) == 2:
+            item = (item[0], item[1], self.eng._in_side)
+        list.append(self, item)
+
+
 class NT:
     """NHWC strided view (channel stride 1) -- the Python twin of cgen_view."""
     __slots__ = ("ptr", "n", "h", "w", "c", "sn", "sh", "sw", "base", "coff", "rg", "keep", "_cv", "es", "cpad", "bsrc")
@@ -178,7 +189,13 @@ class Engine:
         self.es = 4 if self.dt == F32 else 2
         self.tdtype = torch.float32 if self.dt == F32 else torch.bfloat16
         self.arena = Arena(self.device)
-        self.tape, self.recording = [], False
+        self.tape, self.recording = _Tape(), False
+        self.tape.eng = self
+        # backward with the decoder's z strand on the side stream (mirror of the forward pipeline).  Correct (same parameters
+        # bit for bit), but MEASURED SLOWER on MI355X: 18.15 vs 17.25 ms/step -- three cross-stream edges per layer inside the
+        # hipGraph cost more than the three launches they take off the critical path.  Off by default.
+        self.bwd_branch = os.environ.get("CGEN_BWD_BRANCH", "0") != "0"
+        self._bw_strand = None  # None: single-stream backward; 0 / 1: strand of the tape entry being run
         self.grads = {}
         self.sites, self.site_by_id = [], {}
         self.stream = 0
@@ -187,6 +204,7 @@ class Engine:
         self._wg_events = []
         self._wg_reduced, self._wg_seen = 0, set()
         self._in_side = False
+        self._wg_marks_deferred = self._wg_marks_pending = False
         self._rng_override = None
         self._dbg_names = {} if os.environ.get("CGEN_DEBUG_NAMES") else None  # id(tensor) -> producing conv (tools/ab_grads.py)
         self._riders = {}
@@ -476,7 +494,7 @@ class Engine:
         if self.recording:
             if self._dbg_names is not None:
                 self._dbg_names[id(out.base)] = site.name
-            (self.tape if tape_hold is None else tape_hold).append((self._bw_conv, (site, segs, act, out, res1, res2)))
+            (self.tape if tape_hold is None else tape_hold).append((self._bw_conv, (site, segs, act, out, res1, res2), self._in_side))
         return out
 
     def block2(self, site1, site2, segs, act, res1=None):
@@ -830,6 +848,8 @@ class Engine:
         job = self._riders.pop(id(base), None)
         if job is not None:
             gv, g, acc = job
+            self._bw_touch(gv, True)
+            self._bw_touch(g, False)
             self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
             self.launches += 1
 
@@ -841,9 +861,11 @@ class Engine:
         g, ivs, base = self._gentry(t.base)
         a, b = t.coff, t.coff + t.c
         miss = self._missing(ivs, a, b)
+        self._bw_touch(g, True)
         if miss != [(a, b)] and not defer_hazard and self._frozen(t):
             self._cow(t)
             g = self.grads[id(t.base)][0]
+            self._bw_touch(g, True)
         gv = g.chan(a, b)
         if not miss:
             return gv, True
@@ -867,6 +889,7 @@ class Engine:
         miss = self._missing(ivs, a, b)
         if miss == [(a, b)]:
             return None
+        self._bw_touch(g, bool(miss))
         for (s, e2) in miss:
             self.fill(g.chan(s, e2), 0.0)
             ivs.append((s, e2))
@@ -931,12 +954,72 @@ class Engine:
         return gv
 
     # ------------------------------------------------------------------ backward
+    def _bw_touch(self, g, write):
+        """Two-strand backward: the tape entry being run (strand self._bw_strand) is about to read / write the gradient
+        buffer behind `g`.  Make its stream wait for the other strand's last conflicting access (read-after-write,
+        write-after-write, write-after-read -- adopted buffers are accumulated in place), and note the access: the entry's
+        end-of-entry event becomes the buffer's last read / write of this strand."""
+        me = self._bw_strand
+        if me is None:
+            return
+        key = g if isinstance(g, int) else g.base.ptr
+        st = self._bw_state.get(key)
+        if st is None:
+            st = self._bw_state[key] = [None, None, None]  # [last write (strand, event), last read event of strand 0, of strand 1]
+        lw = st[0]
+        mine = self._bw_streams[me]
+        if lw is not None and lw[0] != me and lw[1] is not None:
+            mine.wait_event(lw[1])
+        if write and st[2 - me] is not None:
+            mine.wait_event(st[2 - me])
+        (self._bw_wr if write else self._bw_rd).add(key)
+
     def backward(self):
         if self.wgrad_flush_frac:  # total weight-gradient work of this pass: the background-flush marks are fractions of it
             self._wg_total = sum(2.0 * a[0].ci * a[0].taps * a[0].co * a[1][0].n * a[1][0].h * a[1][0].w
-                                 for fn, a in self.tape if fn == self._bw_conv and self._needs_wgrad(a[0]))
-        for fn, args in reversed(self.tape):
-            fn(*args)
+                                 for fn, a, _ in self.tape if fn == self._bw_conv and self._needs_wgrad(a[0]))
+        main_t = torch.cuda.current_stream(self.device)
+        two = (self.bwd_branch and self.prof is None and self._fwd_side is not None and self.stream == main_t.cuda_stream
+               and any(e[2] for e in self.tape))
+        if not two:
+            for fn, args, _ in reversed(self.tape):
+                fn(*args)
+        else:
+            # Two strands, as in the forward pass: entries recorded on the side stream (the decoder's z strand: prior Blocks,
+            # z_feat_proj, the upsampling of z) run there again, everything else on the main stream.  Ordering between the
+            # strands is per gradient BUFFER (_bw_touch); weight-gradient flush marks are honoured between entries, with the
+            # strands joined (the flush forks from the main stream).
+            side_t = self._fwd_side
+            side_t.wait_stream(main_t)
+            self._bw_streams, self._bw_state = (main_t, side_t), {}
+            handles = (self.stream, side_t.cuda_stream)
+            self._wg_marks_deferred = True
+            try:
+                for fn, args, side in reversed(self.tape):
+                    me = 1 if side else 0
+                    self._bw_strand, self._bw_wr, self._bw_rd = me, set(), set()
+                    self.stream = handles[me]
+                    fn(*args)
+                    self.stream = handles[0]
+                    if self._bw_wr or self._bw_rd:
+                        ev = torch.cuda.Event()
+                        ev.record(self._bw_streams[me])
+                        for k in self._bw_wr:
+                            st = self._bw_state[k]
+                            st[0] = (me, ev)
+                            st[1 + me] = ev  # (a write is also an access the other strand's writers must respect)
+                        for k in self._bw_rd:
+                            self._bw_state[k][1 + me] = ev
+                    if self._wg_marks_pending:
+                        self._bw_strand = None
+                        main_t.wait_stream(side_t)
+                        self._wgrad_marks()
+                        side_t.wait_stream(main_t)
+            finally:
+                self.stream = handles[0]
+                self._bw_strand = None
+                self._wg_marks_deferred = False
+            main_t.wait_stream(side_t)
         for bid in list(self._riders):
             gv, g, acc = self._riders.pop(bid)
             self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
@@ -989,6 +1072,7 @@ class Engine:
             else:
                 self._cow(s)
                 gv = prev = self.grads[id(s.base)][0].chan(s.coff, s.coff + s.c)
+            self._bw_touch(gv, True)
         return gv, prev, acc
 
     def _bw_block2(self, site1, site2, segs, act, t, out, res1):
@@ -1060,29 +1144,37 @@ class Engine:
             cost = 2.0 * site.ci * site.taps * site.co * x0.n * x0.h * x0.w
             self._wg_deferred.append((a, cost))
             self._wg_cum += cost
-            k = self._wg_nflush  # cumulative-cost marks, fractions of the pass's total
-            if (self.wgrad_batch and self.prof is None and k < len(self.wgrad_flush_frac) and self._wg_total > 0
-                    and self._wg_cum >= self.wgrad_flush_frac[k] * self._wg_total):
-                self._wg_nflush += 1
-                self._launch_batched_wgrads(background=True)
-            if (self.on_split is not None and not self._split_done and self._wg_nflush >= max(1, len(self.wgrad_flush_frac)) and self._wg_total > 0
-                    and self._wg_cum >= self.split_frac * self._wg_total):
-                self._split_done = True
-                if self._wg_forked:  # join the background flush + its reduction: by now it has long finished (no stall)
-                    main = torch.cuda.current_stream(self.device)
-                    for st in self._wg_pool:
-                        main.wait_stream(st)
-                    self._wg_forked = False
-                final = set()
-                for st_, _, _ in self._wg_events[:self._wg_reduced]:
-                    final.add(id(st_.conv.weight))
-                    if st_.conv.bias is not None:
-                        final.add(id(st_.conv.bias))
-                self.early_final = final
-                self.on_split()
+            if self._wg_marks_deferred:  # two-strand backward: honoured between tape entries, strands joined
+                self._wg_marks_pending = True
+            else:
+                self._wgrad_marks()
         else:
             self._timed("conv_wgrad", site, x0, lambda: self.lib.conv2d_wgrad(C.byref(a), self.stream))
         self._wg_events.append((site, key, nsplit))
+
+    def _wgrad_marks(self):
+        """Background-flush and data-parallel split marks of the weight-gradient work deferred so far (see _wgrad)."""
+        self._wg_marks_pending = False
+        k = self._wg_nflush  # cumulative-cost marks, fractions of the pass's total
+        if (self.wgrad_batch and self.prof is None and k < len(self.wgrad_flush_frac) and self._wg_total > 0
+                and self._wg_cum >= self.wgrad_flush_frac[k] * self._wg_total):
+            self._wg_nflush += 1
+            self._launch_batched_wgrads(background=True)
+        if (self.on_split is not None and not self._split_done and self._wg_nflush >= max(1, len(self.wgrad_flush_frac)) and self._wg_total > 0
+                and self._wg_cum >= self.split_frac * self._wg_total):
+            self._split_done = True
+            if self._wg_forked:  # join the background flush + its reduction: by now it has long finished (no stall)
+                main = torch.cuda.current_stream(self.device)
+                for st in self._wg_pool:
+                    main.wait_stream(st)
+                self._wg_forked = False
+            final = set()
+            for st_, _, _ in self._wg_events[:self._wg_reduced]:
+                final.add(id(st_.conv.weight))
+                if st_.conv.bias is not None:
+                    final.add(id(st_.conv.bias))
+            self.early_final = final
+            self.on_split()
 
     def _launch_deferred_wgrads(self, final=True):
         main = torch.cuda.current_stream(self.device)
@@ -1300,6 +1392,7 @@ class Engine:
                 ent = (param, self.arena.alloc(c * h * w * 4))
                 self._pgrad_tmp[id(param)] = ent
             dst = ent[1]
+        self._bw_touch(dst, True)  # (both strands upsample with the same bias parameter)
         self.lib.batch_reduce(self.dt, g.n, g.h, g.w, g.cv(), dst, 1 if acc else 0, self.stream)
         self.launches += 1
         self.pgrad_init.add(id(param))
@@ -1333,6 +1426,8 @@ class Engine:
         passes of DSCM.forward draw z from q but contribute no KL term: their coefficient is a device-side zero)."""
         gz = self.grad_read(z)
         job = self._riders.pop(id(p_loc.base), None)  # (taken before grad_write would land it as a launch of its own)
+        if job is not None:
+            self._bw_touch(job[1], False)
         gql, a1 = self.grad_write(q_loc)
         gqs, a2 = self.grad_write(q_ls)
         gpl, a3 = self.grad_write(p_loc)

@@ -659,3 +659,37 @@ def test_virtual_parents_equal_materialised():
         for k in ("expand", "flat"):
             for i, what in enumerate(("elbo", "grads", "decoded mean")):
                 assert torch.equal(res[k][i], res["repeat"][i]), (name, dt, k, what)
+
+
+def test_two_strand_backward_equals_single_stream():
+    """CGEN_BWD_BRANCH (engine.bwd_branch): the decoder's z strand of the backward pass on the side stream, ordered against the
+    h strand per gradient buffer.  Off by default (slower inside a hipGraph on MI355X), kept correct: gradients must equal the
+    single-stream backward bit for bit, also where both strands accumulate into one buffer (shared upsampling biases)."""
+    from causal_gen_amd import vae
+    from causal_gen_amd.hps import setup_hparams
+
+    hp = setup_hparams("ukbb192")
+    torch.manual_seed(3)
+    m = vae.HVAE(hp).cuda()
+    m.compute_dtype = "bf16"
+    m.train()
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    x = ((torch.randint(0, 256, (B, hp.input_channels, hp.input_res, hp.input_res), generator=g).float() - 127.5) / 127.5).cuda()
+    pa = torch.randn(B, hp.context_dim, generator=g).cuda()
+    res = {}
+    for two in (False, True, True):
+        m.zero_grad(set_to_none=True)
+        ge = torch.Generator().manual_seed(100)
+        m.noise = [torch.randn(B, b.z_dim, b.res, b.res, generator=ge) for b in m.decoder.blocks if b.stochastic]
+        eng = m.engine()
+        eng.bwd_branch = two
+        out = m(x, pa, beta=hp.beta)
+        out["elbo"].backward()
+        torch.cuda.synchronize()
+        grads = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+        res.setdefault(two, []).append(grads.clone())
+    m.noise = None
+    assert float(res[False][0].abs().sum()) > 0
+    for gtwo in res[True]:
+        assert torch.equal(gtwo, res[False][0])
