@@ -138,12 +138,14 @@ def pmc_traffic(kernel_class, dtype):
         return None, None
     path = cands[-1]
     try:
-        val = json.load(open(path))[kernel_class]["hbm_bytes_per_dispatch"]
+        blob = json.load(open(path))
+        val = blob[kernel_class]["hbm_bytes_per_dispatch"]
     except Exception:
         return None, None
-    sha = None
+    sha = (blob.get("_source") or {}).get("code_git_sha")  # stamped into the summary when it was committed (the GPU box has no .git)
     try:
-        sha = subprocess.run(["git", "log", "-1", "--format=%h", "--", path], cwd=ROOT, capture_output=True, text=True, timeout=10).stdout.strip() or None
+        if sha is None:
+            sha = subprocess.run(["git", "log", "-1", "--format=%h", "--", path], cwd=ROOT, capture_output=True, text=True, timeout=10).stdout.strip() or None
     except Exception:
         pass
     return val, dict(file=os.path.relpath(path, ROOT), git_sha=sha, method="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 (gfx950)")

@@ -86,6 +86,17 @@ for s, e, n, *_ in step:
     a = fam[n.split("(")[0].split("<")[0][:50]]; a[0] += 1; a[1] += e - s
 for n, (c, d) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:16]:
     P("  %-50s x%-4d sum %.3f ms  avg %.1f us" % (n, c, d / 1e6, d / c / 1e3))
+# a window of consecutive kernels in the middle of the backward chain: start offset, duration, gap to the previous END on the
+# same queue (negative = it started before the previous kernel of that queue had ended)
+if fin:
+    mid = [r for r in step if r[0] > fin[1]]
+    mid = mid[len(mid) // 3: len(mid) // 3 + 40]
+    last_end = {}
+    P("window of 40 consecutive launches (backward, after a third of the chain): start us | dur us | gap to previous end on the same queue | queue | kernel (grid)")
+    for s_, e_, n_, q_, st_ in mid:
+        gap = (s_ - last_end[q_]) / 1e3 if q_ in last_end else float("nan")
+        last_end[q_] = e_
+        P("    %9.1f | %6.1f | %6.1f | q%s | %s" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, gap, q_, n_.split("(")[0][:48]))
 txt = "\n".join(out)
 print(txt)
 if len(sys.argv) > 2:
