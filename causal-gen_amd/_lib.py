@@ -76,6 +76,8 @@ PROTOTYPES = {
     "cgen_wgrad_reduce": [vp, vp, vp, i32, vp],
     "cgen_avgpool_fwd": [i32, i32, i32, i32, i32, View, View, vp],
     "cgen_avgpool_bwd": [i32, i32, i32, i32, i32, View, View, i32, vp],
+    "cgen_adaptive_avgpool_fwd": [i32, i32, i32, i32, i32, i32, View, View, vp],
+    "cgen_adaptive_avgpool_bwd": [i32, i32, i32, i32, i32, i32, View, View, i32, vp],
     "cgen_upsample_fwd": [i32, i32, i32, i32, i32, i32, View, vp, View, vp],
     "cgen_upsample_bwd": [i32, i32, i32, i32, i32, i32, View, View, i32, vp],
     "cgen_batch_reduce": [i32, i32, i32, i32, View, vp, i32, vp],

@@ -92,6 +92,69 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(Shape4 si, int d, View
   }
 }
 
+// aten::adaptive_avg_pool2d (vae.py:79-81, Block with a float down-rate): window of output cell o along an axis of length
+// `in` -> `out` is [floor(o * in / out), ceil((o + 1) * in / out))
+__device__ __forceinline__ int ap_start(int o, int in, int out) { return (int)(((int64_t)o * in) / out); }
+__device__ __forceinline__ int ap_end(int o, int in, int out) { return (int)((((int64_t)(o + 1)) * in + out - 1) / out); }
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void adaptive_avgpool_fwd_kernel(Shape4 so, int hi, int wi, View in, View out) {
+  GRID_STRIDE(g) {
+    int n, y, x, c;
+    if (!decode<V>(g, so, n, y, x, c)) return;
+    const int y0 = ap_start(y, hi, so.h), y1 = ap_end(y, hi, so.h), x0 = ap_start(x, wi, so.w), x1 = ap_end(x, wi, so.w);
+    float a[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] = 0.f;
+    for (int yy = y0; yy < y1; ++yy)
+      for (int xx = x0; xx < x1; ++xx) {
+        float v[V];
+        VecIO<T, V>::ld(vptr<T>(in, n, yy, xx) + c, v);
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += v[e];
+      }
+    const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] *= inv;
+    VecIO<T, V>::st(vptr<T>(out, n, y, x) + c, a);
+  }
+}
+
+// gather form of the backward pass: input pixel (y, x) collects gout / area from every output cell whose window holds it
+// (windows overlap by at most one pixel per side, so the candidates are the cells around floor(y * out / in))
+template <typename T, int V>
+__global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(Shape4 si, int ho, int wo, View gout, View gin, int accumulate) {
+  GRID_STRIDE(g) {
+    int n, y, x, c;
+    if (!decode<V>(g, si, n, y, x, c)) return;
+    float a[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] = 0.f;
+    const int oy_c = (int)(((int64_t)y * ho) / si.h), ox_c = (int)(((int64_t)x * wo) / si.w);
+    for (int oy = max(0, oy_c - 1); oy <= min(ho - 1, oy_c + 1); ++oy) {
+      const int y0 = ap_start(oy, si.h, ho), y1 = ap_end(oy, si.h, ho);
+      if (y < y0 || y >= y1) continue;
+      for (int ox = max(0, ox_c - 1); ox <= min(wo - 1, ox_c + 1); ++ox) {
+        const int x0 = ap_start(ox, si.w, wo), x1 = ap_end(ox, si.w, wo);
+        if (x < x0 || x >= x1) continue;
+        float v[V];
+        VecIO<T, V>::ld(vptr<T>(gout, n, oy, ox) + c, v);
+        const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += v[e] * inv;
+      }
+    }
+    T* dst = vptr<T>(gin, n, y, x) + c;
+    if (accumulate) {
+      float o[V];
+      VecIO<T, V>::ld(dst, o);
+#pragma unroll
+      for (int e = 0; e < V; ++e) a[e] += o[e];
+    }
+    VecIO<T, V>::st(dst, a);
+  }
+}
+
 // nearest-neighbour source index exactly as ATen's upsample_nearest2d with an explicit scale_factor:
 // src = min(floorf(dst * (float)(1/scale_factor)), in-1)
 __device__ __forceinline__ int nn_src(int dst, float inv_scale, int in_size) {
@@ -444,6 +507,28 @@ extern "C" int cgen_avgpool_bwd(int32_t dtype, int32_t n, int32_t ho, int32_t wo
   const int64_t items = (int64_t)n * si.h * si.w * (v ? gin.c / 4 : gin.c);
   DISPATCH_TV(dtype, v, avgpool_bwd_kernel, items, stream, si, d, mk(gout), mk(gin), accumulate);
   return check_launch("cgen_avgpool_bwd");
+}
+
+extern "C" int cgen_adaptive_avgpool_fwd(int32_t dtype, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo, cgen_view in, cgen_view out,
+                                         cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_adaptive_avgpool_fwd");
+  CGEN_REQUIRE(in.p && out.p && in.c == out.c && n > 0 && ho > 0 && wo > 0 && hi >= ho && wi >= wo, "cgen_adaptive_avgpool_fwd: bad args");
+  Shape4 so{n, ho, wo, out.c};
+  const bool v = vec4_ok(esz_of(dtype), out.c, {&in, &out});
+  const int64_t items = (int64_t)n * ho * wo * (v ? out.c / 4 : out.c);
+  DISPATCH_TV(dtype, v, adaptive_avgpool_fwd_kernel, items, stream, so, hi, wi, mk(in), mk(out));
+  return check_launch("cgen_adaptive_avgpool_fwd");
+}
+
+extern "C" int cgen_adaptive_avgpool_bwd(int32_t dtype, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo, cgen_view gout, cgen_view gin,
+                                         int32_t accumulate, cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_adaptive_avgpool_bwd");
+  CGEN_REQUIRE(gout.p && gin.p && gin.c == gout.c && n > 0 && ho > 0 && wo > 0 && hi >= ho && wi >= wo, "cgen_adaptive_avgpool_bwd: bad args");
+  Shape4 si{n, hi, wi, gin.c};
+  const bool v = vec4_ok(esz_of(dtype), gin.c, {&gout, &gin});
+  const int64_t items = (int64_t)n * hi * wi * (v ? gin.c / 4 : gin.c);
+  DISPATCH_TV(dtype, v, adaptive_avgpool_bwd_kernel, items, stream, si, ho, wo, mk(gout), mk(gin), accumulate);
+  return check_launch("cgen_adaptive_avgpool_bwd");
 }
 
 static inline float inv_scale(int out, int in) { return (float)(1.0 / ((double)out / (double)in)); }

@@ -575,8 +575,15 @@ class Engine:
         return out
 
     def pool(self, x, d):
-        out = self.new(x.n, x.h // d, x.w // d, x.c)
-        self.lib.avgpool_fwd(self.dt, x.n, out.h, out.w, d, x.cv(), out.cv(), self.stream)
+        """F.avg_pool2d(kernel = stride = d) for an integer down-rate, F.adaptive_avg_pool2d(int(W / d)) for a float one
+        (vae.py:79-83)."""
+        if isinstance(d, float):
+            ho, wo = int(x.w / d), int(x.w / d)  # (the reference sizes both axes from the last one)
+            out = self.new(x.n, ho, wo, x.c)
+            self.lib.adaptive_avgpool_fwd(self.dt, x.n, x.h, x.w, ho, wo, x.cv(), out.cv(), self.stream)
+        else:
+            out = self.new(x.n, x.h // d, x.w // d, x.c)
+            self.lib.avgpool_fwd(self.dt, x.n, out.h, out.w, d, x.cv(), out.cv(), self.stream)
         self.launches += 1
         if self.recording:
             self.tape.append((self._bw_pool, (x, out, d)))
@@ -1378,7 +1385,10 @@ class Engine:
         if g is None:
             return
         gv, acc = self.grad_write(x)
-        self.lib.avgpool_bwd(self.dt, x.n, out.h, out.w, d, g.cv(), gv.cv(), 1 if acc else 0, self.stream)
+        if isinstance(d, float):
+            self.lib.adaptive_avgpool_bwd(self.dt, x.n, x.h, x.w, out.h, out.w, g.cv(), gv.cv(), 1 if acc else 0, self.stream)
+        else:
+            self.lib.avgpool_bwd(self.dt, x.n, out.h, out.w, d, g.cv(), gv.cv(), 1 if acc else 0, self.stream)
         self.launches += 1
 
     def _param_reduce(self, param, g):

@@ -379,9 +379,7 @@ class HVAE(nn.Module):
                 last = j == len(cs) - 2
                 h = eng.conv(self._site(eng, c), [h], act, res1=res if last else None)
         if blk.d:
-            if isinstance(blk.d, float):
-                raise NotImplementedError("adaptive_avg_pool2d down-rates are not used by any preset")
-            h = eng.pool(h, blk.d)
+            h = eng.pool(h, blk.d)  # int: avg_pool2d; float: adaptive_avg_pool2d (vae.py:79-83)
         return h
 
     def _encode(self, eng, x):

@@ -154,6 +154,12 @@ int cgen_wgrad_reduce(const cgen_wred_desc* descs_dev, const int32_t* chunk_site
 int cgen_avgpool_fwd(int32_t dtype, int32_t n, int32_t ho, int32_t wo, int32_t d, cgen_view in, cgen_view out, cgen_stream_t);
 int cgen_avgpool_bwd(int32_t dtype, int32_t n, int32_t ho, int32_t wo, int32_t d, cgen_view gout, cgen_view gin,
                      int32_t accumulate, cgen_stream_t);
+/* aten::adaptive_avg_pool2d fwd/bwd for a Block with a float down-rate (vae.py:79-81): output cell o averages
+ * [floor(o*in/out), ceil((o+1)*in/out)) along each axis; the backward pass gathers gout / window area. */
+int cgen_adaptive_avgpool_fwd(int32_t dtype, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo, cgen_view in, cgen_view out,
+                              cgen_stream_t);
+int cgen_adaptive_avgpool_bwd(int32_t dtype, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo, cgen_view gout, cgen_view gin,
+                              int32_t accumulate, cgen_stream_t);
 /* out[n,y,x,:] = in[n, floor(y*hi/ho), floor(x*wi/wo), :] + (bias ? bias[y,x,:] : 0); bias is f32 [ho][wo][C] */
 int cgen_upsample_fwd(int32_t dtype, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo, cgen_view in,
                       const float* bias, cgen_view out, cgen_stream_t);

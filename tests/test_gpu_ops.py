@@ -150,6 +150,29 @@ def test_avgpool(d):
     torch.testing.assert_close(nhwc_to_torch(eng, eng.grad_read(xt)), xr.grad, rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("size,d", [(12, 1.5), (14, 1.75), (10, 2.5), (9, 1.2), (16, 2.0), (7, 7.0)])
+def test_adaptive_avgpool_float_down_rate(size, d):
+    """Block with a float down-rate (vae.py:79-81): F.adaptive_avg_pool2d(out, int(W / d)), forward and backward (overlapping,
+    uneven windows), accumulated into an existing gradient as well."""
+    g = torch.Generator().manual_seed(int(size * 10 + d * 4))
+    x = torch.randn(3, 12, size, size, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.adaptive_avg_pool2d(xr, int(xr.shape[-1] / d)) + 0.5 * xr.mean(dim=(2, 3), keepdim=True)
+    gout = torch.randn(3, 12, int(size / d), int(size / d), generator=g)
+    F.adaptive_avg_pool2d(xr, int(xr.shape[-1] / d)).backward(gout)
+    eng, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]])
+    eng.recording = True
+    xt = eng.from_nchw(x.cuda(), rg=True)
+    xt.rg = True
+    y = eng.pool(xt, d)
+    assert (y.h, y.w) == (int(size / d), int(size / d))
+    torch.testing.assert_close(nhwc_to_torch(eng, y), F.adaptive_avg_pool2d(x, int(size / d)), rtol=1e-5, atol=1e-6)
+    gy = eng.seed_grad(y)
+    eng.lib.axpby(eng.dt, y.n, y.h, y.w, eng.from_nchw(gout.cuda()).cv(), gy.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
+    eng.backward()
+    torch.testing.assert_close(nhwc_to_torch(eng, eng.grad_read(xt)), xr.grad, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("hi,ho", [(1, 4), (1, 6), (4, 8), (6, 12), (8, 14), (14, 28), (48, 96)])
 def test_upsample_matches_interpolate(hi, ho):
     g = torch.Generator().manual_seed(hi * 100 + ho)

@@ -65,7 +65,8 @@ for case in range(n):
             if hp.cond_prior:
                 m.decoder.__dict__["drop_cond"] = lambda: (1, 1)  # no conditioning dropout: both runs must see the same graph
             x = ((torch.randint(0, 256, (B, C, R, R), generator=g).float() - 127.5) / 127.5).cuda()
-            pa = torch.randn(B, hp.context_dim, generator=g)[..., None, None].repeat(1, 1, R, R).cuda()
+            pa = torch.randn(B, hp.context_dim, generator=g).cuda()[..., None, None]
+            pa = pa.repeat(1, 1, R, R) if os.environ.get("FUZZ_PA") == "repeat" else pa.expand(-1, -1, R, R)  # stride-0 view: the virtual-parents path
             eng = m.engine()
             eng.rng_ptr()
             eng.rng.copy_(torch.tensor([5, 0], dtype=torch.int64, device=eng.rng.device))
