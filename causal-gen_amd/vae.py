@@ -14,6 +14,8 @@ import math
 from typing import Dict, List, Optional
 
 import numpy as np
+import weakref
+
 import torch
 from torch import Tensor, nn
 
@@ -69,6 +71,82 @@ def sample_gaussian(loc: Tensor, logscale: Tensor) -> Tensor:
     return out
 
 
+_SA_ENGINES = weakref.WeakKeyDictionary()  # standalone engines of holder modules used outside an HVAE (inference only)
+
+
+def _block_sites(sites, name, blk, seg_c, seg_rg):
+    cs = blk.convs()
+    sites.append(ConvSite(f"{name}.conv.1", cs[0], seg_c, seg_rg, len(sites)))
+    for j, c in enumerate(cs[1:]):
+        sites.append(ConvSite(f"{name}.conv.{3 + 2 * j}", c, [c.in_channels], [True], len(sites)))
+    if hasattr(blk, "width_proj"):
+        sites.append(ConvSite(f"{name}.width_proj", blk.width_proj, seg_c, seg_rg, len(sites)))
+
+
+def run_block(eng, blk, segs):
+    """Block.forward (vae.py:73-84) as fused launches."""
+    site = lambda conv: eng.site_by_id[id(conv)]
+    act = ACT_RELU if blk.light else ACT_GELU
+    cs = blk.convs()
+    res = None
+    if blk.residual:
+        x = segs[0]
+        if x.c != cs[-1].out_channels:
+            res = eng.conv(site(blk.width_proj), segs, ACT_NONE)
+        else:
+            res = x
+    if blk.light and len(cs) == 2:  # the two 3x3 convs of a light Block: one fused launch where the kernel serves the shape
+        h = eng.block2(site(cs[0]), site(cs[1]), segs, act, res1=res)
+    else:
+        h = eng.conv(site(cs[0]), segs, act, res1=res if len(cs) == 1 else None)
+        for j, c in enumerate(cs[1:]):
+            last = j == len(cs) - 2
+            h = eng.conv(site(c), [h], act, res1=res if last else None)
+    if blk.d:
+        h = eng.pool(h, blk.d)  # int: avg_pool2d; float: adaptive_avg_pool2d (vae.py:79-83)
+    return h
+
+
+def run_encoder(eng, enc, x):
+    """Encoder.forward (vae.py:112-134): {resolution: activation}."""
+    stem = eng.site_by_id[id(enc.stem)]
+    h = eng.conv(stem, [eng.im2col(x, stem.im2col)], ACT_NONE)
+    acts = {}
+    for blk in enc.blocks:
+        h = run_block(eng, blk, [h])
+        if h.h % 2 and h.h > 1:
+            h = eng.pad_br(h)
+        acts[h.w] = h
+    return acts
+
+
+def _standalone_engine(mod, make_sites):
+    """Engine of a holder module used on its own (``Block(...)(x)``, ``Encoder(args)(x)``, ``DGaussNet(args).predict(h)``):
+    the reference's classes are importable and callable by themselves.  Inference only -- training runs through
+    ``HVAE``, whose engine owns the tape.  ``mod.compute_dtype`` ("f32" default, or "bf16") picks the kernels."""
+    dev = next(mod.parameters()).device
+    dt = getattr(mod, "compute_dtype", "f32")
+    eng = _SA_ENGINES.get(mod)
+    if eng is None or eng.device != dev or eng.dtype_name != dt:
+        if dev.type != "cuda":
+            raise _lib.CgenError(f"{type(mod).__name__} runs on an MI355X only: move it to the GPU; there is no CPU fallback")
+        eng = Engine(dev, dt)
+        eng.bind(mod, make_sites())
+        _SA_ENGINES[mod] = eng
+    else:
+        eng.check_params()
+    eng.begin()
+    eng.recording = False
+    eng.prepare_weights()
+    return eng
+
+
+def _no_standalone_grad(mod, *tensors):
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        raise RuntimeError(f"{type(mod).__name__} on its own is inference-only here: gradients flow through HVAE.forward "
+                           "(one tape for the whole model); call it under torch.no_grad() or detach the input")
+
+
 class Block(nn.Module):
     """Parameter holder mirroring vae.py:33-84 (two variants, optional width_proj)."""
 
@@ -94,8 +172,20 @@ class Block(nn.Module):
     def convs(self):
         return [m for m in self.conv if isinstance(m, nn.Conv2d)]
 
+    @torch.no_grad()
+    def _forward_standalone(self, x):
+        def sites():
+            out = []
+            _block_sites(out, "block", self, [self.convs()[0].in_channels], [True])
+            return out
+
+        eng = _standalone_engine(self, sites)
+        return eng.to_nchw(run_block(eng, self, [eng.from_nchw(x.to(eng.device, torch.float32))]))
+
     def forward(self, x):
-        raise RuntimeError("Block is a parameter holder; run it through HVAE (HIP engine)")
+        """vae.py:73-84 on the HIP engine (standalone use: inference only; inside an HVAE the model's engine runs the Block)."""
+        _no_standalone_grad(self, x)
+        return self._forward_standalone(x)
 
 
 class Encoder(nn.Module):
@@ -119,8 +209,22 @@ class Encoder(nn.Module):
             b.conv[-1].weight.data *= np.sqrt(1 / len(blocks))
         self.blocks = nn.ModuleList(blocks)
 
+    @torch.no_grad()
+    def _forward_standalone(self, x):
+        def sites():
+            out = [ConvSite("stem", self.stem, [self.stem.in_channels * 49], [False], 0, as_1x1=True)]
+            for i, b in enumerate(self.blocks):
+                _block_sites(out, f"blocks.{i}", b, [b.convs()[0].in_channels], [True])
+            return out
+
+        eng = _standalone_engine(self, sites)
+        acts = run_encoder(eng, self, eng.from_nchw(x.to(eng.device, torch.float32)))
+        return {r: eng.to_nchw(a) for r, a in acts.items()}
+
     def forward(self, x):
-        raise RuntimeError("Encoder is a parameter holder; run it through HVAE (HIP engine)")
+        """vae.py:112-134 on the HIP engine: {resolution: activation [B,C,r,r]} (standalone use: inference only)."""
+        _no_standalone_grad(self, x)
+        return self._forward_standalone(x)
 
 
 class DecoderBlock(nn.Module):
@@ -217,8 +321,75 @@ class DGaussNet(nn.Module):
     def out_channels(self):
         return 2 * self.channels + (3 if self.channels == 3 else 0)
 
-    def forward(self, *a, **k):
-        raise RuntimeError("DGaussNet is a parameter holder; run it through HVAE (HIP engine)")
+    # ---- standalone use (inference only; inside an HVAE the model's engine drives these kernels)
+    def _standalone_params(self, h):
+        def sites():
+            return [ConvSite(nm, cv, [cv.in_channels], [True], i)
+                    for i, (nm, cv) in enumerate(zip(("x_loc", "x_logscale", "channel_coeffs"), self.heads()))]
+
+        eng = _standalone_engine(self, sites)
+        ht = eng.from_nchw(h.to(eng.device, torch.float32))
+        buf = eng.new(ht.n, ht.h, ht.w, self.out_channels())
+        o = 0
+        for cv in self.heads():
+            eng.conv(eng.site_by_id[id(cv)], [ht], ACT_NONE, out=buf.chan(o, o + cv.out_channels))
+            o += cv.out_channels
+        return eng, buf
+
+    @torch.no_grad()
+    def _forward_standalone(self, h, x=None, t=None):
+        eng, buf = self._standalone_params(h)
+        C = self.channels
+        p = eng.to_nchw(buf)
+        loc, logscale = p[:, :C], p[:, C:2 * C].clamp(min=-9.0)  # EPS = -9 (vae.py:11, 355)
+        if C == 3:  # vae.py:357-383 (a handful of per-pixel torch ops on the heads' outputs: not a hot path on its own)
+            coeff = torch.tanh(p[:, 2 * C:2 * C + 3])
+            if x is None:
+                f = lambda v: v.clamp(-1, 1)
+                r = f(loc[:, 0])
+                g_ = f(loc[:, 1] + coeff[:, 0] * r)
+                b = f(loc[:, 2] + coeff[:, 1] * r + coeff[:, 2] * g_)
+            else:
+                x = x.to(p.device, torch.float32)
+                r = loc[:, 0]
+                g_ = loc[:, 1] + coeff[:, 0] * x[:, 0]
+                b = loc[:, 2] + coeff[:, 1] * x[:, 0] + coeff[:, 2] * x[:, 1]
+            loc = torch.stack([r, g_, b], 1)
+        if t is not None:
+            logscale = logscale + float(torch.tensor(t).log())
+        return loc.contiguous(), logscale.contiguous()
+
+    def forward(self, h, x=None, t=None):
+        """vae.py:352-386: (loc, logscale) of the pixel distribution given the decoder's last hidden state."""
+        _no_standalone_grad(self, h, x)
+        return self._forward_standalone(h, x, t)
+
+    @torch.no_grad()
+    def nll(self, h, x):
+        """vae.py:393-411: per-sample negative log-likelihood in nats / dim (`cgen_dgauss_nll_fwd`)."""
+        eng, buf = self._standalone_params(h)
+        lib = eng.lib
+        B, R, W = buf.n, buf.h, buf.w
+        xt = eng.from_nchw(x.to(eng.device, torch.float32))
+        nchunk = lib.like_chunks(R, W)
+        part = torch.empty((B, nchunk), dtype=torch.float32, device=eng.device)
+        lib.dgauss_nll_fwd(eng.dt, B, R, W, self.channels, buf.cv(), xt.cv(), part.data_ptr(), eng.stream)
+        return part.sum(1) / float(self.channels * R * W)
+
+    @torch.no_grad()
+    def sample(self, h, return_loc=True, t=None):
+        """vae.py:413-422 (`cgen_dgauss_sample`): (x clamped to [-1, 1], scale)."""
+        if not return_loc and t is not None and self.channels == 3:
+            raise TypeError("'float' object is not subscriptable")  # vae.py:418 hands t over as `x`: the reference raises here
+        eng, buf = self._standalone_params(h)
+        B, R, W, C = buf.n, buf.h, buf.w, self.channels
+        xo = torch.empty((B, C, R, W), dtype=torch.float32, device=eng.device)
+        so = torch.empty_like(xo)
+        if not return_loc:
+            eng.rng_advance(1)
+        eng.lib.dgauss_sample(eng.dt, B, R, W, C, buf.cv(), 0.0, None if return_loc else eng.rng_ptr(), 978, xo.data_ptr(),
+                              so.data_ptr(), eng.stream)
+        return xo, so
 
 
 class _HVAEFunction(torch.autograd.Function):
@@ -323,12 +494,7 @@ class HVAE(nn.Module):
             sites.append(ConvSite(name, conv, seg_c, seg_rg, len(sites), as_1x1=as_1x1))
 
         def add_block(name, blk, seg_c, seg_rg):
-            cs = blk.convs()
-            add(f"{name}.conv.1", cs[0], seg_c, seg_rg)
-            for j, c in enumerate(cs[1:]):
-                add(f"{name}.conv.{3 + 2 * j}", c, [c.in_channels], [True])
-            if hasattr(blk, "width_proj"):
-                add(f"{name}.width_proj", blk.width_proj, seg_c, seg_rg)
+            _block_sites(sites, name, blk, seg_c, seg_rg)
 
         C = self.input_channels
         add("encoder.stem", self.encoder.stem, [C * 49], [False], as_1x1=True)
@@ -361,37 +527,10 @@ class HVAE(nn.Module):
 
     # ------------------------------------------------------------------ graph pieces
     def _run_block(self, eng, blk, segs):
-        """Block.forward (vae.py:73-84) as fused launches."""
-        act = ACT_RELU if blk.light else ACT_GELU
-        cs = blk.convs()
-        res = None
-        if blk.residual:
-            x = segs[0]
-            if x.c != cs[-1].out_channels:
-                res = eng.conv(self._site(eng, blk.width_proj), segs, ACT_NONE)
-            else:
-                res = x
-        if blk.light and len(cs) == 2:  # the two 3x3 convs of a light Block: one fused launch where the kernel serves the shape
-            h = eng.block2(self._site(eng, cs[0]), self._site(eng, cs[1]), segs, act, res1=res)
-        else:
-            h = eng.conv(self._site(eng, cs[0]), segs, act, res1=res if len(cs) == 1 else None)
-            for j, c in enumerate(cs[1:]):
-                last = j == len(cs) - 2
-                h = eng.conv(self._site(eng, c), [h], act, res1=res if last else None)
-        if blk.d:
-            h = eng.pool(h, blk.d)  # int: avg_pool2d; float: adaptive_avg_pool2d (vae.py:79-83)
-        return h
+        return run_block(eng, blk, segs)
 
     def _encode(self, eng, x):
-        stem = self._site(eng, self.encoder.stem)
-        h = eng.conv(stem, [eng.im2col(x, stem.im2col)], ACT_NONE)
-        acts = {}
-        for blk in self.encoder.blocks:
-            h = self._run_block(eng, blk, [h])
-            if h.h % 2 and h.h > 1:
-                h = eng.pad_br(h)
-            acts[h.w] = h
-        return acts
+        return run_encoder(eng, self.encoder, x)
 
     def _next_eps(self, eng, shape_nhwc):
         src = self.__dict__["noise"]
