@@ -32,6 +32,18 @@ class BlockArgs(C.Structure):
                 ("mid", View), ("mid_aux", View), ("out", View), ("aux", View), ("res1", View)]
 
 
+class LatentZprojArgs(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("co", C.c_int32),
+                ("q_loc", View), ("q_ls", View), ("p_loc", View), ("p_ls", View), ("eps_in", View), ("z", View), ("eps_out", View),
+                ("rng", C.c_void_p), ("stream_id", C.c_uint32), ("logt", C.c_float), ("kl_part", C.c_void_p),
+                ("kl_stride", C.c_int32), ("reserved0", C.c_int32),
+                ("pa", View), ("hres", View), ("pfeat", View), ("out", View), ("w_fwd", C.c_void_p), ("bias", C.c_void_p),
+                ("gout", View), ("gz", View), ("g_q_loc", View), ("g_q_ls", View), ("g_p_loc", View), ("g_p_ls", View),
+                ("w_dgrad", C.c_void_p), ("kl_coef_dev", C.c_void_p), ("kl_chan_scale", C.c_void_p),
+                ("coef_stride", C.c_int32), ("acc_q", C.c_int32), ("acc_p", C.c_int32), ("ride_acc", C.c_int32),
+                ("ride_src", View), ("ride_dst", View)]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("ks", C.c_int32),
                 ("nseg", C.c_int32), ("act", C.c_int32), ("nsplit", C.c_int32), ("seg", View * MAX_SEG), ("gout", View),
@@ -92,6 +104,9 @@ PROTOTYPES = {
                             View, i32, i32, vp],
     "cgen_reparam_kl_bwd_rider": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, View, vp, i32, vp, View, View, View,
                                   View, i32, i32, View, View, i32, vp],
+    "cgen_latent_zproj_supported": [C.POINTER(LatentZprojArgs)],
+    "cgen_latent_zproj_fwd": [C.POINTER(LatentZprojArgs), vp],
+    "cgen_latent_zproj_bwd": [C.POINTER(LatentZprojArgs), vp],
     "cgen_kl_channel_sums": [i32, i32, i32, i32, i32, View, View, View, View, f32, vp, i32, vp],
     "cgen_elbo_finalize_fb": [i32, vp, i32, f32, vp, i32, f32, f32, f32, vp, vp, vp, vp],
     "cgen_im2col_strided": [i32, i32, i32, i32, i32, i32, i32, i32, i32, View, View, vp],
@@ -123,7 +138,7 @@ PROTOTYPES = {
 }
 _RESTYPES = {"cgen_last_error": C.c_char_p}
 _NOCHECK = {"cgen_version", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks",
-            "cgen_block2_supported"}
+            "cgen_block2_supported", "cgen_latent_zproj_supported"}
 
 
 class WgradBatchLaunch(C.Structure):

@@ -240,6 +240,11 @@ class Engine:
         # fused light-Block kernel (two 3x3 convs per launch, csrc/block_fused.inc): 0 off, 1 forward only, 2 forward + data gradient.
         # OFF by default: correct (tests/test_gpu_block.py) but, at one wave per SIMD, still slower than the two launches it
         # replaces on MI355X (DESIGN.md section 3.6 has the per-phase cycle stamps and what bounds it)
+        # latent layer (reparameterise + KL + z_proj, and z_proj's data gradient + the reparameterisation gradient) in one launch:
+        # 76 launches fewer per ukbb192 step (1066 -> 990) and NO measurable gain (17.17 vs 17.15 ms; counterfactuals 1 % slower):
+        # the merged kernel is as long as the two it replaces.  Off by default, tested.
+        self.lat_fuse = os.environ.get("CGEN_LAT_FUSE", "0") != "0"
+        self._lat_fused, self._zp_pending = set(), None
         self.blk_fuse = int(os.environ.get("CGEN_BLK_FUSE", "0"))
         self.blk_minres = int(os.environ.get("CGEN_BLK_MINRES", "24"))
         self.blk_th4_maxres = int(os.environ.get("CGEN_BLK_TH4_MAXRES", "0"))  # images up to this size use 4-row tiles (experiment: slower)
@@ -261,6 +266,7 @@ class Engine:
         self._wg_events = []
         self._wg_reduced, self._wg_seen = 0, set()
         self._riders = {}
+        self._lat_fused, self._zp_pending = set(), None
         self.pgrad_init = set()
         self._pnhwc, self._pgrad_tmp = {}, {}
         self._adopted = set()
@@ -657,6 +663,43 @@ class Engine:
             self.tape.append((self._bw_reparam, (q_loc, q_ls, p_loc, p_ls, z, logt, None if fb is None else fb[2], self.kl_coef_override)))
         return z
 
+    def latent_zproj(self, q_loc, q_ls, p_loc, p_ls, eps, stream_id, logt, kl_ptr, kl_stride, fb, site, pa, hres, pfeat):
+        """reparam_kl(...) and conv(z_proj, [z, pa], res1=hres, res2=pfeat) as ONE launch (csrc/latent.hip: the z fragment the
+        reparameterisation leaves in registers is the MFMA operand of the 1x1 conv).  Returns (z, h') or None when the shape
+        is not served (then the caller issues the two launches).  The tape gets the same two entries; the backward pass then
+        folds z_proj's data gradient w.r.t. z into the reparameterisation kernel as well."""
+        if not (self.lat_fuse and self.dt == BF16 and site.ks == 1 and q_loc.c == 16 and len(site.seg_c) == 2 and site.seg_c[0] == 16
+                and site.seg_rg[0] and not site.seg_rg[1]):
+            return None
+        a = _lib.LatentZprojArgs()
+        a.dtype, a.n, a.h, a.w, a.c, a.co = self.dt, q_loc.n, q_loc.h, q_loc.w, 16, site.co
+        a.q_loc, a.q_ls, a.p_loc, a.p_ls = q_loc.cv(), q_ls.cv(), p_loc.cv(), p_ls.cv()
+        a.eps_in = eps.cv() if eps is not None else NULL_VIEW
+        a.eps_out = NULL_VIEW
+        z = self.new(q_loc.n, q_loc.h, q_loc.w, 16)
+        out = self.new(q_loc.n, q_loc.h, q_loc.w, site.co)
+        a.z, a.out, a.pa = z.cv(), out.cv(), pa.cv()
+        a.hres = hres.cv() if hres is not None else NULL_VIEW
+        a.pfeat = pfeat.cv() if pfeat is not None else NULL_VIEW
+        a.gout = a.gz = a.g_q_loc = a.g_q_ls = a.g_p_loc = a.g_p_ls = a.ride_src = a.ride_dst = NULL_VIEW
+        a.rng, a.stream_id, a.logt, a.kl_part, a.kl_stride = self.rng_ptr(), stream_id, logt, kl_ptr, kl_stride
+        a.w_fwd = site.img_fwd
+        b = site.conv.bias
+        a.bias = b.data_ptr() if b is not None else None
+        if not self.lib.latent_zproj_supported(C.byref(a)):
+            return None  # (the two tensors just allocated are simply not used: the arena is reset per step)
+        if fb is not None:
+            self.lib.kl_channel_sums(self.dt, z.n, z.h, z.w, z.c, q_loc.cv(), q_ls.cv(), p_loc.cv(), p_ls.cv(), logt,
+                                     fb[0] + 4 * fb[2], fb[1], self.stream)
+            self.launches += 1
+        self.lib.latent_zproj_fwd(C.byref(a), self.stream)
+        self.launches += 1
+        if self.recording:
+            self.tape.append((self._bw_reparam, (q_loc, q_ls, p_loc, p_ls, z, logt, None if fb is None else fb[2], self.kl_coef_override)))
+            self._lat_fused.add(id(out))
+            self.tape.append((self._bw_conv, (site, [z, pa], ACT_NONE, out, hres, pfeat)))
+        return z, out
+
     def sample_gaussian(self, loc, ls, eps, stream_id, logt):
         z = self.new(loc.n, loc.h, loc.w, loc.c)
         self.lib.sample_gaussian(self.dt, z.n, z.h, z.w, z.c, loc.cv(), ls.cv(), eps.cv() if eps is not None else NULL_VIEW,
@@ -1052,18 +1095,26 @@ class Engine:
         for k, s in enumerate(segs):
             if not (s.rg and site.seg_rg[k]):
                 continue
-            gv, prev, acc = self._dgrad_target(s)
-            a = _lib.ConvArgs()
-            gn, gh, gw, vw = self._geom(site.ks, [g, gv, s, prev])
-            a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = self.dt, gn, gh, gw, site.ks, 1, ACT_NONE, act
-            a.seg[0] = vw(g)
-            a.weight = site.img_dg[k]
-            a.bias = None
-            a.out = vw(gv)
-            a.aux = vw(s) if act != ACT_NONE else NULL_VIEW
-            a.res1 = vw(prev) if acc else NULL_VIEW
-            a.res2 = NULL_VIEW
-            self._timed("conv_dgrad", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream), ci=s.c)
+            if k == 0 and id(out) in self._lat_fused:
+                # z_proj of a fused latent layer: its data gradient w.r.t. z is computed inside the reparameterisation backward
+                # kernel, which is the next tape entry (reparam_kl was recorded right before this conv)
+                self._zp_pending = (site, g, s, act, x0)
+                continue
+            self._dgrad_one(site, g, s, k, act, x0)
+
+    def _dgrad_one(self, site, g, s, k, act, x0):
+        gv, prev, acc = self._dgrad_target(s)
+        a = _lib.ConvArgs()
+        gn, gh, gw, vw = self._geom(site.ks, [g, gv, s, prev])
+        a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = self.dt, gn, gh, gw, site.ks, 1, ACT_NONE, act
+        a.seg[0] = vw(g)
+        a.weight = site.img_dg[k]
+        a.bias = None
+        a.out = vw(gv)
+        a.aux = vw(s) if act != ACT_NONE else NULL_VIEW
+        a.res1 = vw(prev) if acc else NULL_VIEW
+        a.res2 = NULL_VIEW
+        self._timed("conv_dgrad", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream), ci=s.c)
 
     def _dgrad_target(self, s):
         """Where the data gradient of input tensor `s` goes: (view to write, view to add when accumulating, accumulate?)."""
@@ -1434,6 +1485,10 @@ class Engine:
     def _bw_reparam(self, q_loc, q_ls, p_loc, p_ls, z, logt, fb_col=None, coef_ptr=None):
         """`coef_ptr`: device address of d(loss)/d(sum kl) for this layer when it is not the engine-wide one (the abduction
         passes of DSCM.forward draw z from q but contribute no KL term: their coefficient is a device-side zero)."""
+        pend, self._zp_pending = self._zp_pending, None
+        if pend is not None and pend[2] is not z:  # (cannot happen: the pending z_proj belongs to the entry recorded before it)
+            self._dgrad_one(pend[0], pend[1], pend[2], 0, pend[3], pend[4])
+            pend = None
         gz = self.grad_read(z)
         job = self._riders.pop(id(p_loc.base), None)  # (taken before grad_write would land it as a launch of its own)
         if job is not None:
@@ -1454,6 +1509,32 @@ class Engine:
                 gz.cv() if gz is not None else NULL_VIEW, self.kl_coef_ptr if coef_ptr is None else coef_ptr, 0,
                 None if fb_col is None else self.kl_chan_ptr + 4 * fb_col, gql.cv(), gqs.cv(), gpl.cv(),
                 gps.cv(), 1 if a1 else 0, 1 if a3 else 0)
+        if pend is not None:
+            site, gh = pend[0], pend[1]
+            a = _lib.LatentZprojArgs()
+            a.dtype, a.n, a.h, a.w, a.c, a.co = self.dt, z.n, z.h, z.w, 16, site.co
+            a.q_loc, a.q_ls, a.p_loc, a.p_ls, a.z = q_loc.cv(), q_ls.cv(), p_loc.cv(), p_ls.cv(), z.cv()
+            a.eps_in = a.eps_out = a.pa = a.hres = a.pfeat = a.out = NULL_VIEW
+            a.logt = logt
+            a.gout = gh.cv()
+            a.gz = gz.cv() if gz is not None else NULL_VIEW
+            a.g_q_loc, a.g_q_ls, a.g_p_loc, a.g_p_ls = gql.cv(), gqs.cv(), gpl.cv(), gps.cv()
+            a.w_dgrad = site.img_dg[0]
+            a.kl_coef_dev = self.kl_coef_ptr if coef_ptr is None else coef_ptr
+            a.kl_chan_scale = None if fb_col is None else self.kl_chan_ptr + 4 * fb_col
+            a.coef_stride, a.acc_q, a.acc_p = 0, 1 if a1 else 0, 1 if a3 else 0
+            if job is not None:
+                a.ride_src, a.ride_dst, a.ride_acc = job[1].cv(), job[0].cv(), 1 if job[2] else 0
+            else:
+                a.ride_src = a.ride_dst = NULL_VIEW
+            if self.lib.latent_zproj_supported(C.byref(a)):
+                self.lib.latent_zproj_bwd(C.byref(a), self.stream)
+                self.launches += 1
+                return
+            # not served after all (layout of a gradient view): the two launches
+            self._dgrad_one(pend[0], pend[1], pend[2], 0, pend[3], pend[4])
+            gz = self.grad_read(z)
+            args = args[:11] + (gz.cv(),) + args[12:]
         if job is None:
             self.lib.reparam_kl_bwd(*args, self.stream)
         else:

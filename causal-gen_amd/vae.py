@@ -581,6 +581,7 @@ class HVAE(nn.Module):
                         z = eng.on_side(lambda: eng.upsample(z_lo, res, bp))
                     else:
                         z = eng.upsample(z, res, bp)
+            h_next = None
             p_in = h if blk.q_correction else z
             run_prior = lambda: self._run_block(eng, blk.prior, [p_in, pa_sto] if blk.cond_prior else [p_in])
             # the prior and the posterior Block of a layer are independent: two streams (one fork / join per layer)
@@ -603,7 +604,12 @@ class HVAE(nn.Module):
                     kptr = kl[0] + 4 * kl[2][i] if kl is not None else self._scratch_kl(eng, B, res, zd)
                     kstride = kl[1] if kl is not None else _lib.load().reparam_kl_chunks(res, res, zd)
                     fbl = None if fb is None else (fb[0], fb[1], fb[2][i])
-                    z = eng.reparam_kl(q_loc, q_ls, p_loc, p_ls, eps, sid, logt, kptr, kstride, fb=fbl)
+                    # reparameterise + KL + z_proj (+ h + p_feat) in one launch where the kernel serves the shape
+                    fz = eng.latent_zproj(q_loc, q_ls, p_loc, p_ls, eps, sid, logt, kptr, kstride, fbl, self._site(eng, blk.z_proj), pa, h, p_feat)
+                    if fz is not None:
+                        z, h_next = fz
+                    else:
+                        z = eng.reparam_kl(q_loc, q_ls, p_loc, p_ls, eps, sid, logt, kptr, kstride, fb=fbl)
                     if collect == "z":
                         out.append(z)
                     elif collect == "q":
@@ -626,7 +632,7 @@ class HVAE(nn.Module):
                 z = eng.on_side(lambda: eng.conv(self._site(eng, blk.z_feat_proj), [z_cur, p_feat], ACT_NONE, tape_hold=hold))
                 side_ahead = True
                 feat = False
-            h = eng.conv(self._site(eng, blk.z_proj), [z_cur, pa], ACT_NONE, res1=h, res2=p_feat)
+            h = h_next if h_next is not None else eng.conv(self._site(eng, blk.z_proj), [z_cur, pa], ACT_NONE, res1=h, res2=p_feat)
             h = self._run_block(eng, blk.conv, [h])
             eng.tape.extend(hold)  # (backward order as before: z_feat_proj after the conv Block)
             if feat:

@@ -239,6 +239,33 @@ int cgen_kl_channel_sums(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t
  * (-0.5 + p_ls - q_ls + 0.5 * (exp(q_ls)^2 + (q_loc - p_loc)^2) / exp(p_ls)^2; no clamps) */
 int cgen_gaussian_kl_map(int64_t count, const float* q_loc, const float* q_ls, const float* p_loc, const float* p_ls,
                          float* out, cgen_stream_t);
+/* Latent layer in one launch (bf16, z_dim 16): reparameterise + KL (vae.py:14-30,264-269) AND z_proj with its residuals,
+ * h' = z_proj(cat[z, pa]) + h + p_feat (vae.py:288-294), as a single-K-step MFMA on the fragment the reparameterisation
+ * leaves in registers; backward: z_proj's data gradient w.r.t. z + the reparameterisation / KL gradient (+ the rider copy of
+ * cgen_reparam_kl_bwd_rider).  Same z, same Philox draws and the same KL partial layout as cgen_reparam_kl_fwd.
+ * w_fwd / w_dgrad: z_proj's forward image and the data-gradient image of its z segment (cgen_weight_prep layouts). */
+typedef struct cgen_latent_zproj_args {
+  int32_t dtype, n, h, w, c, co;            /* c: z_dim (16); co: z_proj output channels */
+  cgen_view q_loc, q_ls, p_loc, p_ls, eps_in, z, eps_out;
+  const uint64_t* rng;
+  uint32_t stream_id;
+  float logt;
+  float* kl_part;
+  int32_t kl_stride, reserved0;
+  cgen_view pa, hres, pfeat, out;           /* forward: parents (<= 16 channels), residuals (optional), h' */
+  const void* w_fwd;
+  const float* bias;
+  /* backward */
+  cgen_view gout, gz, g_q_loc, g_q_ls, g_p_loc, g_p_ls;
+  const void* w_dgrad;
+  const float* kl_coef_dev;
+  const float* kl_chan_scale;
+  int32_t coef_stride, acc_q, acc_p, ride_acc;
+  cgen_view ride_src, ride_dst;
+} cgen_latent_zproj_args;
+int cgen_latent_zproj_supported(const cgen_latent_zproj_args* args);
+int cgen_latent_zproj_fwd(const cgen_latent_zproj_args* args, cgen_stream_t);
+int cgen_latent_zproj_bwd(const cgen_latent_zproj_args* args, cgen_stream_t);
 /* z = loc + exp(ls + logt) * eps (prior sampling, vae.py:283-286); eps as above */
 int cgen_sample_gaussian(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view loc, cgen_view ls,
                          cgen_view eps_in, const uint64_t* rng, uint32_t stream_id, float logt, cgen_view z,
