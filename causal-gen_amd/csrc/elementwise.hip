@@ -330,11 +330,13 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(Shape4 s, View in, fl
 // im2col for the KSxKS stem: out[n,y,x, c*KS*KS + tap] = in[n, y+dy, x+dx, c] (zero outside the image and in the padding
 // channels [C*KS*KS, out.cpad)).  Turns the thin-K 7x7 stem (Ci = 1 or 3) into a 1x1 conv over 49*Ci channels that the
 // tiled MFMA kernels serve; the OIHW weight [Co][Ci][7][7] is already the [Co][49*Ci] matrix this needs.
-template <typename T>
-__global__ __launch_bounds__(256) void im2col_kernel(Shape4 s, int ks, int cin, View in, View out, int cphys) {
+template <typename T, int KS>  // KS > 0: compile-time kernel size (the divisions below become multiplies); 0: run-time `ks`
+__global__ __launch_bounds__(256) void im2col_kernel(Shape4 s, int ks_rt, int cin, View in, View out, int cphys) {
+  const int ks = KS > 0 ? KS : ks_rt;
   const int taps = ks * ks, pad = ks / 2;
   const int groups = cphys / 8;
   const int64_t total = (int64_t)s.n * s.h * s.w * groups;
+  const bool vec = ((uintptr_t)out.p % 16 == 0) && ((out.sn * sizeof(T)) % 16 == 0) && ((out.sh * sizeof(T)) % 16 == 0) && ((out.sw * sizeof(T)) % 16 == 0);
   GRID_STRIDE(g) {
     if (g >= total) return;
     const int cg = (int)(g % groups) * 8;
@@ -342,21 +344,29 @@ __global__ __launch_bounds__(256) void im2col_kernel(Shape4 s, int ks, int cin, 
     const int x = (int)(r % s.w); r /= s.w;
     const int y = (int)(r % s.h);
     const int n = (int)(r / s.h);
+    const T* src0 = vptr<T>(in, n, y, x);
     T vals[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int oc = cg + e;
-      T v = (T)0;
-      if (oc < cin * taps) {
-        const int c = oc / taps, tap = oc - c * taps;
-        const int yy = y + tap / ks - pad, xx = x + tap % ks - pad;
-        if (yy >= 0 && yy < s.h && xx >= 0 && xx < s.w) v = *(vptr<T>(in, n, yy, xx) + c);
-      }
-      vals[e] = v;
+      const int c = oc / taps, tap = oc - c * taps;
+      const int dy = tap / ks - pad, dx = tap - (tap / ks) * ks - pad;
+      const int yy = y + dy, xx = x + dx;
+      const bool ok = oc < cin * taps && yy >= 0 && yy < s.h && xx >= 0 && xx < s.w;
+      // (never a load under a condition: hipcc would branch around it and wait on the spot; an in-range dummy address instead)
+      const T v = *(ok ? src0 + ((int64_t)dy * in.sh + (int64_t)dx * in.sw + c) : src0);
+      vals[e] = ok ? v : (T)0;
     }
     T* dst = vptr<T>(out, n, y, x) + cg;
+    if (vec && sizeof(T) == 2) {
+      union { T e[8]; uint4 v; } u;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dst[e] = vals[e];
+      for (int e = 0; e < 8; ++e) u.e[e] = vals[e];
+      *(uint4*)dst = u.v;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dst[e] = vals[e];
+    }
   }
 }
 
@@ -627,8 +637,13 @@ extern "C" int cgen_im2col(int32_t dtype, int32_t n, int32_t h, int32_t w, int32
   CGEN_REQUIRE(out.cpad >= cphys, "cgen_im2col: out.cpad must cover the 8-channel padding (%d < %d)", out.cpad, cphys);
   Shape4 s{n, h, w, out.c};
   const int64_t items = (int64_t)n * h * w * (cphys / 8);
-  if (dtype == CGEN_F32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
-  else hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
+  if (dtype == CGEN_F32) {
+    if (ks == 7) hipLaunchKernelGGL((im2col_kernel<float, 7>), dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
+    else hipLaunchKernelGGL((im2col_kernel<float, 0>), dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
+  } else {
+    if (ks == 7) hipLaunchKernelGGL((im2col_kernel<bf16_t, 7>), dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
+    else hipLaunchKernelGGL((im2col_kernel<bf16_t, 0>), dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
+  }
   return check_launch("cgen_im2col");
 }
 
