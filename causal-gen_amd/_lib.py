@@ -97,6 +97,8 @@ PROTOTYPES = {
     "cgen_axpby": [i32, i32, i32, i32, View, View, f32, f32, i32, i32, vp],
     "cgen_nchw_to_nhwc": [i32, i32, i32, i32, i32, i32, vp, View, f32, f32, vp],
     "cgen_nhwc_to_nchw": [i32, i32, i32, i32, i32, View, vp, vp],
+    "cgen_stem_conv_supported": [i32, i32, i32, i32],
+    "cgen_stem_conv_fwd": [i32, i32, i32, i32, i32, i32, i32, View, vp, vp, View, vp],
     "cgen_im2col": [i32, i32, i32, i32, i32, View, View, vp],
     "cgen_reparam_kl_chunks": [i32, i32, i32],
     "cgen_reparam_kl_fwd": [i32, i32, i32, i32, i32, View, View, View, View, View, vp, u32, f32, View, View, vp, i32, vp],
@@ -138,7 +140,7 @@ PROTOTYPES = {
 }
 _RESTYPES = {"cgen_last_error": C.c_char_p}
 _NOCHECK = {"cgen_version", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks",
-            "cgen_block2_supported", "cgen_latent_zproj_supported"}
+            "cgen_block2_supported", "cgen_latent_zproj_supported", "cgen_stem_conv_supported"}
 
 
 class WgradBatchLaunch(C.Structure):

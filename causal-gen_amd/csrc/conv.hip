@@ -1510,6 +1510,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_mega_kernel(const Wg2P* __r
       case 12: wgrad_tile_body<6, 4, 1>(p, bx, by, bz); break;
       case 13: wgrad_tile_body<6, 4, 3>(p, bx, by, bz); break;
       case 16: wgrad_tile_body<8, 3, 1>(p, bx, by, bz); break;
+      case 33: wgrad_tile_body<1, 16, 7>(p, bx, by, bz); break;
+      case 34: wgrad_tile_body<2, 16, 7>(p, bx, by, bz); break;
       default: wgrad_tile_body<8, 3, 3>(p, bx, by, bz); break;
     }
     __syncthreads();
@@ -1521,11 +1523,16 @@ struct Wg2Geom { int ncf, njw, cwin, nsplit, tps, ntiles, tiles_x, tiles_y, n_cw
 // returns false when the shape is not served by the tiled kernel
 static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2Geom& g) {
   static const int min_hw = [] { const char* e = getenv("CGEN_WG2_MINHW"); return e ? atoi(e) : 3; }();  // tiny images waste most of a tile, but the packed launch still beats the generic kernel
-  if (!(ks == 1 || ks == 3) || H < min_hw || W < min_hw) return false;
+  if (!(ks == 1 || ks == 3 || ks == 7) || H < min_hw || W < min_hw) return false;
   const int taps = ks * ks;
   const int halo = ks / 2;
   g.ncf = co <= 16 ? 1 : (co <= 32 ? 2 : (co <= 64 ? 4 : (co <= 96 ? 6 : 8)));
   g.njw = g.ncf == 1 ? 16 : WG2_MAXACC / g.ncf;
+  if (ks == 7) {  // the 7x7 stem (Cin <= 8: ONE 16-channel group, 49 taps -> 49 fragments = 13 per wave): at most 32 co columns per workgroup
+    if (ctot8 > 16) return false;
+    g.ncf = co <= 16 ? 1 : 2;
+    g.njw = 16;
+  }
   g.n_co = ceil_div(co, g.ncf * 16);
   int maxgrp = (4 * g.njw) / taps;  // 16-channel groups per window that fit the accumulators
   if (maxgrp < 1) return false;
@@ -1575,6 +1582,14 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
 template <int NCF, int NJW>
 static void launch_wgrad2_ks(const Wg2P& p, const Wg2Geom& g, hipStream_t st) {
   dim3 grid(g.nsplit, g.n_cwin, g.n_co), block(256);
+  if (p.KS == 7) {
+    if constexpr (NJW == 16 && NCF <= 2) {
+      static bool once7 = false;
+      if (!once7) { (void)hipFuncSetAttribute((const void*)wgrad_tile_kernel<NCF, 16, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once7 = true; }
+      hipLaunchKernelGGL((wgrad_tile_kernel<NCF, 16, 7>), grid, block, g.lds, st, p);
+    }
+    return;
+  }
   if (p.KS == 3) {
     static bool once3 = false;
     if (!once3) { (void)hipFuncSetAttribute((const void*)wgrad_tile_kernel<NCF, NJW, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once3 = true; }
@@ -2500,7 +2515,7 @@ static bool wgrad_tiled_ok(const cgen_wgrad_args* a, Wg2Geom& g) {
   }
   // the kernel does its address arithmetic in 32 bits: every view must span less than 2^31 bytes (tile overhang included)
   auto fits = [&](const cgen_view& v) {
-    const int64_t ext = (int64_t)a->n * v.sn + (int64_t)(a->h + TILE_H + 2) * v.sh + (int64_t)(a->w + TILE_W + 2) * v.sw + v.c;
+    const int64_t ext = (int64_t)a->n * v.sn + (int64_t)(a->h + TILE_H + a->ks) * v.sh + (int64_t)(a->w + TILE_W + a->ks) * v.sw + v.c;
     return ext * 2 < ((int64_t)1 << 31);
   };
   if (!fits(a->gout)) return false;
@@ -2542,7 +2557,7 @@ static bool build_wg2(const cgen_wgrad_args* a, Wg2P& q, Wg2Geom& g) {
   q.tiles_x = g.tiles_x; q.tiles_y = g.tiles_y; q.ntiles = g.ntiles; q.nsplit = g.nsplit; q.tiles_per_split = g.tps;
   q.cwin = g.cwin; q.cog = g.ncf * 16; q.xt = g.xt; q.gt = g.gt;
   q.d_tx = mk_fastdiv(g.tiles_x); q.d_ty = mk_fastdiv(g.tiles_y);
-  q.variant = g.ncf * 2 + (a->ks == 3 ? 1 : 0);
+  q.variant = a->ks == 7 ? 32 + g.ncf : g.ncf * 2 + (a->ks == 3 ? 1 : 0);
   q.dbuf = g.dbuf;
   { const char* e = getenv("CGEN_WG2_DBG"); q.dbg = e ? atoi(e) : 0; }
   return true;
@@ -2584,6 +2599,11 @@ extern "C" int cgen_conv2d_wgrad_batch_plan(const cgen_wgrad_args* args, int32_t
     items.push_back(it);
   }
   static const bool mega = [] { const char* e = getenv("CGEN_WGRAD_MEGA"); return !e || atoi(e) != 0; }();
+  if (!mega) {  // the per-variant launches have no 7x7 instance: the stem goes to the caller's single launch
+    std::vector<Item> keep;
+    for (auto& it : items) { if (args[it.idx].ks == 7) eligible[it.idx] = 0; else keep.push_back(it); }
+    items.swap(keep);
+  }
   if (mega) {  // one launch for everything: longest blocks first (the resident workgroups take them round robin)
     for (auto& it : items) {
       it.key = 0;
@@ -2685,7 +2705,7 @@ extern "C" int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream)
       hipStream_t st = (hipStream_t)stream;
       switch (g.ncf) {
         case 1: launch_wgrad2_ks<1, 16>(q, g, st); break;
-        case 2: launch_wgrad2_ks<2, 12>(q, g, st); break;
+        case 2: if (a->ks == 7) launch_wgrad2_ks<2, 16>(q, g, st); else launch_wgrad2_ks<2, 12>(q, g, st); break;
         case 4: launch_wgrad2_ks<4, 6>(q, g, st); break;
         case 6: launch_wgrad2_ks<6, 4>(q, g, st); break;
         default: launch_wgrad2_ks<8, 3>(q, g, st); break;

@@ -370,6 +370,92 @@ __global__ __launch_bounds__(256) void im2col_kernel(Shape4 s, int ks_rt, int ci
   }
 }
 
+
+// ============================================================================= direct 7x7 stem conv (vae.py:104-110, 126)
+// The encoder's first layer: Cin = 1 or 3, 7x7, Cout = widths[0].  K = 49 * Cin is too thin for the tiled MFMA convs, and
+// the im2col + 1x1 route writes and re-reads a [N,H,W,56] patch tensor (132 MB at 32 x 192^2) on the forward critical path.
+// Here a workgroup stages the (8+6) x (32+6) input halo tile and the whole [49 * Cin][Cout] weight matrix in LDS as f32;
+// a thread keeps the 49-value window of its pixel in registers and accumulates all Cout outputs (weights are LDS broadcast
+// reads: every lane of a wave asks for the same address).  Output traffic only: 2 B in, 2 * Cout B out per pixel.
+#define STEM_TH 8
+#define STEM_TW 64
+template <typename T, int NCO>  // NCO: Cout / 16 (1, 2 or 4)
+__global__ __launch_bounds__(256) void stem7_kernel(int N, int H, int W, int cin, View in, const float* __restrict__ wgt,
+                                                    const float* __restrict__ bias, View out, int round_bf16) {
+  constexpr int KS = 7, TAPS = 49, PAD = 3, XH = STEM_TH + KS - 1, XW = STEM_TW + KS - 1, CO = NCO * 16;
+  constexpr int NPX = NCO == 4 ? 1 : 2;  // pixels per thread (columns tx and tx + 32): every weight read from LDS feeds NPX FMAs
+  extern __shared__ __attribute__((aligned(16))) float stem_smem[];
+  float* xs = stem_smem;                   // [cin][XH][XW]
+  float* ws = stem_smem + cin * XH * XW;   // [cin * 49][CO]   (offset is a multiple of 4 floats: XH * XW = 14 * 70)
+  const int tid = threadIdx.x;
+  const int tiles_x = (W + STEM_TW - 1) / STEM_TW, tiles_y = (H + STEM_TH - 1) / STEM_TH;
+  int b = blockIdx.x;
+  const int txi = b % tiles_x; b /= tiles_x;
+  const int tyi = b % tiles_y;
+  const int n = b / tiles_y;
+  const int y0 = tyi * STEM_TH, x0 = txi * STEM_TW;
+  for (int i = tid; i < cin * TAPS * CO; i += 256) {  // OIHW [co][c][7][7] -> [c * 49 + tap][co]
+    const int co = i % CO, k = i / CO;
+    float v = wgt[(size_t)co * cin * TAPS + k];
+    if (round_bf16) v = bf2f(f2bf(v));  // the bf16 engine multiplies bf16-rounded weights everywhere else too
+    ws[i] = v;
+  }
+  for (int i = tid; i < cin * XH * XW; i += 256) {
+    const int xx = i % XW, r = i / XW, yy = r % XH, c = r / XH;
+    const int gy = y0 + yy - PAD, gx = x0 + xx - PAD;
+    const bool ok = gy >= 0 && gy < H && gx >= 0 && gx < W;
+    const T* src = vptr<T>(in, n, ok ? gy : 0, ok ? gx : 0) + c;
+    const float v = Elem<T>::ld(src);
+    xs[i] = ok ? v : 0.f;
+  }
+  __syncthreads();
+  const int ty = tid >> 5, tx = tid & 31;
+#pragma unroll 1
+  for (int half = 0; half < 2 / NPX; ++half) {  // (NCO == 4: one pixel at a time, twice)
+    float acc[NPX][CO];
+#pragma unroll
+    for (int q = 0; q < NPX; ++q)
+#pragma unroll
+      for (int j = 0; j < CO; ++j) acc[q][j] = bias ? bias[j] : 0.f;
+    for (int c = 0; c < cin; ++c) {
+      float win[NPX][TAPS];
+      const float* xp = xs + (c * XH + ty) * XW + tx + half * 32;
+#pragma unroll
+      for (int q = 0; q < NPX; ++q)
+#pragma unroll
+        for (int dy = 0; dy < KS; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < KS; ++dx) win[q][dy * KS + dx] = xp[dy * XW + dx + q * 32];
+      const float* wp = ws + (size_t)c * TAPS * CO;
+#pragma unroll  // (fully: a run-time index would put the window in scratch)
+      for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+        for (int j = 0; j < CO; j += 4) {
+          const float4 w4 = *(const float4*)(wp + t * CO + j);
+#pragma unroll
+          for (int q = 0; q < NPX; ++q) {
+            const float xv = win[q][t];
+            acc[q][j] = fmaf(xv, w4.x, acc[q][j]); acc[q][j + 1] = fmaf(xv, w4.y, acc[q][j + 1]);
+            acc[q][j + 2] = fmaf(xv, w4.z, acc[q][j + 2]); acc[q][j + 3] = fmaf(xv, w4.w, acc[q][j + 3]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NPX; ++q) {
+      const int gy = y0 + ty, gx = x0 + tx + (half + q) * 32;
+      if (gy < H && gx < W) {
+        T* dst = vptr<T>(out, n, gy, gx);
+#pragma unroll
+        for (int j = 0; j < CO; j += 4) {
+          float v[4] = {acc[q][j], acc[q][j + 1], acc[q][j + 2], acc[q][j + 3]};
+          VecIO<T, 4>::st(dst + j, v);
+        }
+      }
+    }
+  }
+}
+
 static inline int grid_for(int64_t items) {
   int64_t b = (items + 255) / 256;
   if (b < 1) b = 1;
@@ -645,6 +731,31 @@ extern "C" int cgen_im2col(int32_t dtype, int32_t n, int32_t h, int32_t w, int32
     else hipLaunchKernelGGL((im2col_kernel<bf16_t, 0>), dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
   }
   return check_launch("cgen_im2col");
+}
+
+
+extern "C" int cgen_stem_conv_supported(int32_t dtype, int32_t cin, int32_t ks, int32_t co) {
+  return (dtype == CGEN_F32 || dtype == CGEN_BF16) && ks == 7 && cin >= 1 && cin <= 4 && (co == 16 || co == 32 || co == 64);
+}
+
+extern "C" int cgen_stem_conv_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t ks, int32_t co, cgen_view in,
+                                  const float* weight_oihw, const float* bias, cgen_view out, cgen_stream_t stream) {
+  CHECK_DTYPE("cgen_stem_conv_fwd");
+  CGEN_REQUIRE(cgen_stem_conv_supported(dtype, cin, ks, co), "cgen_stem_conv_fwd: shape not served (7x7, Cin <= 4, Cout 16 / 32 / 64)");
+  CGEN_REQUIRE(in.p && out.p && weight_oihw && in.c == cin && out.c == co && n > 0 && h > 0 && w > 0, "cgen_stem_conv_fwd: bad args");
+  const int esz = esz_of(dtype);
+  CGEN_REQUIRE(vec4_ok(esz, co, {&out}), "cgen_stem_conv_fwd: the output view must allow 4-channel vector stores");
+  const int tiles = n * ((h + STEM_TH - 1) / STEM_TH) * ((w + STEM_TW - 1) / STEM_TW);
+  const size_t lds = (size_t)(cin * (STEM_TH + 6) * (STEM_TW + 6) + cin * 49 * co) * sizeof(float);
+  const int rb = dtype == CGEN_BF16 ? 1 : 0;
+#define STEM_LAUNCH(T_, NCO_) hipLaunchKernelGGL((stem7_kernel<T_, NCO_>), dim3(tiles), dim3(256), lds, (hipStream_t)stream, n, h, w, cin, mk(in), weight_oihw, bias, mk(out), rb)
+  if (dtype == CGEN_F32) {
+    if (co == 16) STEM_LAUNCH(float, 1); else if (co == 32) STEM_LAUNCH(float, 2); else STEM_LAUNCH(float, 4);
+  } else {
+    if (co == 16) STEM_LAUNCH(bf16_t, 1); else if (co == 32) STEM_LAUNCH(bf16_t, 2); else STEM_LAUNCH(bf16_t, 4);
+  }
+#undef STEM_LAUNCH
+  return check_launch("cgen_stem_conv_fwd");
 }
 
 extern "C" int cgen_nhwc_to_nchw(int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, cgen_view in, float* dst,

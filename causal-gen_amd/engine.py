@@ -244,6 +244,7 @@ class Engine:
         # 76 launches fewer per ukbb192 step (1066 -> 990) and NO measurable gain (17.17 vs 17.15 ms; counterfactuals 1 % slower):
         # the merged kernel is as long as the two it replaces.  Off by default, tested.
         self.lat_fuse = os.environ.get("CGEN_LAT_FUSE", "0") != "0"
+        self._side_join_pending = False
         self._lat_fused, self._zp_pending = set(), None
         self.blk_fuse = int(os.environ.get("CGEN_BLK_FUSE", "0"))
         self.blk_minres = int(os.environ.get("CGEN_BLK_MINRES", "24"))
@@ -572,6 +573,21 @@ class Engine:
         ent[1].append((e0, e1))
         ent[2] += 1
 
+    def stem(self, site, x):
+        """Encoder.stem (vae.py:104-110,126): the direct 7x7 kernel (csrc/elementwise.hip) for a 7x7 site -- its weight
+        gradient reads x itself through the tiled kernel's 7x7 instance (bf16) or the generic kernel (f32) -- else im2col +
+        1x1 conv over the 49 * Cin patch channels."""
+        if site.im2col:
+            return self.conv(site, [self.im2col(x, site.im2col)], ACT_NONE)
+        out = self.new(x.n, x.h, x.w, site.co)
+        b = site.conv.bias
+        self._timed("conv_fwd", site, x, lambda: self.lib.stem_conv_fwd(
+            self.dt, x.n, x.h, x.w, site.ci, site.ks, site.co, x.cv(), site.conv.weight.data_ptr(), b.data_ptr() if b is not None else None,
+            out.cv(), self.stream))
+        if self.recording:
+            self.tape.append((self._bw_conv, (site, [x], ACT_NONE, out, None, None)))
+        return out
+
     def im2col(self, x, ks):
         c = x.c * ks * ks
         out = self.new(x.n, x.h, x.w, c, rg=False)
@@ -873,6 +889,7 @@ class Engine:
 
     def join_side(self):
         torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)
+        self._side_join_pending = False
 
     def _defer_wgrad(self):
         return self.wgrad_batch or (self.wgrad_streams > 1 and self.prof is None)
@@ -1029,6 +1046,8 @@ class Engine:
             self._wg_total = sum(2.0 * a[0].ci * a[0].taps * a[0].co * a[1][0].n * a[1][0].h * a[1][0].w
                                  for fn, a, _ in self.tape if fn == self._bw_conv and self._needs_wgrad(a[0]))
         main_t = torch.cuda.current_stream(self.device)
+        if self._side_join_pending:  # side-stream work of the forward pass nobody has joined yet (the stem's im2col)
+            self.join_side()
         two = (self.bwd_branch and self.prof is None and self._fwd_side is not None and self.stream == main_t.cuda_stream
                and any(e[2] for e in self.tape))
         if not two:

@@ -11,6 +11,7 @@ Layout: activations live NHWC in an arena; API tensors are accepted as NCHW (eit
 as NCHW-shaped tensors.  ``HVAE.compute_dtype`` selects "f32" (exact f32-MFMA path, parity) or "bf16".
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -74,6 +75,16 @@ def sample_gaussian(loc: Tensor, logscale: Tensor) -> Tensor:
 _SA_ENGINES = weakref.WeakKeyDictionary()  # standalone engines of holder modules used outside an HVAE (inference only)
 
 
+def _stem_site(name, conv, index, dtype=None):
+    """The 7x7 stem: a real 7x7 site when the direct kernel serves it (Engine.stem), else im2col + 1x1 over 49 * Cin channels."""
+    lib = _lib.load()
+    direct = (os.environ.get("CGEN_STEM_DIRECT", "1") != "0" and conv.kernel_size[0] == 7
+              and lib.stem_conv_supported(_lib.BF16 if dtype == "bf16" else _lib.F32, conv.in_channels, 7, conv.out_channels))
+    if direct:
+        return ConvSite(name, conv, [conv.in_channels], [False], index)
+    return ConvSite(name, conv, [conv.in_channels * conv.kernel_size[0] ** 2], [False], index, as_1x1=True)
+
+
 def _block_sites(sites, name, blk, seg_c, seg_rg):
     cs = blk.convs()
     sites.append(ConvSite(f"{name}.conv.1", cs[0], seg_c, seg_rg, len(sites)))
@@ -110,7 +121,7 @@ def run_block(eng, blk, segs):
 def run_encoder(eng, enc, x):
     """Encoder.forward (vae.py:112-134): {resolution: activation}."""
     stem = eng.site_by_id[id(enc.stem)]
-    h = eng.conv(stem, [eng.im2col(x, stem.im2col)], ACT_NONE)
+    h = eng.stem(stem, x)
     acts = {}
     for blk in enc.blocks:
         h = run_block(eng, blk, [h])
@@ -212,7 +223,7 @@ class Encoder(nn.Module):
     @torch.no_grad()
     def _forward_standalone(self, x):
         def sites():
-            out = [ConvSite("stem", self.stem, [self.stem.in_channels * 49], [False], 0, as_1x1=True)]
+            out = [_stem_site("stem", self.stem, 0)]
             for i, b in enumerate(self.blocks):
                 _block_sites(out, f"blocks.{i}", b, [b.convs()[0].in_channels], [True])
             return out
@@ -497,7 +508,7 @@ class HVAE(nn.Module):
             _block_sites(sites, name, blk, seg_c, seg_rg)
 
         C = self.input_channels
-        add("encoder.stem", self.encoder.stem, [C * 49], [False], as_1x1=True)
+        sites.append(_stem_site("encoder.stem", self.encoder.stem, len(sites), self.compute_dtype))
         for i, b in enumerate(self.encoder.blocks):
             add_block(f"encoder.blocks.{i}", b, [b.convs()[0].in_channels], [True])
         zd, ctx = self.z_dim, self.context_dim

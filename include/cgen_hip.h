@@ -176,6 +176,13 @@ int cgen_axpby(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view in, cge
 /* NCHW (f32 or u8, contiguous) -> NHWC view in `dtype`: out = (in - sub) * mul */
 int cgen_nchw_to_nhwc(int32_t src_is_u8, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, const void* src,
                       cgen_view out, float sub, float mul, cgen_stream_t);
+/* Direct 7x7 stem conv, forward (vae.py:104-110,126: Encoder.stem, Cin 1..4, Cout 16 / 32 / 64): halo tile and the whole
+ * weight matrix in LDS, one output pixel x all Cout per thread; weight_oihw / bias are the f32 parameters themselves (the bf16
+ * engine rounds the weights to bf16 on load).  No patch tensor on the forward path; cgen_im2col + the 1x1 weight-gradient
+ * kernels remain the backward route. */
+int cgen_stem_conv_supported(int32_t dtype, int32_t cin, int32_t ks, int32_t co);
+int cgen_stem_conv_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t ks, int32_t co, cgen_view in,
+                       const float* weight_oihw, const float* bias, cgen_view out, cgen_stream_t);
 /* im2col for the thin-K stem conv (vae.py:104-110): out[n,y,x, c*ks*ks + tap] = in[n, y+dy, x+dx, c], zeros outside the
  * image and in out's padding channels (out.c = in.c*ks*ks, out.cpad = ceil8(out.c)).  The 7x7 stem then runs as a 1x1
  * conv over 49*Ci channels on the MFMA kernels, with the OIHW weight used as the [Co][49*Ci] matrix unchanged. */

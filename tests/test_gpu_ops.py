@@ -523,3 +523,50 @@ def _model_like_cases(n, seed):
 @pytest.mark.parametrize("case,dtype", _model_like_cases(28, 5))
 def test_conv_fwd_bwd_model_like_shapes(case, dtype):
     test_conv_fwd_bwd(case, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cin,co,h,w", [(1, 32, 40, 70), (3, 16, 33, 33), (1, 16, 8, 8), (3, 64, 20, 45), (1, 32, 5, 3)])
+def test_stem_direct_7x7(dtype, cin, co, h, w):
+    """Encoder.stem (vae.py:104-110) as a real 7x7 site: the direct forward kernel and the 7x7 instance of the tiled weight-gradient
+    kernel (bf16; the generic kernel in f32), no patch tensor -- against torch conv2d and against the im2col + 1x1 route they
+    replace; ragged tiles, images smaller than the halo."""
+    from causal_gen_amd.engine import ConvSite, Engine
+
+    g = torch.Generator().manual_seed(cin * 100 + co + h)
+    conv = torch.nn.Conv2d(cin, co, 7, padding=3)
+    x = torch.randn(3, cin, h, w, generator=g)
+    gout = torch.randn(3, co, h, w, generator=g)
+    if dtype == "bf16":
+        x, gout = x.bfloat16().float(), gout.bfloat16().float()
+    outs = {}
+    for direct in (True, False):
+        eng = Engine("cuda", dtype)
+        holder = torch.nn.ModuleList([conv]).cuda()
+        site = ConvSite("stem", holder[0], [cin], [False], 0) if direct else ConvSite("stem", holder[0], [cin * 49], [False], 0, as_1x1=True)
+        eng.bind(holder, [site])
+        eng.begin()
+        eng.prepare_weights(force=True)
+        eng.recording = True
+        xt = eng.from_nchw(x.cuda())
+        n0 = eng.launches
+        y = eng.stem(site, xt)
+        nl = eng.launches - n0
+        gy = eng.seed_grad(y)
+        eng.lib.axpby(eng.dt, y.n, y.h, y.w, eng.from_nchw(gout.cuda()).cv(), gy.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
+        eng.recording = False
+        eng.backward()
+        torch.cuda.synchronize()
+        outs[direct] = (nhwc_to_torch(eng, y), eng.param_grad_view(holder[0].weight).cpu().clone(), eng.param_grad_view(holder[0].bias).cpu().clone(), nl)
+    wq = conv.weight.detach().cpu().bfloat16().float() if dtype == "bf16" else conv.weight.detach().cpu()
+    wr = wq.clone().requires_grad_(True)
+    br = conv.bias.detach().cpu().clone().requires_grad_(True)
+    ref = F.conv2d(x, wr, br, padding=3)
+    ref.backward(gout)
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == "f32" else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(outs[True][0], ref.detach(), **tol)
+    torch.testing.assert_close(outs[True][0], outs[False][0], **tol)
+    gtol = 1e-4 if dtype == "f32" else 2e-2
+    for k, r in ((1, wr.grad), (2, br.grad)):
+        assert float((outs[True][k] - r).norm()) <= gtol * float(r.norm()) + 1e-5
+        assert float((outs[False][k] - r).norm()) <= gtol * float(r.norm()) + 1e-5
