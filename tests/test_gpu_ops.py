@@ -570,3 +570,61 @@ def test_stem_direct_7x7(dtype, cin, co, h, w):
     for k, r in ((1, wr.grad), (2, br.grad)):
         assert float((outs[True][k] - r).norm()) <= gtol * float(r.norm()) + 1e-5
         assert float((outs[False][k] - r).norm()) <= gtol * float(r.norm()) + 1e-5
+
+
+def _philox_words(seed, offset, stream, idx):
+    """numpy twin of Philox::gen (csrc/common.h): Philox4x32-10 words for counter `idx` (uint64 array) -> [len(idx), 4] uint32."""
+    import numpy as np
+
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask = np.uint64(0xFFFFFFFF)
+    idx = np.asarray(idx, dtype=np.uint64)
+    c0, c1 = idx & mask, idx >> np.uint64(32)
+    c2 = np.full_like(idx, (np.uint64(offset) & mask) ^ np.uint64((stream * 0x9E3779B9) & 0xFFFFFFFF))
+    c3 = np.full_like(idx, ((np.uint64(offset) >> np.uint64(32)) + np.uint64(stream)) & mask)
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+    return np.stack([c0, c1, c2, c3], 1).astype(np.uint32)
+
+
+def _u01(r):
+    import numpy as np
+
+    return ((r >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+
+
+def test_dmol_sampling_is_the_reference_formula_on_the_kernels_own_uniforms():
+    """discretized_mix_logistic sampling (dmol.py:121-161): Gumbel-max over the mixture logits, then a logistic draw per channel,
+    autoregressive means, clamp.  The kernel's uniforms are Philox words at (pixel * 4 + {0,1,2}); a numpy Philox twin rebuilds
+    them and the oracle's dmol_sample fed with them must give the same pixels and scales -- with and without a temperature."""
+    import numpy as np
+    from oracle import dmol_ref
+
+    d = load_golden("ops.pt")["dmol"]
+    l = d["l"]
+    N, H, W, _ = l.shape
+    eng, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]])
+    lt = eng.wrap_nhwc(l.cuda().contiguous())
+    seed, offset, stream = 1234567, 3, 5
+    rng = torch.tensor([seed, offset], dtype=torch.int64, device="cuda")
+    gi = np.arange(N * H * W, dtype=np.uint64)
+    r, r2, r3 = (_philox_words(seed, offset, stream, gi * np.uint64(4) + np.uint64(k)) for k in range(3))
+    mixw = np.concatenate([r, r2, r3[:, :2]], 1)                                   # 10 mixture uniforms per pixel
+    pixw = np.stack([r3[:, 2], r3[:, 3], r2[:, 3] ^ np.uint32(0x9E3779B9)], 1)     # one per channel
+    f = lambda wds: torch.from_numpy(np.float32(1e-5) + np.float32(1.0 - 2e-5) * _u01(wds))
+    u_mix = f(mixw).view(N, H, W, 10)
+    u_pix = f(pixw).view(N, H, W, 3)
+    for t in (None, 0.7):
+        xo, so = torch.empty(N, 3, H, W, device="cuda"), torch.empty(N, 3, H, W, device="cuda")
+        eng.lib.dmol_decode(eng.dt, N, H, W, lt.cv(), 2, rng.data_ptr(), stream, 0.0 if t is None else float(np.log(t)), xo.data_ptr(),
+                            so.data_ptr(), eng.stream)
+        rx, rs = dmol_ref.dmol_sample(l, t=t, u_mix=u_mix, u_pix=u_pix)
+        rx = rx.clamp(-1, 1)
+        # a Gumbel arg-max decided by < 1e-6 may fall the other way in f32 device math: allow a handful of pixels
+        bad = ((xo.cpu().permute(0, 2, 3, 1) - rx).abs() > 1e-4).any(-1)
+        assert int(bad.sum()) <= max(1, N * H * W // 500), int(bad.sum())
+        torch.testing.assert_close(so.cpu().permute(0, 2, 3, 1)[~bad], rs[~bad], rtol=1e-4, atol=1e-6)

@@ -80,3 +80,33 @@ def test_dgaussnet_standalone(C):
     torch.testing.assert_close(sc.cpu(), rs, rtol=1e-4, atol=1e-6)
     xr, _ = lk.sample(h.cuda(), return_loc=False)
     assert torch.isfinite(xr).all() and float(xr.abs().max()) <= 1.0 and not torch.equal(xr, xs)
+
+
+@pytest.mark.parametrize("C", [1, 3])
+def test_dgauss_sampling_is_the_reference_formula_on_the_kernels_own_noise(C):
+    """DGaussNet.sample(h, return_loc=False) (vae.py:413-422): x = clamp(loc + exp(logscale) * eps).  The kernel draws eps from
+    Philox at the NCHW element index; `cgen_philox_normal` reproduces that stream on the same state, and the oracle's restatement of
+    the reference formula fed with it must give the same pixels -- sampling parity, not just finite / in-range / reproducible."""
+    from causal_gen_amd import _lib, vae
+    from causal_gen_amd.hps import setup_hparams
+    from oracle import hvae_ref
+
+    hp = setup_hparams("morphomnist", input_channels=C)
+    torch.manual_seed(7)
+    lk = vae.DGaussNet(hp).cuda()
+    with torch.no_grad():
+        for p in lk.parameters():
+            p.add_(0.3 * torch.randn_like(p))
+    sd = _sd(lk, "likelihood.")
+    h = torch.randn(4, hp.widths[0], 12, 12, generator=torch.Generator().manual_seed(8))
+    xs, sc = lk.sample(h.cuda(), return_loc=False)
+    eng = vae._SA_ENGINES[lk]
+    eps = torch.empty(xs.numel(), device="cuda")
+    _lib.load().philox_normal(eps.data_ptr(), eps.numel(), eng.rng_ptr(), 978, torch.cuda.current_stream().cuda_stream)
+    eps = eps.view_as(xs).cpu()
+    rx, rs = hvae_ref.dgauss_sample(sd, hp, h, return_loc=False, noise=lambda like: eps)
+    torch.testing.assert_close(sc.cpu(), rs, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(xs.cpu(), rx, rtol=1e-4, atol=2e-5)
+    assert float((xs.cpu() - hvae_ref.dgauss_sample(sd, hp, h)[0]).abs().max()) > 1e-3  # (the noise did something)
+    xs2, _ = lk.sample(h.cuda(), return_loc=False)
+    assert not torch.equal(xs, xs2)  # a fresh draw per call
