@@ -50,7 +50,9 @@ def test_forward_elbo_and_grads(name):
         d = (got[n].cpu() - g).abs().max().item()
         scale = g.abs().max().item() + 1e-8
         worst = max(worst, d / scale)
-        assert d / scale < 2e-3, (n, d, scale)
+        # measured on MI355X (f32 MFMA 16x16x4, f32 accumulation in a different order than ATen's CPU kernels, fast exp / tanh):
+        # 3e-5 .. 3.7e-4 of the tensor's largest entry over the seven fixtures; the bound leaves a factor ~2
+        assert d / scale < 7e-4, (n, d, scale)
     for n, p in m.named_parameters():
         if n not in f["grads"]:
             assert p.grad is None, n
