@@ -1522,7 +1522,9 @@ struct Wg2Geom { int ncf, njw, cwin, nsplit, tps, ntiles, tiles_x, tiles_y, n_cw
 
 // returns false when the shape is not served by the tiled kernel
 static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2Geom& g) {
-  static const int min_hw = [] { const char* e = getenv("CGEN_WG2_MINHW"); return e ? atoi(e) : 3; }();  // tiny images waste most of a tile, but the packed launch still beats the generic kernel
+  // tiny images waste most of a tile, but the packed launch still beats the generic kernel -- down to 1x1 images (round 2): the
+  // 21 generic launches of ukbb192's 1x1-resolution layers sat in the exposed tail of the step (0.21 ms); packed: 16.89 vs 17.1 ms
+  static const int min_hw = [] { const char* e = getenv("CGEN_WG2_MINHW"); return e ? atoi(e) : 1; }();
   if (!(ks == 1 || ks == 3 || ks == 7) || H < min_hw || W < min_hw) return false;
   const int taps = ks * ks;
   const int halo = ks / 2;
