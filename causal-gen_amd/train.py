@@ -76,7 +76,11 @@ class TrainStep:
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.bucket_elems = int(bucket_mb * (1 << 20) // 4)
-        if self.world > 1 and getattr(model, "free_bits", 0) > 0:
+        import os as _os0
+        # the data-parallel machinery (communication stream, split backward graph, bucketed all-reduce) is active with more than
+        # one rank -- or, for a dry run of exactly that code through RCCL on ONE GPU, with CGEN_DP_FORCE=1 and a 1-rank group
+        self.dp = self.world > 1 or (process_group is not None and _os0.environ.get("CGEN_DP_FORCE") == "1")
+        if self.dp and getattr(model, "free_bits", 0) > 0:
             self.use_graph = False  # free bits exchange per-channel KL sums inside the forward pass (vae.py): not capturable
         model.train()
         eng = model.engine()
@@ -104,7 +108,7 @@ class TrainStep:
         # DP: all-reduce of the already-final half of the gradient under the rest of the backward pass (CGEN_DP_OVERLAP=0: the
         # serialized round-1 form, kept for A/B and as the bit-equality reference)
         import os as _os
-        self.dp_overlap = self.world > 1 and _os.environ.get("CGEN_DP_OVERLAP", "1") != "0"
+        self.dp_overlap = self.dp and _os.environ.get("CGEN_DP_OVERLAP", "1") != "0"
         if self.dp_overlap:
             # a second background flush at the end of the DECODER's backward pass (75.5 % of the weight-gradient work of the
             # 192^2 presets; costs 0.8 % on one GPU): from there on every decoder / likelihood gradient is final -- 48 of the
@@ -167,7 +171,7 @@ class TrainStep:
     def _allreduce(self, out3):
         """Average the flat gradient (and the reported scalars, whose NaN-ness feeds the skip predicate) over the
         data-parallel ranks: a few large buckets, not 800 small tensors (xGMI rings are per-link bound)."""
-        if self.world > 1:
+        if self.dp:
             dp.bucketed_allreduce_mean(self._gbuf(), self.bucket_elems, self.pg, extra=(out3,))
 
     # -- gradient all-reduce overlapped with the backward pass (north_star; SURVEY 5 / 8e) -------------------------
@@ -371,11 +375,11 @@ class TrainStep:
             else:
                 with torch.cuda.graph(g1):
                     so = self._fwd_bwd(sx, sp, beta)
-                    if self.world == 1 and do_step:
+                    if not self.dp and do_step:
                         self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
                         self._optim(so)
             g2 = None
-            if self.world > 1 and do_step:
+            if self.dp and do_step:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2):
                     self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
