@@ -269,7 +269,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
-    if world > 1:
+    # more than one rank -- or a ONE-rank dry run of the same code through RCCL (CGEN_DP_FORCE=1 under torch.distributed.run):
+    # process group, barriers, max-over-ranks timing, split backward graph and bucketed all-reduces, on a single GPU
+    distributed = world > 1 or (os.environ.get("CGEN_DP_FORCE") == "1" and "WORLD_SIZE" in os.environ)
+    if distributed:
         import torch.distributed as dist
 
         backend = os.environ.get("CGEN_DIST_BACKEND", "nccl")  # nccl == RCCL on ROCm
@@ -292,20 +295,20 @@ def main():
         out = ts.step(x, pa)
 
     def sync():
-        if world > 1:
+        if distributed:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
     sync()
-    ts.time_comm = world > 1
+    ts.time_comm = distributed
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = ts.step(x, pa)
     sync()
     dt = time.perf_counter() - t0
     ts.time_comm = False
-    exposed_comm = ts.exposed_comm_ms() if world > 1 else None
-    if world > 1:
+    exposed_comm = ts.exposed_comm_ms() if distributed else None
+    if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -332,11 +335,12 @@ def main():
             "model_mfma_frac": img_s * gf * 1e9 / 1e12 / (MFMA_PEAK_TF[a.dtype] * world),
             "param_abs_sum": float(sum(p.detach().double().abs().sum() for p in m.parameters())),
         }
-        if world > 1:
+        if distributed:
             res["dp"] = {"allreduce_overlapped_with_backward": bool(ts.dp_overlap and ts.early_ranges),
                          "exposed_comm_ms_per_step": exposed_comm,
                          "early_bytes": 4 * sum(hi - lo for lo, hi in (ts.early_ranges or [])),
                          "late_bytes": 4 * sum(hi - lo for lo, hi in (ts.late_ranges or [(0, ts._gbuf().numel())])),
+                         "overlap_policy": getattr(ts, "dp_policy", None),
                          "backend": os.environ.get("CGEN_DIST_BACKEND", "nccl")}
         res["roofline"] = roof
         if not a.no_cf:
@@ -366,7 +370,7 @@ def main():
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(a.config)
         print(json.dumps(res))
-    if world > 1:
+    if distributed:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

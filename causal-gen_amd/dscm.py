@@ -110,7 +110,7 @@ class GraphedCounterfactual:
             sx, sp, sc = x.clone(), StaticParents(parents), StaticParents(cf_parents)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):  # (a live NCCL watchdog thread must not invalidate the capture: train.CAPTURE_MODE)
                 so = counterfactual(vae, sx, sp.t, sc.t, **self.kw)
             self.graphs[key] = (g, sx, sp, sc, so)
             return out

@@ -45,6 +45,12 @@ def preprocess_batch(args, batch, expand_pa=False):
     return batch
 
 
+# hipGraph captures are THREAD-LOCAL: with a ProcessGroupNCCL alive, its watchdog thread polls events (hipEventQuery) at any
+# moment, which a capture in the default "global" mode treats as an illegal call and dies of ("operation failed due to a previous
+# error during capture") -- found by tools/dp_rccl_dryrun.py, invisible to the gloo tests
+CAPTURE_MODE = "thread_local"
+
+
 def _subtract_ranges(whole, holes):
     """[lo, hi) ranges of `whole` not covered by `holes` (both sorted, non-overlapping)."""
     out = []
@@ -105,10 +111,22 @@ class TrainStep:
         self.out3 = None
         self.beta = float(args.beta)
         self.it = 0
-        # DP: all-reduce of the already-final half of the gradient under the rest of the backward pass (CGEN_DP_OVERLAP=0: the
-        # serialized round-1 form, kept for A/B and as the bit-equality reference)
+        # DP: the gradient exchange either follows the backward graph (serialized: graph | bucketed all-reduce | optimiser graph)
+        # or travels under it (overlap: the backward graph is cut where the decoder half of the gradient is final, that half is
+        # exchanged on the communication stream under the encoder's backward pass).  Overlap is not free: it needs a second
+        # background weight-gradient flush (+0.35 ms) and a third graph, +1.0 ms per step on ukbb192 measured on one MI355X
+        # through a 1-rank RCCL group (tools/dp_rccl_dryrun.py, bench.py with CGEN_DP_FORCE=1: 18.43 vs 17.39 ms), while the
+        # serialized exchange of its 69.5 MB costs ~0.4 ms on an xGMI node (2 (N-1)/N x bytes at ~300 GB/s bus bandwidth).
+        # CGEN_DP_OVERLAP=1 / 0 forces a form; unset, the step overlaps only when the estimated exchange exceeds that price.
         import os as _os
-        self.dp_overlap = self.dp and _os.environ.get("CGEN_DP_OVERLAP", "1") != "0"
+        _ov = _os.environ.get("CGEN_DP_OVERLAP")
+        if _ov is None:
+            est_s = 4.0 * n * 2.0 * max(self.world - 1, 0) / max(self.world, 1) / float(_os.environ.get("CGEN_DP_BUS_GBS", "300")) / 1e9
+            self.dp_overlap = self.dp and est_s > 1.0e-3
+            self.dp_policy = "auto: estimated exchange %.2f ms %s the ~1 ms the overlapped form costs" % (1e3 * est_s, ">" if self.dp_overlap else "<=")
+        else:
+            self.dp_overlap = self.dp and _ov != "0"
+            self.dp_policy = "forced by CGEN_DP_OVERLAP=" + _ov
         if self.dp_overlap:
             # a second background flush at the end of the DECODER's backward pass (75.5 % of the weight-gradient work of the
             # 192^2 presets; costs 0.8 % on one GPU): from there on every decoder / likelihood gradient is final -- 48 of the
@@ -172,7 +190,14 @@ class TrainStep:
         """Average the flat gradient (and the reported scalars, whose NaN-ness feeds the skip predicate) over the
         data-parallel ranks: a few large buckets, not 800 small tensors (xGMI rings are per-link bound)."""
         if self.dp:
+            t0 = None
+            if self.time_comm:  # (serialized form: the whole exchange is exposed)
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record()
             dp.bucketed_allreduce_mean(self._gbuf(), self.bucket_elems, self.pg, extra=(out3,))
+            if t0 is not None:
+                t1.record()
+                self._comm_events.append((t0, t1))
 
     # -- gradient all-reduce overlapped with the backward pass (north_star; SURVEY 5 / 8e) -------------------------
     def _ranges_of(self, ids):
@@ -358,11 +383,11 @@ class TrainStep:
 
                 def at_split():
                     g1.capture_end()
-                    g1b.capture_begin(pool=g1.pool())
+                    g1b.capture_begin(pool=g1.pool(), capture_error_mode=CAPTURE_MODE)
                     fired.append(True)
 
                 with torch.cuda.stream(cap):
-                    g1.capture_begin()
+                    g1.capture_begin(capture_error_mode=CAPTURE_MODE)
                     self.eng.on_split = at_split
                     try:
                         so = self._fwd_bwd(sx, sp, beta)
@@ -373,7 +398,7 @@ class TrainStep:
                 if not fired:
                     g1b = None
             else:
-                with torch.cuda.graph(g1):
+                with torch.cuda.graph(g1, capture_error_mode=CAPTURE_MODE):
                     so = self._fwd_bwd(sx, sp, beta)
                     if not self.dp and do_step:
                         self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
@@ -381,7 +406,7 @@ class TrainStep:
             g2 = None
             if self.dp and do_step:
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2):
+                with torch.cuda.graph(g2, capture_error_mode=CAPTURE_MODE):
                     self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
                     self._optim(so)
             self.graphs[key] = (g1, g2, sx, spb, so, g1b)
