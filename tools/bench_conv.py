@@ -128,8 +128,10 @@ def main():
                 v = st.cpu().tolist()
                 n = v[63]
                 d = [v[i + 1] - v[i] for i in range(n - 1)]
-                print("   stamps(cycles): setup %d | per tile [issue, wait, act, mfma, bar]: %s | tail %d" % (
-                    d[0], [d[1 + k * 5:1 + k * 5 + 5] for k in range(min(3, (n - 3) // 5))], d[-1]))
+                # stamps of workgroup 0: entry, setup done, then per tile [barrier (tile landed), next tile's DMA issued,
+                # activation pass + barrier, MFMAs], ..., partial slab written
+                print("   stamps(cycles): setup %d | per tile [wait+barrier, issue next, act, mfma]: %s | tail %d" % (
+                    d[0], [d[1 + k * 4:1 + k * 4 + 4] for k in range(min(5, (n - 3) // 4))], d[-1]))
         for k, us in res.items():
             print("%-5s %s N%d res%-3d ci%-12s co%-3d ks%d : %8.1f us  %7.1f TF/s  %6.2f TB/s(alg)" % (
                 k, dtype, N, R, str(segc), Co, ks, us, flops / us / 1e6, bytes_alg / us / 1e6))
