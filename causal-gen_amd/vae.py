@@ -94,6 +94,23 @@ def _block_sites(sites, name, blk, seg_c, seg_rg):
         sites.append(ConvSite(f"{name}.width_proj", blk.width_proj, seg_c, seg_rg, len(sites)))
 
 
+def _decoder_sites(sites, dec, prefix, zd, ctx):
+    """Every conv of the decoder with its input segmentation (the virtual torch.cat's of vae.py:176,188,294,300)."""
+    for i, b in enumerate(dec.blocks):
+        w = b.in_width
+        n = f"{prefix}blocks.{i}"
+        if b.cond_prior:
+            _block_sites(sites, n + ".prior", b.prior, [w, ctx], [True, False])
+        else:
+            _block_sites(sites, n + ".prior", b.prior, [w], [True])
+        if b.stochastic:
+            _block_sites(sites, n + ".posterior", b.posterior, [w, ctx, w], [True, False, True])
+        sites.append(ConvSite(n + ".z_proj", b.z_proj, [zd, ctx], [True, False], len(sites)))
+        if not b.q_correction:
+            sites.append(ConvSite(n + ".z_feat_proj", b.z_feat_proj, [zd, w], [True, True], len(sites)))
+        _block_sites(sites, n + ".conv", b.conv, [w], [True])
+
+
 def run_block(eng, blk, segs):
     """Block.forward (vae.py:73-84) as fused launches."""
     site = lambda conv: eng.site_by_id[id(conv)]
@@ -297,8 +314,78 @@ class Decoder(nn.Module):
         opt = int(torch.distributions.Categorical(1 / 3 * torch.ones(3)).sample())
         return {0: (0, 1), 1: (1, 0), 2: (1, 1)}[opt]
 
-    def forward(self, *a, **k):
-        raise RuntimeError("Decoder is a parameter holder; run it through HVAE (HIP engine)")
+    # ---- standalone use (inference only): the HVAE's own decoder pass (HVAE._decode) on a private engine
+    def _host(self):
+        h = self.__dict__.get("_sa_host")
+        if h is None:
+            h = self.__dict__["_sa_host"] = _DecoderHost(self)
+        return h
+
+    @torch.no_grad()
+    def _forward_standalone(self, parents, x=None, t=None, abduct=False, latents=()):
+        host = self._host()
+        zd = self.blocks[0].z_dim
+        ctx = self.blocks[0].z_proj.in_channels - zd
+
+        def sites():
+            out = []
+            _decoder_sites(out, self, "", zd, ctx)
+            return out
+
+        eng = _standalone_engine(self, sites)
+        eng.rng_advance(1)
+        R = max(b.res for b in self.blocks)
+        pa = eng.from_parents(parents, R, R)
+        acts = None if x is None else {int(r): eng.from_nchw(v.to(eng.device, torch.float32)) for r, v in x.items()}
+        lat = [None if z is None else eng.from_nchw(z.to(eng.device, torch.float32)) for z in latents]
+        drop = self.drop_cond() if (self.training and self.cond_prior) else (1, 1)
+        collect = "qp" if acts is not None else ("p" if (abduct and self.cond_prior) else None)
+        h, out = HVAE._decode(host, eng, pa, acts=acts, t=t, latents=lat, collect=collect, drop=drop)
+        stats = []
+        if acts is not None:
+            for z, ql, qs, pl, ps in out:
+                ql, qs, pl, ps = (eng.to_nchw(v) for v in (ql, qs, pl, ps))
+                st = dict(kl=gaussian_kl(ql, qs, pl, ps))
+                if abduct:
+                    zt = eng.to_nchw(z)
+                    st["z"] = {"z": zt, "q_loc": ql, "q_logscale": qs} if self.cond_prior else zt
+                stats.append(st)
+        elif collect == "p":
+            stats = [dict(z={"p_loc": eng.to_nchw(pl), "p_logscale": eng.to_nchw(ps)}) for pl, ps in out]
+        return eng.to_nchw(h), stats
+
+    def forward(self, parents, x=None, t=None, abduct=False, latents=()):
+        """vae.py:222-301 on the HIP engine: (h, stats).  ``x`` is the encoder's {res: activation} dict (posterior pass: every
+        stochastic block contributes ``dict(kl=...)``, plus ``z`` when ``abduct``), or None (prior sampling / replay of
+        ``latents``).  Standalone use is inference only; inside an HVAE the model's engine runs the decoder."""
+        _no_standalone_grad(self, parents, *(x.values() if x is not None else ()))
+        return self._forward_standalone(parents, x, t, abduct, latents)
+
+
+class _DecoderHost:
+    """What HVAE._decode needs from its model when a Decoder runs on its own."""
+
+    def __init__(self, dec):
+        self.decoder = dec
+        self.__dict__["noise"] = None
+
+    def _site(self, eng, conv):
+        return eng.site_by_id[id(conv)]
+
+    def _run_block(self, eng, blk, segs):
+        return run_block(eng, blk, segs)
+
+    def _next_eps(self, eng, shape_nhwc):
+        src = self.decoder.__dict__.get("noise")  # optional list of NCHW eps tensors, consumed in draw order (parity tests)
+        if not src:
+            return None  # Philox inside the kernels
+        e = src.pop(0)
+        n, h, w, c = shape_nhwc
+        assert tuple(e.shape) == (n, c, h, w), (tuple(e.shape), shape_nhwc)
+        return eng.from_nchw(e.to(eng.device, torch.float32))
+
+    def _scratch_kl(self, eng, B, res, zd):
+        return eng.new_f32(B * _lib.load().reparam_kl_chunks(res, res, zd))
 
 
 class DGaussNet(nn.Module):
@@ -511,20 +598,7 @@ class HVAE(nn.Module):
         sites.append(_stem_site("encoder.stem", self.encoder.stem, len(sites), self.compute_dtype))
         for i, b in enumerate(self.encoder.blocks):
             add_block(f"encoder.blocks.{i}", b, [b.convs()[0].in_channels], [True])
-        zd, ctx = self.z_dim, self.context_dim
-        for i, b in enumerate(self.decoder.blocks):
-            w = b.in_width
-            n = f"decoder.blocks.{i}"
-            if b.cond_prior:
-                add_block(n + ".prior", b.prior, [w, ctx], [True, False])
-            else:
-                add_block(n + ".prior", b.prior, [w], [True])
-            if b.stochastic:
-                add_block(n + ".posterior", b.posterior, [w, ctx, w], [True, False, True])
-            add(n + ".z_proj", b.z_proj, [zd, ctx], [True, False])
-            if not b.q_correction:
-                add(n + ".z_feat_proj", b.z_feat_proj, [zd, w], [True, True])
-            add_block(n + ".conv", b.conv, [w], [True])
+        _decoder_sites(sites, self.decoder, "decoder.", self.z_dim, self.context_dim)
         lk = self.likelihood
         if lk.kind == "dgauss":
             for nme, cv in zip(("x_loc", "x_logscale", "channel_coeffs"), lk.heads()):
@@ -625,6 +699,8 @@ class HVAE(nn.Module):
                         out.append(z)
                     elif collect == "q":
                         out.append((z, q_loc, q_ls))
+                    elif collect == "qp":  # (standalone Decoder.forward: everything a stats dict needs)
+                        out.append((z, q_loc, q_ls, p_loc, p_ls))
                 else:
                     zi = latents[i] if i < len(latents) else None
                     if zi is not None:

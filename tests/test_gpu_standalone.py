@@ -110,3 +110,49 @@ def test_dgauss_sampling_is_the_reference_formula_on_the_kernels_own_noise(C):
     assert float((xs.cpu() - hvae_ref.dgauss_sample(sd, hp, h)[0]).abs().max()) > 1e-3  # (the noise did something)
     xs2, _ = lk.sample(h.cuda(), return_loc=False)
     assert not torch.equal(xs, xs2)  # a fresh draw per call
+
+
+@pytest.mark.parametrize("name", ["morphomnist", "ukbb192"])
+def test_decoder_standalone(name):
+    """Decoder.forward (vae.py:222-301) on its own: posterior pass on an encoder's activations (h and every block's KL map,
+    z when abducting), replay of those latents, and prior sampling -- against the oracle's decode on the module's own
+    state_dict, with the eps the oracle drew injected (``decoder.noise``)."""
+    from causal_gen_amd import vae
+    from causal_gen_amd.hps import setup_hparams
+    from oracle import hvae_ref
+
+    hp = setup_hparams(name)
+    hp.vr = "light" if "ukbb" in hp.hps else None
+    torch.manual_seed(4)
+    enc, dec = vae.Encoder(hp).cuda(), vae.Decoder(hp).cuda()
+    with torch.no_grad():
+        for p in dec.parameters():  # (the prior heads are zero-initialised: give the KL something to measure)
+            p.add_(0.02 * torch.randn_like(p))
+    dec.eval()
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randint(0, 256, (B, hp.input_channels, hp.input_res, hp.input_res), generator=g).float() - 127.5) / 127.5
+    pc = torch.randn(B, hp.context_dim, generator=g)
+    pa = pc[..., None, None].repeat(1, 1, hp.input_res, hp.input_res)
+    sd = {**_sd(enc, "encoder."), **_sd(dec, "decoder.")}
+    acts_ref = hvae_ref.encode(sd, hp, x)
+    noise = hvae_ref._Noise()
+    h_ref, stats_ref = hvae_ref.decode(sd, hp, pa, acts=acts_ref, abduct=True, noise=noise)
+    acts = enc(x.cuda())
+    dec.noise = [e.clone() for e in noise.drawn]
+    h, stats = dec(pa.cuda(), x=acts, abduct=True)
+    assert not dec.noise and len(stats) == len(stats_ref) > 0
+    torch.testing.assert_close(h.cpu(), h_ref, rtol=2e-3, atol=2e-3)
+    for s, r in zip(stats, stats_ref):
+        torch.testing.assert_close(s["kl"].cpu(), r["kl"], rtol=2e-3, atol=2e-4)
+        zr = r["z"]["z"] if isinstance(r["z"], dict) else r["z"]
+        zs = s["z"]["z"] if isinstance(s["z"], dict) else s["z"]
+        torch.testing.assert_close(zs.cpu(), zr, rtol=2e-3, atol=2e-3)
+    # replay of the abducted latents under the same parents reproduces h; the broadcast parent vector is accepted as well
+    zs = [(s["z"]["z"] if isinstance(s["z"], dict) else s["z"]) for s in stats]
+    lat = [zs.pop(0) if b.stochastic else None for b in dec.blocks]
+    h2, st2 = dec(pc.cuda(), latents=lat)
+    assert st2 == []
+    torch.testing.assert_close(h2, h, rtol=1e-3, atol=1e-3)
+    h3, _ = dec(pa.cuda())  # prior sampling
+    assert torch.isfinite(h3).all() and not torch.equal(h3, h)
