@@ -626,7 +626,7 @@ class HVAE(nn.Module):
         assert tuple(e.shape) == (n, c, h, w), (tuple(e.shape), shape_nhwc)
         return eng.from_nchw(e.to(eng.device, torch.float32))
 
-    def _decode(self, eng, parents, acts=None, t=None, latents=None, collect=None, drop=(1, 1), kl=None, fb=None):
+    def _decode(self, eng, parents, acts=None, t=None, latents=None, collect=None, drop=(1, 1), kl=None, fb=None, lat_fuse=False):
         """Decoder.forward (vae.py:222-301).  `collect`: None | "z" | "q" (q stats for cond-prior abduction) |
         "p" (prior stats).  `kl` = (ptr, stride, offsets) when the KL is wanted."""
         dec = self.decoder
@@ -690,7 +690,10 @@ class HVAE(nn.Module):
                     kstride = kl[1] if kl is not None else _lib.load().reparam_kl_chunks(res, res, zd)
                     fbl = None if fb is None else (fb[0], fb[1], fb[2][i])
                     # reparameterise + KL + z_proj (+ h + p_feat) in one launch where the kernel serves the shape
-                    fz = eng.latent_zproj(q_loc, q_ls, p_loc, p_ls, eps, sid, logt, kptr, kstride, fbl, self._site(eng, blk.z_proj), pa, h, p_feat)
+                    # (only in the plain ELBO pass: an abduction pass must leave bit for bit the hidden state a replay of its
+                    #  latents rebuilds with the separate z_proj conv -- the null-intervention identity of dscm.counterfactual)
+                    fz = (eng.latent_zproj(q_loc, q_ls, p_loc, p_ls, eps, sid, logt, kptr, kstride, fbl, self._site(eng, blk.z_proj), pa, h, p_feat)
+                          if lat_fuse else None)
                     if fz is not None:
                         z, h_next = fz
                     else:
@@ -803,7 +806,7 @@ class HVAE(nn.Module):
                     ncol += blk.z_dim
             s_buf = torch.empty(B * ncol + ncol, dtype=torch.float32, device=eng.device)  # S[B][ncol] then chan_mask[ncol]
             fb = (s_buf.data_ptr(), ncol, cols)
-        h, _ = self._decode(eng, pa, acts=acts, drop=drop, kl=(kl_ptr, kl_total, offs), fb=fb)
+        h, _ = self._decode(eng, pa, acts=acts, drop=drop, kl=(kl_ptr, kl_total, offs), fb=fb, lat_fuse=True)
         if fb is not None and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             # one small exchange: every row of S is replaced by the global per-channel mean, so that the finalize kernel
             # floors (and masks the gradient of) the same batch statistic on every rank; the per-sample gradient weight
