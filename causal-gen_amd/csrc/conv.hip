@@ -1585,7 +1585,7 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
   g.n_cwin = ceil_div(ctot8, cwin);
   g.tiles_x = ceil_div(W, TILE_W); g.tiles_y = ceil_div(H, TILE_H);
   g.ntiles = N * g.tiles_x * g.tiles_y;
-  static const int want_total = [] { const char* e = getenv("CGEN_WG2_WANT"); return e ? atoi(e) : 64; }();  // (round 2: 160 -> 64 workgroups per problem: -25 % split-K partial bytes, +2.8 % step throughput)
+  static const int want_total = [] { const char* e = getenv("CGEN_WG2_WANT"); return e ? atoi(e) : 32; }();  // (round 2: 160 -> 64 -> 32 workgroups per problem; with 16 tiles per workgroup: split-K partials 945 -> 429 MB per ukbb192 step, 1779 -> 1930 img/s overall)
   // workgroups per problem: the batched launch packs all problems of a step into one grid, so a problem need not fill
   // the chip by itself -- fewer, longer workgroups mean fewer split-K partials (measured optimum on MI355X: ~160 / >= 4 tiles)
   int want = ceil_div(want_total, g.n_cwin * g.n_co);
@@ -1602,7 +1602,7 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
   // (12 tiles per workgroup halves the split-K partials of ukbb192, 1.8 -> 0.94 GB per step, +1.7 %); the batch-256 32x32
   // models measured 1-2 % better with 4
   static const int min_tps_env = [] { const char* e = getenv("CGEN_WG2_MINTPS"); return e ? atoi(e) : 0; }();
-  const int min_tps = min_tps_env > 0 ? min_tps_env : (N <= 64 ? 12 : 4);
+  const int min_tps = min_tps_env > 0 ? min_tps_env : (N <= 64 ? 16 : 4);
   if (g.tps < min_tps && g.ntiles >= min_tps) g.tps = min_tps;
   g.nsplit = ceil_div(g.ntiles, g.tps);
   return true;
