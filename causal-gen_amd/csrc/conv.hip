@@ -1557,6 +1557,39 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
   const int halo = ks / 2;
   g.ncf = co <= 16 ? 1 : (co <= 32 ? 2 : (co <= 64 ? 4 : (co <= 96 ? 6 : 8)));
   g.njw = g.ncf == 1 ? 16 : WG2_MAXACC / g.ncf;
+  // The widest co block is not always the cheapest slab: the accumulators cap (co block) x (input-channel window), and every
+  // window re-reads the gradient tile while every co block re-reads the input tile.  Pick the block width that moves the
+  // fewest bytes per tile position (32 -> 160 @ 3x3: 128 + 32 co x two 16-channel windows = 151 KB; three 64-co blocks with
+  // one 32-channel window = 82 KB).  A narrower block must save >= 10 %: it also means more LDS fragment reads per MFMA.
+  static const int ncf_search = [] { const char* e = getenv("CGEN_WG2_NCF_SEARCH"); return e ? atoi(e) : 1; }();
+  if (ncf_search && ks != 7) {
+    static const int cand[5] = {1, 2, 4, 6, 8};
+    const int halo_ = ks / 2, c16_ = pad_to(ctot8, 16), co8 = pad_to(co, 8);
+    const long xpix = (long)(TILE_H + 2 * halo_) * (TILE_W + 2 * halo_), gpix = (long)TILE_H * TILE_W;
+    long best = -1, base = -1;
+    int best_ncf = g.ncf;
+    for (int k = 0; k < 5 && cand[k] <= g.ncf; ++k) {
+      const int ncf = cand[k], njw = ncf == 1 ? 16 : WG2_MAXACC / ncf;
+      const int mg = (4 * njw) / taps;
+      if (mg < 1) continue;
+      int cw = std::min(mg * 16, c16_);
+      const PixTile gt = mk_pixtile(ncf * 16, 2, TILE_H, TILE_W);
+      for (; cw >= 16; cw -= 16) {
+        const PixTile xt = mk_pixtile(cw, 2, TILE_H + 2 * halo_, TILE_W + 2 * halo_);
+        if (gt.ppp >= 1 && xt.ppp >= 1 && xt.bytes + gt.bytes <= 78 * 1024) break;
+      }
+      if (cw < 16) continue;
+      const long n_cw = ceil_div(ctot8, cw), n_co = ceil_div(co, ncf * 16);
+      const long bytes = n_co * n_cw * (xpix * std::min(cw, ctot8) * 2 + gpix * std::min(ncf * 16, co8) * 2);
+      if (ncf == g.ncf) base = bytes;
+      if (best < 0 || bytes < best) { best = bytes; best_ncf = ncf; }
+    }
+    static const int ncf_pct = [] { const char* e = getenv("CGEN_WG2_NCF_PCT"); return e ? atoi(e) : 90; }();
+    if (base > 0 && best_ncf != g.ncf && best * 100 <= base * ncf_pct) {
+      g.ncf = best_ncf;
+      g.njw = g.ncf == 1 ? 16 : WG2_MAXACC / g.ncf;
+    }
+  }
   if (ks == 7) {  // the 7x7 stem (Cin <= 8: ONE 16-channel group, 49 taps -> 49 fragments = 13 per wave): at most 32 co columns per workgroup
     if (ctot8 > 16) return false;
     g.ncf = co <= 16 ? 1 : 2;
