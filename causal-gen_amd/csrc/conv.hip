@@ -1608,6 +1608,17 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
     if (g.gt.ppp >= 1 && g.xt.ppp >= 1 && g.xt.bytes + g.gt.bytes <= 78 * 1024) break;
   }
   if (g.gt.ppp < 1) return false;
+  {  // equal windows: 96 channels as 48 + 48 rather than 80 + 16 -- same passes over the gradient tile, a smaller input tile
+     // (which may make room for the second tile buffer) and workgroups of equal length.  Measured: the packed launches alone
+     // 4.00 -> 3.88 ms, the STEP 1940 -> 1928 img/s (three interleaved pairs) -- off.
+    static const int balance = [] { const char* e = getenv("CGEN_WG2_BALANCE"); return e ? atoi(e) : 0; }();
+    const int nwin = ceil_div(ctot8, cwin);
+    const int bal = pad_to(ceil_div(ctot8, nwin), 16);
+    if (balance && nwin > 1 && bal < cwin) {
+      cwin = bal;
+      g.xt = mk_pixtile(cwin, 2, TILE_H + 2 * halo, TILE_W + 2 * halo);
+    }
+  }
   g.lds = (size_t)g.xt.bytes + g.gt.bytes;
   // two tile buffers where they fit next to a second workgroup on the CU: the next tile's DMA runs under this tile's MFMAs
   // (ablation on ukbb192: DMA-only 2.1 ms, MFMA-only ~1.6 ms, both 4.6 ms with one buffer -- the two phases did not overlap)
