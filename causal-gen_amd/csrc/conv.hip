@@ -1539,6 +1539,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tile_mega_kernel(const Wg2P* __r
       case 16: wgrad_tile_body<8, 3, 1>(p, bx, by, bz); break;
       case 33: wgrad_tile_body<1, 16, 7>(p, bx, by, bz); break;
       case 34: wgrad_tile_body<2, 16, 7>(p, bx, by, bz); break;
+      case 36: wgrad_tile_body<2, 16, 1>(p, bx, by, bz); break;
+      case 37: wgrad_tile_body<2, 16, 3>(p, bx, by, bz); break;
       default: wgrad_tile_body<8, 3, 3>(p, bx, by, bz); break;
     }
     __syncthreads();
@@ -1563,13 +1565,17 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
   // one 32-channel window = 82 KB).  A narrower block must save >= 10 %: it also means more LDS fragment reads per MFMA.
   static const int ncf_search = [] { const char* e = getenv("CGEN_WG2_NCF_SEARCH"); return e ? atoi(e) : 1; }();
   if (ncf_search && ks != 7) {
-    static const int cand[5] = {1, 2, 4, 6, 8};
+    // (co-block width in 16-column units, accumulator fragments per wave): the five standard slabs, plus a taller two-block
+    // slab (32 fragments) that holds 112 input channels of a 3x3 conv in one window -- 96 -> 24 needs no second pass
+    static const int cand[6][2] = {{1, 16}, {2, 12}, {2, 16}, {4, 6}, {6, 4}, {8, 3}};
+    static const int tall = [] { const char* e = getenv("CGEN_WG2_TALL"); return e ? atoi(e) : 1; }();
     const int halo_ = ks / 2, c16_ = pad_to(ctot8, 16), co8 = pad_to(co, 8);
     const long xpix = (long)(TILE_H + 2 * halo_) * (TILE_W + 2 * halo_), gpix = (long)TILE_H * TILE_W;
     long best = -1, base = -1;
-    int best_ncf = g.ncf;
-    for (int k = 0; k < 5 && cand[k] <= g.ncf; ++k) {
-      const int ncf = cand[k], njw = ncf == 1 ? 16 : WG2_MAXACC / ncf;
+    int best_ncf = g.ncf, best_njw = g.njw;
+    for (int k = 0; k < 6; ++k) {
+      const int ncf = cand[k][0], njw = cand[k][1];
+      if (ncf > g.ncf || (njw == 16 && ncf == 2 && !tall)) continue;
       const int mg = (4 * njw) / taps;
       if (mg < 1) continue;
       int cw = std::min(mg * 16, c16_);
@@ -1581,13 +1587,13 @@ static bool wgrad2_geometry(int N, int H, int W, int co, int ctot8, int ks, Wg2G
       if (cw < 16) continue;
       const long n_cw = ceil_div(ctot8, cw), n_co = ceil_div(co, ncf * 16);
       const long bytes = n_co * n_cw * (xpix * std::min(cw, ctot8) * 2 + gpix * std::min(ncf * 16, co8) * 2);
-      if (ncf == g.ncf) base = bytes;
-      if (best < 0 || bytes < best) { best = bytes; best_ncf = ncf; }
+      if (ncf == g.ncf && njw == g.njw) base = bytes;
+      if (best < 0 || bytes < best) { best = bytes; best_ncf = ncf; best_njw = njw; }
     }
     static const int ncf_pct = [] { const char* e = getenv("CGEN_WG2_NCF_PCT"); return e ? atoi(e) : 90; }();
-    if (base > 0 && best_ncf != g.ncf && best * 100 <= base * ncf_pct) {
+    if (base > 0 && (best_ncf != g.ncf || best_njw != g.njw) && best * 100 <= base * ncf_pct) {
       g.ncf = best_ncf;
-      g.njw = g.ncf == 1 ? 16 : WG2_MAXACC / g.ncf;
+      g.njw = best_njw;
     }
   }
   if (ks == 7) {  // the 7x7 stem (Cin <= 8: ONE 16-channel group, 49 taps -> 49 fragments = 13 per wave): at most 32 co columns per workgroup
@@ -2620,7 +2626,7 @@ static bool build_wg2(const cgen_wgrad_args* a, Wg2P& q, Wg2Geom& g) {
   q.tiles_x = g.tiles_x; q.tiles_y = g.tiles_y; q.ntiles = g.ntiles; q.nsplit = g.nsplit; q.tiles_per_split = g.tps;
   q.cwin = g.cwin; q.cog = g.ncf * 16; q.xt = g.xt; q.gt = g.gt;
   q.d_tx = mk_fastdiv(g.tiles_x); q.d_ty = mk_fastdiv(g.tiles_y);
-  q.variant = a->ks == 7 ? 32 + g.ncf : g.ncf * 2 + (a->ks == 3 ? 1 : 0);
+  q.variant = a->ks == 7 ? 32 + g.ncf : (g.ncf == 2 && g.njw == 16 ? 36 + (a->ks == 3 ? 1 : 0) : g.ncf * 2 + (a->ks == 3 ? 1 : 0));
   q.dbuf = g.dbuf;
   { const char* e = getenv("CGEN_WG2_DBG"); q.dbg = e ? atoi(e) : 0; }
   return true;
@@ -2664,7 +2670,7 @@ extern "C" int cgen_conv2d_wgrad_batch_plan(const cgen_wgrad_args* args, int32_t
   static const bool mega = [] { const char* e = getenv("CGEN_WGRAD_MEGA"); return !e || atoi(e) != 0; }();
   if (!mega) {  // the per-variant launches have no 7x7 instance: the stem goes to the caller's single launch
     std::vector<Item> keep;
-    for (auto& it : items) { if (args[it.idx].ks == 7) eligible[it.idx] = 0; else keep.push_back(it); }
+    for (auto& it : items) { if (args[it.idx].ks == 7 || (it.g.ncf == 2 && it.g.njw == 16)) eligible[it.idx] = 0; else keep.push_back(it); }
     items.swap(keep);
   }
   if (mega) {  // one launch for everything: longest blocks first (the resident workgroups take them round robin)
@@ -2768,7 +2774,7 @@ extern "C" int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream)
       hipStream_t st = (hipStream_t)stream;
       switch (g.ncf) {
         case 1: launch_wgrad2_ks<1, 16>(q, g, st); break;
-        case 2: if (a->ks == 7) launch_wgrad2_ks<2, 16>(q, g, st); else launch_wgrad2_ks<2, 12>(q, g, st); break;
+        case 2: if (a->ks == 7 || g.njw == 16) launch_wgrad2_ks<2, 16>(q, g, st); else launch_wgrad2_ks<2, 12>(q, g, st); break;
         case 4: launch_wgrad2_ks<4, 6>(q, g, st); break;
         case 6: launch_wgrad2_ks<6, 4>(q, g, st); break;
         default: launch_wgrad2_ks<8, 3>(q, g, st); break;
