@@ -1,7 +1,8 @@
 """Parent-SCM counterfactuals without Pyro: the mechanisms of ``src/pgm/flow_pgm.py`` for the parents of
 the image -- ``FlowPGM`` (UKBB: sex, mri_seq, age, brain_volume, ventricle_volume; flow_pgm.py:111-205) and
-``MorphoMNISTPGM`` (thickness, intensity, digit; flow_pgm.py:314-385) -- restated in plain torch with CLOSED-FORM
-abduction, so that ``DSCM.forward`` / ``dscm.counterfactual`` run on a box without pyro.
+``MorphoMNISTPGM`` (thickness, intensity, digit; flow_pgm.py:314-385), ``ColourMNISTPGM`` (digit, colour: two categorical
+roots; flow_pgm.py:451-530) and ``ChestPGM`` (race, sex, age -> finding; flow_pgm.py:533-710) -- restated in plain torch with
+CLOSED-FORM abduction, so that ``DSCM.forward`` / ``dscm.counterfactual`` run on a box without pyro.
 
 The reference gets abduction -> action -> prediction from Pyro effect handlers (``BasePGM.counterfactual``,
 flow_pgm.py:71-108: trace the conditioned model, invert every TransformedDistribution's transforms at the observed value,
@@ -17,7 +18,9 @@ with f = linear rational spline (pyro ``T.Spline(1, count_bins=4, order="linear"
 ``2 sigmoid(.) - 1``, and -- for discrete mechanisms -- the Gumbel-max posterior of layers.py:107-171.
 
 Scalars only; there is no kernel here (a few floats per sample, host-side torch).  The parameter / module names follow
-the reference's so that its ``state_dict`` keys load.
+the reference's so that its ``state_dict`` keys load: ``load_reference_state_dict`` takes a reference PGM checkpoint, drops the
+anticausal predictors the reference keeps on the same module (``encoder_*``: CNN / ResNet heads used by ``train_pgm.py`` and the
+classifier guide, outside this path -- SURVEY 8f-3) and loads everything else strictly.
 
 PARITY UNPINNED: pyro cannot be imported in the build image, so no reference-made vectors exist for this file.  It is pinned
 by the invariants the mechanisms must satisfy (tests/test_pgm.py): f^{-1}(f(eps)) = eps, strict monotonicity, identity
@@ -25,6 +28,7 @@ outside the spline's bound, null intervention = observation, interventions move 
 reproduces the observed class.  The spline follows Dolatabadi et al. 2020 ("Invertible generative modeling using linear
 rational splines") as implemented by pyro 1.8 (``_monotonic_rational_spline``), restated from its published formulae.
 """
+import math
 from typing import Dict, List, Optional
 
 import torch
@@ -234,9 +238,23 @@ class _BasePGM(nn.Module):
                     val[k] = obs[k]
                 else:
                     val[k] = self._predict(k, eps[k], val)
+            if getattr(self, "discrete_variables", None) and "age" not in intervention and "finding" not in intervention:
+                # flow_pgm.py:96-105: abduction of a discrete mechanism is stochastic (Gumbel-max posterior), so "finding" keeps
+                # its observed value unless it or its parent is intervened on
+                val["finding"] = obs["finding"]
             for k in obs:
                 avg[k] = avg[k] + val[k] / num_particles
         return avg
+
+    def load_reference_state_dict(self, sd: Dict[str, Tensor]):
+        """Load a reference PGM ``state_dict`` (train_cf.py:340-347 loads it into the pyro module).  The reference keeps its
+        anticausal predictors on the same module (``encoder_s/m/a/b/v``, ``encoder_t/i/y``, ``encoder_y/c``, ``encoder_s/r/f/a``);
+        they are not part of the counterfactual path and have no counterpart here: those keys are dropped, every other key must
+        match exactly."""
+        kept = {k: v for k, v in sd.items() if not k.split(".")[0].startswith("encoder_")}
+        dropped = sorted(set(sd) - set(kept))
+        self.load_state_dict(kept, strict=True)
+        return dropped
 
 
 class FlowPGM(_BasePGM):
@@ -311,4 +329,74 @@ class MorphoMNISTPGM(_BasePGM):
         val = {"digit": F.one_hot(torch.multinomial(probs, 1, generator=generator).squeeze(-1), 10).float().to(dev)}
         for k in ("thickness", "intensity"):
             val[k] = self._predict(k, torch.randn(n, 1, generator=generator).to(dev), val)
+        return val
+
+
+class ColourMNISTPGM(_BasePGM):
+    """Colour-MNIST parents (flow_pgm.py:451-530): digit and colour, two independent one-hot categorical ROOTS ([B, 10] each)
+    with learned prior logits.  Neither has a flow, hence no exogenous noise: a counterfactual keeps the observed value of
+    whatever is not intervened on (BasePGM.counterfactual, flow_pgm.py:84-88)."""
+    variables = {"digit": "categorical", "colour": "categorical"}
+    order = ["digit", "colour"]
+
+    def __init__(self, args=None):
+        super().__init__()
+        self.digit_logits = nn.Parameter(torch.zeros(1, 10))   # uniform prior
+        self.colour_logits = nn.Parameter(torch.zeros(1, 10))  # uniform prior
+
+    def _abduct(self, obs):
+        return {}
+
+    @torch.no_grad()
+    def sample(self, n: int, generator: Optional[torch.Generator] = None) -> Dict[str, Tensor]:
+        dev = self.digit_logits.device
+        draw = lambda logits: F.one_hot(torch.multinomial(F.softmax(logits, -1).expand(n, -1).cpu(), 1, generator=generator).squeeze(-1), 10).float().to(dev)
+        return {"digit": draw(self.digit_logits), "colour": draw(self.colour_logits)}
+
+
+class ChestPGM(_BasePGM):
+    """MIMIC-CXR parents (flow_pgm.py:533-710): race (one-hot [B, 3]) and sex ([B, 1]) are roots without a flow; age ~ Normal ->
+    ``T.Spline(1)`` (pyro defaults: 8 bins, bound 3, linear order); finding | age is a Gumbel-max mechanism whose two logits are
+    ``DenseNN(1, [8, 16], [2], Sigmoid)(age)`` (layers.py:107-171, 174-195).  Abduction of `finding` is the stochastic
+    posterior of layers.py:139-160 ([B, 2] Gumbel noise, `gumbel_max_abduct`); the reference therefore keeps the observed
+    finding unless `age` or `finding` is intervened on (flow_pgm.py:96-105), and so does `_BasePGM.counterfactual`."""
+    variables = {"race": "categorical", "sex": "binary", "finding": "binary", "age": "continuous"}
+    discrete_variables = {"finding": "binary"}
+    order = ["sex", "age", "race", "finding"]
+
+    def __init__(self, args=None, exact_gumbel_posterior: bool = False):
+        super().__init__()
+        for k in ("a", "f"):
+            self.register_buffer(f"{k}_base_loc", torch.zeros(1))
+            self.register_buffer(f"{k}_base_scale", torch.ones(1))
+        self.age_flow_components = nn.ModuleList([LinearSpline(1, count_bins=8, bound=3.0)])
+        self.finding_transform_GumbelMax = nn.Module()
+        self.finding_transform_GumbelMax.context_nn = DenseNN(1, [8, 16], [2], nn.Sigmoid())
+        self.sex_logit = nn.Parameter(math.log(1 / 2) * torch.ones(1))
+        self.race_logits = nn.Parameter(math.log(1 / 3) * torch.ones(1, 3))
+        self.exact_gumbel_posterior = exact_gumbel_posterior
+        self.generator: Optional[torch.Generator] = None  # set for reproducible Gumbel abduction (tests)
+
+    def finding_logits(self, age: Tensor) -> Tensor:
+        return self.finding_transform_GumbelMax.context_nn(age)
+
+    def _abduct(self, obs):
+        post = gumbel_max_abduct_exact if self.exact_gumbel_posterior else gumbel_max_abduct
+        return {"age": self.age_flow_components[0].inv(obs["age"]),
+                "finding": post(obs["finding"], self.finding_logits(obs["age"]), self.generator)}
+
+    def _predict(self, k, eps, val):
+        if k == "age":
+            return self.age_flow_components[0](eps)
+        return gumbel_max_forward(eps, self.finding_logits(val["age"])).to(eps.dtype)
+
+    @torch.no_grad()
+    def sample(self, n: int, generator: Optional[torch.Generator] = None) -> Dict[str, Tensor]:
+        dev = self.sex_logit.device
+        r = lambda *shape: torch.rand(*shape, generator=generator).to(dev)
+        val = {"sex": (r(n, 1) < torch.sigmoid(self.sex_logit)).float()}
+        val["age"] = self._predict("age", torch.randn(n, 1, generator=generator).to(dev), val)
+        val["race"] = F.one_hot(torch.multinomial(F.softmax(self.race_logits, -1).expand(n, -1).cpu(), 1, generator=generator).squeeze(-1), 3).float().to(dev)
+        gum = -(-(r(n, 2).log())).log()
+        val["finding"] = self._predict("finding", gum, val)
         return val

@@ -112,3 +112,111 @@ def test_dscm_vae_preprocess_accepts_the_pgm_output():
     cf = m.counterfactual(obs, {"sex": 1 - obs["sex"]})
     pa = dscm.ukbb_preprocess({k: v.clone() for k, v in cf.items()})
     assert set(pa) == set(cf) and all(torch.isfinite(v).all() for v in pa.values())
+
+
+def test_linear_spline_hand_computed_values():
+    """Zero raw parameters: 4 equal bins of width 1.5 on [-3, 3], interior derivatives d = 1e-3 + softplus(0) = 0.694147...,
+    tails 1, lambda = 0.5.  Middle bin [0, 1.5] (d_k = d_{k+1}): w_b = 1, s = 1, w_c = d, y_c = 0.75, so
+    y(theta) = (0 * (.5 - theta) + d * .75 * theta) / ((.5 - theta) + d * theta) for theta <= .5 -- evaluated by hand below.
+    First bin [-3, -1.5] (d_0 = 1 at the tail): w_b = sqrt(1 / d), w_c = .5 + .5 w_b d, y_c = (-1.5 - .75 w_b) / (.5 + .5 w_b) ."""
+    import math
+
+    sp = pgm.LinearSpline(1, count_bins=4).double()
+    with torch.no_grad():
+        for p in sp.parameters():
+            p.zero_()
+    d = 1e-3 + math.log(2.0)
+    # middle bin, theta = 0.2 (x = 0.3) and theta = 0.8 (x = 1.2)
+    th = 0.2
+    y_l = (d * 0.75 * th) / ((0.5 - th) + d * th)
+    th = 0.8
+    y_r = (d * 0.75 * (1 - th) + 1.5 * (th - 0.5)) / (d * (1 - th) + (th - 0.5))
+    # first bin, theta = 0.4 (x = -2.4)
+    wb = math.sqrt(1.0 / d)
+    wc = 0.5 * 1.0 + 0.5 * wb * d
+    yc = (0.5 * -3.0 + 0.5 * wb * -1.5) / (0.5 + 0.5 * wb)
+    th = 0.4
+    y_f = (-3.0 * (0.5 - th) + wc * yc * th) / ((0.5 - th) + wc * th)
+    x = torch.tensor([[0.3], [1.2], [-2.4], [0.0], [1.5], [4.0]], dtype=torch.float64)
+    y = sp(x).squeeze(-1).tolist()
+    for got, want in zip(y, [y_l, y_r, y_f, 0.0, 1.5, 4.0]):
+        assert abs(got - want) < 1e-12, (got, want)
+    assert (sp.inv(sp(x)) - x).abs().max() < 1e-12
+
+
+def test_conditional_affine_hand_computed_value():
+    """layers.py:33-43 with a one-layer-deep net made explicit: loc = 0.3 + 0.5 c, log_scale = -0.2 + 0.25 c."""
+    import math
+
+    nn_ = pgm.DenseNN(1, [1], [1, 1], torch.nn.Identity())
+    with torch.no_grad():
+        nn_.layers[0].weight.fill_(1.0); nn_.layers[0].bias.zero_()
+        nn_.layers[1].weight.copy_(torch.tensor([[0.5], [0.25]])); nn_.layers[1].bias.copy_(torch.tensor([0.3, -0.2]))
+    aff = pgm.ConditionalAffine(nn_)
+    c, eps = torch.tensor([[2.0]]), torch.tensor([[-1.5]])
+    want = (0.3 + 0.5 * 2.0) + math.exp(-0.2 + 0.25 * 2.0) * -1.5
+    assert abs(aff(eps, c).item() - want) < 1e-6
+    assert abs(aff.inv(torch.tensor([[want]]), c).item() - -1.5) < 1e-6
+    # the [-1, 1] normalisation: 2 sigmoid(0.7) - 1 = tanh(0.35)
+    assert abs(pgm.normalize_fwd(torch.tensor(0.7)).item() - math.tanh(0.35)) < 1e-7
+
+
+def test_colour_mnist_pgm_counterfactuals():
+    """flow_pgm.py:451-530: two categorical roots, no exogenous noise: intervened variables take the value, the rest keep theirs."""
+    m = pgm.ColourMNISTPGM(SimpleNamespace())
+    assert sorted(k for k, _ in m.named_parameters()) == ["colour_logits", "digit_logits"]
+    obs = m.sample(7, torch.Generator().manual_seed(8))
+    assert obs["digit"].shape == (7, 10) and obs["colour"].shape == (7, 10)
+    assert torch.equal(obs["digit"].sum(-1), torch.ones(7)) and torch.equal(obs["colour"].sum(-1), torch.ones(7))
+    same = m.counterfactual(obs, {})
+    assert all(torch.equal(same[k], obs[k]) for k in obs)
+    do = {"colour": obs["colour"].roll(1, 0)}
+    cf = m.counterfactual(obs, do, num_particles=2)
+    assert torch.equal(cf["colour"], do["colour"]) and torch.equal(cf["digit"], obs["digit"])
+    assert m.infer_exogeneous(obs) == {}
+
+
+def test_chest_pgm_counterfactuals():
+    """flow_pgm.py:533-710: age spline (8 bins), finding | age by Gumbel-max, race / sex roots."""
+    m = pgm.ChestPGM(SimpleNamespace())
+    keys = sorted(m.state_dict())
+    assert "age_flow_components.0.unnormalized_widths" in keys and "finding_transform_GumbelMax.context_nn.layers.2.weight" in keys
+    assert m.age_flow_components[0].unnormalized_widths.shape == (1, 8) and m.race_logits.shape == (1, 3)
+    _randomise(m, 9)
+    obs = m.sample(16, torch.Generator().manual_seed(10))
+    assert set(obs) == set(m.variables) and obs["race"].shape == (16, 3) and obs["finding"].shape == (16, 1)
+    m.generator = torch.Generator().manual_seed(11)
+    # null intervention: everything is reproduced (finding through the reference's pin, flow_pgm.py:96-105)
+    same = m.counterfactual(obs, {})
+    for k in obs:
+        assert (same[k] - obs[k]).abs().max() < 1e-4, k
+    # do(sex) / do(race): roots without descendants: nothing else moves
+    cf = m.counterfactual(obs, {"sex": 1 - obs["sex"], "race": obs["race"].roll(1, 1)})
+    assert torch.equal(cf["sex"], 1 - obs["sex"]) and (cf["age"] - obs["age"]).abs().max() < 1e-4 and torch.equal(cf["finding"], obs["finding"])
+    # do(age): finding is re-predicted from the abducted Gumbel noise under the new logits, values stay binary
+    cf = m.counterfactual(obs, {"age": obs["age"] + 1.0})
+    assert torch.equal(cf["age"], obs["age"] + 1.0) and set(cf["finding"].flatten().tolist()) <= {0.0, 1.0}
+    # ... and with the exact posterior an intervention that leaves the logits unchanged reproduces the observed class
+    m.exact_gumbel_posterior = True
+    cf = m.counterfactual(obs, {"age": obs["age"].clone()})
+    assert torch.equal(cf["finding"], obs["finding"])
+    # do(finding) overrides the mechanism
+    cf = m.counterfactual(obs, {"finding": 1 - obs["finding"]})
+    assert torch.equal(cf["finding"], 1 - obs["finding"]) and (cf["age"] - obs["age"]).abs().max() < 1e-4
+    eps = m.infer_exogeneous(obs)
+    assert eps["age_base"].shape == (16, 1) and eps["finding_base"].shape == (16, 2)
+
+
+def test_reference_pgm_checkpoints_load_without_their_predictors():
+    """The reference keeps its anticausal predictors (encoder_*) on the PGM module; load_reference_state_dict drops exactly those."""
+    m = pgm.MorphoMNISTPGM(SimpleNamespace(widths=[8, 8]))
+    sd = {k: v.clone() + 1 for k, v in m.state_dict().items()}
+    sd["encoder_t.cnn.0.weight"] = torch.zeros(3)
+    sd["encoder_y.fc.2.bias"] = torch.zeros(10)
+    dropped = m.load_reference_state_dict(sd)
+    assert dropped == ["encoder_t.cnn.0.weight", "encoder_y.fc.2.bias"]
+    assert torch.equal(m.digit_logits, sd["digit_logits"])
+    import pytest
+
+    with pytest.raises(RuntimeError):
+        m.load_reference_state_dict({"nonsense": torch.zeros(1)})
