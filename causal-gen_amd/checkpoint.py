@@ -50,13 +50,21 @@ def load_checkpoint(path: str, which: str = "ema", device: Optional[str] = "cuda
 
 def resume_train_step(path: str, train_step) -> dict:
     """main.py:75-90: restore model / EMA weights and the optimiser + schedule state of ``train_step`` from ``path``.
-    Returns the checkpoint's bookkeeping (epoch, step, best_loss)."""
+    Returns the checkpoint's bookkeeping (epoch, step, best_loss).
+    LR schedule: the warm-up position is derived from the optimiser's step count, i.e. a checkpoint taken inside the 100-step
+    warm-up continues the ramp.  (The reference does not restore its scheduler at all: main.py:82-90 resets ``lr`` /
+    ``initial_lr`` to ``args.lr`` under a constant LambdaLR, so a resumed reference run never re-enters warm-up.  Past step 100
+    the two agree; inside the warm-up this harness deliberately keeps the ramp.)"""
     ckpt = torch.load(path, map_location="cpu", weights_only=False)
     train_step.model.load_state_dict(ckpt["model_state_dict"])
     if train_step.ema_model is not None:
         train_step.ema_model.load_state_dict(ckpt["ema_model_state_dict"])
     if ckpt.get("optimizer_state_dict") is not None:
         train_step.load_state_dict(ckpt["optimizer_state_dict"])
+        if "cgen" not in ckpt["optimizer_state_dict"] and ckpt.get("step") is not None:
+            # a reference-made checkpoint: the ITERATION counter (beta warm-up, trainer.py:57) is ckpt["step"], which runs ahead of
+            # the optimiser's step count whenever updates were skipped or accu_steps > 1
+            train_step.it = int(ckpt["step"])
     train_step._mark_weights_written()
     return {k: ckpt.get(k) for k in ("epoch", "step", "best_loss")}
 

@@ -735,7 +735,12 @@ extern "C" int cgen_im2col(int32_t dtype, int32_t n, int32_t h, int32_t w, int32
 
 
 extern "C" int cgen_stem_conv_supported(int32_t dtype, int32_t cin, int32_t ks, int32_t co) {
-  return (dtype == CGEN_F32 || dtype == CGEN_BF16) && ks == 7 && cin >= 1 && cin <= 4 && (co == 16 || co == 32 || co == 64);
+  // the kernel stages the halo tile and the whole [49 Cin][Cout] weight matrix in LDS as f32 and launches without the
+  // >64 KB opt-in: a shape whose footprint exceeds 64 KB (Cin = 4 with Cout = 64: 65 856 B) is NOT served -- the caller
+  // (vae._stem_site) then takes the im2col + 1x1 route instead of failing at launch
+  const size_t lds = (size_t)(cin * (STEM_TH + 6) * (STEM_TW + 6) + cin * 49 * co) * sizeof(float);
+  return (dtype == CGEN_F32 || dtype == CGEN_BF16) && ks == 7 && cin >= 1 && cin <= 4 && (co == 16 || co == 32 || co == 64) &&
+         lds <= 64 * 1024;
 }
 
 extern "C" int cgen_stem_conv_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t ks, int32_t co, cgen_view in,

@@ -51,6 +51,11 @@ def preprocess_batch(args, batch, expand_pa=False):
 CAPTURE_MODE = "thread_local"
 
 
+def _covers(have, want):
+    """True when every [lo, hi) of `want` lies inside one range of `have` (both sorted, disjoint)."""
+    return all(any(a <= lo and hi <= b for a, b in have) for lo, hi in want)
+
+
 def _subtract_ranges(whole, holes):
     """[lo, hi) ranges of `whole` not covered by `holes` (both sorted, non-overlapping)."""
     out = []
@@ -137,6 +142,7 @@ class TrainStep:
                 eng.split_frac = 0.9
         self.comm_stream = None
         self.early_ranges = self.late_ranges = None
+        self._early_ok = True
         self.time_comm = False
         self._comm_events = []
         # gradient accumulation (trainer.py:64-67): elbo / accu_steps per iteration, summed in a second flat buffer; the
@@ -307,10 +313,17 @@ class TrainStep:
         works, fired = [], []
         if overlap:
             def at_split():
+                now = self._ranges_of(self.eng.early_final)
                 if self.early_ranges is None:  # first step: which flat ranges are final here, and which come later
-                    self.early_ranges = self._ranges_of(self.eng.early_final)
-                works.extend(self._early_launch())
-                fired.append(True)
+                    self.early_ranges = now
+                # the ranges are fixed by the FIRST tape; another tape (other batch shape / drop_cond outcome) may cut at a
+                # place where some of those gradients are still being written: such a step exchanges everything after the
+                # backward pass instead (and its graph is captured without the cut)
+                self._early_ok = _covers(now, self.early_ranges)
+                if self._early_ok:
+                    works.extend(self._early_launch())
+                    fired.append(True)
+            self._early_ok = True
             self.eng.on_split = at_split
         try:
             out3 = self._fwd_bwd(x, pa, beta)
@@ -318,7 +331,9 @@ class TrainStep:
             self.eng.on_split = None
         self.eng.stream = torch.cuda.current_stream(self.eng.device).cuda_stream
         if do_step:
-            if overlap:
+            if overlap and not self._early_ok:
+                self._allreduce(out3)
+            elif overlap:
                 if self.early_ranges is None:
                     self.early_ranges = []  # (the split mark was never reached: tiny model) -> everything is "late"
                 elif not fired:
@@ -373,7 +388,7 @@ class TrainStep:
             # NCCL inside a captured graph is avoided: under DP the step is graphs around eager all-reduces.  With overlap the
             # backward graph is cut where the decoder half of the gradient is final (engine.on_split): graph A | all-reduce of
             # that half on the communication stream | graph B (rest of the backward pass) | all-reduce of the rest | graph C.
-            overlap = self.dp_overlap and do_step and self.acc_g is None and bool(self.early_ranges)
+            overlap = self.dp_overlap and do_step and self.acc_g is None and bool(self.early_ranges) and self._early_ok
             g1, g1b = torch.cuda.CUDAGraph(), None
             if overlap:
                 g1b = torch.cuda.CUDAGraph()

@@ -276,8 +276,60 @@ class DecoderBlock(nn.Module):
             self.z_feat_proj = nn.Conv2d(self.z_dim + in_width, out_width, 1)
         self.conv = Block(in_width, bottleneck, out_width, kernel_size=k, version=args.vr)
 
+    # ---- standalone use (inference only): the two halves of a decoder layer on a private engine
+    def _sa_engine(self):
+        ctx = self.z_proj.in_channels - self.z_dim
+        w = self.in_width
+
+        def sites():
+            out = []
+            _block_sites(out, "prior", self.prior, [w, ctx] if self.cond_prior else [w], [True, False] if self.cond_prior else [True])
+            if self.stochastic:
+                _block_sites(out, "posterior", self.posterior, [w, ctx, w], [True, False, True])
+            return out
+
+        return _standalone_engine(self, sites)
+
+    @staticmethod
+    def _logt(ls, t):
+        return ls if t is None else ls + float(torch.as_tensor(t, dtype=torch.float32).log())
+
+    def forward_prior(self, z, pa=None, t=None):
+        """vae.py:170-182: (p_loc, p_logscale [+ log t], p_features) from the prior Block on ``z`` (``cat[z, pa]`` when the prior
+        is conditional -- a virtual concat: two input segments of the first conv)."""
+        _no_standalone_grad(self, z, pa)
+        with torch.no_grad():
+            return self._prior_sa(z, pa, t)
+
+    def _prior_sa(self, z, pa, t):
+        eng = self._sa_engine()
+        zt = eng.from_nchw(z.to(eng.device, torch.float32))
+        segs = [zt]
+        if self.cond_prior:
+            segs.append(eng.from_parents(pa, zt.h, zt.w).crop(zt.h))
+        out = eng.to_nchw(run_block(eng, self.prior, segs))
+        zd = self.z_dim
+        return out[:, :zd], self._logt(out[:, zd:2 * zd], t), out[:, 2 * zd:]
+
+    def forward_posterior(self, z, x, pa, t=None):
+        """vae.py:184-192: (q_loc, q_logscale [+ log t]) from the posterior Block on the virtual ``cat[z, pa, x]``."""
+        if not self.stochastic:
+            raise AttributeError("this DecoderBlock has no posterior (res > z_max_res)")
+        _no_standalone_grad(self, z, x, pa)
+        with torch.no_grad():
+            return self._posterior_sa(z, x, pa, t)
+
+    def _posterior_sa(self, z, x, pa, t):
+        eng = self._sa_engine()
+        zt = eng.from_nchw(z.to(eng.device, torch.float32))
+        xt = eng.from_nchw(x.to(eng.device, torch.float32))
+        out = eng.to_nchw(run_block(eng, self.posterior, [zt, eng.from_parents(pa, zt.h, zt.w).crop(zt.h), xt]))
+        q_loc, q_ls = out.chunk(2, dim=1)
+        return q_loc, self._logt(q_ls, t)
+
     def forward(self, *a, **k):
-        raise RuntimeError("DecoderBlock is a parameter holder; run it through HVAE (HIP engine)")
+        raise RuntimeError("DecoderBlock has no forward() in the reference either (vae.py:137-192): call forward_prior / "
+                           "forward_posterior, or run the layer through Decoder.forward / HVAE")
 
 
 class Decoder(nn.Module):

@@ -156,3 +156,104 @@ def test_decoder_standalone(name):
     torch.testing.assert_close(h2, h, rtol=1e-3, atol=1e-3)
     h3, _ = dec(pa.cuda())  # prior sampling
     assert torch.isfinite(h3).all() and not torch.equal(h3, h)
+
+
+def test_dmol_python_surface_against_reference_vectors():
+    """The module-level names of src/dmol.py (loss dmol.py:24-118, means :164-215, sampling :121-161) are importable and callable
+    on channels-last tensors; values and the loss gradient against the reference-made ``ops.pt``."""
+    import os
+
+    from causal_gen_amd import dmol
+    from oracle import dmol_ref
+
+    d = torch.load(os.path.join(os.path.dirname(__file__), "golden", "ops.pt"))["dmol"]
+    l = d["l"].cuda().requires_grad_(True)
+    x = d["x"].cuda()
+    loss = dmol.discretized_mix_logistic_loss(x, l)
+    assert loss.shape == (3,)
+    torch.testing.assert_close(loss.detach().cpu(), d["loss"], rtol=1e-4, atol=1e-6)  # north-star: DMoL nats/dim within 1e-4 rel
+    loss.sum().backward()
+    torch.testing.assert_close(l.grad.cpu(), d["grad_l"], rtol=2e-3, atol=2e-6)
+    # a non-trivial upstream gradient scales per sample
+    l2 = d["l"].cuda().requires_grad_(True)
+    wts = torch.tensor([0.5, -2.0, 3.0], device="cuda")
+    (dmol.discretized_mix_logistic_loss(x, l2) * wts).sum().backward()
+    torch.testing.assert_close(l2.grad.cpu(), d["grad_l"] * wts.cpu()[:, None, None, None], rtol=2e-3, atol=6e-6)
+    for mask in ("soft", "hard", "top3"):
+        m, s = dmol.mean_discretized_mix_logistic(d["l"].cuda(), 10, mask=mask, return_scale=True)
+        assert m.shape == (3, 7, 7, 3)
+        torch.testing.assert_close(m.cpu(), d[f"mean_{mask}"], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(s.cpu(), d[f"scale_{mask}"], rtol=1e-4, atol=1e-6)
+    assert dmol.mean_discretized_mix_logistic(d["l"].cuda(), 10).shape == (3, 7, 7, 3)
+    a, sa = dmol.sample_from_discretized_mix_logistic(d["l"].cuda(), 10, return_scale=True, t=0.7)
+    b = dmol.sample_from_discretized_mix_logistic(d["l"].cuda(), 10)
+    assert a.shape == (3, 7, 7, 3) and torch.isfinite(a).all() and a.abs().max() <= 1 and (sa > 0).all() and not torch.equal(a, b)
+    with pytest.raises(Exception):
+        dmol.discretized_mix_logistic_loss(d["x"], d["l"])  # CPU tensors: no fallback
+
+
+def test_dmolnet_standalone():
+    """DmolNet.forward / nll / sample (dmol.py:218-245) on their own against the oracle on the module's own state_dict."""
+    from causal_gen_amd import dmol
+    from causal_gen_amd.hps import setup_hparams
+    from oracle import dmol_ref
+
+    hp = setup_hparams("cmnist")
+    torch.manual_seed(5)
+    net = dmol.DmolNet(hp).cuda()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(3.0)
+    sd = _sd(net, "likelihood.")
+    g = torch.Generator().manual_seed(6)
+    h = torch.randn(3, hp.widths[0], 9, 9, generator=g)
+    x = (torch.randint(0, 256, (3, 3, 9, 9), generator=g).float() - 127.5) / 127.5
+    l = net(h.cuda())
+    assert l.shape == (3, 9, 9, 100)
+    torch.testing.assert_close(l.cpu(), dmol_ref.dmolnet_logits(sd, h), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(net.nll(h.cuda(), x.cuda()).cpu(), dmol_ref.dmolnet_nll(sd, h, x), rtol=1e-4, atol=1e-6)
+    for mask in ("soft", "hard", "top2"):
+        net.mask = mask
+        xs, sc = net.sample(h.cuda())
+        rx, rs = dmol_ref.dmolnet_sample(sd, h, mask=mask)
+        torch.testing.assert_close(xs.cpu(), rx, rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(sc.cpu(), rs, rtol=1e-4, atol=1e-6)
+    xs, sc = net.sample(h.cuda(), return_loc=False, t=0.5)
+    assert xs.shape == (3, 3, 9, 9) and xs.abs().max() <= 1 and torch.isfinite(sc).all()
+
+
+@pytest.mark.parametrize("name,cond_prior", [("morphomnist", True), ("ukbb192", False)])
+def test_decoder_block_halves_standalone(name, cond_prior):
+    """DecoderBlock.forward_prior / forward_posterior (vae.py:170-192) on their own against the oracle's Block on the module's own
+    state_dict (virtual cat[z, pa] / cat[z, pa, x]; temperature on the logscales)."""
+    import math
+
+    from causal_gen_amd import vae
+    from causal_gen_amd.hps import setup_hparams
+    from oracle import hvae_ref
+
+    hp = setup_hparams(name)
+    hp.vr = "light" if "ukbb" in hp.hps else None
+    hp.cond_prior = cond_prior
+    torch.manual_seed(7)
+    w, res = 64, 12
+    blk = vae.DecoderBlock(hp, w, w, res).cuda()
+    g = torch.Generator().manual_seed(8)
+    z = torch.randn(2, w, res, res, generator=g)
+    xa = torch.randn(2, w, res, res, generator=g)
+    pc = torch.randn(2, hp.context_dim, generator=g)
+    pa = pc[..., None, None].repeat(1, 1, res, res)
+    light = hp.vr == "light"
+    sd = _sd(blk, "b.")
+    ref_p = hvae_ref._block(sd, "b.prior", torch.cat([z, pa], 1) if cond_prior else z, light, 3, False, None)
+    zd = hp.z_dim
+    p_loc, p_ls, p_feat = blk.forward_prior(z.cuda(), pa.cuda() if cond_prior else None, t=0.8)
+    torch.testing.assert_close(p_loc.cpu(), ref_p[:, :zd], rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(p_ls.cpu(), ref_p[:, zd:2 * zd] + math.log(0.8), rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(p_feat.cpu(), ref_p[:, 2 * zd:], rtol=2e-4, atol=2e-5)
+    ref_q = hvae_ref._block(sd, "b.posterior", torch.cat([z, pa, xa], 1), light, 3, False, None)
+    q_loc, q_ls = blk.forward_posterior(z.cuda(), xa.cuda(), pc.cuda())  # (the broadcast parent vector is accepted as well)
+    torch.testing.assert_close(q_loc.cpu(), ref_q[:, :zd], rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(q_ls.cpu(), ref_q[:, zd:], rtol=2e-4, atol=2e-5)
+    with pytest.raises(RuntimeError, match="inference-only"):
+        blk.forward_prior(z.cuda().requires_grad_(True), pa.cuda())
