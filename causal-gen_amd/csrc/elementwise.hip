@@ -4,92 +4,40 @@
 
 namespace cgen {
 
-template <typename T, int V> struct VecIO;
-template <typename T> struct VecIO<T, 1> {
-  static __device__ __forceinline__ void ld(const T* p, float (&v)[1]) { v[0] = Elem<T>::ld(p); }
-  static __device__ __forceinline__ void st(T* p, const float (&v)[1]) { Elem<T>::st(p, v[0]); }
-};
-template <> struct VecIO<float, 4> {
-  static __device__ __forceinline__ void ld(const float* p, float (&v)[4]) {
-    const float4 t = *(const float4*)p;
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  }
-  static __device__ __forceinline__ void st(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
-};
-template <> struct VecIO<bf16_t, 4> {
-  static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[4]) {
-    const uint2 t = *(const uint2*)p;
-    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-  }
-  static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[4]) {
-    uint2 t;
-    t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-    t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-    *(uint2*)p = t;
-  }
-};
-
-struct Shape4 { int n, h, w, c; };
-template <typename T> union Pack16 { T e[16 / sizeof(T)]; uint4 v; };
-
-// index helper: flat group index -> (n, y, x, c0) for groups of V channels
-template <int V>
-__device__ __forceinline__ bool decode(int64_t g, const Shape4& s, int& n, int& y, int& x, int& c) {
-  const int cg = s.c / V;
-  const int64_t total = (int64_t)s.n * s.h * s.w * cg;
-  if (g >= total) return false;
-  c = (int)(g % cg) * V;
-  int64_t r = g / cg;
-  x = (int)(r % s.w); r /= s.w;
-  y = (int)(r % s.h);
-  n = (int)(r / s.h);
-  return true;
-}
-
-#define GRID_STRIDE(g) for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ; g += (int64_t)gridDim.x * blockDim.x)
+}  // namespace cgen
+#include "elementwise_bodies.inc"
+namespace cgen {
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(Shape4 so, int d, View in, View out) {
-  GRID_STRIDE(g) {
-    int n, y, x, c;
-    if (!decode<V>(g, so, n, y, x, c)) return;
-    float a[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) a[e] = 0.f;
-    for (int dy = 0; dy < d; ++dy)
-      for (int dx = 0; dx < d; ++dx) {
-        float v[V];
-        VecIO<T, V>::ld(vptr<T>(in, n, y * d + dy, x * d + dx) + c, v);
-#pragma unroll
-        for (int e = 0; e < V; ++e) a[e] += v[e];
-      }
-    const float inv = 1.f / (float)(d * d);
-#pragma unroll
-    for (int e = 0; e < V; ++e) a[e] *= inv;
-    VecIO<T, V>::st(vptr<T>(out, n, y, x) + c, a);
-  }
+  avgpool_fwd_body<T, V>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, so, d, in, out);
 }
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(Shape4 si, int d, View gout, View gin, int accumulate) {
-  const float inv = 1.f / (float)(d * d);
-  GRID_STRIDE(g) {
-    int n, y, x, c;
-    if (!decode<V>(g, si, n, y, x, c)) return;
-    float v[V];
-    VecIO<T, V>::ld(vptr<T>(gout, n, y / d, x / d) + c, v);
-#pragma unroll
-    for (int e = 0; e < V; ++e) v[e] *= inv;
-    T* dst = vptr<T>(gin, n, y, x) + c;
-    if (accumulate) {
-      float o[V];
-      VecIO<T, V>::ld(dst, o);
-#pragma unroll
-      for (int e = 0; e < V; ++e) v[e] += o[e];
-    }
-    VecIO<T, V>::st(dst, v);
-  }
+  avgpool_bwd_body<T, V>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, si, d, gout, gin, accumulate);
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(Shape4 so, int hi, int wi, float ish, float isw, View in,
+                                                           const float* bias, View out) {
+  upsample_fwd_body<T, V>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, so, hi, wi, ish, isw, in, bias, out);
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(Shape4 si, int ho, int wo, float ish, float isw, View gout,
+                                                           View gin, int accumulate) {
+  upsample_bwd_body<T, V>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, si, ho, wo, ish, isw, gout, gin, accumulate);
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void batch_broadcast_kernel(Shape4 s, const float* src, View out) {
+  batch_broadcast_body<T, V>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, s, src, out);
+}
+
+template <typename T, int V>
+__global__ __launch_bounds__(256) void axpby_kernel(Shape4 s, View in, View out, float alpha, float beta, int c_from, int accumulate) {
+  axpby_body<T, V>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x, s, in, out, alpha, beta, c_from, accumulate);
 }
 
 // aten::adaptive_avg_pool2d (vae.py:79-81, Block with a float down-rate): window of output cell o along an axis of length
@@ -99,7 +47,7 @@ __device__ __forceinline__ int ap_end(int o, int in, int out) { return (int)((((
 
 template <typename T, int V>
 __global__ __launch_bounds__(256) void adaptive_avgpool_fwd_kernel(Shape4 so, int hi, int wi, View in, View out) {
-  GRID_STRIDE(g) {
+  GRID_STRIDE_GLOBAL(g) {
     int n, y, x, c;
     if (!decode<V>(g, so, n, y, x, c)) return;
     const int y0 = ap_start(y, hi, so.h), y1 = ap_end(y, hi, so.h), x0 = ap_start(x, wi, so.w), x1 = ap_end(x, wi, so.w);
@@ -124,7 +72,7 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_fwd_kernel(Shape4 so, in
 // (windows overlap by at most one pixel per side, so the candidates are the cells around floor(y * out / in))
 template <typename T, int V>
 __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(Shape4 si, int ho, int wo, View gout, View gin, int accumulate) {
-  GRID_STRIDE(g) {
+  GRID_STRIDE_GLOBAL(g) {
     int n, y, x, c;
     if (!decode<V>(g, si, n, y, x, c)) return;
     float a[V];
@@ -155,65 +103,7 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(Shape4 si, in
   }
 }
 
-// nearest-neighbour source index exactly as ATen's upsample_nearest2d with an explicit scale_factor:
 // src = min(floorf(dst * (float)(1/scale_factor)), in-1)
-__device__ __forceinline__ int nn_src(int dst, float inv_scale, int in_size) {
-  const int s = (int)floorf((float)dst * inv_scale);
-  return s < in_size - 1 ? s : in_size - 1;
-}
-
-template <typename T, int V>
-__global__ __launch_bounds__(256) void upsample_fwd_kernel(Shape4 so, int hi, int wi, float ish, float isw, View in,
-                                                           const float* bias, View out) {
-  GRID_STRIDE(g) {
-    int n, y, x, c;
-    if (!decode<V>(g, so, n, y, x, c)) return;
-    float v[V];
-    VecIO<T, V>::ld(vptr<T>(in, n, nn_src(y, ish, hi), nn_src(x, isw, wi)) + c, v);
-    if (bias) {
-      const float* b = bias + ((int64_t)y * so.w + x) * so.c + c;
-#pragma unroll
-      for (int e = 0; e < V; ++e) v[e] = b[e] + v[e];
-    }
-    VecIO<T, V>::st(vptr<T>(out, n, y, x) + c, v);
-  }
-}
-
-template <typename T, int V>
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(Shape4 si, int ho, int wo, float ish, float isw, View gout,
-                                                           View gin, int accumulate) {
-  GRID_STRIDE(g) {
-    int n, y, x, c;
-    if (!decode<V>(g, si, n, y, x, c)) return;
-    float a[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) a[e] = 0.f;
-    // candidate destination rows/cols: a generous window around y/ish, filtered by the exact forward map
-    int y0 = (int)floorf((float)y / ish) - 1, y1 = (int)floorf((float)(y + 1) / ish) + 1;
-    int x0 = (int)floorf((float)x / isw) - 1, x1 = (int)floorf((float)(x + 1) / isw) + 1;
-    y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0;
-    y1 = y1 > ho - 1 ? ho - 1 : y1; x1 = x1 > wo - 1 ? wo - 1 : x1;
-    for (int yo = y0; yo <= y1; ++yo) {
-      if (nn_src(yo, ish, si.h) != y) continue;
-      for (int xo = x0; xo <= x1; ++xo) {
-        if (nn_src(xo, isw, si.w) != x) continue;
-        float v[V];
-        VecIO<T, V>::ld(vptr<T>(gout, n, yo, xo) + c, v);
-#pragma unroll
-        for (int e = 0; e < V; ++e) a[e] += v[e];
-      }
-    }
-    T* dst = vptr<T>(gin, n, y, x) + c;
-    if (accumulate) {
-      float o[V];
-      VecIO<T, V>::ld(dst, o);
-#pragma unroll
-      for (int e = 0; e < V; ++e) a[e] += o[e];
-    }
-    VecIO<T, V>::st(dst, a);
-  }
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void batch_reduce_kernel(Shape4 s, View in, float* out, int accumulate) {
   // a workgroup owns 64 consecutive (y, x, c) elements; its 4 waves split the batch and are combined in a fixed order
@@ -237,44 +127,6 @@ __global__ __launch_bounds__(256) void batch_reduce_kernel(Shape4 s, View in, fl
       out[g] = accumulate ? out[g] + t : t;
     }
     __syncthreads();
-  }
-}
-
-template <typename T, int V>
-__global__ __launch_bounds__(256) void batch_broadcast_kernel(Shape4 s, const float* src, View out) {
-  GRID_STRIDE(g) {
-    int n, y, x, c;
-    if (!decode<V>(g, s, n, y, x, c)) return;
-    float v[V];
-    const float* b = src + ((int64_t)y * s.w + x) * s.c + c;
-#pragma unroll
-    for (int e = 0; e < V; ++e) v[e] = b[e];
-    VecIO<T, V>::st(vptr<T>(out, n, y, x) + c, v);
-  }
-}
-
-template <typename T, int V>
-__global__ __launch_bounds__(256) void axpby_kernel(Shape4 s, View in, View out, float alpha, float beta, int c_from, int accumulate) {
-  GRID_STRIDE(g) {
-    int n, y, x, c;
-    if (!decode<V>(g, s, n, y, x, c)) return;
-    float v[V];
-    if (in.p) {
-      VecIO<T, V>::ld(vptr<T>(in, n, y, x) + c, v);
-#pragma unroll
-      for (int e = 0; e < V; ++e) v[e] *= (c + e >= c_from) ? alpha * beta : alpha;
-    } else {
-#pragma unroll
-      for (int e = 0; e < V; ++e) v[e] = alpha;
-    }
-    T* dst = vptr<T>(out, n, y, x) + c;
-    if (accumulate) {
-      float o[V];
-      VecIO<T, V>::ld(dst, o);
-#pragma unroll
-      for (int e = 0; e < V; ++e) v[e] += o[e];
-    }
-    VecIO<T, V>::st(dst, v);
   }
 }
 
@@ -306,7 +158,7 @@ __global__ __launch_bounds__(256) void axpby_flat_kernel(int64_t nvec, const uin
 
 template <typename T, typename S>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(Shape4 s, const S* src, View out, float sub, float mul) {
-  GRID_STRIDE(g) {
+  GRID_STRIDE_GLOBAL(g) {
     int n, y, x, c;
     if (!decode<1>(g, s, n, y, x, c)) return;
     const float v = ((float)src[(((int64_t)n * s.c + c) * s.h + y) * s.w + x] - sub) * mul;
@@ -317,7 +169,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(Shape4 s, const S* sr
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(Shape4 s, View in, float* dst) {
   const int64_t total = (int64_t)s.n * s.c * s.h * s.w;
-  GRID_STRIDE(g) {
+  GRID_STRIDE_GLOBAL(g) {
     if (g >= total) return;
     const int x = (int)(g % s.w);
     const int y = (int)((g / s.w) % s.h);
@@ -337,7 +189,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(Shape4 s, int ks_rt, int ci
   const int groups = cphys / 8;
   const int64_t total = (int64_t)s.n * s.h * s.w * groups;
   const bool vec = ((uintptr_t)out.p % 16 == 0) && ((out.sn * sizeof(T)) % 16 == 0) && ((out.sh * sizeof(T)) % 16 == 0) && ((out.sw * sizeof(T)) % 16 == 0);
-  GRID_STRIDE(g) {
+  GRID_STRIDE_GLOBAL(g) {
     if (g >= total) return;
     const int cg = (int)(g % groups) * 8;
     int64_t r = g / groups;
@@ -493,7 +345,7 @@ __global__ __launch_bounds__(256) void im2col_strided_kernel(Shape4 so, int hi, 
                                                              int cphys) {
   const int taps = ks * ks;
   const int64_t total = (int64_t)so.n * so.h * so.w * cphys;
-  GRID_STRIDE(g) {
+  GRID_STRIDE_GLOBAL(g) {
     if (g >= total) return;
     const int oc = (int)(g % cphys);
     int64_t r = g / cphys;
@@ -516,7 +368,7 @@ __global__ __launch_bounds__(256) void col2im_strided_kernel(Shape4 si, int ho, 
                                                              int accumulate) {
   const int taps = ks * ks;
   const int64_t total = (int64_t)si.n * si.h * si.w * si.c;
-  GRID_STRIDE(g) {
+  GRID_STRIDE_GLOBAL(g) {
     if (g >= total) return;
     const int c = (int)(g % si.c);
     int64_t r = g / si.c;
@@ -550,7 +402,7 @@ __device__ __forceinline__ float unary_df(int op, float p, float x) {
 template <typename T>
 __global__ __launch_bounds__(256) void unary_fwd_kernel(Shape4 s, int op, float p, View in, View out) {
   const int64_t total = (int64_t)s.n * s.h * s.w * s.c;
-  GRID_STRIDE(g) {
+  GRID_STRIDE_GLOBAL(g) {
     if (g >= total) return;
     const int c = (int)(g % s.c);
     int64_t r = g / s.c;
@@ -563,7 +415,7 @@ __global__ __launch_bounds__(256) void unary_fwd_kernel(Shape4 s, int op, float 
 template <typename T>
 __global__ __launch_bounds__(256) void unary_bwd_kernel(Shape4 s, int op, float p, View xin, View gout, View gin, int accumulate) {
   const int64_t total = (int64_t)s.n * s.h * s.w * s.c;
-  GRID_STRIDE(g) {
+  GRID_STRIDE_GLOBAL(g) {
     if (g >= total) return;
     const int c = (int)(g % s.c);
     int64_t r = g / s.c;

@@ -7,23 +7,29 @@
 
 namespace cgen {
 
-#define LAT_CHUNK 2048  // per-sample elements handled by one block (8 per thread)
+}  // namespace cgen
+#include "latent_bodies.inc"
+namespace cgen {
 
-struct LatP {
-  int n, h, w, c;
-  View q_loc, q_ls, p_loc, p_ls, eps_in, z, eps_out;
-  const uint64_t* rng;
-  uint32_t stream_id;
-  float logt;
-  float* kl_part;
-  int kl_stride;
-};
+__global__ __launch_bounds__(256) void reparam_kl_fwd_vec8_kernel(LatP p) {
+  __shared__ float sm[4];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  uint64_t seed = 0, off = 0;
+  if (!p.eps_in.p) { seed = p.rng[0]; off = p.rng[1]; }
+  const float kl_acc = reparam_kl_fwd_vec8_item(p, b, chunk, threadIdx.x, seed, off);
+  const float tot = block_sum_256(kl_acc, sm);
+  if (threadIdx.x == 0) p.kl_part[(int64_t)b * p.kl_stride + chunk] = tot;
+}
 
-__device__ __forceinline__ void lat_decode(int e, int w, int c, int& y, int& x, int& ch) {
-  ch = e % c;
-  const int r = e / c;
-  x = r % w;
-  y = r / w;
+__global__ __launch_bounds__(256) void reparam_kl_bwd_vec8_kernel(LatBwdP p) {
+  if ((int)blockIdx.x >= p.main_blocks) {  // rider blocks
+    const int64_t tot = (int64_t)p.n * p.h * p.w * (p.ride_c >> 3);
+    const int nb = gridDim.x - p.main_blocks;
+    for (int64_t g = (int64_t)(blockIdx.x - p.main_blocks) * 256 + threadIdx.x; g < tot; g += (int64_t)nb * 256) reparam_ride_item(p, g);
+    return;
+  }
+  const int64_t total = (int64_t)p.n * ((p.h * p.w * p.c) >> 3);
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)p.main_blocks * 256) reparam_kl_bwd_vec8_item(p, g);
 }
 
 template <typename T>
@@ -59,19 +65,6 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(LatP p) {
   if (threadIdx.x == 0) p.kl_part[(int64_t)b * p.kl_stride + chunk] = tot;
 }
 
-struct LatBwdP {
-  int n, h, w, c;
-  View q_loc, q_ls, p_loc, p_ls, z, gz, g_q_loc, g_q_ls, g_p_loc, g_p_ls;
-  const float* coef;
-  const float* chan_scale;  // optional [c]: per-channel multiplier of the KL gradient (free-bits mask)
-  int coef_stride, acc_q, acc_p;
-  float logt;
-  // optional rider (vec8 kernel only): blocks past `main_blocks` copy / accumulate the [n,h,w,ride_c] view ride_src into
-  // ride_dst -- the residual's share of grad(prior output), which would otherwise be a launch of its own
-  View ride_src, ride_dst;
-  int main_blocks, ride_c, ride_acc;
-};
-
 template <typename T>
 __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(LatBwdP p) {
   const int per = p.h * p.w * p.c;
@@ -104,141 +97,6 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(LatBwdP p) {
     o = vptr<T>(p.g_p_ls, b, y, x) + ch;  Elem<T>::st(o, p.acc_p ? Elem<T>::ld(o) + gps : gps);
   }
 }
-
-// ----------------------------------------------------------------------------- bf16 fast paths: 8 channels per thread
-// The scalar kernels above spend ~300 VALU instructions per ELEMENT on index decoding and 64-bit addressing; here a thread
-// owns 8 consecutive channels of one pixel (16-byte accesses, 32-bit offsets, one division per 8 elements, two Philox
-// groups per 8 normals).  Same element -> Philox index mapping as the scalar kernel, so the noise is unchanged.
-__device__ __forceinline__ int off8(const View& v, int b, int y, int x, int ch) { return (int)(b * v.sn + y * v.sh + x * v.sw) + ch; }
-__device__ __forceinline__ void unpack8(uint4 v, float (&o)[8]) {
-  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(w[e] << 16); o[2 * e + 1] = __uint_as_float(w[e] & 0xffff0000u); }
-}
-__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
-  uint4 o;
-  o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]); o.z = f2bf_pk(v[4], v[5]); o.w = f2bf_pk(v[6], v[7]);
-  return o;
-}
-__device__ __forceinline__ uint4 ld8(const View& v, int off) { return *(const uint4*)((const bf16_t*)v.p + off); }
-__device__ __forceinline__ void st8(const View& v, int off, uint4 val) { *(uint4*)((bf16_t*)v.p + off) = val; }
-
-__global__ __launch_bounds__(256) void reparam_kl_fwd_vec8_kernel(LatP p) {
-  __shared__ float sm[4];
-  const int b = blockIdx.y, chunk = blockIdx.x;
-  const int per = p.h * p.w * p.c, cg = p.c >> 3;
-  uint64_t seed = 0, off = 0;
-  if (!p.eps_in.p) { seed = p.rng[0]; off = p.rng[1]; }
-  float kl_acc = 0.f;
-  // this block's LAT_CHUNK elements = LAT_CHUNK / 8 groups, one per thread (LAT_CHUNK == 2048, 256 threads)
-  const int e = chunk * LAT_CHUNK + threadIdx.x * 8;
-  if (e < per) {
-    const int g8 = e >> 3;
-    const int pix = g8 / cg, ch = (g8 - pix * cg) * 8;
-    const int y = pix / p.w, x = pix - y * p.w;
-    float ql[8], qs[8], pl[8], ps[8], eps[8], z[8];
-    unpack8(ld8(p.q_loc, off8(p.q_loc, b, y, x, ch)), ql);
-    unpack8(ld8(p.q_ls, off8(p.q_ls, b, y, x, ch)), qs);
-    unpack8(ld8(p.p_loc, off8(p.p_loc, b, y, x, ch)), pl);
-    unpack8(ld8(p.p_ls, off8(p.p_ls, b, y, x, ch)), ps);
-    if (p.eps_in.p) {
-      unpack8(ld8(p.eps_in, off8(p.eps_in, b, y, x, ch)), eps);
-    } else {
-      const uint64_t i0 = (uint64_t)b * per + e;  // multiple of 8
-      float n4[4];
-      Philox::normal4(seed, off, p.stream_id, i0 >> 2, n4);
-      eps[0] = n4[0]; eps[1] = n4[1]; eps[2] = n4[2]; eps[3] = n4[3];
-      Philox::normal4(seed, off, p.stream_id, (i0 >> 2) + 1, n4);
-      eps[4] = n4[0]; eps[5] = n4[1]; eps[6] = n4[2]; eps[7] = n4[3];
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float q = qs[k] + p.logt, pp = ps[k] + p.logt;
-      const float sq = expf(q), sp = expf(pp), d = ql[k] - pl[k];
-      z[k] = ql[k] + sq * eps[k];
-      kl_acc += -0.5f + pp - q + 0.5f * (sq * sq + d * d) / (sp * sp);
-    }
-    st8(p.z, off8(p.z, b, y, x, ch), pack8(z));
-    if (p.eps_out.p) st8(p.eps_out, off8(p.eps_out, b, y, x, ch), pack8(eps));
-  }
-  const float tot = block_sum_256(kl_acc, sm);
-  if (threadIdx.x == 0) p.kl_part[(int64_t)b * p.kl_stride + chunk] = tot;
-}
-
-__global__ __launch_bounds__(256) void reparam_kl_bwd_vec8_kernel(LatBwdP p) {
-  if ((int)blockIdx.x >= p.main_blocks) {  // rider blocks
-    const int rg = p.ride_c >> 3, per = p.h * p.w * rg;
-    const int64_t tot = (int64_t)p.n * per;
-    const int nb = gridDim.x - p.main_blocks;
-    for (int64_t g = (int64_t)(blockIdx.x - p.main_blocks) * 256 + threadIdx.x; g < tot; g += (int64_t)nb * 256) {
-      const int b = (int)(g / per), g8 = (int)(g - (int64_t)b * per);
-      const int pix = g8 / rg, ch = (g8 - pix * rg) * 8;
-      const int y = pix / p.w, x = pix - y * p.w;
-      uint4 v = ld8(p.ride_src, off8(p.ride_src, b, y, x, ch));
-      const int o = off8(p.ride_dst, b, y, x, ch);
-      if (p.ride_acc) {
-        float a[8], t[8];
-        unpack8(v, a);
-        unpack8(ld8(p.ride_dst, o), t);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a[k] += t[k];
-        v = pack8(a);
-      }
-      st8(p.ride_dst, o, v);
-    }
-    return;
-  }
-  const int per8 = (p.h * p.w * p.c) >> 3, cg = p.c >> 3;
-  const int64_t total = (int64_t)p.n * per8;
-  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)p.main_blocks * 256) {
-    const int b = (int)(g / per8), g8 = (int)(g - (int64_t)b * per8);
-    const int pix = g8 / cg, ch = (g8 - pix * cg) * 8;
-    const int y = pix / p.w, x = pix - y * p.w;
-    float ql[8], qs[8], pl[8], ps[8], gz[8], zv[8];
-    unpack8(ld8(p.q_loc, off8(p.q_loc, b, y, x, ch)), ql);
-    unpack8(ld8(p.q_ls, off8(p.q_ls, b, y, x, ch)), qs);
-    unpack8(ld8(p.p_loc, off8(p.p_loc, b, y, x, ch)), pl);
-    unpack8(ld8(p.p_ls, off8(p.p_ls, b, y, x, ch)), ps);
-    if (p.gz.p) {
-      unpack8(ld8(p.gz, off8(p.gz, b, y, x, ch)), gz);
-      unpack8(ld8(p.z, off8(p.z, b, y, x, ch)), zv);
-    }
-    const float k0 = p.coef[(int64_t)b * p.coef_stride];
-    float o1[8], o2[8], o3[8], o4[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const float kk = k0 * (p.chan_scale ? p.chan_scale[ch + k] : 1.f);
-      const float q = qs[k] + p.logt, pp = ps[k] + p.logt;
-      const float e2q = expf(2.f * q), ie2p = expf(-2.f * pp), d = ql[k] - pl[k];
-      float gql = kk * d * ie2p, gqs = kk * (e2q * ie2p - 1.f);
-      o3[k] = -kk * d * ie2p;
-      o4[k] = kk * (1.f - (e2q + d * d) * ie2p);
-      if (p.gz.p) { gql += gz[k]; gqs += gz[k] * (zv[k] - ql[k]); }
-      o1[k] = gql; o2[k] = gqs;
-    }
-    const int a1 = off8(p.g_q_loc, b, y, x, ch), a2 = off8(p.g_q_ls, b, y, x, ch), a3 = off8(p.g_p_loc, b, y, x, ch), a4 = off8(p.g_p_ls, b, y, x, ch);
-    if (p.acc_q) {
-      float t[8];
-      unpack8(ld8(p.g_q_loc, a1), t);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) o1[k] += t[k];
-      unpack8(ld8(p.g_q_ls, a2), t);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) o2[k] += t[k];
-    }
-    if (p.acc_p) {
-      float t[8];
-      unpack8(ld8(p.g_p_loc, a3), t);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) o3[k] += t[k];
-      unpack8(ld8(p.g_p_ls, a4), t);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) o4[k] += t[k];
-    }
-    st8(p.g_q_loc, a1, pack8(o1)); st8(p.g_q_ls, a2, pack8(o2)); st8(p.g_p_loc, a3, pack8(o3)); st8(p.g_p_ls, a4, pack8(o4));
-  }
-}
-
 
 // ============================================================================= latent layer: reparameterise + KL + z_proj in one launch
 // The decoder's stochastic layer (vae.py:264-294) is  z = q_loc + exp(q_ls) eps;  kl;  h' = z_proj(cat[z, pa]) + h + p_feat.

@@ -1,0 +1,618 @@
+// Per-image STAGE INTERPRETER (bf16): one launch walks a whole run of low-resolution layers.
+//
+// Why.  At <= 12x12 (ukbb192 / mimic) and at every resolution of the 32x32 models a layer has a few hundred MFMAs per image:
+// one launch per conv is a pure latency chain -- dispatch + prologue + operand round trips, ~10 us each, ~900 per step
+// (DESIGN 3.7).  Samples are independent, and a whole low-resolution image fits one CU's LDS.  So the engine hands this
+// kernel a LIST of consecutive ops (convs with their fused prologue / epilogue, pooling, upsampling + bias, reparameterise +
+// KL and its gradient, gradient copies) and ONE workgroup per image executes the list front to back with workgroup barriers
+// between ops instead of kernel boundaries: every tensor an op reads was written by the same workgroup, so
+// __syncthreads() is all the ordering there is (no grid barrier, no cross-CU hand-off -- MI355X_MICROARCH.md prices those
+// at 4-7 us, no better than the launch they would replace).
+//
+// A conv inside the list (vae.py:53-71 Block convs, :165-167 z_proj / z_feat_proj, their data gradients):
+//   * the image's whole input -- every segment of the virtual torch.cat, zero halo -- is staged ONCE by global->LDS DMA
+//     (linear layout, 16-byte channel groups, odd group count per pixel), activation applied in place;
+//   * the 8 waves split the (16-pixel group) x (16-channel tile) output grid by a host-side plan; a wave holds <= 4 x 2 MFMA
+//     accumulators and walks the whole K axis: pixel fragments from LDS (one ds_read_b128 each, tap shifts come from a
+//     host-built K-step table), weight fragments STRAIGHT from the weight image in global memory (L2-resident; a 4-deep
+//     register ring keeps the loads ahead of the MFMAs) -- no weight slab in LDS, no cross-wave reduction, deterministic;
+//   * bias is the accumulators' initial value; the epilogue ((.) * act'(aux) + res1 + res2, bf16 rounding, zero fill of the
+//     padding channels) goes straight from the accumulators to global memory, 8 bytes per lane.
+// The element-wise ops run the SAME bodies as their stand-alone kernels (elementwise_bodies.inc, latent_bodies.inc) over
+// one image.  Everything is planned on the host (cgen_stage_plan) into one device blob the engine caches per op list.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+#include "elementwise_bodies.inc"
+#include "latent_bodies.inc"
+
+namespace cgen {
+
+typedef float st_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 st_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short st_s16x2 __attribute__((ext_vector_type(2)));
+
+#define ST_THREADS 512
+#define ST_WAVES 8
+#define ST_PB 4   // pixel groups per register block
+#define ST_TB 2   // channel tiles per register block
+#define ST_DEPTH 4  // K-steps of weights in flight per wave
+
+__device__ uint4 st_zero16[4];  // DMA / load source of everything that is "zero" (halo, padding groups, absent operands)
+
+struct SDiv { uint32_t mul, shift; };
+static inline SDiv mk_sdiv(uint32_t d) {  // q = (umulhi(n, mul) + n) >> shift, exact for 0 <= n < 2^31 (round-up method)
+  SDiv f;
+  if (d == 1) { f.mul = 0; f.shift = 0; return f; }
+  uint32_t sh = 0;
+  while ((1u << sh) < d) ++sh;
+  f.shift = sh;
+  f.mul = (uint32_t)((((uint64_t)1 << (32 + sh)) + d - 1) / d - ((uint64_t)1 << 32));
+  return f;
+}
+__device__ __forceinline__ int sdiv(int n, const SDiv& f) { return (int)(((uint64_t)__umulhi((uint32_t)n, f.mul) + (uint32_t)n) >> f.shift); }
+
+struct SView {  // per-image view: 64-bit base, 32-bit ELEMENT strides (the host checked that every offset fits)
+  char* p;
+  int sn, sh, sw, c, cpad, pad0;
+};
+
+struct StConv {
+  int H, W, KS, halo, nseg, act, dact, Co;
+  int C8, Gs, Wp, HW, ngroups, npieces, G, T;
+  int nk, krow, k_lo, rows_pad, pixstride, zoff, ktab_off, pad0;
+  SView seg[CGEN_MAX_SEG];
+  int seg_koff[CGEN_MAX_SEG];
+  SView out, aux, res1, res2;
+  const bf16_t* w;
+  const float* bias;
+  SDiv d_gs, d_wp, d_w;
+  int wg0[ST_WAVES], wg1[ST_WAVES], wt0[ST_WAVES], wt1[ST_WAVES];
+};
+
+struct StElem {
+  Shape4 s;      // n == 1 (one image); h, w, c of the tensor the body iterates over
+  int d, hi, wi, accumulate, c_from, vec, pad0, pad1;
+  float ish, isw, alpha, beta;
+  const float* src;
+  View in, out;  // whole-batch views: the kernel shifts them to its image
+};
+
+struct StOp {
+  int kind, lds_bytes, pad0, pad1;
+  union {
+    StConv conv;
+    StElem elem;
+    LatP lat;
+    LatBwdP latb;
+  };
+};
+
+// ----------------------------------------------------------------------------- device: convolution of one image
+__device__ __forceinline__ uint4 st_act_group(uint4 v, const int act) {
+  if (act == CGEN_ACT_RELU) {  // bf16 ReLU == signed 16-bit max(x, 0) on the raw bits
+    union { uint32_t u; st_s16x2 s; } c;
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      c.u = w[e];
+      c.s = __builtin_elementwise_max(c.s, (st_s16x2){0, 0});
+      w[e] = c.u;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  return gelu8_fwd_bf16(v);
+}
+
+__device__ __forceinline__ float st_bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float st_bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ void st_conv(const StConv& c, const int* __restrict__ ktab, const int n, char* __restrict__ smem) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, kg = lane >> 4;
+
+  // ---- stage the image: every 16-byte group of the halo'd, concatenated input, by LDS-DMA (zeros from the zero page)
+  {
+    const char* b0 = c.seg[0].p + (int64_t)n * c.seg[0].sn * 2;
+    const char* b1 = c.seg[1].p + (int64_t)n * c.seg[1].sn * 2;
+    const char* b2 = c.seg[2].p + (int64_t)n * c.seg[2].sn * 2;
+    const char* b3 = c.seg[3].p + (int64_t)n * c.seg[3].sn * 2;
+    for (int pi = wave; pi < c.npieces; pi += ST_WAVES) {
+      const int q = pi * 64 + lane;
+      const int pix = sdiv(q, c.d_gs), grp = q - pix * c.Gs;
+      const int yy = sdiv(pix, c.d_wp), xx = pix - yy * c.Wp;
+      const int y = yy - c.halo, x = xx - c.halo;
+      const int c8 = grp * 8;
+      int s = 0;
+#pragma unroll
+      for (int k = 1; k < CGEN_MAX_SEG; ++k) s += (k < c.nseg && c8 >= c.seg_koff[k]) ? 1 : 0;
+      const char* base = s == 0 ? b0 : (s == 1 ? b1 : (s == 2 ? b2 : b3));
+      const int sh = s == 0 ? c.seg[0].sh : (s == 1 ? c.seg[1].sh : (s == 2 ? c.seg[2].sh : c.seg[3].sh));
+      const int sw = s == 0 ? c.seg[0].sw : (s == 1 ? c.seg[1].sw : (s == 2 ? c.seg[2].sw : c.seg[3].sw));
+      const int sc = s == 0 ? c.seg[0].c : (s == 1 ? c.seg[1].c : (s == 2 ? c.seg[2].c : c.seg[3].c));
+      const int ko = s == 0 ? c.seg_koff[0] : (s == 1 ? c.seg_koff[1] : (s == 2 ? c.seg_koff[2] : c.seg_koff[3]));
+      const int cs = c8 - ko;
+      const bool ok = q < c.ngroups && (unsigned)y < (unsigned)c.H && (unsigned)x < (unsigned)c.W && cs < sc;
+      const char* src = ok ? base + (int64_t)(y * sh + x * sw + cs) * 2 : (const char*)st_zero16;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(smem + pi * 1024), 16, 0, 0);
+    }
+  }
+  __syncthreads();  // (hipcc drains vmcnt before the barrier: the image has landed)
+  if (c.act != CGEN_ACT_NONE) {
+    uint4* img = (uint4*)smem;
+    for (int q = tid; q < c.ngroups; q += ST_THREADS) img[q] = st_act_group(img[q], c.act);
+    __syncthreads();
+  }
+
+  // ---- this wave's share of the (pixel group) x (channel tile) grid
+  const int g0 = c.wg0[wave], g1 = c.wg1[wave], t0 = c.wt0[wave], t1 = c.wt1[wave];
+  const char* outp = c.out.p + (int64_t)n * c.out.sn * 2;
+  const char* auxp = c.aux.p ? c.aux.p + (int64_t)n * c.aux.sn * 2 : nullptr;
+  const char* r1p = c.res1.p ? c.res1.p + (int64_t)n * c.res1.sn * 2 : nullptr;
+  const char* r2p = c.res2.p ? c.res2.p + (int64_t)n * c.res2.sn * 2 : nullptr;
+  const int nk = c.nk;
+  for (int tb = t0; tb < t1; tb += ST_TB) {
+    const int nt = min(ST_TB, t1 - tb);
+    // weight rows of this lane (rows past the image are clamped: their results are never stored)
+    const bf16_t* wrow[ST_TB];
+    st_f32x4 binit[ST_TB];
+#pragma unroll
+    for (int j = 0; j < ST_TB; ++j) {
+      const int row = min((tb + j) * 16 + r, c.rows_pad - 1);
+      wrow[j] = c.w + ((int64_t)row * c.krow + c.k_lo + kg * 8);
+      const int co = (tb + j) * 16 + kg * 4;
+      float b[4] = {0.f, 0.f, 0.f, 0.f};
+      if (c.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = c.bias[min(co + e, c.Co - 1)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[e] = (co + e < c.Co) ? b[e] : 0.f;
+      }
+      binit[j] = (st_f32x4){b[0], b[1], b[2], b[3]};
+    }
+    for (int pb = g0; pb < g1; pb += ST_PB) {
+      const int np = min(ST_PB, g1 - pb);
+      int pbase[ST_PB], py[ST_PB], px[ST_PB];
+      bool pv[ST_PB];
+#pragma unroll
+      for (int i = 0; i < ST_PB; ++i) {
+        int p = (pb + i) * 16 + r;
+        pv[i] = i < np && p < c.HW;
+        p = min(p, c.HW - 1);
+        py[i] = sdiv(p, c.d_w);
+        px[i] = p - py[i] * c.W;
+        pbase[i] = (py[i] * c.Wp + px[i]) * c.pixstride;
+      }
+      st_f32x4 acc[ST_PB][ST_TB];
+#pragma unroll
+      for (int i = 0; i < ST_PB; ++i)
+#pragma unroll
+        for (int j = 0; j < ST_TB; ++j) acc[i][j] = binit[j];
+
+      // ---- K loop: ring of ST_DEPTH K-steps (weight fragments + table entries) in flight
+      st_bf16x8 wf[ST_DEPTH][ST_TB];
+      int kt[ST_DEPTH];
+#pragma unroll
+      for (int d = 0; d < ST_DEPTH; ++d) {
+        kt[d] = -1;
+#pragma unroll
+        for (int j = 0; j < ST_TB; ++j) wf[d][j] = (st_bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (d < nk) {
+          kt[d] = ktab[d * 4 + kg];
+#pragma unroll
+          for (int j = 0; j < ST_TB; ++j)
+            if (j < nt) wf[d][j] = *(const st_bf16x8*)(wrow[j] + d * 32);
+        }
+      }
+      for (int ks0 = 0; ks0 < nk; ks0 += ST_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < ST_DEPTH; ++d) {
+          const int ks = ks0 + d;
+          if (ks < nk) {
+            const int ko = kt[d];
+            st_bf16x8 a[ST_PB];
+#pragma unroll
+            for (int i = 0; i < ST_PB; ++i)
+              if (i < np) a[i] = *(const st_bf16x8*)(smem + (ko < 0 ? c.zoff : pbase[i] + ko));
+#pragma unroll
+            for (int i = 0; i < ST_PB; ++i)
+              if (i < np) {
+#pragma unroll
+                for (int j = 0; j < ST_TB; ++j)
+                  if (j < nt) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[d][j], a[i], acc[i][j], 0, 0, 0);
+              }
+            if (ks + ST_DEPTH < nk) {  // refill this slot
+              kt[d] = ktab[(ks + ST_DEPTH) * 4 + kg];
+#pragma unroll
+              for (int j = 0; j < ST_TB; ++j)
+                if (j < nt) wf[d][j] = *(const st_bf16x8*)(wrow[j] + (ks + ST_DEPTH) * 32);
+            }
+          }
+        }
+      }
+
+      // ---- epilogue: lane owns channels co .. co+3 of pixel (py, px) of every block tile
+#pragma unroll
+      for (int i = 0; i < ST_PB; ++i) {
+        if (!pv[i]) continue;
+        const int o_out = (py[i] * c.out.sh + px[i] * c.out.sw) * 2;
+        const int o_aux = (py[i] * c.aux.sh + px[i] * c.aux.sw) * 2;
+        const int o_r1 = (py[i] * c.res1.sh + px[i] * c.res1.sw) * 2;
+        const int o_r2 = (py[i] * c.res2.sh + px[i] * c.res2.sw) * 2;
+#pragma unroll
+        for (int j = 0; j < ST_TB; ++j) {
+          if (j >= nt) continue;
+          const int co = (tb + j) * 16 + kg * 4;
+          float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+          if (co + 4 <= c.Co) {
+            if (auxp) {
+              const uint2 a2 = *(const uint2*)(auxp + o_aux + co * 2);
+              const float av[4] = {st_bf_lo(a2.x), st_bf_hi(a2.x), st_bf_lo(a2.y), st_bf_hi(a2.y)};
+              if (c.dact == CGEN_ACT_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = av[e] > 0.f ? v[e] : 0.f;
+              } else if (c.dact == CGEN_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  float cdf, pdf;
+                  gelu_terms_fast(av[e], cdf, pdf);
+                  v[e] *= cdf + av[e] * pdf;
+                }
+              }
+            }
+            if (r1p) {
+              const uint2 t = *(const uint2*)(r1p + o_r1 + co * 2);
+              v[0] += st_bf_lo(t.x); v[1] += st_bf_hi(t.x); v[2] += st_bf_lo(t.y); v[3] += st_bf_hi(t.y);
+            }
+            if (r2p) {
+              const uint2 t = *(const uint2*)(r2p + o_r2 + co * 2);
+              v[0] += st_bf_lo(t.x); v[1] += st_bf_hi(t.x); v[2] += st_bf_lo(t.y); v[3] += st_bf_hi(t.y);
+            }
+            uint2 o;
+            o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]);
+            *(uint2*)(outp + o_out + co * 2) = o;
+          } else {  // ragged width: element by element; channels [Co, out.cpad) are written as zeros
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int ce = co + e;
+              if (ce < c.Co) {
+                float u = v[e];
+                if (auxp) u *= act_bwd(c.dact, bf2f(*(const bf16_t*)(auxp + o_aux + ce * 2)));
+                if (r1p) u += bf2f(*(const bf16_t*)(r1p + o_r1 + ce * 2));
+                if (r2p) u += bf2f(*(const bf16_t*)(r2p + o_r2 + ce * 2));
+                *(bf16_t*)(outp + o_out + ce * 2) = f2bf(u);
+              } else if (ce < c.out.cpad) {
+                *(bf16_t*)(outp + o_out + ce * 2) = 0;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------- device: element-wise ops of one image
+__device__ __forceinline__ View st_shift(View v, const int n) {
+  if (v.p) v.p += (int64_t)n * v.sn * 2;
+  return v;
+}
+
+template <int V>
+__device__ __forceinline__ void st_elem(const int kind, const StElem& e, const int n) {
+  typedef bf16_t T;
+  const int64_t g0 = threadIdx.x, gs = ST_THREADS;
+  const View in = st_shift(e.in, n), out = st_shift(e.out, n);
+  switch (kind) {
+    case CGEN_ST_AVGPOOL_FWD: avgpool_fwd_body<T, V>(g0, gs, e.s, e.d, in, out); break;
+    case CGEN_ST_AVGPOOL_BWD: avgpool_bwd_body<T, V>(g0, gs, e.s, e.d, in, out, e.accumulate); break;
+    case CGEN_ST_UPSAMPLE_FWD: upsample_fwd_body<T, V>(g0, gs, e.s, e.hi, e.wi, e.ish, e.isw, in, e.src, out); break;
+    case CGEN_ST_UPSAMPLE_BWD: upsample_bwd_body<T, V>(g0, gs, e.s, e.hi, e.wi, e.ish, e.isw, in, out, e.accumulate); break;
+    case CGEN_ST_BCAST: batch_broadcast_body<T, V>(g0, gs, e.s, e.src, out); break;
+    default: axpby_body<T, V>(g0, gs, e.s, in, out, e.alpha, e.beta, e.c_from, e.accumulate); break;
+  }
+}
+
+// reparameterise + KL of one image: the stand-alone kernel's per-thread item over the image's chunks, two chunks at a time
+// (one per 256-thread half), each half reduced in block_sum_256's order -> the same partials bit for bit
+__device__ __forceinline__ void st_reparam_fwd(const LatP& p, const int n, float* red) {
+  const int tid = threadIdx.x, half = tid >> 8, t = tid & 255;
+  const int nchunks = (p.h * p.w * p.c + LAT_CHUNK - 1) / LAT_CHUNK;
+  uint64_t seed = 0, off = 0;
+  if (!p.eps_in.p) { seed = p.rng[0]; off = p.rng[1]; }
+  for (int c0 = 0; c0 < nchunks; c0 += 2) {
+    const int chunk = c0 + half;
+    float v = 0.f;
+    if (chunk < nchunks) v = reparam_kl_fwd_vec8_item(p, n, chunk, t, seed, off);
+    v = wave_sum(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (t == 0 && chunk < nchunks) p.kl_part[(int64_t)n * p.kl_stride + chunk] = (red[half * 4] + red[half * 4 + 1]) + (red[half * 4 + 2] + red[half * 4 + 3]);
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void st_reparam_bwd(const LatBwdP& p, const int n) {
+  const int per8 = (p.h * p.w * p.c) >> 3;
+  for (int g = threadIdx.x; g < per8; g += ST_THREADS) reparam_kl_bwd_vec8_item(p, (int64_t)n * per8 + g);
+  if (p.ride_src.p) {
+    const int rper = p.h * p.w * (p.ride_c >> 3);
+    for (int g = threadIdx.x; g < rper; g += ST_THREADS) reparam_ride_item(p, (int64_t)n * rper + g);
+  }
+}
+
+__global__ __launch_bounds__(ST_THREADS) void stage_kernel(const char* __restrict__ blob, const int nops) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float red[ST_WAVES];
+  const StOp* ops = (const StOp*)blob;
+  const int n = blockIdx.x;
+  for (int i = 0; i < nops; ++i) {
+    const StOp& op = ops[i];
+    const int kind = op.kind;
+    if (kind == CGEN_ST_CONV) {
+      st_conv(op.conv, (const int*)(blob + op.conv.ktab_off), n, smem);
+    } else if (kind == CGEN_ST_REPARAM_FWD) {
+      st_reparam_fwd(op.lat, n, red);
+    } else if (kind == CGEN_ST_REPARAM_BWD) {
+      st_reparam_bwd(op.latb, n);
+    } else {
+      if (op.elem.vec) st_elem<4>(kind, op.elem, n);
+      else st_elem<1>(kind, op.elem, n);
+    }
+    __syncthreads();  // the next op reads what this one wrote (same workgroup: workgroup scope is enough) and reuses the LDS
+  }
+}
+
+// ----------------------------------------------------------------------------- host: eligibility and planning
+static inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+static inline int64_t span_elems(const cgen_view& v, int n, int h, int w) {
+  return (int64_t)(n - 1) * v.sn + (int64_t)(h - 1) * v.sh + (int64_t)(w - 1) * v.sw + std::max(v.c, v.cpad);
+}
+static bool sview(const cgen_view& v, int n, int h, int w, SView& o) {
+  memset(&o, 0, sizeof(o));
+  if (!v.p) return true;
+  if (v.sn < 0 || v.sh < 0 || v.sw < 0 || v.sn >= ((int64_t)1 << 30) || span_elems(v, n, h, w) * 2 >= ((int64_t)1 << 31)) return false;
+  if ((int64_t)(h - 1) * v.sh + (int64_t)(w - 1) * v.sw + std::max(v.c, v.cpad) >= ((int64_t)1 << 30)) return false;
+  o.p = (char*)v.p; o.sn = (int)v.sn; o.sh = (int)v.sh; o.sw = (int)v.sw; o.c = v.c; o.cpad = v.cpad;
+  return true;
+}
+static inline bool al(const cgen_view& v, int bytes) {  // base and every stride multiples of `bytes`
+  if (!v.p) return true;
+  return ((uintptr_t)v.p % bytes) == 0 && (v.sn * 2) % bytes == 0 && (v.sh * 2) % bytes == 0 && (v.sw * 2) % bytes == 0;
+}
+
+static int stage_budget() {
+  static const int b = [] { const char* e = getenv("CGEN_STAGE_MFMA"); return e ? atoi(e) : 4096; }();
+  return b;
+}
+
+// fills `o` (without the K-step table); returns the LDS bytes the conv needs, 0 when the op is not served
+static int plan_conv(const cgen_conv_args* a, StConv& o, std::vector<int>* ktab) {
+  memset(&o, 0, sizeof(o));
+  if (a->dtype != CGEN_BF16 || (a->ks != 1 && a->ks != 3) || a->nseg < 1 || a->nseg > CGEN_MAX_SEG || a->n < 1 || a->h < 1 || a->w < 1) return 0;
+  if (!a->weight || !a->out.p || a->out.c < 1) return 0;
+  o.H = a->h; o.W = a->w; o.KS = a->ks; o.halo = a->ks / 2; o.nseg = a->nseg; o.act = a->act; o.dact = a->dact; o.Co = a->out.c;
+  int c8 = 0;
+  for (int s = 0; s < a->nseg; ++s) {
+    const cgen_view& v = a->seg[s];
+    if (!v.p || v.c < 1 || !al(v, 16)) return 0;
+    if (v.c % 8 != 0 && v.cpad < pad_to(v.c, 8)) return 0;  // whole 16-byte groups are fetched: ragged widths need zero padding
+    if (!sview(v, a->n, a->h, a->w, o.seg[s])) return 0;
+    o.seg_koff[s] = c8;
+    c8 += pad_to(v.c, 8);
+  }
+  for (int s = a->nseg; s < CGEN_MAX_SEG; ++s) { o.seg[s] = o.seg[0]; o.seg_koff[s] = 1 << 30; }
+  o.C8 = c8;
+  if (!al(a->out, 8) || !al(a->aux, 8) || !al(a->res1, 8) || !al(a->res2, 8)) return 0;
+  if (!sview(a->out, a->n, a->h, a->w, o.out) || !sview(a->aux, a->n, a->h, a->w, o.aux) || !sview(a->res1, a->n, a->h, a->w, o.res1) ||
+      !sview(a->res2, a->n, a->h, a->w, o.res2)) return 0;
+  if ((a->aux.p && a->aux.c != o.Co) || (a->res1.p && a->res1.c != o.Co) || (a->res2.p && a->res2.c != o.Co)) return 0;
+  o.out.cpad = a->out.cpad;
+  const int taps = a->ks * a->ks;
+  int tap0 = 0, tap1 = taps;
+  if (a->h == 1 && a->w == 1 && a->ks > 1) { tap0 = taps / 2; tap1 = tap0 + 1; }
+  o.k_lo = tap0 * c8;
+  const int k_hi = tap1 * c8;
+  o.nk = (k_hi - o.k_lo + 31) / 32;
+  o.krow = pad_to(taps * c8, 32) + 32;
+  o.rows_pad = pad_to(o.Co, 16);
+  o.Gs = c8 / 8;
+  if ((o.Gs & 1) == 0) ++o.Gs;
+  o.pixstride = o.Gs * 16;
+  o.Wp = a->w + 2 * o.halo;
+  const int Hp = a->h + 2 * o.halo;
+  o.HW = a->h * a->w;
+  o.ngroups = Hp * o.Wp * o.Gs;
+  o.npieces = (o.ngroups + 1 + 63) / 64;  // + the zero slot right behind the image
+  o.zoff = o.ngroups * 16;
+  const int lds = o.npieces * 1024;
+  if (lds > 156 * 1024) return 0;
+  o.G = (o.HW + 15) / 16;
+  o.T = (o.Co + 15) / 16;
+  if ((int64_t)o.G * o.T * o.nk > stage_budget()) return 0;  // too much work for one CU per image: a chip-wide launch is faster
+  o.w = (const bf16_t*)a->weight;
+  o.bias = a->bias;
+  o.d_gs = mk_sdiv(o.Gs); o.d_wp = mk_sdiv(o.Wp); o.d_w = mk_sdiv(a->w);
+  // ---- wave plan: PW x TW waves over (pixel groups) x (channel tiles); cost = the busiest SIMD's MFMAs (waves w and w + 4
+  // share a SIMD) + the weight traffic, which grows with PW (every pixel chunk re-reads its tiles' weights from L2)
+  double best = 1e30;
+  int bpw = 1, btw = 1;
+  static const int cand[][2] = {{8, 1}, {4, 2}, {2, 4}, {1, 8}, {4, 1}, {2, 2}, {1, 4}, {2, 1}, {1, 2}, {1, 1}};
+  for (auto& pt : cand) {
+    const int pw = std::min(pt[0], o.G), tw = std::min(pt[1], o.T);
+    int tiles[ST_WAVES] = {0};
+    for (int w = 0; w < pw * tw; ++w) {
+      const int ip = w % pw, it = w / pw;
+      const int gp = o.G / pw + (ip < o.G % pw ? 1 : 0), gt = o.T / tw + (it < o.T % tw ? 1 : 0);
+      // register blocks are ST_PB x ST_TB: a partial block costs its real tiles only (guards are wave-uniform branches)
+      tiles[w] = gp * gt;
+    }
+    int simd = 0;
+    for (int w = 0; w < 4; ++w) simd = std::max(simd, tiles[w] + tiles[w + 4]);
+    const double mfma_cyc = (double)simd * o.nk * 16.0;
+    const double wbytes = (double)pw * o.T * 16 * o.nk * 64;  // every pixel chunk streams all its tiles' weights
+    const double cost = std::max(mfma_cyc, wbytes / 48.0) + 0.25 * std::min(mfma_cyc, wbytes / 48.0);
+    if (cost < best) { best = cost; bpw = pw; btw = tw; }
+  }
+  for (int w = 0; w < ST_WAVES; ++w) { o.wg0[w] = o.wg1[w] = o.wt0[w] = o.wt1[w] = 0; }
+  {
+    int gstart[ST_WAVES + 1] = {0}, tstart[ST_WAVES + 1] = {0};
+    for (int i = 0; i < bpw; ++i) gstart[i + 1] = gstart[i] + o.G / bpw + (i < o.G % bpw ? 1 : 0);
+    for (int i = 0; i < btw; ++i) tstart[i + 1] = tstart[i] + o.T / btw + (i < o.T % btw ? 1 : 0);
+    for (int w = 0; w < bpw * btw; ++w) {
+      const int ip = w % bpw, it = w / bpw;
+      o.wg0[w] = gstart[ip]; o.wg1[w] = gstart[ip + 1]; o.wt0[w] = tstart[it]; o.wt1[w] = tstart[it + 1];
+    }
+  }
+  if (ktab) {
+    ktab->clear();
+    for (int ks = 0; ks < o.nk; ++ks)
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int kidx = o.k_lo + ks * 32 + g4 * 8;
+        if (kidx >= k_hi) { ktab->push_back(-1); continue; }
+        const int tap = kidx / c8, cc = kidx - tap * c8;
+        const int dy = tap / a->ks, dx = tap - dy * a->ks;
+        ktab->push_back((dy * o.Wp + dx) * o.pixstride + cc * 2);
+      }
+  }
+  return lds;
+}
+
+static bool flat_ok(const cgen_view& v, int n, int h, int w) {
+  if (!v.p) return true;
+  return v.sn >= 0 && v.sh >= 0 && v.sw >= 0 && span_elems(v, n, h, w) * 2 < ((int64_t)1 << 31);
+}
+static bool vec4v(const cgen_view& v) { return !v.p || (((uintptr_t)v.p % 8) == 0 && (v.sn * 2) % 8 == 0 && (v.sh * 2) % 8 == 0 && (v.sw * 2) % 8 == 0); }
+static inline float inv_scale(int out, int in) { return (float)(1.0 / ((double)out / (double)in)); }
+
+static int plan_elem(int kind, const cgen_stage_elem_args* a, StElem& o) {
+  memset(&o, 0, sizeof(o));
+  if (a->dtype != CGEN_BF16 || a->n < 1 || !a->out.p) return 0;
+  const int c = a->out.c;
+  int ih = a->h, iw = a->w;  // the tensor the body iterates over
+  switch (kind) {
+    case CGEN_ST_AVGPOOL_FWD: if (!a->in.p || a->d < 1 || a->in.c != c) return 0; break;
+    case CGEN_ST_AVGPOOL_BWD: if (!a->in.p || a->d < 1 || a->in.c != c) return 0; ih = a->h * a->d; iw = a->w * a->d; break;
+    case CGEN_ST_UPSAMPLE_FWD: if (!a->in.p || a->in.c != c || a->hi < 1 || a->wi < 1 || a->h < a->hi || a->w < a->wi) return 0; break;
+    case CGEN_ST_UPSAMPLE_BWD: if (!a->in.p || a->in.c != c) return 0; ih = a->hi; iw = a->wi; break;
+    case CGEN_ST_BCAST: if (!a->src) return 0; break;
+    case CGEN_ST_AXPBY: if (a->in.p && a->in.c != c) return 0; break;
+    default: return 0;
+  }
+  const int big_h = std::max(a->h, std::max(ih, a->hi)) * std::max(1, a->d), big_w = std::max(a->w, std::max(iw, a->wi)) * std::max(1, a->d);
+  if (!flat_ok(a->in, a->n, big_h, big_w) || !flat_ok(a->out, a->n, big_h, big_w)) return 0;
+  o.s = Shape4{1, ih, iw, c};
+  o.d = a->d; o.hi = a->hi; o.wi = a->wi; o.accumulate = a->accumulate; o.c_from = a->c_from;
+  o.alpha = a->alpha; o.beta = a->beta; o.src = a->src;
+  o.in = mk(a->in); o.out = mk(a->out);
+  o.vec = (c % 4 == 0 && vec4v(a->in) && vec4v(a->out)) ? 1 : 0;
+  if (kind == CGEN_ST_UPSAMPLE_FWD) { o.ish = inv_scale(a->h, a->hi); o.isw = inv_scale(a->w, a->wi); }
+  if (kind == CGEN_ST_UPSAMPLE_BWD) { o.hi = a->h; o.wi = a->w; o.ish = inv_scale(a->h, a->hi); o.isw = inv_scale(a->w, a->wi); }
+  return 1;
+}
+
+static bool lat_ok(int n, int c, std::initializer_list<cgen_view> vs) {
+  if (c % 8) return false;
+  for (const cgen_view& v : vs) {
+    if (!v.p) continue;
+    if (!vec16_ok(v, 2)) return false;
+    if ((int64_t)n * v.sn >= ((int64_t)1 << 31)) return false;
+  }
+  return true;
+}
+
+static int plan_reparam(const cgen_stage_reparam_args* a, LatP& p) {
+  if (a->dtype != CGEN_BF16 || !(a->q_loc.p && a->q_ls.p && a->p_loc.p && a->p_ls.p && a->z.p && a->kl_part) || !(a->eps_in.p || a->rng)) return 0;
+  if (!lat_ok(a->n, a->c, {a->q_loc, a->q_ls, a->p_loc, a->p_ls, a->eps_in, a->z})) return 0;
+  memset(&p, 0, sizeof(p));
+  p.n = a->n; p.h = a->h; p.w = a->w; p.c = a->c;
+  p.q_loc = mk(a->q_loc); p.q_ls = mk(a->q_ls); p.p_loc = mk(a->p_loc); p.p_ls = mk(a->p_ls);
+  p.eps_in = mk(a->eps_in); p.z = mk(a->z);
+  p.rng = a->rng; p.stream_id = a->stream_id; p.logt = a->logt; p.kl_part = a->kl_part; p.kl_stride = a->kl_stride;
+  return 1;
+}
+
+static int plan_reparam_bwd(const cgen_stage_reparam_bwd_args* a, LatBwdP& p) {
+  if (a->dtype != CGEN_BF16 || !(a->q_loc.p && a->q_ls.p && a->p_loc.p && a->p_ls.p && a->kl_coef_dev && a->g_q_loc.p && a->g_q_ls.p && a->g_p_loc.p && a->g_p_ls.p)) return 0;
+  if (a->gz.p && !a->z.p) return 0;
+  if (!lat_ok(a->n, a->c, {a->q_loc, a->q_ls, a->p_loc, a->p_ls, a->z, a->gz, a->g_q_loc, a->g_q_ls, a->g_p_loc, a->g_p_ls})) return 0;
+  memset(&p, 0, sizeof(p));
+  p.n = a->n; p.h = a->h; p.w = a->w; p.c = a->c;
+  p.q_loc = mk(a->q_loc); p.q_ls = mk(a->q_ls); p.p_loc = mk(a->p_loc); p.p_ls = mk(a->p_ls); p.z = mk(a->z); p.gz = mk(a->gz);
+  p.g_q_loc = mk(a->g_q_loc); p.g_q_ls = mk(a->g_q_ls); p.g_p_loc = mk(a->g_p_loc); p.g_p_ls = mk(a->g_p_ls);
+  p.coef = a->kl_coef_dev; p.chan_scale = a->kl_chan_scale; p.coef_stride = a->coef_stride; p.acc_q = a->acc_q; p.acc_p = a->acc_p; p.logt = a->logt;
+  if (a->ride_src.p) {
+    if (!a->ride_dst.p || a->ride_src.c != a->ride_dst.c || !lat_ok(a->n, a->ride_src.c, {a->ride_src, a->ride_dst})) return 0;
+    p.ride_src = mk(a->ride_src); p.ride_dst = mk(a->ride_dst); p.ride_c = a->ride_src.c; p.ride_acc = a->ride_acc;
+  }
+  return 1;
+}
+
+static int plan_op(int kind, const void* args, StOp& op, std::vector<int>* ktab) {
+  memset(&op, 0, sizeof(op));
+  op.kind = kind;
+  int lds = 0;
+  switch (kind) {
+    case CGEN_ST_CONV: lds = plan_conv((const cgen_conv_args*)args, op.conv, ktab); break;
+    case CGEN_ST_REPARAM_FWD: lds = plan_reparam((const cgen_stage_reparam_args*)args, op.lat); break;
+    case CGEN_ST_REPARAM_BWD: lds = plan_reparam_bwd((const cgen_stage_reparam_bwd_args*)args, op.latb); break;
+    case CGEN_ST_AVGPOOL_FWD: case CGEN_ST_AVGPOOL_BWD: case CGEN_ST_UPSAMPLE_FWD: case CGEN_ST_UPSAMPLE_BWD: case CGEN_ST_BCAST: case CGEN_ST_AXPBY:
+      lds = plan_elem(kind, (const cgen_stage_elem_args*)args, op.elem); break;
+    default: return 0;
+  }
+  op.lds_bytes = lds;
+  return lds;
+}
+
+}  // namespace cgen
+
+using namespace cgen;
+
+extern "C" int cgen_stage_accepts(int32_t kind, const void* args) {
+  if (!args) return 0;
+  StOp op;
+  return plan_op(kind, args, op, nullptr);
+}
+
+extern "C" int cgen_stage_plan(const int32_t* kinds, const void* const* args, int32_t count, void* blob_host, int64_t capacity,
+                               int64_t* blob_bytes, int32_t* lds_bytes) {
+  CGEN_REQUIRE(kinds && args && count > 0 && blob_bytes && lds_bytes, "cgen_stage_plan: bad args");
+  std::vector<StOp> ops(count);
+  std::vector<int> table, kt;
+  const int64_t ops_bytes = (int64_t)count * sizeof(StOp);
+  int lds = 16;
+  for (int i = 0; i < count; ++i) {
+    const int l = plan_op(kinds[i], args[i], ops[i], &kt);
+    CGEN_REQUIRE(l > 0, "cgen_stage_plan: op %d (kind %d) is not served (ask cgen_stage_accepts first)", i, kinds[i]);
+    lds = std::max(lds, l);
+    if (kinds[i] == CGEN_ST_CONV) {
+      ops[i].conv.ktab_off = (int)(ops_bytes + (int64_t)table.size() * 4);
+      table.insert(table.end(), kt.begin(), kt.end());
+    }
+  }
+  const int64_t total = ops_bytes + (int64_t)table.size() * 4;
+  *blob_bytes = total;
+  *lds_bytes = lds;
+  if (!blob_host) return CGEN_OK;
+  CGEN_REQUIRE(capacity >= total, "cgen_stage_plan: blob buffer too small (%lld < %lld)", (long long)capacity, (long long)total);
+  memcpy(blob_host, ops.data(), ops_bytes);
+  if (!table.empty()) memcpy((char*)blob_host + ops_bytes, table.data(), table.size() * 4);
+  return CGEN_OK;
+}
+
+extern "C" int cgen_stage_run(const void* blob_dev, int32_t count, int32_t n_images, int32_t lds_bytes, cgen_stream_t stream) {
+  CGEN_REQUIRE(blob_dev && count > 0 && n_images > 0 && lds_bytes >= 0 && lds_bytes <= 159 * 1024, "cgen_stage_run: bad args");
+  static bool once = false;
+  if (!once) {  // (the kernel also has 32 bytes of static LDS: the dynamic part may take the rest of the CU's 160 KiB)
+    (void)hipFuncSetAttribute((const void*)stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipGetLastError();
+    once = true;
+  }
+  hipLaunchKernelGGL(stage_kernel, dim3(n_images), dim3(ST_THREADS), (size_t)lds_bytes, (hipStream_t)stream, (const char*)blob_dev, count);
+  return check_launch("cgen_stage_run");
+}

@@ -16,6 +16,7 @@ import math
 import torch
 
 from . import _lib
+from .stage import StagedLib, StageMixin
 from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, NULL_VIEW, UNARY_CLAMP_MIN, UNARY_LEAKY_RELU, View
 
 _ALIGN = 256
@@ -175,11 +176,13 @@ class ConvSite:
         self.img_dg = [None] * len(seg_c)
 
 
-class Engine:
+class Engine(StageMixin):
     CHUNK = 1024  # elements per block of the multi-tensor kernels (MT_CHUNK in conv.hip)
 
     def __init__(self, device, dtype="f32"):
-        self.lib = _lib.require_gpu()
+        rawlib = _lib.require_gpu()
+        # every launch goes through this proxy: ops at staged resolutions are collected into per-image op lists (stage.py)
+        self.lib = StagedLib(rawlib, self)
         self.device = torch.device(device)
         assert self.device.type == "cuda"
         if self.device.index is None:
@@ -255,10 +258,12 @@ class Engine:
         self.split_frac = float(os.environ.get("CGEN_DP_SPLIT_FRAC", "0.8"))
         self.on_split = None
         self.early_final = None
+        self._stage_init(rawlib)
 
     # ------------------------------------------------------------------ memory
     def begin(self):
         """Start a new step/pass: recycle the arena, clear the tape and gradient bookkeeping."""
+        self.stage_flush()
         self.generation = getattr(self, "generation", 0) + 1  # a recorded pass is only valid within its generation
         self.kl_coef_override = None
         self.arena.reset()
@@ -344,6 +349,9 @@ class Engine:
         dst = self.wrap_nhwc(t)
         self.lib.axpby(self.dt, x.n, x.h, x.w, x.cv(), dst.cv(), 1.0, 1.0, 1 << 30, 0, self.stream)
         self.launches += 1
+        # `t` leaves the engine: the copy must be ON the stream before the caller can read -- or FREE -- it (a deferred
+        # stage op would write into memory torch may have handed to somebody else by then)
+        self.stage_flush()
         return t.permute(0, 3, 1, 2)
 
     # ------------------------------------------------------------------ parameters and weight images
@@ -462,6 +470,7 @@ class Engine:
             self.launches += 1
             self._pnhwc[id(p)] = ptr
             if self._in_side:
+                self.stage_flush()
                 # created lazily inside a side-stream section, cached for everybody: the main stream must not read it before
                 # this conversion has run (found by tools/fuzz_model.py: two concurrent replays sharing the decoder biases)
                 torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)
@@ -546,12 +555,19 @@ class Engine:
         self.launches += 1
         if self.prof is None:
             return fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        fn()
-        e1.record()
         ci = site.ci if ci is None else ci
         flops = 2.0 * ci * site.taps * site.co * x0.n * x0.h * x0.w
+        if not self.stage_covers(x0.h):
+            self.stage_flush()  # (so that a pending list is not launched -- and timed -- inside this conv's event pair)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._stage_deferred = False
+        fn()
+        if self._stage_deferred:
+            # deferred into a stage list: its time is that of the list's launch (stage_flush tallies the list's FLOPs)
+            self._stage_flops[kind] = self._stage_flops.get(kind, 0.0) + flops
+            return
+        e1.record()
         key = (kind, site.ks, ci, site.co, x0.h)
         ent = self.prof.setdefault(key, [0.0, [], 0])
         ent[0] += flops
@@ -742,8 +758,7 @@ class Engine:
         self.launches += 1
 
     # ------------------------------------------------------------------ gradient bookkeeping
-    @staticmethod
-    def _geom(ks, ts):
+    def _geom(self, ks, ts, stageable=True):
         """Launch geometry (n, h, w) and the view constructor for a conv over tensors `ts` (None entries allowed).
         A 1x1 conv does not care about the spatial structure: on tiny images (< 5x5, where the tiled kernels do not apply)
         pixel-contiguous tensors are presented as ONE image of 16-pixel rows, [1, P/16, 16, C], which the tiled /
@@ -751,6 +766,8 @@ class Engine:
         t0 = next(t for t in ts if t is not None)
         n, h, w = t0.n, t0.h, t0.w
         P = n * h * w
+        if stageable and self.stage_covers(h):  # (the stage interpreter works per image: keep the real geometry)
+            return n, h, w, (lambda t: NULL_VIEW if t is None else t.cv())
         if ks == 1 and h * w < 25 and P % 16 == 0 and P >= 256 and all(
                 t is None or (t.sh == t.w * t.sw and t.sn == t.h * t.sh) for t in ts):
             return 1, P // 16, 16, (lambda t: NULL_VIEW if t is None else View(t.ptr, P * t.sw, 16 * t.sw, t.sw, t.c, t.cpad))
@@ -871,6 +888,7 @@ class Engine:
         """Returns True when a side stream is available; everything enqueued so far is visible to it."""
         if not self.fwd_branch or self.prof is not None:
             return False
+        self.stage_flush()
         if self._fwd_side is None:
             self._fwd_side = torch.cuda.Stream(self.device)
         self._fwd_side.wait_stream(torch.cuda.current_stream(self.device))
@@ -878,16 +896,19 @@ class Engine:
 
     def on_side(self, fn):
         """Run `fn()` with every launch going to the side stream."""
+        self.stage_flush()
         old = self.stream
         self.stream = self._fwd_side.cuda_stream
         self._in_side = True
         try:
             return fn()
         finally:
+            self.stage_flush()
             self.stream = old
             self._in_side = False
 
     def join_side(self):
+        self.stage_flush()
         torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)
         self._side_join_pending = False
 
@@ -1045,6 +1066,7 @@ class Engine:
         if self.wgrad_flush_frac:  # total weight-gradient work of this pass: the background-flush marks are fractions of it
             self._wg_total = sum(2.0 * a[0].ci * a[0].taps * a[0].co * a[1][0].n * a[1][0].h * a[1][0].w
                                  for fn, a, _ in self.tape if fn == self._bw_conv and self._needs_wgrad(a[0]))
+        self.stage_flush()
         main_t = torch.cuda.current_stream(self.device)
         if self._side_join_pending:  # side-stream work of the forward pass nobody has joined yet (the stem's im2col)
             self.join_side()
@@ -1093,12 +1115,14 @@ class Engine:
             gv, g, acc = self._riders.pop(bid)
             self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
             self.launches += 1
+        self.stage_flush()
         self._reduce_wgrads()
         for p, ptr in self._pgrad_tmp.values():  # NHWC-accumulated gradients of [1,C,h,w] parameters -> NCHW
             _, c, h, w = p.shape
             v = NT(ptr, 1, h, w, c, h * w * c, w * c, c, 4, rg=False)
             self.lib.nhwc_to_nchw(F32, 1, c, h, w, v.cv(), self.param_grad_ptr(p), self.stream)
             self.launches += 1
+        self.stage_flush()
         self.tape.clear()
 
     def _bw_conv(self, site, segs, act, out, res1, res2):
@@ -1200,7 +1224,7 @@ class Engine:
     def _wgrad(self, site, segs, act, g):
         x0 = segs[0]
         a = _lib.WgradArgs()
-        gn, gh, gw, vw = self._geom(site.ks, list(segs) + [g])
+        gn, gh, gw, vw = self._geom(site.ks, list(segs) + [g], stageable=False)
         a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act = self.dt, gn, gh, gw, site.ks, len(segs), act
         for k, s in enumerate(segs):
             a.seg[k] = vw(s)
@@ -1240,6 +1264,7 @@ class Engine:
         if (self.on_split is not None and not self._split_done and self._wg_nflush >= max(1, len(self.wgrad_flush_frac)) and self._wg_total > 0
                 and self._wg_cum >= self.split_frac * self._wg_total):
             self._split_done = True
+            self.stage_flush()
             if self._wg_forked:  # join the background flush + its reduction: by now it has long finished (no stall)
                 main = torch.cuda.current_stream(self.device)
                 for st in self._wg_pool:
@@ -1254,6 +1279,7 @@ class Engine:
             self.on_split()
 
     def _launch_deferred_wgrads(self, final=True):
+        self.stage_flush()
         main = torch.cuda.current_stream(self.device)
         if self.wgrad_batch:
             if self._wg_deferred:
@@ -1286,6 +1312,7 @@ class Engine:
     def _launch_batched_wgrads(self, background=False):
         """All deferred weight-gradient problems in a handful of launches.  The packed problem table is planned once per
         distinct set of launch arguments (addresses are stable: the arena is deterministic) and kept on the device."""
+        self.stage_flush()  # (the batch forks from / joins the main stream: everything issued so far must be ON the stream)
         args = [a for a, _ in self._wg_deferred]
         n = len(args)
         if os.environ.get("CGEN_WG_DEBUG"):

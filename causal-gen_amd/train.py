@@ -82,7 +82,7 @@ class TrainStep:
 
     def __init__(self, model, args, ema=True, use_graph=True, process_group=None, bucket_mb=32):
         self.model, self.args = model, args
-        self.lib = _lib.require_gpu()
+        self.lib = _lib.require_gpu()  # (the step tail's own kernels; the model's launches go through eng.lib, the staging proxy)
         self.use_graph = use_graph
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1

@@ -683,6 +683,7 @@ def test_two_strand_backward_equals_single_stream():
         ge = torch.Generator().manual_seed(100)
         m.noise = [torch.randn(B, b.z_dim, b.res, b.res, generator=ge) for b in m.decoder.blocks if b.stochastic]
         eng = m.engine()
+        eng.stage_enabled = False  # (the two-strand backward keeps launch-per-op; compare like with like -- the stage interpreter's convs sum in another order)
         eng.bwd_branch = two
         out = m(x, pa, beta=hp.beta)
         out["elbo"].backward()
