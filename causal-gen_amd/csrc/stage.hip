@@ -64,13 +64,15 @@ struct StConv {
   int H, W, KS, halo, nseg, act, dact, Co;
   int C8, Gs, Wp, HW, ngroups, npieces, G, T;
   int nk, krow, k_lo, rows_pad, pixstride, zoff, ktab_off, pad0;
+  int wg0[ST_WAVES], wg1[ST_WAVES], wt0[ST_WAVES], wt1[ST_WAVES];  // (kept inside the first 64 dwords of the op: one v_readlane with a wave index)
   SView seg[CGEN_MAX_SEG];
   int seg_koff[CGEN_MAX_SEG];
   SView out, aux, res1, res2;
   const bf16_t* w;
   const float* bias;
+  const char* next_w;  // weight image of the next conv of the list (L2 warm-up), or this op's own
+  int next_w_bytes, pad1;
   SDiv d_gs, d_wp, d_w;
-  int wg0[ST_WAVES], wg1[ST_WAVES], wt0[ST_WAVES], wt1[ST_WAVES];
 };
 
 struct StElem {
@@ -110,52 +112,110 @@ __device__ __forceinline__ uint4 st_act_group(uint4 v, const int act) {
 __device__ __forceinline__ float st_bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float st_bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-__device__ __forceinline__ void st_conv(const StConv& c, const int* __restrict__ ktab, const int n, char* __restrict__ smem) {
+#define ST_STAMP(k) do { if (stamp) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
+// The op descriptor of the CURRENT op lives in LDS (ST_OPBUF bytes per slot, two slots: the next op's descriptor is DMA'd in
+// while this one runs).  Every lane holds a 64-way slice of it (dword j*64 + lane in opw[j]); a field is then ONE v_readlane
+// away, wave-uniform in an SGPR -- instead of a chain of dependent scalar loads from global memory (~0.5 us per miss, five
+// deep per op when the table is cold).
+#define ST_OPBUF 1024
+#define ST_IMG_OFF 4096  // [op slot 0 | op slot 1 | spare] then the staged image
+struct OpW { uint32_t w[ST_OPBUF / 256]; };
+__device__ __forceinline__ OpW st_load_op(const char* smem, const int slot, const int lane) {
+  OpW o;
+  const uint32_t* src = (const uint32_t*)(smem + slot * ST_OPBUF) + lane;
+#pragma unroll
+  for (int j = 0; j < ST_OPBUF / 256; ++j) o.w[j] = src[j * 64];
+  return o;
+}
+#define ST_FIELD_DW(member) ((int)((offsetof(StOp, conv) + offsetof(StConv, member)) / 4))
+#define SI(member) ((int)__builtin_amdgcn_readlane((int)ow.w[ST_FIELD_DW(member) / 64], ST_FIELD_DW(member) % 64))
+#define SI_AT(member, idx) ((int)__builtin_amdgcn_readlane((int)ow.w[(ST_FIELD_DW(member) + (idx)) / 64], (ST_FIELD_DW(member) + (idx)) % 64))
+__device__ __forceinline__ const char* st_ptr(const int lo, const int hi) { return (const char*)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo); }
+#define SP(member) st_ptr(SI_AT(member, 0), SI_AT(member, 1))
+
+__device__ __forceinline__ void st_conv(const OpW& ow, const char* __restrict__ blob, const int n, char* __restrict__ smem, unsigned long long* stamp, uint32_t (&pf)[3]) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, kg = lane >> 4;
+  char* img = smem + ST_IMG_OFF;
 
-  // ---- stage the image: every 16-byte group of the halo'd, concatenated input, by LDS-DMA (zeros from the zero page)
+  const int H = SI(H), W = SI(W), halo = SI(halo), Gs = SI(Gs), Wp = SI(Wp), ngroups = SI(ngroups), npieces = SI(npieces);
+  // ---- stage the image: every 16-byte group of the halo'd, concatenated input, by LDS-DMA (zeros from the zero page).
+  // The loop body is ONE basic block (selects only): with a branch inside, hipcc drains vmcnt at the loop header and the
+  // DMAs go out one round trip at a time.
   {
-    const char* b0 = c.seg[0].p + (int64_t)n * c.seg[0].sn * 2;
-    const char* b1 = c.seg[1].p + (int64_t)n * c.seg[1].sn * 2;
-    const char* b2 = c.seg[2].p + (int64_t)n * c.seg[2].sn * 2;
-    const char* b3 = c.seg[3].p + (int64_t)n * c.seg[3].sn * 2;
-    for (int pi = wave; pi < c.npieces; pi += ST_WAVES) {
+    const SDiv d_gs = {(uint32_t)SI(d_gs.mul), (uint32_t)SI(d_gs.shift)}, d_wp = {(uint32_t)SI(d_wp.mul), (uint32_t)SI(d_wp.shift)};
+    const int ko1 = SI_AT(seg_koff, 1), ko2 = SI_AT(seg_koff, 2), ko3 = SI_AT(seg_koff, 3);  // (absent segments: 1 << 30)
+    const uint64_t z64 = (uint64_t)(uintptr_t)st_zero16;
+    uint64_t b[CGEN_MAX_SEG];
+    int sh[CGEN_MAX_SEG], sw[CGEN_MAX_SEG], sc[CGEN_MAX_SEG];
+#define ST_SEG(k) b[k] = (uint64_t)(uintptr_t)SP(seg[k].p) + (uint64_t)((int64_t)n * SI(seg[k].sn) * 2); sh[k] = SI(seg[k].sh); sw[k] = SI(seg[k].sw); sc[k] = SI(seg[k].c);
+    ST_SEG(0) ST_SEG(1) ST_SEG(2) ST_SEG(3)
+#undef ST_SEG
+    for (int pi = wave; pi < npieces; pi += ST_WAVES) {
       const int q = pi * 64 + lane;
-      const int pix = sdiv(q, c.d_gs), grp = q - pix * c.Gs;
-      const int yy = sdiv(pix, c.d_wp), xx = pix - yy * c.Wp;
-      const int y = yy - c.halo, x = xx - c.halo;
+      const int pix = sdiv(q, d_gs), grp = q - pix * Gs;
+      const int yy = sdiv(pix, d_wp), xx = pix - yy * Wp;
+      const int y = yy - halo, x = xx - halo;
       const int c8 = grp * 8;
-      int s = 0;
-#pragma unroll
-      for (int k = 1; k < CGEN_MAX_SEG; ++k) s += (k < c.nseg && c8 >= c.seg_koff[k]) ? 1 : 0;
-      const char* base = s == 0 ? b0 : (s == 1 ? b1 : (s == 2 ? b2 : b3));
-      const int sh = s == 0 ? c.seg[0].sh : (s == 1 ? c.seg[1].sh : (s == 2 ? c.seg[2].sh : c.seg[3].sh));
-      const int sw = s == 0 ? c.seg[0].sw : (s == 1 ? c.seg[1].sw : (s == 2 ? c.seg[2].sw : c.seg[3].sw));
-      const int sc = s == 0 ? c.seg[0].c : (s == 1 ? c.seg[1].c : (s == 2 ? c.seg[2].c : c.seg[3].c));
-      const int ko = s == 0 ? c.seg_koff[0] : (s == 1 ? c.seg_koff[1] : (s == 2 ? c.seg_koff[2] : c.seg_koff[3]));
+      const bool s1 = c8 >= ko1, s2 = c8 >= ko2, s3 = c8 >= ko3;
+      const uint64_t base = s3 ? b[3] : (s2 ? b[2] : (s1 ? b[1] : b[0]));
+      const int vsh = s3 ? sh[3] : (s2 ? sh[2] : (s1 ? sh[1] : sh[0]));
+      const int vsw = s3 ? sw[3] : (s2 ? sw[2] : (s1 ? sw[1] : sw[0]));
+      const int vsc = s3 ? sc[3] : (s2 ? sc[2] : (s1 ? sc[1] : sc[0]));
+      const int ko = s3 ? ko3 : (s2 ? ko2 : (s1 ? ko1 : 0));
       const int cs = c8 - ko;
-      const bool ok = q < c.ngroups && (unsigned)y < (unsigned)c.H && (unsigned)x < (unsigned)c.W && cs < sc;
-      const char* src = ok ? base + (int64_t)(y * sh + x * sw + cs) * 2 : (const char*)st_zero16;
-      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(smem + pi * 1024), 16, 0, 0);
+      const int ok = (int)(q < ngroups) & (int)((unsigned)y < (unsigned)H) & (int)((unsigned)x < (unsigned)W) & (int)(cs < vsc);
+      const uint64_t m = (uint64_t)0 - (uint64_t)ok;  // all ones / zero
+      const uint64_t cand = base + (uint64_t)(int64_t)((y * vsh + x * vsw + cs) * 2);
+      const uint64_t src = (cand & m) | (z64 & ~m);
+      __builtin_amdgcn_global_load_lds((gbl_ptr)(uintptr_t)src, (lds_ptr)(img + pi * 1024), 16, 0, 0);
     }
   }
+  // ---- warm L2 for the NEXT op: one dword per 128-byte line of its weight image (the loads are consumed -- as dead values --
+  // at the end of this op, so their round trip hides under this op's work)
+  {
+    const char* nw = SP(next_w);
+    const int nbytes = SI(next_w_bytes);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int off = (tid + j * ST_THREADS) * 128;
+      pf[j] = *(const uint32_t*)(nw + min(off, max(nbytes - 4, 0)));
+    }
+  }
+  ST_STAMP(1);
   __syncthreads();  // (hipcc drains vmcnt before the barrier: the image has landed)
-  if (c.act != CGEN_ACT_NONE) {
-    uint4* img = (uint4*)smem;
-    for (int q = tid; q < c.ngroups; q += ST_THREADS) img[q] = st_act_group(img[q], c.act);
+  ST_STAMP(2);
+  const int act = SI(act);
+  if (act != CGEN_ACT_NONE) {
+    uint4* im = (uint4*)img;
+    for (int q = tid; q < ngroups; q += ST_THREADS) im[q] = st_act_group(im[q], act);
     __syncthreads();
   }
 
+  ST_STAMP(3);
   // ---- this wave's share of the (pixel group) x (channel tile) grid
-  const int g0 = c.wg0[wave], g1 = c.wg1[wave], t0 = c.wt0[wave], t1 = c.wt1[wave];
-  const char* outp = c.out.p + (int64_t)n * c.out.sn * 2;
-  const char* auxp = c.aux.p ? c.aux.p + (int64_t)n * c.aux.sn * 2 : nullptr;
-  const char* r1p = c.res1.p ? c.res1.p + (int64_t)n * c.res1.sn * 2 : nullptr;
-  const char* r2p = c.res2.p ? c.res2.p + (int64_t)n * c.res2.sn * 2 : nullptr;
-  const int nk = c.nk;
+  const int g0 = __builtin_amdgcn_readlane((int)ow.w[ST_FIELD_DW(wg0) / 64], (ST_FIELD_DW(wg0) % 64) + wave);
+  const int g1 = __builtin_amdgcn_readlane((int)ow.w[ST_FIELD_DW(wg1) / 64], (ST_FIELD_DW(wg1) % 64) + wave);
+  const int t0 = __builtin_amdgcn_readlane((int)ow.w[ST_FIELD_DW(wt0) / 64], (ST_FIELD_DW(wt0) % 64) + wave);
+  const int t1 = __builtin_amdgcn_readlane((int)ow.w[ST_FIELD_DW(wt1) / 64], (ST_FIELD_DW(wt1) % 64) + wave);
+  const int Co = SI(Co), HW = SI(HW), nk = SI(nk), krow = SI(krow), k_lo = SI(k_lo), rows_pad = SI(rows_pad), pixstride = SI(pixstride), zoff = SI(zoff);
+  const int dact = SI(dact), out_cpad = SI(out.cpad);
+  const SDiv d_w = {(uint32_t)SI(d_w.mul), (uint32_t)SI(d_w.shift)};
+  const bf16_t* wimg = (const bf16_t*)SP(w);
+  const float* bias = (const float*)SP(bias);
+  const int* ktab = (const int*)(blob + SI(ktab_off));
+  const char* outp = SP(out.p) + (int64_t)n * SI(out.sn) * 2;
+  const char* auxp0 = SP(aux.p);
+  const char* r1p0 = SP(res1.p);
+  const char* r2p0 = SP(res2.p);
+  const char* auxp = auxp0 ? auxp0 + (int64_t)n * SI(aux.sn) * 2 : nullptr;
+  const char* r1p = r1p0 ? r1p0 + (int64_t)n * SI(res1.sn) * 2 : nullptr;
+  const char* r2p = r2p0 ? r2p0 + (int64_t)n * SI(res2.sn) * 2 : nullptr;
+  const int out_sh = SI(out.sh), out_sw = SI(out.sw), aux_sh = SI(aux.sh), aux_sw = SI(aux.sw);
+  const int r1_sh = SI(res1.sh), r1_sw = SI(res1.sw), r2_sh = SI(res2.sh), r2_sw = SI(res2.sw);
   for (int tb = t0; tb < t1; tb += ST_TB) {
     const int nt = min(ST_TB, t1 - tb);
     // weight rows of this lane (rows past the image are clamped: their results are never stored)
@@ -163,17 +223,17 @@ __device__ __forceinline__ void st_conv(const StConv& c, const int* __restrict__
     st_f32x4 binit[ST_TB];
 #pragma unroll
     for (int j = 0; j < ST_TB; ++j) {
-      const int row = min((tb + j) * 16 + r, c.rows_pad - 1);
-      wrow[j] = c.w + ((int64_t)row * c.krow + c.k_lo + kg * 8);
+      const int row = min((tb + j) * 16 + r, rows_pad - 1);
+      wrow[j] = wimg + ((int64_t)row * krow + k_lo + kg * 8);
       const int co = (tb + j) * 16 + kg * 4;
-      float b[4] = {0.f, 0.f, 0.f, 0.f};
-      if (c.bias) {
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) b[e] = c.bias[min(co + e, c.Co - 1)];
+        for (int e = 0; e < 4; ++e) bv[e] = bias[min(co + e, Co - 1)];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) b[e] = (co + e < c.Co) ? b[e] : 0.f;
+        for (int e = 0; e < 4; ++e) bv[e] = (co + e < Co) ? bv[e] : 0.f;
       }
-      binit[j] = (st_f32x4){b[0], b[1], b[2], b[3]};
+      binit[j] = (st_f32x4){bv[0], bv[1], bv[2], bv[3]};
     }
     for (int pb = g0; pb < g1; pb += ST_PB) {
       const int np = min(ST_PB, g1 - pb);
@@ -182,18 +242,12 @@ __device__ __forceinline__ void st_conv(const StConv& c, const int* __restrict__
 #pragma unroll
       for (int i = 0; i < ST_PB; ++i) {
         int p = (pb + i) * 16 + r;
-        pv[i] = i < np && p < c.HW;
-        p = min(p, c.HW - 1);
-        py[i] = sdiv(p, c.d_w);
-        px[i] = p - py[i] * c.W;
-        pbase[i] = (py[i] * c.Wp + px[i]) * c.pixstride;
+        pv[i] = i < np && p < HW;
+        p = min(p, HW - 1);
+        py[i] = sdiv(p, d_w);
+        px[i] = p - py[i] * W;
+        pbase[i] = (py[i] * Wp + px[i]) * pixstride;
       }
-      st_f32x4 acc[ST_PB][ST_TB];
-#pragma unroll
-      for (int i = 0; i < ST_PB; ++i)
-#pragma unroll
-        for (int j = 0; j < ST_TB; ++j) acc[i][j] = binit[j];
-
       // ---- K loop: ring of ST_DEPTH K-steps (weight fragments + table entries) in flight
       st_bf16x8 wf[ST_DEPTH][ST_TB];
       int kt[ST_DEPTH];
@@ -209,6 +263,25 @@ __device__ __forceinline__ void st_conv(const StConv& c, const int* __restrict__
             if (j < nt) wf[d][j] = *(const st_bf16x8*)(wrow[j] + d * 32);
         }
       }
+      // epilogue operands of the whole block: requested now, consumed after the K loop (vmcnt is in order: they are back
+      // long before the last weight fragment)
+      uint2 ea[ST_PB][ST_TB], er1[ST_PB][ST_TB], er2[ST_PB][ST_TB];
+#pragma unroll
+      for (int i = 0; i < ST_PB; ++i)
+#pragma unroll
+        for (int j = 0; j < ST_TB; ++j) {
+          const int co = (tb + j) * 16 + kg * 4;
+          const bool live = pv[i] && j < nt && co + 4 <= Co;
+          ea[i][j] = er1[i][j] = er2[i][j] = make_uint2(0, 0);
+          if (auxp) ea[i][j] = *(const uint2*)(live ? auxp + (py[i] * aux_sh + px[i] * aux_sw + co) * 2 : (const char*)st_zero16);
+          if (r1p) er1[i][j] = *(const uint2*)(live ? r1p + (py[i] * r1_sh + px[i] * r1_sw + co) * 2 : (const char*)st_zero16);
+          if (r2p) er2[i][j] = *(const uint2*)(live ? r2p + (py[i] * r2_sh + px[i] * r2_sw + co) * 2 : (const char*)st_zero16);
+        }
+      st_f32x4 acc[ST_PB][ST_TB];
+#pragma unroll
+      for (int i = 0; i < ST_PB; ++i)
+#pragma unroll
+        for (int j = 0; j < ST_TB; ++j) acc[i][j] = binit[j];
       for (int ks0 = 0; ks0 < nk; ks0 += ST_DEPTH) {
 #pragma unroll
         for (int d = 0; d < ST_DEPTH; ++d) {
@@ -218,7 +291,7 @@ __device__ __forceinline__ void st_conv(const StConv& c, const int* __restrict__
             st_bf16x8 a[ST_PB];
 #pragma unroll
             for (int i = 0; i < ST_PB; ++i)
-              if (i < np) a[i] = *(const st_bf16x8*)(smem + (ko < 0 ? c.zoff : pbase[i] + ko));
+              if (i < np) a[i] = *(const st_bf16x8*)(img + (ko < 0 ? zoff : pbase[i] + ko));
 #pragma unroll
             for (int i = 0; i < ST_PB; ++i)
               if (i < np) {
@@ -236,27 +309,25 @@ __device__ __forceinline__ void st_conv(const StConv& c, const int* __restrict__
         }
       }
 
+      ST_STAMP(4);
       // ---- epilogue: lane owns channels co .. co+3 of pixel (py, px) of every block tile
 #pragma unroll
       for (int i = 0; i < ST_PB; ++i) {
         if (!pv[i]) continue;
-        const int o_out = (py[i] * c.out.sh + px[i] * c.out.sw) * 2;
-        const int o_aux = (py[i] * c.aux.sh + px[i] * c.aux.sw) * 2;
-        const int o_r1 = (py[i] * c.res1.sh + px[i] * c.res1.sw) * 2;
-        const int o_r2 = (py[i] * c.res2.sh + px[i] * c.res2.sw) * 2;
+        const int o_out = (py[i] * out_sh + px[i] * out_sw) * 2;
 #pragma unroll
         for (int j = 0; j < ST_TB; ++j) {
           if (j >= nt) continue;
           const int co = (tb + j) * 16 + kg * 4;
           float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-          if (co + 4 <= c.Co) {
+          if (co + 4 <= Co) {
             if (auxp) {
-              const uint2 a2 = *(const uint2*)(auxp + o_aux + co * 2);
+              const uint2 a2 = ea[i][j];
               const float av[4] = {st_bf_lo(a2.x), st_bf_hi(a2.x), st_bf_lo(a2.y), st_bf_hi(a2.y)};
-              if (c.dact == CGEN_ACT_RELU) {
+              if (dact == CGEN_ACT_RELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = av[e] > 0.f ? v[e] : 0.f;
-              } else if (c.dact == CGEN_ACT_GELU) {
+              } else if (dact == CGEN_ACT_GELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                   float cdf, pdf;
@@ -266,27 +337,28 @@ __device__ __forceinline__ void st_conv(const StConv& c, const int* __restrict__
               }
             }
             if (r1p) {
-              const uint2 t = *(const uint2*)(r1p + o_r1 + co * 2);
+              const uint2 t = er1[i][j];
               v[0] += st_bf_lo(t.x); v[1] += st_bf_hi(t.x); v[2] += st_bf_lo(t.y); v[3] += st_bf_hi(t.y);
             }
             if (r2p) {
-              const uint2 t = *(const uint2*)(r2p + o_r2 + co * 2);
+              const uint2 t = er2[i][j];
               v[0] += st_bf_lo(t.x); v[1] += st_bf_hi(t.x); v[2] += st_bf_lo(t.y); v[3] += st_bf_hi(t.y);
             }
             uint2 o;
             o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]);
             *(uint2*)(outp + o_out + co * 2) = o;
           } else {  // ragged width: element by element; channels [Co, out.cpad) are written as zeros
+            const int o_aux = (py[i] * aux_sh + px[i] * aux_sw) * 2, o_r1 = (py[i] * r1_sh + px[i] * r1_sw) * 2, o_r2 = (py[i] * r2_sh + px[i] * r2_sw) * 2;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const int ce = co + e;
-              if (ce < c.Co) {
+              if (ce < Co) {
                 float u = v[e];
-                if (auxp) u *= act_bwd(c.dact, bf2f(*(const bf16_t*)(auxp + o_aux + ce * 2)));
+                if (auxp) u *= act_bwd(dact, bf2f(*(const bf16_t*)(auxp + o_aux + ce * 2)));
                 if (r1p) u += bf2f(*(const bf16_t*)(r1p + o_r1 + ce * 2));
                 if (r2p) u += bf2f(*(const bf16_t*)(r2p + o_r2 + ce * 2));
                 *(bf16_t*)(outp + o_out + ce * 2) = f2bf(u);
-              } else if (ce < c.out.cpad) {
+              } else if (ce < out_cpad) {
                 *(bf16_t*)(outp + o_out + ce * 2) = 0;
               }
             }
@@ -322,7 +394,7 @@ __device__ __forceinline__ void st_elem(const int kind, const StElem& e, const i
 // (one per 256-thread half), each half reduced in block_sum_256's order -> the same partials bit for bit
 __device__ __forceinline__ void st_reparam_fwd(const LatP& p, const int n, float* red) {
   const int tid = threadIdx.x, half = tid >> 8, t = tid & 255;
-  const int nchunks = (p.h * p.w * p.c + LAT_CHUNK - 1) / LAT_CHUNK;
+  const int nchunks = __builtin_amdgcn_readfirstlane((p.h * p.w * p.c + LAT_CHUNK - 1) / LAT_CHUNK);
   uint64_t seed = 0, off = 0;
   if (!p.eps_in.p) { seed = p.rng[0]; off = p.rng[1]; }
   for (int c0 = 0; c0 < nchunks; c0 += 2) {
@@ -346,25 +418,60 @@ __device__ __forceinline__ void st_reparam_bwd(const LatBwdP& p, const int n) {
   }
 }
 
-__global__ __launch_bounds__(ST_THREADS) void stage_kernel(const char* __restrict__ blob, const int nops) {
+static_assert(sizeof(StOp) <= ST_OPBUF, "an op descriptor must fit its LDS slot");
+static_assert(ST_FIELD_DW(wt1) + ST_WAVES <= 64 && ST_FIELD_DW(wg0) / 64 == 0, "the per-wave plan must sit in the first 64 dwords of the op");
+
+__device__ __forceinline__ void st_fetch_op(const char* __restrict__ blob, const int i, char* smem, const int lane) {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  // one wave-wide DMA: 64 lanes x 16 bytes = the whole slot (bytes past sizeof(StOp) belong to the next op or the tables:
+  // readable, ignored)
+  __builtin_amdgcn_global_load_lds((gbl_ptr)(blob + (size_t)i * sizeof(StOp) + lane * 16), (lds_ptr)(smem + (i & 1) * ST_OPBUF), 16, 0, 0);
+}
+
+__global__ __launch_bounds__(ST_THREADS) void stage_kernel(const char* __restrict__ blob, const int nops, unsigned long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float red[ST_WAVES];
-  const StOp* ops = (const StOp*)blob;
   const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave == 0) st_fetch_op(blob, 0, smem, lane);
+  __syncthreads();
   for (int i = 0; i < nops; ++i) {
-    const StOp& op = ops[i];
-    const int kind = op.kind;
+    unsigned long long* stamp = (stamps && n == 0 && threadIdx.x == 0 && i < 256) ? stamps + 8 * i : nullptr;  // CGEN_STAGE_STAMPS: 100 MHz clock per phase, workgroup 0
+    ST_STAMP(0);
+    const int slot = i & 1;
+    const OpW ow = st_load_op(smem, slot, lane);
+    const int kind = __builtin_amdgcn_readlane((int)ow.w[0], 0);
+    uint32_t pf[3] = {0, 0, 0};
     if (kind == CGEN_ST_CONV) {
-      st_conv(op.conv, (const int*)(blob + op.conv.ktab_off), n, smem);
-    } else if (kind == CGEN_ST_REPARAM_FWD) {
-      st_reparam_fwd(op.lat, n, red);
-    } else if (kind == CGEN_ST_REPARAM_BWD) {
-      st_reparam_bwd(op.latb, n);
+      if (wave == ST_WAVES - 1 && i + 1 < nops) st_fetch_op(blob, i + 1, smem, lane);  // lands with this op's first barrier
+      st_conv(ow, blob, n, smem, stamp, pf);
+      ST_STAMP(5);
     } else {
-      if (op.elem.vec) st_elem<4>(kind, op.elem, n);
-      else st_elem<1>(kind, op.elem, n);
+      // element-wise / latent ops: the descriptor is copied out of LDS (per-lane registers), then the next one is fetched
+      const char* od = smem + slot * ST_OPBUF;
+      if (kind == CGEN_ST_REPARAM_FWD) {
+        const LatP p = *(const LatP*)(od + offsetof(StOp, lat));
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the copy is in registers before the slot's neighbour is overwritten... (and before any DMA is in flight)
+        if (wave == ST_WAVES - 1 && i + 1 < nops) st_fetch_op(blob, i + 1, smem, lane);
+        st_reparam_fwd(p, n, red);
+      } else if (kind == CGEN_ST_REPARAM_BWD) {
+        const LatBwdP p = *(const LatBwdP*)(od + offsetof(StOp, latb));
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (wave == ST_WAVES - 1 && i + 1 < nops) st_fetch_op(blob, i + 1, smem, lane);
+        st_reparam_bwd(p, n);
+      } else {
+        const StElem e = *(const StElem*)(od + offsetof(StOp, elem));
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (wave == ST_WAVES - 1 && i + 1 < nops) st_fetch_op(blob, i + 1, smem, lane);
+        if (e.vec) st_elem<4>(kind, e, n);
+        else st_elem<1>(kind, e, n);
+      }
     }
     __syncthreads();  // the next op reads what this one wrote (same workgroup: workgroup scope is enough) and reuses the LDS
+    asm volatile("" ::"v"(pf[0]), "v"(pf[1]), "v"(pf[2]));  // (the L2 warm-up loads end here)
+    ST_STAMP(6);
+    if (stamp) stamp[7] = (unsigned long long)kind;
   }
 }
 
@@ -430,13 +537,15 @@ static int plan_conv(const cgen_conv_args* a, StConv& o, std::vector<int>* ktab)
   o.ngroups = Hp * o.Wp * o.Gs;
   o.npieces = (o.ngroups + 1 + 63) / 64;  // + the zero slot right behind the image
   o.zoff = o.ngroups * 16;
-  const int lds = o.npieces * 1024;
+  const int lds = ST_IMG_OFF + o.npieces * 1024;
   if (lds > 156 * 1024) return 0;
   o.G = (o.HW + 15) / 16;
   o.T = (o.Co + 15) / 16;
   if ((int64_t)o.G * o.T * o.nk > stage_budget()) return 0;  // too much work for one CU per image: a chip-wide launch is faster
   o.w = (const bf16_t*)a->weight;
   o.bias = a->bias;
+  o.next_w = (const char*)a->weight;  // (cgen_stage_plan points it at the next conv of the list)
+  o.next_w_bytes = 0;
   o.d_gs = mk_sdiv(o.Gs); o.d_wp = mk_sdiv(o.Wp); o.d_w = mk_sdiv(a->w);
   // ---- wave plan: PW x TW waves over (pixel groups) x (channel tiles); cost = the busiest SIMD's MFMAs (waves w and w + 4
   // share a SIMD) + the weight traffic, which grows with PW (every pixel chunk re-reads its tiles' weights from L2)
@@ -565,6 +674,7 @@ static int plan_op(int kind, const void* args, StOp& op, std::vector<int>* ktab)
       lds = plan_elem(kind, (const cgen_stage_elem_args*)args, op.elem); break;
     default: return 0;
   }
+  if (lds > 0 && lds < ST_IMG_OFF) lds = ST_IMG_OFF;  // (the descriptor slots)
   op.lds_bytes = lds;
   return lds;
 }
@@ -595,6 +705,16 @@ extern "C" int cgen_stage_plan(const int32_t* kinds, const void* const* args, in
       table.insert(table.end(), kt.begin(), kt.end());
     }
   }
+  for (int i = 0; i < count; ++i) {  // L2 warm-up target of every conv: the weight image of the next conv of the list
+    if (kinds[i] != CGEN_ST_CONV) continue;
+    for (int j = i + 1; j < count; ++j)
+      if (kinds[j] == CGEN_ST_CONV) {
+        ops[i].conv.next_w = (const char*)ops[j].conv.w;
+        ops[i].conv.next_w_bytes = ops[j].conv.rows_pad * ops[j].conv.krow * 2;
+        break;
+      }
+  }
+  table.resize(table.size() + 256, 0);  // (the last descriptor's slot DMA reads a full KiB)
   const int64_t total = ops_bytes + (int64_t)table.size() * 4;
   *blob_bytes = total;
   *lds_bytes = lds;
@@ -613,6 +733,8 @@ extern "C" int cgen_stage_run(const void* blob_dev, int32_t count, int32_t n_ima
     (void)hipGetLastError();
     once = true;
   }
-  hipLaunchKernelGGL(stage_kernel, dim3(n_images), dim3(ST_THREADS), (size_t)lds_bytes, (hipStream_t)stream, (const char*)blob_dev, count);
+  unsigned long long* stamps = nullptr;
+  { const char* e = getenv("CGEN_STAGE_STAMPS"); if (e) stamps = (unsigned long long*)strtoull(e, nullptr, 0); }
+  hipLaunchKernelGGL(stage_kernel, dim3(n_images), dim3(ST_THREADS), (size_t)lds_bytes, (hipStream_t)stream, (const char*)blob_dev, count, stamps);
   return check_launch("cgen_stage_run");
 }

@@ -347,12 +347,21 @@ class Engine(StageMixin):
         """engine tensor -> torch tensor of NCHW *shape* in channels-last memory (zero-copy view of a clone)."""
         t = torch.empty((x.n, x.h, x.w, x.c), dtype=self.tdtype, device=self.device)
         dst = self.wrap_nhwc(t)
-        self.lib.axpby(self.dt, x.n, x.h, x.w, x.cv(), dst.cv(), 1.0, 1.0, 1 << 30, 0, self.stream)
-        self.launches += 1
-        # `t` leaves the engine: the copy must be ON the stream before the caller can read -- or FREE -- it (a deferred
-        # stage op would write into memory torch may have handed to somebody else by then)
+        # `t` leaves the engine: the copy must be ON the stream before the caller can read -- or FREE -- it (a deferred stage
+        # op would write into memory torch may have handed to somebody else by then), and its address is not stable
+        # across passes: never part of a stage list
         self.stage_flush()
+        self._rawlib.axpby(self.dt, x.n, x.h, x.w, x.cv(), dst.cv(), 1.0, 1.0, 1 << 30, 0, self.stream)
+        self.launches += 1
         return t.permute(0, 3, 1, 2)
+
+    def copy_in(self, x):
+        """Arena copy of a tensor that lives in torch-allocated memory (stable addresses for the stage op lists)."""
+        out = self.new(x.n, x.h, x.w, x.c, rg=False)
+        self.stage_flush()
+        self._rawlib.axpby(self.dt, x.n, x.h, x.w, x.cv(), out.cv(), 1.0, 1.0, 1 << 30, 0, self.stream)
+        self.launches += 1
+        return out
 
     # ------------------------------------------------------------------ parameters and weight images
     def bind(self, model, sites):

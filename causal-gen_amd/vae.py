@@ -1198,7 +1198,10 @@ class HVAE(nn.Module):
                 z = z["z"]
             z = z.to(eng.device)
             if z.dtype == eng.tdtype and z.permute(0, 2, 3, 1).is_contiguous():
-                ins.append(eng.wrap_nhwc(z.permute(0, 2, 3, 1)))
+                nt = eng.wrap_nhwc(z.permute(0, 2, 3, 1))
+                # (at a staged resolution the latent moves into the arena: the op lists of a captured pass then hold the same
+                #  addresses as the eager warm-up's -- a torch allocation inside the capture would not)
+                ins.append(eng.copy_in(nt) if eng.stage_covers(nt.h) else nt)
             else:
                 ins.append(eng.from_nchw(z.float()))
         return ins
