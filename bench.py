@@ -105,7 +105,7 @@ def cpu_baseline(name, budget_s=8.0, hard_limit_s=75.0):
 
     ncpu = os.cpu_count() or 8
     tried, best = {}, None
-    for nt in sorted({min(8, ncpu), min(32, ncpu), ncpu}):
+    for nt in sorted({min(8, ncpu), min(32, ncpu)}):  # (all hardware threads: slower than 8 by 10-20x on these hosts, and past its time limit at 256)
         env = dict(os.environ, OMP_NUM_THREADS=str(nt), MKL_NUM_THREADS=str(nt), HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", name, str(nt), str(budget_s)], env=env,
@@ -199,6 +199,51 @@ def profile_step(ts, x, pa, dtype, workload_key=None):
                     for k, v in top])
 
 
+def cf_parents(pa):
+    """train_cf.py:149 feeds a permutation of the batch's parents as `do`."""
+    return pa[:, :, 0, 0].roll(1, 0)[..., None, None].expand_as(pa) if pa.stride(2) == 0 else pa.roll(1, 0)
+
+
+def cf_leg(model, x, pa, config, n_cf=10):
+    """Counterfactuals/s of `model` (abduct -> act -> predict as one hipGraph replay per batch) and the FLOPs it executes."""
+    from causal_gen_amd.dscm import GraphedCounterfactual
+
+    cfp = cf_parents(pa)
+    counterfactual = GraphedCounterfactual(model)
+    for _ in range(3):
+        counterfactual(x, pa, cfp)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(n_cf):
+        counterfactual(x, pa, cfp)
+    torch.cuda.synchronize()
+    cf_s = x.shape[0] * n_cf / (time.perf_counter() - t1)
+    reuse = os.environ.get("CGEN_CF_REUSE", "1") != "0"
+    cf_gf = (CF_GFLOP_REUSE if reuse else CF_GFLOP)[config]
+    return {"counterfactuals_per_s": cf_s, "cf_tflops": cf_s * cf_gf * 1e9 / 1e12,  # FLOPs the loop executes, not the three-pass figure
+            "cf_gflop_per_counterfactual": {"executed": cf_gf, "reference_three_pass": CF_GFLOP[config],
+                                            "reconstruction_from_abduction_pass": reuse}}
+
+
+def cf_deviation(m_a, m_b, x, pa):
+    """max |cf_x| difference between two models holding the SAME weights (bf16 path vs f32 parity path) on the benched batch,
+    same Philox state: what the reduced precision does to counterfactual pixels (north_star: 1e-3 abs vs the reference)."""
+    from causal_gen_amd.dscm import counterfactual
+
+    outs = []
+    for mod in (m_a, m_b):
+        was = mod.training
+        mod.eval()
+        eng = mod.engine()
+        eng.rng_ptr()
+        eng.rng.copy_(torch.tensor([20240608, 0], dtype=torch.int64))
+        with torch.no_grad():
+            o = counterfactual(mod, x, pa, cf_parents(pa))
+        outs.append((o["x"] if isinstance(o, dict) else o).float().clone())
+        mod.train(was)
+    return float((outs[0] - outs[1]).abs().max())
+
+
 def f32_leg(a, hp, B, dev, x, pa, m_bf16):
     """The PARITY path (exact f32 MFMA chains: the one the 1e-4 ELBO tests hold on) timed in the same run on the same
     workload, with its own roofline (157.3 TF dense f32 MFMA), and the bf16 path's ELBO deviation from it on the benched
@@ -234,13 +279,125 @@ def f32_leg(a, hp, B, dev, x, pa, m_bf16):
     rel = [abs(b - f) / max(abs(f), 1e-12) for b, f in zip(vals["bf16"], vals["f32"])]
     gf = TRAIN_GFLOP_PER_IMG[a.config]
     img_s = B * steps / dt
+    cf32 = cf_leg(m32, x, pa, a.config, n_cf=4) if not a.no_cf else {}
+    cfdev = cf_deviation(m_bf16, m32, x, pa) if not a.no_cf else None
     del ts32, m32
     torch.cuda.empty_cache()
-    return {"images_s": img_s, "ms_per_step": 1e3 * dt / steps, "steps": steps, "model_tflops": img_s * gf / 1e3,
+    return {"images_s": img_s, "counterfactuals_per_s": cf32.get("counterfactuals_per_s"), "cf_tflops": cf32.get("cf_tflops"),
+            "bf16_vs_f32_cf_maxabs": cfdev, "ms_per_step": 1e3 * dt / steps, "steps": steps, "model_tflops": img_s * gf / 1e3,
             "model_mfma_frac": img_s * gf / 1e3 / MFMA_PEAK_TF["f32"],
             "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us", "classes")},
             "elbo_nll_kl_f32": vals["f32"], "elbo_nll_kl_bf16": vals["bf16"], "bf16_vs_f32_elbo_rel": rel[0],
             "bf16_vs_f32_nll_rel": rel[1], "bf16_vs_f32_kl_rel": rel[2]}
+
+
+def side_config(name, dmol, B, dev, steps=10, prep=12, cf=True, parity=True):
+    """One more workload in the same run (bf16 train step under a hipGraph, synthetic batch resident in HBM): images/s, fraction
+    of the dense bf16 MFMA peak, counterfactuals/s, and the bf16 path's ELBO deviation from the f32 parity path at identical
+    weights and noise."""
+    from causal_gen_amd.train import TrainStep
+
+    m, hp = build_model(name, "bf16", dmol)
+    m = m.to(dev)
+    ts = TrainStep(m, hp, ema=cf, use_graph=True)
+    x, pa = synth_batch(name, hp, B, dev, seed=100)
+    out = None
+    for _ in range(prep):
+        out = ts.step(x, pa)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = ts.step(x, pa)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    img_s = B * steps / dt
+    gf = TRAIN_GFLOP_PER_IMG[name]
+    r = {"workload": f"{name} HVAE train step ({hp.input_res}x{hp.input_res}x{hp.input_channels}, {'DMoL' if dmol else 'DGauss'} likelihood)",
+         "per_gpu_batch": B, "images_s": img_s, "ms_per_step": 1e3 * dt / steps, "steps": steps, "model_tflops": img_s * gf / 1e3,
+         "model_mfma_frac": img_s * gf / 1e3 / MFMA_PEAK_TF["bf16"], "elbo_nats_per_dim": float(out[0]),
+         "launches_per_step_eager": None}
+    if cf:
+        r.update({k: v for k, v in cf_leg(ts.ema_model, x, pa, name, n_cf=6).items() if k != "cf_gflop_per_counterfactual"})
+    if parity:
+        m32, _ = build_model(name, "f32", dmol)
+        m32 = m32.to(dev)
+        m32.load_state_dict(m.state_dict())
+        vals = {}
+        for tag, mod in (("bf16", m), ("f32", m32)):
+            was = mod.training
+            mod.eval()
+            eng = mod.engine()
+            eng.rng_ptr()
+            eng.rng.copy_(torch.tensor([20240607, 0], dtype=torch.int64))
+            with torch.no_grad():
+                o = mod(x, pa, beta=hp.beta)
+            vals[tag] = float(o["elbo"])
+            mod.train(was)
+        r["elbo_f32_same_weights"] = vals["f32"]
+        r["bf16_vs_f32_elbo_rel"] = abs(vals["bf16"] - vals["f32"]) / max(abs(vals["f32"]), 1e-12)
+        if cf:
+            r["bf16_vs_f32_cf_maxabs"] = cf_deviation(m, m32, x, pa)
+        del m32
+    del ts, m
+    torch.cuda.empty_cache()
+    return r
+
+
+def bandwidth_kernels(dev):
+    """The HBM-bound kernels of the step against the HBM roofline ("report all three"): algorithmic bytes / HIP-event
+    time of the stand-alone launch at the ukbb192 shapes (batch 32, bf16), next to 6.3 TB/s achievable and 8 TB/s spec."""
+    from causal_gen_amd import _lib
+    from causal_gen_amd.engine import Engine
+
+    eng = Engine(dev, "bf16")
+    eng.begin()
+    lib = eng.lib
+    out = {}
+
+    def timed(fn, nbytes, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = 1e3 * e0.elapsed_time(e1) / reps
+        gbs = nbytes / us / 1e3
+        return {"us": us, "algorithmic_bytes": nbytes, "GB_s": gbs, "frac_of_6.3TBs": gbs / 6300.0, "frac_of_8TBs": gbs / 8000.0}
+
+    B, R, Z = 32, 96, 16
+    heads = [eng.new(B, R, R, 2 * Z + 64), eng.new(B, R, R, 2 * Z)]  # prior Block output [p_loc | p_ls | p_feat], posterior [q_loc | q_ls]
+    for t in heads:
+        eng.fill(t, 0.1)
+    p, q = heads
+    z = eng.new(B, R, R, Z)
+    kl = torch.zeros(B * lib.reparam_kl_chunks(R, R, Z), device=dev)
+    n = B * R * R * Z
+    eng.rng_ptr()
+    out["reparam_kl_fwd_96"] = timed(lambda: lib.reparam_kl_fwd(eng.dt, B, R, R, Z, q.chan(0, Z).cv(), q.chan(Z, 2 * Z).cv(), p.chan(0, Z).cv(),
+                                                                  p.chan(Z, 2 * Z).cv(), _lib.NULL_VIEW, eng.rng_ptr(), 7, 0.0, z.cv(), _lib.NULL_VIEW,
+                                                                  kl.data_ptr(), kl.numel() // B, eng.stream), n * 2 * 5)  # 4 reads + 1 write
+    gq, gp, gz = eng.new(B, R, R, 2 * Z), eng.new(B, R, R, 2 * Z + 64), eng.new(B, R, R, Z)
+    eng.fill(gz, 0.01)
+    coef = torch.ones(1, device=dev)
+    out["reparam_kl_bwd_96"] = timed(lambda: lib.reparam_kl_bwd(eng.dt, B, R, R, Z, q.chan(0, Z).cv(), q.chan(Z, 2 * Z).cv(), p.chan(0, Z).cv(),
+                                                                  p.chan(Z, 2 * Z).cv(), z.cv(), 0.0, gz.cv(), coef.data_ptr(), 0, None,
+                                                                  gq.chan(0, Z).cv(), gq.chan(Z, 2 * Z).cv(), gp.chan(0, Z).cv(), gp.chan(Z, 2 * Z).cv(), 0, 0,
+                                                                  eng.stream), n * 2 * 10)  # 6 reads + 4 writes
+    Rx = 192
+    params, xin = eng.new(B, Rx, Rx, 2), eng.new(B, Rx, Rx, 1)
+    eng.fill(params, 0.0)
+    eng.fill(xin, 0.3)
+    part = torch.zeros(B * lib.like_chunks(Rx, Rx), device=dev)
+    out["dgauss_nll_fwd_192"] = timed(lambda: lib.dgauss_nll_fwd(eng.dt, B, Rx, Rx, 1, params.cv(), xin.cv(), part.data_ptr(), eng.stream),
+                                      B * Rx * Rx * 2 * 3)
+    gpar = eng.new(B, Rx, Rx, 2)
+    out["dgauss_nll_bwd_192"] = timed(lambda: lib.dgauss_nll_bwd(eng.dt, B, Rx, Rx, 1, params.cv(), xin.cv(), coef.data_ptr(), 0, gpar.cv(), eng.stream),
+                                      B * Rx * Rx * 2 * 5)
+    return out
 
 
 def main():
@@ -258,6 +415,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cf", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32 parity-path leg (default: timed after the bf16 headline at N=1)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs, the batch sweep and the bandwidth-kernel table (default ukbb192 run only)")
     ap.add_argument("--prep-steps", type=int, default=20, help="untimed optimiser steps so the prior heads are non-zero")
     a = ap.parse_args()
 
@@ -344,29 +502,19 @@ def main():
                          "backend": os.environ.get("CGEN_DIST_BACKEND", "nccl")}
         res["roofline"] = roof
         if not a.no_cf:
-            from causal_gen_amd.dscm import GraphedCounterfactual
-
-            ema = ts.ema_model
-            # train_cf.py:149 feeds a permutation of the batch's parents as `do`
-            cfp = pa[:, :, 0, 0].roll(1, 0)[..., None, None].expand_as(pa) if pa.stride(2) == 0 else pa.roll(1, 0)
-            counterfactual = GraphedCounterfactual(ema)  # abduct -> act -> predict as one hipGraph replay per batch
-            for _ in range(3):
-                counterfactual(x, pa, cfp)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            n_cf = 10
-            for _ in range(n_cf):
-                counterfactual(x, pa, cfp)
-            torch.cuda.synchronize()
-            cf_s = B * n_cf / (time.perf_counter() - t1)
-            reuse = os.environ.get("CGEN_CF_REUSE", "1") != "0"
-            cf_gf = (CF_GFLOP_REUSE if reuse else CF_GFLOP)[a.config]
-            res["counterfactuals_per_s"] = cf_s
-            res["cf_tflops"] = cf_s * cf_gf * 1e9 / 1e12  # FLOPs the loop executes, not the three-pass figure
-            res["cf_gflop_per_counterfactual"] = {"executed": cf_gf, "reference_three_pass": CF_GFLOP[a.config],
-                                                  "reconstruction_from_abduction_pass": reuse}
+            res.update(cf_leg(ts.ema_model, x, pa, a.config))
         if world == 1 and a.dtype == "bf16" and not a.no_f32:
             res["f32"] = f32_leg(a, hp, B, dev, x, pa, m)
+        if world == 1 and not a.no_extra and a.config == "ukbb192" and a.batch is None and a.dtype == "bf16":
+            # the other BASELINE.json configs and a per-GPU batch sweep of the headline model, same process, same code
+            del ts
+            torch.cuda.empty_cache()
+            res["bandwidth_kernels"] = bandwidth_kernels(dev)
+            res["configs"] = {}
+            for key, cfg, dmol, Bc in (("morphomnist_b256", "morphomnist", False, 256), ("cmnist_dmol_b256", "cmnist", True, 256),
+                                       ("mimic224_b32", "mimic224", False, 32)):
+                res["configs"][key] = side_config(cfg, dmol, Bc, dev)
+            res["batch_sweep_ukbb192"] = {str(Bs): side_config("ukbb192", False, Bs, dev, cf=False, parity=False) for Bs in (64, 128)}
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(a.config)
         print(json.dumps(res))

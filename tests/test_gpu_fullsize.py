@@ -29,6 +29,10 @@ GRAD_TOL = 2e-3       # of the tensor's max |gradient|
 # bf16 storage of activations / weight images (f32 accumulate, f32 KL / NLL / reductions): measured deviation of the ELBO
 # from the reference at full size is 1e-4 .. 8e-4 relative depending on the preset (printed below); it is held to this bound.
 BF16_ELBO_TOL = 2e-3
+# ... and its counterfactual pixels: u = (x - rec_loc) / rec_scale amplifies the bf16 rounding of the reconstruction wherever the
+# abducted scale is small; measured 1.1e-2 (cmnist + DMoL) .. 5.9e-2 (ukbb192) absolute against the reference-made sample.  The
+# parity-grade counterfactual is the f32 one (CF_TOL above); the bf16 one is HELD to this bound so that it cannot drift unseen.
+BF16_CF_TOL = 9e-2
 
 
 def _model(name, dmol, dtype):
@@ -117,7 +121,9 @@ def test_fullsize_forward_backward_counterfactual(name, B, dmol):
     with torch.no_grad():
         cf_x = dscm.counterfactual(m, x.cuda(), pa.cuda(), cf_pa.cuda(), t_abduct=1.0)
     assert not m.noise
-    ok = row["cf"]["rec_scale"] > 1e-3
+    ok = row["cf"]["rec_scale"] > 1e-3  # (pixels whose abducted scale is degenerate amplify f32 rounding itself; counted below)
+    n_masked, n_pix = int((~ok).sum()), int(ok.numel())
+    assert n_masked <= 0.02 * n_pix, (n_masked, n_pix)
     d_cf = (R.sample_img(cf_x).cpu() - row["cf"]["cf_x"]).abs()
     assert float(d_cf[ok].max()) < CF_TOL, float(d_cf[ok].max())
     assert abs(float((cf_x.cpu() - x).abs().mean()) - row["cf"]["moved"]) < 1e-3
@@ -135,11 +141,12 @@ def test_fullsize_forward_backward_counterfactual(name, B, dmol):
         cf_b = dscm.counterfactual(mb, x.cuda(), pa.cuda(), cf_pa.cuda(), t_abduct=1.0)
     d_cfb = float((R.sample_img(cf_b).cpu() - row["cf"]["cf_x"]).abs()[ok].max())
     print("FULLSIZE %s: f32 vs reference elbo %.2e nll %.2e kl %.2e | grads: worst %.2e (fixture sample) %.2e (oracle, %d tensors) | "
-          "cf %.2e || bf16 vs reference elbo %.2e nll %.2e kl %.2e cf %.2e" % (
+          "cf %.2e (%d of %d sampled pixels masked: rec_scale <= 1e-3) || bf16 vs reference elbo %.2e nll %.2e kl %.2e cf %.2e" % (
               R.key(name, dmol), _rel(got["elbo"], row["elbo"]), _rel(got["nll"], row["nll"]), _rel(got["kl"], row["kl"]), worst_fx,
-              worst, n_checked, float(d_cf[ok].max()), dev["elbo"], dev["nll"], dev["kl"], d_cfb))
+              worst, n_checked, float(d_cf[ok].max()), n_masked, n_pix, dev["elbo"], dev["nll"], dev["kl"], d_cfb))
     assert dev["elbo"] < BF16_ELBO_TOL and dev["nll"] < BF16_ELBO_TOL, dev
     assert dev["kl"] < 2e-2, dev
+    assert d_cfb < BF16_CF_TOL, d_cfb
 
 
 @pytest.mark.parametrize("name", ["morphomnist", "cmnist", "ukbb192"])
