@@ -498,6 +498,12 @@ def main():
                          "exposed_comm_ms_per_step": exposed_comm,
                          "early_bytes": 4 * sum(hi - lo for lo, hi in (ts.early_ranges or [])),
                          "late_bytes": 4 * sum(hi - lo for lo, hi in (ts.late_ranges or [(0, ts._gbuf().numel())])),
+                         # bus bandwidth the exchange actually reached (ring: 2 (N-1)/N x bytes over the time the all-reduce
+                         # was exposed); meaningful for the serialized form, where all of it is exposed -- the number the
+                         # overlap policy's assumed CGEN_DP_BUS_GBS (300) should be re-decided from
+                         "bus_GB_s_achieved": (None if not exposed_comm else
+                                               2.0 * (world - 1) / max(world, 1) * 4.0 * ts._gbuf().numel() / (exposed_comm * 1e-3) / 1e9),
+                         "gradient_bytes": 4 * ts._gbuf().numel(),
                          "overlap_policy": getattr(ts, "dp_policy", None),
                          "backend": os.environ.get("CGEN_DIST_BACKEND", "nccl")}
         res["roofline"] = roof

@@ -228,6 +228,29 @@ def test_gradient_accumulation_graph_equals_eager():
         assert torch.equal(s0[k], s1[k]), k
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return str(s_.getsockname()[1])
+
+
+def test_dp_two_ranks_reproduce_the_single_process_step():
+    """Two ranks x B/2 through the default graph-captured data-parallel TrainStep == one process x B after three optimiser steps
+    (tests/dp_trainstep_worker.py): the rank-averaged flat gradient is the gradient of the global-batch mean on the real path."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), os.path.join(root, "tests", "dp_trainstep_worker.py")]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DP_TRAINSTEP_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_dp_bench_path_two_gloo_ranks_on_one_gpu():
     """The data-parallel step (hipGraph fwd+bwd -> bucketed gradient all-reduce -> hipGraph step tail) end to end: two
     ranks share this GPU over gloo (RCCL wants one device per rank; the code path is the same).  Both ranks must finish
@@ -240,7 +263,7 @@ def test_dp_bench_path_two_gloo_ranks_on_one_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, CGEN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--config", "morphomnist", "--batch", "16",
+           "--master-port", _free_port(), os.path.join(root, "bench.py"), "--gpus", "2", "--config", "morphomnist", "--batch", "16",
            "--steps", "2", "--warmup", "1", "--prep-steps", "1", "--no-cf"]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -263,7 +286,7 @@ def test_dp_allreduce_overlapped_with_backward_equals_the_serialized_exchange():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
-    for overlap, port in (("0", "29521"), ("1", "29523")):
+    for overlap, port in (("0", _free_port()), ("1", _free_port())):
         env = dict(os.environ, CGEN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", CGEN_DP_OVERLAP=overlap)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "ukbb192", "--batch", "2",
@@ -429,7 +452,7 @@ def test_free_bits_under_data_parallelism():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29519", os.path.join(root, "tests", "dp_free_bits_worker.py")]
+           "--master-port", _free_port(), os.path.join(root, "tests", "dp_free_bits_worker.py")]
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
     assert "DP_FREE_BITS_OK" in r.stdout, r.stdout[-1500:]
