@@ -39,7 +39,7 @@ typedef short st_s16x2 __attribute__((ext_vector_type(2)));
 #define ST_WAVES 8
 #define ST_PB 4   // pixel groups per register block
 #define ST_TB 2   // channel tiles per register block
-#define ST_DEPTH 4  // K-steps of weights in flight per wave
+#define ST_KC 8     // K-steps per chunk: all of a chunk's weight fragments are in flight together
 
 __device__ uint4 st_zero16[4];  // DMA / load source of everything that is "zero" (halo, padding groups, absent operands)
 
@@ -64,7 +64,7 @@ struct StConv {
   int H, W, KS, halo, nseg, act, dact, Co;
   int C8, Gs, Wp, HW, ngroups, npieces, G, T;
   int nk, krow, k_lo, rows_pad, pixstride, zoff, ktab_off, pad0;
-  int wg0[ST_WAVES], wg1[ST_WAVES], wt0[ST_WAVES], wt1[ST_WAVES];  // (kept inside the first 64 dwords of the op: one v_readlane with a wave index)
+  int PW, TW, npp, ntp, KC, woff, wslot, ktab_bytes;  // wave grid (PW x TW waves, each <= ST_PB pixel groups x ST_TB tiles per pass), passes, K-steps per weight chunk, LDS offset / slot size of the weight ring
   SView seg[CGEN_MAX_SEG];
   int seg_koff[CGEN_MAX_SEG];
   SView out, aux, res1, res2;
@@ -119,7 +119,8 @@ __device__ __forceinline__ float st_bf_hi(uint32_t w) { return __uint_as_float(w
 // away, wave-uniform in an SGPR -- instead of a chain of dependent scalar loads from global memory (~0.5 us per miss, five
 // deep per op when the table is cold).
 #define ST_OPBUF 1024
-#define ST_IMG_OFF 4096  // [op slot 0 | op slot 1 | spare] then the staged image
+#define ST_KTAB_OFF 2048 // this op's K-step table (<= 2 KiB: 128 K-steps)
+#define ST_IMG_OFF 4096  // [op slot 0 | op slot 1 | K-step table] then the staged image, then the two slots of the weight ring
 struct OpW { uint32_t w[ST_OPBUF / 256]; };
 __device__ __forceinline__ OpW st_load_op(const char* smem, const int slot, const int lane) {
   OpW o;
@@ -154,6 +155,12 @@ __device__ __forceinline__ void st_conv(const OpW& ow, const char* __restrict__ 
 #define ST_SEG(k) b[k] = (uint64_t)(uintptr_t)SP(seg[k].p) + (uint64_t)((int64_t)n * SI(seg[k].sn) * 2); sh[k] = SI(seg[k].sh); sw[k] = SI(seg[k].sw); sc[k] = SI(seg[k].c);
     ST_SEG(0) ST_SEG(1) ST_SEG(2) ST_SEG(3)
 #undef ST_SEG
+    if (wave == ST_WAVES - 2) {  // this op's K-step table -> LDS (read back with ds_read in the K loop: no global round trip there)
+      const char* kt_src = blob + SI(ktab_off);
+      const int ktb = SI(ktab_bytes);
+      for (int o = 0; o < ktb; o += 1024)
+        __builtin_amdgcn_global_load_lds((gbl_ptr)(kt_src + o + lane * 16), (lds_ptr)(smem + ST_KTAB_OFF + o), 16, 0, 0);
+    }
     for (int pi = wave; pi < npieces; pi += ST_WAVES) {
       const int q = pi * 64 + lane;
       const int pix = sdiv(q, d_gs), grp = q - pix * Gs;
@@ -174,17 +181,6 @@ __device__ __forceinline__ void st_conv(const OpW& ow, const char* __restrict__ 
       __builtin_amdgcn_global_load_lds((gbl_ptr)(uintptr_t)src, (lds_ptr)(img + pi * 1024), 16, 0, 0);
     }
   }
-  // ---- warm L2 for the NEXT op: one dword per 128-byte line of its weight image (the loads are consumed -- as dead values --
-  // at the end of this op, so their round trip hides under this op's work)
-  {
-    const char* nw = SP(next_w);
-    const int nbytes = SI(next_w_bytes);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int off = (tid + j * ST_THREADS) * 128;
-      pf[j] = *(const uint32_t*)(nw + min(off, max(nbytes - 4, 0)));
-    }
-  }
   ST_STAMP(1);
   __syncthreads();  // (hipcc drains vmcnt before the barrier: the image has landed)
   ST_STAMP(2);
@@ -196,17 +192,12 @@ __device__ __forceinline__ void st_conv(const OpW& ow, const char* __restrict__ 
   }
 
   ST_STAMP(3);
-  // ---- this wave's share of the (pixel group) x (channel tile) grid
-  const int g0 = __builtin_amdgcn_readlane((int)ow.w[ST_FIELD_DW(wg0) / 64], (ST_FIELD_DW(wg0) % 64) + wave);
-  const int g1 = __builtin_amdgcn_readlane((int)ow.w[ST_FIELD_DW(wg1) / 64], (ST_FIELD_DW(wg1) % 64) + wave);
-  const int t0 = __builtin_amdgcn_readlane((int)ow.w[ST_FIELD_DW(wt0) / 64], (ST_FIELD_DW(wt0) % 64) + wave);
-  const int t1 = __builtin_amdgcn_readlane((int)ow.w[ST_FIELD_DW(wt1) / 64], (ST_FIELD_DW(wt1) % 64) + wave);
   const int Co = SI(Co), HW = SI(HW), nk = SI(nk), krow = SI(krow), k_lo = SI(k_lo), rows_pad = SI(rows_pad), pixstride = SI(pixstride), zoff = SI(zoff);
+  const int G = SI(G), T = SI(T), PW = SI(PW), TW = SI(TW), npp = SI(npp), ntp = SI(ntp), KC = SI(KC), woff = SI(woff), wslot = SI(wslot);
   const int dact = SI(dact), out_cpad = SI(out.cpad);
   const SDiv d_w = {(uint32_t)SI(d_w.mul), (uint32_t)SI(d_w.shift)};
   const bf16_t* wimg = (const bf16_t*)SP(w);
   const float* bias = (const float*)SP(bias);
-  const int* ktab = (const int*)(blob + SI(ktab_off));
   const char* outp = SP(out.p) + (int64_t)n * SI(out.sn) * 2;
   const char* auxp0 = SP(aux.p);
   const char* r1p0 = SP(res1.p);
@@ -216,99 +207,115 @@ __device__ __forceinline__ void st_conv(const OpW& ow, const char* __restrict__ 
   const char* r2p = r2p0 ? r2p0 + (int64_t)n * SI(res2.sn) * 2 : nullptr;
   const int out_sh = SI(out.sh), out_sw = SI(out.sw), aux_sh = SI(aux.sh), aux_sw = SI(aux.sw);
   const int r1_sh = SI(res1.sh), r1_sw = SI(res1.sw), r2_sh = SI(res2.sh), r2_sw = SI(res2.sw);
-  for (int tb = t0; tb < t1; tb += ST_TB) {
-    const int nt = min(ST_TB, t1 - tb);
-    // weight rows of this lane (rows past the image are clamped: their results are never stored)
-    const bf16_t* wrow[ST_TB];
+  const int nchunks = (nk + KC - 1) / KC, KCP = KC >> 1;
+  char* ring = smem + woff;
+  const char* ktl = smem + ST_KTAB_OFF;
+  // weight ring, producer side.  One DMA instruction = 8 rows x 128 bytes (two K-steps, FULL cache lines) of the weight image
+  // -> 1 KiB of LDS; this lane fetches (row r8, K-step parity kpar, K group kg8) into slot `lane`, and that slot is where the
+  // consuming lane (r & 7 == r8, kg == kg8, odd / even K-step) reads it back: conflict-free by construction.
+  const int r8 = lane & 7, kg8 = (lane >> 3) & 3, kpar = lane >> 5;
+  const int wlane = r8 * krow + kpar * 32 + kg8 * 8;  // element offset of this lane's 16 bytes inside (8-row block, K-step pair)
+  // consumer side: lane (r, kg) of an MFMA A fragment
+  const int wrd = (r >> 3) * 1024 + ((r & 7) + 8 * kg) * 16;
+  const int ip = wave % PW, it = wave / PW;
+  const bool wave_on = wave < PW * TW;
+
+  for (int tp = 0; tp < ntp; ++tp) {
+    const int tbase = tp * TW * ST_TB;
+    const int tiles_pass = min(TW * ST_TB, T - tbase);
+    const int nfrag = tiles_pass * KC;  // 1-KiB DMA instructions per chunk
+    auto issue_w = [&](char* __restrict__ dst, const int c) {
+      for (int f = wave; f < nfrag; f += ST_WAVES) {
+        const int blk = f & 1, kp = (f >> 1) % KCP, j = (f >> 1) / KCP;
+        const int row8 = min((tbase + j) * 16 + blk * 8, rows_pad - 8);            // (rows past the image: clamped, never stored)
+        const int kst = min(c * KC + 2 * kp, ((nk + 1) & ~1) - 2);                  // (K-step pairs past the end: the last pair again, never used)
+        const bf16_t* src = wimg + ((int64_t)row8 * krow + k_lo + kst * 32 + wlane);
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(dst + f * 1024), 16, 0, 0);
+      }
+    };
+    const int t0 = tbase + it * ST_TB;
+    const int nt = wave_on ? max(0, min(ST_TB, min(T, tbase + tiles_pass) - t0)) : 0;
     st_f32x4 binit[ST_TB];
 #pragma unroll
     for (int j = 0; j < ST_TB; ++j) {
-      const int row = min((tb + j) * 16 + r, rows_pad - 1);
-      wrow[j] = wimg + ((int64_t)row * krow + k_lo + kg * 8);
-      const int co = (tb + j) * 16 + kg * 4;
+      const int co = (t0 + j) * 16 + kg * 4;
       float bv[4] = {0.f, 0.f, 0.f, 0.f};
       if (bias) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[e] = bias[min(co + e, Co - 1)];
+        for (int e = 0; e < 4; ++e) bv[e] = bias[max(0, min(co + e, Co - 1))];
 #pragma unroll
         for (int e = 0; e < 4; ++e) bv[e] = (co + e < Co) ? bv[e] : 0.f;
       }
       binit[j] = (st_f32x4){bv[0], bv[1], bv[2], bv[3]};
     }
-    for (int pb = g0; pb < g1; pb += ST_PB) {
-      const int np = min(ST_PB, g1 - pb);
+    const int wtile = (t0 - tbase) * KCP * 2048;  // this wave's first tile inside a ring slot
+    for (int pp = 0; pp < npp; ++pp) {
+      const int g0 = (pp * PW + ip) * ST_PB;
+      const int np = (wave_on && nt > 0) ? max(0, min(ST_PB, G - g0)) : 0;
       int pbase[ST_PB], py[ST_PB], px[ST_PB];
       bool pv[ST_PB];
 #pragma unroll
       for (int i = 0; i < ST_PB; ++i) {
-        int p = (pb + i) * 16 + r;
+        int p = (g0 + i) * 16 + r;
         pv[i] = i < np && p < HW;
-        p = min(p, HW - 1);
+        p = max(0, min(p, HW - 1));
         py[i] = sdiv(p, d_w);
         px[i] = p - py[i] * W;
         pbase[i] = (py[i] * Wp + px[i]) * pixstride;
       }
-      // ---- K loop: ring of ST_DEPTH K-steps (weight fragments + table entries) in flight
-      st_bf16x8 wf[ST_DEPTH][ST_TB];
-      int kt[ST_DEPTH];
+      st_f32x4 acc[ST_PB][ST_TB];
 #pragma unroll
-      for (int d = 0; d < ST_DEPTH; ++d) {
-        kt[d] = -1;
+      for (int i = 0; i < ST_PB; ++i)
 #pragma unroll
-        for (int j = 0; j < ST_TB; ++j) wf[d][j] = (st_bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (d < nk) {
-          kt[d] = ktab[d * 4 + kg];
+        for (int j = 0; j < ST_TB; ++j) acc[i][j] = binit[j];
+
+      // ---- K loop: the weights of chunk c + 1 (all tiles of this pass, shared by the eight waves) travel global -> LDS
+      // while chunk c is multiplied out of the other ring slot; pixel fragments come from the staged image.  The ring slots,
+      // the image and the K-step table are handed to the step as __restrict__ pointers (hipcc would otherwise drain the DMA
+      // in flight before every LDS read it cannot prove disjoint -- DESIGN 3.7).
+      __syncthreads();  // every wave is done with both slots (previous pass) before chunk 0 overwrites slot 0
+      issue_w(ring, 0);
+      auto step = [&](const char* __restrict__ cur, char* __restrict__ nxt, const char* __restrict__ imgp, const char* __restrict__ ktp, const int c) {
+        if (c + 1 < nchunks) issue_w(nxt, c + 1);
+        const int nkc = min(KC, nk - c * KC);
+        for (int d = 0; d < nkc; ++d) {
+          const int ks = c * KC + d;
+          const int ko = *(const int*)(ktp + (ks * 4 + kg) * 4);
+          st_bf16x8 wfr[ST_TB];
 #pragma unroll
           for (int j = 0; j < ST_TB; ++j)
-            if (j < nt) wf[d][j] = *(const st_bf16x8*)(wrow[j] + d * 32);
+            if (j < nt) wfr[j] = *(const st_bf16x8*)(cur + wtile + (j * KCP + (d >> 1)) * 2048 + (d & 1) * 512 + wrd);
+          st_bf16x8 a[ST_PB];
+#pragma unroll
+          for (int i = 0; i < ST_PB; ++i)
+            if (i < np) a[i] = *(const st_bf16x8*)(imgp + (ko < 0 ? zoff : pbase[i] + ko));
+#pragma unroll
+          for (int i = 0; i < ST_PB; ++i)
+            if (i < np) {
+#pragma unroll
+              for (int j = 0; j < ST_TB; ++j)
+                if (j < nt) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[j], a[i], acc[i][j], 0, 0, 0);
+            }
         }
+      };
+      for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();  // chunk c has landed (hipcc drains vmcnt here); every wave is done reading the slot chunk c + 1 goes to
+        step(ring + (c & 1) * wslot, ring + ((c & 1) ^ 1) * wslot, img, ktl, c);
       }
-      // epilogue operands of the whole block: requested now, consumed after the K loop (vmcnt is in order: they are back
-      // long before the last weight fragment)
+
+      // epilogue operands of the block (requested together, one round trip)
       uint2 ea[ST_PB][ST_TB], er1[ST_PB][ST_TB], er2[ST_PB][ST_TB];
 #pragma unroll
       for (int i = 0; i < ST_PB; ++i)
 #pragma unroll
         for (int j = 0; j < ST_TB; ++j) {
-          const int co = (tb + j) * 16 + kg * 4;
+          const int co = (t0 + j) * 16 + kg * 4;
           const bool live = pv[i] && j < nt && co + 4 <= Co;
           ea[i][j] = er1[i][j] = er2[i][j] = make_uint2(0, 0);
           if (auxp) ea[i][j] = *(const uint2*)(live ? auxp + (py[i] * aux_sh + px[i] * aux_sw + co) * 2 : (const char*)st_zero16);
           if (r1p) er1[i][j] = *(const uint2*)(live ? r1p + (py[i] * r1_sh + px[i] * r1_sw + co) * 2 : (const char*)st_zero16);
           if (r2p) er2[i][j] = *(const uint2*)(live ? r2p + (py[i] * r2_sh + px[i] * r2_sw + co) * 2 : (const char*)st_zero16);
         }
-      st_f32x4 acc[ST_PB][ST_TB];
-#pragma unroll
-      for (int i = 0; i < ST_PB; ++i)
-#pragma unroll
-        for (int j = 0; j < ST_TB; ++j) acc[i][j] = binit[j];
-      for (int ks0 = 0; ks0 < nk; ks0 += ST_DEPTH) {
-#pragma unroll
-        for (int d = 0; d < ST_DEPTH; ++d) {
-          const int ks = ks0 + d;
-          if (ks < nk) {
-            const int ko = kt[d];
-            st_bf16x8 a[ST_PB];
-#pragma unroll
-            for (int i = 0; i < ST_PB; ++i)
-              if (i < np) a[i] = *(const st_bf16x8*)(img + (ko < 0 ? zoff : pbase[i] + ko));
-#pragma unroll
-            for (int i = 0; i < ST_PB; ++i)
-              if (i < np) {
-#pragma unroll
-                for (int j = 0; j < ST_TB; ++j)
-                  if (j < nt) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[d][j], a[i], acc[i][j], 0, 0, 0);
-              }
-            if (ks + ST_DEPTH < nk) {  // refill this slot
-              kt[d] = ktab[(ks + ST_DEPTH) * 4 + kg];
-#pragma unroll
-              for (int j = 0; j < ST_TB; ++j)
-                if (j < nt) wf[d][j] = *(const st_bf16x8*)(wrow[j] + (ks + ST_DEPTH) * 32);
-            }
-          }
-        }
-      }
-
       ST_STAMP(4);
       // ---- epilogue: lane owns channels co .. co+3 of pixel (py, px) of every block tile
 #pragma unroll
@@ -318,7 +325,7 @@ __device__ __forceinline__ void st_conv(const OpW& ow, const char* __restrict__ 
 #pragma unroll
         for (int j = 0; j < ST_TB; ++j) {
           if (j >= nt) continue;
-          const int co = (tb + j) * 16 + kg * 4;
+          const int co = (t0 + j) * 16 + kg * 4;
           float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
           if (co + 4 <= Co) {
             if (auxp) {
@@ -419,7 +426,7 @@ __device__ __forceinline__ void st_reparam_bwd(const LatBwdP& p, const int n) {
 }
 
 static_assert(sizeof(StOp) <= ST_OPBUF, "an op descriptor must fit its LDS slot");
-static_assert(ST_FIELD_DW(wt1) + ST_WAVES <= 64 && ST_FIELD_DW(wg0) / 64 == 0, "the per-wave plan must sit in the first 64 dwords of the op");
+
 
 __device__ __forceinline__ void st_fetch_op(const char* __restrict__ blob, const int i, char* smem, const int lane) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -537,8 +544,7 @@ static int plan_conv(const cgen_conv_args* a, StConv& o, std::vector<int>* ktab)
   o.ngroups = Hp * o.Wp * o.Gs;
   o.npieces = (o.ngroups + 1 + 63) / 64;  // + the zero slot right behind the image
   o.zoff = o.ngroups * 16;
-  const int lds = ST_IMG_OFF + o.npieces * 1024;
-  if (lds > 156 * 1024) return 0;
+  if (ST_IMG_OFF + o.npieces * 1024 > 150 * 1024) return 0;
   o.G = (o.HW + 15) / 16;
   o.T = (o.Co + 15) / 16;
   if ((int64_t)o.G * o.T * o.nk > stage_budget()) return 0;  // too much work for one CU per image: a chip-wide launch is faster
@@ -547,37 +553,40 @@ static int plan_conv(const cgen_conv_args* a, StConv& o, std::vector<int>* ktab)
   o.next_w = (const char*)a->weight;  // (cgen_stage_plan points it at the next conv of the list)
   o.next_w_bytes = 0;
   o.d_gs = mk_sdiv(o.Gs); o.d_wp = mk_sdiv(o.Wp); o.d_w = mk_sdiv(a->w);
-  // ---- wave plan: PW x TW waves over (pixel groups) x (channel tiles); cost = the busiest SIMD's MFMAs (waves w and w + 4
-  // share a SIMD) + the weight traffic, which grows with PW (every pixel chunk re-reads its tiles' weights from L2)
-  double best = 1e30;
-  int bpw = 1, btw = 1;
-  static const int cand[][2] = {{8, 1}, {4, 2}, {2, 4}, {1, 8}, {4, 1}, {2, 2}, {1, 4}, {2, 1}, {1, 2}, {1, 1}};
-  for (auto& pt : cand) {
-    const int pw = std::min(pt[0], o.G), tw = std::min(pt[1], o.T);
-    int tiles[ST_WAVES] = {0};
-    for (int w = 0; w < pw * tw; ++w) {
-      const int ip = w % pw, it = w / pw;
-      const int gp = o.G / pw + (ip < o.G % pw ? 1 : 0), gt = o.T / tw + (it < o.T % tw ? 1 : 0);
-      // register blocks are ST_PB x ST_TB: a partial block costs its real tiles only (guards are wave-uniform branches)
-      tiles[w] = gp * gt;
-    }
-    int simd = 0;
-    for (int w = 0; w < 4; ++w) simd = std::max(simd, tiles[w] + tiles[w + 4]);
-    const double mfma_cyc = (double)simd * o.nk * 16.0;
-    const double wbytes = (double)pw * o.T * 16 * o.nk * 64;  // every pixel chunk streams all its tiles' weights
-    const double cost = std::max(mfma_cyc, wbytes / 48.0) + 0.25 * std::min(mfma_cyc, wbytes / 48.0);
-    if (cost < best) { best = cost; bpw = pw; btw = tw; }
-  }
-  for (int w = 0; w < ST_WAVES; ++w) { o.wg0[w] = o.wg1[w] = o.wt0[w] = o.wt1[w] = 0; }
+  // ---- pass plan.  PW x TW waves; in one pass a wave owns <= ST_PB pixel groups x ST_TB channel tiles (its accumulators) and
+  // walks the whole K axis; the weights of the pass's TW * ST_TB tiles stream through a two-slot LDS ring shared by all waves, KC
+  // K-steps per slot.  Passes partition the channel tiles (every weight is fetched once per pixel pass).
   {
-    int gstart[ST_WAVES + 1] = {0}, tstart[ST_WAVES + 1] = {0};
-    for (int i = 0; i < bpw; ++i) gstart[i + 1] = gstart[i] + o.G / bpw + (i < o.G % bpw ? 1 : 0);
-    for (int i = 0; i < btw; ++i) tstart[i + 1] = tstart[i] + o.T / btw + (i < o.T % btw ? 1 : 0);
-    for (int w = 0; w < bpw * btw; ++w) {
-      const int ip = w % bpw, it = w / bpw;
-      o.wg0[w] = gstart[ip]; o.wg1[w] = gstart[ip + 1]; o.wt0[w] = tstart[it]; o.wt1[w] = tstart[it + 1];
+    double best = 1e30;
+    int bpw = 1, btw = 1;
+    static const int cand[][2] = {{8, 1}, {4, 2}, {2, 2}, {4, 1}, {2, 1}, {1, 2}, {1, 1}};
+    for (auto& pt : cand) {
+      const int pw = pt[0], tw = pt[1];
+      if (pw > 1 && (pw / 2) * ST_PB >= o.G && !(pw == 2 && tw == 2)) { /* more pixel columns than the image needs */ }
+      const int npp = (o.G + pw * ST_PB - 1) / (pw * ST_PB), ntp = (o.T + tw * ST_TB - 1) / (tw * ST_TB);
+      const int gw = std::min(ST_PB, (o.G + pw * npp - 1) / (pw * npp)), tw_t = std::min(ST_TB, (o.T + tw * ntp - 1) / (tw * ntp));
+      // per pass: nk K-steps of (gw x tw_t MFMAs + gw + tw_t LDS reads) on the busiest wave, two waves per SIMD when all 8 run
+      const double per = (double)o.nk * (gw * tw_t * 16.0 + (gw + tw_t) * 8.0) * (pw * tw > 4 ? 2.0 : 1.0) + 1500.0;
+      const double cost = (double)npp * ntp * per;
+      if (cost < best) { best = cost; bpw = pw; btw = tw; }
     }
+    o.PW = bpw; o.TW = btw;
+    o.npp = (o.G + bpw * ST_PB - 1) / (bpw * ST_PB);
+    o.ntp = (o.T + btw * ST_TB - 1) / (btw * ST_TB);
   }
+  o.ktab_bytes = o.nk * 16;
+  if (o.ktab_bytes > ST_IMG_OFF - ST_KTAB_OFF) return 0;
+  const int img_bytes = o.npieces * 1024;
+  o.woff = ST_IMG_OFF + img_bytes;
+  {
+    const int tiles_pass = std::min(o.TW * ST_TB, o.T);
+    int kc = 16;
+    while (kc > 2 && (o.woff + 2 * tiles_pass * kc * 1024 > 156 * 1024 || kc >= 2 * (((o.nk + 1) & ~1)))) kc -= 2;
+    if (o.woff + 2 * tiles_pass * kc * 1024 > 156 * 1024) return 0;
+    o.KC = kc;
+    o.wslot = tiles_pass * kc * 1024;
+  }
+  const int lds_total = o.woff + 2 * o.wslot;
   if (ktab) {
     ktab->clear();
     for (int ks = 0; ks < o.nk; ++ks)
@@ -589,7 +598,7 @@ static int plan_conv(const cgen_conv_args* a, StConv& o, std::vector<int>* ktab)
         ktab->push_back((dy * o.Wp + dx) * o.pixstride + cc * 2);
       }
   }
-  return lds;
+  return lds_total;
 }
 
 static bool flat_ok(const cgen_view& v, int n, int h, int w) {
