@@ -151,6 +151,24 @@ def pmc_traffic(kernel_class, dtype):
     return val, dict(file=os.path.relpath(path, ROOT), git_sha=sha, method="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 (gfx950)")
 
 
+def pmc_mfma_busy(kernel_class):
+    """SQ counters of the dominant kernel class from the committed PMC passes (tools/pmc_insts.sh + tools/pmc_classes.py):
+    MFMA-pipe busy share of a wave's lifetime (SQ_VALU_MFMA_BUSY_CYCLES / 4 SQ_WAVE_CYCLES) and VALU / SALU / LDS instructions
+    per MFMA -- what north_star calls the MFMA-utilisation counters."""
+    import glob
+
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_busy_by_class.json")))
+    if not cands:
+        return None
+    try:
+        blob = json.load(open(cands[-1]))
+        d = dict(blob[kernel_class])
+        d["source"] = {"file": os.path.relpath(cands[-1], ROOT), "git_sha": (blob.get("_source") or {}).get("code_git_sha")}
+        return d
+    except Exception:
+        return None
+
+
 def profile_step(ts, x, pa, dtype, workload_key=None):
     """One eager step with HIP events around every conv launch (on the launch stream) -> per-class totals."""
     eng = ts.eng
@@ -190,9 +208,10 @@ def profile_step(ts, x, pa, dtype, workload_key=None):
                 f.write("%-10s ks%d ci%-4d co%-4d res%-4d n%-3d ms %8.3f  TF/s %8.2f\n" % (k[0], k[1], k[2], k[3], k[4], v[2], v[1], v[0] / (v[1] * 1e-3) / 1e12))
     top = top[:8]
     traffic, traffic_src = pmc_traffic(dom, dtype) if workload_key == ("ukbb192", 32) else (None, None)
+    busy = pmc_mfma_busy(dom) if workload_key == ("ukbb192", 32) and dtype == "bf16" else None
     return dict(
         bound="mfma", kernel=dom, achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_PEAK_TF[dtype], unit="TFLOP/s",
-        frac=flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dtype], traffic=traffic, traffic_source=traffic_src, launches=n, avg_launch_us=1e3 * ms / n,
+        frac=flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dtype], traffic=traffic, traffic_source=traffic_src, mfma_counters=busy, launches=n, avg_launch_us=1e3 * ms / n,
         algorithmic_flops_per_launch=flops / n, launches_per_step=launches_per_step,
         classes={k: dict(tflops=v[0] / (v[1] * 1e-3) / 1e12, ms=v[1], launches=v[2]) for k, v in classes.items()},
         top_shapes=[dict(kind=k[0], ks=k[1], ci=k[2], co=k[3], res=k[4], ms=v[1], tflops=v[0] / (v[1] * 1e-3) / 1e12, n=v[2])

@@ -12,10 +12,12 @@
 // A conv inside the list (vae.py:53-71 Block convs, :165-167 z_proj / z_feat_proj, their data gradients):
 //   * the image's whole input -- every segment of the virtual torch.cat, zero halo -- is staged ONCE by global->LDS DMA
 //     (linear layout, 16-byte channel groups, odd group count per pixel), activation applied in place;
-//   * the 8 waves split the (16-pixel group) x (16-channel tile) output grid by a host-side plan; a wave holds <= 4 x 2 MFMA
-//     accumulators and walks the whole K axis: pixel fragments from LDS (one ds_read_b128 each, tap shifts come from a
-//     host-built K-step table), weight fragments STRAIGHT from the weight image in global memory (L2-resident; a 4-deep
-//     register ring keeps the loads ahead of the MFMAs) -- no weight slab in LDS, no cross-wave reduction, deterministic;
+//   * the weights of a pass's <= 4 channel tiles stream through a two-slot LDS ring shared by the eight waves: one DMA
+//     instruction = 8 rows x 128 bytes of the weight image (full cache lines) landing in MFMA-fragment order (conflict-free
+//     ds_read_b128); chunk c + 1 is in flight under chunk c's MFMAs (the step lambda takes the slots as __restrict__ pointers,
+//     so hipcc keeps vmcnt out of the loop); a wave holds <= 4 x 2 accumulator tiles and walks the whole K axis, pixel
+//     fragments from the staged image through a host-built K-step table (tap shifts) that sits in LDS too -- no cross-wave
+//     reduction, deterministic;
 //   * bias is the accumulators' initial value; the epilogue ((.) * act'(aux) + res1 + res2, bf16 rounding, zero fill of the
 //     padding channels) goes straight from the accumulators to global memory, 8 bytes per lane.
 // The element-wise ops run the SAME bodies as their stand-alone kernels (elementwise_bodies.inc, latent_bodies.inc) over
