@@ -28,7 +28,7 @@ CF_GFLOP = {"morphomnist": 0.185, "cmnist": 0.192, "ukbb192": 47.67, "mimic192":
 # prior-only replay; the reconstruction is read off the abduction pass (0.086+0.049 / 0.091+0.050 /
 # 23.06+12.31 / 9.12+5.22 / 12.45+7.13 GFLOP)
 CF_GFLOP_REUSE = {"morphomnist": 0.135, "cmnist": 0.141, "ukbb192": 35.37, "mimic192": 14.34, "mimic224": 19.58}
-MFMA_PEAK_TF = {"f32": 157.3, "bf16": 2500.0}  # dense, MI355X_MICROARCH.md
+MFMA_PEAK_TF = {"f32": 157.3, "f16": 2500.0}  # dense, MI355X_MICROARCH.md
 
 
 def synth_batch(name, hp, B, device, seed):
@@ -200,7 +200,7 @@ def profile_step(ts, x, pa, dtype, workload_key=None):
     flops, ms, n = merged[dom]
     top = sorted(shapes.items(), key=lambda kv: -kv[1][1])
     dump = os.environ.get("CGEN_SHAPE_DUMP")
-    if dump and dtype != "bf16":
+    if dump and dtype != "f16":
         dump = dump + "." + dtype
     if dump:
         with open(dump, "w") as f:
@@ -208,7 +208,7 @@ def profile_step(ts, x, pa, dtype, workload_key=None):
                 f.write("%-10s ks%d ci%-4d co%-4d res%-4d n%-3d ms %8.3f  TF/s %8.2f\n" % (k[0], k[1], k[2], k[3], k[4], v[2], v[1], v[0] / (v[1] * 1e-3) / 1e12))
     top = top[:8]
     traffic, traffic_src = pmc_traffic(dom, dtype) if workload_key == ("ukbb192", 32) else (None, None)
-    busy = pmc_mfma_busy(dom) if workload_key == ("ukbb192", 32) and dtype == "bf16" else None
+    busy = pmc_mfma_busy(dom) if workload_key == ("ukbb192", 32) and dtype == "f16" else None
     return dict(
         bound="mfma", kernel=dom, achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_PEAK_TF[dtype], unit="TFLOP/s",
         frac=flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dtype], traffic=traffic, traffic_source=traffic_src, mfma_counters=busy, launches=n, avg_launch_us=1e3 * ms / n,
@@ -285,7 +285,7 @@ def f32_leg(a, hp, B, dev, x, pa, m_bf16):
     # same weights, same noise: the bf16-trained parameters go into the f32 model; both draw from one Philox state
     m32.load_state_dict(m_bf16.state_dict())
     vals = {}
-    for name, mod in (("bf16", m_bf16), ("f32", m32)):
+    for name, mod in (("f16", m_bf16), ("f32", m32)):
         was = mod.training
         mod.eval()
         eng = mod.engine()
@@ -295,7 +295,7 @@ def f32_leg(a, hp, B, dev, x, pa, m_bf16):
             o = mod(x, pa, beta=hp.beta)
         vals[name] = [float(o[k]) for k in ("elbo", "nll", "kl")]
         mod.train(was)
-    rel = [abs(b - f) / max(abs(f), 1e-12) for b, f in zip(vals["bf16"], vals["f32"])]
+    rel = [abs(b - f) / max(abs(f), 1e-12) for b, f in zip(vals["f16"], vals["f32"])]
     gf = TRAIN_GFLOP_PER_IMG[a.config]
     img_s = B * steps / dt
     cf32 = cf_leg(m32, x, pa, a.config, n_cf=4) if not a.no_cf else {}
@@ -303,11 +303,11 @@ def f32_leg(a, hp, B, dev, x, pa, m_bf16):
     del ts32, m32
     torch.cuda.empty_cache()
     return {"images_s": img_s, "counterfactuals_per_s": cf32.get("counterfactuals_per_s"), "cf_tflops": cf32.get("cf_tflops"),
-            "bf16_vs_f32_cf_maxabs": cfdev, "ms_per_step": 1e3 * dt / steps, "steps": steps, "model_tflops": img_s * gf / 1e3,
+            "f16_vs_f32_cf_maxabs": cfdev, "ms_per_step": 1e3 * dt / steps, "steps": steps, "model_tflops": img_s * gf / 1e3,
             "model_mfma_frac": img_s * gf / 1e3 / MFMA_PEAK_TF["f32"],
             "roofline": {k: roof[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us", "classes")},
-            "elbo_nll_kl_f32": vals["f32"], "elbo_nll_kl_bf16": vals["bf16"], "bf16_vs_f32_elbo_rel": rel[0],
-            "bf16_vs_f32_nll_rel": rel[1], "bf16_vs_f32_kl_rel": rel[2]}
+            "elbo_nll_kl_f32": vals["f32"], "elbo_nll_kl_f16": vals["f16"], "f16_vs_f32_elbo_rel": rel[0],
+            "f16_vs_f32_nll_rel": rel[1], "f16_vs_f32_kl_rel": rel[2]}
 
 
 def side_config(name, dmol, B, dev, steps=10, prep=12, cf=True, parity=True):
@@ -316,7 +316,7 @@ def side_config(name, dmol, B, dev, steps=10, prep=12, cf=True, parity=True):
     weights and noise."""
     from causal_gen_amd.train import TrainStep
 
-    m, hp = build_model(name, "bf16", dmol)
+    m, hp = build_model(name, "f16", dmol)
     m = m.to(dev)
     ts = TrainStep(m, hp, ema=cf, use_graph=True)
     x, pa = synth_batch(name, hp, B, dev, seed=100)
@@ -333,7 +333,7 @@ def side_config(name, dmol, B, dev, steps=10, prep=12, cf=True, parity=True):
     gf = TRAIN_GFLOP_PER_IMG[name]
     r = {"workload": f"{name} HVAE train step ({hp.input_res}x{hp.input_res}x{hp.input_channels}, {'DMoL' if dmol else 'DGauss'} likelihood)",
          "per_gpu_batch": B, "images_s": img_s, "ms_per_step": 1e3 * dt / steps, "steps": steps, "model_tflops": img_s * gf / 1e3,
-         "model_mfma_frac": img_s * gf / 1e3 / MFMA_PEAK_TF["bf16"], "elbo_nats_per_dim": float(out[0]),
+         "model_mfma_frac": img_s * gf / 1e3 / MFMA_PEAK_TF["f16"], "elbo_nats_per_dim": float(out[0]),
          "launches_per_step_eager": None}
     if cf:
         r.update({k: v for k, v in cf_leg(ts.ema_model, x, pa, name, n_cf=6).items() if k != "cf_gflop_per_counterfactual"})
@@ -342,7 +342,7 @@ def side_config(name, dmol, B, dev, steps=10, prep=12, cf=True, parity=True):
         m32 = m32.to(dev)
         m32.load_state_dict(m.state_dict())
         vals = {}
-        for tag, mod in (("bf16", m), ("f32", m32)):
+        for tag, mod in (("f16", m), ("f32", m32)):
             was = mod.training
             mod.eval()
             eng = mod.engine()
@@ -353,9 +353,9 @@ def side_config(name, dmol, B, dev, steps=10, prep=12, cf=True, parity=True):
             vals[tag] = float(o["elbo"])
             mod.train(was)
         r["elbo_f32_same_weights"] = vals["f32"]
-        r["bf16_vs_f32_elbo_rel"] = abs(vals["bf16"] - vals["f32"]) / max(abs(vals["f32"]), 1e-12)
+        r["f16_vs_f32_elbo_rel"] = abs(vals["f16"] - vals["f32"]) / max(abs(vals["f32"]), 1e-12)
         if cf:
-            r["bf16_vs_f32_cf_maxabs"] = cf_deviation(m, m32, x, pa)
+            r["f16_vs_f32_cf_maxabs"] = cf_deviation(m, m32, x, pa)
         del m32
     del ts, m
     torch.cuda.empty_cache()
@@ -368,7 +368,7 @@ def bandwidth_kernels(dev):
     from causal_gen_amd import _lib
     from causal_gen_amd.engine import Engine
 
-    eng = Engine(dev, "bf16")
+    eng = Engine(dev, "f16")
     eng.begin()
     lib = eng.lib
     out = {}
@@ -428,7 +428,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="ukbb192", choices=sorted(TRAIN_GFLOP_PER_IMG))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 32 at 192^2/224^2, 256 at 32^2)")
-    ap.add_argument("--dtype", default="bf16", choices=["f32", "bf16"])
+    ap.add_argument("--dtype", default="f16", choices=["f32", "f16"])
     ap.add_argument("--dmol", action="store_true", help="DMoL likelihood head (cmnist)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
@@ -528,9 +528,9 @@ def main():
         res["roofline"] = roof
         if not a.no_cf:
             res.update(cf_leg(ts.ema_model, x, pa, a.config))
-        if world == 1 and a.dtype == "bf16" and not a.no_f32:
+        if world == 1 and a.dtype == "f16" and not a.no_f32:
             res["f32"] = f32_leg(a, hp, B, dev, x, pa, m)
-        if world == 1 and not a.no_extra and a.config == "ukbb192" and a.batch is None and a.dtype == "bf16":
+        if world == 1 and not a.no_extra and a.config == "ukbb192" and a.batch is None and a.dtype == "f16":
             # the other BASELINE.json configs and a per-GPU batch sweep of the headline model, same process, same code
             del ts
             torch.cuda.empty_cache()

@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcgen_hip.so")
 
-F32, BF16 = 0, 1
+F32, F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 UNARY_LEAKY_RELU, UNARY_CLAMP_MIN, UNARY_ADD = 3, 4, 5
 MAX_SEG = 4
@@ -22,7 +22,8 @@ NULL_VIEW = View(None, 0, 0, 0, 0, 0)
 class ConvArgs(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("ks", C.c_int32),
                 ("nseg", C.c_int32), ("act", C.c_int32), ("dact", C.c_int32), ("seg", View * MAX_SEG),
-                ("weight", C.c_void_p), ("bias", C.c_void_p), ("out", View), ("aux", View), ("res1", View), ("res2", View)]
+                ("weight", C.c_void_p), ("bias", C.c_void_p), ("out", View), ("aux", View), ("res1", View), ("res2", View),
+                ("out_rem", C.c_int64), ("res1_rem", C.c_int64)]
 
 
 class BlockArgs(C.Structure):
@@ -60,7 +61,7 @@ class WprepDesc(C.Structure):
 class WredDesc(C.Structure):
     _fields_ = [("partial_w", C.c_void_p), ("partial_b", C.c_void_p), ("grad_w", C.c_void_p), ("grad_b", C.c_void_p),
                 ("co", C.c_int32), ("ci_total", C.c_int32), ("ks", C.c_int32), ("nsplit", C.c_int32),
-                ("accumulate", C.c_int32), ("reserved", C.c_int32), ("numel", C.c_int64)]
+                ("accumulate", C.c_int32), ("unscale", C.c_float), ("numel", C.c_int64)]
 
 
 class AdamwArgs(C.Structure):
@@ -115,7 +116,7 @@ PROTOTYPES = {
     "cgen_adaptive_avgpool_bwd": [i32, i32, i32, i32, i32, i32, View, View, i32, vp],
     "cgen_upsample_fwd": [i32, i32, i32, i32, i32, i32, View, vp, View, vp],
     "cgen_upsample_bwd": [i32, i32, i32, i32, i32, i32, View, View, i32, vp],
-    "cgen_batch_reduce": [i32, i32, i32, i32, View, vp, i32, vp],
+    "cgen_batch_reduce": [i32, i32, i32, i32, View, vp, i32, f32, vp],
     "cgen_batch_broadcast": [i32, i32, i32, i32, vp, View, vp],
     "cgen_axpby": [i32, i32, i32, i32, View, View, f32, f32, i32, i32, vp],
     "cgen_nchw_to_nhwc": [i32, i32, i32, i32, i32, i32, vp, View, f32, f32, vp],

@@ -33,21 +33,63 @@ int check_launch(const char* what);
   } while (0)
 
 // ----------------------------------------------------------------------------- dtypes
-typedef uint16_t bf16_t;  // raw bits
-
-__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// The 16-bit storage format of the throughput path is IEEE binary16 (11-bit significand): at identical weights and noise its
+// ELBO / counterfactual pixels sit 8x closer to the f32 path than bf16's (8-bit significand) did -- tools/bf16_trunk_sim.py,
+// DESIGN section 1a -- at the same MFMA rate (v_mfma_f32_16x16x32_f16).  Activations are O(1..1e3), far from 65504; GRADIENTS
+// are carried times a power-of-two loss scale (engine.py `loss_scale`) so that they stay in binary16's normal range.
+// -DCGEN_H16_BF16 rebuilds the library with bfloat16 storage for an A/B measurement (one format per build, never both).
+typedef uint16_t h16_t;  // raw bits
+#ifdef CGEN_H16_BF16
+typedef __bf16 h16n_t;  // the compiler's native type of the format
+#else
+typedef _Float16 h16n_t;
+#endif
+typedef h16n_t h16x2_t __attribute__((ext_vector_type(2)));
+typedef h16n_t h16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
-  union { __bf16 b; bf16_t u; } c;
-  c.b = (__bf16)f;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float h2f(h16_t v) {
+  union { h16_t u; h16n_t h; } c;
+  c.u = v;
+  return (float)c.h;
+}
+// low / high half of a packed pair -> f32 (fp16: v_cvt_f32_f16 with a word select; bf16: a shift / a mask)
+__device__ __forceinline__ float h_lo(uint32_t w) {
+#ifdef CGEN_H16_BF16
+  return __uint_as_float(w << 16);
+#else
+  union { uint32_t u; h16x2_t h; } c;
+  c.u = w;
+  return (float)c.h[0];
+#endif
+}
+__device__ __forceinline__ float h_hi(uint32_t w) {
+#ifdef CGEN_H16_BF16
+  return __uint_as_float(w & 0xffff0000u);
+#else
+  union { uint32_t u; h16x2_t h; } c;
+  c.u = w;
+  return (float)c.h[1];
+#endif
+}
+__device__ __forceinline__ h16_t f2h(float f) {  // round-to-nearest-even
+  union { h16n_t h; h16_t u; } c;
+  c.h = (h16n_t)f;
   return c.u;
 }
-__device__ __forceinline__ uint32_t f2bf_pk(float lo, float hi) {  // two floats -> packed bf16 pair, one instruction
-  union { bf16x2_t b; uint32_t u; } c;
+__device__ __forceinline__ uint32_t f2h_pk(float lo, float hi) {  // two floats -> packed pair: one v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32
+  union { h16x2_t h; uint32_t u; } c;
   const f32x2_t v = {lo, hi};
-  c.b = __builtin_convertvector(v, bf16x2_t);
+  c.h = __builtin_convertvector(v, h16x2_t);
   return c.u;
+}
+__device__ __forceinline__ f32x4_t mfma_h16(h16x8 a, h16x8 b, f32x4_t c, int, int, int) {
+#ifdef CGEN_H16_BF16
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
 }
 
 template <typename T> struct Elem;
@@ -56,10 +98,10 @@ template <> struct Elem<float> {
   static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
   static __device__ __forceinline__ float to(float v) { return v; }
 };
-template <> struct Elem<bf16_t> {
-  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
-  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
-  static __device__ __forceinline__ bf16_t to(float v) { return f2bf(v); }
+template <> struct Elem<h16_t> {
+  static __device__ __forceinline__ float ld(const h16_t* p) { return h2f(*p); }
+  static __device__ __forceinline__ void st(h16_t* p, float v) { *p = f2h(v); }
+  static __device__ __forceinline__ h16_t to(float v) { return f2h(v); }
 };
 
 // ----------------------------------------------------------------------------- views
@@ -123,25 +165,25 @@ __device__ __forceinline__ void gelu_terms_fast(float x, float& cdf, float& pdf)
   pdf = CGEN_INV_SQRT_2PI * e;
 }
 struct F8 { float v[8]; };
-__device__ __noinline__ uint4 gelu8_fwd_bf16(uint4 x) {
+__device__ __noinline__ uint4 gelu8_fwd_h16(uint4 x) {
   uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float a = __uint_as_float(w[i] << 16), b = __uint_as_float(w[i] & 0xffff0000u);
+    const float a = h_lo(w[i]), b = h_hi(w[i]);
     float ca, cb, pa, pb;
     gelu_terms_fast(a, ca, pa);
     gelu_terms_fast(b, cb, pb);
-    w[i] = f2bf_pk(a * ca, b * cb);
+    w[i] = f2h_pk(a * ca, b * cb);
   }
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 // gelu'(x) for the eight bf16 pre-activations of a group
-__device__ __noinline__ F8 gelu8_bwd_bf16(uint4 x) {
+__device__ __noinline__ F8 gelu8_bwd_h16(uint4 x) {
   const uint32_t w[4] = {x.x, x.y, x.z, x.w};
   F8 r;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float a = __uint_as_float(w[i] << 16), b = __uint_as_float(w[i] & 0xffff0000u);
+    const float a = h_lo(w[i]), b = h_hi(w[i]);
     float ca, cb, pa, pb;
     gelu_terms_fast(a, ca, pa);
     gelu_terms_fast(b, cb, pb);

@@ -35,7 +35,6 @@
 namespace cgen {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // Division by a run-time constant without v_rcp/loops: q = umulhi(n, mul) >> shift, exact for 0 <= n < 2^31
@@ -70,6 +69,7 @@ struct ConvP {
   const void* w;
   const float* bias;
   View out, aux, res1, res2;
+  long long out_rem, r1_rem;  // byte offsets of the remainder planes of out / res1 (f16 residual trunk: value = hi + rem); 0 = none
   int epi_vec, force_generic, dma_ok, epi_vec16;
   int tap0, tap1;  // taps that can touch the image (a 3x3 conv on a 1x1 image only ever sees its centre tap)
 };
@@ -80,23 +80,27 @@ template <> __device__ __forceinline__ void ld4<float>(const float* p, float (&v
   const float4 t = *(const float4*)p;
   v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
 }
-template <> __device__ __forceinline__ void ld4<bf16_t>(const bf16_t* p, float (&v)[4]) {
+template <> __device__ __forceinline__ void ld4<h16_t>(const h16_t* p, float (&v)[4]) {
   const uint2 t = *(const uint2*)p;
-  v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-  v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+  v[0] = h_lo(t.x); v[1] = h_hi(t.x);
+  v[2] = h_lo(t.y); v[3] = h_hi(t.y);
 }
 template <typename T> __device__ __forceinline__ void st4(T* p, const float (&v)[4]);
 template <> __device__ __forceinline__ void st4<float>(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
-template <> __device__ __forceinline__ void st4<bf16_t>(bf16_t* p, const float (&v)[4]) {
+template <> __device__ __forceinline__ void st4<h16_t>(h16_t* p, const float (&v)[4]) {
   uint2 t;
-  t.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  t.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  t.x = f2h_pk(v[0], v[1]);
+  t.y = f2h_pk(v[2], v[3]);
   *(uint2*)p = t;
 }
 template <typename T, int N> union Pack {
   T e[N];
   uint4 v4;
 };
+
+// Remainder plane of the f16 residual trunk: out = rn16(v) goes to the tensor, rn16(v - out) to the plane `rem` bytes further
+// (include/cgen_hip.h, cgen_conv_args): hi + rem carries ~22 significant bits through the ~100 residual updates of a pass.
+__device__ __forceinline__ float h16_rem(float v) { return v - h2f(f2h(v)); }
 
 // (bias + acc) * act'(aux) + res1 + res2 for 4 consecutive output channels of one pixel
 template <typename T>
@@ -114,6 +118,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4& a, in
   const T* aptr = p.aux.p ? vptr<T>(p.aux, pn, py, px) : nullptr;
   const T* r1 = p.res1.p ? vptr<T>(p.res1, pn, py, px) : nullptr;
   const T* r2 = p.res2.p ? vptr<T>(p.res2, pn, py, px) : nullptr;
+  const T* r1l = (r1 && p.r1_rem) ? (const T*)((const char*)r1 + p.r1_rem) : nullptr;
+  T* orem = p.out_rem ? (T*)((char*)optr + p.out_rem) : nullptr;
   float v[4] = {a[0], a[1], a[2], a[3]};
   if ((co + 4 <= p.Co) && p.epi_vec) {
     if (p.bias) {
@@ -136,6 +142,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4& a, in
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] += t4[e];
     }
+    if constexpr (sizeof(T) == 2) {
+      if (r1l) {
+        ld4<T>(r1l + co, t4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += t4[e];
+      }
+      if (orem) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t4[e] = h16_rem(v[e]);
+        st4<T>(orem + co, t4);
+      }
+    }
     st4<T>(optr + co, v);
   } else {
 #pragma unroll
@@ -145,6 +163,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4& a, in
         if (aptr) u *= act_bwd(p.dact, Elem<T>::ld(aptr + co + e));
         if (r1) u += Elem<T>::ld(r1 + co + e);
         if (r2) u += Elem<T>::ld(r2 + co + e);
+        if constexpr (sizeof(T) == 2) {
+          if (r1l) u += Elem<T>::ld(r1l + co + e);
+          if (orem) Elem<T>::st(orem + co + e, h16_rem(u));
+        }
         Elem<T>::st(optr + co + e, u);
       } else if (co + e < p.out.cpad) {
         optr[co + e] = (T)0;
@@ -158,7 +180,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4& a, in
 // "load aux/residual -> store" per chunk therefore serialises a full load + store round trip per chunk.  The kernels
 // issue ALL operand loads of a tile first (Epi8, before or during the MFMA loop) and finish with pure math + stores.
 struct Epi8 {
-  uint4 a, r1, r2;
+  uint4 a, r1, r2, r1l;
 };
 struct Bias8 {
   float4 b0, b1;
@@ -168,47 +190,59 @@ __device__ __forceinline__ void bias8_load(const ConvP& p, int co, Bias8& l) {
   if (p.bias) { l.b0 = *(const float4*)(p.bias + co); l.b1 = *(const float4*)(p.bias + co + 4); }
 }
 __device__ __forceinline__ void epi8_load(const ConvP& p, int pn, int py, int px, int co, Epi8& l) {
-  typedef bf16_t T;
-  l.a = l.r1 = l.r2 = make_uint4(0, 0, 0, 0);
+  typedef h16_t T;
+  l.a = l.r1 = l.r2 = l.r1l = make_uint4(0, 0, 0, 0);
   if (p.aux.p) l.a = *(const uint4*)(vptr<T>(p.aux, pn, py, px) + co);
   if (p.res1.p) l.r1 = *(const uint4*)(vptr<T>(p.res1, pn, py, px) + co);
+  if (p.r1_rem) l.r1l = *(const uint4*)((const char*)(vptr<T>(p.res1, pn, py, px) + co) + p.r1_rem);
   if (p.res2.p) l.r2 = *(const uint4*)(vptr<T>(p.res2, pn, py, px) + co);
 }
 // v = (bias + v) * act'(aux) + res1 + res2, rounded once, stored as one 16-byte chunk (fast path only: whole aligned chunk)
 __device__ __forceinline__ void epi8_finish(const ConvP& p, float (&v)[8], const Epi8& l, const Bias8& bb, int pn, int py, int px, int co) {
-  typedef bf16_t T;
+  typedef h16_t T;
   v[0] += bb.b0.x; v[1] += bb.b0.y; v[2] += bb.b0.z; v[3] += bb.b0.w; v[4] += bb.b1.x; v[5] += bb.b1.y; v[6] += bb.b1.z; v[7] += bb.b1.w;
   Pack<T, 8> t;
   if (p.aux.p) {
     t.v4 = l.a;
     if (p.dact == CGEN_ACT_GELU) {
-      const F8 gp = gelu8_bwd_bf16(l.a);
+      const F8 gp = gelu8_bwd_h16(l.a);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] *= gp.v[e];
     } else if (p.dact == CGEN_ACT_RELU) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = bf2f(t.e[e]) > 0.f ? v[e] : 0.f;
+      for (int e = 0; e < 8; ++e) v[e] = h2f(t.e[e]) > 0.f ? v[e] : 0.f;
     }
   }
   if (p.res1.p) {
     t.v4 = l.r1;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += bf2f(t.e[e]);
+    for (int e = 0; e < 8; ++e) v[e] += h2f(t.e[e]);
   }
   if (p.res2.p) {
     t.v4 = l.r2;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += bf2f(t.e[e]);
+    for (int e = 0; e < 8; ++e) v[e] += h2f(t.e[e]);
+  }
+  if (p.r1_rem) {
+    t.v4 = l.r1l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += h2f(t.e[e]);
+  }
+  T* optr = vptr<T>(p.out, pn, py, px) + co;
+  if (p.out_rem) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t.e[e] = f2h(h16_rem(v[e]));
+    *(uint4*)((char*)optr + p.out_rem) = t.v4;
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) t.e[e] = f2bf(v[e]);
-  *(uint4*)(vptr<T>(p.out, pn, py, px) + co) = t.v4;
+  for (int e = 0; e < 8; ++e) t.e[e] = f2h(v[e]);
+  *(uint4*)optr = t.v4;
 }
 
 // 8 consecutive output channels of one pixel (16-byte bf16 I/O): same math as conv_epilogue, used by the LDS-staged
 // epilogues where consecutive lanes own consecutive 16-byte chunks of a pixel row (fully coalesced stores / loads)
-__device__ __forceinline__ void conv_epilogue8_bf16(const ConvP& p, float (&v)[8], int pn, int py, int px, int co) {
-  typedef bf16_t T;
+__device__ __forceinline__ void conv_epilogue8_h16(const ConvP& p, float (&v)[8], int pn, int py, int px, int co) {
+  typedef h16_t T;
   if (co >= p.Co) {
     if (co < p.out.cpad) {
       T* z = vptr<T>(p.out, pn, py, px);
@@ -222,6 +256,8 @@ __device__ __forceinline__ void conv_epilogue8_bf16(const ConvP& p, float (&v)[8
   const T* aptr = p.aux.p ? vptr<T>(p.aux, pn, py, px) + co : nullptr;
   const T* r1 = p.res1.p ? vptr<T>(p.res1, pn, py, px) + co : nullptr;
   const T* r2 = p.res2.p ? vptr<T>(p.res2, pn, py, px) + co : nullptr;
+  const T* r1l = (r1 && p.r1_rem) ? (const T*)((const char*)r1 + p.r1_rem) : nullptr;
+  T* orem = p.out_rem ? (T*)((char*)optr + p.out_rem) : nullptr;
   if (co + 8 <= p.Co && p.epi_vec16) {
     if (p.bias) {
       const float4 b0 = *(const float4*)(p.bias + co), b1 = *(const float4*)(p.bias + co + 4);
@@ -231,36 +267,48 @@ __device__ __forceinline__ void conv_epilogue8_bf16(const ConvP& p, float (&v)[8
     if (aptr) {
       t.v4 = *(const uint4*)aptr;
       if (p.dact == CGEN_ACT_GELU) {
-        const F8 gp = gelu8_bwd_bf16(t.v4);
+        const F8 gp = gelu8_bwd_h16(t.v4);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= gp.v[e];
       } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= act_bwd(p.dact, bf2f(t.e[e]));
+        for (int e = 0; e < 8; ++e) v[e] *= act_bwd(p.dact, h2f(t.e[e]));
       }
     }
     if (r1) {
       t.v4 = *(const uint4*)r1;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bf2f(t.e[e]);
+      for (int e = 0; e < 8; ++e) v[e] += h2f(t.e[e]);
     }
     if (r2) {
       t.v4 = *(const uint4*)r2;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bf2f(t.e[e]);
+      for (int e = 0; e < 8; ++e) v[e] += h2f(t.e[e]);
+    }
+    if (r1l) {
+      t.v4 = *(const uint4*)r1l;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += h2f(t.e[e]);
+    }
+    if (orem) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t.e[e] = f2h(h16_rem(v[e]));
+      *(uint4*)orem = t.v4;
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) t.e[e] = f2bf(v[e]);
+    for (int e = 0; e < 8; ++e) t.e[e] = f2h(v[e]);
     *(uint4*)optr = t.v4;
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       if (co + e < p.Co) {
         float u = v[e] + (p.bias ? p.bias[co + e] : 0.f);
-        if (aptr) u *= act_bwd(p.dact, bf2f(aptr[e]));
-        if (r1) u += bf2f(r1[e]);
-        if (r2) u += bf2f(r2[e]);
-        optr[e] = f2bf(u);
+        if (aptr) u *= act_bwd(p.dact, h2f(aptr[e]));
+        if (r1) u += h2f(r1[e]);
+        if (r2) u += h2f(r2[e]);
+        if (r1l) u += h2f(r1l[e]);
+        if (orem) orem[e] = f2h(h16_rem(u));
+        optr[e] = f2h(u);
       } else if (co + e < p.out.cpad) {
         optr[e] = 0;
       }
@@ -270,7 +318,7 @@ __device__ __forceinline__ void conv_epilogue8_bf16(const ConvP& p, float (&v)[8
 
 template <typename T> struct Frag;
 template <> struct Frag<float> { typedef f32x4 type; };
-template <> struct Frag<bf16_t> { typedef bf16x8 type; };
+template <> struct Frag<h16_t> { typedef h16x8 type; };
 
 template <typename T, int NTC>
 __global__ __launch_bounds__(256) void conv_kernel(ConvP p) {
@@ -395,15 +443,15 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvP p) {
             for (int f = 0; f < 2; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][j], b[f][j], acc[t][f], 0, 0, 0);
       }
     } else {
-      bf16x8 b[2], a[NTC];
+      h16x8 b[2], a[NTC];
 #pragma unroll
-      for (int f = 0; f < 2; ++f) b[f] = *(const bf16x8*)(Xs + (wave * 32 + f * 16 + fr) * CONV_LDK + fg * 8);
+      for (int f = 0; f < 2; ++f) b[f] = *(const h16x8*)(Xs + (wave * 32 + f * 16 + fr) * CONV_LDK + fg * 8);
 #pragma unroll
-      for (int t = 0; t < NTC; ++t) a[t] = *(const bf16x8*)(Ws + (t * 16 + fr) * CONV_LDK + fg * 8);
+      for (int t = 0; t < NTC; ++t) a[t] = *(const h16x8*)(Ws + (t * 16 + fr) * CONV_LDK + fg * 8);
 #pragma unroll
       for (int t = 0; t < NTC; ++t)
 #pragma unroll
-        for (int f = 0; f < 2; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b[f], acc[t][f], 0, 0, 0);
+        for (int f = 0; f < 2; ++f) acc[t][f] = mfma_h16(a[t], b[f], acc[t][f], 0, 0, 0);
     }
   }
 
@@ -467,7 +515,7 @@ __device__ __forceinline__ uint4 act_group(uint4 v, int act) {
       return tv.v4;
     }
     if (act == CGEN_ACT_GELU) {
-      return gelu8_fwd_bf16(v);
+      return gelu8_fwd_h16(v);
     }
     return v;
   }
@@ -654,15 +702,15 @@ __global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP 
 #pragma unroll
             for (int f = 0; f < 2; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[t][j], bq[f][j], acc[t][f], 0, 0, 0);
       } else {
-        bf16x8 bq[2], aq[NTC];
+        h16x8 bq[2], aq[NTC];
 #pragma unroll
-        for (int f = 0; f < 2; ++f) bq[f] = *(const bf16x8*)(xb + f * HW * q.ldc + off);
+        for (int f = 0; f < 2; ++f) bq[f] = *(const h16x8*)(xb + f * HW * q.ldc + off);
 #pragma unroll
-        for (int t = 0; t < NTC; ++t) aq[t] = *(const bf16x8*)(wb + t * 16 * q.ldw + k0);
+        for (int t = 0; t < NTC; ++t) aq[t] = *(const h16x8*)(wb + t * 16 * q.ldw + k0);
 #pragma unroll
         for (int t = 0; t < NTC; ++t)
 #pragma unroll
-          for (int f = 0; f < 2; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[t], bq[f], acc[t][f], 0, 0, 0);
+          for (int f = 0; f < 2; ++f) acc[t][f] = mfma_h16(aq[t], bq[f], acc[t][f], 0, 0, 0);
       }
       tap += kq; c += krem;
       if (c >= cw) { c -= cw; ++tap; }
@@ -690,7 +738,7 @@ __global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP 
         const f32x4 lo = *(const f32x4*)(es + pl * LDE + ch * 8), hi = *(const f32x4*)(es + pl * LDE + ch * 8 + 4);
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         if (efast[k]) epi8_finish(p, v, epl[k], ebias, n, py, px, co_base + ch * 8);
-        else conv_epilogue8_bf16(p, v, n, py, px, co_base + ch * 8);
+        else conv_epilogue8_h16(p, v, n, py, px, co_base + ch * 8);
       }
     }
   } else {
@@ -762,7 +810,7 @@ __global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, Fast
   CGEN_SETPRIO();
   unsigned long long* stamp = (stamps != nullptr && threadIdx.x == 0) ? stamps + 8 * (blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
   if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
-  typedef bf16_t T;
+  typedef h16_t T;
   constexpr int HALO = KS / 2, TAPS = KS * KS;  // KU K-steps are issued together per wave
   __shared__ __attribute__((aligned(16))) float red[4 * SP_NCO * 2 * 256];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -853,7 +901,7 @@ __global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, Fast
       }
 #pragma unroll
       for (int j = 0; j < KU; ++j) {
-        union { u32x4 u; uint4 q; bf16x8 v; } a0, b0;
+        union { u32x4 u; uint4 q; h16x8 v; } a0, b0;
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
           b0.u = bq[j][f];
@@ -861,7 +909,7 @@ __global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, Fast
 #pragma unroll
           for (int t = 0; t < SP_NCO; ++t) {
             a0.u = aq[j][t];
-            acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0.v, b0.v, acc[t][f], 0, 0, 0);
+            acc[t][f] = mfma_h16(a0.v, b0.v, acc[t][f], 0, 0, 0);
           }
         }
       }
@@ -956,7 +1004,7 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
       if (take && launch_conv_px(p, st)) { conv_trace(p, "px"); return check_launch("cgen_conv2d(px)"); }
     }
     if ((p.KS == 1 || p.KS == 3) && p.H >= 5 && p.W >= 5 && p.dma_ok && !p.force_generic && !getenv("CGEN_CONV_NO_WS")) {
-      if (launch_conv_ws(p, st)) { conv_trace(p, "ws"); return check_launch("cgen_conv2d(ws)"); }
+      if (!p.out_rem && !p.r1_rem && launch_conv_ws(p, st)) { conv_trace(p, "ws"); return check_launch("cgen_conv2d(ws)"); }
     }
   }
   if ((p.KS == 1 || p.KS == 3) && p.H >= 5 && p.W >= 5 && !p.force_generic && p.dma_ok) {
@@ -1243,23 +1291,23 @@ struct Wg2P {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1, const bool plain = false) {
+__device__ __forceinline__ h16x8 tr_pair(const char* p0, const char* p1, const bool plain = false) {
   typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
   if (plain) {  // ablation (CGEN_WG2_DBG & 8): ordinary 8-byte LDS reads instead of the transposing ones (wrong math, same traffic)
-    union { s16x4 h[2]; bf16x8 v; } u;
+    union { s16x4 h[2]; h16x8 v; } u;
     u.h[0] = *(const s16x4*)p0; u.h[1] = *(const s16x4*)p1;
     return u.v;
   }
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p0);
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p1);
-  union { s16x4 h[2]; bf16x8 v; } u;
+  union { s16x4 h[2]; h16x8 v; } u;
   u.h[0] = lo; u.h[1] = hi;
   return u.v;
 }
 
 template <int NCF, int NJW, int KS>
 __device__ __forceinline__ void wgrad_tile_body(const Wg2P& p, const int bid_x, const int bid_y, const int bid_z) {
-  typedef bf16_t T;
+  typedef h16_t T;
   constexpr int G = 8;
   constexpr int HALO = KS / 2, HH = TILE_H + 2 * HALO, HW = TILE_W + 2 * HALO;
   constexpr int TAPS = KS * KS;
@@ -1363,9 +1411,9 @@ __device__ __forceinline__ void wgrad_tile_body(const Wg2P& p, const int bid_x, 
   }
   const int nj_eff = (njf + 3) >> 2;  // fragments per wave, the same for all four waves
   const int go0 = pix_off(p.gt, krow, kx) + qd * 8, go1 = pix_off(p.gt, krow, kx + 4) + qd * 8;
-  bf16x8 ones;
+  h16x8 ones;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
+  for (int e = 0; e < 8; ++e) ones[e] = (h16n_t)1.0f;
 
   const bool stamp = p.stamps != nullptr && bid_x == 0 && bid_y == 0 && bid_z == 0 && tid == 0;
 #ifdef CGEN_WG2_ABLATE
@@ -1397,19 +1445,19 @@ __device__ __forceinline__ void wgrad_tile_body(const Wg2P& p, const int bid_x, 
       constexpr int CH = (NJW % 4 == 0) ? 4 : 3;
 #pragma unroll
       for (int ks = 0; ks < TILE_H / 2; ++ks) {
-        bf16x8 af[NCF];
+        h16x8 af[NCF];
         const char* gk = Gb + ks * 2 * p.gt.rowbytes;
 #pragma unroll
         for (int a = 0; a < NCF; ++a) af[a] = tr_pair(gk + go0 + a * 32, gk + go1 + a * 32, plain_rd);
         if (do_bias) {
 #pragma unroll
-          for (int a = 0; a < NCF; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], ones, accb[a], 0, 0, 0);
+          for (int a = 0; a < NCF; ++a) accb[a] = mfma_h16(af[a], ones, accb[a], 0, 0, 0);
         }
         const char* xk = Xb + ks * 2 * p.xt.rowbytes;
 #pragma unroll
         for (int j0 = 0; j0 < NJW; j0 += CH) {
           if (j0 < nj_eff) {
-            bf16x8 bfv[CH];
+            h16x8 bfv[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u) bfv[u] = tr_pair(xk + xo0[j0 + u], xk + xo1[j0 + u], plain_rd);
 #pragma unroll
@@ -1418,14 +1466,14 @@ __device__ __forceinline__ void wgrad_tile_body(const Wg2P& p, const int bid_x, 
               for (int a = 0; a < NCF; ++a) {
 #ifdef CGEN_WG2_ABLATE  // (tools/coexec_probe.py, CGEN_WG2_DBG & 16): keep the LDS reads alive without the matrix instruction
                 if (no_mfma) {
-                  union { bf16x8 v; float f[4]; } ua, ub;
+                  union { h16x8 v; float f[4]; } ua, ub;
                   ua.v = af[a]; ub.v = bfv[u];
                   acc[a][j0 + u][0] += ua.f[0] + ub.f[0]; acc[a][j0 + u][1] += ua.f[1] + ub.f[1];
                   acc[a][j0 + u][2] += ua.f[2] + ub.f[2]; acc[a][j0 + u][3] += ua.f[3] + ub.f[3];
                   continue;
                 }
 #endif
-                acc[a][j0 + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfv[u], acc[a][j0 + u], 0, 0, 0);
+                acc[a][j0 + u] = mfma_h16(af[a], bfv[u], acc[a][j0 + u], 0, 0, 0);
               }
           }
         }
@@ -1714,13 +1762,11 @@ struct PxP {
 };
 
 // bf16 pair -> two floats
-__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 template <int NP, int KS, bool ONESEG>
 __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
   CGEN_SETPRIO();  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
-  typedef bf16_t T;
+  typedef h16_t T;
   constexpr int G = 8, HALO = KS / 2, HW = TILE_W + 2 * HALO, TAPS = KS * KS;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
@@ -1798,6 +1844,7 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
   // epilogue: this lane owns pixel (row wave*2 + f, column fr) and channels co_base + pr*32 + fg*8 .. +8
   const int ch0 = co_base + fg * 8;
   const bool has_aux = p.aux.p != nullptr, has_r1 = p.res1.p != nullptr, has_r2 = p.res2.p != nullptr;
+  const bool has_r1l = p.r1_rem != 0, has_orem = p.out_rem != 0;  // remainder planes of the f16 residual trunk (cgen_conv_args)
   int eo_out[2], eo_aux[2], eo_r1[2], eo_r2[2];  // byte offsets from the tile origin of each tensor (strides < 2^24)
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
@@ -1838,7 +1885,7 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
     // ---- epilogue operands: requested now, consumed after the MFMA loop
     const bool colv = x0 + fr < p.W;
     bool pv[2];
-    uint4 ea[NP][2], er[NP][2];
+    uint4 ea[NP][2], er[NP][2], el[NP][2];
     {
       const char* aux_t = has_aux ? (const char*)vptr32<T>(p.aux, n, y0, x0) : nullptr;
       const char* r1_t = has_r1 ? (const char*)vptr32<T>(p.res1, n, y0, x0) : nullptr;
@@ -1852,6 +1899,8 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
           er[pr][f] = make_uint4(0, 0, 0, 0);
           if (has_aux) ea[pr][f] = *(const uint4*)(ok ? aux_t + eo_aux[f] + pr * 64 : (const char*)g_zero16);
           if (has_r1) er[pr][f] = *(const uint4*)(ok ? r1_t + eo_r1[f] + pr * 64 : (const char*)g_zero16);
+          el[pr][f] = make_uint4(0, 0, 0, 0);
+          if (has_r1l) el[pr][f] = *(const uint4*)(ok ? r1_t + p.r1_rem + eo_r1[f] + pr * 64 : (const char*)g_zero16);
         }
       }
     }
@@ -1878,29 +1927,29 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
     // ---- MFMAs: 2 tile rows x NP*32 channels per wave, bias as the initial value
     f32x4 acc[NP][2][2];
     {  // K-step 0 always exists: the bias registers are its C operand (no accumulator initialisation moves)
-      const bf16x8 b0 = *(const bf16x8*)(x_rows + koff[0]);
-      const bf16x8 b1 = *(const bf16x8*)(x_rows + q.xt.rowbytes + koff[0]);
+      const h16x8 b0 = *(const h16x8*)(x_rows + koff[0]);
+      const h16x8 b1 = *(const h16x8*)(x_rows + q.xt.rowbytes + koff[0]);
 #pragma unroll
       for (int pr = 0; pr < NP; ++pr)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const bf16x8 aq = *(const bf16x8*)(a_base + (size_t)(pr * 32 + h * 16) * q.ldw * 2);
-          acc[pr][h][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, b0, binit[pr][h], 0, 0, 0);
-          acc[pr][h][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, b1, binit[pr][h], 0, 0, 0);
+          const h16x8 aq = *(const h16x8*)(a_base + (size_t)(pr * 32 + h * 16) * q.ldw * 2);
+          acc[pr][h][0] = mfma_h16(aq, b0, binit[pr][h], 0, 0, 0);
+          acc[pr][h][1] = mfma_h16(aq, b1, binit[pr][h], 0, 0, 0);
         }
     }
 #pragma unroll
     for (int i = 1; i < PX_MAXKS; ++i) {
       if (i >= q.nks) break;  // (a break, not a guard: one scalar compare-and-branch per K-step instead of 15 precomputed masks)
-      const bf16x8 b0 = *(const bf16x8*)(x_rows + koff[i]);
-      const bf16x8 b1 = *(const bf16x8*)(x_rows + q.xt.rowbytes + koff[i]);
+      const h16x8 b0 = *(const h16x8*)(x_rows + koff[i]);
+      const h16x8 b1 = *(const h16x8*)(x_rows + q.xt.rowbytes + koff[i]);
 #pragma unroll
       for (int pr = 0; pr < NP; ++pr)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const bf16x8 aq = *(const bf16x8*)(a_base + (size_t)(pr * 32 + h * 16) * q.ldw * 2 + i * 64);
-          acc[pr][h][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, b0, acc[pr][h][0], 0, 0, 0);
-          acc[pr][h][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, b1, acc[pr][h][1], 0, 0, 0);
+          const h16x8 aq = *(const h16x8*)(a_base + (size_t)(pr * 32 + h * 16) * q.ldw * 2 + i * 64);
+          acc[pr][h][0] = mfma_h16(aq, b0, acc[pr][h][0], 0, 0, 0);
+          acc[pr][h][1] = mfma_h16(aq, b1, acc[pr][h][1], 0, 0, 0);
         }
     }
 
@@ -1922,11 +1971,11 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
             if (p.dact == CGEN_ACT_RELU) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                v[2 * e] = bf_lo(w[e]) > 0.f ? v[2 * e] : 0.f;
-                v[2 * e + 1] = bf_hi(w[e]) > 0.f ? v[2 * e + 1] : 0.f;
+                v[2 * e] = h_lo(w[e]) > 0.f ? v[2 * e] : 0.f;
+                v[2 * e + 1] = h_hi(w[e]) > 0.f ? v[2 * e + 1] : 0.f;
               }
             } else if (p.dact == CGEN_ACT_GELU) {
-              const F8 gp = gelu8_bwd_bf16(make_uint4(w[0], w[1], w[2], w[3]));
+              const F8 gp = gelu8_bwd_h16(make_uint4(w[0], w[1], w[2], w[3]));
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] *= gp.v[e];
             }
@@ -1934,16 +1983,27 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
           if (has_r1) {
             const uint32_t w[4] = {er[pr][f].x, er[pr][f].y, er[pr][f].z, er[pr][f].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(w[e]); v[2 * e + 1] += bf_hi(w[e]); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] += h_lo(w[e]); v[2 * e + 1] += h_hi(w[e]); }
           }
           if (has_r2) {
             const uint4 r = *(const uint4*)(r2_t + eo_r2[f] + pr * 64);
             const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(w[e]); v[2 * e + 1] += bf_hi(w[e]); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] += h_lo(w[e]); v[2 * e + 1] += h_hi(w[e]); }
+          }
+          if (has_r1l) {
+            const uint32_t w[4] = {el[pr][f].x, el[pr][f].y, el[pr][f].z, el[pr][f].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[2 * e] += h_lo(w[e]); v[2 * e + 1] += h_hi(w[e]); }
           }
           uint4 o;
-          o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]); o.z = f2bf_pk(v[4], v[5]); o.w = f2bf_pk(v[6], v[7]);
+          o.x = f2h_pk(v[0], v[1]); o.y = f2h_pk(v[2], v[3]); o.z = f2h_pk(v[4], v[5]); o.w = f2h_pk(v[6], v[7]);
+          if (has_orem) {  // what the rounding just dropped goes to the remainder plane
+            uint4 ol;
+            ol.x = f2h_pk(v[0] - h_lo(o.x), v[1] - h_hi(o.x)); ol.y = f2h_pk(v[2] - h_lo(o.y), v[3] - h_hi(o.y));
+            ol.z = f2h_pk(v[4] - h_lo(o.z), v[5] - h_hi(o.z)); ol.w = f2h_pk(v[6] - h_lo(o.w), v[7] - h_hi(o.w));
+            *(uint4*)(out_t + p.out_rem + eo_out[f] + pr * 64) = ol;
+          }
           *(uint4*)(out_t + eo_out[f] + pr * 64) = o;
         }
     }
@@ -2059,7 +2119,7 @@ struct WsP {
 template <int NTC, int NKW, bool ONESEG>
 __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
   CGEN_SETPRIO();  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
-  typedef bf16_t T;
+  typedef h16_t T;
   constexpr int G = 8, NF = NTC * TILE_H;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
@@ -2073,7 +2133,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
   const int co_base = blockIdx.y * (NTC * 16);
 
   // ---- this wave's K-steps of the weight image, resident in registers
-  bf16x8 aw[NTC][NKW];
+  h16x8 aw[NTC][NKW];
   int koff[NKW];
   {
     int pxo[3];  // LDS byte offset of pixel x = fr + dx inside a tile row
@@ -2087,7 +2147,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
         // unconditional: rows past the image are clamped to its last row (never stored), K-steps past nk read the 32 zero
         // columns that close every weight row (krow = ceil32(K) + 32)
         const int row = min(co_base + t * 16 + fr, q.rows_pad - 1);
-        aw[t][i] = *(const bf16x8*)((const T*)p.w + (__umul24(row, p.krow) + min(ks, q.nk) * 32 + fg * 8));
+        aw[t][i] = *(const h16x8*)((const T*)p.w + (__umul24(row, p.krow) + min(ks, q.nk) * 32 + fg * 8));
       }
       const int kidx = min(ks, q.nk - 1) * 32 + fg * 8;
       int tap = fdiv(kidx, q.d_ctot8);
@@ -2202,13 +2262,13 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
     if (!(q.dbg & 4)) {
 #pragma unroll
       for (int i = 0; i < NKW; ++i) {
-        bf16x8 bq[TILE_H];
+        h16x8 bq[TILE_H];
 #pragma unroll
-        for (int f = 0; f < TILE_H; ++f) bq[f] = *(const bf16x8*)(Xb + f * q.xt.rowbytes + koff[i]);
+        for (int f = 0; f < TILE_H; ++f) bq[f] = *(const h16x8*)(Xb + f * q.xt.rowbytes + koff[i]);
 #pragma unroll
         for (int f = 0; f < TILE_H; ++f)
 #pragma unroll
-          for (int tt = 0; tt < NTC; ++tt) acc[tt][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[tt][i], bq[f], acc[tt][f], 0, 0, 0);
+          for (int tt = 0; tt < NTC; ++tt) acc[tt][f] = mfma_h16(aw[tt][i], bq[f], acc[tt][f], 0, 0, 0);
       }
     }
     __syncthreads();  // everyone is done reading the tile: its LDS is reused for the partial sums
@@ -2243,11 +2303,11 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
             if (p.dact == CGEN_ACT_RELU) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                v[2 * e] = bf_lo(w[e]) > 0.f ? v[2 * e] : 0.f;
-                v[2 * e + 1] = bf_hi(w[e]) > 0.f ? v[2 * e + 1] : 0.f;
+                v[2 * e] = h_lo(w[e]) > 0.f ? v[2 * e] : 0.f;
+                v[2 * e + 1] = h_hi(w[e]) > 0.f ? v[2 * e + 1] : 0.f;
               }
             } else if (p.dact == CGEN_ACT_GELU) {
-              const F8 gp = gelu8_bwd_bf16(make_uint4(w[0], w[1], w[2], w[3]));
+              const F8 gp = gelu8_bwd_h16(make_uint4(w[0], w[1], w[2], w[3]));
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] *= gp.v[e];
             }
@@ -2255,15 +2315,15 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
           if (has_r1) {
             const uint32_t w[4] = {er1[k].x, er1[k].y, er1[k].z, er1[k].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(w[e]); v[2 * e + 1] += bf_hi(w[e]); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] += h_lo(w[e]); v[2 * e + 1] += h_hi(w[e]); }
           }
           if (has_r2) {
             const uint32_t w[4] = {er2[k].x, er2[k].y, er2[k].z, er2[k].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[2 * e] += bf_lo(w[e]); v[2 * e + 1] += bf_hi(w[e]); }
+            for (int e = 0; e < 4; ++e) { v[2 * e] += h_lo(w[e]); v[2 * e + 1] += h_hi(w[e]); }
           }
           uint4 o;
-          o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]); o.z = f2bf_pk(v[4], v[5]); o.w = f2bf_pk(v[6], v[7]);
+          o.x = f2h_pk(v[0], v[1]); o.y = f2h_pk(v[2], v[3]); o.z = f2h_pk(v[4], v[5]); o.w = f2h_pk(v[6], v[7]);
           *(uint4*)(out_t + eo_out[k]) = o;
         }
       }
@@ -2392,7 +2452,7 @@ __global__ __launch_bounds__(256) void wprep_kernel(const cgen_wprep_desc* descs
         if (r < d.seg_c[0] && c < d.co) v = d.src[((int64_t)c * d.ci_total + d.seg_off + r) * taps + (taps - 1 - tap)];
       }
     }
-    if (d.dtype == CGEN_F32) ((float*)d.dst)[o] = v; else ((bf16_t*)d.dst)[o] = f2bf(v);
+    if (d.dtype == CGEN_F32) ((float*)d.dst)[o] = v; else ((h16_t*)d.dst)[o] = f2h(v);
   }
 }
 
@@ -2401,6 +2461,7 @@ __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, 
   // nsplit-deep reads are coalesced 16-byte streams; the sum is scattered into the OIHW gradient (1/nsplit of the bytes).
   const cgen_wred_desc d = descs[csite[blockIdx.x]];
   const int taps = d.ks * d.ks;
+  const float us = d.unscale == 0.f ? 1.f : d.unscale;  // 1 / loss scale of the f16 engine (a power of two: exact)
   const int nw = d.co * d.ci_total * taps;  // < 2^31 (checked on the host)
   const int s0 = cidx[blockIdx.x] * MT_CHUNK + threadIdx.x * 4;
   if (s0 >= d.numel) return;
@@ -2445,7 +2506,7 @@ __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, 
       const unsigned r = sidx / (unsigned)d.ci_total, ci = sidx - r * d.ci_total;
       const unsigned co = r / (unsigned)taps, tap = r - co * taps;
       const size_t o = ((size_t)co * d.ci_total + ci) * taps + tap;
-      d.grad_w[o] = d.accumulate ? d.grad_w[o] + a[e] : a[e];
+      d.grad_w[o] = d.accumulate ? d.grad_w[o] + a[e] * us : a[e] * us;
     }
   }
   if (d.grad_b) {  // elements nw .. numel-1 are the bias gradient
@@ -2455,7 +2516,7 @@ __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, 
         const int co = o - nw;
         float acc = 0.f;
         for (int sp = 0; sp < d.nsplit; ++sp) acc += d.partial_b[(size_t)sp * d.co + co];
-        d.grad_b[co] = d.accumulate ? d.grad_b[co] + acc : acc;
+        d.grad_b[co] = d.accumulate ? d.grad_b[co] + acc * us : acc * us;
       }
     }
   }
@@ -2478,7 +2539,7 @@ static bool blk_bv(const cgen_view& v, int n, int h, int w, BV& o) {  // 64-bit 
 }
 
 static int blk_fill(const cgen_block_args* a, BlkP& p) {
-  if (!a || a->dtype != CGEN_BF16 || a->nseg < 1 || a->nseg > 3 || a->n <= 0 || a->h <= 0 || a->w <= 0) return 0;
+  if (!a || a->dtype != CGEN_F16 || a->nseg < 1 || a->nseg > 3 || a->n <= 0 || a->h <= 0 || a->w <= 0) return 0;
   memset(&p, 0, sizeof(p));
   p.N = a->n; p.H = a->h; p.W = a->w; p.mode = a->mode; p.nseg = a->nseg; p.pre_act = a->pre_act;
   p.TH = a->tile_h ? a->tile_h : 8;
@@ -2497,7 +2558,7 @@ static int blk_fill(const cgen_block_args* a, BlkP& p) {
   auto v8 = [](const cgen_view& v) { return !v.p || (((uintptr_t)v.p % 8 == 0) && v.sn % 4 == 0 && v.sh % 4 == 0 && v.sw % 4 == 0); };
   if (!v8(a->mid) || !v8(a->mid_aux) || !v8(a->out) || !v8(a->aux) || !v8(a->res1)) return 0;
   if (((uintptr_t)a->w_a % 16) || ((uintptr_t)a->w_b % 16) || (a->bias_a && (uintptr_t)a->bias_a % 16) || (a->bias_b && (uintptr_t)a->bias_b % 16)) return 0;
-  p.wA = (const bf16_t*)a->w_a; p.wB = (const bf16_t*)a->w_b; p.biasA = a->bias_a; p.biasB = a->bias_b;
+  p.wA = (const h16_t*)a->w_a; p.wB = (const h16_t*)a->w_b; p.biasA = a->bias_a; p.biasB = a->bias_b;
   p.krowA = pad_to(9 * p.CU, 32) + 32; p.krowB = pad_to(9 * pad_to(p.CT, 8), 32) + 32;
   p.rowsA = pad_to(p.CT, 16); p.rowsB = pad_to(p.CV, 16);
   if (!blk_bv(a->mid, a->n, a->h, a->w, p.t) || !blk_bv(a->mid_aux, a->n, a->h, a->w, p.taux) || !blk_bv(a->out, a->n, a->h, a->w, p.out) ||
@@ -2520,7 +2581,7 @@ extern "C" int cgen_block2(const cgen_block_args* a, cgen_stream_t stream) {
 
 extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
   CGEN_REQUIRE(a, "cgen_conv2d: null args");
-  CGEN_REQUIRE(a->dtype == CGEN_F32 || a->dtype == CGEN_BF16, "cgen_conv2d: bad dtype %d", a->dtype);
+  CGEN_REQUIRE(a->dtype == CGEN_F32 || a->dtype == CGEN_F16, "cgen_conv2d: bad dtype %d", a->dtype);
   CGEN_REQUIRE(a->ks == 1 || a->ks == 3 || a->ks == 5 || a->ks == 7, "cgen_conv2d: kernel size %d unsupported", a->ks);
   CGEN_REQUIRE(a->nseg >= 1 && a->nseg <= CGEN_MAX_SEG, "cgen_conv2d: nseg %d", a->nseg);
   CGEN_REQUIRE(a->n > 0 && a->h > 0 && a->w > 0 && a->out.c > 0 && a->out.p && a->weight, "cgen_conv2d: bad shape/pointers");
@@ -2548,6 +2609,9 @@ extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
   p.w = a->weight; p.bias = a->bias;
   CGEN_REQUIRE(((uintptr_t)a->weight) % 16 == 0, "cgen_conv2d: weight image must be 16-byte aligned");
   p.out = mk(a->out); p.aux = mk(a->aux); p.res1 = mk(a->res1); p.res2 = mk(a->res2);
+  CGEN_REQUIRE((!a->out_rem && !a->res1_rem) || a->dtype == CGEN_F16, "cgen_conv2d: remainder planes are an f16 feature");
+  CGEN_REQUIRE(a->out_rem % 16 == 0 && a->res1_rem % 16 == 0, "cgen_conv2d: remainder-plane offsets must be multiples of 16 bytes");
+  p.out_rem = a->out_rem; p.r1_rem = a->res1.p ? a->res1_rem : 0;
   if (!a->dact) p.aux.p = nullptr;
   // 4-channel vector epilogue: needs 4*esz-byte alignment on every view it touches
   auto epi_ok = [&](const cgen_view& v) {
@@ -2558,7 +2622,7 @@ extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
   p.force_generic = getenv("CGEN_CONV_GENERIC") != nullptr;
   p.epi_vec = epi_ok(a->out) && epi_ok(a->aux) && epi_ok(a->res1) && epi_ok(a->res2) && (!a->bias || ((uintptr_t)a->bias % 16 == 0));
   p.epi_vec16 = vec16_ok(a->out, esz) && vec16_ok(a->aux, esz) && vec16_ok(a->res1, esz) && vec16_ok(a->res2, esz) && (!a->bias || ((uintptr_t)a->bias % 16 == 0));
-  return a->dtype == CGEN_F32 ? launch_conv<float>(p, (hipStream_t)stream) : launch_conv<bf16_t>(p, (hipStream_t)stream);
+  return a->dtype == CGEN_F32 ? launch_conv<float>(p, (hipStream_t)stream) : launch_conv<h16_t>(p, (hipStream_t)stream);
 }
 
 static int count_chunks(const cgen_view* seg, int nseg) {
@@ -2575,7 +2639,7 @@ static int ctot8_of(const int32_t* seg_c, int nseg) {
 
 // can the streaming tiled kernel serve this call?
 static bool wgrad_tiled_ok(const cgen_wgrad_args* a, Wg2Geom& g) {
-  if (a->dtype != CGEN_BF16 || getenv("CGEN_WGRAD_GENERIC")) return false;
+  if (a->dtype != CGEN_F16 || getenv("CGEN_WGRAD_GENERIC")) return false;
   if (!dma_clean(a->gout, 2)) return false;
   int segc[CGEN_MAX_SEG];
   for (int s = 0; s < a->nseg; ++s) {
@@ -2654,7 +2718,7 @@ extern "C" int cgen_conv2d_wgrad_batch_plan(const cgen_wgrad_args* args, int32_t
     Item it;
     it.idx = i;
     eligible[i] = 0;
-    if (args[i].dtype != CGEN_BF16 || !args[i].partial_w) continue;
+    if (args[i].dtype != CGEN_F16 || !args[i].partial_w) continue;
     if (!build_wg2(&args[i], it.q, it.g)) continue;
     if (it.g.nsplit != args[i].nsplit) continue;
     eligible[i] = 1;
@@ -2745,7 +2809,7 @@ extern "C" int cgen_conv2d_wgrad_batch_run(const void* blob_dev, const cgen_wgra
 
 extern "C" int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream) {
   CGEN_REQUIRE(a && a->partial_w, "cgen_conv2d_wgrad: null args");
-  CGEN_REQUIRE(a->dtype == CGEN_F32 || a->dtype == CGEN_BF16, "cgen_conv2d_wgrad: bad dtype");
+  CGEN_REQUIRE(a->dtype == CGEN_F32 || a->dtype == CGEN_F16, "cgen_conv2d_wgrad: bad dtype");
   CGEN_REQUIRE(a->nseg >= 1 && a->nseg <= CGEN_MAX_SEG && a->gout.p && a->gout.c > 0, "cgen_conv2d_wgrad: bad args");
   const int esz = a->dtype == CGEN_F32 ? 4 : 2;
   WgP p;
@@ -2796,7 +2860,7 @@ extern "C" int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream)
     p.gout_vec = ((uintptr_t)a->gout.p % q == 0) && ((a->gout.sn * esz) % q == 0) && ((a->gout.sh * esz) % q == 0) && ((a->gout.sw * esz) % q == 0);
   }
   p.pw = a->partial_w; p.pb = a->partial_b;
-  return a->dtype == CGEN_F32 ? launch_wgrad<float>(p, (hipStream_t)stream) : launch_wgrad<bf16_t>(p, (hipStream_t)stream);
+  return a->dtype == CGEN_F32 ? launch_wgrad<float>(p, (hipStream_t)stream) : launch_wgrad<h16_t>(p, (hipStream_t)stream);
 }
 
 extern "C" int cgen_weight_prep(const cgen_wprep_desc* descs, const int32_t* csite, const int32_t* cidx, int32_t nchunks,

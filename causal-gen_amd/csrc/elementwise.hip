@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(Shape4 si, in
 
 // src = min(floorf(dst * (float)(1/scale_factor)), in-1)
 template <typename T>
-__global__ __launch_bounds__(256) void batch_reduce_kernel(Shape4 s, View in, float* out, int accumulate) {
+__global__ __launch_bounds__(256) void batch_reduce_kernel(Shape4 s, View in, float* out, int accumulate, float unscale) {
   // a workgroup owns 64 consecutive (y, x, c) elements; its 4 waves split the batch and are combined in a fixed order
   __shared__ float part[4][64];
   const int64_t per = (int64_t)s.h * s.w * s.c;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void batch_reduce_kernel(Shape4 s, View in, fl
     part[phase][lane] = a;
     __syncthreads();
     if (phase == 0 && g < per) {
-      const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+      const float t = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) * unscale;
       out[g] = accumulate ? out[g] + t : t;
     }
     __syncthreads();
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void stem7_kernel(int N, int H, int W, int cin
   for (int i = tid; i < cin * TAPS * CO; i += 256) {  // OIHW [co][c][7][7] -> [c * 49 + tap][co]
     const int co = i % CO, k = i / CO;
     float v = wgt[(size_t)co * cin * TAPS + k];
-    if (round_bf16) v = bf2f(f2bf(v));  // the bf16 engine multiplies bf16-rounded weights everywhere else too
+    if (round_bf16) v = h2f(f2h(v));  // the bf16 engine multiplies bf16-rounded weights everywhere else too
     ws[i] = v;
   }
   for (int i = tid; i < cin * XH * XW; i += 256) {
@@ -332,8 +332,8 @@ static inline bool vec4_ok(int esz, int c, std::initializer_list<const cgen_view
       if (vec) hipLaunchKernelGGL((KERNEL<float, 4>), dim3(grid__), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
       else hipLaunchKernelGGL((KERNEL<float, 1>), dim3(grid__), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);     \
     } else {                                                                                                  \
-      if (vec) hipLaunchKernelGGL((KERNEL<bf16_t, 4>), dim3(grid__), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-      else hipLaunchKernelGGL((KERNEL<bf16_t, 1>), dim3(grid__), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);     \
+      if (vec) hipLaunchKernelGGL((KERNEL<h16_t, 4>), dim3(grid__), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+      else hipLaunchKernelGGL((KERNEL<h16_t, 1>), dim3(grid__), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);     \
     }                                                                                                         \
   } while (0)
 
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void unary_bwd_kernel(Shape4 s, int op, float 
 
 using namespace cgen;
 
-#define CHECK_DTYPE(name) CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, name ": bad dtype %d", dtype)
+#define CHECK_DTYPE(name) CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, name ": bad dtype %d", dtype)
 static inline int esz_of(int dtype) { return dtype == CGEN_F32 ? 4 : 2; }
 
 extern "C" int cgen_avgpool_fwd(int32_t dtype, int32_t n, int32_t ho, int32_t wo, int32_t d, cgen_view in, cgen_view out,
@@ -504,13 +504,13 @@ extern "C" int cgen_upsample_bwd(int32_t dtype, int32_t n, int32_t hi, int32_t w
 }
 
 extern "C" int cgen_batch_reduce(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view in, float* out, int32_t accumulate,
-                                 cgen_stream_t stream) {
+                                 float unscale, cgen_stream_t stream) {
   CHECK_DTYPE("cgen_batch_reduce");
   CGEN_REQUIRE(in.p && out, "cgen_batch_reduce: bad args");
   Shape4 s{n, h, w, in.c};
   const int64_t items = (int64_t)h * w * in.c;
-  if (dtype == CGEN_F32) hipLaunchKernelGGL(batch_reduce_kernel<float>, dim3(grid_for(items * 4)), dim3(256), 0, (hipStream_t)stream, s, mk(in), out, accumulate);
-  else hipLaunchKernelGGL(batch_reduce_kernel<bf16_t>, dim3(grid_for(items * 4)), dim3(256), 0, (hipStream_t)stream, s, mk(in), out, accumulate);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(batch_reduce_kernel<float>, dim3(grid_for(items * 4)), dim3(256), 0, (hipStream_t)stream, s, mk(in), out, accumulate, unscale);
+  else hipLaunchKernelGGL(batch_reduce_kernel<h16_t>, dim3(grid_for(items * 4)), dim3(256), 0, (hipStream_t)stream, s, mk(in), out, accumulate, unscale);
   return check_launch("cgen_batch_reduce");
 }
 
@@ -539,7 +539,7 @@ extern "C" int cgen_axpby(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_v
       const int64_t nvec = (int64_t)n * h * w * c * esz / 16;
       const dim3 g(grid_for(nvec)), b(256);
       if (dtype == CGEN_F32) hipLaunchKernelGGL(axpby_flat_kernel<float>, g, b, 0, (hipStream_t)stream, nvec, (const uint4*)in.p, (uint4*)out.p, alpha, accumulate);
-      else hipLaunchKernelGGL(axpby_flat_kernel<bf16_t>, g, b, 0, (hipStream_t)stream, nvec, (const uint4*)in.p, (uint4*)out.p, alpha, accumulate);
+      else hipLaunchKernelGGL(axpby_flat_kernel<h16_t>, g, b, 0, (hipStream_t)stream, nvec, (const uint4*)in.p, (uint4*)out.p, alpha, accumulate);
       return check_launch("cgen_axpby");
     }
   }
@@ -561,8 +561,8 @@ extern "C" int cgen_nchw_to_nhwc(int32_t src_is_u8, int32_t dtype, int32_t n, in
     if (src_is_u8) hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, uint8_t>), g, b, 0, st, s, (const uint8_t*)src, mk(out), sub, mul);
     else hipLaunchKernelGGL((nchw_to_nhwc_kernel<float, float>), g, b, 0, st, s, (const float*)src, mk(out), sub, mul);
   } else {
-    if (src_is_u8) hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t, uint8_t>), g, b, 0, st, s, (const uint8_t*)src, mk(out), sub, mul);
-    else hipLaunchKernelGGL((nchw_to_nhwc_kernel<bf16_t, float>), g, b, 0, st, s, (const float*)src, mk(out), sub, mul);
+    if (src_is_u8) hipLaunchKernelGGL((nchw_to_nhwc_kernel<h16_t, uint8_t>), g, b, 0, st, s, (const uint8_t*)src, mk(out), sub, mul);
+    else hipLaunchKernelGGL((nchw_to_nhwc_kernel<h16_t, float>), g, b, 0, st, s, (const float*)src, mk(out), sub, mul);
   }
   return check_launch("cgen_nchw_to_nhwc");
 }
@@ -579,8 +579,8 @@ extern "C" int cgen_im2col(int32_t dtype, int32_t n, int32_t h, int32_t w, int32
     if (ks == 7) hipLaunchKernelGGL((im2col_kernel<float, 7>), dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
     else hipLaunchKernelGGL((im2col_kernel<float, 0>), dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
   } else {
-    if (ks == 7) hipLaunchKernelGGL((im2col_kernel<bf16_t, 7>), dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
-    else hipLaunchKernelGGL((im2col_kernel<bf16_t, 0>), dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
+    if (ks == 7) hipLaunchKernelGGL((im2col_kernel<h16_t, 7>), dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
+    else hipLaunchKernelGGL((im2col_kernel<h16_t, 0>), dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, ks, in.c, mk(in), mk(out), cphys);
   }
   return check_launch("cgen_im2col");
 }
@@ -591,7 +591,7 @@ extern "C" int cgen_stem_conv_supported(int32_t dtype, int32_t cin, int32_t ks, 
   // >64 KB opt-in: a shape whose footprint exceeds 64 KB (Cin = 4 with Cout = 64: 65 856 B) is NOT served -- the caller
   // (vae._stem_site) then takes the im2col + 1x1 route instead of failing at launch
   const size_t lds = (size_t)(cin * (STEM_TH + 6) * (STEM_TW + 6) + cin * 49 * co) * sizeof(float);
-  return (dtype == CGEN_F32 || dtype == CGEN_BF16) && ks == 7 && cin >= 1 && cin <= 4 && (co == 16 || co == 32 || co == 64) &&
+  return (dtype == CGEN_F32 || dtype == CGEN_F16) && ks == 7 && cin >= 1 && cin <= 4 && (co == 16 || co == 32 || co == 64) &&
          lds <= 64 * 1024;
 }
 
@@ -604,12 +604,12 @@ extern "C" int cgen_stem_conv_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w
   CGEN_REQUIRE(vec4_ok(esz, co, {&out}), "cgen_stem_conv_fwd: the output view must allow 4-channel vector stores");
   const int tiles = n * ((h + STEM_TH - 1) / STEM_TH) * ((w + STEM_TW - 1) / STEM_TW);
   const size_t lds = (size_t)(cin * (STEM_TH + 6) * (STEM_TW + 6) + cin * 49 * co) * sizeof(float);
-  const int rb = dtype == CGEN_BF16 ? 1 : 0;
+  const int rb = dtype == CGEN_F16 ? 1 : 0;
 #define STEM_LAUNCH(T_, NCO_) hipLaunchKernelGGL((stem7_kernel<T_, NCO_>), dim3(tiles), dim3(256), lds, (hipStream_t)stream, n, h, w, cin, mk(in), weight_oihw, bias, mk(out), rb)
   if (dtype == CGEN_F32) {
     if (co == 16) STEM_LAUNCH(float, 1); else if (co == 32) STEM_LAUNCH(float, 2); else STEM_LAUNCH(float, 4);
   } else {
-    if (co == 16) STEM_LAUNCH(bf16_t, 1); else if (co == 32) STEM_LAUNCH(bf16_t, 2); else STEM_LAUNCH(bf16_t, 4);
+    if (co == 16) STEM_LAUNCH(h16_t, 1); else if (co == 32) STEM_LAUNCH(h16_t, 2); else STEM_LAUNCH(h16_t, 4);
   }
 #undef STEM_LAUNCH
   return check_launch("cgen_stem_conv_fwd");
@@ -622,7 +622,7 @@ extern "C" int cgen_nhwc_to_nchw(int32_t dtype, int32_t n, int32_t c, int32_t h,
   Shape4 s{n, h, w, c};
   const int64_t items = (int64_t)n * h * w * c;
   if (dtype == CGEN_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, mk(in), dst);
-  else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, mk(in), dst);
+  else hipLaunchKernelGGL(nhwc_to_nchw_kernel<h16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, mk(in), dst);
   return check_launch("cgen_nhwc_to_nchw");
 }
 
@@ -635,7 +635,7 @@ extern "C" int cgen_im2col_strided(int32_t dtype, int32_t n, int32_t h, int32_t 
   Shape4 so{n, ho, wo, out.c};
   const int64_t items = (int64_t)n * ho * wo * cphys;
   if (dtype == CGEN_F32) hipLaunchKernelGGL(im2col_strided_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, so, h, w, ks, stride, pad, in.c, mk(in), mk(out), cphys);
-  else hipLaunchKernelGGL(im2col_strided_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, so, h, w, ks, stride, pad, in.c, mk(in), mk(out), cphys);
+  else hipLaunchKernelGGL(im2col_strided_kernel<h16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, so, h, w, ks, stride, pad, in.c, mk(in), mk(out), cphys);
   return check_launch("cgen_im2col_strided");
 }
 
@@ -646,7 +646,7 @@ extern "C" int cgen_col2im_strided(int32_t dtype, int32_t n, int32_t h, int32_t 
   Shape4 si{n, h, w, gin.c};
   const int64_t items = (int64_t)n * h * w * gin.c;
   if (dtype == CGEN_F32) hipLaunchKernelGGL(col2im_strided_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, si, ho, wo, ks, stride, pad, mk(gcol), mk(gin), accumulate);
-  else hipLaunchKernelGGL(col2im_strided_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, si, ho, wo, ks, stride, pad, mk(gcol), mk(gin), accumulate);
+  else hipLaunchKernelGGL(col2im_strided_kernel<h16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, si, ho, wo, ks, stride, pad, mk(gcol), mk(gin), accumulate);
   return check_launch("cgen_col2im_strided");
 }
 
@@ -657,7 +657,7 @@ extern "C" int cgen_unary_fwd(int32_t dtype, int32_t op, float param, int32_t n,
   Shape4 s{n, h, w, c};
   const int64_t items = (int64_t)n * h * w * c;
   if (dtype == CGEN_F32) hipLaunchKernelGGL(unary_fwd_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, op, param, mk(in), mk(out));
-  else hipLaunchKernelGGL(unary_fwd_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, op, param, mk(in), mk(out));
+  else hipLaunchKernelGGL(unary_fwd_kernel<h16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, op, param, mk(in), mk(out));
   return check_launch("cgen_unary_fwd");
 }
 
@@ -668,6 +668,6 @@ extern "C" int cgen_unary_bwd(int32_t dtype, int32_t op, float param, int32_t n,
   Shape4 s{n, h, w, c};
   const int64_t items = (int64_t)n * h * w * c;
   if (dtype == CGEN_F32) hipLaunchKernelGGL(unary_bwd_kernel<float>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, op, param, mk(x), mk(gout), mk(gin), accumulate);
-  else hipLaunchKernelGGL(unary_bwd_kernel<bf16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, op, param, mk(x), mk(gout), mk(gin), accumulate);
+  else hipLaunchKernelGGL(unary_bwd_kernel<h16_t>, dim3(grid_for(items)), dim3(256), 0, (hipStream_t)stream, s, op, param, mk(x), mk(gout), mk(gin), accumulate);
   return check_launch("cgen_unary_bwd");
 }

@@ -107,13 +107,12 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(LatBwdP p) {
 // v_mfma_f32_16x16x32_bf16 -- and the weight image rows are the A fragments: no LDS, no shuffles.  z is stored once (bf16) for
 // z_feat_proj, the weight gradients and the backward pass, with the same Philox indexing as the unfused kernel.
 typedef float lat_f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 lat_bf16x8 __attribute__((ext_vector_type(8)));
 __device__ uint4 lat_zero16[2];  // zeros: source of absent operands (loads are never issued under a condition)
 
 struct LatZpFwdP {
   LatP l;
   View pa, hres, pfeat, out;  // pa: [n,h,w,ctx] (ctx8 <= 16); hres / pfeat: optional residuals; out: [n,h,w,co]
-  const bf16_t* w;            // z_proj forward image: rows ceil16(co) x krow, column = concat8 index (z 0..15, parents 16..)
+  const h16_t* w;            // z_proj forward image: rows ceil16(co) x krow, column = concat8 index (z 0..15, parents 16..)
   const float* bias;
   int co, krow, rows, pa_groups;  // pa_groups: 8-channel groups of the parents (0, 1 or 2)
 };
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(512) void reparam_zproj_fwd_kernel(LatZpFwdP q) {  
     const int pix = chunk * (LAT_CHUNK / 16) + wave * 16 + fr;
     const bool valid = pix < npix;
     const int y = valid ? pix / p.w : 0, x = valid ? pix - y * p.w : 0;
-    union { uint4 u; lat_bf16x8 v; } bfrag;
+    union { uint4 u; h16x8 v; } bfrag;
     bfrag.u = make_uint4(0, 0, 0, 0);
     if (fg < 2) {
       const int ch = fg * 8;
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(512) void reparam_zproj_fwd_kernel(LatZpFwdP q) {  
     }
     // ---- h'[co] = W[co][0:32] . [z | pa] + bias + h + p_feat: one MFMA per 16 output channels.  All operands of up to
     // eight channel tiles are requested first (one memory round trip per batch, not per tile), then MFMAs + stores.
-    const bf16_t* wl = q.w + fg * 8;
+    const h16_t* wl = q.w + fg * 8;
     const int o_out = off8(q.out, b, y, x, 0), o_h = off8(q.hres, b, y, x, 0), o_f = off8(q.pfeat, b, y, x, 0);
 #pragma unroll 1
     for (int ct0 = 0; ct0 < co16; ct0 += 8) {
@@ -183,24 +182,24 @@ __global__ __launch_bounds__(512) void reparam_zproj_fwd_kernel(LatZpFwdP q) {  
         const bool live = valid && c0 < q.co;
         aw[j] = *(const uint4*)(wl + (int64_t)row * q.krow);
         bb[j] = *(const float4*)((q.bias && c0 + 4 <= q.co) ? (const void*)(q.bias + c0) : (const void*)lat_zero16);
-        rh[j] = *(const uint2*)((live && q.hres.p) ? (const void*)((const bf16_t*)q.hres.p + o_h + c0) : (const void*)lat_zero16);
-        rf[j] = *(const uint2*)((live && q.pfeat.p) ? (const void*)((const bf16_t*)q.pfeat.p + o_f + c0) : (const void*)lat_zero16);
+        rh[j] = *(const uint2*)((live && q.hres.p) ? (const void*)((const h16_t*)q.hres.p + o_h + c0) : (const void*)lat_zero16);
+        rf[j] = *(const uint2*)((live && q.pfeat.p) ? (const void*)((const h16_t*)q.pfeat.p + o_f + c0) : (const void*)lat_zero16);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c0 = (ct0 + j) * 16 + fg * 4;
-        union { uint4 u; lat_bf16x8 v; } a;
+        union { uint4 u; h16x8 v; } a;
         a.u = aw[j];
         lat_f32x4 acc = {bb[j].x, bb[j].y, bb[j].z, bb[j].w};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bfrag.v, acc, 0, 0, 0);
+        acc = mfma_h16(a.v, bfrag.v, acc, 0, 0, 0);
         if (valid && c0 < q.co) {
-          const float v0 = acc[0] + __uint_as_float(rh[j].x << 16) + __uint_as_float(rf[j].x << 16);
-          const float v1 = acc[1] + __uint_as_float(rh[j].x & 0xffff0000u) + __uint_as_float(rf[j].x & 0xffff0000u);
-          const float v2 = acc[2] + __uint_as_float(rh[j].y << 16) + __uint_as_float(rf[j].y << 16);
-          const float v3 = acc[3] + __uint_as_float(rh[j].y & 0xffff0000u) + __uint_as_float(rf[j].y & 0xffff0000u);
+          const float v0 = acc[0] + h_lo(rh[j].x) + h_lo(rf[j].x);
+          const float v1 = acc[1] + h_hi(rh[j].x) + h_hi(rf[j].x);
+          const float v2 = acc[2] + h_lo(rh[j].y) + h_lo(rf[j].y);
+          const float v3 = acc[3] + h_hi(rh[j].y) + h_hi(rf[j].y);
           uint2 o;
-          o.x = f2bf_pk(v0, v1); o.y = f2bf_pk(v2, v3);
-          *(uint2*)((bf16_t*)q.out.p + o_out + c0) = o;
+          o.x = f2h_pk(v0, v1); o.y = f2h_pk(v2, v3);
+          *(uint2*)((h16_t*)q.out.p + o_out + c0) = o;
         }
       }
     }
@@ -217,7 +216,7 @@ __global__ __launch_bounds__(512) void reparam_zproj_fwd_kernel(LatZpFwdP q) {  
 struct LatZpBwdP {
   LatBwdP l;
   View gh;            // grad of z_proj's output [n,h,w,co]
-  const bf16_t* wdg;  // z_proj data-gradient image of the z segment: rows 16 (z channel) x krow_dg, column = co
+  const h16_t* wdg;  // z_proj data-gradient image of the z segment: rows 16 (z channel) x krow_dg, column = co
   int co, krow_dg, groups;  // groups: 16-pixel groups in total
 };
 
@@ -254,11 +253,11 @@ __global__ __launch_bounds__(256) void reparam_zproj_bwd_kernel(LatZpBwdP q) {
     const int y = valid ? pix / p.w : 0, x = valid ? pix - y * p.w : 0;
     lat_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int o_g = off8(q.gh, b, y, x, 0);
-    const bf16_t* wl = q.wdg + (int64_t)fr * q.krow_dg + fg * 8;
+    const h16_t* wl = q.wdg + (int64_t)fr * q.krow_dg + fg * 8;
     const int ch = fg * 4;
     // element-wise operands of this lane's four z channels: requested now, consumed after the MFMAs
     auto ld4u = [&](const View& v, bool on) -> uint2 {
-      return *(const uint2*)((on && valid && v.p) ? (const void*)((const bf16_t*)v.p + off8(v, b, y, x, ch)) : (const void*)lat_zero16);
+      return *(const uint2*)((on && valid && v.p) ? (const void*)((const h16_t*)v.p + off8(v, b, y, x, ch)) : (const void*)lat_zero16);
     };
     const uint2 u_ql = ld4u(p.q_loc, true), u_qs = ld4u(p.q_ls, true), u_pl = ld4u(p.p_loc, true), u_ps = ld4u(p.p_ls, true), u_z = ld4u(p.z, true);
     const uint2 u_gz = ld4u(p.gz, true);
@@ -271,24 +270,24 @@ __global__ __launch_bounds__(256) void reparam_zproj_bwd_kernel(LatZpBwdP q) {
         const int ks = min(ks0 + j, nks - 1);
         const int c = (ks0 + j) * 32 + fg * 8;
         aw[j] = *(const uint4*)(wl + ks * 32);  // (the image is zero beyond co: its row length is padded by 32)
-        bw[j] = *(const uint4*)((valid && c < q.co) ? (const void*)((const bf16_t*)q.gh.p + o_g + c) : (const void*)lat_zero16);
+        bw[j] = *(const uint4*)((valid && c < q.co) ? (const void*)((const h16_t*)q.gh.p + o_g + c) : (const void*)lat_zero16);
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        union { uint4 u; lat_bf16x8 v; } a, bq;
+        union { uint4 u; h16x8 v; } a, bq;
         a.u = aw[j]; bq.u = bw[j];
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bq.v, acc, 0, 0, 0);  // (steps past nks multiply by a zero fragment)
+        acc = mfma_h16(a.v, bq.v, acc, 0, 0, 0);  // (steps past nks multiply by a zero fragment)
       }
     }
     if (!valid) continue;
     auto un4 = [](const uint2 t, float (&o)[4]) {
-      o[0] = __uint_as_float(t.x << 16); o[1] = __uint_as_float(t.x & 0xffff0000u);
-      o[2] = __uint_as_float(t.y << 16); o[3] = __uint_as_float(t.y & 0xffff0000u);
+      o[0] = h_lo(t.x); o[1] = h_hi(t.x);
+      o[2] = h_lo(t.y); o[3] = h_hi(t.y);
     };
     auto st4f = [&](const View& v, const float (&o)[4]) {
       uint2 t;
-      t.x = f2bf_pk(o[0], o[1]); t.y = f2bf_pk(o[2], o[3]);
-      *(uint2*)((bf16_t*)v.p + off8(v, b, y, x, ch)) = t;
+      t.x = f2h_pk(o[0], o[1]); t.y = f2h_pk(o[2], o[3]);
+      *(uint2*)((h16_t*)v.p + off8(v, b, y, x, ch)) = t;
     };
     float ql[4], qs[4], pl[4], ps[4], zv[4], gz[4] = {acc[0], acc[1], acc[2], acc[3]};
     un4(u_ql, ql); un4(u_qs, qs); un4(u_pl, pl); un4(u_ps, ps); un4(u_z, zv);
@@ -434,7 +433,7 @@ extern "C" int cgen_reparam_kl_fwd(int32_t dtype, int32_t n, int32_t h, int32_t 
                                    cgen_view p_loc, cgen_view p_ls, cgen_view eps_in, const uint64_t* rng, uint32_t stream_id,
                                    float logt, cgen_view z, cgen_view eps_out, float* kl_part, int32_t kl_stride,
                                    cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_reparam_kl_fwd: bad dtype");
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_reparam_kl_fwd: bad dtype");
   CGEN_REQUIRE(q_loc.p && q_ls.p && p_loc.p && p_ls.p && z.p && kl_part, "cgen_reparam_kl_fwd: null view");
   CGEN_REQUIRE(eps_in.p || rng, "cgen_reparam_kl_fwd: need eps or rng");
   LatP p;
@@ -445,7 +444,7 @@ extern "C" int cgen_reparam_kl_fwd(int32_t dtype, int32_t n, int32_t h, int32_t 
   dim3 grid(cgen_reparam_kl_chunks(h, w, c), n);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(reparam_kl_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
   else if (lat_vec8_ok(n, c, {q_loc, q_ls, p_loc, p_ls, eps_in, z, eps_out})) hipLaunchKernelGGL(reparam_kl_fwd_vec8_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(reparam_kl_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(reparam_kl_fwd_kernel<h16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("cgen_reparam_kl_fwd");
 }
 
@@ -454,7 +453,7 @@ static int reparam_kl_bwd_impl(int32_t dtype, int32_t n, int32_t h, int32_t w, i
                                const float* kl_chan_scale, cgen_view g_q_loc, cgen_view g_q_ls, cgen_view g_p_loc, cgen_view g_p_ls,
                                int32_t acc_q, int32_t acc_p, const cgen_view* ride_src, const cgen_view* ride_dst, int32_t ride_acc,
                                cgen_stream_t stream, const char* who) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "%s: bad dtype", who);
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "%s: bad dtype", who);
   CGEN_REQUIRE(q_loc.p && q_ls.p && p_loc.p && p_ls.p && kl_coef_dev && g_q_loc.p && g_q_ls.p && g_p_loc.p && g_p_ls.p, "%s: null view", who);
   CGEN_REQUIRE(!gz.p || z.p, "%s: gz given without z", who);
   LatBwdP p;
@@ -464,7 +463,7 @@ static int reparam_kl_bwd_impl(int32_t dtype, int32_t n, int32_t h, int32_t w, i
   p.g_q_loc = mk(g_q_loc); p.g_q_ls = mk(g_q_ls); p.g_p_loc = mk(g_p_loc); p.g_p_ls = mk(g_p_ls);
   p.coef = kl_coef_dev; p.chan_scale = kl_chan_scale; p.coef_stride = coef_stride; p.acc_q = acc_q; p.acc_p = acc_p; p.logt = logt;
   const int grid = lat_grid((int64_t)n * h * w * c);
-  const bool vec8 = dtype == CGEN_BF16 && lat_vec8_ok(n, c, {q_loc, q_ls, p_loc, p_ls, z, gz, g_q_loc, g_q_ls, g_p_loc, g_p_ls});
+  const bool vec8 = dtype == CGEN_F16 && lat_vec8_ok(n, c, {q_loc, q_ls, p_loc, p_ls, z, gz, g_q_loc, g_q_ls, g_p_loc, g_p_ls});
   if (ride_src) {
     CGEN_REQUIRE(vec8 && ride_dst && ride_src->p && ride_dst->p && ride_src->c == ride_dst->c && ride_src->c % 8 == 0 &&
                      lat_vec8_ok(n, ride_src->c, {*ride_src, *ride_dst}),
@@ -476,7 +475,7 @@ static int reparam_kl_bwd_impl(int32_t dtype, int32_t n, int32_t h, int32_t w, i
     p.main_blocks = lat_grid((int64_t)n * h * w * c / 8);
     const int ride_blocks = ride_src ? lat_grid((int64_t)n * h * w * ride_src->c / 8) : 0;
     hipLaunchKernelGGL(reparam_kl_bwd_vec8_kernel, dim3(p.main_blocks + ride_blocks), dim3(256), 0, (hipStream_t)stream, p);
-  } else hipLaunchKernelGGL(reparam_kl_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  } else hipLaunchKernelGGL(reparam_kl_bwd_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch(who);
 }
 
@@ -504,7 +503,7 @@ static inline bool lat_v8(const cgen_view& v) {  // 8-byte vector access on a bf
 }
 
 extern "C" int cgen_latent_zproj_supported(const cgen_latent_zproj_args* a) {
-  if (!a || a->dtype != CGEN_BF16 || a->c != 16 || a->n <= 0 || a->h <= 0 || a->w <= 0 || a->co <= 0 || a->co % 4) return 0;
+  if (!a || a->dtype != CGEN_F16 || a->c != 16 || a->n <= 0 || a->h <= 0 || a->w <= 0 || a->co <= 0 || a->co % 4) return 0;
   const int pa8 = a->pa.p ? (a->pa.c + 7) / 8 * 8 : 0;
   if (pa8 > 16 || (a->pa.p && !(a->pa.c % 8 == 0 || a->pa.cpad >= pa8))) return 0;
   if (!lat_vec8_ok(a->n, 16, {a->q_loc, a->q_ls, a->p_loc, a->p_ls, a->eps_in, a->z, a->eps_out})) return 0;
@@ -529,7 +528,7 @@ extern "C" int cgen_latent_zproj_fwd(const cgen_latent_zproj_args* a, cgen_strea
   p.eps_in = mk(a->eps_in); p.z = mk(a->z); p.eps_out = mk(a->eps_out);
   p.rng = a->rng; p.stream_id = a->stream_id; p.logt = a->logt; p.kl_part = a->kl_part; p.kl_stride = a->kl_stride;
   q.pa = mk(a->pa); q.hres = mk(a->hres); q.pfeat = mk(a->pfeat); q.out = mk(a->out);
-  q.w = (const bf16_t*)a->w_fwd; q.bias = a->bias; q.co = a->co;
+  q.w = (const h16_t*)a->w_fwd; q.bias = a->bias; q.co = a->co;
   const int pa8 = a->pa.p ? (a->pa.c + 7) / 8 * 8 : 0;
   q.pa_groups = pa8 / 8;
   q.krow = ((16 + pa8 + 31) / 32) * 32 + 32;
@@ -550,7 +549,7 @@ extern "C" int cgen_latent_zproj_bwd(const cgen_latent_zproj_args* a, cgen_strea
   p.q_loc = mk(a->q_loc); p.q_ls = mk(a->q_ls); p.p_loc = mk(a->p_loc); p.p_ls = mk(a->p_ls); p.z = mk(a->z); p.gz = mk(a->gz);
   p.g_q_loc = mk(a->g_q_loc); p.g_q_ls = mk(a->g_q_ls); p.g_p_loc = mk(a->g_p_loc); p.g_p_ls = mk(a->g_p_ls);
   p.coef = a->kl_coef_dev; p.chan_scale = a->kl_chan_scale; p.coef_stride = a->coef_stride; p.acc_q = a->acc_q; p.acc_p = a->acc_p; p.logt = a->logt;
-  q.gh = mk(a->gout); q.wdg = (const bf16_t*)a->w_dgrad; q.co = a->co;
+  q.gh = mk(a->gout); q.wdg = (const h16_t*)a->w_dgrad; q.co = a->co;
   q.krow_dg = (((a->co + 7) / 8 * 8) + 31) / 32 * 32 + 32;
   const int gps = (a->h * a->w + 15) / 16;
   q.groups = a->n * gps;
@@ -569,26 +568,26 @@ extern "C" int cgen_latent_zproj_bwd(const cgen_latent_zproj_args* a, cgen_strea
 extern "C" int cgen_sample_gaussian(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view loc, cgen_view ls,
                                     cgen_view eps_in, const uint64_t* rng, uint32_t stream_id, float logt, cgen_view z,
                                     cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_sample_gaussian: bad dtype");
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_sample_gaussian: bad dtype");
   CGEN_REQUIRE(loc.p && ls.p && z.p && (eps_in.p || rng), "cgen_sample_gaussian: bad args");
   const int grid = lat_grid((int64_t)n * h * w * c);
   if (dtype == CGEN_F32)
     hipLaunchKernelGGL(sample_gaussian_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(loc), mk(ls), mk(eps_in), rng, stream_id, logt, mk(z));
   else
-    hipLaunchKernelGGL(sample_gaussian_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(loc), mk(ls), mk(eps_in), rng, stream_id, logt, mk(z));
+    hipLaunchKernelGGL(sample_gaussian_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(loc), mk(ls), mk(eps_in), rng, stream_id, logt, mk(z));
   return check_launch("cgen_sample_gaussian");
 }
 
 extern "C" int cgen_mediator_mix(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view z, cgen_view q_loc,
                                  cgen_view q_ls, cgen_view p_loc, cgen_view p_ls, float alpha, float t, float logt,
                                  int32_t linear_var, cgen_view out, cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_mediator_mix: bad dtype");
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_mediator_mix: bad dtype");
   CGEN_REQUIRE(z.p && q_loc.p && q_ls.p && p_loc.p && p_ls.p && out.p, "cgen_mediator_mix: null view");
   const int grid = lat_grid((int64_t)n * h * w * c);
   if (dtype == CGEN_F32)
     hipLaunchKernelGGL(mediator_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(z), mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), alpha, t, logt, linear_var, mk(out));
   else
-    hipLaunchKernelGGL(mediator_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(z), mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), alpha, t, logt, linear_var, mk(out));
+    hipLaunchKernelGGL(mediator_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(z), mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), alpha, t, logt, linear_var, mk(out));
   return check_launch("cgen_mediator_mix");
 }
 
@@ -602,11 +601,11 @@ extern "C" int cgen_gaussian_kl_map(int64_t count, const float* q_loc, const flo
 
 extern "C" int cgen_kl_channel_sums(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls,
                                     cgen_view p_loc, cgen_view p_ls, float logt, float* out, int32_t out_stride, cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_kl_channel_sums: bad dtype");
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_kl_channel_sums: bad dtype");
   CGEN_REQUIRE(q_loc.p && q_ls.p && p_loc.p && p_ls.p && out && out_stride >= c, "cgen_kl_channel_sums: bad args");
   CGEN_REQUIRE(c >= 1 && c <= 256 && 256 % c == 0, "cgen_kl_channel_sums: the latent width must divide 256 (got %d)", c);
   using namespace cgen;
   if (dtype == CGEN_F32) hipLaunchKernelGGL(kl_channel_sums_kernel<float>, dim3(n), dim3(256), 0, (hipStream_t)stream, h, w, c, mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), logt, out, out_stride);
-  else hipLaunchKernelGGL(kl_channel_sums_kernel<bf16_t>, dim3(n), dim3(256), 0, (hipStream_t)stream, h, w, c, mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), logt, out, out_stride);
+  else hipLaunchKernelGGL(kl_channel_sums_kernel<h16_t>, dim3(n), dim3(256), 0, (hipStream_t)stream, h, w, c, mk(q_loc), mk(q_ls), mk(p_loc), mk(p_ls), logt, out, out_stride);
   return check_launch("cgen_kl_channel_sums");
 }

@@ -632,75 +632,75 @@ extern "C" int cgen_like_chunks(int32_t h, int32_t w) { return ceil_div((int64_t
 
 extern "C" int cgen_dgauss_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x,
                                    float* nll_part, cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dgauss_nll_fwd: bad dtype");
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_dgauss_nll_fwd: bad dtype");
   CGEN_REQUIRE((c == 1 || c == 3) && params.p && x.p && nll_part && params.c >= 2 * c, "cgen_dgauss_nll_fwd: bad args");
   DgP p;
   memset(&p, 0, sizeof(p));
   p.n = n; p.h = h; p.w = w; p.c = c; p.ar = (c == 3 && params.c >= 9); p.params = mk(params); p.x = mk(x); p.part = nll_part;
   dim3 grid(cgen_like_chunks(h, w), n);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(dgauss_nll_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(dgauss_nll_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(dgauss_nll_fwd_kernel<h16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("cgen_dgauss_nll_fwd");
 }
 
 extern "C" int cgen_dgauss_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x,
                                    const float* coef_dev, int32_t coef_stride, cgen_view g_params, cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dgauss_nll_bwd: bad dtype");
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_dgauss_nll_bwd: bad dtype");
   CGEN_REQUIRE((c == 1 || c == 3) && params.p && x.p && coef_dev && g_params.p && params.c >= 2 * c && g_params.c >= (c == 3 && params.c >= 9 ? 9 : 2 * c), "cgen_dgauss_nll_bwd: bad args");
   DgP p;
   memset(&p, 0, sizeof(p));
   p.n = n; p.h = h; p.w = w; p.c = c; p.ar = (c == 3 && params.c >= 9); p.params = mk(params); p.x = mk(x); p.g = mk(g_params); p.coef = coef_dev; p.coef_stride = coef_stride;
   const int grid = like_grid((int64_t)n * h * w);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(dgauss_nll_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(dgauss_nll_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(dgauss_nll_bwd_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("cgen_dgauss_nll_bwd");
 }
 
 extern "C" int cgen_dgauss_sample(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, float logt,
                                   const uint64_t* rng, uint32_t stream_id, float* x_nchw, float* scale_nchw, cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dgauss_sample: bad dtype");
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_dgauss_sample: bad dtype");
   CGEN_REQUIRE((c == 1 || c == 3) && params.p && x_nchw && scale_nchw && params.c >= 2 * c, "cgen_dgauss_sample: bad args");
   const int ar = (c == 3 && params.c >= 9);
   const int grid = like_grid((int64_t)n * h * w);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(dgauss_sample_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, ar, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
-  else hipLaunchKernelGGL(dgauss_sample_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, ar, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
+  else hipLaunchKernelGGL(dgauss_sample_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, ar, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
   return check_launch("cgen_dgauss_sample");
 }
 
 extern "C" int cgen_dmol_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, cgen_view x, float* nll_part,
                                  cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dmol_nll_fwd: bad dtype");
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_dmol_nll_fwd: bad dtype");
   CGEN_REQUIRE(logits.p && x.p && nll_part && logits.c == 100 && x.c == 3, "cgen_dmol_nll_fwd: bad args");
   DmP p;
   memset(&p, 0, sizeof(p));
   p.n = n; p.h = h; p.w = w; p.logits = mk(logits); p.x = mk(x); p.part = nll_part;
   dim3 grid(cgen_like_chunks(h, w), n);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(dmol_nll_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(dmol_nll_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(dmol_nll_fwd_kernel<h16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("cgen_dmol_nll_fwd");
 }
 
 extern "C" int cgen_dmol_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, cgen_view x,
                                  const float* coef_dev, int32_t coef_stride, cgen_view g_logits, cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dmol_nll_bwd: bad dtype");
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_dmol_nll_bwd: bad dtype");
   CGEN_REQUIRE(logits.p && x.p && coef_dev && g_logits.p && logits.c == 100 && g_logits.c == 100, "cgen_dmol_nll_bwd: bad args");
   DmP p;
   memset(&p, 0, sizeof(p));
   p.n = n; p.h = h; p.w = w; p.logits = mk(logits); p.x = mk(x); p.g = mk(g_logits); p.coef = coef_dev; p.coef_stride = coef_stride;
   const int grid = like_grid((int64_t)n * h * w);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(dmol_nll_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(dmol_nll_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(dmol_nll_bwd_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("cgen_dmol_nll_bwd");
 }
 
 extern "C" int cgen_dmol_decode(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, int32_t mode,
                                 const uint64_t* rng, uint32_t stream_id, float logt, float* x_nchw, float* scale_nchw,
                                 cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_dmol_decode: bad dtype");
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_dmol_decode: bad dtype");
   CGEN_REQUIRE(logits.p && logits.c == 100 && x_nchw && scale_nchw && ((mode >= 0 && mode <= 2) || (mode >= 11 && mode <= 19)) && (mode != 2 || rng), "cgen_dmol_decode: bad args");
   const int grid = like_grid((int64_t)n * h * w);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(dmol_decode_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, mk(logits), mode, rng, stream_id, logt, x_nchw, scale_nchw);
-  else hipLaunchKernelGGL(dmol_decode_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, mk(logits), mode, rng, stream_id, logt, x_nchw, scale_nchw);
+  else hipLaunchKernelGGL(dmol_decode_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, mk(logits), mode, rng, stream_id, logt, x_nchw, scale_nchw);
   return check_launch("cgen_dmol_decode");
 }
 
@@ -724,14 +724,14 @@ extern "C" int cgen_cf_pixels(int64_t count, const float* x, const float* rec_lo
 extern "C" int cgen_cf_dgauss_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view rec_params, cgen_view cf_params,
                                   cgen_view x, const float* g_cfx_nchw, float gscale, cgen_view g_rec_params, cgen_view g_cf_params,
                                   cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_cf_dgauss_bwd: bad dtype");
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_cf_dgauss_bwd: bad dtype");
   CGEN_REQUIRE((c == 1 || c == 3) && rec_params.p && cf_params.p && x.p && g_cfx_nchw && g_rec_params.p && g_cf_params.p &&
                    rec_params.c >= 2 * c && cf_params.c == rec_params.c && g_rec_params.c == rec_params.c && g_cf_params.c == rec_params.c,
                "cgen_cf_dgauss_bwd: bad args");
   const int ar = (c == 3 && rec_params.c >= 9);
   const int grid = like_grid((int64_t)n * h * w);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(cf_dgauss_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, ar, mk(rec_params), mk(cf_params), mk(x), g_cfx_nchw, gscale, mk(g_rec_params), mk(g_cf_params));
-  else hipLaunchKernelGGL(cf_dgauss_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, ar, mk(rec_params), mk(cf_params), mk(x), g_cfx_nchw, gscale, mk(g_rec_params), mk(g_cf_params));
+  else hipLaunchKernelGGL(cf_dgauss_bwd_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, ar, mk(rec_params), mk(cf_params), mk(x), g_cfx_nchw, gscale, mk(g_rec_params), mk(g_cf_params));
   return check_launch("cgen_cf_dgauss_bwd");
 }
 
@@ -746,21 +746,21 @@ extern "C" int cgen_elbo_finalize_fb(int32_t n, const float* nll_part, int32_t n
 
 extern "C" int cgen_gauss_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x, cgen_view u,
                                   const uint64_t* rng, uint32_t stream_id, float* nll_part, cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_gauss_nll_fwd: bad dtype");
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_gauss_nll_fwd: bad dtype");
   CGEN_REQUIRE((c == 1 || c == 3) && params.p && x.p && nll_part && params.c >= 2 * c && (u.p || rng), "cgen_gauss_nll_fwd: bad args");
   GsP p;
   memset(&p, 0, sizeof(p));
   p.n = n; p.h = h; p.w = w; p.c = c; p.params = mk(params); p.x = mk(x); p.u = mk(u); p.rng = rng; p.stream_id = stream_id; p.part = nll_part;
   dim3 grid(cgen_like_chunks(h, w), n);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(gauss_nll_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(gauss_nll_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gauss_nll_fwd_kernel<h16_t>, grid, dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("cgen_gauss_nll_fwd");
 }
 
 extern "C" int cgen_gauss_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x, cgen_view u,
                                   const uint64_t* rng, uint32_t stream_id, const float* coef_dev, int32_t coef_stride,
                                   cgen_view g_params, cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_gauss_nll_bwd: bad dtype");
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_gauss_nll_bwd: bad dtype");
   CGEN_REQUIRE((c == 1 || c == 3) && params.p && x.p && coef_dev && g_params.p && params.c >= 2 * c && g_params.c >= 2 * c && (u.p || rng),
                "cgen_gauss_nll_bwd: bad args");
   GsP p;
@@ -769,16 +769,16 @@ extern "C" int cgen_gauss_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w
   p.coef = coef_dev; p.coef_stride = coef_stride;
   const int grid = like_grid((int64_t)n * h * w);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(gauss_nll_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(gauss_nll_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(gauss_nll_bwd_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("cgen_gauss_nll_bwd");
 }
 
 extern "C" int cgen_gauss_sample(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, float logt,
                                  const uint64_t* rng, uint32_t stream_id, float* x_nchw, float* scale_nchw, cgen_stream_t stream) {
-  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_BF16, "cgen_gauss_sample: bad dtype");
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_gauss_sample: bad dtype");
   CGEN_REQUIRE((c == 1 || c == 3) && params.p && x_nchw && scale_nchw && params.c >= 2 * c, "cgen_gauss_sample: bad args");
   const int grid = like_grid((int64_t)n * h * w);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(gauss_sample_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
-  else hipLaunchKernelGGL(gauss_sample_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
+  else hipLaunchKernelGGL(gauss_sample_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
   return check_launch("cgen_gauss_sample");
 }

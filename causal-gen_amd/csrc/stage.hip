@@ -34,7 +34,6 @@
 namespace cgen {
 
 typedef float st_f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 st_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short st_s16x2 __attribute__((ext_vector_type(2)));
 
 #define ST_THREADS 512
@@ -70,7 +69,7 @@ struct StConv {
   SView seg[CGEN_MAX_SEG];
   int seg_koff[CGEN_MAX_SEG];
   SView out, aux, res1, res2;
-  const bf16_t* w;
+  const h16_t* w;
   const float* bias;
   const char* next_w;  // weight image of the next conv of the list (L2 warm-up), or this op's own
   int next_w_bytes, pad1;
@@ -108,11 +107,9 @@ __device__ __forceinline__ uint4 st_act_group(uint4 v, const int act) {
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
   }
-  return gelu8_fwd_bf16(v);
+  return gelu8_fwd_h16(v);
 }
 
-__device__ __forceinline__ float st_bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float st_bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
 #define ST_STAMP(k) do { if (stamp) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 
@@ -198,7 +195,7 @@ __device__ __forceinline__ void st_conv(const OpW& ow, const char* __restrict__ 
   const int G = SI(G), T = SI(T), PW = SI(PW), TW = SI(TW), npp = SI(npp), ntp = SI(ntp), KC = SI(KC), woff = SI(woff), wslot = SI(wslot);
   const int dact = SI(dact), out_cpad = SI(out.cpad);
   const SDiv d_w = {(uint32_t)SI(d_w.mul), (uint32_t)SI(d_w.shift)};
-  const bf16_t* wimg = (const bf16_t*)SP(w);
+  const h16_t* wimg = (const h16_t*)SP(w);
   const float* bias = (const float*)SP(bias);
   const char* outp = SP(out.p) + (int64_t)n * SI(out.sn) * 2;
   const char* auxp0 = SP(aux.p);
@@ -231,7 +228,7 @@ __device__ __forceinline__ void st_conv(const OpW& ow, const char* __restrict__ 
         const int blk = f & 1, kp = (f >> 1) % KCP, j = (f >> 1) / KCP;
         const int row8 = min((tbase + j) * 16 + blk * 8, rows_pad - 8);            // (rows past the image: clamped, never stored)
         const int kst = min(c * KC + 2 * kp, ((nk + 1) & ~1) - 2);                  // (K-step pairs past the end: the last pair again, never used)
-        const bf16_t* src = wimg + ((int64_t)row8 * krow + k_lo + kst * 32 + wlane);
+        const h16_t* src = wimg + ((int64_t)row8 * krow + k_lo + kst * 32 + wlane);
         __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(dst + f * 1024), 16, 0, 0);
       }
     };
@@ -283,20 +280,20 @@ __device__ __forceinline__ void st_conv(const OpW& ow, const char* __restrict__ 
         for (int d = 0; d < nkc; ++d) {
           const int ks = c * KC + d;
           const int ko = *(const int*)(ktp + (ks * 4 + kg) * 4);
-          st_bf16x8 wfr[ST_TB];
+          h16x8 wfr[ST_TB];
 #pragma unroll
           for (int j = 0; j < ST_TB; ++j)
-            if (j < nt) wfr[j] = *(const st_bf16x8*)(cur + wtile + (j * KCP + (d >> 1)) * 2048 + (d & 1) * 512 + wrd);
-          st_bf16x8 a[ST_PB];
+            if (j < nt) wfr[j] = *(const h16x8*)(cur + wtile + (j * KCP + (d >> 1)) * 2048 + (d & 1) * 512 + wrd);
+          h16x8 a[ST_PB];
 #pragma unroll
           for (int i = 0; i < ST_PB; ++i)
-            if (i < np) a[i] = *(const st_bf16x8*)(imgp + (ko < 0 ? zoff : pbase[i] + ko));
+            if (i < np) a[i] = *(const h16x8*)(imgp + (ko < 0 ? zoff : pbase[i] + ko));
 #pragma unroll
           for (int i = 0; i < ST_PB; ++i)
             if (i < np) {
 #pragma unroll
               for (int j = 0; j < ST_TB; ++j)
-                if (j < nt) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[j], a[i], acc[i][j], 0, 0, 0);
+                if (j < nt) acc[i][j] = mfma_h16(wfr[j], a[i], acc[i][j], 0, 0, 0);
             }
         }
       };
@@ -332,7 +329,7 @@ __device__ __forceinline__ void st_conv(const OpW& ow, const char* __restrict__ 
           if (co + 4 <= Co) {
             if (auxp) {
               const uint2 a2 = ea[i][j];
-              const float av[4] = {st_bf_lo(a2.x), st_bf_hi(a2.x), st_bf_lo(a2.y), st_bf_hi(a2.y)};
+              const float av[4] = {h_lo(a2.x), h_hi(a2.x), h_lo(a2.y), h_hi(a2.y)};
               if (dact == CGEN_ACT_RELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = av[e] > 0.f ? v[e] : 0.f;
@@ -347,14 +344,14 @@ __device__ __forceinline__ void st_conv(const OpW& ow, const char* __restrict__ 
             }
             if (r1p) {
               const uint2 t = er1[i][j];
-              v[0] += st_bf_lo(t.x); v[1] += st_bf_hi(t.x); v[2] += st_bf_lo(t.y); v[3] += st_bf_hi(t.y);
+              v[0] += h_lo(t.x); v[1] += h_hi(t.x); v[2] += h_lo(t.y); v[3] += h_hi(t.y);
             }
             if (r2p) {
               const uint2 t = er2[i][j];
-              v[0] += st_bf_lo(t.x); v[1] += st_bf_hi(t.x); v[2] += st_bf_lo(t.y); v[3] += st_bf_hi(t.y);
+              v[0] += h_lo(t.x); v[1] += h_hi(t.x); v[2] += h_lo(t.y); v[3] += h_hi(t.y);
             }
             uint2 o;
-            o.x = f2bf_pk(v[0], v[1]); o.y = f2bf_pk(v[2], v[3]);
+            o.x = f2h_pk(v[0], v[1]); o.y = f2h_pk(v[2], v[3]);
             *(uint2*)(outp + o_out + co * 2) = o;
           } else {  // ragged width: element by element; channels [Co, out.cpad) are written as zeros
             const int o_aux = (py[i] * aux_sh + px[i] * aux_sw) * 2, o_r1 = (py[i] * r1_sh + px[i] * r1_sw) * 2, o_r2 = (py[i] * r2_sh + px[i] * r2_sw) * 2;
@@ -363,12 +360,12 @@ __device__ __forceinline__ void st_conv(const OpW& ow, const char* __restrict__ 
               const int ce = co + e;
               if (ce < Co) {
                 float u = v[e];
-                if (auxp) u *= act_bwd(dact, bf2f(*(const bf16_t*)(auxp + o_aux + ce * 2)));
-                if (r1p) u += bf2f(*(const bf16_t*)(r1p + o_r1 + ce * 2));
-                if (r2p) u += bf2f(*(const bf16_t*)(r2p + o_r2 + ce * 2));
-                *(bf16_t*)(outp + o_out + ce * 2) = f2bf(u);
+                if (auxp) u *= act_bwd(dact, h2f(*(const h16_t*)(auxp + o_aux + ce * 2)));
+                if (r1p) u += h2f(*(const h16_t*)(r1p + o_r1 + ce * 2));
+                if (r2p) u += h2f(*(const h16_t*)(r2p + o_r2 + ce * 2));
+                *(h16_t*)(outp + o_out + ce * 2) = f2h(u);
               } else if (ce < out_cpad) {
-                *(bf16_t*)(outp + o_out + ce * 2) = 0;
+                *(h16_t*)(outp + o_out + ce * 2) = 0;
               }
             }
           }
@@ -386,7 +383,7 @@ __device__ __forceinline__ View st_shift(View v, const int n) {
 
 template <int V>
 __device__ __forceinline__ void st_elem(const int kind, const StElem& e, const int n) {
-  typedef bf16_t T;
+  typedef h16_t T;
   const int64_t g0 = threadIdx.x, gs = ST_THREADS;
   const View in = st_shift(e.in, n), out = st_shift(e.out, n);
   switch (kind) {
@@ -510,8 +507,9 @@ static int stage_budget() {
 // fills `o` (without the K-step table); returns the LDS bytes the conv needs, 0 when the op is not served
 static int plan_conv(const cgen_conv_args* a, StConv& o, std::vector<int>* ktab) {
   memset(&o, 0, sizeof(o));
-  if (a->dtype != CGEN_BF16 || (a->ks != 1 && a->ks != 3) || a->nseg < 1 || a->nseg > CGEN_MAX_SEG || a->n < 1 || a->h < 1 || a->w < 1) return 0;
+  if (a->dtype != CGEN_F16 || (a->ks != 1 && a->ks != 3) || a->nseg < 1 || a->nseg > CGEN_MAX_SEG || a->n < 1 || a->h < 1 || a->w < 1) return 0;
   if (!a->weight || !a->out.p || a->out.c < 1) return 0;
+  if (a->out_rem || a->res1_rem) return 0;  // (remainder planes of the f16 residual trunk: the stand-alone kernels serve those)
   o.H = a->h; o.W = a->w; o.KS = a->ks; o.halo = a->ks / 2; o.nseg = a->nseg; o.act = a->act; o.dact = a->dact; o.Co = a->out.c;
   int c8 = 0;
   for (int s = 0; s < a->nseg; ++s) {
@@ -550,7 +548,7 @@ static int plan_conv(const cgen_conv_args* a, StConv& o, std::vector<int>* ktab)
   o.G = (o.HW + 15) / 16;
   o.T = (o.Co + 15) / 16;
   if ((int64_t)o.G * o.T * o.nk > stage_budget()) return 0;  // too much work for one CU per image: a chip-wide launch is faster
-  o.w = (const bf16_t*)a->weight;
+  o.w = (const h16_t*)a->weight;
   o.bias = a->bias;
   o.next_w = (const char*)a->weight;  // (cgen_stage_plan points it at the next conv of the list)
   o.next_w_bytes = 0;
@@ -612,7 +610,7 @@ static inline float inv_scale(int out, int in) { return (float)(1.0 / ((double)o
 
 static int plan_elem(int kind, const cgen_stage_elem_args* a, StElem& o) {
   memset(&o, 0, sizeof(o));
-  if (a->dtype != CGEN_BF16 || a->n < 1 || !a->out.p) return 0;
+  if (a->dtype != CGEN_F16 || a->n < 1 || !a->out.p) return 0;
   const int c = a->out.c;
   int ih = a->h, iw = a->w;  // the tensor the body iterates over
   switch (kind) {
@@ -647,7 +645,7 @@ static bool lat_ok(int n, int c, std::initializer_list<cgen_view> vs) {
 }
 
 static int plan_reparam(const cgen_stage_reparam_args* a, LatP& p) {
-  if (a->dtype != CGEN_BF16 || !(a->q_loc.p && a->q_ls.p && a->p_loc.p && a->p_ls.p && a->z.p && a->kl_part) || !(a->eps_in.p || a->rng)) return 0;
+  if (a->dtype != CGEN_F16 || !(a->q_loc.p && a->q_ls.p && a->p_loc.p && a->p_ls.p && a->z.p && a->kl_part) || !(a->eps_in.p || a->rng)) return 0;
   if (!lat_ok(a->n, a->c, {a->q_loc, a->q_ls, a->p_loc, a->p_ls, a->eps_in, a->z})) return 0;
   memset(&p, 0, sizeof(p));
   p.n = a->n; p.h = a->h; p.w = a->w; p.c = a->c;
@@ -658,7 +656,7 @@ static int plan_reparam(const cgen_stage_reparam_args* a, LatP& p) {
 }
 
 static int plan_reparam_bwd(const cgen_stage_reparam_bwd_args* a, LatBwdP& p) {
-  if (a->dtype != CGEN_BF16 || !(a->q_loc.p && a->q_ls.p && a->p_loc.p && a->p_ls.p && a->kl_coef_dev && a->g_q_loc.p && a->g_q_ls.p && a->g_p_loc.p && a->g_p_ls.p)) return 0;
+  if (a->dtype != CGEN_F16 || !(a->q_loc.p && a->q_ls.p && a->p_loc.p && a->p_ls.p && a->kl_coef_dev && a->g_q_loc.p && a->g_q_ls.p && a->g_p_loc.p && a->g_p_ls.p)) return 0;
   if (a->gz.p && !a->z.p) return 0;
   if (!lat_ok(a->n, a->c, {a->q_loc, a->q_ls, a->p_loc, a->p_ls, a->z, a->gz, a->g_q_loc, a->g_q_ls, a->g_p_loc, a->g_p_ls})) return 0;
   memset(&p, 0, sizeof(p));

@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from .stage import StagedLib, StageMixin
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, BF16, F32, NULL_VIEW, UNARY_CLAMP_MIN, UNARY_LEAKY_RELU, View
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, F16, F32, NULL_VIEW, UNARY_CLAMP_MIN, UNARY_LEAKY_RELU, View
 
 _ALIGN = 256
 
@@ -72,7 +72,7 @@ class _Tape(list):
 
 class NT:
     """NHWC strided view (channel stride 1) -- the Python twin of cgen_view."""
-    __slots__ = ("ptr", "n", "h", "w", "c", "sn", "sh", "sw", "base", "coff", "rg", "keep", "_cv", "es", "cpad", "bsrc")
+    __slots__ = ("ptr", "n", "h", "w", "c", "sn", "sh", "sw", "base", "coff", "rg", "keep", "_cv", "es", "cpad", "bsrc", "rem")
 
     def __init__(self, ptr, n, h, w, c, sn, sh, sw, es, base=None, coff=0, rg=True, keep=None):
         self.ptr, self.n, self.h, self.w, self.c = ptr, n, h, w, c
@@ -81,6 +81,9 @@ class NT:
         self.coff, self.rg, self.keep, self._cv = coff, rg, keep, None
         self.cpad = 0  # channels [c, cpad) are guaranteed zero (see cgen_view.cpad)
         self.bsrc = None  # the [n,1,1,c] tensor this one broadcasts over H x W (row / pixel strides 0), else None
+        # f16 residual trunk: byte offset of the REMAINDER plane (same layout; value = this + remainder, include/cgen_hip.h
+        # cgen_conv_args.out_rem), 0 = none.  Only residual epilogues read it; a conv input is the 16-bit tensor alone.
+        self.rem = 0
 
     def broadcast(self, h, w):
         """A [n,1,1,c] tensor seen as [n,h,w,c] with row and pixel stride 0: spatially constant parents without the
@@ -104,6 +107,7 @@ class NT:
                base=self.base, coff=self.coff + a, rg=self.rg, keep=self.keep)
         if b == self.c and self.cpad:  # a view that ends where the tensor ends keeps its zero padding
             v.cpad = self.cpad - a
+        v.rem = self.rem
         return v
 
     def crop(self, r):
@@ -187,10 +191,17 @@ class Engine(StageMixin):
         assert self.device.type == "cuda"
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.dt = {"f32": F32, "bf16": BF16}[dtype]
+        self.dt = {"f32": F32, "f16": F16}[dtype]
         self.dtype_name = dtype
         self.es = 4 if self.dt == F32 else 2
-        self.tdtype = torch.float32 if self.dt == F32 else torch.bfloat16
+        self.tdtype = torch.float32 if self.dt == F32 else torch.float16
+        # f16 engine: activation GRADIENTS are carried times a power-of-two loss scale so that they sit in binary16's normal
+        # range (the seeds are ~1 / (B * dims) ~ 1e-6); the kernels that turn them into f32 parameter gradients (the split-K
+        # reduce, the batch reduce of the decoder biases) multiply by 1 / scale.  Exact: scaling by 2^k commutes with rounding.
+        # Set per backward pass by set_loss_scale(B * dims); 1 for the f32 engine.
+        self.loss_scale = 1.0
+        # f16 engine: the residual trunk as (value, remainder) pairs -- see conv(trunk=True); CGEN_TRUNK_REM=0 switches it off
+        self.trunk_rem = self.dt != F32 and os.environ.get("CGEN_TRUNK_REM", "1") != "0"
         self.arena = Arena(self.device)
         self.tape, self.recording = _Tape(), False
         self.tape.eng = self
@@ -260,6 +271,18 @@ class Engine(StageMixin):
         self.early_final = None
         self._stage_init(rawlib)
 
+    def set_loss_scale(self, n_terms):
+        """Loss scale of the coming backward pass: the seeds are O(1 / n_terms) (n_terms = batch * dims * accumulation steps);
+        2^k with k = round(log2 n_terms) - 4 puts them at ~1/16 per pixel, ~20 binades below overflow and ~20 above the
+        subnormals.  ``CGEN_LOSS_SCALE_LOG2`` overrides k."""
+        if self.dt == F32:
+            self.loss_scale = 1.0
+        else:
+            k = os.environ.get("CGEN_LOSS_SCALE_LOG2")
+            k = int(k) if k is not None else max(0, int(round(math.log2(max(float(n_terms), 1.0)))) - 4)
+            self.loss_scale = float(2 ** k)
+        return self.loss_scale
+
     # ------------------------------------------------------------------ memory
     def begin(self):
         """Start a new step/pass: recycle the arena, clear the tape and gradient bookkeeping."""
@@ -283,13 +306,18 @@ class Engine(StageMixin):
         self.passes = 0
         self.stream = torch.cuda.current_stream(self.device).cuda_stream
 
-    def new(self, n, h, w, c, rg=True, es=None):
+    def new(self, n, h, w, c, rg=True, es=None, rem=False):
         """Fresh NHWC tensor.  The pixel stride is rounded up to 8 channels so every pixel starts on a 16-byte
-        boundary (16-byte vector / LDS-DMA access needs it); the padding channels are never read as data."""
+        boundary (16-byte vector / LDS-DMA access needs it); the padding channels are never read as data.
+        `rem`: with a remainder plane behind it (f16 residual trunk)."""
         es = self.es if es is None else es
         cp = _ceil(c, 8)
-        ptr = self.arena.alloc(n * h * w * cp * es)
-        return NT(ptr, n, h, w, c, h * w * cp, w * cp, cp, es, rg=rg)
+        nbytes = _ceil(n * h * w * cp * es, _ALIGN)
+        ptr = self.arena.alloc(nbytes * (2 if rem else 1))
+        t = NT(ptr, n, h, w, c, h * w * cp, w * cp, cp, es, rg=rg)
+        if rem:
+            t.rem = nbytes
+        return t
 
     def new_f32(self, count):
         return self.arena.alloc(count * 4)
@@ -493,12 +521,16 @@ class Engine(StageMixin):
         return self.flat_g[o:o + p.numel()].view(p.shape)
 
     # ------------------------------------------------------------------ forward ops
-    def conv(self, site, segs, act=ACT_NONE, res1=None, res2=None, out=None, tape_hold=None):
+    def conv(self, site, segs, act=ACT_NONE, res1=None, res2=None, out=None, tape_hold=None, trunk=False):
         """`tape_hold` (a list): the backward entry goes there instead of onto the tape -- for an op that is LAUNCHED early (on
-        the side stream) but keeps its place in the backward order (the caller extends the tape with the list later)."""
+        the side stream) but keeps its place in the backward order (the caller extends the tape with the list later).
+        `trunk`: the result is the next value of the residual trunk (h = h + f(h)): on the f16 engine it gets a remainder
+        plane, and a `res1` that has one is added with it (value = hi + remainder, ~22 significant bits)."""
         x0 = segs[0]
+        if res2 is not None and res2.rem and (res1 is None or not res1.rem):
+            res1, res2 = res2, res1  # (only res1 carries a remainder plane)
         if out is None:
-            out = self.new(x0.n, x0.h, x0.w, site.co)
+            out = self.new(x0.n, x0.h, x0.w, site.co, rem=trunk and self.trunk_rem)
             if site.co % 8:  # ragged width (e.g. the 4-channel bottleneck of a 16-wide Block): the kernel zero-fills the
                 out.cpad = _ceil(site.co, 8)  # padding channels, which keeps the tensor DMA-clean for its consumers
         assert out.c == site.co and len(segs) == len(site.seg_c)
@@ -515,6 +547,8 @@ class Engine(StageMixin):
         a.aux = NULL_VIEW
         a.res1 = vw(res1)
         a.res2 = vw(res2)
+        a.out_rem = out.rem
+        a.res1_rem = res1.rem if res1 is not None else 0
         self._timed("conv_fwd", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream))
         if self.recording:
             if self._dbg_names is not None:
@@ -522,15 +556,16 @@ class Engine(StageMixin):
             (self.tape if tape_hold is None else tape_hold).append((self._bw_conv, (site, segs, act, out, res1, res2), self._in_side))
         return out
 
-    def block2(self, site1, site2, segs, act, res1=None):
+    def block2(self, site1, site2, segs, act, res1=None, trunk=False):
         """A whole light Block -- conv3x3(act(cat segs)) -> conv3x3(act(.)) (+ res1), vae.py:60-71,73-84 -- as ONE launch when
         the fused kernel serves the shape (bf16, >= blk_minres pixels wide, concat width a multiple of 32, bottleneck <= 32),
         else as the two conv launches.  The bottleneck tensor is written either way (weight gradients, backward mask), so
         the tape is the same."""
         x0 = segs[0]
         a = None
-        if (self.blk_fuse and self.dt == BF16 and act == ACT_RELU and site1.ks == 3 and site2.ks == 3 and len(segs) <= 3
-                and min(x0.h, x0.w) >= self.blk_minres):
+        wants_rem = self.trunk_rem and (trunk or (res1 is not None and res1.rem))  # (the fused kernel knows no remainder planes)
+        if (self.blk_fuse and self.dt == F16 and act == ACT_RELU and site1.ks == 3 and site2.ks == 3 and len(segs) <= 3
+                and min(x0.h, x0.w) >= self.blk_minres and not wants_rem):
             a = _lib.BlockArgs()
             a.dtype, a.n, a.h, a.w, a.mode, a.nseg, a.pre_act = self.dt, x0.n, x0.h, x0.w, 0, len(segs), 1
             a.tile_h = 4 if max(x0.h, x0.w) <= self.blk_th4_maxres else 8
@@ -556,7 +591,7 @@ class Engine(StageMixin):
                 return out
             # (the two tensors just allocated are simply not used: the arena is reset per step)
         t = self.conv(site1, segs, act)
-        return self.conv(site2, [t], act, res1=res1)
+        return self.conv(site2, [t], act, res1=res1, trunk=trunk)
 
     def _timed(self, kind, site, x0, fn, ci=None):
         """Launch `fn`; when profiling, bracket it with events on the launch stream and tally algorithmic FLOPs
@@ -709,7 +744,7 @@ class Engine(StageMixin):
         reparameterisation leaves in registers is the MFMA operand of the 1x1 conv).  Returns (z, h') or None when the shape
         is not served (then the caller issues the two launches).  The tape gets the same two entries; the backward pass then
         folds z_proj's data gradient w.r.t. z into the reparameterisation kernel as well."""
-        if not (self.lat_fuse and self.dt == BF16 and site.ks == 1 and q_loc.c == 16 and len(site.seg_c) == 2 and site.seg_c[0] == 16
+        if not (self.lat_fuse and not self.trunk_rem and self.dt == F16 and site.ks == 1 and q_loc.c == 16 and len(site.seg_c) == 2 and site.seg_c[0] == 16
                 and site.seg_rg[0] and not site.seg_rg[1]):
             return None
         a = _lib.LatentZprojArgs()
@@ -994,7 +1029,7 @@ class Engine(StageMixin):
 
     def grad_add(self, t, g, may_ride=False):
         gv, acc = self.grad_write(t)
-        if (may_ride and self.ride and self.dt == BF16 and self._defer_wgrad() and t.base is not t and id(t.base) not in self._riders
+        if (may_ride and self.ride and self.dt == F16 and self._defer_wgrad() and t.base is not t and id(t.base) not in self._riders
                 and t.c % 8 == 0 and self._v16(gv) and self._v16(g) and id(self.grads[id(t.base)][0]) not in self._adopted):
             # channel slice of a wider gradient buffer (the prior Block's output): the copy rides on the reparam backward
             # that writes the neighbouring channels (grad buffers are immutable under deferral, so `g` can wait)
@@ -1453,7 +1488,7 @@ class Engine(StageMixin):
         for site, _, _ in events:  # a site used before in this pass accumulates
             flags.append(site.index in self._wg_seen)
             self._wg_seen.add(site.index)
-        sig = (tuple(k for _, k, _ in events), tuple(flags))
+        sig = (tuple(k for _, k, _ in events), tuple(flags), self.loss_scale)
         tab = self._red_tabs.get(sig)
         if tab is None:
             descs, csite, cidx = [], [], []
@@ -1467,6 +1502,7 @@ class Engine(StageMixin):
                 d.grad_b = self.param_grad_ptr(site.conv.bias) if site.conv.bias is not None else None
                 d.co, d.ci_total, d.ks, d.nsplit = site.co, site.ci, site.ks, nsplit
                 d.accumulate = 1 if acc else 0
+                d.unscale = 1.0 / self.loss_scale
                 d.numel = nw + (site.co if site.conv.bias is not None else 0)
                 descs.append(d)
             for i, d in enumerate(descs):
@@ -1509,7 +1545,7 @@ class Engine(StageMixin):
                 self._pgrad_tmp[id(param)] = ent
             dst = ent[1]
         self._bw_touch(dst, True)  # (both strands upsample with the same bias parameter)
-        self.lib.batch_reduce(self.dt, g.n, g.h, g.w, g.cv(), dst, 1 if acc else 0, self.stream)
+        self.lib.batch_reduce(self.dt, g.n, g.h, g.w, g.cv(), dst, 1 if acc else 0, 1.0 / self.loss_scale, self.stream)
         self.launches += 1
         self.pgrad_init.add(id(param))
 

@@ -16,7 +16,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (BF16, NULL_VIEW, ST_AVGPOOL_BWD, ST_AVGPOOL_FWD, ST_AXPBY, ST_BCAST, ST_CONV, ST_REPARAM_BWD, ST_REPARAM_FWD,
+from ._lib import (F16, NULL_VIEW, ST_AVGPOOL_BWD, ST_AVGPOOL_FWD, ST_AXPBY, ST_BCAST, ST_CONV, ST_REPARAM_BWD, ST_REPARAM_FWD,
                    ST_UPSAMPLE_BWD, ST_UPSAMPLE_FWD, StageElemArgs, StageReparamArgs, StageReparamBwdArgs)
 
 # entry points that answer on the host and launch nothing
@@ -150,7 +150,7 @@ class StageMixin:
 
     @property
     def stage_active(self):
-        return self.stage_enabled and self.dt == BF16 and bool(self.stage_res) and not self.bwd_branch
+        return self.stage_enabled and self.dt == F16 and bool(self.stage_res) and not self.bwd_branch
 
     def stage_covers(self, res):
         """True when the ops of a layer at this resolution go into stage lists (the forward pass then keeps them on ONE stream:
@@ -162,7 +162,7 @@ class StageMixin:
         if got is None:
             return False
         kind, args, n, res = got
-        if res not in self.stage_res or args.dtype != BF16:
+        if res not in self.stage_res or args.dtype != F16:
             return False
         stream = a[-1]
         if not self._rawlib.stage_accepts(kind, C.addressof(args)):

@@ -161,13 +161,15 @@ class TrainStep:
         if ent is None:
             ent = self.coefs[(B, dims)] = [torch.zeros(3, device=self.eng.device), None]
         if ent[1] != beta:
-            ent[0].copy_(torch.tensor([1.0 / (B * dims * self.accu), beta / (B * dims * self.accu), beta], dtype=torch.float32))
+            S = self.eng.set_loss_scale(B * dims * self.accu)  # (1 for f32; divided out again by the parameter-gradient reduces)
+            ent[0].copy_(torch.tensor([S / (B * dims * self.accu), S * beta / (B * dims * self.accu), beta], dtype=torch.float32))
             ent[1] = beta
         return ent[0]
 
     def _fwd_bwd(self, x, pa, beta):
         m, eng = self.model, self.eng
         self.coef = self.coefs[(int(x.shape[0]), float(x[0].numel()))][0]  # written by step() before any capture / replay
+        eng.set_loss_scale(int(x.shape[0]) * float(x[0].numel()) * self.accu)
         m.__dict__["_beta_dev"] = self.coef.data_ptr() + 8
         try:
             out3 = m._run_forward(x, pa, beta, record=True)

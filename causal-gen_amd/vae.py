@@ -8,7 +8,7 @@ same module tree and therefore the same ``state_dict`` keys and the same default
 ``HVAE`` through ``engine.Engine`` as fused HIP launches (libcgen_hip.so); there is no ATen / CPU fallback.
 
 Layout: activations live NHWC in an arena; API tensors are accepted as NCHW (either memory format) and returned
-as NCHW-shaped tensors.  ``HVAE.compute_dtype`` selects "f32" (exact f32-MFMA path, parity) or "bf16".
+as NCHW-shaped tensors.  ``HVAE.compute_dtype`` selects "f32" (exact f32-MFMA path, parity) or "f16".
 """
 import math
 import os
@@ -79,7 +79,7 @@ def _stem_site(name, conv, index, dtype=None):
     """The 7x7 stem: a real 7x7 site when the direct kernel serves it (Engine.stem), else im2col + 1x1 over 49 * Cin channels."""
     lib = _lib.load()
     direct = (os.environ.get("CGEN_STEM_DIRECT", "1") != "0" and conv.kernel_size[0] == 7
-              and lib.stem_conv_supported(_lib.BF16 if dtype == "bf16" else _lib.F32, conv.in_channels, 7, conv.out_channels))
+              and lib.stem_conv_supported(_lib.F16 if dtype == "f16" else _lib.F32, conv.in_channels, 7, conv.out_channels))
     if direct:
         return ConvSite(name, conv, [conv.in_channels], [False], index)
     return ConvSite(name, conv, [conv.in_channels * conv.kernel_size[0] ** 2], [False], index, as_1x1=True)
@@ -124,12 +124,13 @@ def run_block(eng, blk, segs):
         else:
             res = x
     if blk.light and len(cs) == 2:  # the two 3x3 convs of a light Block: one fused launch where the kernel serves the shape
-        h = eng.block2(site(cs[0]), site(cs[1]), segs, act, res1=res)
+        h = eng.block2(site(cs[0]), site(cs[1]), segs, act, res1=res, trunk=blk.residual)
     else:
-        h = eng.conv(site(cs[0]), segs, act, res1=res if len(cs) == 1 else None)
+        # (a residual Block's last conv writes the next value of the trunk: h = x + f(x), vae.py:78)
+        h = eng.conv(site(cs[0]), segs, act, res1=res if len(cs) == 1 else None, trunk=blk.residual and len(cs) == 1)
         for j, c in enumerate(cs[1:]):
             last = j == len(cs) - 2
-            h = eng.conv(site(c), [h], act, res1=res if last else None)
+            h = eng.conv(site(c), [h], act, res1=res if last else None, trunk=blk.residual and last)
     if blk.d:
         h = eng.pool(h, blk.d)  # int: avg_pool2d; float: adaptive_avg_pool2d (vae.py:79-83)
     return h
@@ -151,7 +152,7 @@ def run_encoder(eng, enc, x):
 def _standalone_engine(mod, make_sites):
     """Engine of a holder module used on its own (``Block(...)(x)``, ``Encoder(args)(x)``, ``DGaussNet(args).predict(h)``):
     the reference's classes are importable and callable by themselves.  Inference only -- training runs through
-    ``HVAE``, whose engine owns the tape.  ``mod.compute_dtype`` ("f32" default, or "bf16") picks the kernels."""
+    ``HVAE``, whose engine owns the tape.  ``mod.compute_dtype`` ("f32" default, or "f16") picks the kernels."""
     dev = next(mod.parameters()).device
     dt = getattr(mod, "compute_dtype", "f32")
     eng = _SA_ENGINES.get(mod)
@@ -835,7 +836,7 @@ class HVAE(nn.Module):
                 z = eng.on_side(lambda: eng.conv(self._site(eng, blk.z_feat_proj), [z_cur, p_feat], ACT_NONE, tape_hold=hold))
                 side_ahead = True
                 feat = False
-            h = h_next if h_next is not None else eng.conv(self._site(eng, blk.z_proj), [z_cur, pa], ACT_NONE, res1=h, res2=p_feat)
+            h = h_next if h_next is not None else eng.conv(self._site(eng, blk.z_proj), [z_cur, pa], ACT_NONE, res1=h, res2=p_feat, trunk=True)
             h = self._run_block(eng, blk.conv, [h])
             eng.tape.extend(hold)  # (backward order as before: z_feat_proj after the conv Block)
             if feat:
@@ -1018,9 +1019,10 @@ class HVAE(nn.Module):
             g = g_cf.to(eng.device, torch.float32).contiguous()
             eng.stream = torch.cuda.current_stream(eng.device).cuda_stream
             B, R, Cx = xin.n, xin.h, xin.c
+            S = eng.set_loss_scale(B * float(Cx * R * R))  # (the same value _run_backward sets for this pass)
             for rec_params, cf_params in passes:
                 g_rec, g_cfp = eng.seed_grad(rec_params), eng.seed_grad(cf_params)
-                eng.lib.cf_dgauss_bwd(eng.dt, B, R, R, Cx, rec_params.cv(), cf_params.cv(), xin.cv(), g.data_ptr(), 1.0 / len(passes),
+                eng.lib.cf_dgauss_bwd(eng.dt, B, R, R, Cx, rec_params.cv(), cf_params.cv(), xin.cv(), g.data_ptr(), S / len(passes),
                                       g_rec.cv(), g_cfp.cv(), eng.stream)
                 eng.launches += 1
             self.__dict__["_coef_keep"] = g
@@ -1041,7 +1043,8 @@ class HVAE(nn.Module):
         gn = g_nll if g_nll is not None else z
         gk = g_kl if g_kl is not None else z
         # d/d(sum_b nll_b) and d/d(sum_b kl_b): scalar glue on 0-dim tensors
-        coef = torch.stack([(ge + gn) / (B * dims), (ge * beta + gk) / (B * dims)]).float().contiguous()
+        S = eng.set_loss_scale(B * dims)  # (1 for f32; the reduces that produce parameter gradients divide it out again)
+        coef = torch.stack([(ge + gn) * (S / (B * dims)), (ge * beta + gk) * (S / (B * dims))]).float().contiguous()
         self.__dict__["_coef"] = coef
         eng.stream = torch.cuda.current_stream(eng.device).cuda_stream
         eng.kl_coef_ptr = coef.data_ptr() + 4

@@ -9,7 +9,7 @@
  *   - Activations are NHWC *views*: channel stride 1, arbitrary (n,h,w) strides in ELEMENTS.  A channel slice
  *     or a [:res,:res] crop of a bigger tensor is therefore a view, and torch.cat along C is never materialised
  *     (multi-segment inputs).  dtype: CGEN_F32 (exact path: f32 MFMA 16x16x4, bit-level fmaf chains) or
- *     CGEN_BF16 (bf16 storage + bf16 MFMA 16x16x32, f32 accumulate).  Parameters/gradients are always f32.
+ *     CGEN_F16 (bf16 storage + bf16 MFMA 16x16x32, f32 accumulate).  Parameters/gradients are always f32.
  *   - Ownership: the caller owns every buffer including workspaces; the library never allocates, frees or
  *     synchronises, and keeps no mutable global state (deepcopy / fork / hipGraph-capture safe).
  *   - Every call only enqueues work on `stream` and returns 0, or a negative cgen_status (message via
@@ -29,7 +29,7 @@ extern "C" {
 typedef void* cgen_stream_t; /* hipStream_t */
 
 enum cgen_status { CGEN_OK = 0, CGEN_EINVAL = -1, CGEN_ELAUNCH = -2, CGEN_EUNSUPPORTED = -3 };
-enum cgen_dtype { CGEN_F32 = 0, CGEN_BF16 = 1 };
+enum cgen_dtype { CGEN_F32 = 0, CGEN_F16 = 1 };
 enum cgen_act { CGEN_ACT_NONE = 0, CGEN_ACT_RELU = 1, CGEN_ACT_GELU = 2 };
 
 /* NHWC strided view; strides in elements; p == NULL means "absent".
@@ -57,7 +57,12 @@ const char* cgen_last_error(void);
  * seg = grad_out, weight = the "dgrad image" from cgen_weight_prep, dact/aux = the forward activation and
  * its input, res1 = out (accumulate).  res1/res2 may alias out.
  * weight: image built by cgen_weight_prep: [ceil16(Co)][krow], column k = tap * C8 + c with C8 = sum_s ceil8(C_s)
- * (segments side by side at 8-channel granularity), krow = ceil32(KS*KS*C8) + 32, in `dtype`, zero padded. */
+ * (segments side by side at 8-channel granularity), krow = ceil32(KS*KS*C8) + 32, in `dtype`, zero padded.
+ * Remainder planes (CGEN_F16 only; 0 = absent): the residual trunk of the HVAE (vae.py:78, 253, 292-294: ~100 consecutive
+ * `h = h + f(h)` updates) is carried as a PAIR of binary16 tensors, value = hi + rem with |rem| <= ulp(hi)/2, so that the sum
+ * keeps ~22 significant bits although every conv still reads 16-bit operands (hi alone).  `res1_rem` / `out_rem` are BYTE
+ * offsets from res1.p / out.p to a plane of identical layout: the epilogue adds res1 + res1_rem in f32, stores
+ * out = rn16(v) and, when out_rem != 0, out_rem = rn16(v - out). */
 typedef struct cgen_conv_args {
   int32_t dtype, n, h, w, ks, nseg, act, dact;
   cgen_view seg[CGEN_MAX_SEG];
@@ -65,6 +70,7 @@ typedef struct cgen_conv_args {
   const float* bias; /* [Co] or NULL */
   cgen_view out;     /* out.c = Co */
   cgen_view aux, res1, res2;
+  int64_t out_rem, res1_rem;
 } cgen_conv_args;
 int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream);
 
@@ -141,7 +147,8 @@ typedef struct cgen_wred_desc { /* split-K partials -> OIHW f32 gradient (+bias 
   float* grad_w; /* [Co][Ci][KS][KS] */
   float* grad_b; /* [Co] or NULL */
   int32_t co, ci_total, ks, nsplit;
-  int32_t accumulate, reserved;
+  int32_t accumulate;
+  float unscale; /* the sums are multiplied by this (1 / loss scale of the f16 engine); 0 means 1 */
   int64_t numel; /* co*ci_total*ks*ks + co */
 } cgen_wred_desc;
 int cgen_wgrad_reduce(const cgen_wred_desc* descs_dev, const int32_t* chunk_site_dev, const int32_t* chunk_index_dev,
@@ -165,9 +172,10 @@ int cgen_upsample_fwd(int32_t dtype, int32_t n, int32_t hi, int32_t wi, int32_t 
                       const float* bias, cgen_view out, cgen_stream_t);
 int cgen_upsample_bwd(int32_t dtype, int32_t n, int32_t hi, int32_t wi, int32_t ho, int32_t wo, cgen_view gout,
                       cgen_view gin, int32_t accumulate, cgen_stream_t);
-/* out[y,x,c] (+)= sum_n in[n,y,x,c]  (gradient of a batch-broadcast parameter); out f32 contiguous [h][w][C] */
+/* out[y,x,c] (+)= unscale * sum_n in[n,y,x,c]  (gradient of a batch-broadcast parameter); out f32 contiguous [h][w][C];
+ * unscale = 1 / loss scale of the engine whose 16-bit gradients `in` holds (1 for f32) */
 int cgen_batch_reduce(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view in, float* out, int32_t accumulate,
-                      cgen_stream_t);
+                      float unscale, cgen_stream_t);
 /* out[n,y,x,c] = src[y,x,c] (batch broadcast of an f32 [h][w][C] parameter) */
 int cgen_batch_broadcast(int32_t dtype, int32_t n, int32_t h, int32_t w, const float* src, cgen_view out, cgen_stream_t);
 /* out = alpha*in (+ out if accumulate); channels >= c_from additionally scaled by beta.  in may be absent (fill alpha). */

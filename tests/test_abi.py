@@ -102,7 +102,7 @@ def test_product_path_fails_loudly_without_gpu():
 
 def test_device_code_has_no_packed_f32_instructions():
     """MI355X erratum found in round 1 (tools/coexec_probe.py): v_pk_mul/add/fma_f32 in one wave return
-    corrupted results while a wave of ANOTHER kernel on the same SIMD executes v_mfma_f32_16x16x32_bf16 -- the background
+    corrupted results while a wave of ANOTHER kernel on the same SIMD executes a 16-bit MFMA (found with v_mfma_f32_16x16x32_bf16; the f16 build keeps the guard) -- the background
     weight-gradient kernel runs next to the whole backward chain.  build.sh switches the packed-fp32 feature off; this
     checks the shipped library instead of the flag."""
     import glob
@@ -126,7 +126,7 @@ def test_device_code_has_no_packed_f32_instructions():
         n_inst = 0
         for b in bundles:
             asm = subprocess.run([objdump, "-d", b], check=True, capture_output=True, text=True).stdout
-            n_inst += asm.count("v_mfma_f32_16x16x32_bf16")
+            n_inst += asm.count("v_mfma_f32_16x16x32_f16") + asm.count("v_mfma_f32_16x16x32_bf16")
             bad = re.findall(r"v_pk_(?:mul|add|fma)_f32", asm)
             assert not bad, "%d packed-f32 instructions in %s" % (len(bad), os.path.basename(b))
         assert n_inst > 0  # we did look at the real kernels

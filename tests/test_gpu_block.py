@@ -38,10 +38,10 @@ def _run(case, fuse, seed=0, th=8):
         c2.weight.copy_(torch.randn(c2.weight.shape, generator=g) / math.sqrt(b * 9 / 2))
         c1.bias.copy_(torch.randn(b, generator=g) * 0.2)
         c2.bias.copy_(torch.randn(co, generator=g) * 0.2)
-    xs = [torch.randn(N, c, H, W, generator=g).bfloat16().float() for c in segc]
-    res = torch.randn(N, co, H, W, generator=g).bfloat16().float() if with_res else None
-    gout = torch.randn(N, co, H, W, generator=g).bfloat16().float()
-    eng = Engine("cuda", "bf16")
+    xs = [torch.randn(N, c, H, W, generator=g).half().float() for c in segc]
+    res = torch.randn(N, co, H, W, generator=g).half().float() if with_res else None
+    gout = torch.randn(N, co, H, W, generator=g).half().float()
+    eng = Engine("cuda", "f16")
     eng.blk_fuse, eng.blk_minres = fuse, 8
     eng.blk_th4_maxres = 1 << 20 if th == 4 else 0   # tile height of the fused kernel: 4 rows or 8
     holder = torch.nn.ModuleList([c1, c2]).cuda()
@@ -90,7 +90,7 @@ def test_fused_block_matches_two_launch_path_and_torch(case, th):
         assert float((a - c).norm()) <= 1e-2 * float(c.norm()) + 1e-6, (float((a - c).norm()), float(c.norm()))
     # ---- (b) against torch f32 on the same bf16-quantised operands
     c1, c2 = one["convs"]
-    w1, w2 = c1.weight.detach().cpu().bfloat16().float().requires_grad_(True), c2.weight.detach().cpu().bfloat16().float().requires_grad_(True)
+    w1, w2 = c1.weight.detach().cpu().half().float().requires_grad_(True), c2.weight.detach().cpu().half().float().requires_grad_(True)
     xr = [x.clone().requires_grad_(True) for x in one["xs"]]
     t = F.conv2d(F.relu(torch.cat(xr, 1)), w1, c1.bias.detach().cpu(), padding=1)
     y = F.conv2d(F.relu(t), w2, c2.bias.detach().cpu(), padding=1)

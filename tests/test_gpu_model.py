@@ -161,7 +161,7 @@ def test_philox_noise_statistics_and_determinism():
 def test_bf16_path_close_to_fixture():
     """bf16 storage/MFMA: report-and-bound the deviation (not a parity claim)."""
     fx = load_golden("tiny_light_c1.pt")
-    m, _ = build(fx, dtype="bf16")
+    m, _ = build(fx, dtype="f16")
     f = fx["fwd"]
     m.noise = [e.clone() for e in f["eps"]]
     out = m(fx["x"].cuda(), fx["pa"].cuda(), beta=f["beta"])
@@ -266,7 +266,7 @@ def test_concurrent_replays_equal_sequential_replays_on_first_use(monkeypatch):
     outs = []
     for pair in ("0", "1", "1"):
         monkeypatch.setenv("CGEN_CF_PAIR", pair)
-        m, _ = build(fx, "bf16")  # fresh model => fresh engine => empty caches
+        m, _ = build(fx, "f16")  # fresh model => fresh engine => empty caches
         x, pa = fx["x"].cuda(), fx["pa"].cuda()
         eng = m.engine()
         eng.rng_ptr()
@@ -301,7 +301,7 @@ def test_counterfactual_reusing_the_abduction_pass_gives_the_same_bits(name, te,
     for reuse in ("0", "1"):
         monkeypatch.setenv("CGEN_CF_REUSE", reuse)
         monkeypatch.setenv("CGEN_CF_PAIR", "0")
-        for dt in ("f32", "bf16"):
+        for dt in ("f32", "f16"):
             m, _ = build(fx, dt)
             x, pa = fx["x"].cuda(), fx["pa"].cuda()
             eng = m.engine()

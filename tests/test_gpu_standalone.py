@@ -25,7 +25,7 @@ def test_block_standalone(version, d, cin, cout):
     torch.testing.assert_close(y.cpu(), ref, rtol=1e-4, atol=1e-5)
     with pytest.raises(RuntimeError, match="inference-only"):
         blk(x.cuda().requires_grad_(True))
-    blk.compute_dtype = "bf16"
+    blk.compute_dtype = "f16"
     yb = blk(x.cuda())
     assert float((yb.cpu() - ref).abs().max()) <= 0.05 * float(ref.abs().max())
 

@@ -312,7 +312,7 @@ def test_backward_is_bit_reproducible_next_to_the_background_weight_gradient_ker
     sys.path.insert(0, root)
     import bench
 
-    m, hp = bench.build_model("ukbb192", "bf16")
+    m, hp = bench.build_model("ukbb192", "f16")
     m = m.cuda().train()
     x, pa = bench.synth_batch("ukbb192", hp, 8, "cuda", 1)
     g = torch.Generator().manual_seed(3)
@@ -356,7 +356,7 @@ def test_full_size_bf16_path_agrees_with_the_f32_parity_path():
     import bench
 
     res = {}
-    for dt in ("f32", "bf16"):
+    for dt in ("f32", "f16"):
         m, hp = bench.build_model("ukbb192", dt)
         m = m.cuda().train()
         g = torch.Generator().manual_seed(3)
@@ -374,11 +374,11 @@ def test_full_size_bf16_path_agrees_with_the_f32_parity_path():
                    {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
         del m, eng
     for k in ("elbo", "nll", "kl"):
-        a, b = res["f32"][0][k], res["bf16"][0][k]
+        a, b = res["f32"][0][k], res["f16"][0][k]
         assert abs(a - b) <= 3e-3 * abs(a), (k, a, b)
     errs, cosines = [], []
     for n, gf in res["f32"][1].items():
-        gb = res["bf16"][1][n]
+        gb = res["f16"][1][n]
         den = float(gf.norm())
         if den == 0:
             continue
@@ -401,7 +401,7 @@ def test_full_size_graph_replay_equals_eager_bf16():
 
     outs = []
     for use_graph in (False, True):
-        m, hp = bench.build_model("ukbb192", "bf16")
+        m, hp = bench.build_model("ukbb192", "f16")
         m = m.cuda()
         torch.manual_seed(123)
         ts = TrainStep(m, hp, ema=True, use_graph=use_graph)
@@ -428,7 +428,7 @@ def test_full_size_null_intervention_returns_the_observation():
     import bench
     from causal_gen_amd import dscm
 
-    m, hp = bench.build_model("ukbb192", "bf16")
+    m, hp = bench.build_model("ukbb192", "f16")
     m = m.cuda().eval()
     g = torch.Generator().manual_seed(3)
     with torch.no_grad():
@@ -646,7 +646,7 @@ def test_virtual_parents_equal_materialised():
     from causal_gen_amd import vae
     from causal_gen_amd.hps import setup_hparams
 
-    for name, B, dt in (("ukbb192", 2, "f32"), ("ukbb192", 2, "bf16"), ("morphomnist", 4, "f32"), ("morphomnist", 4, "bf16")):
+    for name, B, dt in (("ukbb192", 2, "f32"), ("ukbb192", 2, "f16"), ("morphomnist", 4, "f32"), ("morphomnist", 4, "f16")):
         hp = setup_hparams(name)
         torch.manual_seed(3)
         m = vae.HVAE(hp).cuda()
@@ -694,7 +694,7 @@ def test_two_strand_backward_equals_single_stream():
     hp = setup_hparams("ukbb192")
     torch.manual_seed(3)
     m = vae.HVAE(hp).cuda()
-    m.compute_dtype = "bf16"
+    m.compute_dtype = "f16"
     m.train()
     B = 2
     g = torch.Generator().manual_seed(5)
@@ -731,7 +731,7 @@ def test_fused_latent_layer_matches_the_two_launch_form():
         hp = setup_hparams(name)
         torch.manual_seed(3)
         m = vae.HVAE(hp).cuda()
-        m.compute_dtype = "bf16"
+        m.compute_dtype = "f16"
         m.train()
         if m.cond_prior:
             m.decoder.__dict__["drop_cond"] = lambda: (1, 1)

@@ -12,7 +12,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--worker":
 
     import bench
     cfg = sys.argv[2]
-    m, hp = bench.build_model(cfg, "bf16")
+    m, hp = bench.build_model(cfg, "f16")
     m = m.cuda().train()
     B = 8 if hp.input_res > 64 else 64
     x, pa = bench.synth_batch(cfg, hp, B, "cuda", 1)
@@ -111,7 +111,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--worker":
                     for ch in eng.arena.chunks:
                         off = buf.ptr - ch.data_ptr()
                         if 0 <= off and off + nbytes <= ch.numel():
-                            dump[k] = (ch[off:off + nbytes].view(torch.bfloat16).float().cpu().view(buf.n, -1), (buf.n, buf.h, buf.w, buf.c, buf.sn, buf.sh, buf.sw))
+                            dump[k] = (ch[off:off + nbytes].view(torch.float16).float().cpu().view(buf.n, -1), (buf.n, buf.h, buf.w, buf.c, buf.sn, buf.sh, buf.sw))
             torch.save(dump, sys.argv[3] + ".dump")
     torch.save({n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}, sys.argv[3])
     print(float(out["elbo"]))

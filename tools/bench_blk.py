@@ -16,7 +16,7 @@ for (N, R, segc, b, co) in SHAPES:
     for fuse in (0, 2):
         ci = sum(segc)
         c1, c2 = torch.nn.Conv2d(ci, b, 3, padding=1), torch.nn.Conv2d(b, co, 3, padding=1)
-        eng = Engine("cuda", "bf16")
+        eng = Engine("cuda", "f16")
         eng.blk_fuse, eng.blk_minres = fuse, 8
         eng.wgrad_flush_frac = []
         holder = torch.nn.ModuleList([c1, c2]).cuda()

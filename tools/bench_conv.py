@@ -25,7 +25,7 @@ def main():
     global SHAPES
     if os.environ.get("NB"):
         SHAPES = [(int(os.environ["NB"]),) + sh[1:] for sh in SHAPES]
-    dtype = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+    dtype = sys.argv[1] if len(sys.argv) > 1 else "f16"
     kind = sys.argv[2] if len(sys.argv) > 2 else "fwd"
     iters = int(os.environ.get("ITERS", "20"))
     convs = [torch.nn.Conv2d(sum(s[2]), s[3], s[4], padding=s[4] // 2) for s in SHAPES]

@@ -8,7 +8,7 @@ from causal_gen_amd.engine import ConvSite, Engine
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 192
 cin = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 co = int(sys.argv[3]) if len(sys.argv) > 3 else 32
-for dt in ("bf16", "f32"):
+for dt in ("f16", "f32"):
     conv = torch.nn.Conv2d(cin, co, 7, padding=3)
     eng = Engine("cuda", dt)
     holder = torch.nn.ModuleList([conv]).cuda()

@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import bench
 from causal_gen_amd.train import TrainStep
 cfg = sys.argv[1]
-m, hp = bench.build_model(cfg, "bf16", False)
+m, hp = bench.build_model(cfg, "f16", False)
 m = m.cuda()
 x, pa = bench.synth_batch(cfg, hp, 64, torch.device("cuda"), seed=5)
 ts = TrainStep(m, hp, ema=False, use_graph=False)

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 import torch
 
 from causal_gen_amd import _lib
-from causal_gen_amd._lib import BF16, NULL_VIEW, View
+from causal_gen_amd._lib import F16, NULL_VIEW, View
 
 lib = _lib.require_gpu()
 n, h, w, c = 8, 24, 24, 16
@@ -18,7 +18,7 @@ g = torch.Generator().manual_seed(0)
 
 
 def t(scale=1.0, ch=c):
-    return (torch.randn(n, h, w, ch, generator=g) * scale).to(torch.bfloat16).cuda()
+    return (torch.randn(n, h, w, ch, generator=g) * scale).to(torch.float16).cuda()
 
 
 q = t(0.05, 32); pr = t(0.05, 32); z = t(1.0); gz = t(1e-7)
@@ -31,13 +31,13 @@ def view(x, c0, cc):
 
 main = torch.cuda.current_stream()
 side = torch.cuda.Stream()
-A = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
-Bm = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+A = torch.randn(4096, 4096, device="cuda", dtype=torch.float16)
+Bm = torch.randn(4096, 4096, device="cuda", dtype=torch.float16)
 big = torch.randn(32 << 20, device="cuda")
 
 
 def run_reparam(out_q, out_p):
-    lib.reparam_kl_bwd(BF16, n, h, w, c, view(q, 0, 16), view(q, 16, 16), view(pr, 0, 16), view(pr, 16, 16), view(z, 0, 16), 0.0,
+    lib.reparam_kl_bwd(F16, n, h, w, c, view(q, 0, 16), view(q, 16, 16), view(pr, 0, 16), view(pr, 16, 16), view(z, 0, 16), 0.0,
                        view(gz, 0, 16), coef.data_ptr(), 0, None, view(out_q, 0, 16), view(out_q, 16, 16), view(out_p, 0, 16),
                        view(out_p, 16, 16), 0, 0, main.cuda_stream)
 
@@ -48,8 +48,8 @@ def trial(name, neighbour, reps=300):
     with torch.cuda.stream(side):
         neighbour()
     for i in range(reps):
-        oq = torch.zeros(n, h, w, 32, dtype=torch.bfloat16, device="cuda")
-        op = torch.zeros(n, h, w, 32, dtype=torch.bfloat16, device="cuda")
+        oq = torch.zeros(n, h, w, 32, dtype=torch.float16, device="cuda")
+        op = torch.zeros(n, h, w, 32, dtype=torch.float16, device="cuda")
         run_reparam(oq, op)
         outs.append((oq, op))
         if i % 20 == 19:
@@ -67,7 +67,7 @@ trial("bf16 matmul neighbour", lambda: [torch.mm(A, Bm) for _ in range(6)])
 
 # the weight-gradient kernel as the neighbour: a few 3x3 problems at 96x96, capped grid
 from causal_gen_amd.engine import ConvSite, Engine
-eng = Engine("cuda", "bf16")
+eng = Engine("cuda", "f16")
 convs = torch.nn.ModuleList([torch.nn.Conv2d(64, 16, 3, padding=1) for _ in range(6)]).cuda()
 sites = [ConvSite(f"c{i}", cv, [64], [True], i) for i, cv in enumerate(convs)]
 eng.bind(convs, sites)
@@ -99,7 +99,7 @@ for cap in (304,):
 # ---- conv kernels as victims next to the weight-gradient neighbour (address arithmetic, epilogue, MFMA of their own)
 def conv_trial(name, N, R, ci, co, ks, reps=600):
     cv = torch.nn.ModuleList([torch.nn.Conv2d(ci, co, ks, padding=ks // 2)]).cuda()
-    e2 = Engine("cuda", "bf16")
+    e2 = Engine("cuda", "f16")
     st = [ConvSite("v0", cv[0], [ci], [True], 0)]
     e2.bind(cv, st)
     e2.begin()

@@ -9,7 +9,7 @@ tag, steps = sys.argv[1], int(sys.argv[2])
 dist.init_process_group("gloo")
 rank = dist.get_rank()
 torch.cuda.set_device(0)
-m, hp = bench.build_model("ukbb192", "bf16")
+m, hp = bench.build_model("ukbb192", "f16")
 m = m.cuda()
 ts = TrainStep(m, hp, ema=False, use_graph=os.environ.get("DBG_GRAPH", "1") == "1", process_group=dist.group.WORLD)
 x, pa = bench.synth_batch("ukbb192", hp, 2, "cuda", 100 + rank)

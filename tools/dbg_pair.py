@@ -5,7 +5,7 @@ fx = load_golden("tiny_light_c1.pt")
 outs = []
 for pair in ("0", "1", "1", "0"):
     os.environ["CGEN_CF_PAIR"] = pair
-    m, _ = build(fx, "bf16")
+    m, _ = build(fx, "f16")
     x, pa = fx["x"].cuda(), fx["pa"].cuda()
     eng = m.engine()
     print("stage_res", sorted(eng.stage_res))

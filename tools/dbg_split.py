@@ -5,7 +5,7 @@ import torch
 import bench
 from causal_gen_amd.train import TrainStep
 
-m, hp = bench.build_model("ukbb192", "bf16")
+m, hp = bench.build_model("ukbb192", "f16")
 m = m.cuda()
 ts = TrainStep(m, hp, ema=False, use_graph=False)
 x, pa = bench.synth_batch("ukbb192", hp, 2, "cuda", 1)

@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 import bench
 from causal_gen_amd.train import TrainStep
 name = sys.argv[1] if len(sys.argv) > 1 else "ukbb192"
-m, hp = bench.build_model(name, "bf16")
+m, hp = bench.build_model(name, "f16")
 m = m.cuda()
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 ts = TrainStep(m, hp, ema=True, use_graph=True)

@@ -29,7 +29,7 @@ def run(dp_on, overlap):
     os.environ["CGEN_DP_OVERLAP"] = "1" if overlap else "0"
     torch.manual_seed(0)
     m = vae.HVAE(hp).cuda()
-    m.compute_dtype = "bf16"
+    m.compute_dtype = "f16"
     ts = TrainStep(m, hp, ema=True, process_group=dist.group.WORLD if dp_on else None)
     g = torch.Generator().manual_seed(1)
     outs = []

@@ -12,7 +12,7 @@ import bench
 cfg = sys.argv[1] if len(sys.argv) > 1 else "ukbb192"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 res = {}
-for dt in ("f32", "bf16"):
+for dt in ("f32", "f16"):
     m, hp = bench.build_model(cfg, dt)
     m = m.cuda().train()
     g = torch.Generator().manual_seed(3)
@@ -29,10 +29,10 @@ for dt in ("f32", "bf16"):
     res[dt] = ({k: float(out[k]) for k in ("elbo", "nll", "kl")}, {n: p.grad.detach().float().cpu() for n, p in m.named_parameters() if p.grad is not None})
     del m
 print("f32 ", res["f32"][0])
-print("bf16", res["bf16"][0])
+print("f16", res["f16"][0])
 errs = []
 for n, gf in res["f32"][1].items():
-    gb = res["bf16"][1][n]
+    gb = res["f16"][1][n]
     den = float(gf.norm())
     if den == 0:
         continue

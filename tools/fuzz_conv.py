@@ -37,7 +37,7 @@ for i in range(n_cases):
     else:
         H, W = res, res if rng.random() < 0.8 else max(1, res - rng.choice([1, 3]))
     case = (N, H, W, segc, Co, ks, act, with_res)
-    for dtype in (["bf16"] if rng.random() < 0.8 else ["bf16", "f32"]):
+    for dtype in (["f16"] if rng.random() < 0.8 else ["f16", "f32"]):
         if i < skip:
             continue
         print("run  %s %s" % (dtype, case), flush=True)

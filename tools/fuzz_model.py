@@ -54,7 +54,7 @@ for case in range(n):
         continue
     outs = {}
     try:
-        for dt in ("f32", "bf16", "bf16#2"):
+        for dt in ("f32", "f16", "bf16#2"):
             hp = setup_hparams(name, **ov)
             torch.manual_seed(case)
             m = vae.HVAE(hp)
@@ -88,7 +88,7 @@ for case in range(n):
             torch.cuda.synchronize()
             outs[dt] = outs[dt] + (cf.float().cpu(),)
             del m, eng
-        a, b = outs["f32"], outs["bf16"]
+        a, b = outs["f32"], outs["f16"]
         rep = [nm for nm in b[1] if not torch.equal(b[1][nm], outs["bf16#2"][1][nm])]
         rep_cf = not torch.equal(b[2], outs["bf16#2"][2])
         rel = max(abs(a[0][k] - b[0][k]) / max(abs(a[0][k]), 1e-6) for k in ("elbo", "nll"))

@@ -9,9 +9,9 @@ conv = torch.nn.Conv2d(sum(segc), Co, ks, padding=ks // 2)
 with torch.no_grad():
     conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / math.sqrt(sum(segc) * ks * ks))
     conv.bias.zero_()
-x = torch.randn(N, segc[0], H, W, generator=g).bfloat16().float()
-y_ref = F.conv2d(x, conv.weight.detach().bfloat16().float(), None, padding=ks // 2)
-eng, (site,) = make_engine([conv], [segc], "bf16")
+x = torch.randn(N, segc[0], H, W, generator=g).half().float()
+y_ref = F.conv2d(x, conv.weight.detach().half().float(), None, padding=ks // 2)
+eng, (site,) = make_engine([conv], [segc], "f16")
 y = nhwc_to_torch(eng, eng.conv(site, [eng.from_nchw(x.cuda())], 0))
 bad = ((y - y_ref).abs() > 0.05).any(dim=1)  # [N,H,W]
 idx = bad.nonzero()

@@ -14,7 +14,7 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "ukbb192"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 outs = []
 for use_graph in (False, True):
-    m, hp = bench.build_model(cfg, "bf16")
+    m, hp = bench.build_model(cfg, "f16")
     m = m.cuda()
     torch.manual_seed(123)
     ts = TrainStep(m, hp, ema=True, use_graph=use_graph)

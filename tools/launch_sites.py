@@ -14,7 +14,7 @@ import bench
 
 name = sys.argv[1]
 cfg = sys.argv[2] if len(sys.argv) > 2 else "ukbb192"
-m, hp = bench.build_model(cfg, "bf16")
+m, hp = bench.build_model(cfg, "f16")
 m = m.cuda().train()
 B = 32 if hp.input_res > 64 else 256
 x, pa = bench.synth_batch(cfg, hp, B, "cuda", 1)

@@ -3,7 +3,7 @@ sys.path.insert(0, "/root/repo")
 import torch, bench
 from causal_gen_amd import dscm
 for cfg, B in (("ukbb192", 4), ("morphomnist", 32), ("mimic224", 2)):
-    m, hp = bench.build_model(cfg, "bf16")
+    m, hp = bench.build_model(cfg, "f16")
     m = m.cuda().eval()
     g = torch.Generator().manual_seed(3)
     with torch.no_grad():

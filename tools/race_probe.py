@@ -12,7 +12,7 @@ from causal_gen_amd.engine import ConvSite, Engine
 SHAPES = [(8, 1, [512], 128, 3), (8, 1, [128], 512, 3), (8, 1, [512], 128, 1), (8, 1, [128], 544, 1), (8, 1, [512, 4, 512], 128, 1),
           (8, 6, [192], 48, 3), (8, 6, [48], 192, 3), (8, 12, [160], 40, 3), (8, 24, [128], 32, 3), (8, 24, [32], 128, 3), (32, 1, [512], 128, 3)]
 convs = [torch.nn.Conv2d(sum(s[2]), s[3], s[4], padding=s[4] // 2) for s in SHAPES]
-eng = Engine("cuda", "bf16")
+eng = Engine("cuda", "f16")
 holder = torch.nn.ModuleList(convs).cuda()
 sites = [ConvSite(f"c{i}", c, s[2], [True] * len(s[2]), i) for i, (c, s) in enumerate(zip(holder, SHAPES))]
 eng.bind(holder, sites)

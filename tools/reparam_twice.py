@@ -13,7 +13,7 @@ import torch
 import bench
 from causal_gen_amd import _lib
 
-m, hp = bench.build_model("ukbb192", "bf16")
+m, hp = bench.build_model("ukbb192", "f16")
 m = m.cuda().train()
 x, pa = bench.synth_batch("ukbb192", hp, 8, "cuda", 1)
 eng = m.engine()
@@ -93,14 +93,14 @@ for it in range(4):
         if not torch.equal(first, second):
             d = (first.view(torch.int16) != second.view(torch.int16)).nonzero().flatten()
             bad.append((k, shape, int(d.numel()), d[:8].tolist()))
-            f16, s16 = first.view(torch.bfloat16).float(), second.view(torch.bfloat16).float()
+            f16, s16 = first.view(torch.float16).float(), second.view(torch.float16).float()
             i0 = int(d[0])
             print("   call %d idx %d: first-run values %s | second-run values %s (8-channel group around it: first %s second %s)" % (
                 k, i0, f16[d[:4]].tolist(), s16[d[:4]].tolist(), f16[i0 // 8 * 8: i0 // 8 * 8 + 8].tolist(), s16[i0 // 8 * 8: i0 // 8 * 8 + 8].tolist()))
             # third opinion: torch recomputation of g_q_ls at that element
             zin = zlast[k]
             names = ["q_loc", "q_ls", "p_loc", "p_ls", "z", "gz"]
-            t = {nm: v.view(torch.bfloat16).float() for nm, v in zip(names, zin)}
+            t = {nm: v.view(torch.float16).float() for nm, v in zip(names, zin)}
             pix, chn = i0 // 32, i0 % 32 - 16
             j = pix * 16 + chn
             e2q, ie2p = torch.exp(2 * t["q_ls"][j]), torch.exp(-2 * t["p_ls"][j])

@@ -2,7 +2,7 @@ import sys, collections
 sys.path.insert(0, "/root/repo")
 import torch, bench
 from causal_gen_amd import engine as E
-m, hp = bench.build_model("ukbb192", "bf16")
+m, hp = bench.build_model("ukbb192", "f16")
 m = m.cuda().train()
 x, pa = bench.synth_batch("ukbb192", hp, 32, "cuda", 1)
 out = m(x, pa, beta=1.0); out["elbo"].backward()

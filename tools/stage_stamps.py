@@ -6,7 +6,7 @@ import bench
 name = sys.argv[1] if len(sys.argv) > 1 else "morphomnist"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 which = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-m, hp = bench.build_model(name, "bf16")
+m, hp = bench.build_model(name, "f16")
 m = m.cuda().eval()
 x, pa = bench.synth_batch(name, hp, B, torch.device("cuda"), 100)
 buf = torch.zeros(8 * 256, dtype=torch.int64, device="cuda")

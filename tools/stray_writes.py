@@ -10,7 +10,7 @@ import torch
 import bench
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "ukbb192"
-m, hp = bench.build_model(cfg, "bf16")
+m, hp = bench.build_model(cfg, "f16")
 m = m.cuda().train()
 B = 8 if hp.input_res > 64 else 64
 x, pa = bench.synth_batch(cfg, hp, B, "cuda", 1)

@@ -8,7 +8,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 dev = torch.device("cuda")
 def mk(b, seed):
-    m, hp = bench.build_model("ukbb192", "bf16")
+    m, hp = bench.build_model("ukbb192", "f16")
     m = m.to(dev)
     ts = TrainStep(m, hp, ema=True, use_graph=True)
     x, pa = bench.synth_batch("ukbb192", hp, b, dev, seed)
