@@ -4,7 +4,7 @@
   from the same seeded recipe (oracle/fullsize_recipe.py): ELBO / NLL / KL within 1e-4 relative, sampled gradients of a
   dozen named parameters, counterfactual pixels within 1e-3 absolute;
 * against the oracle run live on this host's CPU (every parameter gradient);
-* and the bf16 throughput path's measured deviation from those reference values, with the bound it is held to.
+* and the f16 throughput path's measured deviation from those reference values, with the bound it is held to.
 
 The tiny golden models are served by other kernels than these shapes, hence this file."""
 import os
@@ -26,13 +26,21 @@ from oracle import fullsize_recipe as R  # noqa: E402
 ELBO_TOL = 1e-4       # north_star: ELBO and DMoL nats/dim within 1e-4 relative
 CF_TOL = 1e-3         # north_star: counterfactual pixels within 1e-3 absolute
 GRAD_TOL = 2e-3       # of the tensor's max |gradient|
-# bf16 storage of activations / weight images (f32 accumulate, f32 KL / NLL / reductions): measured deviation of the ELBO
-# from the reference at full size is 1e-4 .. 8e-4 relative depending on the preset (printed below); it is held to this bound.
-F16_ELBO_TOL = 2e-3
-# ... and its counterfactual pixels: u = (x - rec_loc) / rec_scale amplifies the bf16 rounding of the reconstruction wherever the
-# abducted scale is small; measured 1.1e-2 (cmnist + DMoL) .. 5.9e-2 (ukbb192) absolute against the reference-made sample.  The
-# parity-grade counterfactual is the f32 one (CF_TOL above); the bf16 one is HELD to this bound so that it cannot drift unseen.
-F16_CF_TOL = 9e-2
+# The 16-bit throughput path: IEEE binary16 storage of activations / weight images (f32 accumulate, f32 KL / NLL / reductions),
+# the residual trunk carried as (value, remainder) pairs.  Measured against the reference's values on these fixtures (round 3):
+# ELBO 1.3e-6 (cmnist + DMoL), 8.7e-6 (mimic224), 1.2e-5 (ukbb192), 2.9e-4 (morphomnist); round 2's bf16 storage had 4e-5 ..
+# 1.2e-3.  What remains on the morphomnist fixture is the rounding of the conv OPERANDS to 11 bits (tools/bf16_trunk_sim.py:
+# with every stored tensor in f32 and only the operands rounded, this fixture -- 4096 white-noise pixels at an NLL of 7.9
+# nats/dim, dominated by a few tail pixels -- already deviates by 5e-4), i.e. the floor of a 16-bit MFMA path.
+F16_ELBO_TOL = {"morphomnist": 6e-4}
+F16_ELBO_TOL_DEFAULT = 5e-5
+# ... and its counterfactual pixels (u = (x - rec_loc) / rec_scale amplifies the rounding of the reconstruction): measured
+# 9.5e-4 (cmnist + DMoL), 2.3e-3 (mimic224), 3.9e-3 (morphomnist), 3.9e-3 (ukbb192) absolute against the reference-made sample
+# (bf16 storage, round 2: 1.1e-2 .. 5.9e-2; binary16 without the remainder planes: 2.4e-3 .. 7.9e-3).  Held to 5e-3; the
+# 1e-3 of north_star is met by the f32 path (CF_TOL above) and, on image-like inputs with init-scale weights, by this one too
+# (bench.py: f16_vs_f32_cf_maxabs).
+F16_CF_TOL = 5e-3
+F16_KL_TOL = 2e-4
 
 
 def _model(name, dmol, dtype):
@@ -128,7 +136,7 @@ def test_fullsize_forward_backward_counterfactual(name, B, dmol):
     assert float(d_cf[ok].max()) < CF_TOL, float(d_cf[ok].max())
     assert abs(float((cf_x.cpu() - x).abs().mean()) - row["cf"]["moved"]) < 1e-3
 
-    # ---- bf16 throughput path: measured deviation from the reference's values on the same inputs
+    # ---- f16 throughput path: measured deviation from the reference's values on the same inputs
     del m
     torch.cuda.empty_cache()
     mb, _ = _model(name, dmol, "f16")
@@ -141,11 +149,12 @@ def test_fullsize_forward_backward_counterfactual(name, B, dmol):
         cf_b = dscm.counterfactual(mb, x.cuda(), pa.cuda(), cf_pa.cuda(), t_abduct=1.0)
     d_cfb = float((R.sample_img(cf_b).cpu() - row["cf"]["cf_x"]).abs()[ok].max())
     print("FULLSIZE %s: f32 vs reference elbo %.2e nll %.2e kl %.2e | grads: worst %.2e (fixture sample) %.2e (oracle, %d tensors) | "
-          "cf %.2e (%d of %d sampled pixels masked: rec_scale <= 1e-3) || bf16 vs reference elbo %.2e nll %.2e kl %.2e cf %.2e" % (
+          "cf %.2e (%d of %d sampled pixels masked: rec_scale <= 1e-3) || f16 vs reference elbo %.2e nll %.2e kl %.2e cf %.2e" % (
               R.key(name, dmol), _rel(got["elbo"], row["elbo"]), _rel(got["nll"], row["nll"]), _rel(got["kl"], row["kl"]), worst_fx,
               worst, n_checked, float(d_cf[ok].max()), n_masked, n_pix, dev["elbo"], dev["nll"], dev["kl"], d_cfb))
-    assert dev["elbo"] < F16_ELBO_TOL and dev["nll"] < F16_ELBO_TOL, dev
-    assert dev["kl"] < 2e-2, dev
+    etol = F16_ELBO_TOL.get(name, F16_ELBO_TOL_DEFAULT)
+    assert dev["elbo"] < etol and dev["nll"] < etol, dev
+    assert dev["kl"] < F16_KL_TOL, dev
     assert d_cfb < F16_CF_TOL, d_cfb
 
 
