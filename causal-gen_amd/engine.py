@@ -200,8 +200,12 @@ class Engine(StageMixin):
         # reduce, the batch reduce of the decoder biases) multiply by 1 / scale.  Exact: scaling by 2^k commutes with rounding.
         # Set per backward pass by set_loss_scale(B * dims); 1 for the f32 engine.
         self.loss_scale = 1.0
-        # f16 engine: the residual trunk as (value, remainder) pairs -- see conv(trunk=True); CGEN_TRUNK_REM=0 switches it off
-        self.trunk_rem = self.dt != F32 and os.environ.get("CGEN_TRUNK_REM", "1") != "0"
+        # f16 engine: the residual trunk as (value, remainder) pairs -- see conv(trunk=True).  CGEN_TRUNK_REM: 0 never, 1 (default)
+        # in inference passes (abduct / forward_latents / sample / a no-grad forward: the counterfactual loop, whose pixels gain
+        # 2x accuracy from it), 2 also in recorded training passes.  Measured on ukbb192 B = 32: the planes double the epilogue
+        # traffic of the trunk convs (HBM-bound at >= 96x96): counterfactuals/s -12.6 %, a training step -8.5 % -- for an ELBO
+        # that is within 1.2e-5 of the reference either way, which is why training keeps the plain trunk.
+        self.trunk_mode = int(os.environ.get("CGEN_TRUNK_REM", "1"))
         self.arena = Arena(self.device)
         self.tape, self.recording = _Tape(), False
         self.tape.eng = self
@@ -270,6 +274,10 @@ class Engine(StageMixin):
         self.on_split = None
         self.early_final = None
         self._stage_init(rawlib)
+
+    @property
+    def trunk_rem(self):
+        return self.dt != F32 and (self.trunk_mode >= 2 or (self.trunk_mode == 1 and not self.recording))
 
     def set_loss_scale(self, n_terms):
         """Loss scale of the coming backward pass: the seeds are O(1 / n_terms) (n_terms = batch * dims * accumulation steps);

@@ -748,7 +748,6 @@ def test_fused_latent_layer_matches_the_two_launch_form():
             m.noise = [torch.randn(B, b.z_dim, b.res, b.res, generator=ge) for b in m.decoder.blocks if b.stochastic]
             eng = m.engine()
             eng.lat_fuse = fuse
-            eng.trunk_rem = False  # (the fused layer knows no remainder planes: both forms run with the plain 16-bit trunk)
             eng.stage_enabled = False  # (launch counts below are those of the launch-per-op chain; the fused layer is not a stage op)
             n0 = eng.launches
             out = m(x, pa, beta=hp.beta)
