@@ -103,7 +103,7 @@ template <typename T, int N> union Pack {
 __device__ __forceinline__ float h16_rem(float v) { return v - h2f(f2h(v)); }
 
 // (bias + acc) * act'(aux) + res1 + res2 for 4 consecutive output channels of one pixel
-template <typename T>
+template <typename T, bool REM = true>
 __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4& a, int pn, int py, int px, int co) {
   if (co >= p.Co) {  // padding channels [Co, out.cpad) are written as zeros so that consumers may fetch whole 16-byte groups
     if (co < p.out.cpad) {
@@ -118,8 +118,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4& a, in
   const T* aptr = p.aux.p ? vptr<T>(p.aux, pn, py, px) : nullptr;
   const T* r1 = p.res1.p ? vptr<T>(p.res1, pn, py, px) : nullptr;
   const T* r2 = p.res2.p ? vptr<T>(p.res2, pn, py, px) : nullptr;
-  const T* r1l = (r1 && p.r1_rem) ? (const T*)((const char*)r1 + p.r1_rem) : nullptr;
-  T* orem = p.out_rem ? (T*)((char*)optr + p.out_rem) : nullptr;
+  const T* r1l = (REM && r1 && p.r1_rem) ? (const T*)((const char*)r1 + p.r1_rem) : nullptr;
+  T* orem = (REM && p.out_rem) ? (T*)((char*)optr + p.out_rem) : nullptr;
   float v[4] = {a[0], a[1], a[2], a[3]};
   if ((co + 4 <= p.Co) && p.epi_vec) {
     if (p.bias) {
@@ -142,7 +142,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4& a, in
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] += t4[e];
     }
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (REM && sizeof(T) == 2) {
       if (r1l) {
         ld4<T>(r1l + co, t4);
 #pragma unroll
@@ -163,7 +163,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x4& a, in
         if (aptr) u *= act_bwd(p.dact, Elem<T>::ld(aptr + co + e));
         if (r1) u += Elem<T>::ld(r1 + co + e);
         if (r2) u += Elem<T>::ld(r2 + co + e);
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (REM && sizeof(T) == 2) {
           if (r1l) u += Elem<T>::ld(r1l + co + e);
           if (orem) Elem<T>::st(orem + co + e, h16_rem(u));
         }
@@ -189,15 +189,19 @@ __device__ __forceinline__ void bias8_load(const ConvP& p, int co, Bias8& l) {
   l.b0 = l.b1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias) { l.b0 = *(const float4*)(p.bias + co); l.b1 = *(const float4*)(p.bias + co + 4); }
 }
+template <bool REM>
 __device__ __forceinline__ void epi8_load(const ConvP& p, int pn, int py, int px, int co, Epi8& l) {
   typedef h16_t T;
   l.a = l.r1 = l.r2 = l.r1l = make_uint4(0, 0, 0, 0);
   if (p.aux.p) l.a = *(const uint4*)(vptr<T>(p.aux, pn, py, px) + co);
   if (p.res1.p) l.r1 = *(const uint4*)(vptr<T>(p.res1, pn, py, px) + co);
-  if (p.r1_rem) l.r1l = *(const uint4*)((const char*)(vptr<T>(p.res1, pn, py, px) + co) + p.r1_rem);
+  if constexpr (REM) {
+    if (p.r1_rem) l.r1l = *(const uint4*)((const char*)(vptr<T>(p.res1, pn, py, px) + co) + p.r1_rem);
+  }
   if (p.res2.p) l.r2 = *(const uint4*)(vptr<T>(p.res2, pn, py, px) + co);
 }
 // v = (bias + v) * act'(aux) + res1 + res2, rounded once, stored as one 16-byte chunk (fast path only: whole aligned chunk)
+template <bool REM>
 __device__ __forceinline__ void epi8_finish(const ConvP& p, float (&v)[8], const Epi8& l, const Bias8& bb, int pn, int py, int px, int co) {
   typedef h16_t T;
   v[0] += bb.b0.x; v[1] += bb.b0.y; v[2] += bb.b0.z; v[3] += bb.b0.w; v[4] += bb.b1.x; v[5] += bb.b1.y; v[6] += bb.b1.z; v[7] += bb.b1.w;
@@ -223,13 +227,13 @@ __device__ __forceinline__ void epi8_finish(const ConvP& p, float (&v)[8], const
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += h2f(t.e[e]);
   }
-  if (p.r1_rem) {
+  if (REM && p.r1_rem) {
     t.v4 = l.r1l;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] += h2f(t.e[e]);
   }
   T* optr = vptr<T>(p.out, pn, py, px) + co;
-  if (p.out_rem) {
+  if (REM && p.out_rem) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) t.e[e] = f2h(h16_rem(v[e]));
     *(uint4*)((char*)optr + p.out_rem) = t.v4;
@@ -241,6 +245,7 @@ __device__ __forceinline__ void epi8_finish(const ConvP& p, float (&v)[8], const
 
 // 8 consecutive output channels of one pixel (16-byte bf16 I/O): same math as conv_epilogue, used by the LDS-staged
 // epilogues where consecutive lanes own consecutive 16-byte chunks of a pixel row (fully coalesced stores / loads)
+template <bool REM>
 __device__ __forceinline__ void conv_epilogue8_h16(const ConvP& p, float (&v)[8], int pn, int py, int px, int co) {
   typedef h16_t T;
   if (co >= p.Co) {
@@ -256,8 +261,8 @@ __device__ __forceinline__ void conv_epilogue8_h16(const ConvP& p, float (&v)[8]
   const T* aptr = p.aux.p ? vptr<T>(p.aux, pn, py, px) + co : nullptr;
   const T* r1 = p.res1.p ? vptr<T>(p.res1, pn, py, px) + co : nullptr;
   const T* r2 = p.res2.p ? vptr<T>(p.res2, pn, py, px) + co : nullptr;
-  const T* r1l = (r1 && p.r1_rem) ? (const T*)((const char*)r1 + p.r1_rem) : nullptr;
-  T* orem = p.out_rem ? (T*)((char*)optr + p.out_rem) : nullptr;
+  const T* r1l = (REM && r1 && p.r1_rem) ? (const T*)((const char*)r1 + p.r1_rem) : nullptr;
+  T* orem = (REM && p.out_rem) ? (T*)((char*)optr + p.out_rem) : nullptr;
   if (co + 8 <= p.Co && p.epi_vec16) {
     if (p.bias) {
       const float4 b0 = *(const float4*)(p.bias + co), b1 = *(const float4*)(p.bias + co + 4);
@@ -557,8 +562,8 @@ __device__ __forceinline__ void act_pieces(char* buf, const int wave, const int 
   }
 }
 
-template <typename T, int NTC, int KS>
-__global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP p, TileP q) {
+template <typename T, int NTC, int KS, bool REM>
+__global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP p, TileP q) {  // REM: remainder planes of the f16 trunk (own instance: the plain one keeps its registers)
   CGEN_SETPRIO();  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   constexpr int G = 16 / sizeof(T);
   constexpr int HALO = KS / 2, HH = TILE_H + 2 * HALO, HW = TILE_W + 2 * HALO, HPX = HH * HW;
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP 
       const int py = y0 + wave * 2 + (pl >> 4), px = x0 + (pl & 15);
       const int co = co_base + ch * 8;
       efast[k] = py < p.H && px < p.W && p.epi_vec16 && co + 8 <= p.Co && !(q.dbg & 16);
-      if (efast[k]) epi8_load(p, n, py, px, co, epl[k]);
+      if (efast[k]) epi8_load<REM>(p, n, py, px, co, epl[k]);
     }
   }
 
@@ -737,8 +742,8 @@ __global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP 
       if (py < p.H && px < p.W) {
         const f32x4 lo = *(const f32x4*)(es + pl * LDE + ch * 8), hi = *(const f32x4*)(es + pl * LDE + ch * 8 + 4);
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        if (efast[k]) epi8_finish(p, v, epl[k], ebias, n, py, px, co_base + ch * 8);
-        else conv_epilogue8_h16(p, v, n, py, px, co_base + ch * 8);
+        if (efast[k]) epi8_finish<REM>(p, v, epl[k], ebias, n, py, px, co_base + ch * 8);
+        else conv_epilogue8_h16<REM>(p, v, n, py, px, co_base + ch * 8);
       }
     }
   } else {
@@ -747,7 +752,7 @@ __global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP 
       const int py = y0 + wave * 2 + f, px = x0 + fr;
       if (py >= p.H || px >= p.W) continue;
 #pragma unroll
-      for (int t = 0; t < NTC; ++t) conv_epilogue<T>(p, acc[t][f], n, py, px, co_base + t * 16 + fg * 4);
+      for (int t = 0; t < NTC; ++t) conv_epilogue<T, REM>(p, acc[t][f], n, py, px, co_base + t * 16 + fg * 4);
     }
   }
 }
@@ -788,9 +793,18 @@ static bool launch_conv_tile(const ConvP& p, hipStream_t st) {
   q.d_gprw = mk_fastdiv(q.ldw / G); q.d_gprx = mk_fastdiv(q.ldc / G); q.d_cw = mk_fastdiv(q.cw);
   { const char* e = getenv("CGEN_TILE_DBG"); q.dbg = e ? atoi(e) : 0; q.pad0 = 0; }
   dim3 block(256);
-  if (ntc == 1) hipLaunchKernelGGL((conv_tile_kernel<T, 1, KS>), dim3(ntiles, ceil_div(p.Co, 16)), block, lds, st, p, q);
-  else if (ntc == 2) hipLaunchKernelGGL((conv_tile_kernel<T, 2, KS>), dim3(ntiles, ceil_div(p.Co, 32)), block, lds, st, p, q);
-  else hipLaunchKernelGGL((conv_tile_kernel<T, 4, KS>), dim3(ntiles, ceil_div(p.Co, 64)), block, lds, st, p, q);
+  const bool rem = sizeof(T) == 2 && (p.out_rem || p.r1_rem);  // (remainder planes: f16 only, checked by cgen_conv2d)
+  if constexpr (sizeof(T) == 2) {
+    if (rem) {
+      if (ntc == 1) hipLaunchKernelGGL((conv_tile_kernel<T, 1, KS, true>), dim3(ntiles, ceil_div(p.Co, 16)), block, lds, st, p, q);
+      else if (ntc == 2) hipLaunchKernelGGL((conv_tile_kernel<T, 2, KS, true>), dim3(ntiles, ceil_div(p.Co, 32)), block, lds, st, p, q);
+      else hipLaunchKernelGGL((conv_tile_kernel<T, 4, KS, true>), dim3(ntiles, ceil_div(p.Co, 64)), block, lds, st, p, q);
+      return true;
+    }
+  }
+  if (ntc == 1) hipLaunchKernelGGL((conv_tile_kernel<T, 1, KS, false>), dim3(ntiles, ceil_div(p.Co, 16)), block, lds, st, p, q);
+  else if (ntc == 2) hipLaunchKernelGGL((conv_tile_kernel<T, 2, KS, false>), dim3(ntiles, ceil_div(p.Co, 32)), block, lds, st, p, q);
+  else hipLaunchKernelGGL((conv_tile_kernel<T, 4, KS, false>), dim3(ntiles, ceil_div(p.Co, 64)), block, lds, st, p, q);
   return true;
 }
 
@@ -1763,7 +1777,7 @@ struct PxP {
 
 // bf16 pair -> two floats
 
-template <int NP, int KS, bool ONESEG>
+template <int NP, int KS, bool ONESEG, bool REM>
 __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
   CGEN_SETPRIO();  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   typedef h16_t T;
@@ -1844,7 +1858,8 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
   // epilogue: this lane owns pixel (row wave*2 + f, column fr) and channels co_base + pr*32 + fg*8 .. +8
   const int ch0 = co_base + fg * 8;
   const bool has_aux = p.aux.p != nullptr, has_r1 = p.res1.p != nullptr, has_r2 = p.res2.p != nullptr;
-  const bool has_r1l = p.r1_rem != 0, has_orem = p.out_rem != 0;  // remainder planes of the f16 residual trunk (cgen_conv_args)
+  // remainder planes of the f16 residual trunk (cgen_conv_args): an instance of their own, the plain one keeps its registers
+  const bool has_r1l = REM && p.r1_rem != 0, has_orem = REM && p.out_rem != 0;
   int eo_out[2], eo_aux[2], eo_r1[2], eo_r2[2];  // byte offsets from the tile origin of each tensor (strides < 2^24)
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
@@ -1885,7 +1900,7 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
     // ---- epilogue operands: requested now, consumed after the MFMA loop
     const bool colv = x0 + fr < p.W;
     bool pv[2];
-    uint4 ea[NP][2], er[NP][2], el[NP][2];
+    uint4 ea[NP][2], er[NP][2], el[REM ? NP : 1][2];
     {
       const char* aux_t = has_aux ? (const char*)vptr32<T>(p.aux, n, y0, x0) : nullptr;
       const char* r1_t = has_r1 ? (const char*)vptr32<T>(p.res1, n, y0, x0) : nullptr;
@@ -1899,8 +1914,10 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
           er[pr][f] = make_uint4(0, 0, 0, 0);
           if (has_aux) ea[pr][f] = *(const uint4*)(ok ? aux_t + eo_aux[f] + pr * 64 : (const char*)g_zero16);
           if (has_r1) er[pr][f] = *(const uint4*)(ok ? r1_t + eo_r1[f] + pr * 64 : (const char*)g_zero16);
-          el[pr][f] = make_uint4(0, 0, 0, 0);
-          if (has_r1l) el[pr][f] = *(const uint4*)(ok ? r1_t + p.r1_rem + eo_r1[f] + pr * 64 : (const char*)g_zero16);
+          if constexpr (REM) {
+            el[pr][f] = make_uint4(0, 0, 0, 0);
+            if (has_r1l) el[pr][f] = *(const uint4*)(ok ? r1_t + p.r1_rem + eo_r1[f] + pr * 64 : (const char*)g_zero16);
+          }
         }
       }
     }
@@ -1991,8 +2008,8 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[2 * e] += h_lo(w[e]); v[2 * e + 1] += h_hi(w[e]); }
           }
-          if (has_r1l) {
-            const uint32_t w[4] = {el[pr][f].x, el[pr][f].y, el[pr][f].z, el[pr][f].w};
+          if (REM && has_r1l) {
+            const uint32_t w[4] = {el[REM ? pr : 0][f].x, el[REM ? pr : 0][f].y, el[REM ? pr : 0][f].z, el[REM ? pr : 0][f].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[2 * e] += h_lo(w[e]); v[2 * e + 1] += h_hi(w[e]); }
           }
@@ -2012,11 +2029,18 @@ __global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
   }
 }
 
+template <int NP, int KS, bool ONESEG, bool REM>
+static void launch_px_inst3(const ConvP& p, const PxP& q, dim3 grid, size_t lds, hipStream_t st) {
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)conv_px_kernel<NP, KS, ONESEG, REM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  hipLaunchKernelGGL((conv_px_kernel<NP, KS, ONESEG, REM>), grid, dim3(256), lds, st, p, q);
+}
 template <int NP, int KS, bool ONESEG>
 static void launch_px_inst2(const ConvP& p, const PxP& q, dim3 grid, size_t lds, hipStream_t st) {
-  static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)conv_px_kernel<NP, KS, ONESEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-  hipLaunchKernelGGL((conv_px_kernel<NP, KS, ONESEG>), grid, dim3(256), lds, st, p, q);
+  if constexpr (NP <= 3) {  // (the remainder-plane instance of four channel pairs would spill: launch_conv_px caps np at 3 for it)
+    if (p.out_rem || p.r1_rem) { launch_px_inst3<NP, KS, ONESEG, true>(p, q, grid, lds, st); return; }
+  }
+  launch_px_inst3<NP, KS, ONESEG, false>(p, q, grid, lds, st);
 }
 template <int NP>
 static void launch_px_inst(const ConvP& p, const PxP& q, dim3 grid, size_t lds, hipStream_t st) {
@@ -2064,6 +2088,7 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st) {
   static const int lds_budget = [] { const char* e = getenv("CGEN_PX_LDS"); return (e ? atoi(e) : 52) * 1024; }();
   while (np > 1 && lds_of(np) > (size_t)lds_budget) --np;
   if (np == 3 && np_all == 4) np = 2;
+  if ((p.out_rem || p.r1_rem) && np > 3) np = np_all % 3 == 0 ? 3 : 2;  // remainder planes: one more operand set in registers
   static const int min_wgs = [] { const char* e = getenv("CGEN_PX_MINWG"); return e ? atoi(e) : 512; }();
   while (np > 1 && (int64_t)q.ntiles * ceil_div(np_all, np) < min_wgs) --np;
   const size_t lds = lds_of(np);
