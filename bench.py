@@ -245,7 +245,7 @@ def cf_leg(model, x, pa, config, n_cf=10):
 
 
 def cf_deviation(m_a, m_b, x, pa):
-    """max |cf_x| difference between two models holding the SAME weights (bf16 path vs f32 parity path) on the benched batch,
+    """max |cf_x| difference between two models holding the SAME weights (f16 path vs f32 parity path) on the benched batch,
     same Philox state: what the reduced precision does to counterfactual pixels (north_star: 1e-3 abs vs the reference)."""
     from causal_gen_amd.dscm import counterfactual
 
@@ -263,9 +263,9 @@ def cf_deviation(m_a, m_b, x, pa):
     return float((outs[0] - outs[1]).abs().max())
 
 
-def f32_leg(a, hp, B, dev, x, pa, m_bf16):
+def f32_leg(a, hp, B, dev, x, pa, m_f16):
     """The PARITY path (exact f32 MFMA chains: the one the 1e-4 ELBO tests hold on) timed in the same run on the same
-    workload, with its own roofline (157.3 TF dense f32 MFMA), and the bf16 path's ELBO deviation from it on the benched
+    workload, with its own roofline (157.3 TF dense f32 MFMA), and the f16 path's ELBO deviation from it on the benched
     batch at identical weights and identical Philox noise."""
     from causal_gen_amd.train import TrainStep
 
@@ -282,10 +282,10 @@ def f32_leg(a, hp, B, dev, x, pa, m_bf16):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     roof = profile_step(ts32, x, pa, "f32", None)
-    # same weights, same noise: the bf16-trained parameters go into the f32 model; both draw from one Philox state
-    m32.load_state_dict(m_bf16.state_dict())
+    # same weights, same noise: the f16-trained parameters go into the f32 model; both draw from one Philox state
+    m32.load_state_dict(m_f16.state_dict())
     vals = {}
-    for name, mod in (("f16", m_bf16), ("f32", m32)):
+    for name, mod in (("f16", m_f16), ("f32", m32)):
         was = mod.training
         mod.eval()
         eng = mod.engine()
@@ -299,12 +299,12 @@ def f32_leg(a, hp, B, dev, x, pa, m_bf16):
     gf = TRAIN_GFLOP_PER_IMG[a.config]
     img_s = B * steps / dt
     cf32 = cf_leg(m32, x, pa, a.config, n_cf=4) if not a.no_cf else {}
-    cfdev = cf_deviation(m_bf16, m32, x, pa) if not a.no_cf else None
+    cfdev = cf_deviation(m_f16, m32, x, pa) if not a.no_cf else None
     cfdev_plain = None
-    if not a.no_cf and m_bf16.engine().trunk_mode == 1:
-        m_bf16.engine().trunk_mode = 0
-        cfdev_plain = cf_deviation(m_bf16, m32, x, pa)
-        m_bf16.engine().trunk_mode = 1
+    if not a.no_cf and m_f16.engine().trunk_mode == 1:
+        m_f16.engine().trunk_mode = 0
+        cfdev_plain = cf_deviation(m_f16, m32, x, pa)
+        m_f16.engine().trunk_mode = 1
     del ts32, m32
     torch.cuda.empty_cache()
     return {"images_s": img_s, "counterfactuals_per_s": cf32.get("counterfactuals_per_s"), "cf_tflops": cf32.get("cf_tflops"),
@@ -316,8 +316,8 @@ def f32_leg(a, hp, B, dev, x, pa, m_bf16):
 
 
 def side_config(name, dmol, B, dev, steps=10, prep=12, cf=True, parity=True):
-    """One more workload in the same run (bf16 train step under a hipGraph, synthetic batch resident in HBM): images/s, fraction
-    of the dense bf16 MFMA peak, counterfactuals/s, and the bf16 path's ELBO deviation from the f32 parity path at identical
+    """One more workload in the same run (f16 train step under a hipGraph, synthetic batch resident in HBM): images/s, fraction
+    of the dense f16 MFMA peak, counterfactuals/s, and the f16 path's ELBO deviation from the f32 parity path at identical
     weights and noise."""
     from causal_gen_amd.train import TrainStep
 
@@ -369,7 +369,7 @@ def side_config(name, dmol, B, dev, steps=10, prep=12, cf=True, parity=True):
 
 def bandwidth_kernels(dev):
     """The HBM-bound kernels of the step against the HBM roofline ("report all three"): algorithmic bytes / HIP-event
-    time of the stand-alone launch at the ukbb192 shapes (batch 32, bf16), next to 6.3 TB/s achievable and 8 TB/s spec."""
+    time of the stand-alone launch at the ukbb192 shapes (batch 32, f16), next to 6.3 TB/s achievable and 8 TB/s spec."""
     from causal_gen_amd import _lib
     from causal_gen_amd.engine import Engine
 
@@ -438,7 +438,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-cf", action="store_true")
-    ap.add_argument("--no-f32", action="store_true", help="skip the f32 parity-path leg (default: timed after the bf16 headline at N=1)")
+    ap.add_argument("--no-f32", action="store_true", help="skip the f32 parity-path leg (default: timed after the f16 headline at N=1)")
     ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs, the batch sweep and the bandwidth-kernel table (default ukbb192 run only)")
     ap.add_argument("--prep-steps", type=int, default=20, help="untimed optimiser steps so the prior heads are non-zero")
     a = ap.parse_args()

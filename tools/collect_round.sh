@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 cd /root/repo
 rm -rf gpurun_out/$tag gpurun_out/${tag}_f gpurun_out/${tag}_w gpurun_out/${tag}_A gpurun_out/${tag}_B
 rocprofv3 --kernel-trace --stats -d gpurun_out/$tag -o $tag --output-format csv -- python bench.py --steps 5 --warmup 2 --no-cpu --no-f32 --no-extra > gpurun_out/$tag.log 2>&1
-python tools/stats_to_txt.py gpurun_out/$tag/*/${tag}_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu --no-f32   (ukbb192, batch 32, bf16, 1 x MI355X; 27 train steps incl. 20 preparation steps + the eager profiling step, then the counterfactual loop)" > gpurun_out/${tag}_kernel_stats.txt 2>/dev/null || python tools/stats_to_txt.py $(find gpurun_out/$tag -name "*kernel_stats.csv" | head -1) "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu --no-f32 (ukbb192, batch 32, bf16, 1 x MI355X)" > gpurun_out/${tag}_kernel_stats.txt
+python tools/stats_to_txt.py gpurun_out/$tag/*/${tag}_kernel_stats.csv "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu --no-f32   (ukbb192, batch 32, f16, 1 x MI355X; 27 train steps incl. 20 preparation steps + the eager profiling step, then the counterfactual loop)" > gpurun_out/${tag}_kernel_stats.txt 2>/dev/null || python tools/stats_to_txt.py $(find gpurun_out/$tag -name "*kernel_stats.csv" | head -1) "rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-cpu --no-f32 (ukbb192, batch 32, f16, 1 x MI355X)" > gpurun_out/${tag}_kernel_stats.txt
 python tools/timeline.py $(find gpurun_out/$tag -name "*kernel_trace.csv" | head -1) gpurun_out/${tag}_step_timeline.txt > /dev/null 2>&1
 rm -rf gpurun_out/$tag/*/*kernel_trace.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${tag}_f -o f --output-format csv -- python bench.py --steps 2 --warmup 1 --prep-steps 1 --no-cpu --no-cf --no-f32 --no-extra > gpurun_out/${tag}_f.log 2>&1
