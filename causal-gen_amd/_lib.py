@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcgen_hip.so")
+LIB_PATH = os.environ.get("CGEN_LIB") or os.path.join(_HERE, "libcgen_hip.so")  # (CGEN_LIB: another build of the same ABI, for A/B runs)
 
 F32, F16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2

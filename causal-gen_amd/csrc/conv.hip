@@ -1778,7 +1778,7 @@ struct PxP {
 // bf16 pair -> two floats
 
 template <int NP, int KS, bool ONESEG, bool REM>
-__global__ __launch_bounds__(256, 2) void conv_px_kernel(ConvP p, PxP q) {
+__global__ __launch_bounds__(256, (NP <= 2 && !REM) ? 3 : 2) void conv_px_kernel(ConvP p, PxP q) {
   CGEN_SETPRIO();  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   typedef h16_t T;
   constexpr int G = 8, HALO = KS / 2, HW = TILE_W + 2 * HALO, TAPS = KS * KS;
@@ -2089,6 +2089,12 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st) {
   while (np > 1 && lds_of(np) > (size_t)lds_budget) --np;
   if (np == 3 && np_all == 4) np = 2;
   if ((p.out_rem || p.r1_rem) && np > 3) np = np_all % 3 == 0 ? 3 : 2;  // remainder planes: one more operand set in registers
+  // Two pairs at most by default: the one- and two-pair instances fit 168 VGPRs (three workgroups per CU, which is what the grid
+  // below assumes), the three- and four-pair ones need 208 / 248 and leave a third of the launched workgroups waiting for a slot.
+  // Measured on ukbb192 B = 32 (interleaved A/B, two rounds): 1954 / 1957 img/s before, 1969 / 1964 with the cap and
+  // __launch_bounds__(256, 3) on the small instances (alone: 1955 / 1959).
+  static const int max_np = [] { const char* e = getenv("CGEN_PX_MAXNP"); return e ? atoi(e) : 2; }();
+  if (np > max_np) np = max_np;
   static const int min_wgs = [] { const char* e = getenv("CGEN_PX_MINWG"); return e ? atoi(e) : 512; }();
   while (np > 1 && (int64_t)q.ntiles * ceil_div(np_all, np) < min_wgs) --np;
   const size_t lds = lds_of(np);
