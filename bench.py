@@ -209,7 +209,13 @@ def profile_step(ts, x, pa, dtype, workload_key=None):
     top = top[:8]
     traffic, traffic_src = pmc_traffic(dom, dtype) if workload_key == ("ukbb192", 32) else (None, None)
     busy = pmc_mfma_busy(dom) if workload_key == ("ukbb192", 32) and dtype == "f16" else None
-    return dict(
+    # the same class against the HBM roofline: counter bytes per launch over the live average launch time (this class mixes
+    # HBM-bound launches -- the C/4 -> C convs at >= 96x96 run at 4.6 TB/s -- with latency-bound ones)
+    hbm = None
+    if traffic:
+        tbs = traffic / (1e-3 * ms / n) / 1e12
+        hbm = dict(achieved_TB_s=tbs, frac_of_8_TB_s=tbs / 8.0, frac_of_6p3_TB_s_achievable=tbs / 6.3)
+    return dict(hbm=hbm, 
         bound="mfma", kernel=dom, achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_PEAK_TF[dtype], unit="TFLOP/s",
         frac=flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dtype], traffic=traffic, traffic_source=traffic_src, mfma_counters=busy, launches=n, avg_launch_us=1e3 * ms / n,
         algorithmic_flops_per_launch=flops / n, launches_per_step=launches_per_step,
