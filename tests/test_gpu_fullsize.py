@@ -63,10 +63,14 @@ def _grad_err(got, ref):
     The relative L2 error has no such allowance."""
     d = (got - ref).abs().reshape(-1)
     mx = float(ref.abs().max()) + 1e-30
+    _grad_err.exempted += int((d > GRAD_TOL * mx).sum())  # elements that actually use the allowance (reported per preset)
     allowed = int(d.numel() * 1e-4)
     if allowed:
         d = d.sort().values[: d.numel() - allowed]
     return float(d.max()) / mx, float((got - ref).double().norm()) / (float(ref.double().norm()) + 1e-30)
+
+
+_grad_err.exempted = 0
 
 
 @pytest.mark.parametrize("name,B,dmol", R.CASES, ids=[R.key(n, d) for n, _, d in R.CASES])
@@ -76,6 +80,7 @@ def test_fullsize_forward_backward_counterfactual(name, B, dmol):
     from oracle import hvae_ref
 
     row = load_golden("fullsize.pt")[R.key(name, dmol)]
+    _grad_err.exempted = 0
     m, hp = _model(name, dmol, "f32")
     abs_sum = float(sum(p.detach().abs().double().sum() for p in m.parameters()))
     assert abs(abs_sum - row["abs_sum"]) < 1e-6 * row["abs_sum"], "the seeded recipe did not rebuild the reference's weights"
@@ -148,10 +153,10 @@ def test_fullsize_forward_backward_counterfactual(name, B, dmol):
     with torch.no_grad():
         cf_b = dscm.counterfactual(mb, x.cuda(), pa.cuda(), cf_pa.cuda(), t_abduct=1.0)
     d_cfb = float((R.sample_img(cf_b).cpu() - row["cf"]["cf_x"]).abs()[ok].max())
-    print("FULLSIZE %s: f32 vs reference elbo %.2e nll %.2e kl %.2e | grads: worst %.2e (fixture sample) %.2e (oracle, %d tensors) | "
+    print("FULLSIZE %s: f32 vs reference elbo %.2e nll %.2e kl %.2e | grads: worst %.2e (fixture sample) %.2e (oracle, %d tensors; %d elements over the max-norm bound, all inside the 1e-4 allowance) | "
           "cf %.2e (%d of %d sampled pixels masked: rec_scale <= 1e-3) || f16 vs reference elbo %.2e nll %.2e kl %.2e cf %.2e" % (
               R.key(name, dmol), _rel(got["elbo"], row["elbo"]), _rel(got["nll"], row["nll"]), _rel(got["kl"], row["kl"]), worst_fx,
-              worst, n_checked, float(d_cf[ok].max()), n_masked, n_pix, dev["elbo"], dev["nll"], dev["kl"], d_cfb))
+              worst, n_checked, _grad_err.exempted, float(d_cf[ok].max()), n_masked, n_pix, dev["elbo"], dev["nll"], dev["kl"], d_cfb))
     etol = F16_ELBO_TOL.get(name, F16_ELBO_TOL_DEFAULT)
     assert dev["elbo"] < etol and dev["nll"] < etol, dev
     assert dev["kl"] < F16_KL_TOL, dev
