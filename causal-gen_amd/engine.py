@@ -287,13 +287,17 @@ class Engine(StageMixin):
         not move between k - 3 and k + 3: it is the forward operand rounding, not gradient underflow.  A non-finite gradient (a
         spike 200x above that) fails the step's NaN / grad_skip predicate like any other (trainer.py:69-77).
         ``CGEN_LOSS_SCALE_LOG2`` overrides k."""
-        if self.dt == F32:
-            self.loss_scale = 1.0
-        else:
-            k = os.environ.get("CGEN_LOSS_SCALE_LOG2")
-            k = int(k) if k is not None else max(0, int(round(math.log2(max(float(n_terms), 1.0)))) - 1)
-            self.loss_scale = float(2 ** k)
+        self.loss_scale = self.loss_scale_rule(n_terms, self.dt == F32)
         return self.loss_scale
+
+    @staticmethod
+    def loss_scale_rule(n_terms, is_f32=False):
+        """The rule itself (host logic, no GPU): 1 for f32, else a power of two, 2^(round(log2 n_terms) - 1), >= 1."""
+        if is_f32:
+            return 1.0
+        k = os.environ.get("CGEN_LOSS_SCALE_LOG2")
+        k = int(k) if k is not None else max(0, int(round(math.log2(max(float(n_terms), 1.0)))) - 1)
+        return float(2 ** k)
 
     # ------------------------------------------------------------------ memory
     def begin(self):

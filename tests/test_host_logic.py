@@ -159,3 +159,28 @@ def test_dmol_hvae_checkpoint_loads(tmp_path):
     assert isinstance(m.likelihood, dmol.DmolNet) and args.x_like == "diag_dmol"
     for k, v in fx["state_dict"].items():
         assert torch.equal(m.state_dict()[k], v), k
+
+
+def test_f16_loss_scale_rule_is_an_exact_power_of_two_tied_to_the_seed_size():
+    """engine.Engine.loss_scale_rule (host logic of the f16 engine's gradient scaling): 1 for f32; otherwise a power
+    of two -- multiplying by it commutes with binary16 rounding -- that puts the seeds 1 / n_terms at 1/4 .. 1 whatever the batch,
+    the image size or the accumulation count, and whose reciprocal (what the reduce kernels multiply by) is exact in f32."""
+    import math
+    import os
+
+    from causal_gen_amd.engine import Engine
+
+    assert "CGEN_LOSS_SCALE_LOG2" not in os.environ
+    assert Engine.loss_scale_rule(32 * 36864, is_f32=True) == 1.0
+    for n in (1, 3, 256 * 1024, 32 * 36864, 8 * 36864, 256 * 3 * 1024, 32 * 224 * 224 * 4, 10 ** 9):
+        s = Engine.loss_scale_rule(n)
+        m, e = math.frexp(s)
+        assert m == 0.5 and s >= 1.0, (n, s)                      # a power of two
+        assert (1.0 / s) * s == 1.0                                # exactly invertible
+        if n >= 4:
+            assert 0.25 <= s / n <= 1.0, (n, s, s / n)             # the seeds land at 1/4 .. 1
+    os.environ["CGEN_LOSS_SCALE_LOG2"] = "5"
+    try:
+        assert Engine.loss_scale_rule(123456) == 32.0
+    finally:
+        del os.environ["CGEN_LOSS_SCALE_LOG2"]
