@@ -206,6 +206,7 @@ class Engine(StageMixin):
         # traffic of the trunk convs (HBM-bound at >= 96x96): counterfactuals/s -12.6 %, a training step -8.5 % -- for an ELBO
         # that is within 1.2e-5 of the reference either way, which is why training keeps the plain trunk.
         self.trunk_mode = int(os.environ.get("CGEN_TRUNK_REM", "1"))
+        self.trunk_maxres = int(os.environ.get("CGEN_TRUNK_REM_MAXRES", "100000"))  # planes only on images up to this side
         self.arena = Arena(self.device)
         self.tape, self.recording = _Tape(), False
         self.tape.eng = self
@@ -546,7 +547,7 @@ class Engine(StageMixin):
         if res2 is not None and res2.rem and (res1 is None or not res1.rem):
             res1, res2 = res2, res1  # (only res1 carries a remainder plane)
         if out is None:
-            out = self.new(x0.n, x0.h, x0.w, site.co, rem=trunk and self.trunk_rem)
+            out = self.new(x0.n, x0.h, x0.w, site.co, rem=trunk and self.trunk_rem and max(x0.h, x0.w) <= self.trunk_maxres)
             if site.co % 8:  # ragged width (e.g. the 4-channel bottleneck of a 16-wide Block): the kernel zero-fills the
                 out.cpad = _ceil(site.co, 8)  # padding channels, which keeps the tensor DMA-clean for its consumers
         assert out.c == site.co and len(segs) == len(site.seg_c)
