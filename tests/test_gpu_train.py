@@ -762,3 +762,38 @@ def test_fused_latent_layer_matches_the_two_launch_form():
             assert abs(res[True][0][k] - res[False][0][k]) <= 1e-4 * abs(res[False][0][k]) + 1e-9, (name, k, res[True][0][k], res[False][0][k])
         ga, gb = res[True][1], res[False][1]
         assert float((ga - gb).norm()) <= 3e-3 * float(gb.norm()), (name, float((ga - gb).norm()), float(gb.norm()))
+
+
+def test_f16_training_tracks_the_f32_path():
+    """Loss-scaled binary16 training against the f32 parity path: two models from one init, the same stream of fresh
+    synthetic batches and the same Philox noise through the captured `TrainStep` (AdamW, warm-up, clip / skip, EMA).  After 40
+    optimiser steps the ELBO curves agree to 1e-4 at every step, no step was skipped on either path, the parameters are within
+    2 % (relative L2).  tools/train_track.py is the long form (300 steps: 4e-5 on ukbb192, 3e-6 on morphomnist)."""
+    import bench
+    from causal_gen_amd.train import TrainStep
+
+    curves, finals, skipped = {}, {}, {}
+    for dt in ("f32", "f16"):
+        m, hp = bench.build_model("morphomnist", dt)
+        m = m.cuda().train()
+        m.decoder.__dict__["drop_cond"] = lambda: (1, 1)
+        ts = TrainStep(m, hp, ema=True, use_graph=True)
+        eng = m.engine()
+        eng.rng_ptr()
+        eng.rng.copy_(torch.tensor([77, 0], dtype=torch.int64, device=eng.rng.device))
+        c = []
+        for it in range(40):
+            x, pa = bench.synth_batch("morphomnist", hp, 16, "cuda", 500 + it)
+            c.append(ts.step(x, pa).clone())
+        torch.cuda.synchronize()
+        curves[dt] = torch.stack(c).cpu()
+        finals[dt] = torch.cat([p.detach().flatten().float() for p in m.parameters()]).cpu()
+        skipped[dt] = ts.stats()["n_skipped"]
+        if dt == "f16":
+            assert eng.loss_scale >= 1024.0  # (16 * 1024 terms -> 2^13)
+    assert skipped == {"f32": 0, "f16": 0}, skipped
+    rel = ((curves["f16"][:, 0] - curves["f32"][:, 0]).abs() / curves["f32"][:, 0].abs()).max()
+    assert float(rel) < 1e-4, float(rel)
+    assert float(curves["f32"][-1, 0]) < float(curves["f32"][0, 0])  # (it did train)
+    d = float((finals["f16"] - finals["f32"]).norm() / finals["f32"].norm())
+    assert d < 2e-2, d
