@@ -206,6 +206,9 @@ class Engine(StageMixin):
         # traffic of the trunk convs (HBM-bound at >= 96x96): counterfactuals/s -12.6 %, a training step -8.5 % -- for an ELBO
         # that is within 1.2e-5 of the reference either way, which is why training keeps the plain trunk.
         self.trunk_mode = int(os.environ.get("CGEN_TRUNK_REM", "1"))
+        # CGEN_ABLATE="f1,d3" (planning tool, results are WRONG): what would the step cost if a light Block were one launch as
+        # long as its HBM-bound half -- the upper bound of Block fusion on the critical path
+        self._ablate = os.environ.get("CGEN_ABLATE", "")
         self.trunk_maxres = int(os.environ.get("CGEN_TRUNK_REM_MAXRES", "100000"))  # planes only on images up to this side
         self.arena = Arena(self.device)
         self.tape, self.recording = _Tape(), False
@@ -566,7 +569,11 @@ class Engine(StageMixin):
         a.res2 = vw(res2)
         a.out_rem = out.rem
         a.res1_rem = res1.rem if res1 is not None else 0
-        self._timed("conv_fwd", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream))
+        if self._ablate and ((site.name.endswith(".conv.1") and "f1" in self._ablate) or ("r12" in self._ablate and x0.h <= 12)
+                             or any(x0.h == r and ("r%d" % r) in self._ablate for r in (24, 48, 96, 192))):
+            pass  # TIMING-ONLY ablation (CGEN_ABLATE, wrong results): the first conv of every Block is not launched
+        else:
+            self._timed("conv_fwd", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream))
         if self.recording:
             if self._dbg_names is not None:
                 self._dbg_names[id(out.base)] = site.name
@@ -1218,6 +1225,9 @@ class Engine(StageMixin):
         a.aux = vw(s) if act != ACT_NONE else NULL_VIEW
         a.res1 = vw(prev) if acc else NULL_VIEW
         a.res2 = NULL_VIEW
+        if self._ablate and ((site.name.endswith(".conv.3") and "d3" in self._ablate) or ("r12" in self._ablate and x0.h <= 12)
+                             or any(x0.h == r and ("r%d" % r) in self._ablate for r in (24, 48, 96, 192))):
+            return  # TIMING-ONLY ablation: the data gradient of every Block's second conv is not launched
         self._timed("conv_dgrad", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream), ci=s.c)
 
     def _dgrad_target(self, s):
