@@ -219,7 +219,7 @@ def profile_step(ts, x, pa, dtype, workload_key=None):
         bound="mfma", kernel=dom, achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_PEAK_TF[dtype], unit="TFLOP/s",
         frac=flops / (ms * 1e-3) / 1e12 / MFMA_PEAK_TF[dtype], traffic=traffic, traffic_source=traffic_src, mfma_counters=busy, launches=n, avg_launch_us=1e3 * ms / n,
         algorithmic_flops_per_launch=flops / n, launches_per_step=launches_per_step,
-        classes={k: dict(tflops=v[0] / (v[1] * 1e-3) / 1e12, ms=v[1], launches=v[2]) for k, v in classes.items()},
+        classes={k: dict(tflops=v[0] / (v[1] * 1e-3) / 1e12 if v[1] else 0.0, ms=v[1], launches=v[2]) for k, v in classes.items()},
         top_shapes=[dict(kind=k[0], ks=k[1], ci=k[2], co=k[3], res=k[4], ms=v[1], tflops=v[0] / (v[1] * 1e-3) / 1e12, n=v[2])
                     for k, v in top])
 

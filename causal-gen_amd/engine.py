@@ -1201,7 +1201,7 @@ class Engine(StageMixin):
             if r is not None and r.rg:
                 self._grad_residual(r, g, out, segs)
         x0 = segs[0]
-        if self._needs_wgrad(site):
+        if self._needs_wgrad(site) and "wg" not in self._ablate:  # ("wg": timing-only ablation, no weight gradients at all)
             self._wgrad(site, segs, act, g)
         for k, s in enumerate(segs):
             if not (s.rg and site.seg_rg[k]):
