@@ -33,6 +33,16 @@ class BlockArgs(C.Structure):
                 ("mid", View), ("mid_aux", View), ("out", View), ("aux", View), ("res1", View)]
 
 
+class Block3Out(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("out", View), ("aux", View), ("res1", View)]
+
+
+class Block3Args(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("nseg", C.c_int32),
+                ("nout", C.c_int32), ("pre_act", C.c_int32), ("reserved", C.c_int32), ("seg", View * MAX_SEG),
+                ("w_a", C.c_void_p), ("bias_a", C.c_void_p), ("mid", View), ("mid_aux", View), ("o", Block3Out * 2)]
+
+
 class LatentZprojArgs(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("co", C.c_int32),
                 ("q_loc", View), ("q_ls", View), ("p_loc", View), ("p_ls", View), ("eps_in", View), ("z", View), ("eps_out", View),
@@ -104,6 +114,8 @@ PROTOTYPES = {
     "cgen_conv2d": [C.POINTER(ConvArgs), vp],
     "cgen_block2_supported": [C.POINTER(BlockArgs)],
     "cgen_block2": [C.POINTER(BlockArgs), vp],
+    "cgen_block3_supported": [C.POINTER(Block3Args)],
+    "cgen_block3": [C.POINTER(Block3Args), vp],
     "cgen_conv2d_wgrad_plan": [C.POINTER(WgradArgs), C.POINTER(i32)],
     "cgen_conv2d_wgrad_batch_plan": [vp, i32, vp, i64, vp, vp, i32, vp, vp],
     "cgen_conv2d_wgrad_batch_run": [vp, vp, i32, i32, vp],
@@ -167,7 +179,7 @@ PROTOTYPES = {
 }
 _RESTYPES = {"cgen_last_error": C.c_char_p}
 _NOCHECK = {"cgen_version", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks",
-            "cgen_block2_supported", "cgen_latent_zproj_supported", "cgen_stem_conv_supported", "cgen_stage_accepts"}
+            "cgen_block2_supported", "cgen_block3_supported", "cgen_latent_zproj_supported", "cgen_stem_conv_supported", "cgen_stage_accepts"}
 
 
 class WgradBatchLaunch(C.Structure):

@@ -1,0 +1,677 @@
+// Fused "light" Block for gfx950 (MI355X): two 3x3 convolutions per launch, the bottleneck tensor resident in LDS.
+//   vae.py:49-56,60-71,73-84 (version == "light"):  out = conv2(relu(conv1(relu(cat(segs))))) (+ residual), bottleneck b = in/4
+// and the same kernel as the Block's data gradient (aten::convolution_backward x2 + threshold_backward x2, input part):
+//   g_t = conv(g_out; dgrad image of conv2) * relu'(t),   g_x = conv(g_t; dgrad image of conv1) * relu'(x) (+ accumulated gradient).
+//
+// Structure (DESIGN.md section 3 has the measurements that led here):
+//   * one workgroup (4 waves) per 8x16 tile of the Block's OUTPUT, persistent over tiles; <= 53 KB of LDS and <= 168 VGPRs for the
+//     narrow instances, so three workgroups share a CU (today every instance takes 256 VGPRs: two per CU);
+//   * phase A (long K, <= 32 outputs) STREAMS the 12x20 halo tile through a two-slot LDS ring in 32-channel chunks by LDS-DMA
+//     (LDS use is independent of the input width: any number of virtual-cat segments); the chunk's 18 weight fragments come straight
+//     from L2 into registers, in a fragment-ordered image (one contiguous KiB per wave load), one chunk ahead of their use.
+//     The K16-steps of a chunk are dealt to two wave pairs (K split 2 x pixel split 2: every wave owns 3 pixel groups of 32 and half
+//     the taps), the two partial sums meet in LDS in a fixed order => deterministic;
+//   * the bottleneck tile (10x18 pixels) lives in LDS only; its interior is written once for the weight gradients / backward mask;
+//   * phase B (short K, wide output): waves split the output channels in 32-wide pairs (and the tile rows when there are fewer than
+//     four pairs); weight fragments straight from L2, B operands from the LDS-resident bottleneck; epilogue from the accumulators with
+//     32 contiguous bytes per lane (the weight rows are permuted so that a lane's 16 accumulator rows are 16 consecutive channels).
+// MFMA: v_mfma_f32_32x32x16_f16.  Its B operand puts 32 PIXELS of one 8-channel group in lanes 0-31, so with an odd pixel stride
+// (in 16-byte groups) the ds_read_b128 service groups {0-3,12-15,20-27} ... of MI355X_MICROARCH.md hit 16 distinct bank groups:
+// conflict-free fragment reads, which no pixel-major layout gives the 16x16x32 form (its lanes 0-15 / 16-31 read different channel
+// groups of 16 pixels: two of every 16 lanes collide).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace cgen {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x2v __attribute__((ext_vector_type(2)));
+
+__device__ uint4 g_b3zero[4];  // 64 bytes of zeros: source of out-of-image / padding loads
+
+#define B3_TH 8
+#define B3_TW 16
+#define B3_HW 20                    // halo tile: 12 x 20 pixels
+#define B3_MW 18                    // bottleneck tile: 10 x 18 pixels
+#define B3_NMP 180
+#define B3_XS 80                    // bytes per halo pixel in LDS: 4 channel groups of 16 B + one pad group (odd stride)
+#define B3_XBYTES (240 * B3_XS + 64)  // one ring slot: 19 200 B + the overhang of the last DMA instruction (lanes 60-63)
+
+struct B3Div { uint32_t mul, shift; };
+static inline B3Div b3_mkdiv(uint32_t d) {
+  B3Div f;
+  if (d == 1) { f.mul = 0; f.shift = 0; return f; }
+  uint32_t sh = 0;
+  while ((1u << sh) < d) ++sh;
+  f.shift = sh;
+  f.mul = (uint32_t)((((uint64_t)1 << (32 + sh)) + d - 1) / d - ((uint64_t)1 << 32));
+  return f;
+}
+__device__ __forceinline__ int b3_div(int n, const B3Div& f) { return (int)(((uint64_t)__umulhi((uint32_t)n, f.mul) + (uint32_t)n) >> f.shift); }
+
+struct BV3 { const char* p; int sn, sh, sw; };  // 32-bit BYTE strides (the host checks every view spans < 2^31 bytes)
+struct B3Out {
+  const char* w;      // phase-B fragment image [pair][K16-step][lane][8]
+  const float* bias;  // [Co] or null
+  BV3 out, aux, res;  // aux: mask (v = aux > 0 ? v : 0); res: added
+  int Co, npb;
+};
+struct B3P {
+  int N, H, W, nseg, nch, b, nout, nksB;
+  int tiles_x, tiles_y, ntiles, ctot8;
+  int ns, wb_persist, scratch_off, pad0;  // ring slots; phase-B weights persistent in registers; LDS offset of the second reduction scratch half (0: none)
+  B3Div d_tx, d_ty;
+  BV3 seg[3];
+  int seg_koff[4];  // first channel of segment s on the 8-granular concatenated axis; [nseg] = ctot8
+  int seg_c8[3];
+  const char* wA;   // phase-A fragment image [chunk][K16-step 0..17][lane][8]
+  const float* biasA;
+  BV3 mid, mid_aux;  // mid: written (interior pixels): forward t (pre-activation), backward g_t; mid_aux: backward mask source t
+  B3Out o[2];
+  unsigned long long* stamps;  // optional (CGEN_BLK3_STAMPS=<device address>): shader-clock stamps of workgroup 0, 8 per tile after 2 launch stamps
+};
+
+__device__ __forceinline__ void b3_pin(h16x8& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ h16x8 b3_relu8(h16x8 v) {  // ReLU on the raw bits: one v_pk_max_i16 per channel pair (-0 -> +0)
+  union { h16x8 h; s16x2v s[4]; } c;
+  c.h = v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c.s[e] = __builtin_elementwise_max(c.s[e], (s16x2v){0, 0});
+  return c.h;
+}
+__device__ __forceinline__ f32x16 b3_mfma(h16x8 a, h16x8 b, f32x16 c) {
+#ifdef CGEN_H16_BF16
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ uint4 b3_pack8(const float* v) {
+  uint4 o;
+  o.x = f2h_pk(v[0], v[1]); o.y = f2h_pk(v[2], v[3]); o.z = f2h_pk(v[4], v[5]); o.w = f2h_pk(v[6], v[7]);
+  return o;
+}
+#define B3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define B3_VMWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+// the 9 K16-steps (one per tap) of one 32-channel chunk that this wave owns: K half kh = channels 16 kh .. + 16 of the chunk (folded
+// into pbA), fragment reads issued one step ahead of the MFMAs that consume them
+template <bool PRE>
+__device__ __forceinline__ void b3_chunk(const char* __restrict__ Xc, const h16x8 (&Ac)[9], const int (&pbA)[3], f32x16 (&acc)[3]) {
+  h16x8 bq[2][3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) bq[0][g] = *(const h16x8*)(Xc + pbA[g]);
+#pragma unroll
+  for (int s = 0; s < 9; ++s) {
+    if (s + 1 < 9) {
+      const int imm = (((s + 1) / 3) * B3_HW + (s + 1) % 3) * B3_XS;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) bq[(s + 1) & 1][g] = *(const h16x8*)(Xc + pbA[g] + imm);
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = b3_mfma(Ac[s], PRE ? b3_relu8(bq[s & 1][g]) : bq[s & 1][g], acc[g]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// PRE: ReLU on the phase-A input (forward); NB = bottleneck width / 8 (1..4); NPG = output pixel groups (of 32) a wave owns in
+// phase B: 1 (one 32-channel pair, four waves split the tile), 2 (two pairs x two halves), 4 (>= 3 pairs: a wave owns pairs w, w+4, ..)
+//
+// Memory pipeline.  The halo chunks travel through a ring of p.ns LDS slots, requested in BURSTS: all chunks of a tile at once (as
+// many as there are slots), and -- when the ring has a slot more than a tile needs -- the whole NEXT tile at the start of this
+// tile's last chunk, so that in the streaming regime (192x192 / 96x96: one or two chunks per tile, many tiles per workgroup) a
+// tile's input is already in LDS when its turn comes.  Loads return in order and hipcc drains every LDS-DMA in flight at the
+// first use of an ordinary load's result, so ordinary loads are kept out of the spans a burst should survive: weights are
+// PERSISTENT in registers where a tile needs <= 2 chunks / the wave's output pair never changes (loaded once per launch), the
+// epilogue operands are requested BEFORE the next tile's burst and consumed at the very end of the tile.
+template <bool PRE, int NB, int NPG, int SM>
+__global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
+  __builtin_amdgcn_s_setprio(3);
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  constexpr int NBS = (NB & 1) ? NB : NB + 1;  // bottleneck pixel stride in 16-byte groups (odd)
+  constexpr int MS = NBS * 16;
+  constexpr int MAXKB = (9 * NB + 1) / 2;      // K16-steps of phase B (= ceil(9 b / 16))
+  constexpr int RD = SM > 0 ? MAXKB : (NPG == 4 ? (MAXKB < 4 ? MAXKB : 4) : (MAXKB < 8 ? MAXKB : 8));  // phase-B weight ring depth (SM > 0: all of them, persistent)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int NS = p.ns;
+  char* const MID = smem + NS * B3_XBYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 31, kg = lane >> 5;
+  const int kh = wave & 1, gp = wave >> 1;
+  const int H = p.H, W = p.W, nch = p.nch, bch = p.b;
+  constexpr bool bwd = !PRE;  // (the host pairs them: forward = ReLU on the input + bias, backward = mask from mid_aux)
+  const char* const zero = (const char*)g_b3zero;
+  unsigned long long* const stamp = (p.stamps != nullptr && blockIdx.x == 0 && tid == 0) ? p.stamps : nullptr;
+  int nstamp = 2;
+#define B3_STAMP(k) do { if (stamp && nstamp + (k) < 250) stamp[nstamp + (k)] = __builtin_readcyclecounter(); } while (0)
+  if (stamp) stamp[0] = __builtin_readcyclecounter();
+  // SM (streaming mode): 0 = nothing persistent (any number of chunks); 1 / 2 = a tile is one / two chunks: the phase-A weights stay
+  // in registers for the whole launch, and so do the phase-B weights (the host picks SM > 0 only when the wave's pair never changes)
+  constexpr bool persistA = SM > 0, persistB = SM > 0;
+
+  // ---- phase-A lane constants: this lane's bottleneck pixel of group g (3 groups of 32 per wave; 6 x 32 = 192 >= 180)
+  int pbA[3], mpx[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const int m = 32 * (gp * 3 + g) + px;
+    const int mc = min(m, B3_NMP - 1);
+    const int my = (mc * 57) >> 10, mx = mc - my * B3_MW;  // (exact for mc < 180)
+    pbA[g] = (my * B3_HW + mx) * B3_XS + kh * 32 + kg * 16;
+    mpx[g] = m < B3_NMP ? (my << 8 | mx) : -1;
+  }
+  // ---- DMA lane constants: a wave instruction fills 12 halo pixels x 5 groups; wave w issues instructions w, w + 4, ... of the 20
+  // per chunk.  Every lane is active (no exec branches): group 4 is the padding slot (zeros), lanes 60-63 re-write the first four
+  // groups of the NEXT instruction's first pixel with the same bytes (the last instruction's overhang lands behind the slot)
+  const int dpl = lane / 5, dq = lane - 5 * dpl;
+  int dyx[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int pi = 12 * (wave + 4 * i) + dpl;
+    const int hy = pi / B3_HW, hx = pi - hy * B3_HW;
+    dyx[i] = hy << 8 | hx;
+  }
+  // ---- phase-B lane constants
+  const int kgmask = kg ? -1 : 0;
+  const int pbB = ((px >> 4) * B3_MW + (px & 15)) * MS;  // out pixel (2 pg + (px >> 4), px & 15) -> bottleneck tile offset (pg part is an immediate)
+  const int pg0 = NPG == 4 ? 0 : (NPG == 2 ? 2 * (wave >> 1) : wave);
+
+  auto tile_of = [&](const int tile, int& n, int& y0, int& x0) {
+    const int b1 = b3_div(tile, p.d_tx), tx = tile - b1 * p.tiles_x;
+    n = b3_div(b1, p.d_ty);
+    y0 = (b1 - n * p.tiles_y) * B3_TH; x0 = tx * B3_TW;
+  };
+  auto dok_of = [&](const int y0, const int x0) {  // which of this lane's DMA pixels lie inside the image
+    int dok = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int iy = y0 - 2 + (dyx[i] >> 8), ix = x0 - 2 + (dyx[i] & 255);
+      dok |= ((dyx[i] >> 8) < 12 && iy >= 0 && iy < H && ix >= 0 && ix < W) ? (1 << i) : 0;
+    }
+    return dok;
+  };
+  // halo pixels of chunk j of tile (n, y0, x0) -> ring slot Xn, by LDS-DMA
+  auto dma_chunk = [&](char* Xn, const int n, const int y0, const int x0, const int dok, const int j) {
+    const int c = 32 * j + 8 * dq;  // this lane's channel group on the concatenated axis
+    const char* base;
+    int sh, sw;
+    bool okc;
+    if (p.nseg == 1) {
+      base = p.seg[0].p + (n * p.seg[0].sn + (y0 - 2) * p.seg[0].sh + (x0 - 2) * p.seg[0].sw) + c * 2;
+      sh = p.seg[0].sh; sw = p.seg[0].sw; okc = dq < 4 && c < p.seg_c8[0];
+    } else {
+      int s = 0;
+      if (p.nseg > 1 && c >= p.seg_koff[1]) s = 1;
+      if (p.nseg > 2 && c >= p.seg_koff[2]) s = 2;
+      const char* sp = s == 0 ? p.seg[0].p : (s == 1 ? p.seg[1].p : p.seg[2].p);
+      const int sn = s == 0 ? p.seg[0].sn : (s == 1 ? p.seg[1].sn : p.seg[2].sn);
+      sh = s == 0 ? p.seg[0].sh : (s == 1 ? p.seg[1].sh : p.seg[2].sh);
+      sw = s == 0 ? p.seg[0].sw : (s == 1 ? p.seg[1].sw : p.seg[2].sw);
+      const int ko = s == 0 ? 0 : (s == 1 ? p.seg_koff[1] : p.seg_koff[2]);
+      const int c8 = s == 0 ? p.seg_c8[0] : (s == 1 ? p.seg_c8[1] : p.seg_c8[2]);
+      okc = dq < 4 && (c - ko) < c8 && c < p.ctot8;
+      base = sp + (n * sn + (y0 - 2) * sh + (x0 - 2) * sw) + (c - ko) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const bool ok = okc && ((dok >> i) & 1);
+      const char* src = ok ? base + ((dyx[i] >> 8) * sh + (dyx[i] & 255) * sw) : zero;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Xn + (wave + 4 * i) * (12 * B3_XS)), 16, 0, 0);
+    }
+  };
+  auto load_A = [&](h16x8 (&An)[9], const int j) {  // the 9 weight fragments (this wave's K half) of chunk j
+    const char* wa = p.wA + (size_t)(j * 18 + kh) * 1024 + lane * 16;  // K16-step kk = 2 tap + channel half
+#pragma unroll
+    for (int s = 0; s < 9; ++s) An[s] = *(const h16x8*)(wa + s * 2048);
+  };
+  h16x8 A0[9], A1[SM == 1 ? 1 : 9], wb[RD];
+  if constexpr (SM > 0) {
+    load_A(A0, 0);
+    if constexpr (SM == 2) load_A(A1, 1);
+    const char* wsrc = p.o[0].w + (size_t)(NPG == 2 ? (wave & 1) : 0) * p.nksB * 1024 + lane * 16;
+#pragma unroll
+    for (int i = 0; i < RD; ++i) wb[i] = *(const h16x8*)(wsrc + i * 1024);
+    B3_VMWAIT();  // landed, and laundered: the compiler must not carry "load pending" into the tile loop (it would drain the DMA
+#pragma unroll   //  bursts at every first use)
+    for (int s = 0; s < 9; ++s) b3_pin(A0[s]);
+    if constexpr (SM == 2) {
+#pragma unroll
+      for (int s = 0; s < 9; ++s) b3_pin(A1[s]);
+    }
+#pragma unroll
+    for (int i = 0; i < RD; ++i) b3_pin(wb[i]);
+  }
+
+  if (stamp) stamp[1] = __builtin_readcyclecounter();
+  int sbase = 0;            // ring slot of the current tile's chunk 0
+  bool prefetched = false;  // this tile's chunks were requested during the previous tile
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    int n, y0, x0;
+    tile_of(tile, n, y0, x0);
+    int issued = nch;
+    if (!prefetched) {
+      const int dok = dok_of(y0, x0);
+      issued = min(nch, NS);
+      for (int k = 0; k < issued; ++k) dma_chunk(smem + ((sbase + k) % NS) * B3_XBYTES, n, y0, x0, dok, k);
+    }
+    if constexpr (!persistA) load_A(A0, 0);
+    B3_STAMP(0);
+    // ------------------------------------------------------------------ phase A
+    f32x16 acc[3];
+    {  // bias as the initial value (the K-half-0 waves; zeros elsewhere): channels 16 kg + i of this lane
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int ch = 16 * kg + 4 * q4;
+        const bool ok = p.biasA != nullptr && kh == 0 && ch < bch;
+        const float4 bb = *(const float4*)(ok ? (const char*)(p.biasA + ch) : zero);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { acc[g][4 * q4] = bb.x; acc[g][4 * q4 + 1] = bb.y; acc[g][4 * q4 + 2] = bb.z; acc[g][4 * q4 + 3] = bb.w; }
+      }
+    }
+    // mask source of the bottleneck gradient (backward): requested now, consumed after phase A
+    uint4 tm[PRE ? 1 : 3][2];
+    int mo[3];  // 1: this lane's bottleneck pixel is an interior pixel of the tile inside the image (stored to `mid`)
+    bool min_img[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const int my = mpx[g] >> 8, mx = mpx[g] & 255;
+      const int iy = y0 - 1 + my, ix = x0 - 1 + mx;
+      min_img[g] = mpx[g] >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      mo[g] = (min_img[g] && my >= 1 && my <= B3_TH && mx >= 1 && mx <= B3_TW) ? 1 : 0;
+      if constexpr (!PRE) {
+#pragma unroll
+        for (int q8 = 0; q8 < 2; ++q8) {
+          const bool ok = min_img[g] && kh == 0 && (16 * kg + 8 * q8) < bch;
+          const char* src = ok ? p.mid_aux.p + (n * p.mid_aux.sn + iy * p.mid_aux.sh + ix * p.mid_aux.sw) + (16 * kg + 8 * q8) * 2 : zero;
+          tm[g][q8] = *(const uint4*)src;
+        }
+      }
+    }
+    // phase-B epilogue operands of the (single) pair this wave owns when NPG <= 2: requested at the start of the tile's last chunk
+    constexpr int NEPI = SM > 0 ? NPG : 1;
+    uint4 ea0[NEPI][2], er0[NEPI][2];
+    constexpr bool early_epi = SM > 0;  // (SM > 0: one output, the wave's pair is fixed -- checked by the host)
+    const int next_tile = tile + gridDim.x;
+    const bool burst_next = next_tile < p.ntiles && NS >= nch + 1;
+    // One chunk step.  Xc (the slot being read) and the ring (DMA destinations: always OTHER slots) are __restrict__ parameters
+    // of ONE body: that is what lets hipcc keep a DMA in flight under the fragment reads.
+    auto step = [&](const char* __restrict__ Xc, char* __restrict__ ring, const h16x8 (&Ac)[9], auto& An, const int j) {
+      if (j == nch - 1) {
+        if (early_epi) {
+          const B3Out& O = p.o[0];
+          const int pair = NPG == 2 ? (wave & 1) : 0, ch0 = pair * 32 + 16 * kg;
+#pragma unroll
+          for (int g = 0; g < NEPI; ++g) {
+            const int oy = y0 + 2 * (pg0 + g) + (px >> 4), ox = x0 + (px & 15);
+            const int oa = n * O.aux.sn + oy * O.aux.sh + ox * O.aux.sw + ch0 * 2;
+            const int orr = n * O.res.sn + oy * O.res.sh + ox * O.res.sw + ch0 * 2;
+#pragma unroll
+            for (int q8 = 0; q8 < 2; ++q8) {
+              const bool ok = oy < H && ox < W && ch0 + 8 * q8 < O.Co;
+              ea0[g][q8] = er0[g][q8] = make_uint4(0, 0, 0, 0);
+              if (O.aux.p != nullptr) ea0[g][q8] = *(const uint4*)(ok ? O.aux.p + oa + 16 * q8 : zero);
+              if (O.res.p != nullptr) er0[g][q8] = *(const uint4*)(ok ? O.res.p + orr + 16 * q8 : zero);
+            }
+          }
+        }
+        if (burst_next) {  // the whole next tile, into the slots behind this tile's
+          int n2, y2, x2;
+          tile_of(next_tile, n2, y2, x2);
+          const int dok2 = dok_of(y2, x2);
+          for (int k = 0; k < nch; ++k) dma_chunk(ring + ((sbase + nch + k) % NS) * B3_XBYTES, n2, y2, x2, dok2, k);
+        }
+      }
+      if constexpr (!persistA) { if (j + 1 < nch) load_A(An, j + 1); }
+      b3_chunk<PRE>(Xc, Ac, pbA, acc);
+    };
+    for (int j = 0; j < nch; j += 2) {
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int jj = j + par;
+        if (jj >= nch) break;
+        if (jj == issued) {  // ring exhausted (more chunks than slots): the next burst, once everyone has left the slots
+          B3_BARRIER();
+          const int dok = dok_of(y0, x0);
+          const int cnt = min(nch - jj, NS);
+          for (int k = 0; k < cnt; ++k) dma_chunk(smem + ((sbase + jj + k) % NS) * B3_XBYTES, n, y0, x0, dok, jj + k);
+          issued += cnt;
+        }
+        B3_VMWAIT();
+        if constexpr (!persistA) {
+#pragma unroll
+          for (int s = 0; s < 9; ++s) b3_pin(par == 0 ? A0[s] : A1[s]);
+        }
+        if constexpr (!PRE) {
+          if (jj == nch - 1) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g) { asm volatile("" : "+v"(tm[g][0].x), "+v"(tm[g][0].y), "+v"(tm[g][0].z), "+v"(tm[g][0].w));
+                                           asm volatile("" : "+v"(tm[g][1].x), "+v"(tm[g][1].y), "+v"(tm[g][1].z), "+v"(tm[g][1].w)); }
+          }
+        }
+        B3_BARRIER();
+        if (jj == 0) B3_STAMP(1);
+        const char* Xc = smem + ((sbase + jj) % NS) * B3_XBYTES;
+        if constexpr (SM == 1) step(Xc, smem, A0, A1, jj);
+        else { if (par == 0) step(Xc, smem, A0, A1, jj); else step(Xc, smem, A1, A0, jj); }
+      }
+    }
+    B3_STAMP(2);
+    // ---- phase-B weights of this wave's first pair (not persistent): requested now, they land under the reduction
+    if constexpr (!persistB) {
+      const int pair = NPG == 4 ? wave : (NPG == 2 ? (wave & 1) : 0);
+      if (pair < p.o[0].npb) {
+        const char* wsrc = p.o[0].w + (size_t)pair * p.nksB * 1024 + lane * 16;
+#pragma unroll
+        for (int i = 0; i < RD; ++i) wb[i] = *(const h16x8*)(wsrc + i * 1024);
+      }
+    }
+    // ---- the K-half-1 waves hand their partial sums over (12 KiB each) through ring slots this tile is done with: the slot of
+    // its last chunk and the one before it (everyone is past the last chunk; the slots BEHIND belong to the next tile's burst).
+    // A one-chunk tile has a single slot: the second wave's half sits in a region of its own behind the bottleneck tile.
+    B3_BARRIER();
+    char* const scr = smem + ((sbase + nch - 1) % NS) * B3_XBYTES;
+    char* const scr2 = nch >= 2 ? smem + ((sbase + nch - 2) % NS) * B3_XBYTES : smem + p.scratch_off;
+    if (kh == 1) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+          *(float4*)((gp == 0 ? scr : scr2) + (g * 4 + q4) * 1024 + lane * 16) = make_float4(acc[g][4 * q4], acc[g][4 * q4 + 1], acc[g][4 * q4 + 2], acc[g][4 * q4 + 3]);
+    }
+    B3_BARRIER();
+    B3_STAMP(3);
+    if (kh == 0) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        float v[16];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 o = *(const float4*)((gp == 0 ? scr : scr2) + (g * 4 + q4) * 1024 + lane * 16);
+          v[4 * q4] = acc[g][4 * q4] + o.x; v[4 * q4 + 1] = acc[g][4 * q4 + 1] + o.y; v[4 * q4 + 2] = acc[g][4 * q4 + 2] + o.z; v[4 * q4 + 3] = acc[g][4 * q4 + 3] + o.w;
+        }
+        const int my = mpx[g] >> 8, mx = mpx[g] & 255;
+        const int iy = y0 - 1 + my, ix = x0 - 1 + mx;
+        char* gdst = (char*)p.mid.p + (n * p.mid.sn + iy * p.mid.sh + ix * p.mid.sw);
+        char* ldst = MID + (my * B3_MW + mx) * MS;
+#pragma unroll
+        for (int q8 = 0; q8 < 2; ++q8) {
+          const int ch = 16 * kg + 8 * q8;
+          if (mpx[g] < 0 || ch >= bch) continue;
+          float u[8];
+          if (bwd) {  // g_t = acc * relu'(t); zero outside the image because t was read as zero there
+            const uint32_t w[4] = {tm[PRE ? 0 : g][q8].x, tm[PRE ? 0 : g][q8].y, tm[PRE ? 0 : g][q8].z, tm[PRE ? 0 : g][q8].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              u[2 * e] = h_lo(w[e]) > 0.f ? v[8 * q8 + 2 * e] : 0.f;
+              u[2 * e + 1] = h_hi(w[e]) > 0.f ? v[8 * q8 + 2 * e + 1] : 0.f;
+            }
+            const uint4 o = b3_pack8(u);
+            if (mo[g]) *(uint4*)(gdst + ch * 2) = o;
+            *(uint4*)(ldst + ch * 2) = o;
+          } else {  // t = acc (+ bias, already in); LDS gets relu(t), zero outside the image (conv2 pads ITS input with zeros)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = v[8 * q8 + e];
+            const uint4 o = b3_pack8(u);
+            if (mo[g]) *(uint4*)(gdst + ch * 2) = o;
+            union { uint4 q; h16x8 h; } r;
+            r.q = o;
+            r.h = b3_relu8(r.h);
+            *(uint4*)(ldst + ch * 2) = min_img[g] ? r.q : make_uint4(0, 0, 0, 0);
+          }
+        }
+      }
+    }
+    B3_BARRIER();
+    B3_STAMP(4);
+    // ------------------------------------------------------------------ phase B
+#pragma unroll 1
+    for (int oi = 0; oi < p.nout; ++oi) {
+      const B3Out& O = p.o[oi];
+      const int npb = O.npb, Co = O.Co, nks = p.nksB;
+#pragma unroll 1
+      for (int r = 0;; ++r) {
+        const int pair = NPG == 4 ? wave + 4 * r : (NPG == 2 ? (wave & 1) + 2 * r : r);
+        if (pair >= npb) break;
+        // weights of the pair stream through a register ring RD K16-steps deep (all of them where the pair's accumulators are
+        // few); the epilogue operands are requested BEHIND the last weight request (loads return in order: a weight fragment
+        // queued behind an HBM-cold residual would wait for it) and are in flight under the remaining MFMAs
+        const char* wsrc = O.w + (size_t)pair * nks * 1024 + lane * 16;
+        if (!persistB && (oi > 0 || r > 0)) {
+#pragma unroll
+          for (int i = 0; i < RD; ++i) wb[i] = *(const h16x8*)(wsrc + i * 1024);
+        }
+        const int ch0 = pair * 32 + 16 * kg;
+        uint4 ea[NPG][2], er[NPG][2];
+        int eoff_o[NPG];
+        bool ev[NPG];
+        const bool has_aux = O.aux.p != nullptr, has_res = O.res.p != nullptr;
+#pragma unroll
+        for (int g = 0; g < NPG; ++g) {
+          const int oy = y0 + 2 * (pg0 + g) + (px >> 4), ox = x0 + (px & 15);
+          ev[g] = oy < H && ox < W;
+          eoff_o[g] = n * O.out.sn + oy * O.out.sh + ox * O.out.sw + ch0 * 2;
+        }
+        auto epi_request = [&]() {
+#pragma unroll
+          for (int g = 0; g < NPG; ++g) {
+            const int oy = y0 + 2 * (pg0 + g) + (px >> 4), ox = x0 + (px & 15);
+            const int oa = n * O.aux.sn + oy * O.aux.sh + ox * O.aux.sw + ch0 * 2;
+            const int orr = n * O.res.sn + oy * O.res.sh + ox * O.res.sw + ch0 * 2;
+#pragma unroll
+            for (int q8 = 0; q8 < 2; ++q8) {
+              const bool ok = ev[g] && ch0 + 8 * q8 < Co;
+              ea[g][q8] = er[g][q8] = make_uint4(0, 0, 0, 0);
+              if (has_aux) ea[g][q8] = *(const uint4*)(ok ? O.aux.p + oa + 16 * q8 : zero);
+              if (has_res) er[g][q8] = *(const uint4*)(ok ? O.res.p + orr + 16 * q8 : zero);
+            }
+          }
+        };
+        if (early_epi) {
+#pragma unroll
+          for (int g = 0; g < NEPI; ++g) { ea[g][0] = ea0[g][0]; ea[g][1] = ea0[g][1]; er[g][0] = er0[g][0]; er[g][1] = er0[g][1]; }
+        } else if (RD == MAXKB) {
+          epi_request();
+        }
+        f32x16 ac[NPG];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const int ch = ch0 + 4 * q4;
+          const bool ok = O.bias != nullptr && ch < Co;
+          const float4 bb = *(const float4*)(ok ? (const char*)(O.bias + ch) : zero);
+#pragma unroll
+          for (int g = 0; g < NPG; ++g) { ac[g][4 * q4] = bb.x; ac[g][4 * q4 + 1] = bb.y; ac[g][4 * q4 + 2] = bb.z; ac[g][4 * q4 + 3] = bb.w; }
+        }
+        const char* mbase = MID + pbB + pg0 * (2 * B3_MW * MS);
+        // K16-step i: lane half kg reads the 8-channel group u = 2 i + kg of the flattened (tap, channel group) axis; fragment
+        // reads one step ahead of the MFMAs
+        auto kaddr = [&](const int i) {
+          const int uE = 2 * i, uO = 2 * i + 1;
+          const int tE = uE / NB < 9 ? uE / NB : 8, tO = uO / NB < 9 ? uO / NB : 8;
+          const int offE = ((tE / 3) * B3_MW + tE % 3) * MS + (uE % NB) * 16;
+          const int offO = ((tO / 3) * B3_MW + tO % 3) * MS + (uO % NB) * 16;
+          return mbase + offE + (kgmask & (offO - offE));
+        };
+        h16x8 bq[2][NPG];
+        {
+          const char* rp = kaddr(0);
+#pragma unroll
+          for (int g = 0; g < NPG; ++g) bq[0][g] = *(const h16x8*)(rp + g * (2 * B3_MW * MS));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MAXKB; ++i) {
+          if (i + 1 < MAXKB) {
+            const char* rp = kaddr(i + 1);
+#pragma unroll
+            for (int g = 0; g < NPG; ++g) bq[(i + 1) & 1][g] = *(const h16x8*)(rp + g * (2 * B3_MW * MS));
+          }
+#pragma unroll
+          for (int g = 0; g < NPG; ++g) ac[g] = b3_mfma(wb[i % RD], bq[i & 1][g], ac[g]);
+          if (i + RD < MAXKB) wb[i % RD] = *(const h16x8*)(wsrc + (i + RD) * 1024);
+          if (NPG != 4 && RD < MAXKB && i + RD == MAXKB - 1) epi_request();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (oi == 0 && r == 0) B3_STAMP(5);
+        if (NPG == 4 && RD < MAXKB) epi_request();  // (four groups x two operands = 64 registers: only once the ring and the fragments are dead)
+        // epilogue straight from the accumulators: 16 consecutive channels of one pixel per lane
+#pragma unroll
+        for (int g = 0; g < NPG; ++g) {
+#pragma unroll
+          for (int q8 = 0; q8 < 2; ++q8) {
+            if (!(ev[g] && ch0 + 8 * q8 < Co)) continue;
+            float u[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = ac[g][8 * q8 + e];
+            if (has_aux) {
+              const uint32_t w[4] = {ea[g][q8].x, ea[g][q8].y, ea[g][q8].z, ea[g][q8].w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                u[2 * e] = h_lo(w[e]) > 0.f ? u[2 * e] : 0.f;
+                u[2 * e + 1] = h_hi(w[e]) > 0.f ? u[2 * e + 1] : 0.f;
+              }
+            }
+            if (has_res) {
+              const uint32_t w[4] = {er[g][q8].x, er[g][q8].y, er[g][q8].z, er[g][q8].w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) { u[2 * e] += h_lo(w[e]); u[2 * e + 1] += h_hi(w[e]); }
+            }
+            *(uint4*)((char*)O.out.p + eoff_o[g] + 16 * q8) = b3_pack8(u);
+          }
+        }
+      }
+    }
+    // (the next tile's first barrier separates these reads of the bottleneck tile from its next writes)
+    B3_STAMP(6);
+    nstamp += 8;
+    if (burst_next) { sbase = (sbase + nch) % NS; prefetched = true; } else { prefetched = false; }
+  }
+}
+
+// ----------------------------------------------------------------------------- host side
+static bool b3_view(const cgen_view& v, int n, int h, int w, BV3& o) {
+  o.p = (const char*)v.p; o.sn = o.sh = o.sw = 0;
+  if (!v.p) return true;
+  const int64_t ext = ((int64_t)n * v.sn + (int64_t)(h + B3_TH + 4) * v.sh + (int64_t)(w + B3_TW + 4) * v.sw + v.c + 64) * 2;
+  if (ext >= ((int64_t)1 << 31) || v.sn < 0 || v.sh < 0 || v.sw < 0) return false;
+  if (((uintptr_t)v.p % 16) || (v.sn * 2) % 16 || (v.sh * 2) % 16 || (v.sw * 2) % 16) return false;
+  o.sn = (int)(v.sn * 2); o.sh = (int)(v.sh * 2); o.sw = (int)(v.sw * 2);
+  return true;
+}
+
+static int b3_fill(const cgen_block3_args* a, B3P& p) {
+  if (!a || a->dtype != CGEN_F16 || a->nseg < 1 || a->nseg > 3 || a->n <= 0 || a->h < 4 || a->w < 4) return 0;
+  if (a->nout < 1 || a->nout > 2 || !a->w_a || !a->mid.p) return 0;
+  memset(&p, 0, sizeof(p));
+  p.N = a->n; p.H = a->h; p.W = a->w; p.nseg = a->nseg; p.nout = a->nout;
+  int koff = 0;
+  for (int s = 0; s < a->nseg; ++s) {
+    if (!a->seg[s].p || a->seg[s].c <= 0 || !dma_clean(a->seg[s], 2)) return 0;
+    if (!b3_view(a->seg[s], a->n, a->h, a->w, p.seg[s])) return 0;
+    p.seg_koff[s] = koff;
+    p.seg_c8[s] = (a->seg[s].c + 7) & ~7;
+    koff += p.seg_c8[s];
+  }
+  for (int s = a->nseg; s < 4; ++s) p.seg_koff[s] = koff;
+  p.ctot8 = koff;
+  p.nch = (koff + 31) / 32;
+  p.b = a->mid.c;
+  if (p.b % 8 != 0 || p.b < 8 || p.b > 32) return 0;
+  p.nksB = (9 * p.b + 15) / 16;
+  if (((uintptr_t)a->w_a % 16) || (a->bias_a && (uintptr_t)a->bias_a % 16)) return 0;
+  p.wA = (const char*)a->w_a; p.biasA = a->bias_a;
+  if (!b3_view(a->mid, a->n, a->h, a->w, p.mid) || !b3_view(a->mid_aux, a->n, a->h, a->w, p.mid_aux)) return 0;
+  if (a->mid_aux.p && a->mid_aux.c != a->mid.c) return 0;
+  for (int o = 0; o < a->nout; ++o) {
+    const cgen_block3_out& s = a->o[o];
+    B3Out& d = p.o[o];
+    if (!s.out.p || !s.w || s.out.c % 8 != 0 || s.out.c < 8) return 0;
+    if (((uintptr_t)s.w % 16) || (s.bias && (uintptr_t)s.bias % 16)) return 0;
+    d.w = (const char*)s.w; d.bias = s.bias; d.Co = s.out.c; d.npb = (s.out.c + 31) / 32;
+    if (!b3_view(s.out, a->n, a->h, a->w, d.out) || !b3_view(s.aux, a->n, a->h, a->w, d.aux) || !b3_view(s.res1, a->n, a->h, a->w, d.res)) return 0;
+    if ((s.aux.p && s.aux.c != s.out.c) || (s.res1.p && s.res1.c != s.out.c)) return 0;
+  }
+  p.tiles_x = ceil_div(a->w, B3_TW); p.tiles_y = ceil_div(a->h, B3_TH);
+  p.ntiles = a->n * p.tiles_x * p.tiles_y;
+  p.d_tx = b3_mkdiv(p.tiles_x); p.d_ty = b3_mkdiv(p.tiles_y);
+  { const char* e = getenv("CGEN_BLK3_STAMPS"); p.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+  return 1;
+}
+
+struct B3Launch { int npg, grid, sm; size_t lds; };
+// Ring depth, persistence and LDS size.  Two workgroups per CU (78 KB each) unless the launch has at most one tile per CU, which
+// may take a whole CU's LDS; a ring one slot deeper than a tile needs lets the next tile's burst travel under this tile's work.
+static B3Launch b3_plan(B3P& p) {
+  B3Launch L;
+  int npb = 0;
+  for (int o = 0; o < p.nout; ++o) npb = p.o[o].npb > npb ? p.o[o].npb : npb;
+  L.npg = npb == 1 ? 1 : (npb == 2 ? 2 : 4);  // the wave split of phase B follows the WIDEST output
+  const int nb = p.b / 8, nbs = (nb & 1) ? nb : nb + 1;
+  const int mid_bytes = B3_NMP * nbs * 16;
+  const int extra = p.nch == 1 ? 12288 : 0;
+  static const int per_cu = [] { const char* e = getenv("CGEN_BLK3_PER_CU"); return e ? atoi(e) : 2; }();
+  const int slots_wg = 256 * per_cu;
+  L.grid = p.ntiles < slots_wg ? p.ntiles : slots_wg;
+  const int budget = (p.ntiles <= 256 ? 150 : (per_cu >= 3 ? 52 : 78)) * 1024 - mid_bytes - extra;
+  int want = p.nch + (p.ntiles > L.grid ? 1 : 0);
+  static const int max_ns = [] { const char* e = getenv("CGEN_BLK3_MAXNS"); return e ? atoi(e) : 8; }();
+  int ns = budget / B3_XBYTES;
+  if (ns > want) ns = want;
+  if (ns > max_ns) ns = max_ns;
+  if (ns < 2) ns = 2;
+  p.ns = ns;
+  p.scratch_off = extra ? ns * B3_XBYTES + mid_bytes : 0;
+  p.wb_persist = (p.nout == 1 && nb <= 2 && p.nch <= 2 && ((L.npg == 1 && npb == 1) || (L.npg == 2 && npb == 2))) ? 1 : 0;
+  static const int no_sm = [] { const char* e = getenv("CGEN_BLK3_NOSM"); return e ? atoi(e) : 0; }();
+  L.sm = (p.wb_persist && !no_sm) ? p.nch : 0;
+  L.lds = (size_t)ns * B3_XBYTES + mid_bytes + extra;
+  return L;
+}
+
+template <bool PRE, int NB, int NPG, int SM>
+static void b3_launch_inst(const B3P& p, const B3Launch& L, hipStream_t st) {
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)blk3_kernel<PRE, NB, NPG, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  hipLaunchKernelGGL((blk3_kernel<PRE, NB, NPG, SM>), dim3(L.grid), dim3(256), L.lds, st, p);
+}
+template <bool PRE, int NB>
+static void b3_launch_nb(const B3P& p, const B3Launch& L, hipStream_t st) {
+  if constexpr (NB <= 2) {  // streaming instances: a tile is one or two chunks, one output, the wave's pair is fixed
+    if (L.sm == 1 && L.npg == 1) return b3_launch_inst<PRE, NB, 1, 1>(p, L, st);
+    if (L.sm == 1 && L.npg == 2) return b3_launch_inst<PRE, NB, 2, 1>(p, L, st);
+    if (L.sm == 2 && L.npg == 1) return b3_launch_inst<PRE, NB, 1, 2>(p, L, st);
+    if (L.sm == 2 && L.npg == 2) return b3_launch_inst<PRE, NB, 2, 2>(p, L, st);
+  }
+  if (L.npg == 1) b3_launch_inst<PRE, NB, 1, 0>(p, L, st);
+  else if (L.npg == 2) b3_launch_inst<PRE, NB, 2, 0>(p, L, st);
+  else b3_launch_inst<PRE, NB, 4, 0>(p, L, st);
+}
+template <bool PRE>
+static void b3_launch_pre(const B3P& p, const B3Launch& L, hipStream_t st) {
+  switch (p.b / 8) {
+    case 1: b3_launch_nb<PRE, 1>(p, L, st); break;
+    case 2: b3_launch_nb<PRE, 2>(p, L, st); break;
+    case 3: b3_launch_nb<PRE, 3>(p, L, st); break;
+    default: b3_launch_nb<PRE, 4>(p, L, st); break;
+  }
+}
+
+}  // namespace cgen
+
+using namespace cgen;
+
+extern "C" int cgen_block3_supported(const cgen_block3_args* a) {
+  B3P p;
+  return b3_fill(a, p);
+}
+
+extern "C" int cgen_block3(const cgen_block3_args* a, cgen_stream_t stream) {
+  B3P p;
+  CGEN_REQUIRE(b3_fill(a, p), "cgen_block3: shape / layout not served by the fused Block kernel (ask cgen_block3_supported first)");
+  CGEN_REQUIRE((a->pre_act != 0) == (a->mid_aux.p == nullptr), "cgen_block3: pre_act = 1 is the forward pass (no mid_aux), pre_act = 0 the data gradient (mid_aux = the forward mid)");
+  const B3Launch L = b3_plan(p);
+  if (a->pre_act) b3_launch_pre<true>(p, L, (hipStream_t)stream);
+  else b3_launch_pre<false>(p, L, (hipStream_t)stream);
+  if (getenv("CGEN_CONV_TRACE")) fprintf(stderr, "blk3[%s] %dx%dx%d ctot8 %d b %d Co %d nseg %d nout %d | ring %d slots, lds %zu, grid %d, persist wb %d\n", a->mid_aux.p ? "bwd" : "fwd", a->n, a->h, a->w, p.ctot8, p.b, p.o[0].Co, a->nseg, a->nout, p.ns, L.lds, L.grid, p.wb_persist);
+  return check_launch("cgen_block3");
+}

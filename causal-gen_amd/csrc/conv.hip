@@ -2461,6 +2461,45 @@ __global__ __launch_bounds__(256) void wprep_kernel(const cgen_wprep_desc* descs
   int ctot8 = 0;
   if (d.mode == 0) { for (int s = 0; s < d.nseg; ++s) ctot8 += (d.seg_c[s] + 7) & ~7; }
   else ctot8 = (d.co + 7) & ~7;
+  if (d.mode >= 2) {  // fragment-ordered images of the fused Block kernel (csrc/block.hip; layout in include/cgen_hip.h)
+    for (int i = threadIdx.x; i < MT_CHUNK; i += 256) {
+      const int64_t o = base + i;
+      if (o >= d.numel) break;
+      const int frag = (int)(o >> 9), w = (int)(o & 511), ln = w >> 3, e = w & 7;
+      const int r32 = ln & 31, kg = ln >> 5;
+      const int row = 16 * ((r32 >> 2) & 1) + (r32 & 3) + 4 * (r32 >> 3);  // channel (inside its 32-block) that fragment row r32 carries
+      float v = 0.f;
+      if (d.mode <= 3) {  // phase A: frag = chunk * 18 + kk
+        const int j = frag / 18, kk = frag - j * 18, tap = kk >> 1;
+        const int kc = 32 * j + 16 * (kk & 1) + 8 * kg + e;  // position on the 8-granular concatenated input axis
+        if (d.mode == 2) {
+          if (row < d.co) {
+            int cc = kc, off = 0, ci = -1;
+            for (int s = 0; s < d.nseg; ++s) {
+              const int c8 = (d.seg_c[s] + 7) & ~7;
+              if (cc < c8) { if (cc < d.seg_c[s]) ci = off + cc; break; }
+              cc -= c8; off += d.seg_c[s];
+            }
+            if (ci >= 0) v = d.src[((int64_t)row * d.ci_total + ci) * 9 + tap];
+          }
+        } else if (row < d.ci_total && kc < d.co) {
+          v = d.src[((int64_t)kc * d.ci_total + row) * 9 + (8 - tap)];
+        }
+      } else {  // phase B: frag = pair * k_pad + K16-step
+        const int pair = frag / d.k_pad, ks16 = frag - pair * d.k_pad;
+        const int k = 16 * ks16 + 8 * kg + e;
+        const int bw = d.mode == 4 ? d.ci_total : d.co;  // bottleneck width (a multiple of 8)
+        const int tap = k / bw, c = k - tap * bw;
+        const int och = pair * 32 + row;
+        if (tap < 9) {
+          if (d.mode == 4) { if (och < d.co) v = d.src[((int64_t)och * d.ci_total + c) * 9 + tap]; }
+          else if (och < d.seg_c[0]) v = d.src[((int64_t)c * d.ci_total + d.seg_off + och) * 9 + (8 - tap)];
+        }
+      }
+      ((h16_t*)d.dst)[o] = f2h(v);
+    }
+    return;
+  }
   for (int i = threadIdx.x; i < MT_CHUNK; i += 256) {
     const int64_t o = base + i;
     if (o >= d.numel) break;

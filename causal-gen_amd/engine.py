@@ -178,6 +178,31 @@ class ConvSite:
         self.dg_numel = [(_ceil(c, 16) * self.krow_dg) if rg else 0 for c, rg in zip(seg_c, seg_rg)]
         self.img_fwd = None   # device address
         self.img_dg = [None] * len(seg_c)
+        # fused light Block (csrc/block.hip): `blk3` = ("a", partner) for the Block's first conv, ("b", partner) for its second;
+        # fragment-ordered weight images (include/cgen_hip.h, cgen_block3_args): device addresses, set by Engine.bind
+        self.blk3 = None
+        self.frag = {}        # "a_fwd" / "b_fwd" / "a_dg" / ("b_dg", k)
+        self.frag_numel = {}
+
+    def plan_frag_images(self):
+        """Element counts of the fragment-ordered images this site needs as part of a fused Block (512 elements = one KiB
+        fragment: 64 lanes x 8)."""
+        self.frag_numel = {}
+        if self.blk3 is None or self.ks != 3:
+            return
+        role, other = self.blk3
+        if role == "a":   # conv1: [b][Ci][3][3]
+            b = self.co
+            nks = (9 * b + 15) // 16
+            self.frag_numel["a_fwd"] = _ceil(sum(_ceil(c, 8) for c in self.seg_c), 32) // 32 * 18 * 512
+            for k, (c, rg) in enumerate(zip(self.seg_c, self.seg_rg)):
+                if rg:
+                    self.frag_numel[("b_dg", k)] = _ceil(c, 32) // 32 * nks * 512
+        else:             # conv2: [Co][b][3][3]
+            b = self.ci
+            nks = (9 * b + 15) // 16
+            self.frag_numel["b_fwd"] = _ceil(self.co, 32) // 32 * nks * 512
+            self.frag_numel["a_dg"] = _ceil(_ceil(self.co, 8), 32) // 32 * 18 * 512
 
 
 class Engine(StageMixin):
@@ -268,6 +293,10 @@ class Engine(StageMixin):
         self.lat_fuse = os.environ.get("CGEN_LAT_FUSE", "0") != "0"
         self._side_join_pending = False
         self._lat_fused, self._zp_pending = set(), None
+        # fused light Block, round 4 (csrc/block.hip, cgen_block3): 0 off, 1 forward only, 2 forward + data gradient; images at
+        # least CGEN_BLK3_MINRES wide
+        self.blk3_on = int(os.environ.get("CGEN_BLK3", "2")) if self.dt == F16 else 0
+        self.blk3_minres = int(os.environ.get("CGEN_BLK3_MINRES", "16"))
         self.blk_fuse = int(os.environ.get("CGEN_BLK_FUSE", "0"))
         self.blk_minres = int(os.environ.get("CGEN_BLK_MINRES", "24"))
         self.blk_th4_maxres = int(os.environ.get("CGEN_BLK_TH4_MAXRES", "0"))  # images up to this size use 4-row tiles (experiment: slower)
@@ -426,6 +455,12 @@ class Engine(StageMixin):
             for d in s.dg_numel:
                 offs.append(total)
                 total += _ceil(d * self.es, _ALIGN)
+            s.frag, s.frag_numel = {}, {}
+            if self.dt == F16 and self.blk3_on:
+                s.plan_frag_images()
+            for key, numel in s.frag_numel.items():
+                offs.append(total)
+                total += _ceil(numel * 2, _ALIGN)
         self._img_buf = torch.zeros(max(total, 1), dtype=torch.uint8, device=self.device)
         base = self._img_buf.data_ptr()
         it = iter(offs)
@@ -434,6 +469,8 @@ class Engine(StageMixin):
             for k in range(len(s.seg_c)):
                 o = next(it)
                 s.img_dg[k] = base + o if s.dg_numel[k] else None
+            for key in s.frag_numel:
+                s.frag[key] = base + next(it)
         self._build_prep_table()
         self._weights_version = None
         # set by whoever writes the flat parameter buffer through raw pointers (the fused AdamW / EMA kernel, which
@@ -489,6 +526,26 @@ class Engine(StageMixin):
                 d.co, d.ci_total, d.ks, d.mode, d.nseg, d.seg_off = s.co, s.ci, s.ks, 1, 1, s.seg_off[k]
                 d.seg_c[0] = c
                 d.dtype, d.rows_pad, d.k_pad, d.numel = self.dt, _ceil(c, 16), s.krow_dg, s.dg_numel[k]
+                descs.append(d)
+        for s in self.sites:  # fragment-ordered images of the fused Block kernel (cgen_weight_prep modes 2-5)
+            for key, numel in s.frag_numel.items():
+                w = s.conv.weight
+                d = _lib.WprepDesc()
+                d.src, d.dst = w.data_ptr(), s.frag[key]
+                d.co, d.ci_total, d.ks, d.nseg, d.seg_off = s.co, s.ci, 3, len(s.seg_c), 0
+                for k, c in enumerate(s.seg_c):
+                    d.seg_c[k] = c
+                d.dtype, d.rows_pad, d.numel = self.dt, 0, numel
+                if key == "a_fwd":
+                    d.mode, d.k_pad = 2, 0
+                elif key == "a_dg":
+                    d.mode, d.k_pad = 3, 0
+                elif key == "b_fwd":
+                    d.mode, d.k_pad = 4, (9 * s.ci + 15) // 16
+                else:
+                    k = key[1]
+                    d.mode, d.k_pad, d.nseg, d.seg_off = 5, (9 * s.co + 15) // 16, 1, s.seg_off[k]
+                    d.seg_c[0] = s.seg_c[k]
                 descs.append(d)
         for i, d in enumerate(descs):
             nch = (d.numel + self.CHUNK - 1) // self.CHUNK
@@ -588,6 +645,12 @@ class Engine(StageMixin):
         x0 = segs[0]
         a = None
         wants_rem = self.trunk_rem and (trunk or (res1 is not None and res1.rem))  # (the fused kernel knows no remainder planes)
+        if (self.blk3_on and act == ACT_RELU and not wants_rem and min(x0.h, x0.w) >= self.blk3_minres and "a_fwd" in site1.frag
+                and "b_fwd" in site2.frag and len(segs) <= 3 and site1.co % 8 == 0 and site1.co <= 32 and site2.co % 8 == 0
+                and not self.stage_covers(x0.h)):
+            out = self._block3_fwd(site1, site2, segs, res1)
+            if out is not None:
+                return out
         if (self.blk_fuse and self.dt == F16 and act == ACT_RELU and site1.ks == 3 and site2.ks == 3 and len(segs) <= 3
                 and min(x0.h, x0.w) >= self.blk_minres and not wants_rem):
             a = _lib.BlockArgs()
@@ -616,6 +679,88 @@ class Engine(StageMixin):
             # (the two tensors just allocated are simply not used: the arena is reset per step)
         t = self.conv(site1, segs, act)
         return self.conv(site2, [t], act, res1=res1, trunk=trunk)
+
+    def _block3_fwd(self, site1, site2, segs, res1):
+        """One launch of cgen_block3 for a light Block (forward); None when the kernel declines the layout."""
+        x0 = segs[0]
+        a = _lib.Block3Args()
+        a.dtype, a.n, a.h, a.w, a.nseg, a.nout, a.pre_act = self.dt, x0.n, x0.h, x0.w, len(segs), 1, 1
+        for k, sg in enumerate(segs):
+            a.seg[k] = sg.cv()
+        b1, b2 = site1.conv.bias, site2.conv.bias
+        a.w_a, a.bias_a = site1.frag["a_fwd"], (b1.data_ptr() if b1 is not None else None)
+        t = self.new(x0.n, x0.h, x0.w, site1.co)
+        out = self.new(x0.n, x0.h, x0.w, site2.co)
+        a.mid, a.mid_aux = t.cv(), NULL_VIEW
+        o = a.o[0]
+        o.w, o.bias = site2.frag["b_fwd"], (b2.data_ptr() if b2 is not None else None)
+        o.out, o.aux, o.res1 = out.cv(), NULL_VIEW, (res1.cv() if res1 is not None else NULL_VIEW)
+        if not self.lib.block3_supported(C.byref(a)):
+            return None  # (the two tensors just allocated are simply not used: the arena is reset per step)
+        if self._ablate and any(x0.h == r and ("r%d" % r) in self._ablate for r in (24, 48, 96, 192)):
+            pass
+        else:
+            self._timed_blk("conv_fwd", site1, site2, x0, lambda: self.lib.block3(C.byref(a), self.stream))
+        if self.recording:
+            if self._dbg_names is not None:
+                self._dbg_names[id(out.base)] = site2.name
+            if self.blk3_on >= 2:
+                self.tape.append((self._bw_block3, (site1, site2, segs, t, out, res1), self._in_side))
+            else:
+                self.tape.append((self._bw_conv, (site1, segs, ACT_RELU, t, None, None), self._in_side))
+                self.tape.append((self._bw_conv, (site2, [t], ACT_RELU, out, res1, None), self._in_side))
+        return out
+
+    def _bw_block3(self, site1, site2, segs, t, out, res1):
+        """Backward of a fused light Block: weight gradients as for the two convs (deferred, batched); the two data-gradient
+        convs as ONE launch of cgen_block3 (pre_act = 0) -- with two outputs when two segments need a gradient (the posterior
+        Block: h and the encoder activation) -- else the two conv launches."""
+        g = self.grad_read(out)
+        if g is None:
+            return
+        act = ACT_RELU
+        dsegs = [k for k, sg in enumerate(segs) if sg.rg and site1.seg_rg[k]]
+        ok = (1 <= len(dsegs) <= 2 and "a_dg" in site2.frag and all(("b_dg", k) in site1.frag for k in dsegs)
+              and all(segs[k].c % 8 == 0 for k in dsegs) and g.c % 8 == 0)
+        if ok:
+            probe = _lib.Block3Args()
+            probe.dtype, probe.n, probe.h, probe.w, probe.nseg, probe.nout, probe.pre_act = self.dt, g.n, g.h, g.w, 1, len(dsegs), 0
+            probe.seg[0] = g.cv()
+            probe.w_a, probe.bias_a = site2.frag["a_dg"], None
+            probe.mid, probe.mid_aux = t.cv(), t.cv()
+            for j, k in enumerate(dsegs):
+                sg = segs[k]
+                probe.o[j].w, probe.o[j].bias = site1.frag[("b_dg", k)], None
+                probe.o[j].out, probe.o[j].aux, probe.o[j].res1 = sg.cv(), sg.cv(), NULL_VIEW
+            ok = bool(self.lib.block3_supported(C.byref(probe)))
+        if not ok:
+            self._bw_conv(site2, [t], act, out, res1, None)
+            self._bw_conv(site1, segs, act, t, None, None)
+            return
+        if res1 is not None and res1.rg:
+            self._grad_residual(res1, g, out, [t])
+        if self._needs_wgrad(site2) and "wg" not in self._ablate:
+            self._wgrad(site2, [t], act, g)
+        gt, acc_t = self.grad_write(t)
+        assert not acc_t
+        a = _lib.Block3Args()
+        a.dtype, a.n, a.h, a.w, a.nseg, a.nout, a.pre_act = self.dt, g.n, g.h, g.w, 1, len(dsegs), 0
+        a.seg[0] = g.cv()
+        a.w_a, a.bias_a = site2.frag["a_dg"], None
+        a.mid, a.mid_aux = gt.cv(), t.cv()
+        for j, k in enumerate(dsegs):
+            sg = segs[k]
+            gv, prev, acc = self._dgrad_target(sg)
+            a.o[j].w, a.o[j].bias = site1.frag[("b_dg", k)], None
+            a.o[j].out, a.o[j].aux = gv.cv(), sg.cv()
+            a.o[j].res1 = prev.cv() if acc else NULL_VIEW
+        x0 = segs[0]
+        if self._ablate and any(x0.h == r and ("r%d" % r) in self._ablate for r in (24, 48, 96, 192)):
+            pass
+        else:
+            self._timed_blk("conv_dgrad", site1, site2, x0, lambda: self.lib.block3(C.byref(a), self.stream))
+        if self._needs_wgrad(site1) and "wg" not in self._ablate:
+            self._wgrad(site1, segs, act, gt)
 
     def _timed(self, kind, site, x0, fn, ci=None):
         """Launch `fn`; when profiling, bracket it with events on the launch stream and tally algorithmic FLOPs
@@ -1134,6 +1279,8 @@ class Engine(StageMixin):
         if self.wgrad_flush_frac:  # total weight-gradient work of this pass: the background-flush marks are fractions of it
             self._wg_total = sum(2.0 * a[0].ci * a[0].taps * a[0].co * a[1][0].n * a[1][0].h * a[1][0].w
                                  for fn, a, _ in self.tape if fn == self._bw_conv and self._needs_wgrad(a[0]))
+            self._wg_total += sum(2.0 * st.ci * st.taps * st.co * a[2][0].n * a[2][0].h * a[2][0].w
+                                  for fn, a, _ in self.tape if fn == self._bw_block3 for st in a[:2] if self._needs_wgrad(st))
         self.stage_flush()
         main_t = torch.cuda.current_stream(self.device)
         if self._side_join_pending:  # side-stream work of the forward pass nobody has joined yet (the stem's im2col)

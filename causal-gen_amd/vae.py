@@ -87,9 +87,13 @@ def _stem_site(name, conv, index, dtype=None):
 
 def _block_sites(sites, name, blk, seg_c, seg_rg):
     cs = blk.convs()
+    first = len(sites)
     sites.append(ConvSite(f"{name}.conv.1", cs[0], seg_c, seg_rg, len(sites)))
     for j, c in enumerate(cs[1:]):
         sites.append(ConvSite(f"{name}.conv.{3 + 2 * j}", c, [c.in_channels], [True], len(sites)))
+    if blk.light and len(cs) == 2 and cs[0].kernel_size[0] == 3 and cs[1].kernel_size[0] == 3:
+        # the two 3x3 convs of a light Block run as ONE launch (Engine.block2 -> cgen_block3): fragment-ordered weight images
+        sites[first].blk3, sites[first + 1].blk3 = ("a", sites[first + 1]), ("b", sites[first])
     if hasattr(blk, "width_proj"):
         sites.append(ConvSite(f"{name}.width_proj", blk.width_proj, seg_c, seg_rg, len(sites)))
 

@@ -97,6 +97,36 @@ typedef struct cgen_block_args {
 int cgen_block2_supported(const cgen_block_args* a);
 int cgen_block2(const cgen_block_args* a, cgen_stream_t stream);
 
+/* ------------------------------------------------------------------ fused "light" Block, round 4 (csrc/block.hip; binary16)
+ * Block.forward with version == "light" (vae.py:49-56, 60-71, 73-84) as ONE launch, the bottleneck tensor resident in LDS:
+ *   pre_act = 1 (forward):   mid = bias_a + conv3x3(relu(cat_C(seg)))          (pre-activation bottleneck, interior pixels written once)
+ *                            o[k].out = o[k].bias + conv3x3(relu(mid)) + o[k].res1
+ *   pre_act = 0 (data gradient: aten::convolution_backward x2 + threshold_backward x2, the input part; mid_aux = the forward `mid`):
+ *                            mid = conv3x3(seg[0] = grad_out; w_a = fragment image of conv2's dgrad) * relu'(mid_aux)
+ *                            o[k].out = conv3x3(mid; o[k].w = fragment image of conv1's dgrad w.r.t. segment k) * relu'(o[k].aux) + o[k].res1
+ * nout = 2 serves a Block with two differentiable input segments (the posterior Block: h and the encoder activation).
+ * Weight images are FRAGMENT-ORDERED (one contiguous KiB per wave load), built by cgen_weight_prep modes 2-5:
+ *   w_a   [ceil(C8 / 32) chunks][18 K16-steps: tap = kk >> 1, channels 16 (kk & 1) .. + 16][64 lanes][8]   (C8 = sum_s ceil8(seg[s].c))
+ *   o[].w [ceil(Co / 32) pairs][ceil(9 b / 16) K16-steps over k = tap * b + c][64 lanes][8]
+ *   lane l of a fragment holds row (l & 31) -> channel 16 ((r >> 2) & 1) + (r & 3) + 4 (r >> 3) of the 32-row block, k = 8 (l >> 5) .. + 8.
+ * Served: mid.c in {8, 16, 24, 32}, out.c a multiple of 8, up to 3 input segments (each DMA-clean: channels a multiple of 8 or
+ * zero padded, cgen_view.cpad), 16-byte aligned views below 2^31 bytes; cgen_block3_supported() answers without launching. */
+typedef struct cgen_block3_out {
+  const void* w;
+  const float* bias;
+  cgen_view out, aux, res1;
+} cgen_block3_out;
+typedef struct cgen_block3_args {
+  int32_t dtype, n, h, w, nseg, nout, pre_act, reserved;
+  cgen_view seg[CGEN_MAX_SEG];
+  const void* w_a;
+  const float* bias_a;
+  cgen_view mid, mid_aux;
+  cgen_block3_out o[2];
+} cgen_block3_args;
+int cgen_block3_supported(const cgen_block3_args* a);
+int cgen_block3(const cgen_block3_args* a, cgen_stream_t stream);
+
 /* Weight gradient (aten::convolution_backward, weight/bias part) as split-K partials:
  *   partial_w[split][Co][KS*KS][Ci_total] (f32), partial_b[split][Co] (f32, may be NULL)
  * with Ci_total = sum_s seg[s].c and nsplit = cgen_conv2d_wgrad_plan(args) (call it with the views filled in; it also
@@ -132,7 +162,13 @@ int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream);
 typedef struct cgen_wprep_desc { /* OIHW f32 parameter -> forward image or dgrad image */
   const float* src;
   void* dst;
-  int32_t co, ci_total, ks, mode; /* mode 0: fwd image, 1: dgrad image of segment [seg_off, seg_off+seg_c[0]) */
+  int32_t co, ci_total, ks, mode; /* mode 0: fwd image, 1: dgrad image of segment [seg_off, seg_off+seg_c[0]);
+                                   * fragment-ordered images of cgen_block3 (src is always the OIHW parameter [co][ci_total][3][3]):
+                                   * 2: w_a of the forward pass (conv1: rows = co, K = the segments' channels),
+                                   * 3: w_a of the data gradient (conv2: rows = ci_total, K = co, taps flipped),
+                                   * 4: o[].w of the forward pass (conv2: rows = co, K = tap * ci_total + c; k_pad = K16-steps per pair),
+                                   * 5: o[].w of the data gradient w.r.t. segment [seg_off, seg_off + seg_c[0]) (conv1: rows = the
+                                   *    segment's channels, K = tap * co + c, taps flipped; k_pad = K16-steps per pair) */
   int32_t nseg, seg_off;
   int32_t seg_c[CGEN_MAX_SEG];
   int32_t dtype, rows_pad, k_pad, reserved; /* k_pad = krow of the image */

@@ -1,0 +1,111 @@
+"""Fused light-Block kernel of round 4 (csrc/block.hip, cgen_block3: two 3x3 convs per launch, bottleneck in LDS, forward and
+data gradient) against (a) the two-launch HIP path it replaces -- same binary16 storage points, so the results agree to an f16 ulp
+here and there (the f32 summation order inside a conv differs; a bottleneck value within rounding of an f16 boundary may round
+the other way) -- and (b) a torch f32 reference of vae.py:60-71,73-84 on the same f16-quantised operands."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (N, H, W, input segments, differentiable?, bottleneck, out channels, residual?)  -- the light-Block shapes of ukbb192 and friends
+CASES = [
+    (2, 40, 40, [32], [1], 8, 32, True),          # 192^2 trunk widths, ragged tiles (40 = 2.5 tiles wide)
+    (2, 24, 48, [32], [1], 8, 64, False),         # prior / down-block widths at 192^2
+    (2, 96, 96, [64], [1], 16, 64, True),         # 96^2 trunk
+    (3, 24, 24, [64], [1], 16, 96, False),        # 96^2 prior (3 channel pairs)
+    (4, 48, 48, [96], [1], 24, 96, True),         # 48^2 trunk
+    (2, 48, 48, [96], [1], 24, 128, False),
+    (8, 24, 24, [128], [1], 32, 128, True),       # 24^2 trunk
+    (4, 24, 24, [128], [1], 32, 160, False),      # 24^2 prior: five pairs -> a wave takes two
+    (2, 32, 32, [32, 32], [1, 1], 16, 64, False),        # two differentiable segments (two gradient outputs)
+    (2, 32, 32, [24, 8, 32], [1, 0, 1], 16, 32, False),  # three segments, 8-channel middle one without a gradient
+    (2, 48, 48, [96, 4, 96], [1, 0, 1], 24, 32, False),  # the posterior Block at 48^2: cat[h, pa, acts], 4 parent channels (zero padded to 8)
+    (2, 20, 28, [64, 4], [1, 0], 16, 96, False),         # the prior Block: cat[h, pa]; ragged image
+]
+
+
+def _run(case, fuse, seed=0):
+    from causal_gen_amd.engine import ConvSite, Engine
+
+    N, H, W, segc, segrg, b, co, with_res = case
+    g = torch.Generator().manual_seed(1000 * seed + H * 7 + co)
+    ci = sum(segc)
+    c1 = torch.nn.Conv2d(ci, b, 3, padding=1)
+    c2 = torch.nn.Conv2d(b, co, 3, padding=1)
+    with torch.no_grad():
+        c1.weight.copy_(torch.randn(c1.weight.shape, generator=g) / math.sqrt(ci * 9 / 2))
+        c2.weight.copy_(torch.randn(c2.weight.shape, generator=g) / math.sqrt(b * 9 / 2))
+        c1.bias.copy_(torch.randn(b, generator=g) * 0.2)
+        c2.bias.copy_(torch.randn(co, generator=g) * 0.2)
+    xs = [torch.randn(N, c, H, W, generator=g).half().float() for c in segc]
+    res = torch.randn(N, co, H, W, generator=g).half().float() if with_res else None
+    gout = torch.randn(N, co, H, W, generator=g).half().float()
+    eng = Engine("cuda", "f16")
+    eng.blk3_on, eng.blk3_minres = fuse, 8
+    holder = torch.nn.ModuleList([c1, c2]).cuda()
+    s1 = ConvSite("c1", holder[0], segc, [bool(r) for r in segrg], 0)
+    s2 = ConvSite("c2", holder[1], [b], [True], 1)
+    s1.blk3, s2.blk3 = ("a", s2), ("b", s1)
+    eng.blk3_on = 2  # (images are planned at bind time)
+    eng.bind(holder, [s1, s2])
+    eng.blk3_on = fuse
+    eng.begin()
+    eng.prepare_weights(force=True)
+    eng.recording = True
+    nts = [eng.from_nchw(x.cuda(), rg=bool(r)) for x, r in zip(xs, segrg)]
+    rt = eng.from_nchw(res.cuda(), rg=False) if with_res else None
+    n0 = eng.launches
+    y = eng.block2(s1, s2, nts, 1, res1=rt)
+    fwd_launches = eng.launches - n0
+    y_t = eng.to_nchw(y).cpu()
+    gy = eng.seed_grad(y)
+    eng.lib.axpby(eng.dt, N, H, W, eng.from_nchw(gout.cuda()).cv(), gy.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
+    eng.recording = False
+    n1 = eng.launches
+    eng.backward()
+    bwd_launches = eng.launches - n1
+    torch.cuda.synchronize()
+    gxs = [eng.to_nchw(eng.grad_read(t)).cpu() if t.rg else None for t in nts]
+    pg = [eng.param_grad_view(p).cpu().clone() for p in (s1.conv.weight, s1.conv.bias, s2.conv.weight, s2.conv.bias)]
+    return dict(y=y_t, gx=gxs, pg=pg, fwd_launches=fwd_launches, bwd_launches=bwd_launches, xs=xs, res=res, gout=gout, convs=(c1, c2))
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[3]}x{c[5]}x{c[6]}@{c[1]}x{c[2]}" for c in CASES])
+def test_fused_block3_matches_two_launch_path_and_torch(case):
+    N, H, W, segc, segrg, b, co, with_res = case
+    two = _run(case, 0)
+    one = _run(case, 2)
+    assert two["fwd_launches"] == 2 and one["fwd_launches"] == 1, (two["fwd_launches"], one["fwd_launches"])
+    assert one["bwd_launches"] < two["bwd_launches"], (one["bwd_launches"], two["bwd_launches"])
+    # ---- (a) against the two-launch path: a handful of f16 flips at most
+    scale = float(two["y"].abs().max())
+    dy = (one["y"] - two["y"]).abs()
+    assert float(dy.max()) <= 0.02 * scale and float((dy > 0).float().mean()) < 0.05, (float(dy.max()), scale, float((dy > 0).float().mean()))
+    for a, c in zip(one["gx"], two["gx"]):
+        if c is None:
+            assert a is None
+            continue
+        s = float(c.abs().max())
+        assert float((a - c).abs().max()) <= 0.03 * s, (float((a - c).abs().max()), s)
+        assert float((a - c).norm()) <= 5e-3 * float(c.norm())
+    for a, c in zip(one["pg"], two["pg"]):
+        assert float((a - c).norm()) <= 1e-2 * float(c.norm()) + 1e-6, (float((a - c).norm()), float(c.norm()))
+    # ---- (b) against torch f32 on the same f16-quantised operands
+    c1, c2 = one["convs"]
+    w1, w2 = c1.weight.detach().cpu().half().float().requires_grad_(True), c2.weight.detach().cpu().half().float().requires_grad_(True)
+    xr = [x.clone().requires_grad_(True) for x in one["xs"]]
+    t = F.conv2d(F.relu(torch.cat(xr, 1)), w1, c1.bias.detach().cpu(), padding=1)
+    y = F.conv2d(F.relu(t), w2, c2.bias.detach().cpu(), padding=1)
+    if with_res:
+        y = y + one["res"]
+    y.backward(one["gout"])
+    tol = dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(one["y"], y.detach(), **tol)
+    for a, x in zip(one["gx"], xr):
+        if a is not None:
+            assert float((a - x.grad).norm()) <= 2e-2 * float(x.grad.norm())
+    assert float((one["pg"][0] - w1.grad).norm()) <= 3e-2 * float(w1.grad.norm())
+    assert float((one["pg"][2] - w2.grad).norm()) <= 3e-2 * float(w2.grad.norm())
