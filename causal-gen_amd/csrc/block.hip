@@ -21,6 +21,8 @@
 // groups of 16 pixels: two of every 16 lanes collide).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace cgen {
@@ -60,7 +62,8 @@ struct B3Out {
 struct B3P {
   int N, H, W, nseg, nch, b, nout, nksB;
   int tiles_x, tiles_y, ntiles, ctot8;
-  int ns, wb_persist, scratch_off, pad0;  // ring slots; phase-B weights persistent in registers; LDS offset of the second reduction scratch half (0: none)
+  int ns, wb_persist, scratch_off, bias_off;
+  int tm_off, tm_bytes, pad1, pad2;  // ring slots; phase-B weights persistent in registers; LDS offset of the second reduction scratch half (0: none)
   B3Div d_tx, d_ty;
   BV3 seg[3];
   int seg_koff[4];  // first channel of segment s on the 8-granular concatenated axis; [nseg] = ctot8
@@ -133,23 +136,22 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   constexpr int NBS = (NB & 1) ? NB : NB + 1;  // bottleneck pixel stride in 16-byte groups (odd)
   constexpr int MS = NBS * 16;
   constexpr int MAXKB = (9 * NB + 1) / 2;      // K16-steps of phase B (= ceil(9 b / 16))
-  constexpr int RD = SM > 0 ? MAXKB : (NPG == 4 ? (MAXKB < 4 ? MAXKB : 4) : (MAXKB < 8 ? MAXKB : 8));  // phase-B weight ring depth (SM > 0: all of them, persistent)
+  constexpr int RD = (SM > 0 || NPG == 1) ? MAXKB : (NPG == 2 ? (MAXKB < 9 ? MAXKB : 9) : (MAXKB < 4 ? MAXKB : 4));  // phase-B weight ring depth (SM > 0: all of them, persistent)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NS = p.ns;
-  char* const MID = smem + NS * B3_XBYTES;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 31, kg = lane >> 5;
   const int kh = wave & 1, gp = wave >> 1;
   const int H = p.H, W = p.W, nch = p.nch, bch = p.b;
   constexpr bool bwd = !PRE;  // (the host pairs them: forward = ReLU on the input + bias, backward = mask from mid_aux)
   const char* const zero = (const char*)g_b3zero;
-  unsigned long long* const stamp = (p.stamps != nullptr && blockIdx.x == 0 && tid == 0) ? p.stamps : nullptr;
+  unsigned long long* const stamp = (p.stamps != nullptr && blockIdx.x == 0 && lane == 0) ? p.stamps + wave * 256 : nullptr;  // (every wave's first lane: 256 slots each)
   int nstamp = 2;
 #define B3_STAMP(k) do { if (stamp && nstamp + (k) < 250) stamp[nstamp + (k)] = __builtin_readcyclecounter(); } while (0)
   if (stamp) stamp[0] = __builtin_readcyclecounter();
   // SM (streaming mode): 0 = nothing persistent (any number of chunks); 1 / 2 = a tile is one / two chunks: the phase-A weights stay
   // in registers for the whole launch, and so do the phase-B weights (the host picks SM > 0 only when the wave's pair never changes)
-  constexpr bool persistA = SM > 0, persistB = SM > 0;
+  constexpr bool persistA = SM > 0, persistB = SM == 1;  // (SM == 2: 72 registers of phase-A weights already; the phase-B ones are re-requested per tile, under the exchange)
 
   // ---- phase-A lane constants: this lane's bottleneck pixel of group g (3 groups of 32 per wave; 6 x 32 = 192 >= 180)
   int pbA[3], mpx[3];
@@ -165,13 +167,6 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   // per chunk.  Every lane is active (no exec branches): group 4 is the padding slot (zeros), lanes 60-63 re-write the first four
   // groups of the NEXT instruction's first pixel with the same bytes (the last instruction's overhang lands behind the slot)
   const int dpl = lane / 5, dq = lane - 5 * dpl;
-  int dyx[5];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int pi = 12 * (wave + 4 * i) + dpl;
-    const int hy = pi / B3_HW, hx = pi - hy * B3_HW;
-    dyx[i] = hy << 8 | hx;
-  }
   // ---- phase-B lane constants
   const int kgmask = kg ? -1 : 0;
   const int pbB = ((px >> 4) * B3_MW + (px & 15)) * MS;  // out pixel (2 pg + (px >> 4), px & 15) -> bottleneck tile offset (pg part is an immediate)
@@ -182,17 +177,8 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     n = b3_div(b1, p.d_ty);
     y0 = (b1 - n * p.tiles_y) * B3_TH; x0 = tx * B3_TW;
   };
-  auto dok_of = [&](const int y0, const int x0) {  // which of this lane's DMA pixels lie inside the image
-    int dok = 0;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int iy = y0 - 2 + (dyx[i] >> 8), ix = x0 - 2 + (dyx[i] & 255);
-      dok |= ((dyx[i] >> 8) < 12 && iy >= 0 && iy < H && ix >= 0 && ix < W) ? (1 << i) : 0;
-    }
-    return dok;
-  };
   // halo pixels of chunk j of tile (n, y0, x0) -> ring slot Xn, by LDS-DMA
-  auto dma_chunk = [&](char* Xn, const int n, const int y0, const int x0, const int dok, const int j) {
+  auto dma_chunk = [&](char* Xn, const int n, const int y0, const int x0, const int j) {
     const int c = 32 * j + 8 * dq;  // this lane's channel group on the concatenated axis
     const char* base;
     int sh, sw;
@@ -213,11 +199,33 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
       okc = dq < 4 && (c - ko) < c8 && c < p.ctot8;
       base = sp + (n * sn + (y0 - 2) * sh + (x0 - 2) * sw) + (c - ko) * 2;
     }
-#pragma unroll
+    // ONE static DMA instruction per call site (a rolled loop): hipcc's wait-count pass keeps alias information for a handful of
+    // LDS-DMA instructions only -- with the five of a chunk unrolled at every call site it falls back to draining all DMA in
+    // flight in front of EVERY LDS access, restrict views or not
+#pragma unroll 1
     for (int i = 0; i < 5; ++i) {
-      const bool ok = okc && ((dok >> i) & 1);
-      const char* src = ok ? base + ((dyx[i] >> 8) * sh + (dyx[i] & 255) * sw) : zero;
+      const int pi = 12 * (wave + 4 * i) + dpl;
+      const int hy = (pi * 3277) >> 16, hx = pi - hy * B3_HW;  // (pi / 20, exact for pi < 252)
+      const int iy = y0 - 2 + hy, ix = x0 - 2 + hx;
+      const bool ok = okc && hy < 12 && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const char* src = ok ? base + (hy * sh + hx * sw) : zero;
       __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Xn + (wave + 4 * i) * (12 * B3_XS)), 16, 0, 0);
+    }
+  };
+  // (SM > 0, backward) the bottleneck mask tile t[10 x 18 pixels][b] of tile (n, y0, x0) -> LDS, dense, by DMA: instruction i of
+  // the 3 NB covers 64 consecutive 16-byte groups; wave w issues i = w, w + 4
+  auto dma_mask = [&](char* dst, const int n, const int y0, const int x0) {
+#pragma unroll 1
+    for (int ii = 0; ii < (3 * NB + 3) / 4; ++ii) {
+      const int i = wave + 4 * ii;
+      if (i < 3 * NB) {
+        const int slot = 64 * i + lane, m = slot / NB, gq = slot - m * NB;
+        const int my = (min(m, B3_NMP - 1) * 57) >> 10, mx = min(m, B3_NMP - 1) - my * B3_MW;
+        const int iy = y0 - 1 + my, ix = x0 - 1 + mx;
+        const bool ok = m < B3_NMP && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const char* src = ok ? p.mid_aux.p + (n * p.mid_aux.sn + iy * p.mid_aux.sh + ix * p.mid_aux.sw) + gq * 16 : zero;
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(dst + i * 1024), 16, 0, 0);
+      }
     }
   };
   auto load_A = [&](h16x8 (&An)[9], const int j) {  // the 9 weight fragments (this wave's K half) of chunk j
@@ -225,13 +233,15 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
 #pragma unroll
     for (int s = 0; s < 9; ++s) An[s] = *(const h16x8*)(wa + s * 2048);
   };
-  h16x8 A0[9], A1[SM == 1 ? 1 : 9], wb[RD];
+  h16x8 A0[9], A1[SM == 1 ? 1 : 9], wbp[SM > 0 ? RD : 1];  // (wbp: the persistent phase-B weights of SM > 0)
   if constexpr (SM > 0) {
     load_A(A0, 0);
     if constexpr (SM == 2) load_A(A1, 1);
-    const char* wsrc = p.o[0].w + (size_t)(NPG == 2 ? (wave & 1) : 0) * p.nksB * 1024 + lane * 16;
+    if constexpr (persistB) {
+      const char* wsrc = p.o[0].w + (size_t)(NPG == 2 ? (wave & 1) : 0) * p.nksB * 1024 + lane * 16;
 #pragma unroll
-    for (int i = 0; i < RD; ++i) wb[i] = *(const h16x8*)(wsrc + i * 1024);
+      for (int i = 0; i < RD; ++i) wbp[i] = *(const h16x8*)(wsrc + i * 1024);
+    }
     B3_VMWAIT();  // landed, and laundered: the compiler must not carry "load pending" into the tile loop (it would drain the DMA
 #pragma unroll   //  bursts at every first use)
     for (int s = 0; s < 9; ++s) b3_pin(A0[s]);
@@ -239,38 +249,62 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
 #pragma unroll
       for (int s = 0; s < 9; ++s) b3_pin(A1[s]);
     }
+    if constexpr (persistB) {
 #pragma unroll
-    for (int i = 0; i < RD; ++i) b3_pin(wb[i]);
+      for (int i = 0; i < RD; ++i) b3_pin(wbp[i]);
+    }
   }
 
+  // biases -> LDS, once (a per-tile global load of them costs an L2 round trip on the critical path of every tile and, worse, its
+  // use makes hipcc drain every DMA in flight)
+  {
+    float* const BIA = (float*)(smem + p.bias_off);
+    if (tid < 32) BIA[tid] = (p.biasA != nullptr && tid < bch) ? p.biasA[tid] : 0.f;
+    const int nb0 = p.o[0].npb * 32;
+    for (int i = tid; i < nb0; i += 256) BIA[32 + i] = (p.o[0].bias != nullptr && i < p.o[0].Co) ? p.o[0].bias[i] : 0.f;
+    __syncthreads();
+  }
   if (stamp) stamp[1] = __builtin_readcyclecounter();
+  // The tile loop sees LDS through TWO __restrict__ views of the same memory: `lw` is only ever the destination of LDS-DMA, `lr` is
+  // what every ds_read / ds_write goes through.  hipcc drains all LDS-DMA in flight (s_waitcnt vmcnt(0)) in front of any LDS access
+  // it cannot prove disjoint from them -- with one view, the next tile's burst would be waited for at the first
+  // fragment read after its request.  The ordering that matters is explicit: B3_VMWAIT + B3_BARRIER before a slot is read.
+  auto run = [&](char* __restrict__ lr, char* __restrict__ lw) {
+  char* const MID = lr + NS * B3_XBYTES;
+  const float* const BIA = (const float*)(lr + p.bias_off);
+  char* const TMB = lr + p.tm_off;  // (SM > 0, backward) two buffers of the bottleneck mask tile, filled by DMA with the bursts
   int sbase = 0;            // ring slot of the current tile's chunk 0
   bool prefetched = false;  // this tile's chunks were requested during the previous tile
+  int tmsel = 0;            // which mask buffer holds the current tile's (SM > 0, backward)
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     int n, y0, x0;
     tile_of(tile, n, y0, x0);
     int issued = nch;
-    if (!prefetched) {
-      const int dok = dok_of(y0, x0);
+    if constexpr (SM == 0) {  // any number of chunks through TWO slots, one chunk ahead (each boundary waits for the chunk requested a step ago)
+      dma_chunk(lw, n, y0, x0, 0);
+    } else if (!prefetched) {
       issued = min(nch, NS);
-      for (int k = 0; k < issued; ++k) dma_chunk(smem + ((sbase + k) % NS) * B3_XBYTES, n, y0, x0, dok, k);
+      for (int k = 0; k < issued; ++k) dma_chunk(lw + ((sbase + k) % NS) * B3_XBYTES, n, y0, x0, k);
+      if constexpr (!PRE) dma_mask(lw + p.tm_off + tmsel * p.tm_bytes, n, y0, x0);
     }
     if constexpr (!persistA) load_A(A0, 0);
     B3_STAMP(0);
     // ------------------------------------------------------------------ phase A
     f32x16 acc[3];
-    {  // bias as the initial value (the K-half-0 waves; zeros elsewhere): channels 16 kg + i of this lane
+    {  // bias as the initial value (the K-half-0 waves; zeros elsewhere): channels 16 kg + i of this lane, from the LDS copy
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const int ch = 16 * kg + 4 * q4;
-        const bool ok = p.biasA != nullptr && kh == 0 && ch < bch;
-        const float4 bb = *(const float4*)(ok ? (const char*)(p.biasA + ch) : zero);
+        float4 bb = *(const float4*)(BIA + 16 * kg + 4 * q4);
+        if (kh != 0) bb = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int g = 0; g < 3; ++g) { acc[g][4 * q4] = bb.x; acc[g][4 * q4 + 1] = bb.y; acc[g][4 * q4 + 2] = bb.z; acc[g][4 * q4 + 3] = bb.w; }
       }
     }
     // mask source of the bottleneck gradient (backward): requested now, consumed after phase A
-    uint4 tm[PRE ? 1 : 3][2];
+    // (finalisation is shared by the two K halves: with a bottleneck of >= 16 channels wave kh finishes the 8-channel half q8 = kh of
+    //  all three groups; with 8 channels -- only q8 = 0 exists -- K-half 0 finishes groups 0 and 1, K-half 1 group 2)
+    constexpr bool QSPLIT = NB >= 2;
+    uint4 tm[(PRE || SM > 0) ? 1 : 3];
     int mo[3];  // 1: this lane's bottleneck pixel is an interior pixel of the tile inside the image (stored to `mid`)
     bool min_img[3];
 #pragma unroll
@@ -279,13 +313,12 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
       const int iy = y0 - 1 + my, ix = x0 - 1 + mx;
       min_img[g] = mpx[g] >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W;
       mo[g] = (min_img[g] && my >= 1 && my <= B3_TH && mx >= 1 && mx <= B3_TW) ? 1 : 0;
-      if constexpr (!PRE) {
-#pragma unroll
-        for (int q8 = 0; q8 < 2; ++q8) {
-          const bool ok = min_img[g] && kh == 0 && (16 * kg + 8 * q8) < bch;
-          const char* src = ok ? p.mid_aux.p + (n * p.mid_aux.sn + iy * p.mid_aux.sh + ix * p.mid_aux.sw) + (16 * kg + 8 * q8) * 2 : zero;
-          tm[g][q8] = *(const uint4*)src;
-        }
+      if constexpr (!PRE && SM == 0) {
+        const int ch = 16 * kg + (QSPLIT ? 8 * kh : 0);
+        const bool mine = QSPLIT || (kh == 0 ? g < 2 : g == 2);
+        const bool ok = min_img[g] && mine && ch < bch;
+        const char* src = ok ? p.mid_aux.p + (n * p.mid_aux.sn + iy * p.mid_aux.sh + ix * p.mid_aux.sw) + ch * 2 : zero;
+        tm[g] = *(const uint4*)src;
       }
     }
     // phase-B epilogue operands of the (single) pair this wave owns when NPG <= 2: requested at the start of the tile's last chunk
@@ -293,11 +326,16 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     uint4 ea0[NEPI][2], er0[NEPI][2];
     constexpr bool early_epi = SM > 0;  // (SM > 0: one output, the wave's pair is fixed -- checked by the host)
     const int next_tile = tile + gridDim.x;
-    const bool burst_next = next_tile < p.ntiles && NS >= nch + 1;
+    const bool burst_next = SM > 0 && next_tile < p.ntiles && NS >= nch + 1;
     // One chunk step.  Xc (the slot being read) and the ring (DMA destinations: always OTHER slots) are __restrict__ parameters
     // of ONE body: that is what lets hipcc keep a DMA in flight under the fragment reads.
     auto step = [&](const char* __restrict__ Xc, char* __restrict__ ring, const h16x8 (&Ac)[9], auto& An, const int j) {
-      if (j == nch - 1) {
+      if constexpr (SM == 0) {
+        if (j + 1 < nch) {
+          dma_chunk(ring + ((j + 1) & 1) * B3_XBYTES, n, y0, x0, j + 1);
+          load_A(An, j + 1);
+        }
+      } else if (j == nch - 1) {
         if (early_epi) {
           const B3Out& O = p.o[0];
           const int pair = NPG == 2 ? (wave & 1) : 0, ch0 = pair * 32 + 16 * kg;
@@ -318,109 +356,117 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
         if (burst_next) {  // the whole next tile, into the slots behind this tile's
           int n2, y2, x2;
           tile_of(next_tile, n2, y2, x2);
-          const int dok2 = dok_of(y2, x2);
-          for (int k = 0; k < nch; ++k) dma_chunk(ring + ((sbase + nch + k) % NS) * B3_XBYTES, n2, y2, x2, dok2, k);
+          for (int k = 0; k < nch; ++k) dma_chunk(ring + ((sbase + nch + k) % NS) * B3_XBYTES, n2, y2, x2, k);
+          if constexpr (!PRE) dma_mask(ring + p.tm_off + (tmsel ^ 1) * p.tm_bytes, n2, y2, x2);
         }
       }
-      if constexpr (!persistA) { if (j + 1 < nch) load_A(An, j + 1); }
+      if (j == nch - 1) B3_STAMP(7);
       b3_chunk<PRE>(Xc, Ac, pbA, acc);
     };
-    for (int j = 0; j < nch; j += 2) {
-#pragma unroll
-      for (int par = 0; par < 2; ++par) {
-        const int jj = j + par;
-        if (jj >= nch) break;
-        if (jj == issued) {  // ring exhausted (more chunks than slots): the next burst, once everyone has left the slots
-          B3_BARRIER();
-          const int dok = dok_of(y0, x0);
-          const int cnt = min(nch - jj, NS);
-          for (int k = 0; k < cnt; ++k) dma_chunk(smem + ((sbase + jj + k) % NS) * B3_XBYTES, n, y0, x0, dok, jj + k);
-          issued += cnt;
-        }
-        B3_VMWAIT();
-        if constexpr (!persistA) {
-#pragma unroll
-          for (int s = 0; s < 9; ++s) b3_pin(par == 0 ? A0[s] : A1[s]);
-        }
-        if constexpr (!PRE) {
-          if (jj == nch - 1) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g) { asm volatile("" : "+v"(tm[g][0].x), "+v"(tm[g][0].y), "+v"(tm[g][0].z), "+v"(tm[g][0].w));
-                                           asm volatile("" : "+v"(tm[g][1].x), "+v"(tm[g][1].y), "+v"(tm[g][1].z), "+v"(tm[g][1].w)); }
-          }
-        }
+    // chunk boundary: everything requested so far has landed (own loads + own DMA pieces), fragments laundered, everyone through
+    auto boundary = [&](const int jj, auto& Acur) {
+      if (SM > 0 && jj == issued) {  // ring exhausted (more chunks than slots): the next burst, once everyone has left the slots
         B3_BARRIER();
-        if (jj == 0) B3_STAMP(1);
-        const char* Xc = smem + ((sbase + jj) % NS) * B3_XBYTES;
-        if constexpr (SM == 1) step(Xc, smem, A0, A1, jj);
-        else { if (par == 0) step(Xc, smem, A0, A1, jj); else step(Xc, smem, A1, A0, jj); }
+        const int cnt = min(nch - jj, NS);
+        for (int k = 0; k < cnt; ++k) dma_chunk(lw + ((sbase + jj + k) % NS) * B3_XBYTES, n, y0, x0, jj + k);
+        issued += cnt;
+      }
+      // a prefetched tile's chunks landed before the previous tile ended (the wait in front of its epilogue); the backward pass
+      // still waits for its mask loads at the last boundary
+      if (SM == 0 || !prefetched) B3_VMWAIT();
+      if constexpr (!persistA) {
+#pragma unroll
+        for (int s = 0; s < 9; ++s) b3_pin(Acur[s]);
+      }
+      if constexpr (!PRE && SM == 0) {
+        if (jj == nch - 1) {
+#pragma unroll
+          for (int g = 0; g < 3; ++g) asm volatile("" : "+v"(tm[g].x), "+v"(tm[g].y), "+v"(tm[g].z), "+v"(tm[g].w));
+        }
+      }
+      B3_BARRIER();
+      if (jj == 0) B3_STAMP(1);
+    };
+    for (int j = 0; j < nch; j += 2) {
+      boundary(j, A0);
+      step(lr + (SM == 0 ? 0 : (sbase + j) % NS) * B3_XBYTES, lw, A0, A1, j);
+      if constexpr (SM != 1) {
+        if (j + 1 < nch) {
+          boundary(j + 1, A1);
+          step(lr + (SM == 0 ? 1 : (sbase + j + 1) % NS) * B3_XBYTES, lw, A1, A0, j + 1);
+        }
       }
     }
     B3_STAMP(2);
-    // ---- phase-B weights of this wave's first pair (not persistent): requested now, they land under the reduction
-    if constexpr (!persistB) {
-      const int pair = NPG == 4 ? wave : (NPG == 2 ? (wave & 1) : 0);
-      if (pair < p.o[0].npb) {
-        const char* wsrc = p.o[0].w + (size_t)pair * p.nksB * 1024 + lane * 16;
+    if constexpr (SM == 2) {  // phase-B weights of this wave's pair: requested now, they land under the exchange
+      const char* wsrc = p.o[0].w + (size_t)(NPG == 2 ? (wave & 1) : 0) * p.nksB * 1024 + lane * 16;
 #pragma unroll
-        for (int i = 0; i < RD; ++i) wb[i] = *(const h16x8*)(wsrc + i * 1024);
-      }
+      for (int i = 0; i < RD; ++i) wbp[i] = *(const h16x8*)(wsrc + i * 1024);
     }
     // ---- the K-half-1 waves hand their partial sums over (12 KiB each) through ring slots this tile is done with: the slot of
     // its last chunk and the one before it (everyone is past the last chunk; the slots BEHIND belong to the next tile's burst).
     // A one-chunk tile has a single slot: the second wave's half sits in a region of its own behind the bottleneck tile.
     B3_BARRIER();
-    char* const scr = smem + ((sbase + nch - 1) % NS) * B3_XBYTES;
-    char* const scr2 = nch >= 2 ? smem + ((sbase + nch - 2) % NS) * B3_XBYTES : smem + p.scratch_off;
-    if (kh == 1) {
+    char* const scr = lr + (SM == 0 ? ((nch - 1) & 1) : (sbase + nch - 1) % NS) * B3_XBYTES;
+    // (streaming modes: the slot before the last chunk's already belongs to the next tile's burst -- a region of its own as well)
+    char* const scr2 = (SM == 0 && nch >= 2) ? lr + (nch & 1) * B3_XBYTES : lr + p.scratch_off;
+    char* const sx = gp == 0 ? scr : scr2;  // this wave pair's 12 KiB
+    auto send = [&](const int g, auto Q) {  // the 8 accumulator rows of half Q of group g -> the partner
+      constexpr int q8 = decltype(Q)::value;
 #pragma unroll
-      for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4)
-          *(float4*)((gp == 0 ? scr : scr2) + (g * 4 + q4) * 1024 + lane * 16) = make_float4(acc[g][4 * q4], acc[g][4 * q4 + 1], acc[g][4 * q4 + 2], acc[g][4 * q4 + 3]);
+      for (int h = 0; h < 2; ++h)
+        *(float4*)(sx + ((kh * 3 + g) * 2 + h) * 1024 + lane * 16) =
+            make_float4(acc[g][8 * q8 + 4 * h], acc[g][8 * q8 + 4 * h + 1], acc[g][8 * q8 + 4 * h + 2], acc[g][8 * q8 + 4 * h + 3]);
+    };
+    const std::integral_constant<int, 0> q0;
+    const std::integral_constant<int, 1> q1;
+    if constexpr (QSPLIT) {
+      if (kh == 0) { send(0, q1); send(1, q1); send(2, q1); } else { send(0, q0); send(1, q0); send(2, q0); }
+    } else {
+      if (kh == 0) send(2, q0); else { send(0, q0); send(1, q0); }
     }
     B3_BARRIER();
     B3_STAMP(3);
-    if (kh == 0) {
+    auto finish = [&](const int g, auto Q) {  // bottleneck pixel of group g, channels 16 kg + 8 Q .. + 8: sum, store, LDS
+      constexpr int q8 = decltype(Q)::value;
+      const int ch = 16 * kg + 8 * q8;
+      if (mpx[g] < 0 || ch >= bch) return;
+      float v[8];
 #pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        float v[16];
-#pragma unroll
-        for (int q4 = 0; q4 < 4; ++q4) {
-          const float4 o = *(const float4*)((gp == 0 ? scr : scr2) + (g * 4 + q4) * 1024 + lane * 16);
-          v[4 * q4] = acc[g][4 * q4] + o.x; v[4 * q4 + 1] = acc[g][4 * q4 + 1] + o.y; v[4 * q4 + 2] = acc[g][4 * q4 + 2] + o.z; v[4 * q4 + 3] = acc[g][4 * q4 + 3] + o.w;
-        }
-        const int my = mpx[g] >> 8, mx = mpx[g] & 255;
-        const int iy = y0 - 1 + my, ix = x0 - 1 + mx;
-        char* gdst = (char*)p.mid.p + (n * p.mid.sn + iy * p.mid.sh + ix * p.mid.sw);
-        char* ldst = MID + (my * B3_MW + mx) * MS;
-#pragma unroll
-        for (int q8 = 0; q8 < 2; ++q8) {
-          const int ch = 16 * kg + 8 * q8;
-          if (mpx[g] < 0 || ch >= bch) continue;
-          float u[8];
-          if (bwd) {  // g_t = acc * relu'(t); zero outside the image because t was read as zero there
-            const uint32_t w[4] = {tm[PRE ? 0 : g][q8].x, tm[PRE ? 0 : g][q8].y, tm[PRE ? 0 : g][q8].z, tm[PRE ? 0 : g][q8].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              u[2 * e] = h_lo(w[e]) > 0.f ? v[8 * q8 + 2 * e] : 0.f;
-              u[2 * e + 1] = h_hi(w[e]) > 0.f ? v[8 * q8 + 2 * e + 1] : 0.f;
-            }
-            const uint4 o = b3_pack8(u);
-            if (mo[g]) *(uint4*)(gdst + ch * 2) = o;
-            *(uint4*)(ldst + ch * 2) = o;
-          } else {  // t = acc (+ bias, already in); LDS gets relu(t), zero outside the image (conv2 pads ITS input with zeros)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) u[e] = v[8 * q8 + e];
-            const uint4 o = b3_pack8(u);
-            if (mo[g]) *(uint4*)(gdst + ch * 2) = o;
-            union { uint4 q; h16x8 h; } r;
-            r.q = o;
-            r.h = b3_relu8(r.h);
-            *(uint4*)(ldst + ch * 2) = min_img[g] ? r.q : make_uint4(0, 0, 0, 0);
-          }
-        }
+      for (int h = 0; h < 2; ++h) {
+        const float4 o = *(const float4*)(sx + (((1 - kh) * 3 + g) * 2 + h) * 1024 + lane * 16);
+        v[4 * h] = acc[g][8 * q8 + 4 * h] + o.x; v[4 * h + 1] = acc[g][8 * q8 + 4 * h + 1] + o.y;
+        v[4 * h + 2] = acc[g][8 * q8 + 4 * h + 2] + o.z; v[4 * h + 3] = acc[g][8 * q8 + 4 * h + 3] + o.w;
       }
+      const int my = mpx[g] >> 8, mx = mpx[g] & 255;
+      const int iy = y0 - 1 + my, ix = x0 - 1 + mx;
+      char* gdst = (char*)p.mid.p + (n * p.mid.sn + iy * p.mid.sh + ix * p.mid.sw) + ch * 2;
+      char* ldst = MID + (my * B3_MW + mx) * MS + ch * 2;
+      if (bwd) {  // g_t = acc * relu'(t); zero outside the image because t was read as zero there
+        uint4 tv = tm[(PRE || SM > 0) ? 0 : g];
+        if constexpr (SM > 0) tv = *(const uint4*)(TMB + tmsel * p.tm_bytes + (my * B3_MW + mx) * (NB * 16) + ch * 2);
+        const uint32_t w[4] = {tv.x, tv.y, tv.z, tv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] = h_lo(w[e]) > 0.f ? v[2 * e] : 0.f;
+          v[2 * e + 1] = h_hi(w[e]) > 0.f ? v[2 * e + 1] : 0.f;
+        }
+        const uint4 o = b3_pack8(v);
+        if (mo[g]) *(uint4*)gdst = o;
+        *(uint4*)ldst = o;
+      } else {  // t = acc (+ bias, already in); LDS gets relu(t), zero outside the image (conv2 pads ITS input with zeros)
+        const uint4 o = b3_pack8(v);
+        if (mo[g]) *(uint4*)gdst = o;
+        union { uint4 q; h16x8 h; } r;
+        r.q = o;
+        r.h = b3_relu8(r.h);
+        *(uint4*)ldst = min_img[g] ? r.q : make_uint4(0, 0, 0, 0);
+      }
+    };
+    if constexpr (QSPLIT) {
+      if (kh == 0) { finish(0, q0); finish(1, q0); finish(2, q0); } else { finish(0, q1); finish(1, q1); finish(2, q1); }
+    } else {
+      if (kh == 0) { finish(0, q0); finish(1, q0); } else finish(2, q0);
     }
     B3_BARRIER();
     B3_STAMP(4);
@@ -437,7 +483,9 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
         // few); the epilogue operands are requested BEHIND the last weight request (loads return in order: a weight fragment
         // queued behind an HBM-cold residual would wait for it) and are in flight under the remaining MFMAs
         const char* wsrc = O.w + (size_t)pair * nks * 1024 + lane * 16;
-        if (!persistB && (oi > 0 || r > 0)) {
+        h16x8 wbl[SM > 0 ? 1 : RD];
+        auto& wb = *[&]() { if constexpr (SM > 0) return &wbp; else return &wbl; }();
+        if constexpr (SM == 0) {
 #pragma unroll
           for (int i = 0; i < RD; ++i) wb[i] = *(const h16x8*)(wsrc + i * 1024);
         }
@@ -476,9 +524,8 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
         f32x16 ac[NPG];
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-          const int ch = ch0 + 4 * q4;
-          const bool ok = O.bias != nullptr && ch < Co;
-          const float4 bb = *(const float4*)(ok ? (const char*)(O.bias + ch) : zero);
+          float4 bb = *(const float4*)(BIA + 32 + ch0 + 4 * q4);  // (the LDS copy holds output 0's bias, zero padded)
+          if (oi != 0) bb = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
           for (int g = 0; g < NPG; ++g) { ac[g][4 * q4] = bb.x; ac[g][4 * q4 + 1] = bb.y; ac[g][4 * q4 + 2] = bb.z; ac[g][4 * q4 + 3] = bb.w; }
         }
@@ -513,6 +560,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
           __builtin_amdgcn_sched_barrier(0);
         }
         if (oi == 0 && r == 0) B3_STAMP(5);
+        if constexpr (SM > 0) B3_VMWAIT();  // the early epilogue operands AND the next tile's burst (requested a whole tile ago): the only wait of a streaming tile
         if (NPG == 4 && RD < MAXKB) epi_request();  // (four groups x two operands = 64 registers: only once the ring and the fragments are dead)
         // epilogue straight from the accumulators: 16 consecutive channels of one pixel per lane
 #pragma unroll
@@ -544,8 +592,15 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     // (the next tile's first barrier separates these reads of the bottleneck tile from its next writes)
     B3_STAMP(6);
     nstamp += 8;
-    if (burst_next) { sbase = (sbase + nch) % NS; prefetched = true; } else { prefetched = false; }
+    if (SM > 0 && burst_next) { sbase = (sbase + nch) % NS; prefetched = true; tmsel ^= 1; } else { prefetched = false; }
   }
+  };
+  // (the two views differ by opaque zero offsets: handed the same CONSTANT address twice, interprocedural constant propagation
+  //  substitutes it for both parameters and the restrict information is gone before the lambda is inlined)
+  int off_r = 0, off_w = 0;
+  asm volatile("" : "+s"(off_r));
+  asm volatile("" : "+s"(off_w));
+  run(smem + off_r, smem + off_w);
 }
 
 // ----------------------------------------------------------------------------- host side
@@ -590,6 +645,7 @@ static int b3_fill(const cgen_block3_args* a, B3P& p) {
     d.w = (const char*)s.w; d.bias = s.bias; d.Co = s.out.c; d.npb = (s.out.c + 31) / 32;
     if (!b3_view(s.out, a->n, a->h, a->w, d.out) || !b3_view(s.aux, a->n, a->h, a->w, d.aux) || !b3_view(s.res1, a->n, a->h, a->w, d.res)) return 0;
     if ((s.aux.p && s.aux.c != s.out.c) || (s.res1.p && s.res1.c != s.out.c)) return 0;
+    if (o > 0 && s.bias) return 0;  // (only the first output's bias has an LDS copy: the forward pass has one output)
   }
   p.tiles_x = ceil_div(a->w, B3_TW); p.tiles_y = ceil_div(a->h, B3_TH);
   p.ntiles = a->n * p.tiles_x * p.tiles_y;
@@ -608,11 +664,11 @@ static B3Launch b3_plan(B3P& p) {
   L.npg = npb == 1 ? 1 : (npb == 2 ? 2 : 4);  // the wave split of phase B follows the WIDEST output
   const int nb = p.b / 8, nbs = (nb & 1) ? nb : nb + 1;
   const int mid_bytes = B3_NMP * nbs * 16;
-  const int extra = p.nch == 1 ? 12288 : 0;
+  const int extra = p.nch <= 2 ? 12288 : 0;  // second half of the partial-sum exchange (one-chunk tiles, and every streaming launch)
   static const int per_cu = [] { const char* e = getenv("CGEN_BLK3_PER_CU"); return e ? atoi(e) : 2; }();
   const int slots_wg = 256 * per_cu;
   L.grid = p.ntiles < slots_wg ? p.ntiles : slots_wg;
-  const int budget = (p.ntiles <= 256 ? 150 : (per_cu >= 3 ? 52 : 78)) * 1024 - mid_bytes - extra;
+  const int budget = (p.ntiles <= 256 ? 150 : (per_cu >= 3 ? 52 : 78)) * 1024 - mid_bytes - extra - 2560 - (p.mid_aux.p ? 6 * nb * 1024 : 0);
   int want = p.nch + (p.ntiles > L.grid ? 1 : 0);
   static const int max_ns = [] { const char* e = getenv("CGEN_BLK3_MAXNS"); return e ? atoi(e) : 8; }();
   int ns = budget / B3_XBYTES;
@@ -624,7 +680,11 @@ static B3Launch b3_plan(B3P& p) {
   p.wb_persist = (p.nout == 1 && nb <= 2 && p.nch <= 2 && ((L.npg == 1 && npb == 1) || (L.npg == 2 && npb == 2))) ? 1 : 0;
   static const int no_sm = [] { const char* e = getenv("CGEN_BLK3_NOSM"); return e ? atoi(e) : 0; }();
   L.sm = (p.wb_persist && !no_sm) ? p.nch : 0;
-  L.lds = (size_t)ns * B3_XBYTES + mid_bytes + extra;
+  if (L.sm == 0) { ns = 2; p.ns = 2; p.scratch_off = extra ? ns * B3_XBYTES + mid_bytes : 0; }
+  p.bias_off = ns * B3_XBYTES + mid_bytes + extra;
+  p.tm_off = p.bias_off + 128 + p.o[0].npb * 128;
+  p.tm_bytes = (L.sm > 0 && p.mid_aux.p) ? (3 * nb * 1024) : 0;  // whole DMA instructions (>= 180 pixels x b x 2 bytes)
+  L.lds = (size_t)p.tm_off + 2 * (size_t)p.tm_bytes;
   return L;
 }
 

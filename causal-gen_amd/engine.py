@@ -297,6 +297,12 @@ class Engine(StageMixin):
         # least CGEN_BLK3_MINRES wide
         self.blk3_on = int(os.environ.get("CGEN_BLK3", "2")) if self.dt == F16 else 0
         self.blk3_minres = int(os.environ.get("CGEN_BLK3_MINRES", "16"))
+        # ... at which image sides: CGEN_BLK3_RES for Blocks with one or two input segments (trunk / prior / down Blocks),
+        # CGEN_BLK3_RES3 for three-segment Blocks (the posterior: cat[h, pa, acts]); empty = every side >= CGEN_BLK3_MINRES
+        # Defaults = where the fused launch beats the two it replaces INSIDE the step on MI355X (ukbb192 B = 32, interleaved A/B of
+        # bench.py): everything at 24x24, the posterior Block also at 48x48; "0" = every side
+        self.blk3_res = [int(v) for v in os.environ.get("CGEN_BLK3_RES", "24").split(",") if v and int(v) > 0]
+        self.blk3_res3 = [int(v) for v in os.environ.get("CGEN_BLK3_RES3", "24,48").split(",") if v and int(v) > 0]
         self.blk_fuse = int(os.environ.get("CGEN_BLK_FUSE", "0"))
         self.blk_minres = int(os.environ.get("CGEN_BLK_MINRES", "24"))
         self.blk_th4_maxres = int(os.environ.get("CGEN_BLK_TH4_MAXRES", "0"))  # images up to this size use 4-row tiles (experiment: slower)
@@ -645,7 +651,9 @@ class Engine(StageMixin):
         x0 = segs[0]
         a = None
         wants_rem = self.trunk_rem and (trunk or (res1 is not None and res1.rem))  # (the fused kernel knows no remainder planes)
+        res_ok = self.blk3_res3 if len(segs) >= 3 else self.blk3_res
         if (self.blk3_on and act == ACT_RELU and not wants_rem and min(x0.h, x0.w) >= self.blk3_minres and "a_fwd" in site1.frag
+                and (not res_ok or x0.h in res_ok)
                 and "b_fwd" in site2.frag and len(segs) <= 3 and site1.co % 8 == 0 and site1.co <= 32 and site2.co % 8 == 0
                 and not self.stage_covers(x0.h)):
             out = self._block3_fwd(site1, site2, segs, res1)

@@ -45,6 +45,7 @@ def _run(case, fuse, seed=0):
     gout = torch.randn(N, co, H, W, generator=g).half().float()
     eng = Engine("cuda", "f16")
     eng.blk3_on, eng.blk3_minres = fuse, 8
+    eng.blk3_res, eng.blk3_res3 = [], []
     holder = torch.nn.ModuleList([c1, c2]).cuda()
     s1 = ConvSite("c1", holder[0], segc, [bool(r) for r in segrg], 0)
     s2 = ConvSite("c2", holder[1], [b], [True], 1)

@@ -19,6 +19,7 @@ for (N, R, segc, b, co) in SHAPES:
         c1, c2 = torch.nn.Conv2d(ci, b, 3, padding=1), torch.nn.Conv2d(b, co, 3, padding=1)
         eng = Engine("cuda", "f16")
         eng.blk3_on, eng.blk3_minres = 2, 8
+        eng.blk3_res, eng.blk3_res3 = [], []
         eng.wgrad_flush_frac = []
         holder = torch.nn.ModuleList([c1, c2]).cuda()
         rgs = [c >= 8 for c in segc]  # (the narrow segment stands for the parents: no gradient)

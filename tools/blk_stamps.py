@@ -14,6 +14,7 @@ for key in [int(a) for a in sys.argv[1:]] or [192, 96, 48, 24]:
     c1, c2 = torch.nn.Conv2d(ci, b, 3, padding=1), torch.nn.Conv2d(b, co, 3, padding=1)
     eng = Engine("cuda", "f16")
     eng.blk3_on, eng.blk3_minres = 2, 8
+    eng.blk3_res, eng.blk3_res3 = [], []
     eng.wgrad_flush_frac = []
     holder = torch.nn.ModuleList([c1, c2]).cuda()
     rgs = [c >= 8 for c in segc]
@@ -25,7 +26,7 @@ for key in [int(a) for a in sys.argv[1:]] or [192, 96, 48, 24]:
     xs = [torch.randn(N, c, R, R).cuda() for c in segc]
     res = torch.randn(N, co, R, R).cuda() if co == ci else None
     gout = torch.randn(N, co, R, R).cuda()
-    st = torch.zeros(256, dtype=torch.int64, device="cuda")
+    st = torch.zeros(1024, dtype=torch.int64, device="cuda")
     for mode in ("fwd", "bwd"):
         for it in range(3):
             eng.begin(); eng.prepare_weights(force=(it == 0)); eng.recording = True
@@ -47,14 +48,20 @@ for key in [int(a) for a in sys.argv[1:]] or [192, 96, 48, 24]:
             eng.backward()
             torch.cuda.synchronize()
             os.environ.pop("CGEN_BLK3_STAMPS", None)
-        t = st.cpu().tolist()
-        print("res %d %s->%d->%d %s: prologue %d cycles" % (R, segc, b, co, mode, t[1] - t[0]))
-        k, prev_end = 2, t[1]
-        while k + 6 < 256 and t[k] > 0:
-            row = t[k:k + 7]
-            d = [row[0] - prev_end] + [row[i + 1] - row[i] for i in range(6)]
-            print("   tile %2d: " % ((k - 2) // 8) + " | ".join("%s %d" % (nm, v) for nm, v in zip(names, d)) + " | total %d" % (row[6] - prev_end))
-            prev_end = row[6]
-            k += 8
-            if (k - 2) // 8 >= 6:
-                break
+        tall = st.cpu().tolist()
+        for wv in (0, 3):
+          t = tall[wv * 256:(wv + 1) * 256]
+          print("res %d %s->%d->%d %s wave %d: prologue %d cycles, start offset vs wave 0 %d" % (R, segc, b, co, mode, wv, t[1] - t[0], t[0] - tall[0]))
+          k, prev_end = 2, t[1]
+          while k + 6 < 256 and t[k] > 0:
+              row = t[k:k + 8]
+              if (k - 2) // 8 not in (1, 2):
+                  prev_end = row[6]; k += 8
+                  continue
+              d = [row[0] - prev_end] + [row[i + 1] - row[i] for i in range(6)]
+              print("   tile %2d: " % ((k - 2) // 8) + " | ".join("%s %d" % (nm, v) for nm, v in zip(names, d)) + " | total %d | last chunk: requests %d, mfma %d" % (row[6] - prev_end, row[7] - row[1] if row[7] > row[1] else -1, row[2] - row[7]))
+              print("            absolute (vs wave 0 kernel start): " + " ".join("%d" % (v - tall[0]) for v in row[:7]))
+              prev_end = row[6]
+              k += 8
+              if (k - 2) // 8 >= 6:
+                  break
