@@ -110,6 +110,7 @@ i32, i64, u32, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_
 # tests/test_abi.py parses the header and checks every declared symbol is exported and bound here.
 PROTOTYPES = {
     "cgen_version": [],
+    "cgen_h16_format": [],
     "cgen_last_error": [],
     "cgen_conv2d": [C.POINTER(ConvArgs), vp],
     "cgen_block2_supported": [C.POINTER(BlockArgs)],
@@ -178,7 +179,8 @@ PROTOTYPES = {
     "cgen_stage_run": [vp, i32, i32, i32, vp],
 }
 _RESTYPES = {"cgen_last_error": C.c_char_p}
-_NOCHECK = {"cgen_version", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks",
+ABI_VERSION = 400  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
+_NOCHECK = {"cgen_version", "cgen_h16_format", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks",
             "cgen_block2_supported", "cgen_block3_supported", "cgen_latent_zproj_supported", "cgen_stem_conv_supported", "cgen_stage_accepts"}
 
 
@@ -200,6 +202,11 @@ class _Lib:
             fn.restype = _RESTYPES.get(name, C.c_int)
             setattr(self, "_raw_" + name, fn)
             setattr(self, name[len("cgen_"):], fn if name in _NOCHECK else self._checked(name, fn))
+        if self.cdll.cgen_version() != ABI_VERSION:
+            raise CgenError(f"{path}: ABI version {self.cdll.cgen_version()}, this binding needs {ABI_VERSION} -- a stale or foreign build "
+                            "(rebuild with causal-gen_amd/build.sh)")
+        # 16-bit storage format of THIS build: torch tensors handed over as CGEN_F16 must be in it
+        self.h16_is_bf16 = bool(self.cdll.cgen_h16_format())
 
     def _checked(self, name, fn):
         def call(*a):

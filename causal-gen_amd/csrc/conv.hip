@@ -2471,14 +2471,14 @@ __global__ __launch_bounds__(256) void wprep_kernel(const cgen_wprep_desc* descs
       float v = 0.f;
       if (d.mode <= 3) {  // phase A: frag = chunk * 18 + kk
         const int j = frag / 18, kk = frag - j * 18, tap = kk >> 1;
-        const int kc = 32 * j + 16 * (kk & 1) + 8 * kg + e;  // position on the 8-granular concatenated input axis
+        const int kc = 32 * j + 16 * (kk & 1) + 8 * kg + e;  // position on the concatenated input axis (segments in whole chunks)
         if (d.mode == 2) {
           if (row < d.co) {
             int cc = kc, off = 0, ci = -1;
-            for (int s = 0; s < d.nseg; ++s) {
-              const int c8 = (d.seg_c[s] + 7) & ~7;
-              if (cc < c8) { if (cc < d.seg_c[s]) ci = off + cc; break; }
-              cc -= c8; off += d.seg_c[s];
+            for (int s = 0; s < d.nseg; ++s) {  // (every segment padded to whole 32-channel chunks)
+              const int c32 = (d.seg_c[s] + 31) & ~31;
+              if (cc < c32) { if (cc < d.seg_c[s]) ci = off + cc; break; }
+              cc -= c32; off += d.seg_c[s];
             }
             if (ci >= 0) v = d.src[((int64_t)row * d.ci_total + ci) * 9 + tap];
           }

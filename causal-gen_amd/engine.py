@@ -194,7 +194,7 @@ class ConvSite:
         if role == "a":   # conv1: [b][Ci][3][3]
             b = self.co
             nks = (9 * b + 15) // 16
-            self.frag_numel["a_fwd"] = _ceil(sum(_ceil(c, 8) for c in self.seg_c), 32) // 32 * 18 * 512
+            self.frag_numel["a_fwd"] = sum(_ceil(c, 32) // 32 for c in self.seg_c) * 18 * 512  # (segments in whole 32-channel chunks)
             for k, (c, rg) in enumerate(zip(self.seg_c, self.seg_rg)):
                 if rg:
                     self.frag_numel[("b_dg", k)] = _ceil(c, 32) // 32 * nks * 512
@@ -216,15 +216,22 @@ class Engine(StageMixin):
         assert self.device.type == "cuda"
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
+        if dtype not in ("f32", "f16"):
+            raise ValueError("compute dtype %r: the engine computes in 'f32' (exact f32 MFMA) or 'f16' (binary16 storage, f32 accumulate; "
+                             "the bfloat16 storage of rounds 1-2 is gone -- use 'f16')" % (dtype,))
         self.dt = {"f32": F32, "f16": F16}[dtype]
         self.dtype_name = dtype
         self.es = 4 if self.dt == F32 else 2
-        self.tdtype = torch.float32 if self.dt == F32 else torch.float16
+        self.tdtype = torch.float32 if self.dt == F32 else (torch.bfloat16 if rawlib.h16_is_bf16 else torch.float16)  # (what the library was built for)
         # f16 engine: activation GRADIENTS are carried times a power-of-two loss scale so that they sit in binary16's normal
         # range (the seeds are ~1 / (B * dims) ~ 1e-6); the kernels that turn them into f32 parameter gradients (the split-K
         # reduce, the batch reduce of the decoder biases) multiply by 1 / scale.  Exact: scaling by 2^k commutes with rounding.
         # Set per backward pass by set_loss_scale(B * dims); 1 for the f32 engine.
         self.loss_scale = 1.0
+        # back-off of that rule in powers of two (<= 0): lowered by TrainStep when a step was dropped for a non-finite gradient
+        # (an activation gradient past binary16's 65504), raised again after a run of clean steps -- the reduce tables are keyed by
+        # the scale, captured graphs are rebuilt by whoever changes it
+        self.loss_scale_shift = 0
         # f16 engine: the residual trunk as (value, remainder) pairs -- see conv(trunk=True).  CGEN_TRUNK_REM: 0 never, 1 (default)
         # in inference passes (abduct / forward_latents / sample / a no-grad forward: the counterfactual loop, whose pixels gain
         # 2x accuracy from it), 2 also in recorded training passes.  Measured on ukbb192 B = 32: the planes double the epilogue
@@ -233,7 +240,11 @@ class Engine(StageMixin):
         self.trunk_mode = int(os.environ.get("CGEN_TRUNK_REM", "1"))
         # CGEN_ABLATE="f1,d3" (planning tool, results are WRONG): what would the step cost if a light Block were one launch as
         # long as its HBM-bound half -- the upper bound of Block fusion on the critical path
-        self._ablate = os.environ.get("CGEN_ABLATE", "")
+        self._ablate = frozenset(t for t in os.environ.get("CGEN_ABLATE", "").split(",") if t)  # exact tokens
+        if self._ablate:
+            import sys
+            print("causal-gen_amd: CGEN_ABLATE=%s -- TIMING-ONLY ablation, launches are skipped and every result is WRONG" % ",".join(sorted(self._ablate)),
+                  file=sys.stderr, flush=True)
         self.trunk_maxres = int(os.environ.get("CGEN_TRUNK_REM_MAXRES", "100000"))  # planes only on images up to this side
         self.arena = Arena(self.device)
         self.tape, self.recording = _Tape(), False
@@ -299,10 +310,10 @@ class Engine(StageMixin):
         self.blk3_minres = int(os.environ.get("CGEN_BLK3_MINRES", "16"))
         # ... at which image sides: CGEN_BLK3_RES for Blocks with one or two input segments (trunk / prior / down Blocks),
         # CGEN_BLK3_RES3 for three-segment Blocks (the posterior: cat[h, pa, acts]); empty = every side >= CGEN_BLK3_MINRES
-        # Defaults = where the fused launch beats the two it replaces INSIDE the step on MI355X (ukbb192 B = 32, interleaved A/B of
-        # bench.py): everything at 24x24, the posterior Block also at 48x48; "0" = every side
-        self.blk3_res = [int(v) for v in os.environ.get("CGEN_BLK3_RES", "24").split(",") if v and int(v) > 0]
-        self.blk3_res3 = [int(v) for v in os.environ.get("CGEN_BLK3_RES3", "24,48").split(",") if v and int(v) > 0]
+        # Defaults = where the fused launch beats the two it replaces INSIDE the step on MI355X (ukbb192 B = 32, A/B of bench.py in
+        # one session): 24x24 and 48x48, the posterior Block also at 96x96; "0" = every side
+        self.blk3_res = [int(v) for v in os.environ.get("CGEN_BLK3_RES", "24,48").split(",") if v and int(v) > 0]
+        self.blk3_res3 = [int(v) for v in os.environ.get("CGEN_BLK3_RES3", "24,48,96").split(",") if v and int(v) > 0]
         self.blk_fuse = int(os.environ.get("CGEN_BLK_FUSE", "0"))
         self.blk_minres = int(os.environ.get("CGEN_BLK_MINRES", "24"))
         self.blk_th4_maxres = int(os.environ.get("CGEN_BLK_TH4_MAXRES", "0"))  # images up to this size use 4-row tiles (experiment: slower)
@@ -327,6 +338,8 @@ class Engine(StageMixin):
         spike 200x above that) fails the step's NaN / grad_skip predicate like any other (trainer.py:69-77).
         ``CGEN_LOSS_SCALE_LOG2`` overrides k."""
         self.loss_scale = self.loss_scale_rule(n_terms, self.dt == F32)
+        if self.dt != F32 and self.loss_scale_shift:
+            self.loss_scale = max(1.0, self.loss_scale * 2.0 ** self.loss_scale_shift)
         return self.loss_scale
 
     @staticmethod

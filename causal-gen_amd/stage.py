@@ -204,8 +204,9 @@ class StageMixin:
             # has been planned by the eager warm-up step that precedes the capture (same addresses: the arena is deterministic)
             dev = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.device)
             host = None
-            if len(self._stage_tabs) > 256:
-                self._stage_tabs.clear()
+            # never evicted: a captured hipGraph (TrainStep.graphs, GraphedCounterfactual) has this table's ADDRESS baked into its
+            # cgen_stage_run node -- dropping the tensor would let the caching allocator hand the memory out again and a later
+            # replay would walk a foreign op table.  A table is a few KB; a model has a few hundred distinct lists.
             ent = self._stage_tabs[key] = (dev, host, lds.value)
         dev, _, lds = ent
         if os.environ.get("CGEN_STAGE_DEBUG"):

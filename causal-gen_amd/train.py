@@ -12,6 +12,7 @@ buckets between the backward and the norm; ranks share the seed-driven draws and
 (the flag is a function of the all-reduced gradient and of the all-reduced nll/kl).
 """
 import copy
+import math
 import ctypes as C
 
 import torch
@@ -148,6 +149,7 @@ class TrainStep:
         # gradient accumulation (trainer.py:64-67): elbo / accu_steps per iteration, summed in a second flat buffer; the
         # optimiser tail runs on iterations with (it - 1) % accu_steps == 0 and reads that buffer
         self.accu = max(1, int(getattr(args, "accu_steps", 1) or 1))
+        self.overflow_backoffs, self._clean_calls, self.ls_growth_interval = 0, 0, 20
         self.acc_g = torch.zeros(n, device=dev) if self.accu > 1 else None
 
     # -- pieces -----------------------------------------------------------------------------------------
@@ -499,6 +501,33 @@ class TrainStep:
             self.acc_g.copy_(extra["acc_g"])
 
     def stats(self):
-        """Host read of the device-side step state (one sync; call every N steps, not every step)."""
+        """Host read of the device-side step state (one sync; call every N steps, not every step).  On the f16 engine this
+        is also where the gradient loss scale is looked after: a step dropped for a NON-FINITE gradient norm means
+        an activation gradient left binary16's range -- the scale is halved (captured graphs and coefficient tables are
+        rebuilt at the next step) instead of every later step being dropped as well; after `ls_growth_interval` clean calls
+        it is doubled back towards the rule's value.  `overflow_backoffs` counts the halvings, `loss_scale_shift` is the
+        current log2 offset."""
         s = self.state.cpu().tolist()
-        return dict(grad_norm=s[1], clip_coef=s[2], skipped_last=bool(s[3]), n_skipped=int(s[4]), opt_steps=int(s[5]))
+        out = dict(grad_norm=s[1], clip_coef=s[2], skipped_last=bool(s[3]), n_skipped=int(s[4]), opt_steps=int(s[5]))
+        if self.eng.dtype_name != "f32":
+            overflow = bool(s[3]) and not math.isfinite(s[1])
+            if overflow:
+                self._rescale(-1)
+                self.overflow_backoffs += 1
+                self._clean_calls = 0
+            else:
+                self._clean_calls += 1
+                if self.eng.loss_scale_shift < 0 and self._clean_calls >= self.ls_growth_interval:
+                    self._rescale(+1)
+                    self._clean_calls = 0
+            out.update(loss_scale=self.eng.loss_scale, loss_scale_shift=self.eng.loss_scale_shift, overflow_backoffs=self.overflow_backoffs)
+        return out
+
+    def _rescale(self, d):
+        """Move the loss-scale back-off by `d` powers of two: everything that baked the old scale in is dropped (the captured
+        step graphs, the seed coefficients, the engine's reduce tables are keyed by the scale)."""
+        self.eng.loss_scale_shift = min(0, self.eng.loss_scale_shift + d)
+        torch.cuda.synchronize()
+        self.graphs.clear()
+        for ent in self.coefs.values():
+            ent[1] = None

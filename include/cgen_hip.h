@@ -9,7 +9,10 @@
  *   - Activations are NHWC *views*: channel stride 1, arbitrary (n,h,w) strides in ELEMENTS.  A channel slice
  *     or a [:res,:res] crop of a bigger tensor is therefore a view, and torch.cat along C is never materialised
  *     (multi-segment inputs).  dtype: CGEN_F32 (exact path: f32 MFMA 16x16x4, bit-level fmaf chains) or
- *     CGEN_F16 (bf16 storage + bf16 MFMA 16x16x32, f32 accumulate).  Parameters/gradients are always f32.
+ *     CGEN_F16 (IEEE binary16 storage + v_mfma_f32_16x16x32_f16 / 32x32x16_f16, f32 accumulate; activation GRADIENTS are carried
+ *     times a power-of-two loss scale chosen by the caller, and the two kernels that turn them into f32 parameter gradients --
+ *     cgen_wgrad_reduce via cgen_wred_desc.unscale, cgen_batch_reduce via its `unscale` argument -- multiply by its inverse).
+ *     Parameters/gradients are always f32.
  *   - Ownership: the caller owns every buffer including workspaces; the library never allocates, frees or
  *     synchronises, and keeps no mutable global state (deepcopy / fork / hipGraph-capture safe).
  *   - Every call only enqueues work on `stream` and returns 0, or a negative cgen_status (message via
@@ -46,7 +49,12 @@ typedef struct cgen_view {
 
 #define CGEN_MAX_SEG 4
 
+/* ABI version of this header.  cgen_version() of the loaded library must equal it (causal-gen_amd/_lib.py checks): struct layouts,
+ * enum values and signatures are only compatible within one version.  cgen_h16_format(): the 16-bit storage format the library was
+ * BUILT for -- 0 = IEEE binary16 (default), 1 = bfloat16 (-DCGEN_H16_BF16, an A/B build); CGEN_F16 tensors must be in that format. */
+#define CGEN_ABI_VERSION 400
 int cgen_version(void);
+int cgen_h16_format(void);
 const char* cgen_last_error(void);
 
 /* ------------------------------------------------------------------ convolution (K1/K2/K3/K4/K5/K8/K9)
@@ -106,7 +114,8 @@ int cgen_block2(const cgen_block_args* a, cgen_stream_t stream);
  *                            o[k].out = conv3x3(mid; o[k].w = fragment image of conv1's dgrad w.r.t. segment k) * relu'(o[k].aux) + o[k].res1
  * nout = 2 serves a Block with two differentiable input segments (the posterior Block: h and the encoder activation).
  * Weight images are FRAGMENT-ORDERED (one contiguous KiB per wave load), built by cgen_weight_prep modes 2-5:
- *   w_a   [ceil(C8 / 32) chunks][18 K16-steps: tap = kk >> 1, channels 16 (kk & 1) .. + 16][64 lanes][8]   (C8 = sum_s ceil8(seg[s].c))
+ *   w_a   [sum_s ceil(seg[s].c / 32) chunks][18 K16-steps: tap = kk >> 1, channels 16 (kk & 1) .. + 16][64 lanes][8]   (every segment
+ *         occupies whole 32-channel chunks of the K axis, zero padded)
  *   o[].w [ceil(Co / 32) pairs][ceil(9 b / 16) K16-steps over k = tap * b + c][64 lanes][8]
  *   lane l of a fragment holds row (l & 31) -> channel 16 ((r >> 2) & 1) + (r & 3) + 4 (r >> 3) of the 32-row block, k = 8 (l >> 5) .. + 8.
  * Served: mid.c in {8, 16, 24, 32}, out.c a multiple of 8, up to 3 input segments (each DMA-clean: channels a multiple of 8 or

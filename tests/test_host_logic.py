@@ -184,3 +184,17 @@ def test_f16_loss_scale_rule_is_an_exact_power_of_two_tied_to_the_seed_size():
         assert Engine.loss_scale_rule(123456) == 32.0
     finally:
         del os.environ["CGEN_LOSS_SCALE_LOG2"]
+
+
+def test_loss_scale_rule_and_backoff_shift():
+    """engine.loss_scale_rule: a power of two near B * dims / 2, >= 1, 1 for f32; the back-off shift that
+    TrainStep.stats() applies after a step dropped for a non-finite gradient halves it."""
+    from causal_gen_amd.engine import Engine
+
+    assert Engine.loss_scale_rule(32 * 192 * 192, is_f32=True) == 1.0
+    s = Engine.loss_scale_rule(32 * 192 * 192)
+    assert s == 2.0 ** 19 and Engine.loss_scale_rule(1) == 1.0
+    import math
+    for n in (7, 1000, 256 * 32 * 32, 3 * 224 * 224 * 32):
+        k = math.log2(Engine.loss_scale_rule(n))
+        assert k == int(k) and 0.2 * n <= 2.0 ** k <= 0.8 * n or n < 8
