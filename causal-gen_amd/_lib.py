@@ -26,13 +26,6 @@ class ConvArgs(C.Structure):
                 ("out_rem", C.c_int64), ("res1_rem", C.c_int64)]
 
 
-class BlockArgs(C.Structure):
-    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("mode", C.c_int32),
-                ("nseg", C.c_int32), ("pre_act", C.c_int32), ("tile_h", C.c_int32), ("seg", View * MAX_SEG),
-                ("w_a", C.c_void_p), ("bias_a", C.c_void_p), ("w_b", C.c_void_p), ("bias_b", C.c_void_p),
-                ("mid", View), ("mid_aux", View), ("out", View), ("aux", View), ("res1", View)]
-
-
 class Block3Out(C.Structure):
     _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("out", View), ("aux", View), ("res1", View)]
 
@@ -41,18 +34,6 @@ class Block3Args(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("nseg", C.c_int32),
                 ("nout", C.c_int32), ("pre_act", C.c_int32), ("reserved", C.c_int32), ("seg", View * MAX_SEG),
                 ("w_a", C.c_void_p), ("bias_a", C.c_void_p), ("mid", View), ("mid_aux", View), ("o", Block3Out * 2)]
-
-
-class LatentZprojArgs(C.Structure):
-    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("co", C.c_int32),
-                ("q_loc", View), ("q_ls", View), ("p_loc", View), ("p_ls", View), ("eps_in", View), ("z", View), ("eps_out", View),
-                ("rng", C.c_void_p), ("stream_id", C.c_uint32), ("logt", C.c_float), ("kl_part", C.c_void_p),
-                ("kl_stride", C.c_int32), ("reserved0", C.c_int32),
-                ("pa", View), ("hres", View), ("pfeat", View), ("out", View), ("w_fwd", C.c_void_p), ("bias", C.c_void_p),
-                ("gout", View), ("gz", View), ("g_q_loc", View), ("g_q_ls", View), ("g_p_loc", View), ("g_p_ls", View),
-                ("w_dgrad", C.c_void_p), ("kl_coef_dev", C.c_void_p), ("kl_chan_scale", C.c_void_p),
-                ("coef_stride", C.c_int32), ("acc_q", C.c_int32), ("acc_p", C.c_int32), ("ride_acc", C.c_int32),
-                ("ride_src", View), ("ride_dst", View)]
 
 
 class WgradArgs(C.Structure):
@@ -113,8 +94,6 @@ PROTOTYPES = {
     "cgen_h16_format": [],
     "cgen_last_error": [],
     "cgen_conv2d": [C.POINTER(ConvArgs), vp],
-    "cgen_block2_supported": [C.POINTER(BlockArgs)],
-    "cgen_block2": [C.POINTER(BlockArgs), vp],
     "cgen_block3_supported": [C.POINTER(Block3Args)],
     "cgen_block3": [C.POINTER(Block3Args), vp],
     "cgen_conv2d_wgrad_plan": [C.POINTER(WgradArgs), C.POINTER(i32)],
@@ -143,9 +122,6 @@ PROTOTYPES = {
                             View, i32, i32, vp],
     "cgen_reparam_kl_bwd_rider": [i32, i32, i32, i32, i32, View, View, View, View, View, f32, View, vp, i32, vp, View, View, View,
                                   View, i32, i32, View, View, i32, vp],
-    "cgen_latent_zproj_supported": [C.POINTER(LatentZprojArgs)],
-    "cgen_latent_zproj_fwd": [C.POINTER(LatentZprojArgs), vp],
-    "cgen_latent_zproj_bwd": [C.POINTER(LatentZprojArgs), vp],
     "cgen_kl_channel_sums": [i32, i32, i32, i32, i32, View, View, View, View, f32, vp, i32, vp],
     "cgen_elbo_finalize_fb": [i32, vp, i32, f32, vp, i32, f32, f32, f32, vp, vp, vp, vp],
     "cgen_im2col_strided": [i32, i32, i32, i32, i32, i32, i32, i32, i32, View, View, vp],
@@ -158,6 +134,7 @@ PROTOTYPES = {
     "cgen_like_chunks": [i32, i32],
     "cgen_dgauss_nll_fwd": [i32, i32, i32, i32, i32, View, View, vp, vp],
     "cgen_dgauss_nll_bwd": [i32, i32, i32, i32, i32, View, View, vp, i32, View, vp],
+    "cgen_dgauss_params": [i32, i32, i32, i32, i32, View, View, f32, vp, vp, vp],
     "cgen_dgauss_sample": [i32, i32, i32, i32, i32, View, f32, vp, u32, vp, vp, vp],
     "cgen_gauss_nll_fwd": [i32, i32, i32, i32, i32, View, View, View, vp, u32, vp, vp],
     "cgen_gauss_nll_bwd": [i32, i32, i32, i32, i32, View, View, View, vp, u32, vp, i32, View, vp],
@@ -181,7 +158,7 @@ PROTOTYPES = {
 _RESTYPES = {"cgen_last_error": C.c_char_p}
 ABI_VERSION = 400  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
 _NOCHECK = {"cgen_version", "cgen_h16_format", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks",
-            "cgen_block2_supported", "cgen_block3_supported", "cgen_latent_zproj_supported", "cgen_stem_conv_supported", "cgen_stage_accepts"}
+            "cgen_block3_supported", "cgen_stem_conv_supported", "cgen_stage_accepts"}
 
 
 class WgradBatchLaunch(C.Structure):

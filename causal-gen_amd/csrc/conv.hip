@@ -1757,18 +1757,10 @@ static void launch_wgrad2_ks(const Wg2P& p, const Wg2Geom& g, hipStream_t st) {
 //     its pixel (two MFMA results): the epilogue is a 16-byte load / store per lane straight from the accumulators --
 //     no LDS staging, no extra barrier; bias is the accumulators' initial value; bf16 rounding is v_cvt_pk_bf16_f32;
 //   * epilogue operands (aux, residual) are requested before the halo DMA wait and consumed after the MFMA loop.
-// Measured on MI355X (ukbb192, B=32): grouping neighbouring tiles on one XCD is 2 % SLOWER than the round-robin order
-// (1750 vs 1786 img/s) -- these launches are issue / latency bound, halo re-reads are served by the Infinity Cache either
-// way, and neighbours on one XCD queue on the same L2 channels at the same moment.  Off by default; kept as a knob.
-static bool xcd_remap_on() {
-  static const int on = [] { const char* e = getenv("CGEN_XCD_REMAP"); return e ? atoi(e) : 0; }();
-  return on != 0;
-}
-
 struct PxP {
   PixTile xt;
   int tiles_x, tiles_y, ntiles, nks;
-  int xcd_chunk, pad_x;  // > 0: gridDim.x / 8 -- workgroup b starts at tile (b % 8) * xcd_chunk + b / 8, so that the tiles an XCD works on (workgroups go round-robin over the 8 XCDs) are neighbours and share halo rows in that XCD's L2
+  int pad_x0, pad_x;
   int ldw, wpieces, rows_pad, co8;  // co8: output channels incl. zero padding to 8 (== Co unless the output view carries cpad)
   FastDiv d_gprw, d_ctot8, d_tx, d_ty;
   int ktab[PX_MAXKS * 4];  // [K-step][lane group fg]: ((tap row * rowbytes + channel * 2) << 3) | (tap column == 2) << 2 | tap column -- read with VECTOR loads from the kernarg segment
@@ -1883,7 +1875,7 @@ __global__ __launch_bounds__(256, (NP <= 2 && !REM) ? 3 : 2) void conv_px_kernel
   const char* x_rows = Xb + (size_t)(wave * 2) * q.xt.rowbytes;
 
   if (stamp) stamp[5] = __builtin_amdgcn_s_memrealtime();
-  for (int t = q.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * q.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x; t < q.ntiles; t += gridDim.x) {
+  for (int t = (int)blockIdx.x; t < q.ntiles; t += gridDim.x) {
     // ---- tile origin: scalar
     const int b1 = fdiv(t, q.d_tx), tx = t - b1 * q.tiles_x;
     const int n = fdiv(b1, q.d_ty), ty = b1 - n * q.tiles_y;
@@ -2119,7 +2111,6 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st) {
   int gx = 256 * per_cu / parts;
   if (gx < 1) gx = 1;
   if (gx > q.ntiles) gx = q.ntiles;
-  q.xcd_chunk = (xcd_remap_on() && gx % 8 == 0 && gx >= 64) ? gx / 8 : 0;
   q.pad_x = 0;
   dim3 grid(gx, parts);
   switch (np) {
@@ -2142,7 +2133,7 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st) {
 struct WsP {
   PixTile xt;
   int tiles_x, tiles_y, ntiles, nk;  // nk = K-steps that carry weights
-  int rows_pad, red_bytes, dbg, xcd_chunk;  // xcd_chunk: as in PxP
+  int rows_pad, red_bytes, dbg, pad0;
   FastDiv d_ctot8, d_tx, d_ty;
   unsigned long long* stamps;  // optional (CGEN_WS_STAMPS): per-phase cycle stamps of workgroup 0
 };
@@ -2246,7 +2237,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_kernel(ConvP p, WsP q) {
 #define WS_STAMP() do { if (stamp && nst < 60) q.stamps[nst++] = __builtin_readcyclecounter(); } while (0)
   WS_STAMP();
 
-  for (int t = q.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * q.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x; t < q.ntiles; t += gridDim.x) {
+  for (int t = (int)blockIdx.x; t < q.ntiles; t += gridDim.x) {
     const int b1 = fdiv(t, q.d_tx), tx = t - b1 * q.tiles_x;
     const int n = fdiv(b1, q.d_ty), ty = b1 - n * q.tiles_y;
     const int y0 = ty * TILE_H, x0 = tx * TILE_W;
@@ -2417,7 +2408,6 @@ static bool launch_conv_ws(const ConvP& p, hipStream_t st) {
   int grid_x = 256 * per_cu / grid_y;
   if (grid_x < 1) grid_x = 1;
   if (grid_x > q.ntiles) grid_x = q.ntiles;
-  q.xcd_chunk = (xcd_remap_on() && grid_x % 8 == 0 && grid_x >= 64) ? grid_x / 8 : 0;
 #define WS_CASE(NKW) case NKW: if (ntc == 1) launch_ws_inst<1, NKW>(p, q, grid_x, grid_y, lds, st); else launch_ws_inst<2, NKW>(p, q, grid_x, grid_y, lds, st); break;
   switch (bk) {
     WS_CASE(3) WS_CASE(4) WS_CASE(5) WS_CASE(6) WS_CASE(8) WS_CASE(10) WS_CASE(12) WS_CASE(16)
@@ -2592,62 +2582,9 @@ __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, 
   }
 }
 
-#include "block_fused.inc"
-
 }  // namespace cgen
 
 using namespace cgen;
-
-// ----------------------------------------------------------------------------- fused light Block (block_fused.inc)
-static bool blk_bv(const cgen_view& v, int n, int h, int w, BV& o) {  // 64-bit element strides -> 32-bit byte strides (checked)
-  o.p = (const char*)v.p; o.sn = o.sh = o.sw = 0; o.c = v.c;
-  if (!v.p) return true;
-  const int64_t ext = ((int64_t)n * v.sn + (int64_t)(h + BLK_TH + 4) * v.sh + (int64_t)(w + BLK_TW + 4) * v.sw + v.c) * 2;
-  if (ext >= ((int64_t)1 << 31) || v.sn < 0 || v.sh < 0 || v.sw < 0) return false;
-  o.sn = (int)(v.sn * 2); o.sh = (int)(v.sh * 2); o.sw = (int)(v.sw * 2);
-  return true;
-}
-
-static int blk_fill(const cgen_block_args* a, BlkP& p) {
-  if (!a || a->dtype != CGEN_F16 || a->nseg < 1 || a->nseg > 3 || a->n <= 0 || a->h <= 0 || a->w <= 0) return 0;
-  memset(&p, 0, sizeof(p));
-  p.N = a->n; p.H = a->h; p.W = a->w; p.mode = a->mode; p.nseg = a->nseg; p.pre_act = a->pre_act;
-  p.TH = a->tile_h ? a->tile_h : 8;
-  int koff = 0;
-  for (int s = 0; s < a->nseg; ++s) {
-    if (!a->seg[s].p || a->seg[s].c <= 0 || !dma_clean(a->seg[s], 2)) return 0;
-    if (!blk_bv(a->seg[s], a->n, a->h, a->w, p.seg[s])) return 0;
-    p.seg_koff[s] = koff;
-    koff += pad_to(a->seg[s].c, 8);
-  }
-  for (int s = a->nseg; s < 3; ++s) p.seg_koff[s] = 1 << 30;
-  p.CU = koff; p.CT = a->mid.c; p.CV = a->out.c;
-  if (!a->mid.p || !a->out.p || !a->w_a || !a->w_b) return 0;
-  if (a->mode != 0 && (!a->mid_aux.p || !a->aux.p)) return 0;
-  // every epilogue access is an 8-byte vector: 8-byte aligned views
-  auto v8 = [](const cgen_view& v) { return !v.p || (((uintptr_t)v.p % 8 == 0) && v.sn % 4 == 0 && v.sh % 4 == 0 && v.sw % 4 == 0); };
-  if (!v8(a->mid) || !v8(a->mid_aux) || !v8(a->out) || !v8(a->aux) || !v8(a->res1)) return 0;
-  if (((uintptr_t)a->w_a % 16) || ((uintptr_t)a->w_b % 16) || (a->bias_a && (uintptr_t)a->bias_a % 16) || (a->bias_b && (uintptr_t)a->bias_b % 16)) return 0;
-  p.wA = (const h16_t*)a->w_a; p.wB = (const h16_t*)a->w_b; p.biasA = a->bias_a; p.biasB = a->bias_b;
-  p.krowA = pad_to(9 * p.CU, 32) + 32; p.krowB = pad_to(9 * pad_to(p.CT, 8), 32) + 32;
-  p.rowsA = pad_to(p.CT, 16); p.rowsB = pad_to(p.CV, 16);
-  if (!blk_bv(a->mid, a->n, a->h, a->w, p.t) || !blk_bv(a->mid_aux, a->n, a->h, a->w, p.taux) || !blk_bv(a->out, a->n, a->h, a->w, p.out) ||
-      !blk_bv(a->aux, a->n, a->h, a->w, p.aux) || !blk_bv(a->res1, a->n, a->h, a->w, p.res1)) return 0;
-  return launch_blk(p, nullptr, true) ? 1 : 0;
-}
-
-extern "C" int cgen_block2_supported(const cgen_block_args* a) {
-  BlkP p;
-  return blk_fill(a, p);
-}
-
-extern "C" int cgen_block2(const cgen_block_args* a, cgen_stream_t stream) {
-  BlkP p;
-  CGEN_REQUIRE(blk_fill(a, p), "cgen_block2: shape / layout not served by the fused Block kernel (ask cgen_block2_supported first)");
-  CGEN_REQUIRE(launch_blk(p, (hipStream_t)stream), "cgen_block2: no kernel instance for K = %d", p.nksA);
-  if (getenv("CGEN_CONV_TRACE")) fprintf(stderr, "blk2[%s] %dx%dx%d CU %d CT %d CV %d nseg %d\n", a->mode ? "bwd" : "fwd", a->n, a->h, a->w, p.CU, p.CT, p.CV, a->nseg);
-  return check_launch("cgen_block2");
-}
 
 extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
   CGEN_REQUIRE(a, "cgen_conv2d: null args");

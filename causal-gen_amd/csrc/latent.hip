@@ -109,225 +109,6 @@ __global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(LatBwdP p) {
 typedef float lat_f32x4 __attribute__((ext_vector_type(4)));
 __device__ uint4 lat_zero16[2];  // zeros: source of absent operands (loads are never issued under a condition)
 
-struct LatZpFwdP {
-  LatP l;
-  View pa, hres, pfeat, out;  // pa: [n,h,w,ctx] (ctx8 <= 16); hres / pfeat: optional residuals; out: [n,h,w,co]
-  const h16_t* w;            // z_proj forward image: rows ceil16(co) x krow, column = concat8 index (z 0..15, parents 16..)
-  const float* bias;
-  int co, krow, rows, pa_groups;  // pa_groups: 8-channel groups of the parents (0, 1 or 2)
-};
-
-__global__ __launch_bounds__(512) void reparam_zproj_fwd_kernel(LatZpFwdP q) {  // 8 waves x 16 pixels = the 128 pixels of a KL chunk, one pass
-  __shared__ float sm[8];
-  const LatP& p = q.l;
-  const int b = blockIdx.y, chunk = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
-  const int npix = p.h * p.w, per = npix * 16;
-  uint64_t seed = 0, off = 0;
-  if (!p.eps_in.p) { seed = p.rng[0]; off = p.rng[1]; }
-  float kl_acc = 0.f;
-  const int co16 = (q.co + 15) >> 4;
-  {
-    const int pix = chunk * (LAT_CHUNK / 16) + wave * 16 + fr;
-    const bool valid = pix < npix;
-    const int y = valid ? pix / p.w : 0, x = valid ? pix - y * p.w : 0;
-    union { uint4 u; h16x8 v; } bfrag;
-    bfrag.u = make_uint4(0, 0, 0, 0);
-    if (fg < 2) {
-      const int ch = fg * 8;
-      if (valid) {
-        float ql[8], qs[8], pl[8], ps[8], eps[8], z[8];
-        unpack8(ld8(p.q_loc, off8(p.q_loc, b, y, x, ch)), ql);
-        unpack8(ld8(p.q_ls, off8(p.q_ls, b, y, x, ch)), qs);
-        unpack8(ld8(p.p_loc, off8(p.p_loc, b, y, x, ch)), pl);
-        unpack8(ld8(p.p_ls, off8(p.p_ls, b, y, x, ch)), ps);
-        if (p.eps_in.p) {
-          unpack8(ld8(p.eps_in, off8(p.eps_in, b, y, x, ch)), eps);
-        } else {
-          const uint64_t i0 = (uint64_t)b * per + (uint64_t)pix * 16 + ch;  // as reparam_kl_fwd_vec8_kernel: same draws
-          float n4[4];
-          Philox::normal4(seed, off, p.stream_id, i0 >> 2, n4);
-          eps[0] = n4[0]; eps[1] = n4[1]; eps[2] = n4[2]; eps[3] = n4[3];
-          Philox::normal4(seed, off, p.stream_id, (i0 >> 2) + 1, n4);
-          eps[4] = n4[0]; eps[5] = n4[1]; eps[6] = n4[2]; eps[7] = n4[3];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float qq = qs[k] + p.logt, pp = ps[k] + p.logt;
-          const float sq = expf(qq), sp = expf(pp), d = ql[k] - pl[k];
-          z[k] = ql[k] + sq * eps[k];
-          kl_acc += -0.5f + pp - qq + 0.5f * (sq * sq + d * d) / (sp * sp);
-        }
-        bfrag.u = pack8(z);
-        st8(p.z, off8(p.z, b, y, x, ch), bfrag.u);
-        if (p.eps_out.p) st8(p.eps_out, off8(p.eps_out, b, y, x, ch), pack8(eps));
-      }
-    } else if (fg - 2 < q.pa_groups) {
-      if (valid) bfrag.u = ld8(q.pa, off8(q.pa, b, y, x, (fg - 2) * 8));
-    }
-    // ---- h'[co] = W[co][0:32] . [z | pa] + bias + h + p_feat: one MFMA per 16 output channels.  All operands of up to
-    // eight channel tiles are requested first (one memory round trip per batch, not per tile), then MFMAs + stores.
-    const h16_t* wl = q.w + fg * 8;
-    const int o_out = off8(q.out, b, y, x, 0), o_h = off8(q.hres, b, y, x, 0), o_f = off8(q.pfeat, b, y, x, 0);
-#pragma unroll 1
-    for (int ct0 = 0; ct0 < co16; ct0 += 8) {
-      uint4 aw[8];
-      float4 bb[8];
-      uint2 rh[8], rf[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int ct = ct0 + j;
-        const int row = min(ct * 16 + fr, q.rows - 1);
-        const int c0 = ct * 16 + fg * 4;
-        const bool live = valid && c0 < q.co;
-        aw[j] = *(const uint4*)(wl + (int64_t)row * q.krow);
-        bb[j] = *(const float4*)((q.bias && c0 + 4 <= q.co) ? (const void*)(q.bias + c0) : (const void*)lat_zero16);
-        rh[j] = *(const uint2*)((live && q.hres.p) ? (const void*)((const h16_t*)q.hres.p + o_h + c0) : (const void*)lat_zero16);
-        rf[j] = *(const uint2*)((live && q.pfeat.p) ? (const void*)((const h16_t*)q.pfeat.p + o_f + c0) : (const void*)lat_zero16);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c0 = (ct0 + j) * 16 + fg * 4;
-        union { uint4 u; h16x8 v; } a;
-        a.u = aw[j];
-        lat_f32x4 acc = {bb[j].x, bb[j].y, bb[j].z, bb[j].w};
-        acc = mfma_h16(a.v, bfrag.v, acc, 0, 0, 0);
-        if (valid && c0 < q.co) {
-          const float v0 = acc[0] + h_lo(rh[j].x) + h_lo(rf[j].x);
-          const float v1 = acc[1] + h_hi(rh[j].x) + h_hi(rf[j].x);
-          const float v2 = acc[2] + h_lo(rh[j].y) + h_lo(rf[j].y);
-          const float v3 = acc[3] + h_hi(rh[j].y) + h_hi(rf[j].y);
-          uint2 o;
-          o.x = f2h_pk(v0, v1); o.y = f2h_pk(v2, v3);
-          *(uint2*)((h16_t*)q.out.p + o_out + c0) = o;
-        }
-      }
-    }
-  }
-  kl_acc = wave_sum(kl_acc);
-  if (lane == 0) sm[wave] = kl_acc;
-  __syncthreads();
-  if (threadIdx.x == 0) p.kl_part[(int64_t)b * p.kl_stride + chunk] = ((sm[0] + sm[1]) + (sm[2] + sm[3])) + ((sm[4] + sm[5]) + (sm[6] + sm[7]));
-}
-
-// Backward: g_z = W_z^T g_h' (K = co, the data gradient of z_proj's z segment) + the part already in grad(z) (z_feat_proj's),
-// then the reparameterisation / KL gradient on it.  A wave owns 16 pixels; the MFMA result leaves lane (pixel fr, K group fg)
-// with z channels fg * 4 .. fg * 4 + 3 of its pixel, and the element-wise part runs on those four.
-struct LatZpBwdP {
-  LatBwdP l;
-  View gh;            // grad of z_proj's output [n,h,w,co]
-  const h16_t* wdg;  // z_proj data-gradient image of the z segment: rows 16 (z channel) x krow_dg, column = co
-  int co, krow_dg, groups;  // groups: 16-pixel groups in total
-};
-
-__global__ __launch_bounds__(256) void reparam_zproj_bwd_kernel(LatZpBwdP q) {
-  const LatBwdP& p = q.l;
-  if ((int)blockIdx.x >= p.main_blocks) {  // rider blocks (as reparam_kl_bwd_vec8_kernel)
-    const int rg = p.ride_c >> 3, per = p.h * p.w * rg;
-    const int64_t tot = (int64_t)p.n * per;
-    const int nb = gridDim.x - p.main_blocks;
-    for (int64_t g = (int64_t)(blockIdx.x - p.main_blocks) * 256 + threadIdx.x; g < tot; g += (int64_t)nb * 256) {
-      const int b = (int)(g / per), g8 = (int)(g - (int64_t)b * per);
-      const int pix = g8 / rg, ch = (g8 - pix * rg) * 8;
-      const int y = pix / p.w, x = pix - y * p.w;
-      uint4 v = ld8(p.ride_src, off8(p.ride_src, b, y, x, ch));
-      const int o = off8(p.ride_dst, b, y, x, ch);
-      if (p.ride_acc) {
-        float a[8], t[8];
-        unpack8(v, a);
-        unpack8(ld8(p.ride_dst, o), t);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a[k] += t[k];
-        v = pack8(a);
-      }
-      st8(p.ride_dst, o, v);
-    }
-    return;
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
-  const int npix = p.h * p.w, gps = (npix + 15) >> 4;  // 16-pixel groups per sample (a group never straddles two samples)
-  const int nks = (q.co + 31) >> 5;
-  for (int g = blockIdx.x * 4 + wave; g < q.groups; g += p.main_blocks * 4) {
-    const int b = g / gps, pix = (g - b * gps) * 16 + fr;
-    const bool valid = pix < npix;
-    const int y = valid ? pix / p.w : 0, x = valid ? pix - y * p.w : 0;
-    lat_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int o_g = off8(q.gh, b, y, x, 0);
-    const h16_t* wl = q.wdg + (int64_t)fr * q.krow_dg + fg * 8;
-    const int ch = fg * 4;
-    // element-wise operands of this lane's four z channels: requested now, consumed after the MFMAs
-    auto ld4u = [&](const View& v, bool on) -> uint2 {
-      return *(const uint2*)((on && valid && v.p) ? (const void*)((const h16_t*)v.p + off8(v, b, y, x, ch)) : (const void*)lat_zero16);
-    };
-    const uint2 u_ql = ld4u(p.q_loc, true), u_qs = ld4u(p.q_ls, true), u_pl = ld4u(p.p_loc, true), u_ps = ld4u(p.p_ls, true), u_z = ld4u(p.z, true);
-    const uint2 u_gz = ld4u(p.gz, true);
-    const uint2 u_a1 = ld4u(p.g_q_loc, p.acc_q != 0), u_a2 = ld4u(p.g_q_ls, p.acc_q != 0), u_a3 = ld4u(p.g_p_loc, p.acc_p != 0), u_a4 = ld4u(p.g_p_ls, p.acc_p != 0);
-#pragma unroll 1
-    for (int ks0 = 0; ks0 < nks; ks0 += 8) {
-      uint4 aw[8], bw[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int ks = min(ks0 + j, nks - 1);
-        const int c = (ks0 + j) * 32 + fg * 8;
-        aw[j] = *(const uint4*)(wl + ks * 32);  // (the image is zero beyond co: its row length is padded by 32)
-        bw[j] = *(const uint4*)((valid && c < q.co) ? (const void*)((const h16_t*)q.gh.p + o_g + c) : (const void*)lat_zero16);
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        union { uint4 u; h16x8 v; } a, bq;
-        a.u = aw[j]; bq.u = bw[j];
-        acc = mfma_h16(a.v, bq.v, acc, 0, 0, 0);  // (steps past nks multiply by a zero fragment)
-      }
-    }
-    if (!valid) continue;
-    auto un4 = [](const uint2 t, float (&o)[4]) {
-      o[0] = h_lo(t.x); o[1] = h_hi(t.x);
-      o[2] = h_lo(t.y); o[3] = h_hi(t.y);
-    };
-    auto st4f = [&](const View& v, const float (&o)[4]) {
-      uint2 t;
-      t.x = f2h_pk(o[0], o[1]); t.y = f2h_pk(o[2], o[3]);
-      *(uint2*)((h16_t*)v.p + off8(v, b, y, x, ch)) = t;
-    };
-    float ql[4], qs[4], pl[4], ps[4], zv[4], gz[4] = {acc[0], acc[1], acc[2], acc[3]};
-    un4(u_ql, ql); un4(u_qs, qs); un4(u_pl, pl); un4(u_ps, ps); un4(u_z, zv);
-    {
-      float t[4];
-      un4(u_gz, t);  // (zeros when grad(z) has no other contribution)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) gz[k] += t[k];
-    }
-    const float k0 = p.coef[(int64_t)b * p.coef_stride];
-    float o1[4], o2[4], o3[4], o4[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float kk = k0 * (p.chan_scale ? p.chan_scale[ch + k] : 1.f);
-      const float qq = qs[k] + p.logt, pp = ps[k] + p.logt;
-      const float e2q = expf(2.f * qq), ie2p = expf(-2.f * pp), d = ql[k] - pl[k];
-      o1[k] = kk * d * ie2p + gz[k];
-      o2[k] = kk * (e2q * ie2p - 1.f) + gz[k] * (zv[k] - ql[k]);
-      o3[k] = -kk * d * ie2p;
-      o4[k] = kk * (1.f - (e2q + d * d) * ie2p);
-    }
-    {
-      float t[4];  // (zeros unless accumulating)
-      un4(u_a1, t);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o1[k] += t[k];
-      un4(u_a2, t);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o2[k] += t[k];
-      un4(u_a3, t);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o3[k] += t[k];
-      un4(u_a4, t);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) o4[k] += t[k];
-    }
-    st4f(p.g_q_loc, o1); st4f(p.g_q_ls, o2); st4f(p.g_p_loc, o3); st4f(p.g_p_ls, o4);
-  }
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void sample_gaussian_kernel(int n, int h, int w, int c, View loc, View ls, View eps_in,
                                                               const uint64_t* rng, uint32_t stream_id, float logt, View z) {
@@ -497,73 +278,6 @@ extern "C" int cgen_reparam_kl_bwd_rider(int32_t dtype, int32_t n, int32_t h, in
                              g_p_loc, g_p_ls, acc_q, acc_p, &ride_src, &ride_dst, ride_acc, stream, "cgen_reparam_kl_bwd_rider");
 }
 
-
-static inline bool lat_v8(const cgen_view& v) {  // 8-byte vector access on a bf16 view
-  return !v.p || (((uintptr_t)v.p % 8 == 0) && v.sn % 4 == 0 && v.sh % 4 == 0 && v.sw % 4 == 0);
-}
-
-extern "C" int cgen_latent_zproj_supported(const cgen_latent_zproj_args* a) {
-  if (!a || a->dtype != CGEN_F16 || a->c != 16 || a->n <= 0 || a->h <= 0 || a->w <= 0 || a->co <= 0 || a->co % 4) return 0;
-  const int pa8 = a->pa.p ? (a->pa.c + 7) / 8 * 8 : 0;
-  if (pa8 > 16 || (a->pa.p && !(a->pa.c % 8 == 0 || a->pa.cpad >= pa8))) return 0;
-  if (!lat_vec8_ok(a->n, 16, {a->q_loc, a->q_ls, a->p_loc, a->p_ls, a->eps_in, a->z, a->eps_out})) return 0;
-  if (a->pa.p && !lat_vec8_ok(a->n, 8, {a->pa})) return 0;
-  if (!lat_v8(a->hres) || !lat_v8(a->pfeat) || !lat_v8(a->out) || !lat_v8(a->gout)) return 0;
-  if (a->gout.p && !lat_vec8_ok(a->n, 8, {a->gout})) return 0;  // 16-byte fragment loads of grad(out)
-  if (!lat_v8(a->gz) || !lat_v8(a->g_q_loc) || !lat_v8(a->g_q_ls) || !lat_v8(a->g_p_loc) || !lat_v8(a->g_p_ls)) return 0;
-  for (const cgen_view* v : {&a->out, &a->hres, &a->pfeat, &a->gout})
-    if (v->p && ((int64_t)a->n * v->sn + (int64_t)a->h * v->sh) * 2 >= ((int64_t)1 << 31)) return 0;
-  return 1;
-}
-
-extern "C" int cgen_latent_zproj_fwd(const cgen_latent_zproj_args* a, cgen_stream_t stream) {
-  CGEN_REQUIRE(cgen_latent_zproj_supported(a), "cgen_latent_zproj_fwd: shape / layout not served (ask cgen_latent_zproj_supported first)");
-  CGEN_REQUIRE(a->q_loc.p && a->q_ls.p && a->p_loc.p && a->p_ls.p && a->z.p && a->kl_part && a->out.p && a->w_fwd, "cgen_latent_zproj_fwd: null view");
-  CGEN_REQUIRE(a->eps_in.p || a->rng, "cgen_latent_zproj_fwd: need eps or rng");
-  LatZpFwdP q;
-  memset(&q, 0, sizeof(q));
-  LatP& p = q.l;
-  p.n = a->n; p.h = a->h; p.w = a->w; p.c = 16;
-  p.q_loc = mk(a->q_loc); p.q_ls = mk(a->q_ls); p.p_loc = mk(a->p_loc); p.p_ls = mk(a->p_ls);
-  p.eps_in = mk(a->eps_in); p.z = mk(a->z); p.eps_out = mk(a->eps_out);
-  p.rng = a->rng; p.stream_id = a->stream_id; p.logt = a->logt; p.kl_part = a->kl_part; p.kl_stride = a->kl_stride;
-  q.pa = mk(a->pa); q.hres = mk(a->hres); q.pfeat = mk(a->pfeat); q.out = mk(a->out);
-  q.w = (const h16_t*)a->w_fwd; q.bias = a->bias; q.co = a->co;
-  const int pa8 = a->pa.p ? (a->pa.c + 7) / 8 * 8 : 0;
-  q.pa_groups = pa8 / 8;
-  q.krow = ((16 + pa8 + 31) / 32) * 32 + 32;
-  q.rows = (a->co + 15) / 16 * 16;
-  dim3 grid(cgen_reparam_kl_chunks(a->h, a->w, 16), a->n);
-  hipLaunchKernelGGL(reparam_zproj_fwd_kernel, grid, dim3(512), 0, (hipStream_t)stream, q);
-  return check_launch("cgen_latent_zproj_fwd");
-}
-
-extern "C" int cgen_latent_zproj_bwd(const cgen_latent_zproj_args* a, cgen_stream_t stream) {
-  CGEN_REQUIRE(cgen_latent_zproj_supported(a), "cgen_latent_zproj_bwd: shape / layout not served (ask cgen_latent_zproj_supported first)");
-  CGEN_REQUIRE(a->q_loc.p && a->q_ls.p && a->p_loc.p && a->p_ls.p && a->z.p && a->kl_coef_dev && a->g_q_loc.p && a->g_q_ls.p && a->g_p_loc.p &&
-                   a->g_p_ls.p && a->gout.p && a->w_dgrad, "cgen_latent_zproj_bwd: null view");
-  LatZpBwdP q;
-  memset(&q, 0, sizeof(q));
-  LatBwdP& p = q.l;
-  p.n = a->n; p.h = a->h; p.w = a->w; p.c = 16;
-  p.q_loc = mk(a->q_loc); p.q_ls = mk(a->q_ls); p.p_loc = mk(a->p_loc); p.p_ls = mk(a->p_ls); p.z = mk(a->z); p.gz = mk(a->gz);
-  p.g_q_loc = mk(a->g_q_loc); p.g_q_ls = mk(a->g_q_ls); p.g_p_loc = mk(a->g_p_loc); p.g_p_ls = mk(a->g_p_ls);
-  p.coef = a->kl_coef_dev; p.chan_scale = a->kl_chan_scale; p.coef_stride = a->coef_stride; p.acc_q = a->acc_q; p.acc_p = a->acc_p; p.logt = a->logt;
-  q.gh = mk(a->gout); q.wdg = (const h16_t*)a->w_dgrad; q.co = a->co;
-  q.krow_dg = (((a->co + 7) / 8 * 8) + 31) / 32 * 32 + 32;
-  const int gps = (a->h * a->w + 15) / 16;
-  q.groups = a->n * gps;
-  p.main_blocks = std::min((q.groups + 3) / 4, 2048);
-  int ride_blocks = 0;
-  if (a->ride_src.p) {
-    CGEN_REQUIRE(a->ride_dst.p && a->ride_src.c == a->ride_dst.c && a->ride_src.c % 8 == 0 && lat_vec8_ok(a->n, a->ride_src.c, {a->ride_src, a->ride_dst}),
-                 "cgen_latent_zproj_bwd: the rider needs 8-channel multiples and 16-byte aligned views");
-    p.ride_src = mk(a->ride_src); p.ride_dst = mk(a->ride_dst); p.ride_c = a->ride_src.c; p.ride_acc = a->ride_acc;
-    ride_blocks = lat_grid((int64_t)a->n * a->h * a->w * a->ride_src.c / 8);
-  }
-  hipLaunchKernelGGL(reparam_zproj_bwd_kernel, dim3(p.main_blocks + ride_blocks), dim3(256), 0, (hipStream_t)stream, q);
-  return check_launch("cgen_latent_zproj_bwd");
-}
 
 extern "C" int cgen_sample_gaussian(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view loc, cgen_view ls,
                                     cgen_view eps_in, const uint64_t* rng, uint32_t stream_id, float logt, cgen_view z,

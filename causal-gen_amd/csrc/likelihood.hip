@@ -144,6 +144,39 @@ __global__ __launch_bounds__(256) void dgauss_sample_kernel(int n, int h, int w,
   }
 }
 
+// DGaussNet.forward (vae.py:352-386): (loc, logscale) of the pixel distribution from the heads' outputs [loc(c) | logscale(c) | coeffs(3)].
+// logscale = max(ls, -9) + log t; RGB: tanh coefficients, autoregressive means on the TRUE pixels when x is given (vae.py:370-377), on the
+// clamped predicted channels otherwise (vae.py:360-369).  NCHW f32 out (what the reference returns).
+template <typename T>
+__global__ __launch_bounds__(256) void dgauss_params_kernel(int n, int h, int w, int c, View params, View x, float logt, float* loc_o, float* ls_o) {
+  const int npix = h * w;
+  const int64_t total = (int64_t)n * npix;
+  for (int64_t gi = (int64_t)blockIdx.x * 256 + threadIdx.x; gi < total; gi += (int64_t)gridDim.x * 256) {
+    const int b = (int)(gi / npix), px = (int)(gi % npix);
+    const T* pp = vptr<T>(params, b, px / w, px % w);
+    float loc[3];
+    for (int ch = 0; ch < c; ++ch) loc[ch] = Elem<T>::ld(pp + ch);
+    if (c == 3) {
+      const float k0 = tanhf(Elem<T>::ld(pp + 6)), k1 = tanhf(Elem<T>::ld(pp + 7)), k2 = tanhf(Elem<T>::ld(pp + 8));
+      if (x.p) {
+        const T* xp = vptr<T>(x, b, px / w, px % w);
+        const float xr = Elem<T>::ld(xp), xg = Elem<T>::ld(xp + 1);
+        loc[1] = loc[1] + k0 * xr;
+        loc[2] = loc[2] + k1 * xr + k2 * xg;
+      } else {
+        const float r = fminf(fmaxf(loc[0], -1.f), 1.f);
+        const float g = fminf(fmaxf(loc[1] + k0 * r, -1.f), 1.f);
+        loc[0] = r; loc[1] = g; loc[2] = fminf(fmaxf(loc[2] + k1 * r + k2 * g, -1.f), 1.f);
+      }
+    }
+    for (int ch = 0; ch < c; ++ch) {
+      const int64_t o = ((int64_t)b * c + ch) * npix + px;
+      loc_o[o] = loc[ch];
+      ls_o[o] = fmaxf(Elem<T>::ld(pp + c + ch), DG_MIN_LS) + logt;
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------- differentiable counterfactual pixel step
 // dscm.py:52-56 with both likelihood heads' (loc, scale) decoded in place (DGaussNet.sample(h) with return_loc=True,
 // vae.py:352-385,413-422):  rec/cf (loc, scale) = decode(params);  u = (x - rec_loc) / max(rec_scale, 1e-12);
@@ -665,6 +698,16 @@ extern "C" int cgen_dgauss_sample(int32_t dtype, int32_t n, int32_t h, int32_t w
   if (dtype == CGEN_F32) hipLaunchKernelGGL(dgauss_sample_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, ar, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
   else hipLaunchKernelGGL(dgauss_sample_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, ar, mk(params), logt, rng, stream_id, x_nchw, scale_nchw);
   return check_launch("cgen_dgauss_sample");
+}
+
+extern "C" int cgen_dgauss_params(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x, float logt,
+                                  float* loc_nchw, float* logscale_nchw, cgen_stream_t stream) {
+  CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_dgauss_params: bad dtype");
+  CGEN_REQUIRE(params.p && loc_nchw && logscale_nchw && c >= 1 && c <= 3 && params.c >= (c == 3 ? 9 : 2 * c) && (!x.p || x.c == c), "cgen_dgauss_params: bad args");
+  const int grid = like_grid((int64_t)n * h * w);
+  if (dtype == CGEN_F32) hipLaunchKernelGGL(dgauss_params_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), mk(x), logt, loc_nchw, logscale_nchw);
+  else hipLaunchKernelGGL(dgauss_params_kernel<h16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, h, w, c, mk(params), mk(x), logt, loc_nchw, logscale_nchw);
+  return check_launch("cgen_dgauss_params");
 }
 
 extern "C" int cgen_dmol_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, cgen_view x, float* nll_part,

@@ -249,11 +249,6 @@ class Engine(StageMixin):
         self.arena = Arena(self.device)
         self.tape, self.recording = _Tape(), False
         self.tape.eng = self
-        # backward with the decoder's z strand on the side stream (mirror of the forward pipeline).  Correct (same parameters
-        # bit for bit), but MEASURED SLOWER on MI355X: 18.15 vs 17.25 ms/step -- three cross-stream edges per layer inside the
-        # hipGraph cost more than the three launches they take off the critical path.  Off by default.
-        self.bwd_branch = os.environ.get("CGEN_BWD_BRANCH", "0") != "0"
-        self._bw_strand = None  # None: single-stream backward; 0 / 1: strand of the tape entry being run
         self.grads = {}
         self.sites, self.site_by_id = [], {}
         self.stream = 0
@@ -262,7 +257,6 @@ class Engine(StageMixin):
         self._wg_events = []
         self._wg_reduced, self._wg_seen = 0, set()
         self._in_side = False
-        self._wg_marks_deferred = self._wg_marks_pending = False
         self._rng_override = None
         self._dbg_names = {} if os.environ.get("CGEN_DEBUG_NAMES") else None  # id(tensor) -> producing conv (tools/ab_grads.py)
         self._riders = {}
@@ -295,15 +289,7 @@ class Engine(StageMixin):
         # independent sub-graphs of the forward pass (prior / posterior Block of a decoder layer) run on two streams
         self.fwd_branch = os.environ.get("CGEN_FWD_BRANCH", "1") != "0"
         self._fwd_side = None
-        # fused light-Block kernel (two 3x3 convs per launch, csrc/block_fused.inc): 0 off, 1 forward only, 2 forward + data gradient.
-        # OFF by default: correct (tests/test_gpu_block.py) but, at one wave per SIMD, still slower than the two launches it
-        # replaces on MI355X (DESIGN.md section 3.6 has the per-phase cycle stamps and what bounds it)
-        # latent layer (reparameterise + KL + z_proj, and z_proj's data gradient + the reparameterisation gradient) in one launch:
-        # 76 launches fewer per ukbb192 step (1066 -> 990) and NO measurable gain (17.17 vs 17.15 ms; counterfactuals 1 % slower):
-        # the merged kernel is as long as the two it replaces.  Off by default, tested.
-        self.lat_fuse = os.environ.get("CGEN_LAT_FUSE", "0") != "0"
         self._side_join_pending = False
-        self._lat_fused, self._zp_pending = set(), None
         # fused light Block, round 4 (csrc/block.hip, cgen_block3): 0 off, 1 forward only, 2 forward + data gradient; images at
         # least CGEN_BLK3_MINRES wide
         self.blk3_on = int(os.environ.get("CGEN_BLK3", "2")) if self.dt == F16 else 0
@@ -314,9 +300,6 @@ class Engine(StageMixin):
         # one session): 24x24 and 48x48, the posterior Block also at 96x96; "0" = every side
         self.blk3_res = [int(v) for v in os.environ.get("CGEN_BLK3_RES", "24,48").split(",") if v and int(v) > 0]
         self.blk3_res3 = [int(v) for v in os.environ.get("CGEN_BLK3_RES3", "24,48,96").split(",") if v and int(v) > 0]
-        self.blk_fuse = int(os.environ.get("CGEN_BLK_FUSE", "0"))
-        self.blk_minres = int(os.environ.get("CGEN_BLK_MINRES", "24"))
-        self.blk_th4_maxres = int(os.environ.get("CGEN_BLK_TH4_MAXRES", "0"))  # images up to this size use 4-row tiles (experiment: slower)
         # data parallelism: once this fraction of the pass's weight-gradient work has been issued (and the background flush is
         # out), `on_split` is called with the side stream joined -- the gradients of every conv reduced so far are FINAL
         # (`early_final`), so their all-reduce can travel under the rest of the backward pass (train.TrainStep)
@@ -363,7 +346,6 @@ class Engine(StageMixin):
         self._wg_events = []
         self._wg_reduced, self._wg_seen = 0, set()
         self._riders = {}
-        self._lat_fused, self._zp_pending = set(), None
         self.pgrad_init = set()
         self._pnhwc, self._pgrad_tmp = {}, {}
         self._adopted = set()
@@ -657,12 +639,10 @@ class Engine(StageMixin):
         return out
 
     def block2(self, site1, site2, segs, act, res1=None, trunk=False):
-        """A whole light Block -- conv3x3(act(cat segs)) -> conv3x3(act(.)) (+ res1), vae.py:60-71,73-84 -- as ONE launch when
-        the fused kernel serves the shape (bf16, >= blk_minres pixels wide, concat width a multiple of 32, bottleneck <= 32),
-        else as the two conv launches.  The bottleneck tensor is written either way (weight gradients, backward mask), so
-        the tape is the same."""
+        """A whole light Block -- conv3x3(act(cat segs)) -> conv3x3(act(.)) (+ res1), vae.py:60-71,73-84 -- as ONE launch of
+        cgen_block3 (csrc/block.hip) where the kernel serves the shape and the policy (blk3_res / blk3_res3) takes it, else as the
+        two conv launches.  The bottleneck tensor is written either way (weight gradients, backward mask)."""
         x0 = segs[0]
-        a = None
         wants_rem = self.trunk_rem and (trunk or (res1 is not None and res1.rem))  # (the fused kernel knows no remainder planes)
         res_ok = self.blk3_res3 if len(segs) >= 3 else self.blk3_res
         if (self.blk3_on and act == ACT_RELU and not wants_rem and min(x0.h, x0.w) >= self.blk3_minres and "a_fwd" in site1.frag
@@ -672,32 +652,6 @@ class Engine(StageMixin):
             out = self._block3_fwd(site1, site2, segs, res1)
             if out is not None:
                 return out
-        if (self.blk_fuse and self.dt == F16 and act == ACT_RELU and site1.ks == 3 and site2.ks == 3 and len(segs) <= 3
-                and min(x0.h, x0.w) >= self.blk_minres and not wants_rem):
-            a = _lib.BlockArgs()
-            a.dtype, a.n, a.h, a.w, a.mode, a.nseg, a.pre_act = self.dt, x0.n, x0.h, x0.w, 0, len(segs), 1
-            a.tile_h = 4 if max(x0.h, x0.w) <= self.blk_th4_maxres else 8
-            for k, sg in enumerate(segs):
-                a.seg[k] = sg.cv()
-            a.w_a, a.w_b = site1.img_fwd, site2.img_fwd
-            b1, b2 = site1.conv.bias, site2.conv.bias
-            a.bias_a = b1.data_ptr() if b1 is not None else None
-            a.bias_b = b2.data_ptr() if b2 is not None else None
-        if a is not None:
-            t = self.new(x0.n, x0.h, x0.w, site1.co)
-            out = self.new(x0.n, x0.h, x0.w, site2.co)
-            a.mid, a.mid_aux, a.out, a.aux = t.cv(), NULL_VIEW, out.cv(), NULL_VIEW
-            a.res1 = res1.cv() if res1 is not None else NULL_VIEW
-            if site1.co % 8 == 0 and site2.co % 8 == 0 and self.lib.block2_supported(C.byref(a)):
-                self._timed_blk("conv_fwd", site1, site2, x0, lambda: self.lib.block2(C.byref(a), self.stream))
-                if self.recording:
-                    if self.blk_fuse >= 2:
-                        self.tape.append((self._bw_block2, (site1, site2, segs, act, t, out, res1)))
-                    else:
-                        self.tape.append((self._bw_conv, (site1, segs, act, t, None, None)))
-                        self.tape.append((self._bw_conv, (site2, [t], act, out, res1, None)))
-                return out
-            # (the two tensors just allocated are simply not used: the arena is reset per step)
         t = self.conv(site1, segs, act)
         return self.conv(site2, [t], act, res1=res1, trunk=trunk)
 
@@ -929,43 +883,6 @@ class Engine(StageMixin):
             self.tape.append((self._bw_reparam, (q_loc, q_ls, p_loc, p_ls, z, logt, None if fb is None else fb[2], self.kl_coef_override)))
         return z
 
-    def latent_zproj(self, q_loc, q_ls, p_loc, p_ls, eps, stream_id, logt, kl_ptr, kl_stride, fb, site, pa, hres, pfeat):
-        """reparam_kl(...) and conv(z_proj, [z, pa], res1=hres, res2=pfeat) as ONE launch (csrc/latent.hip: the z fragment the
-        reparameterisation leaves in registers is the MFMA operand of the 1x1 conv).  Returns (z, h') or None when the shape
-        is not served (then the caller issues the two launches).  The tape gets the same two entries; the backward pass then
-        folds z_proj's data gradient w.r.t. z into the reparameterisation kernel as well."""
-        if not (self.lat_fuse and not self.trunk_rem and self.dt == F16 and site.ks == 1 and q_loc.c == 16 and len(site.seg_c) == 2 and site.seg_c[0] == 16
-                and site.seg_rg[0] and not site.seg_rg[1]):
-            return None
-        a = _lib.LatentZprojArgs()
-        a.dtype, a.n, a.h, a.w, a.c, a.co = self.dt, q_loc.n, q_loc.h, q_loc.w, 16, site.co
-        a.q_loc, a.q_ls, a.p_loc, a.p_ls = q_loc.cv(), q_ls.cv(), p_loc.cv(), p_ls.cv()
-        a.eps_in = eps.cv() if eps is not None else NULL_VIEW
-        a.eps_out = NULL_VIEW
-        z = self.new(q_loc.n, q_loc.h, q_loc.w, 16)
-        out = self.new(q_loc.n, q_loc.h, q_loc.w, site.co)
-        a.z, a.out, a.pa = z.cv(), out.cv(), pa.cv()
-        a.hres = hres.cv() if hres is not None else NULL_VIEW
-        a.pfeat = pfeat.cv() if pfeat is not None else NULL_VIEW
-        a.gout = a.gz = a.g_q_loc = a.g_q_ls = a.g_p_loc = a.g_p_ls = a.ride_src = a.ride_dst = NULL_VIEW
-        a.rng, a.stream_id, a.logt, a.kl_part, a.kl_stride = self.rng_ptr(), stream_id, logt, kl_ptr, kl_stride
-        a.w_fwd = site.img_fwd
-        b = site.conv.bias
-        a.bias = b.data_ptr() if b is not None else None
-        if not self.lib.latent_zproj_supported(C.byref(a)):
-            return None  # (the two tensors just allocated are simply not used: the arena is reset per step)
-        if fb is not None:
-            self.lib.kl_channel_sums(self.dt, z.n, z.h, z.w, z.c, q_loc.cv(), q_ls.cv(), p_loc.cv(), p_ls.cv(), logt,
-                                     fb[0] + 4 * fb[2], fb[1], self.stream)
-            self.launches += 1
-        self.lib.latent_zproj_fwd(C.byref(a), self.stream)
-        self.launches += 1
-        if self.recording:
-            self.tape.append((self._bw_reparam, (q_loc, q_ls, p_loc, p_ls, z, logt, None if fb is None else fb[2], self.kl_coef_override)))
-            self._lat_fused.add(id(out))
-            self.tape.append((self._bw_conv, (site, [z, pa], ACT_NONE, out, hres, pfeat)))
-        return z, out
-
     def sample_gaussian(self, loc, ls, eps, stream_id, logt):
         z = self.new(loc.n, loc.h, loc.w, loc.c)
         self.lib.sample_gaussian(self.dt, z.n, z.h, z.w, z.c, loc.cv(), ls.cv(), eps.cv() if eps is not None else NULL_VIEW,
@@ -1170,8 +1087,6 @@ class Engine(StageMixin):
         job = self._riders.pop(id(base), None)
         if job is not None:
             gv, g, acc = job
-            self._bw_touch(gv, True)
-            self._bw_touch(g, False)
             self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
             self.launches += 1
 
@@ -1183,11 +1098,9 @@ class Engine(StageMixin):
         g, ivs, base = self._gentry(t.base)
         a, b = t.coff, t.coff + t.c
         miss = self._missing(ivs, a, b)
-        self._bw_touch(g, True)
         if miss != [(a, b)] and not defer_hazard and self._frozen(t):
             self._cow(t)
             g = self.grads[id(t.base)][0]
-            self._bw_touch(g, True)
         gv = g.chan(a, b)
         if not miss:
             return gv, True
@@ -1211,7 +1124,6 @@ class Engine(StageMixin):
         miss = self._missing(ivs, a, b)
         if miss == [(a, b)]:
             return None
-        self._bw_touch(g, bool(miss))
         for (s, e2) in miss:
             self.fill(g.chan(s, e2), 0.0)
             ivs.append((s, e2))
@@ -1276,26 +1188,6 @@ class Engine(StageMixin):
         return gv
 
     # ------------------------------------------------------------------ backward
-    def _bw_touch(self, g, write):
-        """Two-strand backward: the tape entry being run (strand self._bw_strand) is about to read / write the gradient
-        buffer behind `g`.  Make its stream wait for the other strand's last conflicting access (read-after-write,
-        write-after-write, write-after-read -- adopted buffers are accumulated in place), and note the access: the entry's
-        end-of-entry event becomes the buffer's last read / write of this strand."""
-        me = self._bw_strand
-        if me is None:
-            return
-        key = g if isinstance(g, int) else g.base.ptr
-        st = self._bw_state.get(key)
-        if st is None:
-            st = self._bw_state[key] = [None, None, None]  # [last write (strand, event), last read event of strand 0, of strand 1]
-        lw = st[0]
-        mine = self._bw_streams[me]
-        if lw is not None and lw[0] != me and lw[1] is not None:
-            mine.wait_event(lw[1])
-        if write and st[2 - me] is not None:
-            mine.wait_event(st[2 - me])
-        (self._bw_wr if write else self._bw_rd).add(key)
-
     def backward(self):
         if self.wgrad_flush_frac:  # total weight-gradient work of this pass: the background-flush marks are fractions of it
             self._wg_total = sum(2.0 * a[0].ci * a[0].taps * a[0].co * a[1][0].n * a[1][0].h * a[1][0].w
@@ -1306,47 +1198,8 @@ class Engine(StageMixin):
         main_t = torch.cuda.current_stream(self.device)
         if self._side_join_pending:  # side-stream work of the forward pass nobody has joined yet (the stem's im2col)
             self.join_side()
-        two = (self.bwd_branch and self.prof is None and self._fwd_side is not None and self.stream == main_t.cuda_stream
-               and any(e[2] for e in self.tape))
-        if not two:
-            for fn, args, _ in reversed(self.tape):
-                fn(*args)
-        else:
-            # Two strands, as in the forward pass: entries recorded on the side stream (the decoder's z strand: prior Blocks,
-            # z_feat_proj, the upsampling of z) run there again, everything else on the main stream.  Ordering between the
-            # strands is per gradient BUFFER (_bw_touch); weight-gradient flush marks are honoured between entries, with the
-            # strands joined (the flush forks from the main stream).
-            side_t = self._fwd_side
-            side_t.wait_stream(main_t)
-            self._bw_streams, self._bw_state = (main_t, side_t), {}
-            handles = (self.stream, side_t.cuda_stream)
-            self._wg_marks_deferred = True
-            try:
-                for fn, args, side in reversed(self.tape):
-                    me = 1 if side else 0
-                    self._bw_strand, self._bw_wr, self._bw_rd = me, set(), set()
-                    self.stream = handles[me]
-                    fn(*args)
-                    self.stream = handles[0]
-                    if self._bw_wr or self._bw_rd:
-                        ev = torch.cuda.Event()
-                        ev.record(self._bw_streams[me])
-                        for k in self._bw_wr:
-                            st = self._bw_state[k]
-                            st[0] = (me, ev)
-                            st[1 + me] = ev  # (a write is also an access the other strand's writers must respect)
-                        for k in self._bw_rd:
-                            self._bw_state[k][1 + me] = ev
-                    if self._wg_marks_pending:
-                        self._bw_strand = None
-                        main_t.wait_stream(side_t)
-                        self._wgrad_marks()
-                        side_t.wait_stream(main_t)
-            finally:
-                self.stream = handles[0]
-                self._bw_strand = None
-                self._wg_marks_deferred = False
-            main_t.wait_stream(side_t)
+        for fn, args, _ in reversed(self.tape):
+            fn(*args)
         for bid in list(self._riders):
             gv, g, acc = self._riders.pop(bid)
             self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
@@ -1373,11 +1226,6 @@ class Engine(StageMixin):
             self._wgrad(site, segs, act, g)
         for k, s in enumerate(segs):
             if not (s.rg and site.seg_rg[k]):
-                continue
-            if k == 0 and id(out) in self._lat_fused:
-                # z_proj of a fused latent layer: its data gradient w.r.t. z is computed inside the reparameterisation backward
-                # kernel, which is the next tape entry (reparam_kl was recorded right before this conv)
-                self._zp_pending = (site, g, s, act, x0)
                 continue
             self._dgrad_one(site, g, s, k, act, x0)
 
@@ -1412,46 +1260,7 @@ class Engine(StageMixin):
             else:
                 self._cow(s)
                 gv = prev = self.grads[id(s.base)][0].chan(s.coff, s.coff + s.c)
-            self._bw_touch(gv, True)
         return gv, prev, acc
-
-    def _bw_block2(self, site1, site2, segs, act, t, out, res1):
-        """Backward of a fused light Block.  Weight gradients as for the two convs (deferred, batched); the two data-gradient
-        convs run as ONE launch of the fused kernel (mode 1) when conv1 has a single differentiable segment and the shape is
-        served, else as the two conv launches."""
-        g = self.grad_read(out)
-        if g is None:
-            return
-        s0 = segs[0]
-        fused = len(segs) == 1 and s0.rg and site1.seg_rg[0] and site1.img_dg[0] is not None and site2.img_dg[0] is not None
-        a = None
-        if fused:
-            a = _lib.BlockArgs()
-            a.dtype, a.n, a.h, a.w, a.mode, a.nseg, a.pre_act = self.dt, s0.n, s0.h, s0.w, 1, 1, 0
-            a.tile_h = 4 if max(s0.h, s0.w) <= self.blk_th4_maxres else 8
-            a.seg[0] = g.cv()
-            a.w_a, a.w_b, a.bias_a, a.bias_b = site2.img_dg[0], site1.img_dg[0], None, None
-            a.mid = View(t.ptr, t.sn, t.sh, t.sw, t.c, 0)      # shape stand-ins for the query; the real views are set below
-            a.mid_aux = t.cv()
-            a.out = View(s0.ptr, s0.sn, s0.sh, s0.sw, s0.c, 0)
-            a.aux, a.res1 = s0.cv(), NULL_VIEW
-            fused = bool(g.c % 8 == 0 and self.lib.block2_supported(C.byref(a)))
-        if not fused:
-            self._bw_conv(site2, [t], act, out, res1, None)
-            self._bw_conv(site1, segs, act, t, None, None)
-            return
-        if res1 is not None and res1.rg:
-            self._grad_residual(res1, g, out, [t])
-        if self._needs_wgrad(site2):
-            self._wgrad(site2, [t], act, g)
-        gt, acc_t = self.grad_write(t)
-        assert not acc_t
-        gv, prev, acc = self._dgrad_target(s0)
-        a.mid, a.out = gt.cv(), gv.cv()
-        a.res1 = prev.cv() if acc else NULL_VIEW
-        self._timed_blk("conv_dgrad", site1, site2, s0, lambda: self.lib.block2(C.byref(a), self.stream))
-        if self._needs_wgrad(site1):
-            self._wgrad(site1, segs, act, gt)
 
     @staticmethod
     def _needs_wgrad(site):
@@ -1484,17 +1293,13 @@ class Engine(StageMixin):
             cost = 2.0 * site.ci * site.taps * site.co * x0.n * x0.h * x0.w
             self._wg_deferred.append((a, cost))
             self._wg_cum += cost
-            if self._wg_marks_deferred:  # two-strand backward: honoured between tape entries, strands joined
-                self._wg_marks_pending = True
-            else:
-                self._wgrad_marks()
+            self._wgrad_marks()
         else:
             self._timed("conv_wgrad", site, x0, lambda: self.lib.conv2d_wgrad(C.byref(a), self.stream))
         self._wg_events.append((site, key, nsplit))
 
     def _wgrad_marks(self):
         """Background-flush and data-parallel split marks of the weight-gradient work deferred so far (see _wgrad)."""
-        self._wg_marks_pending = False
         k = self._wg_nflush  # cumulative-cost marks, fractions of the pass's total
         if (self.wgrad_batch and self.prof is None and k < len(self.wgrad_flush_frac) and self._wg_total > 0
                 and self._wg_cum >= self.wgrad_flush_frac[k] * self._wg_total):
@@ -1739,7 +1544,6 @@ class Engine(StageMixin):
                 ent = (param, self.arena.alloc(c * h * w * 4))
                 self._pgrad_tmp[id(param)] = ent
             dst = ent[1]
-        self._bw_touch(dst, True)  # (both strands upsample with the same bias parameter)
         self.lib.batch_reduce(self.dt, g.n, g.h, g.w, g.cv(), dst, 1 if acc else 0, 1.0 / self.loss_scale, self.stream)
         self.launches += 1
         self.pgrad_init.add(id(param))
@@ -1771,14 +1575,8 @@ class Engine(StageMixin):
     def _bw_reparam(self, q_loc, q_ls, p_loc, p_ls, z, logt, fb_col=None, coef_ptr=None):
         """`coef_ptr`: device address of d(loss)/d(sum kl) for this layer when it is not the engine-wide one (the abduction
         passes of DSCM.forward draw z from q but contribute no KL term: their coefficient is a device-side zero)."""
-        pend, self._zp_pending = self._zp_pending, None
-        if pend is not None and pend[2] is not z:  # (cannot happen: the pending z_proj belongs to the entry recorded before it)
-            self._dgrad_one(pend[0], pend[1], pend[2], 0, pend[3], pend[4])
-            pend = None
         gz = self.grad_read(z)
         job = self._riders.pop(id(p_loc.base), None)  # (taken before grad_write would land it as a launch of its own)
-        if job is not None:
-            self._bw_touch(job[1], False)
         gql, a1 = self.grad_write(q_loc)
         gqs, a2 = self.grad_write(q_ls)
         gpl, a3 = self.grad_write(p_loc)
@@ -1795,32 +1593,6 @@ class Engine(StageMixin):
                 gz.cv() if gz is not None else NULL_VIEW, self.kl_coef_ptr if coef_ptr is None else coef_ptr, 0,
                 None if fb_col is None else self.kl_chan_ptr + 4 * fb_col, gql.cv(), gqs.cv(), gpl.cv(),
                 gps.cv(), 1 if a1 else 0, 1 if a3 else 0)
-        if pend is not None:
-            site, gh = pend[0], pend[1]
-            a = _lib.LatentZprojArgs()
-            a.dtype, a.n, a.h, a.w, a.c, a.co = self.dt, z.n, z.h, z.w, 16, site.co
-            a.q_loc, a.q_ls, a.p_loc, a.p_ls, a.z = q_loc.cv(), q_ls.cv(), p_loc.cv(), p_ls.cv(), z.cv()
-            a.eps_in = a.eps_out = a.pa = a.hres = a.pfeat = a.out = NULL_VIEW
-            a.logt = logt
-            a.gout = gh.cv()
-            a.gz = gz.cv() if gz is not None else NULL_VIEW
-            a.g_q_loc, a.g_q_ls, a.g_p_loc, a.g_p_ls = gql.cv(), gqs.cv(), gpl.cv(), gps.cv()
-            a.w_dgrad = site.img_dg[0]
-            a.kl_coef_dev = self.kl_coef_ptr if coef_ptr is None else coef_ptr
-            a.kl_chan_scale = None if fb_col is None else self.kl_chan_ptr + 4 * fb_col
-            a.coef_stride, a.acc_q, a.acc_p = 0, 1 if a1 else 0, 1 if a3 else 0
-            if job is not None:
-                a.ride_src, a.ride_dst, a.ride_acc = job[1].cv(), job[0].cv(), 1 if job[2] else 0
-            else:
-                a.ride_src = a.ride_dst = NULL_VIEW
-            if self.lib.latent_zproj_supported(C.byref(a)):
-                self.lib.latent_zproj_bwd(C.byref(a), self.stream)
-                self.launches += 1
-                return
-            # not served after all (layout of a gradient view): the two launches
-            self._dgrad_one(pend[0], pend[1], pend[2], 0, pend[3], pend[4])
-            gz = self.grad_read(z)
-            args = args[:11] + (gz.cv(),) + args[12:]
         if job is None:
             self.lib.reparam_kl_bwd(*args, self.stream)
         else:

@@ -20,7 +20,7 @@ from ._lib import (F16, NULL_VIEW, ST_AVGPOOL_BWD, ST_AVGPOOL_FWD, ST_AXPBY, ST_
                    ST_UPSAMPLE_BWD, ST_UPSAMPLE_FWD, StageElemArgs, StageReparamArgs, StageReparamBwdArgs)
 
 # entry points that answer on the host and launch nothing
-_PURE = {"version", "last_error", "block2_supported", "latent_zproj_supported", "stem_conv_supported", "stage_accepts", "stage_plan",
+_PURE = {"version", "last_error", "block3_supported", "stem_conv_supported", "stage_accepts", "stage_plan",
          "reparam_kl_chunks", "like_chunks", "conv2d_wgrad_plan", "conv2d_wgrad_batch_plan"}
 
 
@@ -150,7 +150,7 @@ class StageMixin:
 
     @property
     def stage_active(self):
-        return self.stage_enabled and self.dt == F16 and bool(self.stage_res) and not self.bwd_branch
+        return self.stage_enabled and self.dt == F16 and bool(self.stage_res)
 
     def stage_covers(self, res):
         """True when the ops of a layer at this resolution go into stage lists (the forward pass then keeps them on ONE stream:

@@ -494,25 +494,14 @@ class DGaussNet(nn.Module):
     @torch.no_grad()
     def _forward_standalone(self, h, x=None, t=None):
         eng, buf = self._standalone_params(h)
-        C = self.channels
-        p = eng.to_nchw(buf)
-        loc, logscale = p[:, :C], p[:, C:2 * C].clamp(min=-9.0)  # EPS = -9 (vae.py:11, 355)
-        if C == 3:  # vae.py:357-383 (a handful of per-pixel torch ops on the heads' outputs: not a hot path on its own)
-            coeff = torch.tanh(p[:, 2 * C:2 * C + 3])
-            if x is None:
-                f = lambda v: v.clamp(-1, 1)
-                r = f(loc[:, 0])
-                g_ = f(loc[:, 1] + coeff[:, 0] * r)
-                b = f(loc[:, 2] + coeff[:, 1] * r + coeff[:, 2] * g_)
-            else:
-                x = x.to(p.device, torch.float32)
-                r = loc[:, 0]
-                g_ = loc[:, 1] + coeff[:, 0] * x[:, 0]
-                b = loc[:, 2] + coeff[:, 1] * x[:, 0] + coeff[:, 2] * x[:, 1]
-            loc = torch.stack([r, g_, b], 1)
-        if t is not None:
-            logscale = logscale + float(torch.tensor(t).log())
-        return loc.contiguous(), logscale.contiguous()
+        C, B, R, W = self.channels, buf.n, buf.h, buf.w
+        loc = torch.empty((B, C, R, W), dtype=torch.float32, device=eng.device)
+        logscale = torch.empty_like(loc)
+        xv = eng.from_nchw(x.to(eng.device, torch.float32)).cv() if (x is not None and C == 3) else NULL_VIEW
+        logt = 0.0 if t is None else float(torch.tensor(t).log())
+        # one launch (cgen_dgauss_params): EPS clamp, + log t, and for RGB the autoregressive means of vae.py:357-383
+        eng.lib.dgauss_params(eng.dt, B, R, W, C, buf.cv(), xv, logt, loc.data_ptr(), logscale.data_ptr(), eng.stream)
+        return loc, logscale
 
     def forward(self, h, x=None, t=None):
         """vae.py:352-386: (loc, logscale) of the pixel distribution given the decoder's last hidden state."""
@@ -743,7 +732,7 @@ class HVAE(nn.Module):
         assert tuple(e.shape) == (n, c, h, w), (tuple(e.shape), shape_nhwc)
         return eng.from_nchw(e.to(eng.device, torch.float32))
 
-    def _decode(self, eng, parents, acts=None, t=None, latents=None, collect=None, drop=(1, 1), kl=None, fb=None, lat_fuse=False):
+    def _decode(self, eng, parents, acts=None, t=None, latents=None, collect=None, drop=(1, 1), kl=None, fb=None):
         """Decoder.forward (vae.py:222-301).  `collect`: None | "z" | "q" (q stats for cond-prior abduction) |
         "p" (prior stats).  `kl` = (ptr, stride, offsets) when the KL is wanted."""
         dec = self.decoder
@@ -783,7 +772,6 @@ class HVAE(nn.Module):
                         z = eng.on_side(lambda: eng.upsample(z_lo, res, bp))
                     else:
                         z = eng.upsample(z, res, bp)
-            h_next = None
             p_in = h if blk.q_correction else z
             run_prior = lambda: self._run_block(eng, blk.prior, [p_in, pa_sto] if blk.cond_prior else [p_in])
             # the prior and the posterior Block of a layer are independent: two streams (one fork / join per layer)
@@ -807,15 +795,7 @@ class HVAE(nn.Module):
                     kptr = kl[0] + 4 * kl[2][i] if kl is not None else self._scratch_kl(eng, B, res, zd)
                     kstride = kl[1] if kl is not None else _lib.load().reparam_kl_chunks(res, res, zd)
                     fbl = None if fb is None else (fb[0], fb[1], fb[2][i])
-                    # reparameterise + KL + z_proj (+ h + p_feat) in one launch where the kernel serves the shape
-                    # (only in the plain ELBO pass: an abduction pass must leave bit for bit the hidden state a replay of its
-                    #  latents rebuilds with the separate z_proj conv -- the null-intervention identity of dscm.counterfactual)
-                    fz = (eng.latent_zproj(q_loc, q_ls, p_loc, p_ls, eps, sid, logt, kptr, kstride, fbl, self._site(eng, blk.z_proj), pa, h, p_feat)
-                          if lat_fuse else None)
-                    if fz is not None:
-                        z, h_next = fz
-                    else:
-                        z = eng.reparam_kl(q_loc, q_ls, p_loc, p_ls, eps, sid, logt, kptr, kstride, fb=fbl)
+                    z = eng.reparam_kl(q_loc, q_ls, p_loc, p_ls, eps, sid, logt, kptr, kstride, fb=fbl)
                     if collect == "z":
                         out.append(z)
                     elif collect == "q":
@@ -840,7 +820,7 @@ class HVAE(nn.Module):
                 z = eng.on_side(lambda: eng.conv(self._site(eng, blk.z_feat_proj), [z_cur, p_feat], ACT_NONE, tape_hold=hold))
                 side_ahead = True
                 feat = False
-            h = h_next if h_next is not None else eng.conv(self._site(eng, blk.z_proj), [z_cur, pa], ACT_NONE, res1=h, res2=p_feat, trunk=True)
+            h = eng.conv(self._site(eng, blk.z_proj), [z_cur, pa], ACT_NONE, res1=h, res2=p_feat, trunk=True)
             h = self._run_block(eng, blk.conv, [h])
             eng.tape.extend(hold)  # (backward order as before: z_feat_proj after the conv Block)
             if feat:
@@ -924,7 +904,7 @@ class HVAE(nn.Module):
                     ncol += blk.z_dim
             s_buf = torch.empty(B * ncol + ncol, dtype=torch.float32, device=eng.device)  # S[B][ncol] then chan_mask[ncol]
             fb = (s_buf.data_ptr(), ncol, cols)
-        h, _ = self._decode(eng, pa, acts=acts, drop=drop, kl=(kl_ptr, kl_total, offs), fb=fb, lat_fuse=True)
+        h, _ = self._decode(eng, pa, acts=acts, drop=drop, kl=(kl_ptr, kl_total, offs), fb=fb)
         if fb is not None and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             # one small exchange: every row of S is replaced by the global per-channel mean, so that the finalize kernel
             # floors (and masks the gradient of) the same batch statistic on every rank; the per-sample gradient weight
@@ -972,7 +952,11 @@ class HVAE(nn.Module):
         from .dscm import cf_pixels
 
         if self.likelihood.kind != "dgauss" or getattr(self.likelihood, "logit_space", False):
-            raise NotImplementedError("the differentiable counterfactual branch is built for the DGaussNet head")
+            raise NotImplementedError(
+                "DSCM.forward under autograd (dscm.py:40-72 as train_cf.py:159-183 uses it) is built for the DGaussNet head: with DmolNet "
+                "the counterfactual pixels are the soft mixture mean of dmol.py:218-245, whose gradient w.r.t. the 100 logits per pixel "
+                "has no HIP kernel (cgen_dmol_decode is forward only).  The reference never fine-tunes a DMoL HVAE (config 3 is the "
+                "survey's construct); call DSCM.forward under torch.no_grad() with this head")
         eng = self.engine()
         eng.begin()
         eng.recording = True

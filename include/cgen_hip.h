@@ -82,30 +82,7 @@ typedef struct cgen_conv_args {
 } cgen_conv_args;
 int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream);
 
-/* ------------------------------------------------------------------ fused "light" Block: two 3x3 convs in one launch (bf16)
- * Block.forward with version == "light" (vae.py:60-71,73-84):
- *   mode 0:  mid = bias_a + conv3x3(relu(cat_C(seg)))            (pre-activation bottleneck tensor, written once)
- *            out = bias_b + conv3x3(relu(mid)) + res1            (w_a / w_b: forward weight images of the two convs)
- * and its data gradient (aten::convolution_backward x2 + threshold_backward x2, the input part):
- *   mode 1:  mid = conv3x3(seg[0] = grad_out; w_a = dgrad image of conv2) * relu'(mid_aux)       (= grad of the bottleneck)
- *            out = conv3x3(mid; w_b = dgrad image of conv1's segment) * relu'(aux) + res1         (= grad of the input)
- * The bottleneck tensor stays in LDS between the two convs (halo recomputed); `mid` is written for the weight gradients
- * and the backward mask.  pre_act: apply ReLU to the phase-A input (1 in mode 0, 0 in mode 1).
- * Served shapes: sum_s ceil8(seg[s].c) a multiple of 32 (<= 160), mid.c in {8,16,24,32}, out.c a multiple of 8;
- * cgen_block2_supported() answers without launching (1 = served). */
-typedef struct cgen_block_args {
-  int32_t dtype, n, h, w, mode, nseg, pre_act, tile_h; /* tile_h: output rows per tile, 8 (0 = 8) or 4 */
-  cgen_view seg[CGEN_MAX_SEG];
-  const void* w_a;
-  const float* bias_a;
-  const void* w_b;
-  const float* bias_b;
-  cgen_view mid, mid_aux, out, aux, res1;
-} cgen_block_args;
-int cgen_block2_supported(const cgen_block_args* a);
-int cgen_block2(const cgen_block_args* a, cgen_stream_t stream);
-
-/* ------------------------------------------------------------------ fused "light" Block, round 4 (csrc/block.hip; binary16)
+/* ------------------------------------------------------------------ fused "light" Block (csrc/block.hip; binary16)
  * Block.forward with version == "light" (vae.py:49-56, 60-71, 73-84) as ONE launch, the bottleneck tensor resident in LDS:
  *   pre_act = 1 (forward):   mid = bias_a + conv3x3(relu(cat_C(seg)))          (pre-activation bottleneck, interior pixels written once)
  *                            o[k].out = o[k].bias + conv3x3(relu(mid)) + o[k].res1
@@ -299,33 +276,6 @@ int cgen_kl_channel_sums(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t
  * (-0.5 + p_ls - q_ls + 0.5 * (exp(q_ls)^2 + (q_loc - p_loc)^2) / exp(p_ls)^2; no clamps) */
 int cgen_gaussian_kl_map(int64_t count, const float* q_loc, const float* q_ls, const float* p_loc, const float* p_ls,
                          float* out, cgen_stream_t);
-/* Latent layer in one launch (bf16, z_dim 16): reparameterise + KL (vae.py:14-30,264-269) AND z_proj with its residuals,
- * h' = z_proj(cat[z, pa]) + h + p_feat (vae.py:288-294), as a single-K-step MFMA on the fragment the reparameterisation
- * leaves in registers; backward: z_proj's data gradient w.r.t. z + the reparameterisation / KL gradient (+ the rider copy of
- * cgen_reparam_kl_bwd_rider).  Same z, same Philox draws and the same KL partial layout as cgen_reparam_kl_fwd.
- * w_fwd / w_dgrad: z_proj's forward image and the data-gradient image of its z segment (cgen_weight_prep layouts). */
-typedef struct cgen_latent_zproj_args {
-  int32_t dtype, n, h, w, c, co;            /* c: z_dim (16); co: z_proj output channels */
-  cgen_view q_loc, q_ls, p_loc, p_ls, eps_in, z, eps_out;
-  const uint64_t* rng;
-  uint32_t stream_id;
-  float logt;
-  float* kl_part;
-  int32_t kl_stride, reserved0;
-  cgen_view pa, hres, pfeat, out;           /* forward: parents (<= 16 channels), residuals (optional), h' */
-  const void* w_fwd;
-  const float* bias;
-  /* backward */
-  cgen_view gout, gz, g_q_loc, g_q_ls, g_p_loc, g_p_ls;
-  const void* w_dgrad;
-  const float* kl_coef_dev;
-  const float* kl_chan_scale;
-  int32_t coef_stride, acc_q, acc_p, ride_acc;
-  cgen_view ride_src, ride_dst;
-} cgen_latent_zproj_args;
-int cgen_latent_zproj_supported(const cgen_latent_zproj_args* args);
-int cgen_latent_zproj_fwd(const cgen_latent_zproj_args* args, cgen_stream_t);
-int cgen_latent_zproj_bwd(const cgen_latent_zproj_args* args, cgen_stream_t);
 /* z = loc + exp(ls + logt) * eps (prior sampling, vae.py:283-286); eps as above */
 int cgen_sample_gaussian(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view loc, cgen_view ls,
                          cgen_view eps_in, const uint64_t* rng, uint32_t stream_id, float logt, cgen_view z,
@@ -352,6 +302,11 @@ int cgen_dgauss_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t 
  * x = clamp(loc + scale * N(0,1)) with Philox noise of stream `stream_id` */
 int cgen_dgauss_sample(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, float logt,
                        const uint64_t* rng, uint32_t stream_id, float* x_nchw, float* scale_nchw, cgen_stream_t);
+/* DGaussNet.forward (vae.py:352-386): (loc, logscale) from the heads' outputs `params` = [loc(c) | logscale(c) | coeffs(3 if c == 3)]:
+ * logscale = max(ls, -9) + logt; RGB: autoregressive means with tanh coefficients -- on the TRUE pixels `x` (NHWC view, c channels) when
+ * given (vae.py:370-377), on the clamped predicted channels when x.p == NULL (vae.py:360-369).  Outputs NCHW f32. */
+int cgen_dgauss_params(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, cgen_view x, float logt,
+                       float* loc_nchw, float* logscale_nchw, cgen_stream_t stream);
 /* Logit-space Gaussian of the config-1 model (simple_vae.py:173-248, GaussNet; x_like = *_gauss).  params = [loc(C) |
  * logscale(C)].  nll: x in [-1,1] -> (x+1)*127.5 + u, u ~ U[0,1) -> logit(./256) -> -log N(.; loc, exp(max(logscale,-9)))
  * (simple_vae.py:215-229; no log-determinant, as the reference).  u: NHWC view of injected uniforms (u.p != NULL), else

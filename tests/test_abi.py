@@ -36,9 +36,9 @@ def test_struct_layouts_match_header():
     prog = r'''
 #include <stdio.h>
 #include "cgen_hip.h"
-int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(cgen_view), sizeof(cgen_conv_args), sizeof(cgen_wgrad_args),
-                         sizeof(cgen_wprep_desc), sizeof(cgen_wred_desc), sizeof(cgen_adamw_args), sizeof(cgen_block_args),
-                         sizeof(cgen_latent_zproj_args), sizeof(cgen_stage_elem_args), sizeof(cgen_stage_reparam_args),
+int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(cgen_view), sizeof(cgen_conv_args), sizeof(cgen_wgrad_args),
+                         sizeof(cgen_wprep_desc), sizeof(cgen_wred_desc), sizeof(cgen_adamw_args), sizeof(cgen_block3_args),
+                         sizeof(cgen_stage_elem_args), sizeof(cgen_stage_reparam_args),
                          sizeof(cgen_stage_reparam_bwd_args)); return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
@@ -47,8 +47,8 @@ int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
-    mine = [ctypes.sizeof(t) for t in (_lib.View, _lib.ConvArgs, _lib.WgradArgs, _lib.WprepDesc, _lib.WredDesc, _lib.AdamwArgs, _lib.BlockArgs,
-                                       _lib.LatentZprojArgs, _lib.StageElemArgs, _lib.StageReparamArgs, _lib.StageReparamBwdArgs)]
+    mine = [ctypes.sizeof(t) for t in (_lib.View, _lib.ConvArgs, _lib.WgradArgs, _lib.WprepDesc, _lib.WredDesc, _lib.AdamwArgs, _lib.Block3Args,
+                                       _lib.StageElemArgs, _lib.StageReparamArgs, _lib.StageReparamBwdArgs)]
     assert sizes == mine, (sizes, mine)
 
 

@@ -8,7 +8,7 @@ import csv
 import json
 import sys
 
-CLASSES = {"conv_fwd+dgrad": ("conv_tile_kernel", "conv_ws_kernel", "conv_px_kernel", "conv_smallp_kernel", "conv_kernel", "stem7"),
+CLASSES = {"conv_fwd+dgrad": ("conv_tile_kernel", "conv_ws_kernel", "conv_px_kernel", "conv_smallp_kernel", "conv_kernel", "stem7", "blk3_kernel"),
            "conv_wgrad": ("wgrad_tile", "wgrad_kernel"), "wgrad_reduce": ("wred_kernel",), "reparam_kl": ("reparam_kl",),
            "likelihood": ("dgauss", "dmol"), "optimizer": ("adamw", "sumsq", "clip_decide"), "stage": ("stage_kernel",)}
 tag = sys.argv[1]
@@ -30,4 +30,8 @@ for cls, a in sorted(tot.items()):
                 "valu_per_mfma": a.get("SQ_INSTS_VALU", 0.0) / mf if mf else None, "salu_per_mfma": a.get("SQ_INSTS_SALU", 0.0) / mf if mf else None,
                 "lds_per_mfma": a.get("SQ_INSTS_LDS", 0.0) / mf if mf else None,
                 "issue_stall_pct_of_wave_lifetime": (100.0 * a.get("SQ_WAIT_INST_ANY", 0.0) / wc) if wc else None}
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from tree_sha import tree_sha
+out["_source"] = {"code_tree_sha": tree_sha(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "command": "tools/pmc_insts.sh (two SQ counter passes of one bench step)"}
 print(json.dumps(out, indent=1))

@@ -8,7 +8,7 @@ import csv
 import json
 import sys
 
-CLASSES = {"conv_fwd+dgrad": ("conv_tile_kernel", "conv_ws_kernel", "conv_px_kernel", "conv_smallp_kernel", "conv_kernel"), "conv_wgrad": ("wgrad_tile_kernel", "wgrad_tile_batched_kernel", "wgrad_tile_mega_kernel", "wgrad_kernel"),
+CLASSES = {"conv_fwd+dgrad": ("conv_tile_kernel", "conv_ws_kernel", "conv_px_kernel", "conv_smallp_kernel", "conv_kernel", "blk3_kernel"), "conv_wgrad": ("wgrad_tile_kernel", "wgrad_tile_batched_kernel", "wgrad_tile_mega_kernel", "wgrad_kernel"),
            "wgrad_reduce": ("wred_kernel",), "reparam_kl": ("reparam_kl",), "elementwise": ("axpby", "avgpool", "upsample", "im2col", "batch_")}
 
 
@@ -32,6 +32,11 @@ def main():
         wk, _ = w.get(cls, [0.0, 0])
         out[cls] = dict(dispatches=n, fetch_kb_raw=fk, write_kb_raw=wk, hbm_bytes_total=(2 * fk + wk) * 1024,
                         hbm_bytes_per_dispatch=((2 * fk + wk) * 1024 / n) if n else None)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tree_sha import tree_sha
+    out["_source"] = {"code_tree_sha": tree_sha(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+                      "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 --prep-steps 1 --no-cpu --no-cf --no-f32 --no-extra"}
     print(json.dumps(out, indent=1))
     if len(sys.argv) > 3:
         json.dump(out, open(sys.argv[3], "w"), indent=1)
