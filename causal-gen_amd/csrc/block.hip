@@ -98,6 +98,21 @@ __device__ __forceinline__ uint4 b3_pack8(const float* v) {
 }
 #define B3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define B3_VMWAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define B3_VMWAIT_N(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// a 16-byte global load the compiler does NOT track (no automatic s_waitcnt in front of its uses): the caller waits by count
+// (B3_VMWAIT_N) and launders the register (b3_pin) before the first use.  The "memory" clobber keeps it in program order with the
+// LDS-DMA requests around it -- the counted waits depend on that order.  s_nop 4: the base may have been written by a VALU
+// instruction (v_readlane of a spilled SGPR) right in front of the statement, and the hazard recogniser does not look inside it
+// (VALU writes SGPR -> VMEM reads it: 5 wait states; without them the load uses the stale register: a memory fault).
+// one LDS-DMA instruction (16 B per lane -> LDS at `lds` + 16 lane), also invisible to the compiler's wait-count pass: no automatic
+// vmcnt(0) in front of LDS accesses it cannot prove disjoint, no limit on how many requests may be in flight; ordering is by the
+// counted waits + barriers of the tile loop alone.  (Nothing else in these kernels uses M0; s_nop: M0 write -> LDS-DMA hazard.)
+__device__ __forceinline__ void b3_dma16(const char* src, const uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void b3_gload(h16x8& d, const char* sbase, const int voff) {
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
 
 // the 9 K16-steps (one per tap) of one 32-channel chunk that this wave owns: K half kh = channels 16 kh .. + 16 of the chunk (folded
 // into pbA), fragment reads issued one step ahead of the MFMAs that consume them
@@ -169,6 +184,19 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   // per chunk.  Every lane is active (no exec branches): group 4 is the padding slot (zeros), lanes 60-63 re-write the first four
   // groups of the NEXT instruction's first pixel with the same bytes (the last instruction's overhang lands behind the slot)
   const int dpl = lane / 5, dq = lane - 5 * dpl;
+  // halo pixel (hy, hx) of this lane in the wave's i-th instruction, 9 bits each (hy << 5 | hx), i = 0..2 in hq0, 3..4 in hq1;
+  // lmask bit i: a real pixel and a real channel group
+  uint32_t hq0 = 0, hq1 = 0;
+  int lmask = 0;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int pi = 12 * (wave + 4 * i) + dpl;
+    const int hy = (pi * 3277) >> 16, hx = pi - hy * B3_HW;  // (pi / 20, exact for pi < 252)
+    if (i < 3) hq0 |= (uint32_t)(hy << 5 | hx) << (9 * i); else hq1 |= (uint32_t)(hy << 5 | hx) << (9 * (i - 3));
+    if (dq < 4 && hy < 12) lmask |= 1 << i;
+  }
+  auto hy_of = [&](const int i) { return (int)(((i < 3 ? hq0 : hq1) >> (9 * (i % 3) + 5)) & 15); };
+  auto hx_of = [&](const int i) { return (int)(((i < 3 ? hq0 : hq1) >> (9 * (i % 3))) & 31); };
   // ---- phase-B lane constants
   const int kgmask = kg ? -1 : 0;
   const int pbB = ((px >> 4) * B3_MW + (px & 15)) * MS;  // out pixel (2 pg + (px >> 4), px & 15) -> bottleneck tile offset (pg part is an immediate)
@@ -179,8 +207,20 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     n = b3_div(b1, p.d_ty);
     y0 = (b1 - n * p.tiles_y) * B3_TH; x0 = tx * B3_TW;
   };
-  // halo pixels of chunk j of tile (n, y0, x0) -> ring slot Xn, by LDS-DMA
-  auto dma_chunk = [&](char* Xn, const int n, const int y0, const int x0, const int j) {
+  // which of this lane's five halo pixels of tile (y0, x0) lie inside the image (once per tile, not per chunk)
+  auto tile_valid = [&](const int y0, const int x0) {
+    int vb = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int iy = y0 - 2 + hy_of(i), ix = x0 - 2 + hx_of(i);
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) vb |= 1 << i;
+    }
+    return vb & lmask;
+  };
+  // halo pixels of chunk j of tile (n, y0, x0) -> ring slot Xn, by LDS-DMA: five instructions per wave, ~10 VALU each (the first
+  // version walked them in a rolled loop with the divisions and bounds checks inside: ~2000 cycles per chunk and wave, more than
+  // the chunk's MFMAs)
+  auto dma_chunk = [&](char* Xn, const int n, const int y0, const int x0, const int vb, const int j) {
     // chunk j belongs to ONE segment (the concatenated axis pads every segment to whole 32-channel chunks: the parents' few
     // channels cost a fractional chunk either way), so everything about the source but the lane's pixel is wave-uniform
     int sg = 0;
@@ -197,25 +237,21 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     const int sn = ks->sn, sh = ks->sh, sw = ks->sw;
     const int c8 = ((kint_ptr)(ka + offsetof(B3P, seg_c8)))[sg], k0 = ((kint_ptr)(ka + offsetof(B3P, seg_koff)))[sg];
     const int cs = 32 * (j - k0) + 8 * dq;  // this lane's channel group inside the segment
-    const bool okc = dq < 4 && cs < c8;
-    const char* base = sp + (n * sn + (y0 - 2) * sh + (x0 - 2) * sw) + cs * 2;
-    // ONE static DMA instruction per call site (a rolled loop): hipcc's wait-count pass keeps alias information for a handful of
-    // LDS-DMA instructions only -- with the five of a chunk unrolled at every call site it falls back to draining all DMA in
-    // flight in front of EVERY LDS access, restrict views or not
-#pragma unroll 1
+    const int vbc = cs < c8 ? vb : 0;
+    const char* base = sp + (n * sn + (y0 - 2) * sh + (x0 - 2) * sw);
+    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr)Xn) + wave * (12 * B3_XS);
+#pragma unroll
     for (int i = 0; i < 5; ++i) {
-      const int pi = 12 * (wave + 4 * i) + dpl;
-      const int hy = (pi * 3277) >> 16, hx = pi - hy * B3_HW;  // (pi / 20, exact for pi < 252)
-      const int iy = y0 - 2 + hy, ix = x0 - 2 + hx;
-      const bool ok = okc && hy < 12 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      const char* src = ok ? base + (hy * sh + hx * sw) : zero;
-      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(Xn + (wave + 4 * i) * (12 * B3_XS)), 16, 0, 0);
+      const uint32_t off = __umul24(hy_of(i), sh) + __umul24(hx_of(i), sw) + cs * 2;
+      const char* src = ((vbc >> i) & 1) ? base + off : zero;
+      b3_dma16(src, la + i * (4 * 12 * B3_XS));
     }
   };
   // (SM > 0, backward) the bottleneck mask tile t[10 x 18 pixels][b] of tile (n, y0, x0) -> LDS, dense, by DMA: instruction i of
   // the 3 NB covers 64 consecutive 16-byte groups; wave w issues i = w, w + 4
   auto dma_mask = [&](char* dst, const int n, const int y0, const int x0) {
-#pragma unroll 1
+    const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr)dst);
+#pragma unroll
     for (int ii = 0; ii < (3 * NB + 3) / 4; ++ii) {
       const int i = wave + 4 * ii;
       if (i < 3 * NB) {
@@ -224,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
         const int iy = y0 - 1 + my, ix = x0 - 1 + mx;
         const bool ok = m < B3_NMP && iy >= 0 && iy < H && ix >= 0 && ix < W;
         const char* src = ok ? p.mid_aux.p + (n * p.mid_aux.sn + iy * p.mid_aux.sh + ix * p.mid_aux.sw) + gq * 16 : zero;
-        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(dst + i * 1024), 16, 0, 0);
+        b3_dma16(src, la + i * 1024);
       }
     }
   };
@@ -232,6 +268,12 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     const char* wa = p.wA + (size_t)(j * 18 + kh) * 1024 + lane * 16;  // K16-step kk = 2 tap + channel half
 #pragma unroll
     for (int s = 0; s < 9; ++s) An[s] = *(const h16x8*)(wa + s * 2048);
+  };
+  // (SM == 0) the same fragments by untracked loads: a chunk's DMA stays in flight under the wait for the previous chunk's weights
+  auto load_A_counted = [&](h16x8 (&An)[9], const int j) {
+    const char* wa = p.wA + (size_t)(j * 18 + kh) * 1024;
+#pragma unroll
+    for (int s = 0; s < 9; ++s) b3_gload(An[s], wa + s * 2048, lane * 16);
   };
   h16x8 A0[9], A1[SM == 1 ? 1 : 9], wbp[SM > 0 ? RD : 1];  // (wbp: the persistent phase-B weights of SM > 0)
   if constexpr (SM > 0) {
@@ -279,28 +321,12 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     int n, y0, x0;
     tile_of(tile, n, y0, x0);
+    if (stamp && nstamp == 2) stamp[238] = __builtin_readcyclecounter();
+    const int vb = tile_valid(y0, x0);
+    if (stamp && nstamp == 2) stamp[239] = __builtin_readcyclecounter();
     int issued = nch;
-    if constexpr (SM == 0) {  // any number of chunks through TWO slots, one chunk ahead (each boundary waits for the chunk requested a step ago)
-      dma_chunk(lw, n, y0, x0, 0);
-    } else if (!prefetched) {
-      issued = min(nch, NS);
-      for (int k = 0; k < issued; ++k) dma_chunk(lw + ((sbase + k) % NS) * B3_XBYTES, n, y0, x0, k);
-      if constexpr (!PRE) dma_mask(lw + p.tm_off + tmsel * p.tm_bytes, n, y0, x0);
-    }
-    if constexpr (!persistA) load_A(A0, 0);
-    B3_STAMP(0);
-    // ------------------------------------------------------------------ phase A
-    f32x16 acc[3];
-    {  // bias as the initial value (the K-half-0 waves; zeros elsewhere): channels 16 kg + i of this lane, from the LDS copy
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        float4 bb = *(const float4*)(BIA + 16 * kg + 4 * q4);
-        if (kh != 0) bb = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int g = 0; g < 3; ++g) { acc[g][4 * q4] = bb.x; acc[g][4 * q4 + 1] = bb.y; acc[g][4 * q4 + 2] = bb.z; acc[g][4 * q4 + 3] = bb.w; }
-      }
-    }
-    // mask source of the bottleneck gradient (backward): requested now, consumed after phase A
+    // mask source of the bottleneck gradient (backward, SM == 0): requested FIRST -- ordinary loads, the oldest of the tile, so no
+    // counted wait below has to know about them -- and consumed after phase A
     // (finalisation is shared by the two K halves: with a bottleneck of >= 16 channels wave kh finishes the 8-channel half q8 = kh of
     //  all three groups; with 8 channels -- only q8 = 0 exists -- K-half 0 finishes groups 0 and 1, K-half 1 group 2)
     constexpr bool QSPLIT = NB >= 2;
@@ -321,6 +347,38 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
         tm[g] = *(const uint4*)src;
       }
     }
+    if constexpr (SM == 0) {
+      // any number of chunks through a ring of NS = 2 (<= 2 chunks) or 3 slots, TWO chunks ahead: chunks 0 and 1 now, chunk j + 2 at
+      // the start of chunk j.  Request order per wave: dma 0 (5 instructions), A 0 (9 loads), dma 1, A 1 | dma j+2, A j+2 | ...
+      // => in front of chunk j exactly dma j+1 and A j+1 (14 requests) may still be in flight: s_waitcnt vmcnt(14)
+      if (stamp && nstamp == 2) stamp[240] = __builtin_readcyclecounter();
+      dma_chunk(lw, n, y0, x0, vb, 0);
+      if (stamp && nstamp == 2) stamp[241] = __builtin_readcyclecounter();
+      load_A_counted(A0, 0);
+      if (stamp && nstamp == 2) stamp[242] = __builtin_readcyclecounter();
+      if (nch > 1) {
+        dma_chunk(lw + B3_XBYTES, n, y0, x0, vb, 1);
+        if (stamp && nstamp == 2) stamp[243] = __builtin_readcyclecounter();
+        load_A_counted(A1, 1);
+        if (stamp && nstamp == 2) stamp[244] = __builtin_readcyclecounter();
+      }
+    } else if (!prefetched) {
+      issued = min(nch, NS);
+      for (int k = 0; k < issued; ++k) dma_chunk(lw + ((sbase + k) % NS) * B3_XBYTES, n, y0, x0, vb, k);
+      if constexpr (!PRE) dma_mask(lw + p.tm_off + tmsel * p.tm_bytes, n, y0, x0);
+    }
+    B3_STAMP(0);
+    // ------------------------------------------------------------------ phase A
+    f32x16 acc[3];
+    {  // bias as the initial value (the K-half-0 waves; zeros elsewhere): channels 16 kg + i of this lane, from the LDS copy
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        float4 bb = *(const float4*)(BIA + 16 * kg + 4 * q4);
+        if (kh != 0) bb = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { acc[g][4 * q4] = bb.x; acc[g][4 * q4 + 1] = bb.y; acc[g][4 * q4 + 2] = bb.z; acc[g][4 * q4 + 3] = bb.w; }
+      }
+    }
     // phase-B epilogue operands of the (single) pair this wave owns when NPG <= 2: requested at the start of the tile's last chunk
     constexpr int NEPI = SM > 0 ? NPG : 1;
     uint4 ea0[NEPI][2], er0[NEPI][2];
@@ -329,12 +387,9 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     const bool burst_next = SM > 0 && next_tile < p.ntiles && NS >= nch + 1;
     // One chunk step.  Xc (the slot being read) and the ring (DMA destinations: always OTHER slots) are __restrict__ parameters
     // of ONE body: that is what lets hipcc keep a DMA in flight under the fragment reads.
-    auto step = [&](const char* __restrict__ Xc, char* __restrict__ ring, const h16x8 (&Ac)[9], auto& An, const int j) {
+    auto step = [&](const char* __restrict__ Xc, char* __restrict__ ring, h16x8 (&Ac)[9], auto& An, const int j, const int slot2) {
       if constexpr (SM == 0) {
-        if (j + 1 < nch) {
-          dma_chunk(ring + ((j + 1) & 1) * B3_XBYTES, n, y0, x0, j + 1);
-          load_A(An, j + 1);
-        }
+        if (j + 2 < nch) dma_chunk(ring + slot2 * B3_XBYTES, n, y0, x0, vb, j + 2);  // (slot of chunk j - 1: everyone is through the barrier behind it)
       } else if (j == nch - 1) {
         if (early_epi) {
           const B3Out& O = p.o[0];
@@ -356,24 +411,32 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
         if (burst_next) {  // the whole next tile, into the slots behind this tile's
           int n2, y2, x2;
           tile_of(next_tile, n2, y2, x2);
-          for (int k = 0; k < nch; ++k) dma_chunk(ring + ((sbase + nch + k) % NS) * B3_XBYTES, n2, y2, x2, k);
+          const int vb2 = tile_valid(y2, x2);
+          for (int k = 0; k < nch; ++k) dma_chunk(ring + ((sbase + nch + k) % NS) * B3_XBYTES, n2, y2, x2, vb2, k);
           if constexpr (!PRE) dma_mask(ring + p.tm_off + (tmsel ^ 1) * p.tm_bytes, n2, y2, x2);
         }
       }
       if (j == nch - 1) B3_STAMP(7);
       b3_chunk<PRE>(Xc, Ac, pbA, acc);
+      if constexpr (SM == 0) {
+        if (j + 2 < nch) load_A_counted(Ac, j + 2);  // into the registers this chunk has just finished with
+      }
     };
     // chunk boundary: everything requested so far has landed (own loads + own DMA pieces), fragments laundered, everyone through
     auto boundary = [&](const int jj, auto& Acur) {
       if (SM > 0 && jj == issued) {  // ring exhausted (more chunks than slots): the next burst, once everyone has left the slots
         B3_BARRIER();
         const int cnt = min(nch - jj, NS);
-        for (int k = 0; k < cnt; ++k) dma_chunk(lw + ((sbase + jj + k) % NS) * B3_XBYTES, n, y0, x0, jj + k);
+        for (int k = 0; k < cnt; ++k) dma_chunk(lw + ((sbase + jj + k) % NS) * B3_XBYTES, n, y0, x0, vb, jj + k);
         issued += cnt;
       }
       // a prefetched tile's chunks landed before the previous tile ended (the wait in front of its epilogue); the backward pass
       // still waits for its mask loads at the last boundary
-      if (SM == 0 || !prefetched) B3_VMWAIT();
+      if constexpr (SM == 0) {
+        if (jj + 1 < nch) B3_VMWAIT_N(14); else B3_VMWAIT();
+      } else if (!prefetched) {
+        B3_VMWAIT();
+      }
       if constexpr (!persistA) {
 #pragma unroll
         for (int s = 0; s < 9; ++s) b3_pin(Acur[s]);
@@ -387,13 +450,17 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
       B3_BARRIER();
       if (jj == 0) B3_STAMP(1);
     };
+    int sl = 0;  // (SM == 0) ring slot of chunk j
+    auto nxt = [&](const int v) { return v + 1 == NS ? 0 : v + 1; };
     for (int j = 0; j < nch; j += 2) {
       boundary(j, A0);
-      step(lr + (SM == 0 ? 0 : (sbase + j) % NS) * B3_XBYTES, lw, A0, A1, j);
+      step(lr + (SM == 0 ? sl : (sbase + j) % NS) * B3_XBYTES, lw, A0, A1, j, nxt(nxt(sl)));
+      sl = nxt(sl);
       if constexpr (SM != 1) {
         if (j + 1 < nch) {
           boundary(j + 1, A1);
-          step(lr + (SM == 0 ? 1 : (sbase + j + 1) % NS) * B3_XBYTES, lw, A1, A0, j + 1);
+          step(lr + (SM == 0 ? sl : (sbase + j + 1) % NS) * B3_XBYTES, lw, A1, A0, j + 1, nxt(nxt(sl)));
+          sl = nxt(sl);
         }
       }
     }
@@ -407,9 +474,11 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     // its last chunk and the one before it (everyone is past the last chunk; the slots BEHIND belong to the next tile's burst).
     // A one-chunk tile has a single slot: the second wave's half sits in a region of its own behind the bottleneck tile.
     B3_BARRIER();
-    char* const scr = lr + (SM == 0 ? ((nch - 1) & 1) : (sbase + nch - 1) % NS) * B3_XBYTES;
+    // (SM == 0: sl is one past the last chunk's slot; nothing is in flight here, the last boundary drained the queue)
+    const int sl_last = SM == 0 ? (sl == 0 ? NS - 1 : sl - 1) : 0, sl_prev = SM == 0 ? (sl_last == 0 ? NS - 1 : sl_last - 1) : 0;
+    char* const scr = lr + (SM == 0 ? sl_last : (sbase + nch - 1) % NS) * B3_XBYTES;
     // (streaming modes: the slot before the last chunk's already belongs to the next tile's burst -- a region of its own as well)
-    char* const scr2 = (SM == 0 && nch >= 2) ? lr + (nch & 1) * B3_XBYTES : lr + p.scratch_off;
+    char* const scr2 = (SM == 0 && nch >= 2) ? lr + sl_prev * B3_XBYTES : lr + p.scratch_off;
     char* const sx = gp == 0 ? scr : scr2;  // this wave pair's 12 KiB
     auto send = [&](const int g, auto Q) {  // the 8 accumulator rows of half Q of group g -> the partner
       constexpr int q8 = decltype(Q)::value;
@@ -690,7 +759,7 @@ static B3Launch b3_plan(B3P& p) {
   p.wb_persist = (p.nout == 1 && nb <= 2 && p.nch <= 2 && ((L.npg == 1 && npb == 1) || (L.npg == 2 && npb == 2))) ? 1 : 0;
   static const int no_sm = [] { const char* e = getenv("CGEN_BLK3_NOSM"); return e ? atoi(e) : 0; }();
   L.sm = (p.wb_persist && !no_sm) ? p.nch : 0;
-  if (L.sm == 0) { ns = 2; p.ns = 2; p.scratch_off = extra ? ns * B3_XBYTES + mid_bytes : 0; }
+  if (L.sm == 0) { ns = p.nch >= 3 ? 3 : 2; p.ns = ns; p.scratch_off = extra ? ns * B3_XBYTES + mid_bytes : 0; }  // two chunks ahead (<= 73 KB with a 32-wide bottleneck)
   p.bias_off = ns * B3_XBYTES + mid_bytes + extra;
   p.tm_off = p.bias_off + 128 + p.o[0].npb * 128;
   p.tm_bytes = (L.sm > 0 && p.mid_aux.p) ? (3 * nb * 1024) : 0;  // whole DMA instructions (>= 180 pixels x b x 2 bytes)
