@@ -69,7 +69,7 @@ struct B3P {
   BV3 seg[3];
   int seg_koff[4];  // first CHUNK of segment s (segments are padded to whole 32-channel chunks); [nseg] = nch
   int seg_c8[3];
-  const char* wA;   // phase-A fragment image [chunk][K16-step 0..17][lane][8]
+  const char* wA;   // phase-A fragment image [chunk][channel half 0..1][tap 0..8][lane][8]
   const float* biasA;
   BV3 mid, mid_aux;  // mid: written (interior pixels): forward t (pre-activation), backward g_t; mid_aux: backward mask source t
   B3Out o[2];
@@ -110,8 +110,9 @@ __device__ __forceinline__ uint4 b3_pack8(const float* v) {
 __device__ __forceinline__ void b3_dma16(const char* src, const uint32_t lds) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(lds) : "memory");
 }
+template <int OFF>
 __device__ __forceinline__ void b3_gload(h16x8& d, const char* sbase, const int voff) {
-  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 
 // the 9 K16-steps (one per tap) of one 32-channel chunk that this wave owns: K half kh = channels 16 kh .. + 16 of the chunk (folded
@@ -265,15 +266,18 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     }
   };
   auto load_A = [&](h16x8 (&An)[9], const int j) {  // the 9 weight fragments (this wave's K half) of chunk j
-    const char* wa = p.wA + (size_t)(j * 18 + kh) * 1024 + lane * 16;  // K16-step kk = 2 tap + channel half
+    const char* wa = p.wA + (size_t)(j * 18 + kh * 9) * 1024 + lane * 16;
 #pragma unroll
-    for (int s = 0; s < 9; ++s) An[s] = *(const h16x8*)(wa + s * 2048);
+    for (int s = 0; s < 9; ++s) An[s] = *(const h16x8*)(wa + s * 1024);
   };
   // (SM == 0) the same fragments by untracked loads: a chunk's DMA stays in flight under the wait for the previous chunk's weights
+  // (immediate offsets up to 3 KiB: three scalar bases per call instead of nine)
   auto load_A_counted = [&](h16x8 (&An)[9], const int j) {
-    const char* wa = p.wA + (size_t)(j * 18 + kh) * 1024;
-#pragma unroll
-    for (int s = 0; s < 9; ++s) b3_gload(An[s], wa + s * 2048, lane * 16);
+    const char* wa = p.wA + (size_t)(j * 18 + kh * 9) * 1024;
+    const int vo = lane * 16;
+    b3_gload<0>(An[0], wa, vo); b3_gload<1024>(An[1], wa, vo); b3_gload<2048>(An[2], wa, vo); b3_gload<3072>(An[3], wa, vo);
+    b3_gload<0>(An[4], wa + 4096, vo); b3_gload<1024>(An[5], wa + 4096, vo); b3_gload<2048>(An[6], wa + 4096, vo); b3_gload<3072>(An[7], wa + 4096, vo);
+    b3_gload<0>(An[8], wa + 8192, vo);
   };
   h16x8 A0[9], A1[SM == 1 ? 1 : 9], wbp[SM > 0 ? RD : 1];  // (wbp: the persistent phase-B weights of SM > 0)
   if constexpr (SM > 0) {
@@ -297,14 +301,31 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     }
   }
 
-  // biases -> LDS, once (a per-tile global load of them costs an L2 round trip on the critical path of every tile and, worse, its
-  // use makes hipcc drain every DMA in flight)
-  {
-    float* const BIA = (float*)(smem + p.bias_off);
-    if (tid < 32) BIA[tid] = (p.biasA != nullptr && tid < bch) ? p.biasA[tid] : 0.f;
-    const int nb0 = p.o[0].npb * 32;
-    for (int i = tid; i < nb0; i += 256) BIA[32 + i] = (p.o[0].bias != nullptr && i < p.o[0].Co) ? p.o[0].bias[i] : 0.f;
-    __syncthreads();
+  // biases -> LDS, once, by ONE LDS-DMA instruction of wave 0 (lanes 0-7: the bottleneck's 32 floats, lanes 8..: output 0's, zeros
+  // elsewhere): the oldest request of the launch, covered by the first chunk's wait + barrier -- no register round trip, no
+  // __syncthreads in the prologue
+  if (wave == 0) {
+    const int i4 = 4 * (lane - 8);
+    const char* src = zero;
+    if (lane < 8) { if (p.biasA != nullptr && 4 * lane < bch) src = (const char*)(p.biasA + 4 * lane); }
+    else if (p.o[0].bias != nullptr && i4 < p.o[0].Co) src = (const char*)(p.o[0].bias + i4);
+    b3_dma16(src, (uint32_t)(uintptr_t)(lds_ptr)(smem + p.bias_off));
+  }
+  // ---- (SM == 0) the halo requests of a tile's first two chunks: those of the FIRST tile go out here, before anything else of the
+  // launch (the rest of the prologue -- a few hundred scalar instructions -- runs under their latency; they hold no registers),
+  // those of a later tile at the end of the tile before it.  The register loads follow at the top of the tile.  Request order per
+  // wave: dma 0, dma 1 (5 instructions each) | [mask loads (backward)] A 0, A 1 (9 loads each) | dma j+2, A j+2 at chunk j | ...
+  // => in front of chunk 0 only A 1 may still be in flight (vmcnt(9)), in front of chunk j >= 1 dma j+1 and A j+1 (vmcnt(14))
+  constexpr bool QSPLIT = NB >= 2;
+  int tn = 0, ty0 = 0, tx0 = 0, tvb = 0;  // the tile whose first chunks are in flight
+  auto issue_tile = [&](char* ring, const int tile) {
+    tile_of(tile, tn, ty0, tx0);
+    tvb = tile_valid(ty0, tx0);
+    dma_chunk(ring, tn, ty0, tx0, tvb, 0);
+    if (nch > 1) dma_chunk(ring + B3_XBYTES, tn, ty0, tx0, tvb, 1);
+  };
+  if constexpr (SM == 0) {
+    if ((int)blockIdx.x < p.ntiles) issue_tile(smem, blockIdx.x);
   }
   if (stamp) stamp[1] = __builtin_readcyclecounter();
   // The tile loop sees LDS through TWO __restrict__ views of the same memory: `lw` is only ever the destination of LDS-DMA, `lr` is
@@ -319,20 +340,19 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   bool prefetched = false;  // this tile's chunks were requested during the previous tile
   int tmsel = 0;            // which mask buffer holds the current tile's (SM > 0, backward)
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
-    int n, y0, x0;
-    tile_of(tile, n, y0, x0);
-    if (stamp && nstamp == 2) stamp[238] = __builtin_readcyclecounter();
-    const int vb = tile_valid(y0, x0);
-    if (stamp && nstamp == 2) stamp[239] = __builtin_readcyclecounter();
+    int n, y0, x0, vb;
+    if constexpr (SM == 0) {
+      n = tn; y0 = ty0; x0 = tx0; vb = tvb;  // (requested by issue_tile: in the prologue, or at the end of the previous tile)
+    } else {
+      tile_of(tile, n, y0, x0);
+      vb = tile_valid(y0, x0);
+    }
     int issued = nch;
-    // mask source of the bottleneck gradient (backward, SM == 0): requested FIRST -- ordinary loads, the oldest of the tile, so no
-    // counted wait below has to know about them -- and consumed after phase A
     // (finalisation is shared by the two K halves: with a bottleneck of >= 16 channels wave kh finishes the 8-channel half q8 = kh of
     //  all three groups; with 8 channels -- only q8 = 0 exists -- K-half 0 finishes groups 0 and 1, K-half 1 group 2)
-    constexpr bool QSPLIT = NB >= 2;
-    uint4 tm[(PRE || SM > 0) ? 1 : 3];
     int mo[3];  // 1: this lane's bottleneck pixel is an interior pixel of the tile inside the image (stored to `mid`)
     bool min_img[3];
+    uint4 tm[(PRE || SM > 0) ? 1 : 3];  // mask source of the bottleneck gradient (backward, SM == 0): ordinary loads, consumed after phase A
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
       const int my = mpx[g] >> 8, mx = mpx[g] & 255;
@@ -348,36 +368,23 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
       }
     }
     if constexpr (SM == 0) {
-      // any number of chunks through a ring of NS = 2 (<= 2 chunks) or 3 slots, TWO chunks ahead: chunks 0 and 1 now, chunk j + 2 at
-      // the start of chunk j.  Request order per wave: dma 0 (5 instructions), A 0 (9 loads), dma 1, A 1 | dma j+2, A j+2 | ...
-      // => in front of chunk j exactly dma j+1 and A j+1 (14 requests) may still be in flight: s_waitcnt vmcnt(14)
-      if (stamp && nstamp == 2) stamp[240] = __builtin_readcyclecounter();
-      dma_chunk(lw, n, y0, x0, vb, 0);
-      if (stamp && nstamp == 2) stamp[241] = __builtin_readcyclecounter();
       load_A_counted(A0, 0);
-      if (stamp && nstamp == 2) stamp[242] = __builtin_readcyclecounter();
-      if (nch > 1) {
-        dma_chunk(lw + B3_XBYTES, n, y0, x0, vb, 1);
-        if (stamp && nstamp == 2) stamp[243] = __builtin_readcyclecounter();
-        load_A_counted(A1, 1);
-        if (stamp && nstamp == 2) stamp[244] = __builtin_readcyclecounter();
+      if (nch > 1) load_A_counted(A1, 1);
+    }
+    if constexpr (SM > 0) {
+      if (!prefetched) {
+        issued = min(nch, NS);
+        for (int k = 0; k < issued; ++k) dma_chunk(lw + ((sbase + k) % NS) * B3_XBYTES, n, y0, x0, vb, k);
+        if constexpr (!PRE) dma_mask(lw + p.tm_off + tmsel * p.tm_bytes, n, y0, x0);
       }
-    } else if (!prefetched) {
-      issued = min(nch, NS);
-      for (int k = 0; k < issued; ++k) dma_chunk(lw + ((sbase + k) % NS) * B3_XBYTES, n, y0, x0, vb, k);
-      if constexpr (!PRE) dma_mask(lw + p.tm_off + tmsel * p.tm_bytes, n, y0, x0);
     }
     B3_STAMP(0);
     // ------------------------------------------------------------------ phase A
     f32x16 acc[3];
-    {  // bias as the initial value (the K-half-0 waves; zeros elsewhere): channels 16 kg + i of this lane, from the LDS copy
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        float4 bb = *(const float4*)(BIA + 16 * kg + 4 * q4);
-        if (kh != 0) bb = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < 3; ++g) {
 #pragma unroll
-        for (int g = 0; g < 3; ++g) { acc[g][4 * q4] = bb.x; acc[g][4 * q4 + 1] = bb.y; acc[g][4 * q4 + 2] = bb.z; acc[g][4 * q4 + 3] = bb.w; }
-      }
+      for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;  // (the bias joins at the finalisation, from the LDS copy)
     }
     // phase-B epilogue operands of the (single) pair this wave owns when NPG <= 2: requested at the start of the tile's last chunk
     constexpr int NEPI = SM > 0 ? NPG : 1;
@@ -433,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
       // a prefetched tile's chunks landed before the previous tile ended (the wait in front of its epilogue); the backward pass
       // still waits for its mask loads at the last boundary
       if constexpr (SM == 0) {
-        if (jj + 1 < nch) B3_VMWAIT_N(14); else B3_VMWAIT();
+        if (jj + 1 >= nch) B3_VMWAIT(); else if (jj == 0) B3_VMWAIT_N(9); else B3_VMWAIT_N(14);
       } else if (!prefetched) {
         B3_VMWAIT();
       }
@@ -504,8 +511,9 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const float4 o = *(const float4*)(sx + (((1 - kh) * 3 + g) * 2 + h) * 1024 + lane * 16);
-        v[4 * h] = acc[g][8 * q8 + 4 * h] + o.x; v[4 * h + 1] = acc[g][8 * q8 + 4 * h + 1] + o.y;
-        v[4 * h + 2] = acc[g][8 * q8 + 4 * h + 2] + o.z; v[4 * h + 3] = acc[g][8 * q8 + 4 * h + 3] + o.w;
+        const float4 bb = *(const float4*)(BIA + ch + 4 * h);
+        v[4 * h] = (acc[g][8 * q8 + 4 * h] + o.x) + bb.x; v[4 * h + 1] = (acc[g][8 * q8 + 4 * h + 1] + o.y) + bb.y;
+        v[4 * h + 2] = (acc[g][8 * q8 + 4 * h + 2] + o.z) + bb.z; v[4 * h + 3] = (acc[g][8 * q8 + 4 * h + 3] + o.w) + bb.w;
       }
       const int my = mpx[g] >> 8, mx = mpx[g] & 255;
       const int iy = y0 - 1 + my, ix = x0 - 1 + mx;
@@ -669,6 +677,9 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
       }
     }
     // (the next tile's first barrier separates these reads of the bottleneck tile from its next writes)
+    if constexpr (SM == 0) {
+      if (tile + (int)gridDim.x < p.ntiles) issue_tile(lw, tile + gridDim.x);  // (every ring slot is free: the exchange through them ended before phase B)
+    }
     B3_STAMP(6);
     nstamp += 8;
     if (SM > 0 && burst_next) { sbase = (sbase + nch) % NS; prefetched = true; tmsel ^= 1; } else { prefetched = false; }
@@ -724,6 +735,7 @@ static int b3_fill(const cgen_block3_args* a, B3P& p) {
     d.w = (const char*)s.w; d.bias = s.bias; d.Co = s.out.c; d.npb = (s.out.c + 31) / 32;
     if (!b3_view(s.out, a->n, a->h, a->w, d.out) || !b3_view(s.aux, a->n, a->h, a->w, d.aux) || !b3_view(s.res1, a->n, a->h, a->w, d.res)) return 0;
     if ((s.aux.p && s.aux.c != s.out.c) || (s.res1.p && s.res1.c != s.out.c)) return 0;
+    if (o == 0 && s.out.c > 224) return 0;  // (lanes 8 .. 63 of the bias DMA instruction: 56 x 4 channels)
     if (o > 0 && s.bias) return 0;  // (only the first output's bias has an LDS copy: the forward pass has one output)
   }
   p.tiles_x = ceil_div(a->w, B3_TW); p.tiles_y = ceil_div(a->h, B3_TH);
@@ -747,6 +759,11 @@ static B3Launch b3_plan(B3P& p) {
   static const int per_cu = [] { const char* e = getenv("CGEN_BLK3_PER_CU"); return e ? atoi(e) : 2; }();
   const int slots_wg = 256 * per_cu;
   L.grid = p.ntiles < slots_wg ? p.ntiles : slots_wg;
+  {  // equal tile counts: 576 tiles on 512 slots are two rounds either way -- 288 workgroups of two tiles leave most CUs to one workgroup
+    static const int bal = [] { const char* e = getenv("CGEN_BLK3_BALANCE"); return e ? atoi(e) : 1; }();
+    const int per_wg = (p.ntiles + L.grid - 1) / L.grid;
+    if (bal) L.grid = (p.ntiles + per_wg - 1) / per_wg;
+  }
   const int budget = (p.ntiles <= 256 ? 150 : (per_cu >= 3 ? 52 : 78)) * 1024 - mid_bytes - extra - 2560 - (p.mid_aux.p ? 6 * nb * 1024 : 0);
   int want = p.nch + (p.ntiles > L.grid ? 1 : 0);
   static const int max_ns = [] { const char* e = getenv("CGEN_BLK3_MAXNS"); return e ? atoi(e) : 8; }();
@@ -761,7 +778,7 @@ static B3Launch b3_plan(B3P& p) {
   L.sm = (p.wb_persist && !no_sm) ? p.nch : 0;
   if (L.sm == 0) { ns = p.nch >= 3 ? 3 : 2; p.ns = ns; p.scratch_off = extra ? ns * B3_XBYTES + mid_bytes : 0; }  // two chunks ahead (<= 73 KB with a 32-wide bottleneck)
   p.bias_off = ns * B3_XBYTES + mid_bytes + extra;
-  p.tm_off = p.bias_off + 128 + p.o[0].npb * 128;
+  p.tm_off = p.bias_off + 1024;  // (the bias copy is one whole DMA instruction: 1 KiB)
   p.tm_bytes = (L.sm > 0 && p.mid_aux.p) ? (3 * nb * 1024) : 0;  // whole DMA instructions (>= 180 pixels x b x 2 bytes)
   L.lds = (size_t)p.tm_off + 2 * (size_t)p.tm_bytes;
   return L;

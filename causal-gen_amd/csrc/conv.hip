@@ -2460,8 +2460,8 @@ __global__ __launch_bounds__(256) void wprep_kernel(const cgen_wprep_desc* descs
       const int row = 16 * ((r32 >> 2) & 1) + (r32 & 3) + 4 * (r32 >> 3);  // channel (inside its 32-block) that fragment row r32 carries
       float v = 0.f;
       if (d.mode <= 3) {  // phase A: frag = chunk * 18 + kk
-        const int j = frag / 18, kk = frag - j * 18, tap = kk >> 1;
-        const int kc = 32 * j + 16 * (kk & 1) + 8 * kg + e;  // position on the concatenated input axis (segments in whole chunks)
+        const int j = frag / 18, kk = frag - j * 18, half = kk >= 9 ? 1 : 0, tap = kk - 9 * half;  // (a wave's nine fragments are contiguous)
+        const int kc = 32 * j + 16 * half + 8 * kg + e;  // position on the concatenated input axis (segments in whole chunks)
         if (d.mode == 2) {
           if (row < d.co) {
             int cc = kc, off = 0, ci = -1;

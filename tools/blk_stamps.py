@@ -52,7 +52,6 @@ for key in [int(a) for a in sys.argv[1:]] or [192, 96, 48, 24]:
         for wv in (0, 3):
           t = tall[wv * 256:(wv + 1) * 256]
           print("res %d %s->%d->%d %s wave %d: prologue %d cycles, start offset vs wave 0 %d" % (R, segc, b, co, mode, wv, t[1] - t[0], t[0] - tall[0]))
-          print("      tile-0 detail (vs stamp 1): " + " ".join("%d" % (t[i] - t[1]) for i in range(238, 245)))
           k, prev_end = 2, t[1]
           while k + 6 < 256 and t[k] > 0:
               row = t[k:k + 8]
