@@ -33,13 +33,15 @@ typedef short s16x2v __attribute__((ext_vector_type(2)));
 
 __device__ uint4 g_b3zero[4];  // 64 bytes of zeros: source of out-of-image / padding loads
 
-#define B3_TH 8
+// Tile: TH x 16 output pixels, TH = 8 (any instance) or 12 (the wide-output instances: 576 eight-row tiles of a 48x48 batch of 32
+// are two rounds on the 512 resident workgroups, 384 twelve-row tiles are one)
 #define B3_TW 16
-#define B3_HW 20                    // halo tile: 12 x 20 pixels
-#define B3_MW 18                    // bottleneck tile: 10 x 18 pixels
-#define B3_NMP 180
+#define B3_HW 20                    // halo tile: (TH + 4) x 20 pixels
+#define B3_MW 18                    // bottleneck tile: (TH + 2) x 18 pixels
 #define B3_XS 80                    // bytes per halo pixel in LDS: 4 channel groups of 16 B + one pad group (odd stride)
-#define B3_XBYTES (240 * B3_XS + 64)  // one ring slot: 19 200 B + the overhang of the last DMA instruction (lanes 60-63)
+constexpr int b3_ndi(int th) { return ((th + 4) * B3_HW + 47) / 48; }            // LDS-DMA instructions per wave and chunk (12 halo pixels each): 5 / 7
+constexpr int b3_xbytes(int th) { return 4 * b3_ndi(th) * 12 * B3_XS + 64; }     // one ring slot (whole instructions + the overhang of the last one): 19 264 / 26 944
+constexpr int b3_nmp(int th) { return (th + 2) * B3_MW; }                         // bottleneck pixels: 180 / 252
 
 struct B3Div { uint32_t mul, shift; };
 static inline B3Div b3_mkdiv(uint32_t d) {
@@ -117,20 +119,20 @@ __device__ __forceinline__ void b3_gload(h16x8& d, const char* sbase, const int 
 
 // the 9 K16-steps (one per tap) of one 32-channel chunk that this wave owns: K half kh = channels 16 kh .. + 16 of the chunk (folded
 // into pbA), fragment reads issued one step ahead of the MFMAs that consume them
-template <bool PRE>
-__device__ __forceinline__ void b3_chunk(const char* __restrict__ Xc, const h16x8 (&Ac)[9], const int (&pbA)[3], f32x16 (&acc)[3]) {
-  h16x8 bq[2][3];
+template <bool PRE, int NG>
+__device__ __forceinline__ void b3_chunk(const char* __restrict__ Xc, const h16x8 (&Ac)[9], const int (&pbA)[NG], f32x16 (&acc)[NG]) {
+  h16x8 bq[2][NG];
 #pragma unroll
-  for (int g = 0; g < 3; ++g) bq[0][g] = *(const h16x8*)(Xc + pbA[g]);
+  for (int g = 0; g < NG; ++g) bq[0][g] = *(const h16x8*)(Xc + pbA[g]);
 #pragma unroll
   for (int s = 0; s < 9; ++s) {
     if (s + 1 < 9) {
       const int imm = (((s + 1) / 3) * B3_HW + (s + 1) % 3) * B3_XS;
 #pragma unroll
-      for (int g = 0; g < 3; ++g) bq[(s + 1) & 1][g] = *(const h16x8*)(Xc + pbA[g] + imm);
+      for (int g = 0; g < NG; ++g) bq[(s + 1) & 1][g] = *(const h16x8*)(Xc + pbA[g] + imm);
     }
 #pragma unroll
-    for (int g = 0; g < 3; ++g) acc[g] = b3_mfma(Ac[s], PRE ? b3_relu8(bq[s & 1][g]) : bq[s & 1][g], acc[g]);
+    for (int g = 0; g < NG; ++g) acc[g] = b3_mfma(Ac[s], PRE ? b3_relu8(bq[s & 1][g]) : bq[s & 1][g], acc[g]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -145,15 +147,19 @@ __device__ __forceinline__ void b3_chunk(const char* __restrict__ Xc, const h16x
 // first use of an ordinary load's result, so ordinary loads are kept out of the spans a burst should survive: weights are
 // PERSISTENT in registers where a tile needs <= 2 chunks / the wave's output pair never changes (loaded once per launch), the
 // epilogue operands are requested BEFORE the next tile's burst and consumed at the very end of the tile.
-template <bool PRE, int NB, int NPG, int SM>
+template <bool PRE, int NB, int NPG, int SM, int TH>
 __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
+  constexpr int NMP = b3_nmp(TH), XB = b3_xbytes(TH), NDI = b3_ndi(TH);
+  constexpr int NG = (NMP + 63) / 64;  // bottleneck pixel groups (of 32) per wave in phase A: 3 / 4
+  constexpr int PGW = (TH / 2) / (NPG == 4 ? 1 : (NPG == 2 ? 2 : 4));  // output pixel groups a wave owns in phase B
+  static_assert((TH / 2) % (NPG == 4 ? 1 : (NPG == 2 ? 2 : 4)) == 0, "tile height and phase-B wave split");
   __builtin_amdgcn_s_setprio(3);
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
   constexpr int NBS = (NB & 1) ? NB : NB + 1;  // bottleneck pixel stride in 16-byte groups (odd)
   constexpr int MS = NBS * 16;
   constexpr int MAXKB = (9 * NB + 1) / 2;      // K16-steps of phase B (= ceil(9 b / 16))
-  constexpr int GP = NPG == 4 ? 2 : NPG;  // pixel groups per pass of phase B (four groups = two passes over the pair's weights: half the registers)
+  constexpr int GP = PGW == 1 ? 1 : (PGW == 3 ? 3 : 2);  // pixel groups per pass of phase B (four groups = two passes over the pair's weights: half the registers)
   constexpr int RD = (SM > 0 || NPG == 1) ? MAXKB : (MAXKB < 8 ? MAXKB : 8);  // phase-B weight ring depth (SM > 0: all of them, persistent)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NS = p.ns;
@@ -172,47 +178,49 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   constexpr bool persistA = SM > 0, persistB = SM == 1;  // (SM == 2: 72 registers of phase-A weights already; the phase-B ones are re-requested per tile, under the exchange)
 
   // ---- phase-A lane constants: this lane's bottleneck pixel of group g (3 groups of 32 per wave; 6 x 32 = 192 >= 180)
-  int pbA[3], mpx[3];
+  int pbA[NG], mpx[NG];
 #pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    const int m = 32 * (gp * 3 + g) + px;
-    const int mc = min(m, B3_NMP - 1);
-    const int my = (mc * 57) >> 10, mx = mc - my * B3_MW;  // (exact for mc < 180)
+  for (int g = 0; g < NG; ++g) {
+    const int m = 32 * (gp * NG + g) + px;
+    const int mc = min(m, NMP - 1);
+    const int my = (mc * 57) >> 10, mx = mc - my * B3_MW;  // (mc / 18, exact for mc < 252)
     pbA[g] = (my * B3_HW + mx) * B3_XS + kh * 32 + kg * 16;
-    mpx[g] = m < B3_NMP ? (my << 8 | mx) : -1;
+    mpx[g] = m < NMP ? (my << 8 | mx) : -1;
   }
   // ---- DMA lane constants: a wave instruction fills 12 halo pixels x 5 groups; wave w issues instructions w, w + 4, ... of the 20
   // per chunk.  Every lane is active (no exec branches): group 4 is the padding slot (zeros), lanes 60-63 re-write the first four
   // groups of the NEXT instruction's first pixel with the same bytes (the last instruction's overhang lands behind the slot)
   const int dpl = lane / 5, dq = lane - 5 * dpl;
-  // halo pixel (hy, hx) of this lane in the wave's i-th instruction, 9 bits each (hy << 5 | hx), i = 0..2 in hq0, 3..4 in hq1;
+  // halo pixel (hy, hx) of this lane in the wave's i-th instruction, 10 bits each (hy << 5 | hx), three per register;
   // lmask bit i: a real pixel and a real channel group
-  uint32_t hq0 = 0, hq1 = 0;
+  uint32_t hq[(NDI + 2) / 3];
   int lmask = 0;
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
+  for (int i = 0; i < (NDI + 2) / 3; ++i) hq[i] = 0;
+#pragma unroll
+  for (int i = 0; i < NDI; ++i) {
     const int pi = 12 * (wave + 4 * i) + dpl;
-    const int hy = (pi * 3277) >> 16, hx = pi - hy * B3_HW;  // (pi / 20, exact for pi < 252)
-    if (i < 3) hq0 |= (uint32_t)(hy << 5 | hx) << (9 * i); else hq1 |= (uint32_t)(hy << 5 | hx) << (9 * (i - 3));
-    if (dq < 4 && hy < 12) lmask |= 1 << i;
+    const int hy = (pi * 3277) >> 16, hx = pi - hy * B3_HW;  // (pi / 20, exact for pi < 340)
+    hq[i / 3] |= (uint32_t)(hy << 5 | hx) << (10 * (i % 3));
+    if (dq < 4 && hy < TH + 4) lmask |= 1 << i;
   }
-  auto hy_of = [&](const int i) { return (int)(((i < 3 ? hq0 : hq1) >> (9 * (i % 3) + 5)) & 15); };
-  auto hx_of = [&](const int i) { return (int)(((i < 3 ? hq0 : hq1) >> (9 * (i % 3))) & 31); };
+  auto hy_of = [&](const int i) { return (int)((hq[i / 3] >> (10 * (i % 3) + 5)) & 31); };
+  auto hx_of = [&](const int i) { return (int)((hq[i / 3] >> (10 * (i % 3))) & 31); };
   // ---- phase-B lane constants
   const int kgmask = kg ? -1 : 0;
   const int pbB = ((px >> 4) * B3_MW + (px & 15)) * MS;  // out pixel (2 pg + (px >> 4), px & 15) -> bottleneck tile offset (pg part is an immediate)
-  const int pg0 = NPG == 4 ? 0 : (NPG == 2 ? 2 * (wave >> 1) : wave);
+  const int pg0 = NPG == 4 ? 0 : (NPG == 2 ? PGW * (wave >> 1) : PGW * wave);
 
   auto tile_of = [&](const int tile, int& n, int& y0, int& x0) {
     const int b1 = b3_div(tile, p.d_tx), tx = tile - b1 * p.tiles_x;
     n = b3_div(b1, p.d_ty);
-    y0 = (b1 - n * p.tiles_y) * B3_TH; x0 = tx * B3_TW;
+    y0 = (b1 - n * p.tiles_y) * TH; x0 = tx * B3_TW;
   };
   // which of this lane's five halo pixels of tile (y0, x0) lie inside the image (once per tile, not per chunk)
   auto tile_valid = [&](const int y0, const int x0) {
     int vb = 0;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < NDI; ++i) {
       const int iy = y0 - 2 + hy_of(i), ix = x0 - 2 + hx_of(i);
       if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) vb |= 1 << i;
     }
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     const char* base = sp + (n * sn + (y0 - 2) * sh + (x0 - 2) * sw);
     const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr)Xn) + wave * (12 * B3_XS);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < NDI; ++i) {
       const uint32_t off = __umul24(hy_of(i), sh) + __umul24(hx_of(i), sw) + cs * 2;
       const char* src = ((vbc >> i) & 1) ? base + off : zero;
       b3_dma16(src, la + i * (4 * 12 * B3_XS));
@@ -252,14 +260,15 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   // the 3 NB covers 64 consecutive 16-byte groups; wave w issues i = w, w + 4
   auto dma_mask = [&](char* dst, const int n, const int y0, const int x0) {
     const uint32_t la = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr)dst);
+    constexpr int NMI = (NMP * NB + 63) / 64;  // whole instructions over the dense [pixel][NB groups] tile
 #pragma unroll
-    for (int ii = 0; ii < (3 * NB + 3) / 4; ++ii) {
+    for (int ii = 0; ii < (NMI + 3) / 4; ++ii) {
       const int i = wave + 4 * ii;
-      if (i < 3 * NB) {
+      if (i < NMI) {
         const int slot = 64 * i + lane, m = slot / NB, gq = slot - m * NB;
-        const int my = (min(m, B3_NMP - 1) * 57) >> 10, mx = min(m, B3_NMP - 1) - my * B3_MW;
+        const int my = (min(m, NMP - 1) * 57) >> 10, mx = min(m, NMP - 1) - my * B3_MW;
         const int iy = y0 - 1 + my, ix = x0 - 1 + mx;
-        const bool ok = m < B3_NMP && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const bool ok = m < NMP && iy >= 0 && iy < H && ix >= 0 && ix < W;
         const char* src = ok ? p.mid_aux.p + (n * p.mid_aux.sn + iy * p.mid_aux.sh + ix * p.mid_aux.sw) + gq * 16 : zero;
         b3_dma16(src, la + i * 1024);
       }
@@ -317,12 +326,13 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   // wave: dma 0, dma 1 (5 instructions each) | [mask loads (backward)] A 0, A 1 (9 loads each) | dma j+2, A j+2 at chunk j | ...
   // => in front of chunk 0 only A 1 may still be in flight (vmcnt(9)), in front of chunk j >= 1 dma j+1 and A j+1 (vmcnt(14))
   constexpr bool QSPLIT = NB >= 2;
+  constexpr int GH = (NG + 1) / 2;  // (8-channel bottleneck: K-half 0 finishes groups 0 .. GH - 1, K-half 1 the rest)
   int tn = 0, ty0 = 0, tx0 = 0, tvb = 0;  // the tile whose first chunks are in flight
   auto issue_tile = [&](char* ring, const int tile) {
     tile_of(tile, tn, ty0, tx0);
     tvb = tile_valid(ty0, tx0);
     dma_chunk(ring, tn, ty0, tx0, tvb, 0);
-    if (nch > 1) dma_chunk(ring + B3_XBYTES, tn, ty0, tx0, tvb, 1);
+    if (nch > 1) dma_chunk(ring + XB, tn, ty0, tx0, tvb, 1);
   };
   if constexpr (SM == 0) {
     if ((int)blockIdx.x < p.ntiles) issue_tile(smem, blockIdx.x);
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   // it cannot prove disjoint from them -- with one view, the next tile's burst would be waited for at the first
   // fragment read after its request.  The ordering that matters is explicit: B3_VMWAIT + B3_BARRIER before a slot is read.
   auto run = [&](char* __restrict__ lr, char* __restrict__ lw) {
-  char* const MID = lr + NS * B3_XBYTES;
+  char* const MID = lr + NS * XB;
   const float* const BIA = (const float*)(lr + p.bias_off);
   char* const TMB = lr + p.tm_off;  // (SM > 0, backward) two buffers of the bottleneck mask tile, filled by DMA with the bursts
   int sbase = 0;            // ring slot of the current tile's chunk 0
@@ -350,18 +360,18 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     int issued = nch;
     // (finalisation is shared by the two K halves: with a bottleneck of >= 16 channels wave kh finishes the 8-channel half q8 = kh of
     //  all three groups; with 8 channels -- only q8 = 0 exists -- K-half 0 finishes groups 0 and 1, K-half 1 group 2)
-    int mo[3];  // 1: this lane's bottleneck pixel is an interior pixel of the tile inside the image (stored to `mid`)
-    bool min_img[3];
-    uint4 tm[(PRE || SM > 0) ? 1 : 3];  // mask source of the bottleneck gradient (backward, SM == 0): ordinary loads, consumed after phase A
+    int mo[NG];  // 1: this lane's bottleneck pixel is an interior pixel of the tile inside the image (stored to `mid`)
+    bool min_img[NG];
+    uint4 tm[(PRE || SM > 0) ? 1 : NG];  // mask source of the bottleneck gradient (backward, SM == 0): ordinary loads, consumed after phase A
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
+    for (int g = 0; g < NG; ++g) {
       const int my = mpx[g] >> 8, mx = mpx[g] & 255;
       const int iy = y0 - 1 + my, ix = x0 - 1 + mx;
       min_img[g] = mpx[g] >= 0 && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      mo[g] = (min_img[g] && my >= 1 && my <= B3_TH && mx >= 1 && mx <= B3_TW) ? 1 : 0;
+      mo[g] = (min_img[g] && my >= 1 && my <= TH && mx >= 1 && mx <= B3_TW) ? 1 : 0;
       if constexpr (!PRE && SM == 0) {
         const int ch = 16 * kg + (QSPLIT ? 8 * kh : 0);
-        const bool mine = QSPLIT || (kh == 0 ? g < 2 : g == 2);
+        const bool mine = QSPLIT || (kh == 0 ? g < GH : g >= GH);
         const bool ok = min_img[g] && mine && ch < bch;
         const char* src = ok ? p.mid_aux.p + (n * p.mid_aux.sn + iy * p.mid_aux.sh + ix * p.mid_aux.sw) + ch * 2 : zero;
         tm[g] = *(const uint4*)src;
@@ -374,20 +384,20 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     if constexpr (SM > 0) {
       if (!prefetched) {
         issued = min(nch, NS);
-        for (int k = 0; k < issued; ++k) dma_chunk(lw + ((sbase + k) % NS) * B3_XBYTES, n, y0, x0, vb, k);
+        for (int k = 0; k < issued; ++k) dma_chunk(lw + ((sbase + k) % NS) * XB, n, y0, x0, vb, k);
         if constexpr (!PRE) dma_mask(lw + p.tm_off + tmsel * p.tm_bytes, n, y0, x0);
       }
     }
     B3_STAMP(0);
     // ------------------------------------------------------------------ phase A
-    f32x16 acc[3];
+    f32x16 acc[NG];
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
+    for (int g = 0; g < NG; ++g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;  // (the bias joins at the finalisation, from the LDS copy)
     }
     // phase-B epilogue operands of the (single) pair this wave owns when NPG <= 2: requested at the start of the tile's last chunk
-    constexpr int NEPI = SM > 0 ? NPG : 1;
+    constexpr int NEPI = SM > 0 ? PGW : 1;
     uint4 ea0[NEPI][2], er0[NEPI][2];
     constexpr bool early_epi = SM > 0;  // (SM > 0: one output, the wave's pair is fixed -- checked by the host)
     const int next_tile = tile + gridDim.x;
@@ -396,7 +406,10 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     // of ONE body: that is what lets hipcc keep a DMA in flight under the fragment reads.
     auto step = [&](const char* __restrict__ Xc, char* __restrict__ ring, h16x8 (&Ac)[9], auto& An, const int j, const int slot2) {
       if constexpr (SM == 0) {
-        if (j + 2 < nch) dma_chunk(ring + slot2 * B3_XBYTES, n, y0, x0, vb, j + 2);  // (slot of chunk j - 1: everyone is through the barrier behind it)
+        // three slots: chunk j + 2 into the slot of chunk j - 1 (everyone is through the barrier behind it); two slots (the
+        // twelve-row tiles): chunk j + 1 into the slot of chunk j - 1, one chunk ahead
+        if (NS == 3) { if (j + 2 < nch) dma_chunk(ring + slot2 * XB, n, y0, x0, vb, j + 2); }
+        else if (j >= 1 && j + 1 < nch) dma_chunk(ring + slot2 * XB, n, y0, x0, vb, j + 1);
       } else if (j == nch - 1) {
         if (early_epi) {
           const B3Out& O = p.o[0];
@@ -419,12 +432,12 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
           int n2, y2, x2;
           tile_of(next_tile, n2, y2, x2);
           const int vb2 = tile_valid(y2, x2);
-          for (int k = 0; k < nch; ++k) dma_chunk(ring + ((sbase + nch + k) % NS) * B3_XBYTES, n2, y2, x2, vb2, k);
+          for (int k = 0; k < nch; ++k) dma_chunk(ring + ((sbase + nch + k) % NS) * XB, n2, y2, x2, vb2, k);
           if constexpr (!PRE) dma_mask(ring + p.tm_off + (tmsel ^ 1) * p.tm_bytes, n2, y2, x2);
         }
       }
       if (j == nch - 1) B3_STAMP(7);
-      b3_chunk<PRE>(Xc, Ac, pbA, acc);
+      b3_chunk<PRE, NG>(Xc, Ac, pbA, acc);
       if constexpr (SM == 0) {
         if (j + 2 < nch) load_A_counted(Ac, j + 2);  // into the registers this chunk has just finished with
       }
@@ -434,13 +447,13 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
       if (SM > 0 && jj == issued) {  // ring exhausted (more chunks than slots): the next burst, once everyone has left the slots
         B3_BARRIER();
         const int cnt = min(nch - jj, NS);
-        for (int k = 0; k < cnt; ++k) dma_chunk(lw + ((sbase + jj + k) % NS) * B3_XBYTES, n, y0, x0, vb, jj + k);
+        for (int k = 0; k < cnt; ++k) dma_chunk(lw + ((sbase + jj + k) % NS) * XB, n, y0, x0, vb, jj + k);
         issued += cnt;
       }
       // a prefetched tile's chunks landed before the previous tile ended (the wait in front of its epilogue); the backward pass
       // still waits for its mask loads at the last boundary
       if constexpr (SM == 0) {
-        if (jj + 1 >= nch) B3_VMWAIT(); else if (jj == 0) B3_VMWAIT_N(9); else B3_VMWAIT_N(14);
+        if (jj + 1 >= nch) B3_VMWAIT(); else if (jj == 0 || NS == 2) B3_VMWAIT_N(9); else if (NDI == 5) B3_VMWAIT_N(14); else B3_VMWAIT_N(16);
       } else if (!prefetched) {
         B3_VMWAIT();
       }
@@ -451,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
       if constexpr (!PRE && SM == 0) {
         if (jj == nch - 1) {
 #pragma unroll
-          for (int g = 0; g < 3; ++g) asm volatile("" : "+v"(tm[g].x), "+v"(tm[g].y), "+v"(tm[g].z), "+v"(tm[g].w));
+          for (int g = 0; g < NG; ++g) asm volatile("" : "+v"(tm[g].x), "+v"(tm[g].y), "+v"(tm[g].z), "+v"(tm[g].w));
         }
       }
       B3_BARRIER();
@@ -461,12 +474,12 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     auto nxt = [&](const int v) { return v + 1 == NS ? 0 : v + 1; };
     for (int j = 0; j < nch; j += 2) {
       boundary(j, A0);
-      step(lr + (SM == 0 ? sl : (sbase + j) % NS) * B3_XBYTES, lw, A0, A1, j, nxt(nxt(sl)));
+      step(lr + (SM == 0 ? sl : (sbase + j) % NS) * XB, lw, A0, A1, j, NS == 3 ? nxt(nxt(sl)) : nxt(sl));
       sl = nxt(sl);
       if constexpr (SM != 1) {
         if (j + 1 < nch) {
           boundary(j + 1, A1);
-          step(lr + (SM == 0 ? sl : (sbase + j + 1) % NS) * B3_XBYTES, lw, A1, A0, j + 1, nxt(nxt(sl)));
+          step(lr + (SM == 0 ? sl : (sbase + j + 1) % NS) * XB, lw, A1, A0, j + 1, NS == 3 ? nxt(nxt(sl)) : nxt(sl));
           sl = nxt(sl);
         }
       }
@@ -483,23 +496,23 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     B3_BARRIER();
     // (SM == 0: sl is one past the last chunk's slot; nothing is in flight here, the last boundary drained the queue)
     const int sl_last = SM == 0 ? (sl == 0 ? NS - 1 : sl - 1) : 0, sl_prev = SM == 0 ? (sl_last == 0 ? NS - 1 : sl_last - 1) : 0;
-    char* const scr = lr + (SM == 0 ? sl_last : (sbase + nch - 1) % NS) * B3_XBYTES;
+    char* const scr = lr + (SM == 0 ? sl_last : (sbase + nch - 1) % NS) * XB;
     // (streaming modes: the slot before the last chunk's already belongs to the next tile's burst -- a region of its own as well)
-    char* const scr2 = (SM == 0 && nch >= 2) ? lr + sl_prev * B3_XBYTES : lr + p.scratch_off;
+    char* const scr2 = (SM == 0 && nch >= 2) ? lr + sl_prev * XB : lr + p.scratch_off;
     char* const sx = gp == 0 ? scr : scr2;  // this wave pair's 12 KiB
     auto send = [&](const int g, auto Q) {  // the 8 accumulator rows of half Q of group g -> the partner
       constexpr int q8 = decltype(Q)::value;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
-        *(float4*)(sx + ((kh * 3 + g) * 2 + h) * 1024 + lane * 16) =
+        *(float4*)(sx + ((kh * NG + g) * 2 + h) * 1024 + lane * 16) =
             make_float4(acc[g][8 * q8 + 4 * h], acc[g][8 * q8 + 4 * h + 1], acc[g][8 * q8 + 4 * h + 2], acc[g][8 * q8 + 4 * h + 3]);
     };
     const std::integral_constant<int, 0> q0;
     const std::integral_constant<int, 1> q1;
-    if constexpr (QSPLIT) {
-      if (kh == 0) { send(0, q1); send(1, q1); send(2, q1); } else { send(0, q0); send(1, q0); send(2, q0); }
-    } else {
-      if (kh == 0) send(2, q0); else { send(0, q0); send(1, q0); }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if constexpr (QSPLIT) { if (kh == 0) send(g, q1); else send(g, q0); }
+      else if ((kh == 0) == (g >= GH)) send(g, q0);  // (the half that does NOT finish group g hands it over)
     }
     B3_BARRIER();
     B3_STAMP(3);
@@ -510,7 +523,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
       float v[8];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const float4 o = *(const float4*)(sx + (((1 - kh) * 3 + g) * 2 + h) * 1024 + lane * 16);
+        const float4 o = *(const float4*)(sx + (((1 - kh) * NG + g) * 2 + h) * 1024 + lane * 16);
         const float4 bb = *(const float4*)(BIA + ch + 4 * h);
         v[4 * h] = (acc[g][8 * q8 + 4 * h] + o.x) + bb.x; v[4 * h + 1] = (acc[g][8 * q8 + 4 * h + 1] + o.y) + bb.y;
         v[4 * h + 2] = (acc[g][8 * q8 + 4 * h + 2] + o.z) + bb.z; v[4 * h + 3] = (acc[g][8 * q8 + 4 * h + 3] + o.w) + bb.w;
@@ -540,10 +553,10 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
         *(uint4*)ldst = min_img[g] ? r.q : make_uint4(0, 0, 0, 0);
       }
     };
-    if constexpr (QSPLIT) {
-      if (kh == 0) { finish(0, q0); finish(1, q0); finish(2, q0); } else { finish(0, q1); finish(1, q1); finish(2, q1); }
-    } else {
-      if (kh == 0) { finish(0, q0); finish(1, q0); } else finish(2, q0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if constexpr (QSPLIT) { if (kh == 0) finish(g, q0); else finish(g, q1); }
+      else if ((kh == 0) == (g < GH)) finish(g, q0);
     }
     B3_BARRIER();
     B3_STAMP(4);
@@ -570,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
         const int ch0 = pair * 32 + 16 * kg;
         const bool has_aux = Oaux != nullptr, has_res = Ores != nullptr;
 #pragma unroll 1
-        for (int pass = 0; pass < NPG / GP; ++pass) {
+        for (int pass = 0; pass < PGW / GP; ++pass) {
           const int pgb = pg0 + pass * GP;
           h16x8 wbl[SM > 0 ? 1 : RD];
           auto& wb = *[&]() { if constexpr (SM > 0) return &wbp; else return &wbl; }();
@@ -697,11 +710,17 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
 static bool b3_view(const cgen_view& v, int n, int h, int w, BV3& o) {
   o.p = (const char*)v.p; o.sn = o.sh = o.sw = 0;
   if (!v.p) return true;
-  const int64_t ext = ((int64_t)n * v.sn + (int64_t)(h + B3_TH + 4) * v.sh + (int64_t)(w + B3_TW + 4) * v.sw + v.c + 64) * 2;
+  const int64_t ext = ((int64_t)n * v.sn + (int64_t)(h + 12 + 4) * v.sh + (int64_t)(w + B3_TW + 4) * v.sw + v.c + 64) * 2;
   if (ext >= ((int64_t)1 << 31) || v.sn < 0 || v.sh < 0 || v.sw < 0) return false;
   if (((uintptr_t)v.p % 16) || (v.sn * 2) % 16 || (v.sh * 2) % 16 || (v.sw * 2) % 16) return false;
   o.sn = (int)(v.sn * 2); o.sh = (int)(v.sh * 2); o.sw = (int)(v.sw * 2);
   return true;
+}
+
+static void b3_tiles(B3P& p, int th) {
+  p.tiles_x = ceil_div(p.W, B3_TW); p.tiles_y = ceil_div(p.H, th);
+  p.ntiles = p.N * p.tiles_x * p.tiles_y;
+  p.d_tx = b3_mkdiv(p.tiles_x); p.d_ty = b3_mkdiv(p.tiles_y);
 }
 
 static int b3_fill(const cgen_block3_args* a, B3P& p) {
@@ -738,14 +757,12 @@ static int b3_fill(const cgen_block3_args* a, B3P& p) {
     if (o == 0 && s.out.c > 224) return 0;  // (lanes 8 .. 63 of the bias DMA instruction: 56 x 4 channels)
     if (o > 0 && s.bias) return 0;  // (only the first output's bias has an LDS copy: the forward pass has one output)
   }
-  p.tiles_x = ceil_div(a->w, B3_TW); p.tiles_y = ceil_div(a->h, B3_TH);
-  p.ntiles = a->n * p.tiles_x * p.tiles_y;
-  p.d_tx = b3_mkdiv(p.tiles_x); p.d_ty = b3_mkdiv(p.tiles_y);
+  b3_tiles(p, 8);
   { const char* e = getenv("CGEN_BLK3_STAMPS"); p.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
   return 1;
 }
 
-struct B3Launch { int npg, grid, sm; size_t lds; };
+struct B3Launch { int npg, grid, sm, th; size_t lds; };
 // Ring depth, persistence and LDS size.  Two workgroups per CU (78 KB each) unless the launch has at most one tile per CU, which
 // may take a whole CU's LDS; a ring one slot deeper than a tile needs lets the next tile's burst travel under this tile's work.
 static B3Launch b3_plan(B3P& p) {
@@ -754,41 +771,53 @@ static B3Launch b3_plan(B3P& p) {
   for (int o = 0; o < p.nout; ++o) npb = p.o[o].npb > npb ? p.o[o].npb : npb;
   L.npg = npb == 1 ? 1 : (npb == 2 ? 2 : 4);  // the wave split of phase B follows the WIDEST output
   const int nb = p.b / 8, nbs = (nb & 1) ? nb : nb + 1;
-  const int mid_bytes = B3_NMP * nbs * 16;
-  const int extra = p.nch <= 2 ? 12288 : 0;  // second half of the partial-sum exchange (one-chunk tiles, and every streaming launch)
   static const int per_cu = [] { const char* e = getenv("CGEN_BLK3_PER_CU"); return e ? atoi(e) : 2; }();
   const int slots_wg = 256 * per_cu;
-  L.grid = p.ntiles < slots_wg ? p.ntiles : slots_wg;
-  {  // equal tile counts: 576 tiles on 512 slots are two rounds either way -- 288 workgroups of two tiles leave most CUs to one workgroup
-    static const int bal = [] { const char* e = getenv("CGEN_BLK3_BALANCE"); return e ? atoi(e) : 1; }();
-    const int per_wg = (p.ntiles + L.grid - 1) / L.grid;
-    if (bal) L.grid = (p.ntiles + per_wg - 1) / per_wg;
-  }
-  const int budget = (p.ntiles <= 256 ? 150 : (per_cu >= 3 ? 52 : 78)) * 1024 - mid_bytes - extra - 2560 - (p.mid_aux.p ? 6 * nb * 1024 : 0);
-  int want = p.nch + (p.ntiles > L.grid ? 1 : 0);
-  static const int max_ns = [] { const char* e = getenv("CGEN_BLK3_MAXNS"); return e ? atoi(e) : 8; }();
-  int ns = budget / B3_XBYTES;
-  if (ns > want) ns = want;
-  if (ns > max_ns) ns = max_ns;
-  if (ns < 2) ns = 2;
-  p.ns = ns;
-  p.scratch_off = extra ? ns * B3_XBYTES + mid_bytes : 0;
   p.wb_persist = (p.nout == 1 && nb <= 2 && p.nch <= 2 && ((L.npg == 1 && npb == 1) || (L.npg == 2 && npb == 2))) ? 1 : 0;
   static const int no_sm = [] { const char* e = getenv("CGEN_BLK3_NOSM"); return e ? atoi(e) : 0; }();
   L.sm = (p.wb_persist && !no_sm) ? p.nch : 0;
-  if (L.sm == 0) { ns = p.nch >= 3 ? 3 : 2; p.ns = ns; p.scratch_off = extra ? ns * B3_XBYTES + mid_bytes : 0; }  // two chunks ahead (<= 73 KB with a 32-wide bottleneck)
-  p.bias_off = ns * B3_XBYTES + mid_bytes + extra;
+  // Tile height.  A launch is a whole number of rounds over the resident workgroups: twelve-row tiles where they save a round (48x48
+  // at batch 32: 576 tiles = two rounds of eight rows, 384 = one of twelve); they exist for the wide-output, any-chunk instances
+  L.th = 8;
+  static const int th_env = [] { const char* e = getenv("CGEN_BLK3_TH"); return e ? atoi(e) : 0; }();
+  if (L.npg == 4 && L.sm == 0 && th_env != 8) {
+    const int t8 = p.ntiles, t12 = p.N * p.tiles_x * ceil_div(p.H, 12);
+    const int r8 = ceil_div(t8, slots_wg), r12 = ceil_div(t12, slots_wg);
+    if (th_env == 12 || (r12 * 3 < r8 * 2 + (r8 > 1 ? 1 : 0) && t12 > 128)) L.th = 12;  // (1.5x the work per round: worth it when it removes a round)
+  }
+  if (L.th != 8) b3_tiles(p, L.th);
+  const int xb = b3_xbytes(L.th), nmp = b3_nmp(L.th);
+  const int mid_bytes = nmp * nbs * 16;
+  const int nmi = (nmp * nb + 63) / 64;  // DMA instructions of a mask tile
+  const int extra = p.nch <= 2 ? ((nmp + 63) / 64) * 4096 : 0;  // second half of the partial-sum exchange (one-chunk tiles, and every streaming launch): 4 KiB per pixel group
+  L.grid = p.ntiles < slots_wg ? p.ntiles : slots_wg;
+  const int cap = (p.ntiles <= 256 ? 150 : (per_cu >= 3 ? 52 : 78)) * 1024;
+  int ns;
+  if (L.sm == 0) {  // two chunks ahead where three slots fit next to a second workgroup (<= 73 KB with eight rows and a 32-wide bottleneck)
+    ns = (p.nch >= 3 && 3 * xb + mid_bytes + extra + 1024 <= cap) ? 3 : 2;
+  } else {
+    const int budget = cap - mid_bytes - extra - 2560 - (p.mid_aux.p ? 2 * nmi * 1024 : 0);
+    const int want = p.nch + (p.ntiles > L.grid ? 1 : 0);
+    static const int max_ns = [] { const char* e = getenv("CGEN_BLK3_MAXNS"); return e ? atoi(e) : 8; }();
+    ns = budget / xb;
+    if (ns > want) ns = want;
+    if (ns > max_ns) ns = max_ns;
+    if (ns < 2) ns = 2;
+  }
+  p.ns = ns;
+  p.scratch_off = extra ? ns * xb + mid_bytes : 0;
+  p.bias_off = ns * xb + mid_bytes + extra;
   p.tm_off = p.bias_off + 1024;  // (the bias copy is one whole DMA instruction: 1 KiB)
-  p.tm_bytes = (L.sm > 0 && p.mid_aux.p) ? (3 * nb * 1024) : 0;  // whole DMA instructions (>= 180 pixels x b x 2 bytes)
+  p.tm_bytes = (L.sm > 0 && p.mid_aux.p) ? (nmi * 1024) : 0;  // whole DMA instructions (>= 180 pixels x b x 2 bytes)
   L.lds = (size_t)p.tm_off + 2 * (size_t)p.tm_bytes;
   return L;
 }
 
-template <bool PRE, int NB, int NPG, int SM>
+template <bool PRE, int NB, int NPG, int SM, int TH = 8>
 static void b3_launch_inst(const B3P& p, const B3Launch& L, hipStream_t st) {
   static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)blk3_kernel<PRE, NB, NPG, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-  hipLaunchKernelGGL((blk3_kernel<PRE, NB, NPG, SM>), dim3(L.grid), dim3(256), L.lds, st, p);
+  if (!once) { (void)hipFuncSetAttribute((const void*)blk3_kernel<PRE, NB, NPG, SM, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  hipLaunchKernelGGL((blk3_kernel<PRE, NB, NPG, SM, TH>), dim3(L.grid), dim3(256), L.lds, st, p);
 }
 template <bool PRE, int NB>
 static void b3_launch_nb(const B3P& p, const B3Launch& L, hipStream_t st) {
@@ -800,6 +829,7 @@ static void b3_launch_nb(const B3P& p, const B3Launch& L, hipStream_t st) {
   }
   if (L.npg == 1) b3_launch_inst<PRE, NB, 1, 0>(p, L, st);
   else if (L.npg == 2) b3_launch_inst<PRE, NB, 2, 0>(p, L, st);
+  else if (L.th == 12) b3_launch_inst<PRE, NB, 4, 0, 12>(p, L, st);
   else b3_launch_inst<PRE, NB, 4, 0>(p, L, st);
 }
 template <bool PRE>
@@ -828,6 +858,6 @@ extern "C" int cgen_block3(const cgen_block3_args* a, cgen_stream_t stream) {
   const B3Launch L = b3_plan(p);
   if (a->pre_act) b3_launch_pre<true>(p, L, (hipStream_t)stream);
   else b3_launch_pre<false>(p, L, (hipStream_t)stream);
-  if (getenv("CGEN_CONV_TRACE")) fprintf(stderr, "blk3[%s] %dx%dx%d ctot8 %d b %d Co %d nseg %d nout %d | ring %d slots, lds %zu, grid %d, persist wb %d\n", a->mid_aux.p ? "bwd" : "fwd", a->n, a->h, a->w, p.ctot8, p.b, p.o[0].Co, a->nseg, a->nout, p.ns, L.lds, L.grid, p.wb_persist);
+  if (getenv("CGEN_CONV_TRACE")) fprintf(stderr, "blk3[%s] %dx%dx%d ctot8 %d b %d Co %d nseg %d nout %d | ring %d slots, lds %zu, grid %d, persist wb %d, tile rows %d\n", a->mid_aux.p ? "bwd" : "fwd", a->n, a->h, a->w, p.ctot8, p.b, p.o[0].Co, a->nseg, a->nout, p.ns, L.lds, L.grid, p.wb_persist, L.th);
   return check_launch("cgen_block3");
 }
