@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   constexpr int MS = NBS * 16;
   constexpr int MAXKB = (9 * NB + 1) / 2;      // K16-steps of phase B (= ceil(9 b / 16))
   constexpr int GP = PGW == 1 ? 1 : (PGW == 3 ? 3 : 2);  // pixel groups per pass of phase B (four groups = two passes over the pair's weights: half the registers)
-  constexpr int RD = (SM > 0 || NPG == 1) ? MAXKB : (MAXKB < 8 ? MAXKB : 8);  // phase-B weight ring depth (SM > 0: all of them, persistent)
+  constexpr int RD = MAXKB;  // phase-B weights of a wave's pair: all K16-steps in registers (the phase-A fragments are dead by then)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int NS = p.ns;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -576,21 +576,22 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
       for (int r = 0;; ++r) {
         const int pair = NPG == 4 ? wave + 4 * r : (NPG == 2 ? (wave & 1) + 2 * r : r);
         if (pair >= npb) break;
-        // weights of the pair stream through a register ring RD K16-steps deep (all of them where the pair's accumulators are
-        // few); the epilogue operands are requested BEHIND the last weight request (loads return in order: a weight fragment
-        // queued behind an HBM-cold residual would wait for it) and are in flight under the remaining MFMAs
+        // weights of the pair: all K16-steps in registers, for all passes over it (a ring refilled per pass read them once per
+        // pass, each refill one L2 round trip in front of its MFMA; the phase-A fragments are dead by now); the epilogue
+        // operands are requested behind them (loads return in order: a weight fragment queued behind an HBM-cold residual
+        // would wait for it) and are in flight under the MFMAs
         const char* wsrc = Ow + (size_t)pair * nks * 1024 + lane * 16;
+        h16x8 wfull[SM == 0 ? MAXKB : 1];
+        if constexpr (SM == 0) {
+#pragma unroll
+          for (int i = 0; i < MAXKB; ++i) wfull[i] = *(const h16x8*)(wsrc + i * 1024);
+        }
         const int ch0 = pair * 32 + 16 * kg;
         const bool has_aux = Oaux != nullptr, has_res = Ores != nullptr;
 #pragma unroll 1
         for (int pass = 0; pass < PGW / GP; ++pass) {
           const int pgb = pg0 + pass * GP;
-          h16x8 wbl[SM > 0 ? 1 : RD];
-          auto& wb = *[&]() { if constexpr (SM > 0) return &wbp; else return &wbl; }();
-          if constexpr (SM == 0) {
-#pragma unroll
-            for (int i = 0; i < RD; ++i) wb[i] = *(const h16x8*)(wsrc + i * 1024);
-          }
+          auto& wb = *[&]() { if constexpr (SM > 0) return &wbp; else return &wfull; }();
           uint4 ea[GP][2], er[GP][2];
           int eoff_o[GP];
           bool ev[GP];
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
           if (early_epi) {
 #pragma unroll
             for (int g = 0; g < NEPI; ++g) { ea[g][0] = ea0[g][0]; ea[g][1] = ea0[g][1]; er[g][0] = er0[g][0]; er[g][1] = er0[g][1]; }
-          } else if (RD == MAXKB) {
+          } else {
             epi_request();
           }
           f32x16 ac[GP];
@@ -654,9 +655,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
               for (int g = 0; g < GP; ++g) bq[(i + 1) & 1][g] = *(const h16x8*)(rp + g * (2 * B3_MW * MS));
             }
 #pragma unroll
-            for (int g = 0; g < GP; ++g) ac[g] = b3_mfma(wb[i % RD], bq[i & 1][g], ac[g]);
-            if (i + RD < MAXKB) wb[i % RD] = *(const h16x8*)(wsrc + (i + RD) * 1024);
-            if (RD < MAXKB && i + RD == MAXKB - 1) epi_request();  // behind the last weight request, in flight under the remaining MFMAs
+            for (int g = 0; g < GP; ++g) ac[g] = b3_mfma(wb[i], bq[i & 1][g], ac[g]);
             __builtin_amdgcn_sched_barrier(0);
           }
           if (oi == 0 && r == 0 && pass == 0) B3_STAMP(5);

@@ -55,7 +55,7 @@ for key in [int(a) for a in sys.argv[1:]] or [192, 96, 48, 24]:
           k, prev_end = 2, t[1]
           while k + 6 < 256 and t[k] > 0:
               row = t[k:k + 8]
-              if (k - 2) // 8 not in ((0,) if R <= 24 else (0, 1)):
+              if (k - 2) // 8 not in ((0,) if R <= 24 else (0, 1, 2)):
                   prev_end = row[6]; k += 8
                   continue
               d = [row[0] - prev_end] + [row[i + 1] - row[i] for i in range(6)]
