@@ -173,9 +173,10 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   int nstamp = 2;
 #define B3_STAMP(k) do { if (stamp && nstamp + (k) < 250) stamp[nstamp + (k)] = __builtin_readcyclecounter(); } while (0)
   if (stamp) stamp[0] = __builtin_readcyclecounter();
-  // SM (streaming mode): 0 = nothing persistent (any number of chunks); 1 / 2 = a tile is one / two chunks: the phase-A weights stay
-  // in registers for the whole launch, and so do the phase-B weights (the host picks SM > 0 only when the wave's pair never changes)
-  constexpr bool persistA = SM > 0, persistB = SM == 1;  // (SM == 2: 72 registers of phase-A weights already; the phase-B ones are re-requested per tile, under the exchange)
+  // SM (streaming mode): 0 = nothing persistent (any number of chunks); 1 = a tile is ONE chunk (192x192: 32 channels): the phase-A
+  // weights stay in registers for the whole launch, and so do the phase-B weights (the host picks it only when the wave's pair never
+  // changes).  (A two-chunk streaming mode existed until the any-chunk path got its two-ahead ring: 96x96 then ran 49 us against 52.)
+  constexpr bool persistA = SM > 0, persistB = SM > 0;
 
   // ---- phase-A lane constants: this lane's bottleneck pixel of group g (3 groups of 32 per wave; 6 x 32 = 192 >= 180)
   int pbA[NG], mpx[NG];
@@ -288,10 +289,9 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     b3_gload<0>(An[4], wa + 4096, vo); b3_gload<1024>(An[5], wa + 4096, vo); b3_gload<2048>(An[6], wa + 4096, vo); b3_gload<3072>(An[7], wa + 4096, vo);
     b3_gload<0>(An[8], wa + 8192, vo);
   };
-  h16x8 A0[9], A1[SM == 1 ? 1 : 9], wbp[SM > 0 ? RD : 1];  // (wbp: the persistent phase-B weights of SM > 0)
+  h16x8 A0[9], A1[SM > 0 ? 1 : 9], wbp[SM > 0 ? RD : 1];  // (wbp: the persistent phase-B weights of SM > 0)
   if constexpr (SM > 0) {
     load_A(A0, 0);
-    if constexpr (SM == 2) load_A(A1, 1);
     if constexpr (persistB) {
       const char* wsrc = p.o[0].w + (size_t)(NPG == 2 ? (wave & 1) : 0) * p.nksB * 1024 + lane * 16;
 #pragma unroll
@@ -300,10 +300,6 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     B3_VMWAIT();  // landed, and laundered: the compiler must not carry "load pending" into the tile loop (it would drain the DMA
 #pragma unroll   //  bursts at every first use)
     for (int s = 0; s < 9; ++s) b3_pin(A0[s]);
-    if constexpr (SM == 2) {
-#pragma unroll
-      for (int s = 0; s < 9; ++s) b3_pin(A1[s]);
-    }
     if constexpr (persistB) {
 #pragma unroll
       for (int i = 0; i < RD; ++i) b3_pin(wbp[i]);
@@ -476,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
       boundary(j, A0);
       step(lr + (SM == 0 ? sl : (sbase + j) % NS) * XB, lw, A0, A1, j, NS == 3 ? nxt(nxt(sl)) : nxt(sl));
       sl = nxt(sl);
-      if constexpr (SM != 1) {
+      if constexpr (SM == 0) {
         if (j + 1 < nch) {
           boundary(j + 1, A1);
           step(lr + (SM == 0 ? sl : (sbase + j + 1) % NS) * XB, lw, A1, A0, j + 1, NS == 3 ? nxt(nxt(sl)) : nxt(sl));
@@ -485,11 +481,6 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
       }
     }
     B3_STAMP(2);
-    if constexpr (SM == 2) {  // phase-B weights of this wave's pair: requested now, they land under the exchange
-      const char* wsrc = p.o[0].w + (size_t)(NPG == 2 ? (wave & 1) : 0) * p.nksB * 1024 + lane * 16;
-#pragma unroll
-      for (int i = 0; i < RD; ++i) wbp[i] = *(const h16x8*)(wsrc + i * 1024);
-    }
     // ---- the K-half-1 waves hand their partial sums over (12 KiB each) through ring slots this tile is done with: the slot of
     // its last chunk and the one before it (everyone is past the last chunk; the slots BEHIND belong to the next tile's burst).
     // A one-chunk tile has a single slot: the second wave's half sits in a region of its own behind the bottleneck tile.
@@ -774,12 +765,12 @@ static B3Launch b3_plan(B3P& p) {
   const int slots_wg = 256 * per_cu;
   p.wb_persist = (p.nout == 1 && nb <= 2 && p.nch <= 2 && ((L.npg == 1 && npb == 1) || (L.npg == 2 && npb == 2))) ? 1 : 0;
   static const int no_sm = [] { const char* e = getenv("CGEN_BLK3_NOSM"); return e ? atoi(e) : 0; }();
-  L.sm = (p.wb_persist && !no_sm) ? p.nch : 0;
+  L.sm = (p.wb_persist && !no_sm && p.nch == 1) ? 1 : 0;
   // Tile height.  A launch is a whole number of rounds over the resident workgroups: twelve-row tiles where they save a round (48x48
   // at batch 32: 576 tiles = two rounds of eight rows, 384 = one of twelve); they exist for the wide-output, any-chunk instances
   L.th = 8;
   static const int th_env = [] { const char* e = getenv("CGEN_BLK3_TH"); return e ? atoi(e) : 0; }();
-  if (L.npg == 4 && L.sm == 0 && th_env != 8) {
+  if (L.npg == 4 && L.sm == 0 && nb <= 3 && th_env != 8) {  // (a 32-wide bottleneck with twelve rows spills registers: not built)
     const int t8 = p.ntiles, t12 = p.N * p.tiles_x * ceil_div(p.H, 12);
     const int r8 = ceil_div(t8, slots_wg), r12 = ceil_div(t12, slots_wg);
     if (th_env == 12 || (r12 * 3 < r8 * 2 + (r8 > 1 ? 1 : 0) && t12 > 128)) L.th = 12;  // (1.5x the work per round: worth it when it removes a round)
@@ -823,12 +814,10 @@ static void b3_launch_nb(const B3P& p, const B3Launch& L, hipStream_t st) {
   if constexpr (NB <= 2) {  // streaming instances: a tile is one or two chunks, one output, the wave's pair is fixed
     if (L.sm == 1 && L.npg == 1) return b3_launch_inst<PRE, NB, 1, 1>(p, L, st);
     if (L.sm == 1 && L.npg == 2) return b3_launch_inst<PRE, NB, 2, 1>(p, L, st);
-    if (L.sm == 2 && L.npg == 1) return b3_launch_inst<PRE, NB, 1, 2>(p, L, st);
-    if (L.sm == 2 && L.npg == 2) return b3_launch_inst<PRE, NB, 2, 2>(p, L, st);
   }
   if (L.npg == 1) b3_launch_inst<PRE, NB, 1, 0>(p, L, st);
   else if (L.npg == 2) b3_launch_inst<PRE, NB, 2, 0>(p, L, st);
-  else if (L.th == 12) b3_launch_inst<PRE, NB, 4, 0, 12>(p, L, st);
+  else if (NB <= 3 && L.th == 12) { if constexpr (NB <= 3) b3_launch_inst<PRE, NB, 4, 0, 12>(p, L, st); }
   else b3_launch_inst<PRE, NB, 4, 0>(p, L, st);
 }
 template <bool PRE>

@@ -24,6 +24,11 @@ CASES = [
     (2, 32, 32, [24, 8, 32], [1, 0, 1], 16, 32, False),  # three segments, 8-channel middle one without a gradient
     (2, 48, 48, [96, 4, 96], [1, 0, 1], 24, 32, False),  # the posterior Block at 48^2: cat[h, pa, acts], 4 parent channels (zero padded to 8)
     (2, 20, 28, [64, 4], [1, 0], 16, 96, False),         # the prior Block: cat[h, pa]; ragged image
+    # batch 32 at 48^2: 576 eight-row tiles would be two rounds, so the kernel takes its TWELVE-row tiles (forward and the trunk's
+    # data gradient: three chunks through a two-slot ring; the posterior's data gradient: one chunk, two gradient outputs)
+    (32, 48, 48, [96], [1], 24, 96, True),
+    (32, 48, 48, [96, 4, 96], [1, 0, 1], 24, 32, False),
+    (32, 44, 48, [64], [1], 16, 96, False),              # twelve-row tiles on a ragged image (44 = 3.67 tiles high), 16-wide bottleneck
 ]
 
 
