@@ -150,6 +150,7 @@ typedef struct cgen_wprep_desc { /* OIHW f32 parameter -> forward image or dgrad
   void* dst;
   int32_t co, ci_total, ks, mode; /* mode 0: fwd image, 1: dgrad image of segment [seg_off, seg_off+seg_c[0]);
                                    * fragment-ordered images of cgen_block3 (src is always the OIHW parameter [co][ci_total][3][3]):
+                                   * (1 KiB fragments in v_mfma_f32_32x32x16 A-operand lane order; phase-A images [chunk][channel half][tap])
                                    * 2: w_a of the forward pass (conv1: rows = co, K = the segments' channels),
                                    * 3: w_a of the data gradient (conv2: rows = ci_total, K = co, taps flipped),
                                    * 4: o[].w of the forward pass (conv2: rows = co, K = tap * ci_total + c; k_pad = K16-steps per pair),
