@@ -296,11 +296,13 @@ class Engine(StageMixin, WgradMixin):
         self.blk3_on = int(os.environ.get("CGEN_BLK3", "2")) if self.dt == F16 else 0
         self.blk3_minres = int(os.environ.get("CGEN_BLK3_MINRES", "16"))
         # ... at which image sides: CGEN_BLK3_RES for Blocks with one or two input segments (trunk / prior / down Blocks),
-        # CGEN_BLK3_RES3 for three-segment Blocks (the posterior: cat[h, pa, acts]); empty = every side >= CGEN_BLK3_MINRES
-        # Defaults = where the fused launch beats the two it replaces INSIDE the step on MI355X (ukbb192 B = 32, A/B of bench.py in
-        # one session): 24x24 and 48x48, the posterior Block also at 96x96; "0" = every side
-        self.blk3_res = [int(v) for v in os.environ.get("CGEN_BLK3_RES", "24,48").split(",") if v and int(v) > 0]
-        self.blk3_res3 = [int(v) for v in os.environ.get("CGEN_BLK3_RES3", "24,48,96").split(",") if v and int(v) > 0]
+        # CGEN_BLK3_RES3 for three-segment Blocks (the posterior: cat[h, pa, acts]); a comma list of sides and lo-hi ranges,
+        # "0" = every side >= CGEN_BLK3_MINRES.  Defaults = where the fused launch beats the two it replaces INSIDE the step on MI355X
+        # (A/B of bench.py in one session): the wide, few-pixel layers -- 24x24 / 48x48 of ukbb192, 28x28 / 56x56 of
+        # mimic224 -- and the posterior Block one resolution further (96x96 / 112x112); above that the two launches are HBM-bound
+        # and a tile visit costs the fused kernel more than it saves
+        self.blk3_res = self._side_ranges(os.environ.get("CGEN_BLK3_RES", "20-64"))
+        self.blk3_res3 = self._side_ranges(os.environ.get("CGEN_BLK3_RES3", "20-112"))
         # data parallelism: once this fraction of the pass's weight-gradient work has been issued (and the background flush is
         # out), `on_split` is called with the side stream joined -- the gradients of every conv reduced so far are FINAL
         # (`early_final`), so their all-reduce can travel under the rest of the backward pass (train.TrainStep)
@@ -639,6 +641,18 @@ class Engine(StageMixin, WgradMixin):
             (self.tape if tape_hold is None else tape_hold).append((self._bw_conv, (site, segs, act, out, res1, res2), self._in_side))
         return out
 
+    @staticmethod
+    def _side_ranges(spec):
+        """'24,48,96-112' -> [(24, 24), (48, 48), (96, 112)]; '0' or '' -> [] (no restriction)"""
+        out = []
+        for v in spec.split(","):
+            v = v.strip()
+            if not v or v == "0":
+                continue
+            lo, _, hi = v.partition("-")
+            out.append((int(lo), int(hi or lo)))
+        return out
+
     def block2(self, site1, site2, segs, act, res1=None, trunk=False):
         """A whole light Block -- conv3x3(act(cat segs)) -> conv3x3(act(.)) (+ res1), vae.py:60-71,73-84 -- as ONE launch of
         cgen_block3 (csrc/block.hip) where the kernel serves the shape and the policy (blk3_res / blk3_res3) takes it, else as the
@@ -647,7 +661,7 @@ class Engine(StageMixin, WgradMixin):
         wants_rem = self.trunk_rem and (trunk or (res1 is not None and res1.rem))  # (the fused kernel knows no remainder planes)
         res_ok = self.blk3_res3 if len(segs) >= 3 else self.blk3_res
         if (self.blk3_on and act == ACT_RELU and not wants_rem and min(x0.h, x0.w) >= self.blk3_minres and "a_fwd" in site1.frag
-                and (not res_ok or x0.h in res_ok)
+                and (not res_ok or any(lo <= x0.h <= hi for lo, hi in res_ok))
                 and "b_fwd" in site2.frag and len(segs) <= 3 and site1.co % 8 == 0 and site1.co <= 32 and site2.co % 8 == 0
                 and not self.stage_covers(x0.h)):
             out = self._block3_fwd(site1, site2, segs, res1)

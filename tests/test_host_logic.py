@@ -198,3 +198,19 @@ def test_loss_scale_rule_and_backoff_shift():
     for n in (7, 1000, 256 * 32 * 32, 3 * 224 * 224 * 32):
         k = math.log2(Engine.loss_scale_rule(n))
         assert k == int(k) and 0.2 * n <= 2.0 ** k <= 0.8 * n or n < 8
+
+
+def test_fused_block_side_policy_parsing():
+    """CGEN_BLK3_RES / _RES3: comma list of sides and lo-hi ranges; '0' or empty = every side (engine.Engine._side_ranges)."""
+    from causal_gen_amd.engine import Engine
+
+    assert Engine._side_ranges("24,48") == [(24, 24), (48, 48)]
+    assert Engine._side_ranges("20-64") == [(20, 64)]
+    assert Engine._side_ranges("24, 96-112 ,") == [(24, 24), (96, 112)]
+    assert Engine._side_ranges("0") == [] and Engine._side_ranges("") == []
+    # the defaults take ukbb192's 24x24 / 48x48 (and the posterior's 96x96) and nothing of the 32x32 presets
+    trunk, post = Engine._side_ranges("20-64"), Engine._side_ranges("20-112")
+    take = lambda side, rs: any(lo <= side <= hi for lo, hi in rs)
+    assert [s for s in (192, 96, 48, 24, 12, 6) if take(s, trunk)] == [48, 24]
+    assert [s for s in (192, 96, 48, 24, 12, 6) if take(s, post)] == [96, 48, 24]
+    assert not any(take(s, trunk) for s in (16, 8, 4))
