@@ -29,6 +29,10 @@ CASES = [
     (32, 48, 48, [96], [1], 24, 96, True),
     (32, 48, 48, [96, 4, 96], [1, 0, 1], 24, 32, False),
     (32, 44, 48, [64], [1], 16, 96, False),              # twelve-row tiles on a ragged image (44 = 3.67 tiles high), 16-wide bottleneck
+    # several twelve-row tiles per workgroup (more tiles than resident workgroups): the next tile's requests go out at the end of a
+    # tile; three chunks through the two-slot ring (one chunk ahead) / two chunks
+    (64, 48, 48, [96], [1], 24, 96, True),
+    (32, 96, 96, [64], [1], 16, 96, False),
 ]
 
 
