@@ -27,7 +27,8 @@ class ConvArgs(C.Structure):
 
 
 class Block3Out(C.Structure):
-    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("out", View), ("aux", View), ("res1", View)]
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("out", View), ("aux", View), ("res1", View),
+                ("out_rem", C.c_int64), ("res1_rem", C.c_int64)]
 
 
 class Block3Args(C.Structure):
@@ -156,7 +157,7 @@ PROTOTYPES = {
     "cgen_stage_run": [vp, i32, i32, i32, vp],
 }
 _RESTYPES = {"cgen_last_error": C.c_char_p}
-ABI_VERSION = 400  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
+ABI_VERSION = 401  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
 _NOCHECK = {"cgen_version", "cgen_h16_format", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks",
             "cgen_block3_supported", "cgen_stem_conv_supported", "cgen_stage_accepts"}
 

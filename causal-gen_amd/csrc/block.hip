@@ -61,6 +61,7 @@ struct B3Out {
   const float* bias;  // [Co] or null
   BV3 out, aux, res;  // aux: mask (v = aux > 0 ? v : 0); res: added
   int Co, npb;
+  int out_rem, res_rem, pad0, pad1;  // remainder planes of a residual trunk (byte offsets from out.p / res.p, 0 = none): value = hi + rem
 };
 struct B3P {
   int N, H, W, nseg, nch, b, nout, nksB;
@@ -147,7 +148,7 @@ __device__ __forceinline__ void b3_chunk(const char* __restrict__ Xc, const h16x
 // first use of an ordinary load's result, so ordinary loads are kept out of the spans a burst should survive: weights are
 // PERSISTENT in registers where a tile needs <= 2 chunks / the wave's output pair never changes (loaded once per launch), the
 // epilogue operands are requested BEFORE the next tile's burst and consumed at the very end of the tile.
-template <bool PRE, int NB, int NPG, int SM, int TH>
+template <bool PRE, int NB, int NPG, int SM, int TH, bool REM>
 __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   constexpr int NMP = b3_nmp(TH), XB = b3_xbytes(TH), NDI = b3_ndi(TH);
   constexpr int NG = (NMP + 63) / 64;  // bottleneck pixel groups (of 32) per wave in phase A: 3 / 4
@@ -563,6 +564,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
       const char* const Oaux = Ok->aux.p; const int Oaux_sn = Ok->aux.sn, Oaux_sh = Ok->aux.sh, Oaux_sw = Ok->aux.sw;
       const char* const Ores = Ok->res.p; const int Ores_sn = Ok->res.sn, Ores_sh = Ok->res.sh, Ores_sw = Ok->res.sw;
       const int npb = Ok->npb, Co = Ok->Co, nks = p.nksB;
+      const int Oout_rem = Ok->out_rem, Ores_rem = Ok->res_rem;  // (forward trunk Blocks of an inference pass; 0 otherwise)
 #pragma unroll 1
       for (int r = 0;; ++r) {
         const int pair = NPG == 4 ? wave + 4 * r : (NPG == 2 ? (wave & 1) + 2 * r : r);
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
         for (int pass = 0; pass < PGW / GP; ++pass) {
           const int pgb = pg0 + pass * GP;
           auto& wb = *[&]() { if constexpr (SM > 0) return &wbp; else return &wfull; }();
-          uint4 ea[GP][2], er[GP][2];
+          uint4 ea[GP][2], er[GP][2], el[REM ? GP : 1][2];  // (el: the residual's remainder plane; REM instances only, so that the plain ones keep their registers)
           int eoff_o[GP];
           bool ev[GP];
 #pragma unroll
@@ -604,6 +606,10 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
                 ea[g][q8] = er[g][q8] = make_uint4(0, 0, 0, 0);
                 if (has_aux) ea[g][q8] = *(const uint4*)(ok ? Oaux + oa + 16 * q8 : zero);
                 if (has_res) er[g][q8] = *(const uint4*)(ok ? Ores + orr + 16 * q8 : zero);
+                if constexpr (REM) {
+                  el[g][q8] = make_uint4(0, 0, 0, 0);
+                  if (has_res && Ores_rem != 0) el[g][q8] = *(const uint4*)(ok ? Ores + Ores_rem + orr + 16 * q8 : zero);
+                }
               }
             }
           };
@@ -672,8 +678,25 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
                 const uint32_t w[4] = {er[g][q8].x, er[g][q8].y, er[g][q8].z, er[g][q8].w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { u[2 * e] += h_lo(w[e]); u[2 * e + 1] += h_hi(w[e]); }
+                if constexpr (REM) {
+                  if (Ores_rem != 0) {
+                    const uint32_t wl[4] = {el[g][q8].x, el[g][q8].y, el[g][q8].z, el[g][q8].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { u[2 * e] += h_lo(wl[e]); u[2 * e + 1] += h_hi(wl[e]); }
+                  }
+                }
               }
-              *(uint4*)((char*)Oout + eoff_o[g] + 16 * q8) = b3_pack8(u);
+              const uint4 o16 = b3_pack8(u);
+              *(uint4*)((char*)Oout + eoff_o[g] + 16 * q8) = o16;
+              if constexpr (REM) {
+                if (Oout_rem != 0) {  // what the rounding just dropped goes to the remainder plane: out_rem = rn16(v - out)
+                  const uint32_t wo[4] = {o16.x, o16.y, o16.z, o16.w};
+                  float d[8];
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) { d[2 * e] = u[2 * e] - h_lo(wo[e]); d[2 * e + 1] = u[2 * e + 1] - h_hi(wo[e]); }
+                  *(uint4*)((char*)Oout + Oout_rem + eoff_o[g] + 16 * q8) = b3_pack8(d);
+                }
+              }
             }
           }
         }
@@ -742,6 +765,10 @@ static int b3_fill(const cgen_block3_args* a, B3P& p) {
     if (!s.out.p || !s.w || s.out.c % 8 != 0 || s.out.c < 8) return 0;
     if (((uintptr_t)s.w % 16) || (s.bias && (uintptr_t)s.bias % 16)) return 0;
     d.w = (const char*)s.w; d.bias = s.bias; d.Co = s.out.c; d.npb = (s.out.c + 31) / 32;
+    if (s.out_rem < 0 || s.res1_rem < 0 || s.out_rem >= ((int64_t)1 << 31) || s.res1_rem >= ((int64_t)1 << 31) || (s.out_rem % 16) || (s.res1_rem % 16)) return 0;
+    if ((s.out_rem || s.res1_rem) && (!a->pre_act || a->nout != 1)) return 0;  // (remainder planes: forward, single output)
+    if (s.res1_rem && !s.res1.p) return 0;
+    d.out_rem = (int)s.out_rem; d.res_rem = (int)s.res1_rem;
     if (!b3_view(s.out, a->n, a->h, a->w, d.out) || !b3_view(s.aux, a->n, a->h, a->w, d.aux) || !b3_view(s.res1, a->n, a->h, a->w, d.res)) return 0;
     if ((s.aux.p && s.aux.c != s.out.c) || (s.res1.p && s.res1.c != s.out.c)) return 0;
     if (o == 0 && s.out.c > 224) return 0;  // (lanes 8 .. 63 of the bias DMA instruction: 56 x 4 channels)
@@ -765,7 +792,7 @@ static B3Launch b3_plan(B3P& p) {
   const int slots_wg = 256 * per_cu;
   p.wb_persist = (p.nout == 1 && nb <= 2 && p.nch <= 2 && ((L.npg == 1 && npb == 1) || (L.npg == 2 && npb == 2))) ? 1 : 0;
   static const int no_sm = [] { const char* e = getenv("CGEN_BLK3_NOSM"); return e ? atoi(e) : 0; }();
-  L.sm = (p.wb_persist && !no_sm && p.nch == 1) ? 1 : 0;
+  L.sm = (p.wb_persist && !no_sm && p.nch == 1 && !p.o[0].out_rem && !p.o[0].res_rem) ? 1 : 0;  // (remainder planes: the any-chunk path's epilogue)
   // Tile height.  A launch is a whole number of rounds over the resident workgroups: twelve-row tiles where they save a round (48x48
   // at batch 32: 576 tiles = two rounds of eight rows, 384 = one of twelve); they exist for the wide-output, any-chunk instances
   L.th = 8;
@@ -803,11 +830,18 @@ static B3Launch b3_plan(B3P& p) {
   return L;
 }
 
+template <bool PRE, int NB, int NPG, int SM, int TH, bool REM>
+static void b3_launch_rem(const B3P& p, const B3Launch& L, hipStream_t st) {
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)blk3_kernel<PRE, NB, NPG, SM, TH, REM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  hipLaunchKernelGGL((blk3_kernel<PRE, NB, NPG, SM, TH, REM>), dim3(L.grid), dim3(256), L.lds, st, p);
+}
 template <bool PRE, int NB, int NPG, int SM, int TH = 8>
 static void b3_launch_inst(const B3P& p, const B3Launch& L, hipStream_t st) {
-  static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)blk3_kernel<PRE, NB, NPG, SM, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-  hipLaunchKernelGGL((blk3_kernel<PRE, NB, NPG, SM, TH>), dim3(L.grid), dim3(256), L.lds, st, p);
+  if constexpr (PRE && SM == 0) {  // remainder planes of a residual trunk: forward, any-chunk instances (b3_fill / b3_plan see to that)
+    if (p.o[0].out_rem || p.o[0].res_rem) return b3_launch_rem<PRE, NB, NPG, SM, TH, true>(p, L, st);
+  }
+  b3_launch_rem<PRE, NB, NPG, SM, TH, false>(p, L, st);
 }
 template <bool PRE, int NB>
 static void b3_launch_nb(const B3P& p, const B3Launch& L, hipStream_t st) {

@@ -658,20 +658,20 @@ class Engine(StageMixin, WgradMixin):
         cgen_block3 (csrc/block.hip) where the kernel serves the shape and the policy (blk3_res / blk3_res3) takes it, else as the
         two conv launches.  The bottleneck tensor is written either way (weight gradients, backward mask)."""
         x0 = segs[0]
-        wants_rem = self.trunk_rem and (trunk or (res1 is not None and res1.rem))  # (the fused kernel knows no remainder planes)
         res_ok = self.blk3_res3 if len(segs) >= 3 else self.blk3_res
-        if (self.blk3_on and act == ACT_RELU and not wants_rem and min(x0.h, x0.w) >= self.blk3_minres and "a_fwd" in site1.frag
+        if (self.blk3_on and act == ACT_RELU and min(x0.h, x0.w) >= self.blk3_minres and "a_fwd" in site1.frag
                 and (not res_ok or any(lo <= x0.h <= hi for lo, hi in res_ok))
                 and "b_fwd" in site2.frag and len(segs) <= 3 and site1.co % 8 == 0 and site1.co <= 32 and site2.co % 8 == 0
                 and not self.stage_covers(x0.h)):
-            out = self._block3_fwd(site1, site2, segs, res1)
+            out = self._block3_fwd(site1, site2, segs, res1, trunk)
             if out is not None:
                 return out
         t = self.conv(site1, segs, act)
         return self.conv(site2, [t], act, res1=res1, trunk=trunk)
 
-    def _block3_fwd(self, site1, site2, segs, res1):
-        """One launch of cgen_block3 for a light Block (forward); None when the kernel declines the layout."""
+    def _block3_fwd(self, site1, site2, segs, res1, trunk=False):
+        """One launch of cgen_block3 for a light Block (forward); None when the kernel declines the layout.  A residual-trunk Block
+        of a pass with remainder planes (section 1a) reads res1 as hi + rem and writes out as rn16(v), rn16(v - out), like conv()."""
         x0 = segs[0]
         a = _lib.Block3Args()
         a.dtype, a.n, a.h, a.w, a.nseg, a.nout, a.pre_act = self.dt, x0.n, x0.h, x0.w, len(segs), 1, 1
@@ -680,11 +680,12 @@ class Engine(StageMixin, WgradMixin):
         b1, b2 = site1.conv.bias, site2.conv.bias
         a.w_a, a.bias_a = site1.frag["a_fwd"], (b1.data_ptr() if b1 is not None else None)
         t = self.new(x0.n, x0.h, x0.w, site1.co)
-        out = self.new(x0.n, x0.h, x0.w, site2.co)
+        out = self.new(x0.n, x0.h, x0.w, site2.co, rem=trunk and self.trunk_rem and max(x0.h, x0.w) <= self.trunk_maxres)
         a.mid, a.mid_aux = t.cv(), NULL_VIEW
         o = a.o[0]
         o.w, o.bias = site2.frag["b_fwd"], (b2.data_ptr() if b2 is not None else None)
         o.out, o.aux, o.res1 = out.cv(), NULL_VIEW, (res1.cv() if res1 is not None else NULL_VIEW)
+        o.out_rem, o.res1_rem = out.rem, (res1.rem if res1 is not None else 0)
         if not self.lib.block3_supported(C.byref(a)):
             return None  # (the two tensors just allocated are simply not used: the arena is reset per step)
         if self._ablate and any(x0.h == r and ("r%d" % r) in self._ablate for r in (24, 48, 96, 192)):

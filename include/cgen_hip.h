@@ -52,7 +52,7 @@ typedef struct cgen_view {
 /* ABI version of this header.  cgen_version() of the loaded library must equal it (causal-gen_amd/_lib.py checks): struct layouts,
  * enum values and signatures are only compatible within one version.  cgen_h16_format(): the 16-bit storage format the library was
  * BUILT for -- 0 = IEEE binary16 (default), 1 = bfloat16 (-DCGEN_H16_BF16, an A/B build); CGEN_F16 tensors must be in that format. */
-#define CGEN_ABI_VERSION 400
+#define CGEN_ABI_VERSION 401
 int cgen_version(void);
 int cgen_h16_format(void);
 const char* cgen_last_error(void);
@@ -91,8 +91,8 @@ int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream);
  *                            o[k].out = conv3x3(mid; o[k].w = fragment image of conv1's dgrad w.r.t. segment k) * relu'(o[k].aux) + o[k].res1
  * nout = 2 serves a Block with two differentiable input segments (the posterior Block: h and the encoder activation).
  * Weight images are FRAGMENT-ORDERED (one contiguous KiB per wave load), built by cgen_weight_prep modes 2-5:
- *   w_a   [sum_s ceil(seg[s].c / 32) chunks][18 K16-steps: tap = kk >> 1, channels 16 (kk & 1) .. + 16][64 lanes][8]   (every segment
- *         occupies whole 32-channel chunks of the K axis, zero padded)
+ *   w_a   [sum_s ceil(seg[s].c / 32) chunks][18 K16-steps kk: channel half kk / 9 (channels 16 (kk / 9) .. + 16), tap = kk % 9][64 lanes][8]
+ *         (every segment occupies whole 32-channel chunks of the K axis, zero padded; a wave's nine fragments are contiguous)
  *   o[].w [ceil(Co / 32) pairs][ceil(9 b / 16) K16-steps over k = tap * b + c][64 lanes][8]
  *   lane l of a fragment holds row (l & 31) -> channel 16 ((r >> 2) & 1) + (r & 3) + 4 (r >> 3) of the 32-row block, k = 8 (l >> 5) .. + 8.
  * Served: mid.c in {8, 16, 24, 32}, out.c a multiple of 8, up to 3 input segments (each DMA-clean: channels a multiple of 8 or
@@ -101,6 +101,7 @@ typedef struct cgen_block3_out {
   const void* w;
   const float* bias;
   cgen_view out, aux, res1;
+  int64_t out_rem, res1_rem; /* remainder planes of a residual trunk, as in cgen_conv_args (byte offsets from out.p / res1.p, 0 = none) */
 } cgen_block3_out;
 typedef struct cgen_block3_args {
   int32_t dtype, n, h, w, nseg, nout, pre_act, reserved;

@@ -119,3 +119,68 @@ def test_fused_block3_matches_two_launch_path_and_torch(case):
             assert float((a - x.grad).norm()) <= 2e-2 * float(x.grad.norm())
     assert float((one["pg"][0] - w1.grad).norm()) <= 3e-2 * float(w1.grad.norm())
     assert float((one["pg"][2] - w2.grad).norm()) <= 3e-2 * float(w2.grad.norm())
+
+
+@pytest.mark.parametrize("shape", [(4, 48, 48, 96, 24), (8, 24, 24, 128, 32), (32, 48, 48, 96, 24)], ids=["48x48", "24x24", "48x48-twelve-row"])
+def test_fused_block3_remainder_planes(shape):
+    """Residual-trunk Blocks of an inference pass (value = hi + rem, remainder planes): the fused kernel reads res1 as
+    hi + rem and writes out = rn16(v), out_rem = rn16(v - out), like the two-launch path's second conv (cgen_conv_args.out_rem /
+    res1_rem).  Two chained trunk Blocks, so the second one CONSUMES a remainder plane; hi + rem of the fused path against the
+    two-launch path and against an f64 reference on the f16-quantised operands."""
+    from causal_gen_amd.engine import NT, ConvSite, Engine
+
+    N, H, W, ci, b = shape
+    g = torch.Generator().manual_seed(H + ci)
+    c1, c2 = torch.nn.Conv2d(ci, b, 3, padding=1), torch.nn.Conv2d(b, ci, 3, padding=1)
+    with torch.no_grad():
+        c1.weight.copy_(torch.randn(c1.weight.shape, generator=g) / math.sqrt(ci * 9 / 2))
+        c2.weight.copy_(torch.randn(c2.weight.shape, generator=g) / math.sqrt(b * 9 / 2))
+    x = (torch.randn(N, ci, H, W, generator=g) * 3).half().float()
+    outs = {}
+    for fuse in (0, 2):
+        eng = Engine("cuda", "f16")
+        eng.blk3_minres, eng.blk3_res, eng.blk3_res3 = 8, [], []
+        holder = torch.nn.ModuleList([c1, c2]).cuda()
+        s1, s2 = ConvSite("c1", holder[0], [ci], [True], 0), ConvSite("c2", holder[1], [b], [True], 1)
+        s1.blk3, s2.blk3 = ("a", s2), ("b", s1)
+        eng.blk3_on = 2
+        eng.bind(holder, [s1, s2])
+        eng.blk3_on = fuse
+        eng.begin()
+        eng.prepare_weights(force=True)
+        eng.recording = False
+        assert eng.trunk_rem
+        h0 = eng.from_nchw(x.cuda())
+        n0 = eng.launches
+        h1 = eng.block2(s1, s2, [h0], 1, res1=h0, trunk=True)   # produces a remainder plane
+        h2 = eng.block2(s1, s2, [h1], 1, res1=h1, trunk=True)   # consumes one and produces one
+        assert eng.launches - n0 == (2 if fuse else 4) and h1.rem and h2.rem
+        planes = []
+        for t in (h1, h2):
+            r = NT(t.ptr + t.rem, t.n, t.h, t.w, t.c, t.sn, t.sh, t.sw, t.es, rg=False, keep=t.keep)
+            planes.append((eng.to_nchw(t).double().cpu(), eng.to_nchw(r).double().cpu()))
+        torch.cuda.synchronize()
+        outs[fuse] = planes
+    w1, w2 = c1.weight.detach().cpu().half().double(), c2.weight.detach().cpu().half().double()
+    b1, b2 = c1.bias.detach().cpu().double(), c2.bias.detach().cpu().double()
+
+    def block(hi, v):  # conv inputs read hi alone; the residual adds the full value; the bottleneck is stored in f16
+        t = F.conv2d(F.relu(hi), w1, b1, padding=1).half().double()
+        return v + F.conv2d(F.relu(t), w2, b2, padding=1)
+
+    for fuse in (0, 2):
+        (hi1, rem1), (hi2, rem2) = outs[fuse]
+        v1 = block(x.double(), x.double())
+        # hi is the f16 rounding of hi + rem (but for ties: a remainder that rounds UP to exactly half an ulp)
+        assert float((hi1.half() != (hi1 + rem1).half()).float().mean()) < 1e-3
+        # hi + rem carries ~22 bits; what is left is a bottleneck value within f32 rounding of an f16 boundary taking the other
+        # side than the f64 reference's (one f16 ulp of t times a weight: ~1e-3, a handful of pixels) -- so the MEAN error is held
+        # tight and against the plain tensor's, the maximum loosely
+        e1 = ((hi1 + rem1) - v1).abs()
+        assert float(e1.mean()) <= 2e-6 * float(v1.abs().max()) and float(e1.max()) <= 4e-3, (fuse, float(e1.mean()), float(e1.max()))
+        v2 = block(hi1, hi1 + rem1)
+        e2, plain = ((hi2 + rem2) - v2).abs(), (hi2 - v2).abs()
+        assert float(e2.mean()) <= 2e-6 * float(v2.abs().max()) and float(e2.max()) <= 4e-3, (fuse, float(e2.mean()), float(e2.max()))
+        assert float(e2.mean()) * 20 < float(plain.mean()), (fuse, float(e2.mean()), float(plain.mean()))
+    d = float(((outs[2][1][0] + outs[2][1][1]) - (outs[0][1][0] + outs[0][1][1])).abs().max())
+    assert d <= 0.02 * float(outs[0][1][0].abs().max()), d  # (a bottleneck value within rounding of an f16 boundary may round the other way)
