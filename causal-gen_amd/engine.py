@@ -1051,14 +1051,31 @@ class Engine(StageMixin, WgradMixin):
         self.launches += 1
 
     # ------------------------------------------------------------------ two-stream sections of the forward pass
-    def fork_side(self):
-        """Returns True when a side stream is available; everything enqueued so far is visible to it."""
+    def fork_mark(self):
+        """An event on the main stream: `fork_side(after=ev)` later makes the side stream depend on the work up to HERE only, so the
+        main stream's next launch can be enqueued BEFORE the side stream's.  That order matters under a hipGraph: the executor walks
+        the captured graph depth-first along a node's edges in capture order, and the chain it follows first keeps the queue -- and
+        owns the node where the two chains join.  With the side chain (z_feat_proj -> prior Block) captured first, the join
+        (reparameterise + KL) landed on ITS queue and the critical chain (z_proj -> conv Block -> posterior Block) crossed queues
+        twice per decoder layer, ~11 us each (LABNOTES 9.7)."""
+        if not self.fwd_branch or self.prof is not None:
+            return None
+        self.stage_flush()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev
+
+    def fork_side(self, after=None):
+        """Returns True when a side stream is available; everything enqueued so far (up to the mark `after`) is visible to it."""
         if not self.fwd_branch or self.prof is not None:
             return False
         self.stage_flush()
         if self._fwd_side is None:
             self._fwd_side = torch.cuda.Stream(self.device)
-        self._fwd_side.wait_stream(torch.cuda.current_stream(self.device))
+        if after is not None:
+            self._fwd_side.wait_event(after)
+        else:
+            self._fwd_side.wait_stream(torch.cuda.current_stream(self.device))
         return True
 
     def on_side(self, fn):

@@ -816,11 +816,19 @@ class HVAE(nn.Module):
             z_cur = z
             feat = not blk.q_correction and i + 1 < len(dec.blocks)
             hold = []
-            if feat and pipeline and two and dec.blocks[i + 1].stochastic and not dec.blocks[i + 1].q_correction and eng.fork_side():
+            # the next layer's prior chain (z_feat_proj -> prior Block) on the side stream, forked HERE but enqueued behind z_proj:
+            # the main chain must be the first edge out of the fork for a captured graph to keep it on one queue (Engine.fork_mark)
+            ahead = feat and pipeline and two and dec.blocks[i + 1].stochastic and not dec.blocks[i + 1].q_correction
+            mark = eng.fork_mark() if ahead and os.environ.get("CGEN_FWD_MAINFIRST", "1") != "0" else None
+            if ahead and mark is None and eng.fork_side():
                 z = eng.on_side(lambda: eng.conv(self._site(eng, blk.z_feat_proj), [z_cur, p_feat], ACT_NONE, tape_hold=hold))
                 side_ahead = True
                 feat = False
             h = eng.conv(self._site(eng, blk.z_proj), [z_cur, pa], ACT_NONE, res1=h, res2=p_feat, trunk=True)
+            if mark is not None and eng.fork_side(after=mark):
+                z = eng.on_side(lambda: eng.conv(self._site(eng, blk.z_feat_proj), [z_cur, p_feat], ACT_NONE, tape_hold=hold))
+                side_ahead = True
+                feat = False
             h = self._run_block(eng, blk.conv, [h])
             eng.tape.extend(hold)  # (backward order as before: z_feat_proj after the conv Block)
             if feat:
