@@ -776,7 +776,11 @@ class HVAE(nn.Module):
             run_prior = lambda: self._run_block(eng, blk.prior, [p_in, pa_sto] if blk.cond_prior else [p_in])
             # the prior and the posterior Block of a layer are independent: two streams (one fork / join per layer)
             # (not at a staged resolution: there the whole layer is one op list on one stream, a fork would only cut it)
-            two = blk.stochastic and acts is not None and eng.recording and not eng.stage_covers(res) and (side_ahead or eng.fork_side())
+            want_two = blk.stochastic and acts is not None and eng.recording and not eng.stage_covers(res)
+            # (a fresh fork: the posterior Block -- the main chain -- is enqueued first, the prior Block behind the mark: Engine.fork_mark)
+            mark = eng.fork_mark() if want_two and not side_ahead else None
+            qout = self._run_block(eng, blk.posterior, [h, pa, acts[res]]) if mark is not None else None
+            two = want_two and (side_ahead or eng.fork_side(after=mark))
             if side_ahead and not two:
                 eng.join_side()
                 side_ahead = False
@@ -786,7 +790,8 @@ class HVAE(nn.Module):
             if blk.stochastic:
                 sid += 1
                 if acts is not None:
-                    qout = self._run_block(eng, blk.posterior, [h, pa, acts[res]])
+                    if qout is None:
+                        qout = self._run_block(eng, blk.posterior, [h, pa, acts[res]])
                     if two:
                         eng.join_side()
                         side_ahead = False
