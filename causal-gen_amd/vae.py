@@ -751,7 +751,9 @@ class HVAE(nn.Module):
         # Software pipeline over layers (training / abduction pass): z_feat_proj of layer k, the upsampling of its output and
         # the prior Block of layer k + 1 form a chain that only needs z_k and p_feat_k -- it runs on the side stream while the
         # main stream does z_proj, the conv Block and the posterior Block of layer k + 1.  Same kernels, same tape order.
-        pipeline = acts is not None and eng.recording and eng.fwd_branch and eng.prof is None
+        # (inference passes too -- the abduction pass of the counterfactual loop: +1.5 % cf/s, +3 % on the plain trunk; CGEN_INFER_BRANCH=0 off)
+        rec2 = eng.recording or os.environ.get("CGEN_INFER_BRANCH", "1") != "0"
+        pipeline = acts is not None and rec2 and eng.fwd_branch and eng.prof is None
         if pipeline:
             for p_ in dec.bias:  # (lazily built NHWC images: build them before any side-stream section needs one)
                 eng.param_nhwc(p_)
@@ -776,7 +778,7 @@ class HVAE(nn.Module):
             run_prior = lambda: self._run_block(eng, blk.prior, [p_in, pa_sto] if blk.cond_prior else [p_in])
             # the prior and the posterior Block of a layer are independent: two streams (one fork / join per layer)
             # (not at a staged resolution: there the whole layer is one op list on one stream, a fork would only cut it)
-            want_two = blk.stochastic and acts is not None and eng.recording and not eng.stage_covers(res)
+            want_two = blk.stochastic and acts is not None and rec2 and not eng.stage_covers(res)
             # (a fresh fork: the posterior Block -- the main chain -- is enqueued first, the prior Block behind the mark: Engine.fork_mark)
             mark = eng.fork_mark() if want_two and not side_ahead else None
             qout = self._run_block(eng, blk.posterior, [h, pa, acts[res]]) if mark is not None else None
