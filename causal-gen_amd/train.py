@@ -149,7 +149,12 @@ class TrainStep:
         # gradient accumulation (trainer.py:64-67): elbo / accu_steps per iteration, summed in a second flat buffer; the
         # optimiser tail runs on iterations with (it - 1) % accu_steps == 0 and reads that buffer
         self.accu = max(1, int(getattr(args, "accu_steps", 1) or 1))
-        self.overflow_backoffs, self._clean_calls, self.ls_growth_interval = 0, 0, 20
+        # f16 loss-scale back-off: looked after INSIDE step(), on every rank, every `ls_check_interval` iterations,
+        # keyed by the iteration counter (idempotent); stats() is read-only.  The decision reads the device state of the
+        # previous step, which is identical on all data-parallel ranks (all-reduced gradient + scalars feed clip_decide).
+        self.overflow_backoffs, self._clean_checks, self.ls_growth_interval = 0, 0, 20
+        self.ls_check_interval, self._ls_checked_it, self._ls_last_growth_it = 16, 0, None
+        self.LS_SHIFT_MIN = -16
         self.acc_g = torch.zeros(n, device=dev) if self.accu > 1 else None
 
     # -- pieces -----------------------------------------------------------------------------------------
@@ -368,6 +373,7 @@ class TrainStep:
     def step(self, x, pa):
         """One optimiser step on a batch already resident on the GPU.  Returns the device tensor [elbo, nll, kl]."""
         a = self.args
+        self._loss_scale_check()
         self.it += 1
         beta = self.beta
         if getattr(a, "beta_warmup_steps", 0) > 0:
@@ -465,6 +471,8 @@ class TrainStep:
                  "differentiable": False, "fused": None, "initial_lr": float(a.lr), "params": list(range(len(eng.params)))}
         return {"state": state, "param_groups": [group],
                 "cgen": {"it": self.it, "opt_steps": int(steps), "n_skipped": int(st[4]),
+                         "loss_scale_shift": int(self.eng.loss_scale_shift), "overflow_backoffs": int(self.overflow_backoffs),
+                         "ls_growth_interval": int(self.ls_growth_interval),
                          "acc_g": None if self.acc_g is None else self.acc_g.clone()}}
 
     def scheduler_state_dict(self):
@@ -497,36 +505,55 @@ class TrainStep:
         st[4] = float(extra.get("n_skipped", 0))
         self.state.copy_(st)
         self.it = int(extra.get("it", st[5]))
+        self._ls_checked_it, self._clean_checks, self._ls_last_growth_it = self.it, 0, None
+        self.overflow_backoffs = int(extra.get("overflow_backoffs", 0))
+        self.ls_growth_interval = int(extra.get("ls_growth_interval", self.ls_growth_interval))
+        shift = max(self.LS_SHIFT_MIN, min(0, int(extra.get("loss_scale_shift", 0))))
+        if shift != self.eng.loss_scale_shift:
+            self._rescale(shift - self.eng.loss_scale_shift)
         if self.acc_g is not None and extra.get("acc_g") is not None:
             self.acc_g.copy_(extra["acc_g"])
 
+    def _loss_scale_check(self):
+        """Every `ls_check_interval` iterations (f16 engine only): one host read of the device step state.  The last step was
+        dropped for a NON-FINITE gradient norm => an activation gradient left binary16's range: halve the scale (captured graphs
+        and coefficient tables are rebuilt at this step) instead of dropping every later step as well.  After
+        `ls_growth_interval` clean checks the scale is doubled back towards the rule's value; a growth that overflows again
+        within one interval doubles that interval (no flapping).  The shift is clamped to [LS_SHIFT_MIN, 0]."""
+        if self.eng.dtype_name == "f32" or self.it == 0 or self.it % self.ls_check_interval or self._ls_checked_it == self.it:
+            return
+        self._ls_checked_it = self.it
+        s = self.state.cpu().tolist()
+        overflow = bool(s[3]) and not math.isfinite(s[1])
+        if overflow:
+            if self.eng.loss_scale_shift > self.LS_SHIFT_MIN:
+                self._rescale(-1)
+                self.overflow_backoffs += 1
+            if self._ls_last_growth_it is not None and self.it - self._ls_last_growth_it <= self.ls_growth_interval * self.ls_check_interval:
+                self.ls_growth_interval = min(4096, 2 * self.ls_growth_interval)
+            self._ls_last_growth_it = None
+            self._clean_checks = 0
+        else:
+            self._clean_checks += 1
+            if self.eng.loss_scale_shift < 0 and self._clean_checks >= self.ls_growth_interval:
+                self._rescale(+1)
+                self._clean_checks = 0
+                self._ls_last_growth_it = self.it
+
     def stats(self):
-        """Host read of the device-side step state (one sync; call every N steps, not every step).  On the f16 engine this
-        is also where the gradient loss scale is looked after: a step dropped for a NON-FINITE gradient norm means
-        an activation gradient left binary16's range -- the scale is halved (captured graphs and coefficient tables are
-        rebuilt at the next step) instead of every later step being dropped as well; after `ls_growth_interval` clean calls
-        it is doubled back towards the rule's value.  `overflow_backoffs` counts the halvings, `loss_scale_shift` is the
-        current log2 offset."""
+        """Host read of the device-side step state (one sync; call every N steps, not every step).  Read-only: the f16
+        loss-scale back-off lives in step() (`_loss_scale_check`); `overflow_backoffs` counts the halvings so far,
+        `loss_scale_shift` is the current log2 offset from the rule's value."""
         s = self.state.cpu().tolist()
         out = dict(grad_norm=s[1], clip_coef=s[2], skipped_last=bool(s[3]), n_skipped=int(s[4]), opt_steps=int(s[5]))
         if self.eng.dtype_name != "f32":
-            overflow = bool(s[3]) and not math.isfinite(s[1])
-            if overflow:
-                self._rescale(-1)
-                self.overflow_backoffs += 1
-                self._clean_calls = 0
-            else:
-                self._clean_calls += 1
-                if self.eng.loss_scale_shift < 0 and self._clean_calls >= self.ls_growth_interval:
-                    self._rescale(+1)
-                    self._clean_calls = 0
             out.update(loss_scale=self.eng.loss_scale, loss_scale_shift=self.eng.loss_scale_shift, overflow_backoffs=self.overflow_backoffs)
         return out
 
     def _rescale(self, d):
         """Move the loss-scale back-off by `d` powers of two: everything that baked the old scale in is dropped (the captured
         step graphs, the seed coefficients, the engine's reduce tables are keyed by the scale)."""
-        self.eng.loss_scale_shift = min(0, self.eng.loss_scale_shift + d)
+        self.eng.loss_scale_shift = max(self.LS_SHIFT_MIN, min(0, self.eng.loss_scale_shift + d))
         torch.cuda.synchronize()
         self.graphs.clear()
         for ent in self.coefs.values():

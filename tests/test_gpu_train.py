@@ -1,6 +1,7 @@
 """Fused train step (forward, hand-written backward, device-side clip/skip, AdamW+EMA) against the oracle's
 restatement of trainer.py:54-87; hipGraph replay against eager execution."""
 import copy
+import os
 from types import SimpleNamespace
 
 import pytest
@@ -717,3 +718,64 @@ def test_f16_training_tracks_the_f32_path():
     assert float(curves["f32"][-1, 0]) < float(curves["f32"][0, 0])  # (it did train)
     d = float((finals["f16"] - finals["f32"]).norm() / finals["f32"].norm())
     assert d < 2e-2, d
+
+
+def test_f16_loss_scale_backs_off_inside_step_and_grows_back():
+    """the binary16 loss-scale back-off lives in TrainStep.step() (all ranks, keyed by the iteration counter), not in
+    the reporting getter.  An absurd initial scale (2^30) overflows every activation gradient: every step is dropped for a
+    non-finite norm until enough checks have halved it; each check halves ONCE, rebuilds the captured graph, stats() changes
+    nothing, the shift survives a state_dict round trip, and clean checks grow the scale back (never above the rule)."""
+    import bench
+    from causal_gen_amd.train import TrainStep
+
+    m, hp = bench.build_model("morphomnist", "f16")
+    m = m.cuda().train()
+    m.decoder.__dict__["drop_cond"] = lambda: (1, 1)
+    ts = TrainStep(m, hp, ema=False, use_graph=True)
+    ts.ls_check_interval, ts.ls_growth_interval = 2, 3
+    eng = m.engine()
+    rule = eng.loss_scale_rule(16 * 1024)
+    x, pa = bench.synth_batch("morphomnist", hp, 16, "cuda", 900)
+    ts.step(x, pa)
+    assert eng.loss_scale == rule and eng.loss_scale_shift == 0
+    # poison: a shift ABOVE the rule cannot be set through _rescale (clamped to <= 0) -- emulate a spike by raising the rule itself
+    os.environ["CGEN_LOSS_SCALE_LOG2"] = "30"
+    try:
+        ts._rescale(0)  # drop graphs / coefficient tables: the next step bakes 2^30 in
+        shifts, graphs_seen = [], set()
+        for it in range(120):
+            ts.step(x, pa)
+            st0 = (eng.loss_scale_shift, ts.overflow_backoffs)
+            s1, s2 = ts.stats(), ts.stats()  # read-only, however often it is called
+            assert (eng.loss_scale_shift, ts.overflow_backoffs) == st0 and s1 == s2
+            shifts.append(eng.loss_scale_shift)
+            graphs_seen.add(id(next(iter(ts.graphs.values()))[0]) if ts.graphs else None)
+            if not s1["skipped_last"] and eng.loss_scale_shift < 0:
+                break
+        assert shifts[-1] < 0 and not ts.stats()["skipped_last"], (shifts, ts.stats())
+        d = [b - a for a, b in zip(shifts, shifts[1:])]
+        assert all(v in (0, -1) for v in d), d                      # one halving per check at most
+        assert not any(a == -1 and b == -1 for a, b in zip(d, d[1:]))  # ... and only on check iterations (interval 2)
+        assert ts.overflow_backoffs == -shifts[-1] >= 1
+        assert len(graphs_seen - {None}) >= 2                     # the captured step was rebuilt after a halving
+        assert ts.stats()["n_skipped"] >= 2
+        sd = ts.state_dict()
+        assert sd["cgen"]["loss_scale_shift"] == shifts[-1]
+    finally:
+        del os.environ["CGEN_LOSS_SCALE_LOG2"]
+    # the spike is over (the rule is back): a restored TrainStep carries the shift, clean checks then grow it back to 0, not beyond
+    m2, _ = bench.build_model("morphomnist", "f16")
+    m2 = m2.cuda().train()
+    m2.decoder.__dict__["drop_cond"] = lambda: (1, 1)
+    m2.load_state_dict(m.state_dict())
+    ts2 = TrainStep(m2, hp, ema=False, use_graph=True)
+    ts2.ls_check_interval, ts2.ls_growth_interval = 2, 3
+    ts2.load_state_dict(sd)
+    e2 = m2.engine()
+    assert e2.loss_scale_shift == shifts[-1]
+    seen = []
+    for it in range(2 * 3 * (-shifts[-1]) + 8):
+        ts2.step(x, pa)
+        seen.append(e2.loss_scale_shift)
+    assert seen[-1] == 0 and max(seen) == 0 and all(b - a in (0, 1) for a, b in zip(seen, seen[1:])), seen
+    assert e2.loss_scale == rule and ts2.stats()["skipped_last"] is False

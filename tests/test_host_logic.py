@@ -188,7 +188,8 @@ def test_f16_loss_scale_rule_is_an_exact_power_of_two_tied_to_the_seed_size():
 
 def test_loss_scale_rule_and_backoff_shift():
     """engine.loss_scale_rule: a power of two near B * dims / 2, >= 1, 1 for f32; the back-off shift that
-    TrainStep.stats() applies after a step dropped for a non-finite gradient halves it."""
+    TrainStep.step() applies after a step dropped for a non-finite gradient halves it (GPU test:
+    test_gpu_train.py::test_f16_loss_scale_backs_off_inside_step_and_grows_back)."""
     from causal_gen_amd.engine import Engine
 
     assert Engine.loss_scale_rule(32 * 192 * 192, is_f32=True) == 1.0
@@ -208,9 +209,10 @@ def test_fused_block_side_policy_parsing():
     assert Engine._side_ranges("20-64") == [(20, 64)]
     assert Engine._side_ranges("24, 96-112 ,") == [(24, 24), (96, 112)]
     assert Engine._side_ranges("0") == [] and Engine._side_ranges("") == []
-    # the defaults take ukbb192's 24x24 / 48x48 (and the posterior's 96x96) and nothing of the 32x32 presets
+    # the defaults take ukbb192's 24x24 / 48x48 (and the posterior's 96x96).  Side 32 IS inside 20-64: the 32x32 presets stay on
+    # the launch-per-conv path only because their default (4-conv) Blocks have no fragment images (cgen_block3 is light-Block only)
     trunk, post = Engine._side_ranges("20-64"), Engine._side_ranges("20-112")
     take = lambda side, rs: any(lo <= side <= hi for lo, hi in rs)
     assert [s for s in (192, 96, 48, 24, 12, 6) if take(s, trunk)] == [48, 24]
     assert [s for s in (192, 96, 48, 24, 12, 6) if take(s, post)] == [96, 48, 24]
-    assert not any(take(s, trunk) for s in (16, 8, 4))
+    assert take(32, trunk) and not any(take(s, trunk) for s in (16, 8, 4))
