@@ -117,7 +117,7 @@ int cgen_block3(const cgen_block3_args* a, cgen_stream_t stream);
 /* Weight gradient (aten::convolution_backward, weight/bias part) as split-K partials:
  *   partial_w[split][Co][KS*KS][Ci_total] (f32), partial_b[split][Co] (f32, may be NULL)
  * with Ci_total = sum_s seg[s].c and nsplit = cgen_conv2d_wgrad_plan(args) (call it with the views filled in; it also
- * reports whether the streaming tiled bf16 kernel will serve the call).  Deterministic: partials are summed in a fixed
+ * reports whether the streaming tiled 16-bit (CGEN_F16) kernel will serve the call).  Deterministic: partials are summed in a fixed
  * order by cgen_wgrad_reduce. */
 typedef struct cgen_wgrad_args {
   int32_t dtype, n, h, w, ks, nseg, act, nsplit;
@@ -128,7 +128,7 @@ typedef struct cgen_wgrad_args {
 } cgen_wgrad_args;
 int cgen_conv2d_wgrad_plan(const cgen_wgrad_args* a, int32_t* tiled_out);
 /* Horizontally batched weight gradients.  The weight-gradient launches of a step are independent of each other; most of
- * them fill a fraction of the chip.  `plan` packs every problem the tiled bf16 kernel serves (eligible[i] = 1; the others
+ * them fill a fraction of the chip.  `plan` packs every problem the tiled 16-bit (CGEN_F16) kernel serves (eligible[i] = 1; the others
  * go through cgen_conv2d_wgrad) into a host blob: a table of problems followed by one {problem, split, window, co range}
  * record per workgroup, and describes one launch per kernel variant.  Call it with blob_host = NULL to get the sizes.
  * The caller copies the blob to the device ONCE (addresses are stable across steps: the arena is deterministic) and
@@ -209,8 +209,8 @@ int cgen_axpby(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view in, cge
 int cgen_nchw_to_nhwc(int32_t src_is_u8, int32_t dtype, int32_t n, int32_t c, int32_t h, int32_t w, const void* src,
                       cgen_view out, float sub, float mul, cgen_stream_t);
 /* Direct 7x7 stem conv, forward (vae.py:104-110,126: Encoder.stem, Cin 1..4, Cout 16 / 32 / 64): halo tile and the whole
- * weight matrix in LDS, one output pixel x all Cout per thread; weight_oihw / bias are the f32 parameters themselves (the bf16
- * engine rounds the weights to bf16 on load).  No patch tensor on the forward path; cgen_im2col + the 1x1 weight-gradient
+ * weight matrix in LDS, one output pixel x all Cout per thread; weight_oihw / bias are the f32 parameters themselves (the 16-bit
+ * engine rounds the weights to the 16-bit storage format on load).  No patch tensor on the forward path; cgen_im2col + the 1x1 weight-gradient
  * kernels remain the backward route. */
 int cgen_stem_conv_supported(int32_t dtype, int32_t cin, int32_t ks, int32_t co);
 int cgen_stem_conv_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t ks, int32_t co, cgen_view in,
@@ -262,7 +262,7 @@ int cgen_reparam_kl_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t 
  * ride_src into ride_dst.  In the decoder block  h = z_proj(z, pa) + h + p_feat  (vae.py:279-287) the gradient of the
  * residual p_feat -- a channel slice of the prior Block's output -- is the gradient of h verbatim; it has to land in the
  * prior output's gradient buffer next to the g_p_loc / g_p_ls this kernel writes, and used to be a launch of its own per
- * decoder block.  bf16, every view 16-byte aligned with channel counts in multiples of 8 (CGEN_EINVAL otherwise). */
+ * decoder block.  CGEN_F16 (16-bit storage), every view 16-byte aligned with channel counts in multiples of 8 (CGEN_EINVAL otherwise). */
 int cgen_reparam_kl_bwd_rider(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view q_loc, cgen_view q_ls,
                               cgen_view p_loc, cgen_view p_ls, cgen_view z, float logt, cgen_view gz,
                               const float* kl_coef_dev, int32_t coef_stride, const float* kl_chan_scale, cgen_view g_q_loc,
@@ -379,7 +379,7 @@ int cgen_philox_normal(float* out, int64_t count, const uint64_t* rng, uint32_t 
 /* rng[1] += inc (device-side counter bump so graph replays draw fresh noise) */
 int cgen_rng_advance(uint64_t* rng, uint64_t inc, cgen_stream_t);
 
-/* ------------------------------------------------------------------ per-image stage interpreter (bf16; csrc/stage.hip)
+/* ------------------------------------------------------------------ per-image stage interpreter (CGEN_F16 16-bit storage; csrc/stage.hip)
  * One launch executes a LIST of consecutive low-resolution ops -- Block convs, z_proj / z_feat_proj and their data gradients
  * (vae.py:53-71,165-167), avg-pool / nearest upsample + bias (vae.py:79-83,233-241), reparameterise + KL and its gradient
  * (vae.py:14-30), gradient copies -- with ONE workgroup per image walking the list front to back: an image's tensors at
