@@ -53,7 +53,8 @@ class WprepDesc(C.Structure):
 class WredDesc(C.Structure):
     _fields_ = [("partial_w", C.c_void_p), ("partial_b", C.c_void_p), ("grad_w", C.c_void_p), ("grad_b", C.c_void_p),
                 ("co", C.c_int32), ("ci_total", C.c_int32), ("ks", C.c_int32), ("nsplit", C.c_int32),
-                ("accumulate", C.c_int32), ("unscale", C.c_float), ("numel", C.c_int64)]
+                ("accumulate", C.c_int32), ("unscale", C.c_float), ("layout", C.c_int32), ("reserved", C.c_int32),
+                ("numel", C.c_int64)]
 
 
 class AdamwArgs(C.Structure):
@@ -157,7 +158,7 @@ PROTOTYPES = {
     "cgen_stage_run": [vp, i32, i32, i32, vp],
 }
 _RESTYPES = {"cgen_last_error": C.c_char_p}
-ABI_VERSION = 401  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
+ABI_VERSION = 402  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
 _NOCHECK = {"cgen_version", "cgen_h16_format", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks",
             "cgen_block3_supported", "cgen_stem_conv_supported", "cgen_stage_accepts"}
 

@@ -8,7 +8,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=libcgen_hip.so
 NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"
-SRCS="csrc/runtime.hip csrc/block.hip csrc/conv.hip csrc/elementwise.hip csrc/latent.hip csrc/likelihood.hip csrc/optim.hip csrc/stage.hip"
+SRCS="csrc/runtime.hip csrc/block.hip csrc/conv.hip csrc/wgrad3.hip csrc/elementwise.hip csrc/latent.hip csrc/likelihood.hip csrc/optim.hip csrc/stage.hip"
 mkdir -p build
 OBJS=""
 pids=""
@@ -16,7 +16,7 @@ for s in $SRCS; do
   o=build/$(basename ${s%.hip}).o
   OBJS="$OBJS $o"
   stale=0
-  for dep in "$s" csrc/common.h csrc/*.inc ../include/cgen_hip.h; do
+  for dep in "$s" csrc/common.h csrc/wgrad3.h csrc/*.inc ../include/cgen_hip.h; do
     if [ "$dep" -nt "$o" ]; then stale=1; fi
   done
   if [ ! -f "$o" ] || [ $stale = 1 ]; then

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "common.h"
+#include "wgrad3.h"
 
 #ifdef CGEN_NO_SETPRIO
 #define CGEN_SETPRIO() do {} while (0)
@@ -2526,7 +2527,7 @@ __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, 
   const int s0 = cidx[blockIdx.x] * MT_CHUNK + threadIdx.x * 4;
   if (s0 >= d.numel) return;
   if (s0 < nw) {
-    const bool vec = (d.ci_total & 3) == 0 && (((uintptr_t)d.partial_w) & 15) == 0;  // nw % 4 == 0 follows
+    const bool vec = (nw & 3) == 0 && (((uintptr_t)d.partial_w) & 15) == 0;  // (16-byte loads of 4 consecutive partial elements: any layout)
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     const int cnt = min(4, nw - s0);
     if (vec) {
@@ -2563,9 +2564,16 @@ __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, 
     }
     for (int e = 0; e < cnt; ++e) {
       const unsigned sidx = (unsigned)(s0 + e);
-      const unsigned r = sidx / (unsigned)d.ci_total, ci = sidx - r * d.ci_total;
-      const unsigned co = r / (unsigned)taps, tap = r - co * taps;
-      const size_t o = ((size_t)co * d.ci_total + ci) * taps + tap;
+      size_t o;
+      if (d.layout == 1) {  // [ci][flipped tap][co] (the streaming kernel with grad_out as its shifted operand, csrc/wgrad3.hip)
+        const unsigned r = sidx / (unsigned)d.co, co = sidx - r * d.co;
+        const unsigned ci = r / (unsigned)taps, ft = r - ci * taps;
+        o = ((size_t)co * d.ci_total + ci) * taps + (taps - 1 - ft);
+      } else {
+        const unsigned r = sidx / (unsigned)d.ci_total, ci = sidx - r * d.ci_total;
+        const unsigned co = r / (unsigned)taps, tap = r - co * taps;
+        o = ((size_t)co * d.ci_total + ci) * taps + tap;
+      }
       d.grad_w[o] = d.accumulate ? d.grad_w[o] + a[e] * us : a[e] * us;
     }
   }
@@ -2666,6 +2674,13 @@ static bool wgrad_tiled_ok(const cgen_wgrad_args* a, Wg2Geom& g) {
 
 extern "C" int cgen_conv2d_wgrad_plan(const cgen_wgrad_args* a, int32_t* tiled_out) {
   if (!a || a->nseg < 1 || a->nseg > CGEN_MAX_SEG) return 0;
+  {
+    Wg3Plan g3;
+    if (wg3_plan(a, g3)) {
+      if (tiled_out) *tiled_out = 2 + g3.q.layout;
+      return g3.nsplit_total;
+    }
+  }
   Wg2Geom g;
   if (wgrad_tiled_ok(a, g)) {
     if (tiled_out) *tiled_out = 1;
@@ -2721,11 +2736,23 @@ extern "C" int cgen_conv2d_wgrad_batch_plan(const cgen_wgrad_args* args, int32_t
   CGEN_REQUIRE(args && count >= 0 && blob_bytes && n_launches && eligible, "cgen_conv2d_wgrad_batch_plan: null args");
   struct Item { int idx; Wg2P q; Wg2Geom g; int key; long cost; };
   std::vector<Item> items;
+  struct Item3 { int idx; Wg3Plan g; };
+  std::vector<Item3> items3;  // problems of the streaming kernel (csrc/wgrad3.hip): their own launch, table and block list
   for (int i = 0; i < count; ++i) {
     Item it;
     it.idx = i;
     eligible[i] = 0;
     if (args[i].dtype != CGEN_F16 || !args[i].partial_w) continue;
+    {
+      Item3 i3;
+      i3.idx = i;
+      if (wg3_plan(&args[i], i3.g)) {
+        if (i3.g.nsplit_total != args[i].nsplit) continue;
+        eligible[i] = 1;
+        items3.push_back(i3);
+        continue;
+      }
+    }
     if (!build_wg2(&args[i], it.q, it.g)) continue;
     if (it.g.nsplit != args[i].nsplit) continue;
     eligible[i] = 1;
@@ -2757,10 +2784,17 @@ extern "C" int cgen_conv2d_wgrad_batch_plan(const cgen_wgrad_args* args, int32_t
   const int64_t probs_bytes = pad_to((int)(items.size() * sizeof(Wg2P)), 256);
   int64_t nblocks_total = 0;
   for (auto& it : items) nblocks_total += (int64_t)it.g.nsplit * it.g.n_cwin * it.g.n_co;
-  *blob_bytes = probs_bytes + nblocks_total * (int64_t)sizeof(int4);
+  const int64_t old_bytes = pad_to((int)(probs_bytes + nblocks_total * (int64_t)sizeof(int4)), 256);
+  // streaming-kernel section: [Wg3P table][one int4 per workgroup], longest blocks first
+  std::stable_sort(items3.begin(), items3.end(), [](const Item3& a, const Item3& b) { return a.g.block_bytes > b.g.block_bytes; });
+  const int64_t probs3_bytes = pad_to((int)(items3.size() * sizeof(Wg3P)), 256);
+  int64_t nblocks3 = 0;
+  for (auto& it : items3) nblocks3 += it.g.nblocks;
+  *blob_bytes = old_bytes + (items3.empty() ? 0 : probs3_bytes + nblocks3 * (int64_t)sizeof(int4));
   int nl = 0;
   for (size_t i = 0; i < items.size(); ++i)
     if (i == 0 || items[i].key != items[i - 1].key) ++nl;
+  if (!items3.empty()) ++nl;
   *n_launches = nl;
   if (!blob_host) return CGEN_OK;  // size query
   CGEN_REQUIRE(capacity >= *blob_bytes && launches && max_launches >= nl, "cgen_conv2d_wgrad_batch_plan: buffers too small");
@@ -2783,6 +2817,28 @@ extern "C" int cgen_conv2d_wgrad_batch_plan(const cgen_wgrad_args* args, int32_t
         for (int x = 0; x < it.g.nsplit; ++x) { blocks[b] = make_int4((int)i, x, y, z); ++b; }
     launches[li].nblocks += it.g.nsplit * it.g.n_cwin * it.g.n_co;
   }
+  if (!items3.empty()) {
+    // The block list interleaves the problems: block k of every problem before block k + 1 of any (each problem's blocks are
+    // equally long; problems sorted longest first), so the resident workgroups start on the long problems and the tail is short.
+    Wg3P* probs3 = (Wg3P*)((char*)blob_host + old_bytes);
+    int4* blocks3 = (int4*)((char*)blob_host + old_bytes + probs3_bytes);
+    ++li;
+    launches[li].ncf = -3; launches[li].ks = (int32_t)items3.size(); launches[li].lds_bytes = 0; launches[li].nblocks = (int32_t)nblocks3;
+    launches[li].blocks_offset = old_bytes + probs3_bytes;
+    int64_t b3 = 0;
+    int maxb = 0;
+    for (size_t i = 0; i < items3.size(); ++i) {
+      probs3[i] = items3[i].g.q;
+      probs3[i].pw = args[items3[i].idx].partial_w; probs3[i].pb = args[items3[i].idx].partial_b;
+      if ((int32_t)items3[i].g.lds > launches[li].lds_bytes) launches[li].lds_bytes = (int32_t)items3[i].g.lds;
+      maxb = std::max(maxb, items3[i].g.nblocks);
+    }
+    for (int k = 0; k < maxb; ++k)
+      for (size_t i = 0; i < items3.size(); ++i) {
+        const Wg3P& q3 = items3[i].g.q;
+        if (k < items3[i].g.nblocks) { blocks3[b3] = make_int4((int)i, k % q3.nsplit, k / q3.nsplit, 0); ++b3; }
+      }
+  }
   return CGEN_OK;
 }
 
@@ -2797,6 +2853,11 @@ extern "C" int cgen_conv2d_wgrad_batch_run(const void* blob_dev, const cgen_wgra
     const int4* blocks = (const int4*)((const char*)blob_dev + l.blocks_offset);
     const int grid = max_workgroups > 0 ? std::min(l.nblocks, max_workgroups) : l.nblocks;
     switch (l.ncf) {
+      case -3: {  // streaming kernel: l.ks problems, their table right in front of the block list
+        const int64_t probs3_bytes = pad_to((int)(l.ks * sizeof(Wg3P)), 256);
+        wg3_launch_mega((const Wg3P*)((const char*)blob_dev + l.blocks_offset - probs3_bytes), blocks, l.nblocks, grid, (size_t)l.lds_bytes, st);
+        break;
+      }
       case 0: {
         static bool once = false;
         if (!once) { (void)hipFuncSetAttribute((const void*)wgrad_tile_mega_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
@@ -2836,6 +2897,14 @@ extern "C" int cgen_conv2d_wgrad(const cgen_wgrad_args* a, cgen_stream_t stream)
   p.ci_total = off;
   p.n_cichunks = ch;
   p.n_tapgroups = ceil_div(p.taps, WG_MAXT);
+  {  // streaming kernel of round 5 (csrc/wgrad3.hip) where it serves the shape
+    Wg3Plan g3;
+    if (wg3_plan(a, g3)) {
+      CGEN_REQUIRE(g3.nsplit_total == a->nsplit, "cgen_conv2d_wgrad: nsplit %d != expected %d", a->nsplit, g3.nsplit_total);
+      wg3_launch_single(g3, (hipStream_t)stream);
+      return check_launch("cgen_conv2d_wgrad(stream)");
+    }
+  }
   {  // tiled bf16 kernel when the shape allows it
     int segc[CGEN_MAX_SEG];
     for (int s = 0; s < a->nseg; ++s) segc[s] = a->seg[s].c;

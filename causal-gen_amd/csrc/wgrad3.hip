@@ -1,0 +1,580 @@
+// Streaming weight gradient for gfx950 (MI355X), round 5.  Replaces wgrad_tile_mega_kernel (conv.hip) for every shape it serves.
+//   dW[co][dy][dx][ci] = sum_px G[px][co] * act(X)[px + (dy-1, dx-1)][ci]        (aten::convolution_backward, weight part;
+//                                                                                  reference: src/vae.py:53-55, 63-65 through autograd)
+//
+// GEMM view: the PIXEL axis is the MFMA K dimension (v_mfma_f32_32x32x16_f16, 16 pixels per instruction); both operands sit in
+// HBM channels-contiguous (NHWC), so K is strided and the fragments are gathered by the LDS transpose read ds_read_b64_tr_b16
+// straight from the NHWC tile (a lane supplies the address of 4 channels of one pixel and receives 4 pixels of one channel).
+//
+// What is new against the round-2..4 kernel:
+//   * The NARROW operand is the shifted one.  A Block's convs are C -> C/4 or C/4 -> C: one operand is 4x narrower.  Writing
+//       dW[co][tap][ci] = sum_px P[px][p] * S[px + d(tap)][s]
+//     with S = the narrower of (act(X), G) -- for S = G the shift is mirrored, the taps come out flipped (layout 1) -- packs
+//     (tap, channel) of S densely into the MFMA N axis at 4-channel granularity (9 x 24 = 216 -> 7 fragments of 32, 96 % full)
+//     while P's channels are the M axis (96 = 3 fragments): 21 MFMAs 32x32x16 per 16 pixels where the 16x16x32 tiling needed 54
+//     plus 28 half-empty ones; only the narrow tile carries a halo, so the halo re-read costs 8 % of the bytes instead of 40 %.
+//   * One workgroup owns the WHOLE [P channels] x [taps x S channels] slab of a pixel range where it fits 4 waves x <= 9
+//     fragments (else P is cut into windows): every activation byte is read once per window, not once per (co block x window).
+//   * A ring of `nslot` tile buffers filled by untracked global->LDS DMA with counted vmcnt waits and ONE barrier per tile; all
+//     lane-dependent address parts are launch constants; ReLU is applied to the fragments in registers (one v_pk_max_i16 per
+//     channel pair; GELU keeps an in-LDS pass); bias gradients ride along as v_dot2_f32_f16 sums of the G fragments.
+//   * LDS per workgroup <= 48 KB (CGEN_WG3_LDS), so two of them -- or one next to a fused-Block workgroup -- fit a CU.
+// Deterministic: every partial slab is written by exactly one wave in a fixed order; cgen_wgrad_reduce sums the slabs in order.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "wgrad3.h"
+
+namespace cgen {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short w3s16x4 __attribute__((ext_vector_type(4)));
+typedef short w3s16x2 __attribute__((ext_vector_type(2)));
+
+__device__ uint4 g_w3zero[4];  // DMA source of out-of-image pixels
+
+static inline W3Div mk_w3div(uint32_t d) {  // round-up method, exact for 0 <= n < 2^31 (as FastDiv in conv.hip)
+  W3Div f;
+  if (d <= 1) { f.mul = 0; f.shift = 0; return f; }
+  uint32_t sh = 0;
+  while ((1u << sh) < d) ++sh;
+  f.shift = sh;
+  f.mul = (uint32_t)((((uint64_t)1 << (32 + sh)) + d - 1) / d - ((uint64_t)1 << 32));
+  return f;
+}
+__device__ __forceinline__ int w3div(int n, const W3Div f) {
+  return (int)(((uint64_t)__umulhi((uint32_t)n, f.mul) + (uint32_t)n) >> f.shift);
+}
+
+// one LDS-DMA instruction (16 B per lane -> LDS at `lds` + 16 * lane) the compiler's wait-count pass does not see (block.hip)
+__device__ __forceinline__ void w3_dma16(const char* src, const uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory");
+}
+#define W3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// wait until at most n of this wave's DMA requests are outstanding (n is wave-uniform; requests return in order)
+__device__ __forceinline__ void w3_vmwait(const int n) {
+#define W3_C(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+  switch (n) {
+    W3_C(1) W3_C(2) W3_C(3) W3_C(4) W3_C(5) W3_C(6) W3_C(7) W3_C(8) W3_C(9) W3_C(10) W3_C(11) W3_C(12) W3_C(13) W3_C(14) W3_C(15) W3_C(16)
+    W3_C(17) W3_C(18) W3_C(19) W3_C(20) W3_C(21) W3_C(22) W3_C(23) W3_C(24) W3_C(25) W3_C(26) W3_C(27) W3_C(28) W3_C(29) W3_C(30) W3_C(31) W3_C(32)
+    W3_C(33) W3_C(34) W3_C(35) W3_C(36) W3_C(37) W3_C(38) W3_C(39) W3_C(40) W3_C(41) W3_C(42) W3_C(43) W3_C(44) W3_C(45) W3_C(46) W3_C(47) W3_C(48)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // (0, or more than the table holds: waiting for everything is always safe)
+  }
+#undef W3_C
+}
+
+__device__ __forceinline__ h16x8 w3_tr(const uint32_t a0, const uint32_t a1) {
+  typedef w3s16x4 __attribute__((address_space(3))) * lp;
+  union { w3s16x4 h[2]; h16x8 v; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)a0);
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)a1);
+  return u.v;
+}
+__device__ __forceinline__ h16x8 w3_relu8(const h16x8 v) {  // ReLU on the raw bits (-0 -> +0; a NaN with the sign bit set -> 0, as block.hip)
+  union { h16x8 h; w3s16x2 s[4]; } c;
+  c.h = v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c.s[e] = __builtin_elementwise_max(c.s[e], (w3s16x2){0, 0});
+  return c.h;
+}
+__device__ __forceinline__ f32x16 w3_mfma(const h16x8 a, const h16x8 b, const f32x16 c) {
+#ifdef CGEN_H16_BF16
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+// s + (sum of the 8 values of a fragment register set), f32 accumulate
+__device__ __forceinline__ float w3_sum8(const h16x8 v, float s) {
+#ifdef CGEN_H16_BF16
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += (float)v[e];
+  return s;
+#else
+  union { h16x8 h; h16x2_t p[4]; } c;
+  c.h = v;
+  const h16x2_t one = {(h16n_t)1.0f, (h16n_t)1.0f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_fdot2(c.p[e], one, s, false);
+  return s;
+#endif
+}
+
+// real (OIHW) input-channel index of 8-granular concatenated channel c8i of X, -1 for padding.  The segment tables are indexed
+// THROUGH THE POINTER into the problem record (global memory): a by-value struct indexed by a lane-dependent number ends up in
+// scratch (block.hip has the same note); these lookups happen once per workgroup.
+__device__ __forceinline__ int w3_xreal(const Wg3P* __restrict__ gp, const int nsegx, const int cx8, const int c8i) {
+  int si = 0;
+#pragma unroll
+  for (int k = 1; k < CGEN_MAX_SEG; ++k) si += (k < nsegx && c8i >= gp->x_k8[k]) ? 1 : 0;
+  const int cs = c8i - gp->x_k8[si];
+  return (c8i < cx8 && cs < gp->segx[si].c) ? gp->x_off[si] + cs : -1;
+}
+
+struct W3Lane {
+  const char* base;  // this lane's source for (image 0, row 0, column 0): segment pointer + its channel group
+  int sn, sh, sw;    // byte strides
+  int pl;            // pixel of the lane inside a DMA instruction
+  bool active, data;
+};
+
+// lane -> (pixel inside the instruction, 16-byte channel group) -> segment / channel of operand `o`; `is_x`: the operand is the
+// (concatenated) conv input, else the output gradient; channels [c0, c0 + width) of the operand are staged
+__device__ __forceinline__ W3Lane w3_lane(const Wg3P* __restrict__ gp, const W3Op& o, const bool is_x, const int c0, const int width, const int lane) {
+  W3Lane L;
+  L.pl = w3div(lane, o.d_gpp);
+  const int grp = lane - L.pl * o.gpp;
+  L.active = L.pl < o.ppi;
+  const int c = c0 + grp * 8;
+  const int nsegx = gp->nsegx;
+  int si = 0;
+#pragma unroll
+  for (int k = 1; k < CGEN_MAX_SEG; ++k) si += (is_x && k < nsegx && c >= gp->x_k8[k]) ? 1 : 0;
+  const View* sv = is_x ? &gp->segx[si] : &gp->g;
+  const int k0 = is_x ? gp->x_k8[si] : 0;
+  L.data = L.active && grp * 8 < width && c < o.c8;
+  L.base = sv->p + (c - k0) * 2;
+  L.sn = (int)sv->sn * 2; L.sh = (int)sv->sh * 2; L.sw = (int)sv->sw * 2;
+  return L;
+}
+
+// the tile of operand `o` whose first pixel is (n, y0, x0) -> LDS at `dst`, this wave's share of the DMA instructions
+__device__ __forceinline__ void w3_issue_op(const W3Op& o, const W3Lane& L, const int n, const int y0, const int x0, const int H, const int W,
+                                            const uint32_t dst, const int wave) {
+  const char* const zero = (const char*)g_w3zero;
+  const int noff = n * L.sn;
+  const int step = o.ppi * o.sp;
+  for (int i = wave; i < o.ninstr; i += 4) {
+    const int lin = i * o.ppi + L.pl;
+    const int ry = w3div(lin, o.d_row), rx = lin - ry * o.rowpx;
+    const int gy = y0 + ry, gx = x0 + rx;
+    const bool ok = L.data && lin < o.npx && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+    const char* src = ok ? L.base + (noff + gy * L.sh + gx * L.sw) : zero;
+    if (L.active) w3_dma16(src, __builtin_amdgcn_readfirstlane(dst + i * step));
+  }
+}
+
+template <int MPW, int NSW>
+__device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int sp_i, const int pwin) {
+  // the hot fields of the problem record, once (scalar loads); everything lane-indexed goes through gp
+  struct { int H, W, ks, taps, act, x_is_s, th, tw, tiles_x, tiles_y, ntiles, tps, ksteps, kst_rows, pwin_c, NS, WN, WK, nslot, slot_bytes, co, ci_total,
+           nsegx, cx8; W3Div d_tx, d_ty; W3Op P, S; float* pw; float* pb; } p;
+  p.H = gp->H; p.W = gp->W; p.ks = gp->ks; p.taps = gp->taps; p.act = gp->act; p.x_is_s = gp->x_is_s; p.th = gp->th; p.tw = gp->tw;
+  p.tiles_x = gp->tiles_x; p.tiles_y = gp->tiles_y; p.ntiles = gp->ntiles; p.tps = gp->tps; p.ksteps = gp->ksteps; p.kst_rows = gp->kst_rows;
+  p.pwin_c = gp->pwin_c; p.NS = gp->NS; p.WN = gp->WN; p.WK = gp->WK; p.nslot = gp->nslot; p.slot_bytes = gp->slot_bytes; p.co = gp->co;
+  p.ci_total = gp->ci_total; p.nsegx = gp->nsegx; p.cx8 = gp->cx8; p.d_tx = gp->d_tx; p.d_ty = gp->d_ty; p.P = gp->P; p.S = gp->S;
+  p.pw = gp->pw; p.pb = gp->pb;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr)smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int WK = p.WK, WN = p.WN;
+  const int lwk = __builtin_ctz(WK), lwn = __builtin_ctz(WN);
+  const int wk = wave & (WK - 1), wn = (wave >> lwk) & (WN - 1), wm = wave >> (lwk + lwn);
+  const int H = p.H, W = p.W;
+  const bool x_is_s = p.x_is_s != 0;
+  const int t_begin = sp_i * p.tps, t_end = min(p.ntiles, t_begin + p.tps);
+  const int c0P = pwin * p.pwin_c;
+  const int widthP = min(p.pwin_c, p.P.c8 - c0P);
+
+  // ---- DMA lane constants
+  const W3Lane LP = w3_lane(gp, p.P, !x_is_s, c0P, widthP, lane);
+  const W3Lane LS = w3_lane(gp, p.S, x_is_s, 0, p.S.c8, lane);
+  const int nslot = p.nslot, slot_bytes = p.slot_bytes, pbytes = p.P.bytes;
+  const int haloS = p.S.halo, th = p.th, tw = p.tw;
+  auto issue = [&](const int t, const int slot) {
+    const int b1 = w3div(t, p.d_tx), tx = t - b1 * p.tiles_x;
+    const int n = w3div(b1, p.d_ty), ty = b1 - n * p.tiles_y;
+    const int y0 = ty * th, x0 = tx * tw;
+    const uint32_t sb = lds0 + slot * slot_bytes;
+    w3_issue_op(p.P, LP, n, y0, x0, H, W, sb, wave);
+    w3_issue_op(p.S, LS, n, y0 - haloS, x0 - haloS, H, W, sb + pbytes, wave);
+  };
+  // DMA instructions this wave issues per tile (instruction i goes to wave i & 3)
+  const int ipt = ((p.P.ninstr + 3 - wave) >> 2) + ((p.S.ninstr + 3 - wave) >> 2);
+
+  // ---- fragment lane constants.  16-lane group g: K half g >> 1 (pixels 8 (g >> 1) .. + 8 of the K16-step), channel / column half
+  // g & 1; lane t = 4 r + q of the group supplies (pixel r of the read, channels 4 q .. 4 q + 3) and receives column t's 4 pixels.
+  const int g = lane >> 4, t16 = lane & 15, r = t16 >> 2, q = t16 & 3;
+  const int kh = g >> 1, ch16 = g & 1;
+  const int spP = p.P.sp, spS = p.S.sp;
+  const int klin0 = 8 * kh + r;  // pixel of the FIRST read inside the K16-step (linear over the tile's pixels); second: + 4
+  const uint32_t lp0 = klin0 * spP + (ch16 * 16 + 4 * q) * 2 + (wm * MPW) * 64, lp1 = lp0 + 4 * spP;
+  uint32_t ls0[NSW], ls1[NSW];
+  {
+    const int cs8 = p.S.c8, ncols = p.taps * cs8;
+    const int py0 = tw == 16 ? 0 : klin0 >> 3, px0 = tw == 16 ? klin0 : klin0 & 7;           // first read's pixel inside the K-step
+    const int py1 = tw == 16 ? 0 : (klin0 + 4) >> 3, px1 = tw == 16 ? klin0 + 4 : (klin0 + 4) & 7;
+#pragma unroll
+    for (int j = 0; j < NSW; ++j) {
+      const int fs = min(wn * NSW + j, p.NS - 1);
+      int n = fs * 32 + ch16 * 16 + 4 * q;
+      if (n >= ncols) n = 0;  // padding column: any valid address (never stored)
+      const int tap = n / cs8, c = n - tap * cs8;
+      const int ey = p.ks == 3 ? tap / 3 : 0, ex = p.ks == 3 ? tap - 3 * ey : 0;
+      ls0[j] = ((py0 + ey) * p.S.rowpx + px0 + ex) * spS + c * 2;
+      ls1[j] = ((py1 + ey) * p.S.rowpx + px1 + ex) * spS + c * 2;
+    }
+  }
+  const int kstepP = 16 * spP, kstepS = p.kst_rows * p.S.rowpx * spS;
+  const int ksteps = p.ksteps;
+  const bool relu_p = p.act == CGEN_ACT_RELU && !x_is_s, relu_s = p.act == CGEN_ACT_RELU && x_is_s;
+  const bool gelu = p.act == CGEN_ACT_GELU;
+  const bool bias_p = p.pb != nullptr && x_is_s && wn == 0;                // G is the P operand: row sums of my P fragments
+  const bool bias_s = p.pb != nullptr && !x_is_s && wm == 0 && pwin == 0;  // G is the S operand: column sums of my S fragments
+
+  f32x16 acc[MPW][NSW];
+#pragma unroll
+  for (int i = 0; i < MPW; ++i)
+#pragma unroll
+    for (int j = 0; j < NSW; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  constexpr int NB = MPW > NSW ? MPW : NSW;
+  float bsum[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) bsum[i] = 0.f;
+
+  // ---- tile ring: tiles t .. t + nslot - 2 are in flight / resident while tile t is consumed; one barrier per tile
+  const int ahead = nslot - 1;
+  for (int k = 0; k < ahead; ++k)
+    if (t_begin + k < t_end) issue(t_begin + k, k);
+  int slot = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    {  // tile t has landed (this wave's requests; the barrier makes it everybody's)
+      const int later = min(t_end - 1 - t, ahead - 1);  // tiles after t already requested
+      w3_vmwait(later * ipt);
+      W3_BARRIER();  // ... and every wave is done with the slot the next request overwrites (tile t - 1's)
+    }
+    if (t + ahead < t_end) {
+      int s2 = slot + ahead;
+      if (s2 >= nslot) s2 -= nslot;
+      issue(t + ahead, s2);
+    }
+    const uint32_t bufP = lds0 + slot * slot_bytes, bufS = bufP + pbytes;
+    if (gelu) {  // in-place activation of the staged X tile (ReLU is applied to the fragments instead)
+      const uint32_t xb = x_is_s ? bufS : bufP;
+      const int nb16 = (x_is_s ? p.S.bytes : pbytes) >> 4;
+      for (int s = tid; s < nb16; s += 256) {
+        uint4* ptr = (uint4*)(smem + (xb - lds0) + s * 16);
+        *ptr = gelu8_fwd_h16(*ptr);
+      }
+      W3_BARRIER();
+    }
+#pragma unroll 2
+    for (int ks = wk; ks < ksteps; ks += WK) {
+      const uint32_t pa = bufP + ks * kstepP, sa = bufS + ks * kstepS;
+      h16x8 pf[MPW], sf[NSW];
+#pragma unroll
+      for (int i = 0; i < MPW; ++i) pf[i] = w3_tr(pa + lp0 + i * 64, pa + lp1 + i * 64);
+#pragma unroll
+      for (int j = 0; j < NSW; ++j) sf[j] = w3_tr(sa + ls0[j], sa + ls1[j]);
+      if (bias_p) {
+#pragma unroll
+        for (int i = 0; i < MPW; ++i) bsum[i] = w3_sum8(pf[i], bsum[i]);
+      }
+      if (bias_s) {
+#pragma unroll
+        for (int j = 0; j < NSW; ++j) bsum[j] = w3_sum8(sf[j], bsum[j]);
+      }
+      if (relu_p) {
+#pragma unroll
+        for (int i = 0; i < MPW; ++i) pf[i] = w3_relu8(pf[i]);
+      }
+      if (relu_s) {
+#pragma unroll
+        for (int j = 0; j < NSW; ++j) sf[j] = w3_relu8(sf[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < MPW; ++i)
+#pragma unroll
+        for (int j = 0; j < NSW; ++j) acc[i][j] = w3_mfma(pf[i], sf[j], acc[i][j]);
+    }
+    if (++slot == nslot) slot = 0;
+  }
+  // (the caller's barrier separates this problem's last LDS reads from the next problem's first DMA)
+
+  // ---- write the partial slab straight from the accumulators.  Fragment (i, j): lane l holds rows (e & 3) + 8 (e >> 2) + 4 (l >> 5),
+  // column l & 31: consecutive lanes -> consecutive (tap, channel) of S -> 128-byte runs in both layouts.
+  const int split_eff = sp_i * WK + wk;
+  const int taps = p.taps;
+  const int ncol = x_is_s ? p.ci_total : p.co;  // innermost extent of the partial layout
+  const int nrow = x_is_s ? p.co : p.ci_total;
+  float* const pw = p.pw + (size_t)split_eff * ((size_t)p.co * taps * p.ci_total);
+  {
+    const int cs8 = p.S.c8, ncols = taps * cs8;
+    int coff[NSW];  // tap * ncol + real column channel, -1: nothing to store
+#pragma unroll
+    for (int j = 0; j < NSW; ++j) {
+      const int fs = wn * NSW + j;
+      const int n = fs * 32 + (lane & 31);
+      coff[j] = -1;
+      if (fs < p.NS && n < ncols) {
+        const int tap = n / cs8, c8i = n - tap * cs8;
+        const int cc = x_is_s ? w3_xreal(gp, p.nsegx, p.cx8, c8i) : (c8i < p.co ? c8i : -1);
+        if (cc >= 0) coff[j] = tap * ncol + cc;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+      const int cwin = (wm * MPW + i) * 32;  // first window-relative channel of the fragment's rows
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+#pragma unroll
+        for (int e1 = 0; e1 < 4; ++e1) {
+          const int row = e1 + 8 * e4 + 4 * (lane >> 5);
+          const int pc = c0P + cwin + row;
+          int rr = -1;
+          if (cwin + row < widthP) rr = x_is_s ? (pc < p.co ? pc : -1) : w3_xreal(gp, p.nsegx, p.cx8, pc);
+          if (rr >= 0 && rr < nrow) {
+            float* const rowp = pw + (size_t)rr * taps * ncol;
+#pragma unroll
+            for (int j = 0; j < NSW; ++j)
+              if (coff[j] >= 0) rowp[coff[j]] = acc[i][j][e4 * 4 + e1];
+          }
+        }
+      }
+    }
+  }
+  if (bias_p || bias_s) {
+    float* const pb = p.pb + (size_t)split_eff * p.co;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);  // the two K halves of the fragment
+      if (lane < 32) {
+        if (bias_p && i < MPW) {
+          const int cwin = (wm * MPW + i) * 32 + lane;
+          const int co = c0P + cwin;
+          if (cwin < widthP && co < p.co) pb[co] = tot;
+        }
+        if (bias_s && i < NSW) {
+          const int fs = wn * NSW + i;
+          const int n = fs * 32 + lane;
+          const int cs8 = p.S.c8;
+          const int tap = n / cs8, c = n - tap * cs8;
+          if (fs < p.NS && tap == (taps >> 1) && c < p.co) pb[c] = tot;
+        }
+      }
+    }
+  }
+}
+
+#define W3_DISPATCH(p, a, b, c)                                  \
+  switch ((p)->variant) {                                          \
+    case 4 * 1 + 1: wg3_body<1, 1>(p, a, b); break;               \
+    case 4 * 1 + 2: wg3_body<1, 2>(p, a, b); break;               \
+    case 4 * 1 + 3: wg3_body<1, 3>(p, a, b); break;               \
+    case 4 * 2 + 1: wg3_body<2, 1>(p, a, b); break;               \
+    case 4 * 2 + 2: wg3_body<2, 2>(p, a, b); break;               \
+    case 4 * 2 + 3: wg3_body<2, 3>(p, a, b); break;               \
+    case 4 * 3 + 1: wg3_body<3, 1>(p, a, b); break;               \
+    case 4 * 3 + 2: wg3_body<3, 2>(p, a, b); break;               \
+    case 4 * 3 + 3: wg3_body<3, 3>(p, a, b); break;               \
+    case 4 * 4 + 1: wg3_body<4, 1>(p, a, b); break;               \
+    default: wg3_body<4, 2>(p, a, b); break;                      \
+  }
+
+__global__ __launch_bounds__(256, 2) void wg3_single_kernel(Wg3P p_) {
+  // (the record is read through a pointer, see w3_xreal: here it lives in the kernarg segment)
+  const Wg3P* __restrict__ gp = (const Wg3P*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int b = blockIdx.x;
+  const int ns = gp->nsplit;
+  const int pwin = b / ns, sp_i = b - pwin * ns;
+  W3_DISPATCH(gp, sp_i, pwin, 0)
+}
+
+// All problems of a flush in ONE launch (as wgrad_tile_mega_kernel): a resident set of workgroups walks the block list
+// (longest first), blocks[b] = {problem, split, P window, 0}; problems are read through a uniform pointer, by value.
+__global__ __launch_bounds__(256, 2) void wg3_mega_kernel(const Wg3P* __restrict__ probs, const int4* __restrict__ blocks, const int nblocks) {
+  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const int4 bi = blocks[b];
+    const Wg3P* __restrict__ gp = probs + __builtin_amdgcn_readfirstlane(bi.x);
+    const int sp_i = __builtin_amdgcn_readfirstlane(bi.y), pwin = __builtin_amdgcn_readfirstlane(bi.z);
+    W3_DISPATCH(gp, sp_i, pwin, 0)
+    __syncthreads();
+  }
+}
+
+// ============================================================================= host: plan
+static inline int w3_pad(int v, int m) { return (v + m - 1) / m * m; }
+static int w3_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+static void w3_mk_op(W3Op& o, int c8_staged, int sp, int rows, int rowpx, int halo, int c8_total) {
+  o.c8 = c8_total;
+  o.sp = sp; o.gpp = sp / 16; o.ppi = 64 / o.gpp;
+  o.rows = rows; o.rowpx = rowpx; o.npx = rows * rowpx; o.halo = halo;
+  o.ninstr = (o.npx + o.ppi - 1) / o.ppi;
+  o.bytes = o.ninstr * o.ppi * sp;
+  o.d_row = mk_w3div(rowpx); o.d_gpp = mk_w3div(o.gpp);
+  (void)c8_staged;
+}
+
+bool wg3_plan(const cgen_wgrad_args* a, Wg3Plan& g) {
+  static const int on = w3_env("CGEN_WG3", 1);
+  if (!on || a->dtype != CGEN_F16 || !(a->ks == 1 || a->ks == 3)) return false;
+  if (a->nseg < 1 || a->nseg > CGEN_MAX_SEG || !a->gout.p || a->gout.c <= 0) return false;
+  static const int min_hw = w3_env("CGEN_WG3_MINHW", 2);
+  if (a->h < min_hw || a->w < min_hw) return false;
+  if (!dma_clean(a->gout, 2)) return false;
+  for (int s = 0; s < a->nseg; ++s)
+    if (!dma_clean(a->seg[s], 2)) return false;
+  auto fits = [&](const cgen_view& v) {  // 32-bit byte offsets, tile overhang included
+    const int64_t ext = (int64_t)a->n * v.sn + (int64_t)(a->h + 34) * v.sh + (int64_t)(a->w + 34) * v.sw + v.c + 8;
+    return ext * 2 < ((int64_t)1 << 31) && v.sn >= 0 && v.sh >= 0 && v.sw >= 0;
+  };
+  if (!fits(a->gout)) return false;
+  for (int s = 0; s < a->nseg; ++s)
+    if (!fits(a->seg[s])) return false;
+
+  Wg3P& q = g.q;
+  memset(&q, 0, sizeof(q));
+  q.N = a->n; q.H = a->h; q.W = a->w; q.ks = a->ks; q.taps = a->ks * a->ks; q.act = a->act;
+  q.co = a->gout.c;
+  int k8 = 0, off = 0;
+  q.nsegx = a->nseg;
+  for (int s = 0; s < a->nseg; ++s) {
+    q.segx[s] = mk(a->seg[s]); q.x_k8[s] = k8; q.x_off[s] = off;
+    k8 += w3_pad(a->seg[s].c, 8); off += a->seg[s].c;
+  }
+  for (int s = a->nseg; s <= CGEN_MAX_SEG; ++s) q.x_k8[s] = k8;
+  q.ci_total = off;
+  q.cx8 = k8;
+  q.g = mk(a->gout);
+  const int cx8 = k8, cg8 = w3_pad(q.co, 8);
+  if ((int64_t)q.co * q.taps * q.ci_total >= ((int64_t)1 << 29)) return false;
+  // the narrower operand is the shifted, tap-packed one (ties: X, the standard partial layout)
+  q.x_is_s = cx8 <= cg8 ? 1 : 0;
+  const int cs8 = q.x_is_s ? cx8 : cg8, cp8 = q.x_is_s ? cg8 : cx8;
+  q.layout = q.x_is_s ? 0 : 1;
+  const int NS = (q.taps * cs8 + 31) / 32;
+  const int MPT = (cp8 + 31) / 32;
+  if (NS > 12) return false;  // (S windows: not built; the wide low-resolution layers stay with the older kernel)
+  q.NS = NS;
+
+  // ---- wave grid and per-wave fragment block: fewest P windows (each re-reads S), then fewest MFMA slots, then fewest LDS reads
+  static const int grids[6][3] = {{1, 4, 1}, {2, 2, 1}, {4, 1, 1}, {1, 2, 2}, {2, 1, 2}, {1, 1, 4}};
+  long best_key = -1;
+  int bWM = 1, bWN = 4, bWK = 1, bMPW = 1, bNSW = 1, bNWIN = 1;
+  for (int gi = 0; gi < 6; ++gi) {
+    const int WM = grids[gi][0], WN = grids[gi][1], WK = grids[gi][2];
+    const int NSW = (NS + WN - 1) / WN;
+    if (NSW > 3) continue;
+    const int mpw_max = NSW == 3 ? 3 : (NSW == 2 ? 4 : 4);
+    const int cap = WM * mpw_max;
+    const int nwin = (MPT + cap - 1) / cap;
+    const int mp_win = (MPT + nwin - 1) / nwin;  // balanced windows
+    const int MPW = (mp_win + WM - 1) / WM;
+    if (MPW == 4 && NSW == 3) continue;
+    // MFMA slots per K16-step of a tile, summed over the windows and normalised per wave
+    const long mfma = (long)nwin * MPW * NSW * 12 / WK;  // (x 12 keeps the division exact for WK in {1, 2, 4})
+    const long reads = (long)nwin * (MPW + NSW) * 12 / WK;
+    const long key = ((long)nwin << 40) + (mfma << 20) + reads;
+    if (best_key < 0 || key < best_key) { best_key = key; bWM = WM; bWN = WN; bWK = WK; bMPW = MPW; bNSW = NSW; bNWIN = nwin; }
+  }
+  if (best_key < 0) return false;
+  q.WM = bWM; q.WN = bWN; q.WK = bWK;
+  q.n_pwin = bNWIN;
+  q.MP = bMPW * bWM;
+  q.pwin_c = q.MP * 32;
+  q.n_pwin = (cp8 + q.pwin_c - 1) / q.pwin_c;
+  q.variant = bMPW * 4 + bNSW;
+
+  // ---- LDS pixel strides: P fragments read 64 contiguous bytes of 4 pixels -> stride = 64 x odd is conflict free; S (narrow,
+  // tap-packed) 16 x odd
+  const int wP = std::min(q.pwin_c, cp8);
+  int spP = w3_pad(wP * 2, 64);
+  if (((spP / 64) & 1) == 0) spP += 64;
+  int spS = w3_pad(cs8 * 2, 16);
+  if (((spS / 16) & 1) == 0) spS += 16;
+  static const int sp_plain = w3_env("CGEN_WG3_PLAINSTRIDE", 0);  // (A/B: no padding)
+  if (sp_plain) { spP = w3_pad(wP * 2, 16); spS = w3_pad(cs8 * 2, 16); }
+  if (spP > 1024 || spS > 1024) return false;
+
+  // ---- tile: tw = 16 (8 for narrow images), th from the LDS budget; ring of nslot tiles
+  static const int lds_cap = w3_env("CGEN_WG3_LDS", 48) * 1024;
+  static const int want_slots = w3_env("CGEN_WG3_SLOTS", 3);
+  static const int force_tpx = w3_env("CGEN_WG3_TPX", 0);
+  const int halo = a->ks == 3 ? 1 : 0;
+  q.tw = a->w >= 12 ? 16 : 8;
+  q.kst_rows = 16 / q.tw;
+  const int hpad = w3_pad(a->h, q.kst_rows);
+  static const int tpx_order[3] = {64, 128, 32};
+  int pick = -1, pick_slots = 0;
+  for (int pass = 0; pass < 2 && pick < 0; ++pass) {
+    for (int k = 0; k < 3; ++k) {
+      const int tpx = force_tpx ? force_tpx : tpx_order[k];
+      int th = tpx / q.tw;
+      if (th < q.kst_rows) continue;
+      if (th > hpad && tpx != tpx_order[2] && !force_tpx) continue;  // (a tile taller than the image: only as the last resort)
+      W3Op P, S;
+      w3_mk_op(P, wP, spP, th, q.tw, 0, cp8);
+      w3_mk_op(S, cs8, spS, th + 2 * halo, q.tw + 2 * halo, halo, cs8);
+      const int slot = w3_pad(P.bytes + S.bytes, 16);
+      const int ns = std::min(want_slots + 1, lds_cap / slot);
+      if (ns >= (pass == 0 ? want_slots : 2)) { pick = tpx; pick_slots = std::min(ns, want_slots); break; }
+      if (force_tpx) break;
+    }
+  }
+  if (pick < 0) return false;
+  q.th = pick / q.tw;
+  w3_mk_op(q.P, wP, spP, q.th, q.tw, 0, cp8);
+  w3_mk_op(q.S, cs8, spS, q.th + 2 * halo, q.tw + 2 * halo, halo, cs8);
+  q.slot_bytes = w3_pad(q.P.bytes + q.S.bytes, 16);
+  q.nslot = pick_slots;
+  q.ksteps = q.th * q.tw / 16;
+  q.tiles_x = (a->w + q.tw - 1) / q.tw; q.tiles_y = (a->h + q.th - 1) / q.th;
+  q.ntiles = a->n * q.tiles_x * q.tiles_y;
+  q.d_tx = mk_w3div(q.tiles_x); q.d_ty = mk_w3div(q.tiles_y);
+  if (ceil_div(q.P.ninstr, 4) + ceil_div(q.S.ninstr, 4) > 48 / std::max(1, q.nslot - 2)) {
+    // (more requests per wave in flight than the counted-wait table holds: w3_vmwait would fall back to vmcnt(0) -- correct, slower)
+  }
+
+  // ---- split-K: a workgroup's partial slab (written + re-read by the reduce) must stay a few % of the bytes it streams
+  const long dbytes = 4L * q.co * q.taps * q.ci_total;
+  const long tile_bytes = 2L * (q.th * q.tw * (long)cp8 + (long)q.n_pwin * q.S.npx * cs8);
+  static const int part_pct = w3_env("CGEN_WG3_PARTIAL_PCT", 8);
+  static const int max_split = w3_env("CGEN_WG3_MAXSPLIT", 64);
+  static const int min_tps = w3_env("CGEN_WG3_MINTPS", 4);
+  long tps = (2 * dbytes * 100 + part_pct * tile_bytes - 1) / (part_pct * tile_bytes);
+  tps = std::max<long>(tps, min_tps);
+  tps = std::max<long>(tps, ceil_div(q.ntiles, std::max(1, max_split / (q.n_pwin * q.WK))));
+  tps = std::min<long>(tps, q.ntiles);
+  q.tps = (int)tps;
+  q.nsplit = ceil_div(q.ntiles, q.tps);
+  g.nsplit_total = q.nsplit * q.WK;
+  g.nblocks = q.nsplit * q.n_pwin;
+  g.lds = (size_t)q.nslot * q.slot_bytes;
+  g.block_bytes = (long)q.tps * (2L * (q.th * q.tw * (long)wP + (long)q.S.npx * cs8));
+  q.pw = a->partial_w; q.pb = a->partial_b;
+  if (getenv("CGEN_WG3_PLAN_DEBUG"))
+    fprintf(stderr, "wg3 plan: %dx%dx%d ks%d cx8 %3d co %3d act %d | S=%s cs8 %3d NS %2d | cp8 %3d pwin %3d x%d | grid %dx%dx%d frag %dx%d | tile %2dx%2d sp %3d/%3d "
+            "instr %2d+%2d slot %5d x%d | tiles %5d tps %4d nsplit %3d (x%d) blocks %4d\n",
+            a->n, a->h, a->w, a->ks, cx8, q.co, a->act, q.x_is_s ? "X" : "G", cs8, NS, cp8, q.pwin_c, q.n_pwin, q.WM, q.WN, q.WK, q.variant / 4, q.variant % 4,
+            q.th, q.tw, spP, spS, q.P.ninstr, q.S.ninstr, q.slot_bytes, q.nslot, q.ntiles, q.tps, q.nsplit, q.WK, g.nblocks);
+  return true;
+}
+
+static void w3_attr_once() {
+  static bool once = false;
+  if (!once) {
+    (void)hipFuncSetAttribute((const void*)wg3_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)wg3_mega_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once = true;
+  }
+}
+
+void wg3_launch_single(const Wg3Plan& g, hipStream_t st) {
+  w3_attr_once();
+  hipLaunchKernelGGL(wg3_single_kernel, dim3(g.nblocks), dim3(256), g.lds, st, g.q);
+}
+
+void wg3_launch_mega(const Wg3P* probs_dev, const int4* blocks_dev, int nblocks, int grid, size_t lds, hipStream_t st) {
+  w3_attr_once();
+  hipLaunchKernelGGL(wg3_mega_kernel, dim3(grid), dim3(256), lds, st, probs_dev, blocks_dev, nblocks);
+}
+
+}  // namespace cgen

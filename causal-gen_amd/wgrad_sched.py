@@ -32,10 +32,12 @@ class WgradMixin:
         ent = self._partials.get(key)
         nw = site.co * site.taps * site.ci
         if ent is None:
-            nsplit = self.lib.conv2d_wgrad_plan(C.byref(a), None)
-            ent = (torch.empty(nsplit * (nw + site.co), dtype=torch.float32, device=self.device), nsplit)
+            kind = C.c_int32(0)
+            nsplit = self.lib.conv2d_wgrad_plan(C.byref(a), C.byref(kind))
+            # (kind 3: the streaming kernel leaves its partials as [ci][flipped tap][co]; cgen_wgrad_reduce is told so)
+            ent = (torch.empty(nsplit * (nw + site.co), dtype=torch.float32, device=self.device), nsplit, 1 if kind.value == 3 else 0)
             self._partials[key] = ent  # (reduce tables are keyed by these keys: a new key cannot invalidate an existing table)
-        buf, nsplit = ent
+        buf, nsplit, _layout = ent
         a.nsplit = nsplit
         a.partial_w = buf.data_ptr()
         a.partial_b = buf.data_ptr() + 4 * nsplit * nw if site.conv.bias is not None else None
@@ -119,7 +121,7 @@ class WgradMixin:
                 ["%x-%x" % (c.data_ptr(), c.data_ptr() + c.numel()) for c in self.arena.chunks],
                 ["%x-%x" % (a.partial_w, a.partial_w + 1) for a in args][:4],
                 "%x-%x" % (self.flat_g.data_ptr(), self.flat_g.data_ptr() + 4 * self.flat_g.numel())), flush=True)
-            for key, (buf, ns) in list(self._partials.items())[-4:]:
+            for key, (buf, ns, _lay) in list(self._partials.items())[-4:]:
                 print("   partial %s: %x-%x nsplit %d" % (key, buf.data_ptr(), buf.data_ptr() + 4 * buf.numel(), ns), flush=True)
         arr = (_lib.WgradArgs * n)(*args)
         key = bytes(arr)
@@ -251,6 +253,7 @@ class WgradMixin:
                 d.grad_w = self.param_grad_ptr(site.conv.weight)
                 d.grad_b = self.param_grad_ptr(site.conv.bias) if site.conv.bias is not None else None
                 d.co, d.ci_total, d.ks, d.nsplit = site.co, site.ci, site.ks, nsplit
+                d.layout = self._partials[key][2]
                 d.accumulate = 1 if acc else 0
                 d.unscale = 1.0 / self.loss_scale
                 d.numel = nw + (site.co if site.conv.bias is not None else 0)

@@ -52,7 +52,7 @@ typedef struct cgen_view {
 /* ABI version of this header.  cgen_version() of the loaded library must equal it (causal-gen_amd/_lib.py checks): struct layouts,
  * enum values and signatures are only compatible within one version.  cgen_h16_format(): the 16-bit storage format the library was
  * BUILT for -- 0 = IEEE binary16 (default), 1 = bfloat16 (-DCGEN_H16_BF16, an A/B build); CGEN_F16 tensors must be in that format. */
-#define CGEN_ABI_VERSION 401
+#define CGEN_ABI_VERSION 402
 int cgen_version(void);
 int cgen_h16_format(void);
 const char* cgen_last_error(void);
@@ -116,9 +116,11 @@ int cgen_block3(const cgen_block3_args* a, cgen_stream_t stream);
 
 /* Weight gradient (aten::convolution_backward, weight/bias part) as split-K partials:
  *   partial_w[split][Co][KS*KS][Ci_total] (f32), partial_b[split][Co] (f32, may be NULL)
- * with Ci_total = sum_s seg[s].c and nsplit = cgen_conv2d_wgrad_plan(args) (call it with the views filled in; it also
- * reports whether the streaming tiled 16-bit (CGEN_F16) kernel will serve the call).  Deterministic: partials are summed in a fixed
- * order by cgen_wgrad_reduce. */
+ * with Ci_total = sum_s seg[s].c and nsplit = cgen_conv2d_wgrad_plan(args) (call it with the views filled in).  *tiled_out says
+ * which kernel will serve the call and in which layout it leaves partial_w: 0 = generic kernel, 1 = tiled 16-bit (CGEN_F16) kernel,
+ * 2 = streaming kernel of round 5 (csrc/wgrad3.hip) -- all three the layout above --, 3 = streaming kernel with grad_out as its
+ * shifted operand: partial_w[split][Ci_total][KS*KS - 1 - tap][Co] (pass cgen_wred_desc.layout = 1 to cgen_wgrad_reduce).
+ * Deterministic: partials are summed in a fixed order by cgen_wgrad_reduce. */
 typedef struct cgen_wgrad_args {
   int32_t dtype, n, h, w, ks, nseg, act, nsplit;
   cgen_view seg[CGEN_MAX_SEG];
@@ -173,6 +175,8 @@ typedef struct cgen_wred_desc { /* split-K partials -> OIHW f32 gradient (+bias 
   int32_t co, ci_total, ks, nsplit;
   int32_t accumulate;
   float unscale; /* the sums are multiplied by this (1 / loss scale of the f16 engine); 0 means 1 */
+  int32_t layout; /* of partial_w, as reported by cgen_conv2d_wgrad_plan: 0 = [split][Co][tap][Ci], 1 = [split][Ci][KS*KS-1-tap][Co] */
+  int32_t reserved;
   int64_t numel; /* co*ci_total*ks*ks + co */
 } cgen_wred_desc;
 int cgen_wgrad_reduce(const cgen_wred_desc* descs_dev, const int32_t* chunk_site_dev, const int32_t* chunk_index_dev,

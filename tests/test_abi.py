@@ -65,6 +65,12 @@ def test_pure_queries_and_arg_validation_without_gpu():
     w.seg[0] = _lib.View(4096, 192 * 192 * 32, 192 * 32, 32, 32, 0)
     w.gout = _lib.View(8192, 192 * 192 * 8, 192 * 8, 8, 8, 0)
     tiled = ctypes.c_int32(-1)
+    # 32 -> 8 channels, 3x3: the streaming kernel (round 5) takes it with grad_out (the narrow operand) as the shifted one => layout 1
+    assert lib.conv2d_wgrad_plan(ctypes.byref(w), ctypes.byref(tiled)) >= 1 and tiled.value == 3
+    w.seg[0], w.gout = _lib.View(8192, 192 * 192 * 8, 192 * 8, 8, 8, 0), _lib.View(4096, 192 * 192 * 32, 192 * 32, 32, 32, 0)
+    assert lib.conv2d_wgrad_plan(ctypes.byref(w), ctypes.byref(tiled)) >= 1 and tiled.value == 2  # 8 -> 32: X is the narrow operand
+    w.ks = 7  # the 7x7 stem stays with the tiled kernel of rounds 2-4
+    w.seg[0] = _lib.View(4096, 192 * 192 * 8, 192 * 8, 8, 1, 8)
     assert lib.conv2d_wgrad_plan(ctypes.byref(w), ctypes.byref(tiled)) >= 1 and tiled.value == 1
     # argument validation happens before any launch, so it is testable on a CPU-only host
     a = _lib.ConvArgs()
