@@ -546,7 +546,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "hipgraph": not a.no_graph, "params": sum(p.numel() for p in m.parameters())},
             "elbo_nats_per_dim": elbo, "nll": nll, "kl": kl, "opt_steps": stats["opt_steps"], "skipped": stats["n_skipped"],
-            "wgrad_partial_bytes_per_step": sum(b.numel() * 4 for b, _ in ts.eng._partials.values()),
+            "wgrad_partial_bytes_per_step": sum(e[0].numel() * 4 for e in ts.eng._partials.values()),
             "arena_bytes": ts.eng.arena.high_water, "launches_per_step": roof.get("launches_per_step"),
             "model_tflops": img_s * gf * 1e9 / 1e12,
             "model_mfma_frac": img_s * gf * 1e9 / 1e12 / (MFMA_PEAK_TF[a.dtype] * world),
