@@ -2836,7 +2836,7 @@ extern "C" int cgen_conv2d_wgrad_batch_plan(const cgen_wgrad_args* args, int32_t
     for (int k = 0; k < maxb; ++k)
       for (size_t i = 0; i < items3.size(); ++i) {
         const Wg3P& q3 = items3[i].g.q;
-        if (k < items3[i].g.nblocks) { blocks3[b3] = make_int4((int)i, k % q3.nsplit, k / q3.nsplit, 0); ++b3; }
+        if (k < items3[i].g.nblocks) { const int w = k / q3.nsplit; blocks3[b3] = make_int4((int)i, k % q3.nsplit, w % q3.n_pwin, w / q3.n_pwin); ++b3; }
       }
   }
   return CGEN_OK;

@@ -33,7 +33,8 @@ struct Wg3P {
   W3Op P, S;
   int pwin_c, n_pwin, MP, NS;  // channels per P window (multiple of 32), windows, P fragments per window, S fragments
   int WM, WN, WK;              // wave grid: P-fragment blocks x S-fragment blocks x K split (WM * WN * WK = 4)
-  int variant;                 // MPW * 4 + NSW
+  int variant;                 // MPW * 8 + NSW
+  int n_swin, pad1;            // S fragment windows (WN * NSW fragments each): low-resolution layers whose tap-packed axis exceeds 16 fragments
   int nslot, slot_bytes;       // tile ring
   int layout;                  // partial layout: 0 = [split][co][tap][ci], 1 = [split][ci][flipped tap][co]
   int co, ci_total;
@@ -50,8 +51,8 @@ struct Wg3P {
 
 struct Wg3Plan {
   Wg3P q;          // everything but pw / pb filled in
-  int nsplit_total;  // nsplit * WK: what the caller sizes the partial buffers with
-  int nblocks;       // workgroups: nsplit * n_pwin
+  int nsplit_total;  // = nsplit: what the caller sizes the partial buffers with
+  int nblocks;       // workgroups: nsplit * n_pwin * n_swin
   size_t lds;
   long block_bytes;  // HBM bytes one workgroup moves (sort key of the packed launch)
 };
@@ -59,7 +60,7 @@ struct Wg3Plan {
 // false: the problem is not served by this kernel (the caller falls back to the older kernels)
 bool wg3_plan(const cgen_wgrad_args* a, Wg3Plan& g);
 void wg3_launch_single(const Wg3Plan& g, hipStream_t st);
-// packed form: `probs` is a device table of Wg3P, blocks[b] = {problem, split, window, 0}
+// packed form: `probs` is a device table of Wg3P, blocks[b] = {problem, split, P window, S window}
 void wg3_launch_mega(const Wg3P* probs_dev, const int4* blocks_dev, int nblocks, int grid, size_t lds, hipStream_t st);
 
 }  // namespace cgen

@@ -33,6 +33,8 @@ typedef short w3s16x4 __attribute__((ext_vector_type(4)));
 typedef short w3s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ uint4 g_w3zero[4];  // DMA source of out-of-image pixels
+#define W3_PN 6  // DMA instructions per wave and tile whose lane offsets live in registers: P tile, S tile
+#define W3_SN 3
 
 static inline W3Div mk_w3div(uint32_t d) {  // round-up method, exact for 0 <= n < 2^31 (as FastDiv in conv.hip)
   W3Div f;
@@ -52,16 +54,200 @@ __device__ __forceinline__ void w3_dma16(const char* src, const uint32_t lds) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds) : "memory");
 }
 #define W3_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-// wait until at most n of this wave's DMA requests are outstanding (n is wave-uniform; requests return in order)
-__device__ __forceinline__ void w3_vmwait(const int n) {
-#define W3_C(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-  switch (n) {
-    W3_C(1) W3_C(2) W3_C(3) W3_C(4) W3_C(5) W3_C(6) W3_C(7) W3_C(8) W3_C(9) W3_C(10) W3_C(11) W3_C(12) W3_C(13) W3_C(14) W3_C(15) W3_C(16)
-    W3_C(17) W3_C(18) W3_C(19) W3_C(20) W3_C(21) W3_C(22) W3_C(23) W3_C(24) W3_C(25) W3_C(26) W3_C(27) W3_C(28) W3_C(29) W3_C(30) W3_C(31) W3_C(32)
-    W3_C(33) W3_C(34) W3_C(35) W3_C(36) W3_C(37) W3_C(38) W3_C(39) W3_C(40) W3_C(41) W3_C(42) W3_C(43) W3_C(44) W3_C(45) W3_C(46) W3_C(47) W3_C(48)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // (0, or more than the table holds: waiting for everything is always safe)
+// wait until at most n of this wave's DMA requests are outstanding (n is wave-uniform; requests return in order).  s_waitcnt takes
+// an immediate: a binary decision tree over 0 .. 47 (six scalar branches; a 48-way switch compiled to a compare chain of ~500
+// cycles per tile -- stamps, LABNOTES 10.1); anything above waits for 47, which is more than asked: always safe.
+__device__ __forceinline__ void w3_vmwait(int n) {
+  n = n > 47 ? 47 : n;
+  if (n < 24) {
+    if (n < 12) {
+      if (n < 6) {
+        if (n < 3) {
+          if (n < 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          } else {
+            if (n < 2) {
+              asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            }
+          }
+        } else {
+          if (n < 4) {
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+          } else {
+            if (n < 5) {
+              asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            }
+          }
+        }
+      } else {
+        if (n < 9) {
+          if (n < 7) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+          } else {
+            if (n < 8) {
+              asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            }
+          }
+        } else {
+          if (n < 10) {
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+          } else {
+            if (n < 11) {
+              asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            }
+          }
+        }
+      }
+    } else {
+      if (n < 18) {
+        if (n < 15) {
+          if (n < 13) {
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          } else {
+            if (n < 14) {
+              asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            }
+          }
+        } else {
+          if (n < 16) {
+            asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+          } else {
+            if (n < 17) {
+              asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+            }
+          }
+        }
+      } else {
+        if (n < 21) {
+          if (n < 19) {
+            asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+          } else {
+            if (n < 20) {
+              asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            }
+          }
+        } else {
+          if (n < 22) {
+            asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+          } else {
+            if (n < 23) {
+              asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(23)" ::: "memory");
+            }
+          }
+        }
+      }
+    }
+  } else {
+    if (n < 36) {
+      if (n < 30) {
+        if (n < 27) {
+          if (n < 25) {
+            asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+          } else {
+            if (n < 26) {
+              asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+            }
+          }
+        } else {
+          if (n < 28) {
+            asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+          } else {
+            if (n < 29) {
+              asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(29)" ::: "memory");
+            }
+          }
+        }
+      } else {
+        if (n < 33) {
+          if (n < 31) {
+            asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+          } else {
+            if (n < 32) {
+              asm volatile("s_waitcnt vmcnt(31)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            }
+          }
+        } else {
+          if (n < 34) {
+            asm volatile("s_waitcnt vmcnt(33)" ::: "memory");
+          } else {
+            if (n < 35) {
+              asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(35)" ::: "memory");
+            }
+          }
+        }
+      }
+    } else {
+      if (n < 42) {
+        if (n < 39) {
+          if (n < 37) {
+            asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+          } else {
+            if (n < 38) {
+              asm volatile("s_waitcnt vmcnt(37)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+            }
+          }
+        } else {
+          if (n < 40) {
+            asm volatile("s_waitcnt vmcnt(39)" ::: "memory");
+          } else {
+            if (n < 41) {
+              asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(41)" ::: "memory");
+            }
+          }
+        }
+      } else {
+        if (n < 45) {
+          if (n < 43) {
+            asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
+          } else {
+            if (n < 44) {
+              asm volatile("s_waitcnt vmcnt(43)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(44)" ::: "memory");
+            }
+          }
+        } else {
+          if (n < 46) {
+            asm volatile("s_waitcnt vmcnt(45)" ::: "memory");
+          } else {
+            if (n < 47) {
+              asm volatile("s_waitcnt vmcnt(46)" ::: "memory");
+            } else {
+              asm volatile("s_waitcnt vmcnt(47)" ::: "memory");
+            }
+          }
+        }
+      }
+    }
   }
-#undef W3_C
 }
 
 __device__ __forceinline__ h16x8 w3_tr(const uint32_t a0, const uint32_t a1) {
@@ -139,13 +325,14 @@ __device__ __forceinline__ W3Lane w3_lane(const Wg3P* __restrict__ gp, const W3O
   return L;
 }
 
-// the tile of operand `o` whose first pixel is (n, y0, x0) -> LDS at `dst`, this wave's share of the DMA instructions
+// the tile of operand `o` whose first pixel is (n, y0, x0) -> LDS at `dst`: instructions first, first + 4, ... (the general, slow form:
+// a division and the image-border test per lane and instruction)
 __device__ __forceinline__ void w3_issue_op(const W3Op& o, const W3Lane& L, const int n, const int y0, const int x0, const int H, const int W,
-                                            const uint32_t dst, const int wave) {
+                                            const uint32_t dst, const int first) {
   const char* const zero = (const char*)g_w3zero;
   const int noff = n * L.sn;
   const int step = o.ppi * o.sp;
-  for (int i = wave; i < o.ninstr; i += 4) {
+  for (int i = first; i < o.ninstr; i += 4) {
     const int lin = i * o.ppi + L.pl;
     const int ry = w3div(lin, o.d_row), rx = lin - ry * o.rowpx;
     const int gy = y0 + ry, gx = x0 + rx;
@@ -156,7 +343,7 @@ __device__ __forceinline__ void w3_issue_op(const W3Op& o, const W3Lane& L, cons
 }
 
 template <int MPW, int NSW>
-__device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int sp_i, const int pwin) {
+__device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int sp_i, const int pwin, const int swin) {
   // the hot fields of the problem record, once (scalar loads); everything lane-indexed goes through gp
   struct { int H, W, ks, taps, act, x_is_s, th, tw, tiles_x, tiles_y, ntiles, tps, ksteps, kst_rows, pwin_c, NS, WN, WK, nslot, slot_bytes, co, ci_total,
            nsegx, cx8; W3Div d_tx, d_ty; W3Op P, S; float* pw; float* pb; } p;
@@ -178,18 +365,73 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
   const int c0P = pwin * p.pwin_c;
   const int widthP = min(p.pwin_c, p.P.c8 - c0P);
 
-  // ---- DMA lane constants
+  // ---- DMA lane constants.  Everything about a lane's share of a tile but the tile origin is a launch constant: the byte offset of
+  // its pixel of the wave's k-th P / S instruction (poff / soff), that pixel's (row, column) inside the S tile for the image-border
+  // test (syx, 6 bits each), and whether the slot carries data at all (vmask).  Per tile and instruction that leaves a 64-bit add and
+  // a select (interior tiles) -- the first version redid a division and three multiplies per instruction: ~350 cycles each, 2000 per
+  // tile (stamps, LABNOTES 10.1).  Instructions beyond the W3_PN / W3_SN kept in registers, and ragged P tiles, take the slow path.
   const W3Lane LP = w3_lane(gp, p.P, !x_is_s, c0P, widthP, lane);
   const W3Lane LS = w3_lane(gp, p.S, x_is_s, 0, p.S.c8, lane);
   const int nslot = p.nslot, slot_bytes = p.slot_bytes, pbytes = p.P.bytes;
   const int haloS = p.S.halo, th = p.th, tw = p.tw;
+  int poff[W3_PN], soff[W3_SN];
+  uint32_t syx[(W3_SN + 1) / 2], vmask = 0;
+#pragma unroll
+  for (int k = 0; k < (W3_SN + 1) / 2; ++k) syx[k] = 0;
+#pragma unroll
+  for (int k = 0; k < W3_PN; ++k) {
+    const int lin = (wave + 4 * k) * p.P.ppi + LP.pl;
+    const int ry = w3div(lin, p.P.d_row), rx = lin - ry * p.P.rowpx;
+    poff[k] = ry * LP.sh + rx * LP.sw;
+    if (LP.data && lin < p.P.npx && wave + 4 * k < p.P.ninstr) vmask |= 1u << k;
+  }
+#pragma unroll
+  for (int k = 0; k < W3_SN; ++k) {
+    const int lin = (wave + 4 * k) * p.S.ppi + LS.pl;
+    const int ry = w3div(lin, p.S.d_row), rx = lin - ry * p.S.rowpx;
+    soff[k] = ry * LS.sh + rx * LS.sw;
+    syx[k >> 1] |= (uint32_t)((ry & 63) << 6 | (rx & 63)) << (12 * (k & 1));
+    if (LS.data && lin < p.S.npx && wave + 4 * k < p.S.ninstr) vmask |= 1u << (8 + k);
+  }
+  const int stepP = p.P.ppi * p.P.sp, stepS = p.S.ppi * p.S.sp;
+  const int ninP = p.P.ninstr, ninS = p.S.ninstr;
+  const char* const zero = (const char*)g_w3zero;
   auto issue = [&](const int t, const int slot) {
     const int b1 = w3div(t, p.d_tx), tx = t - b1 * p.tiles_x;
     const int n = w3div(b1, p.d_ty), ty = b1 - n * p.tiles_y;
     const int y0 = ty * th, x0 = tx * tw;
     const uint32_t sb = lds0 + slot * slot_bytes;
-    w3_issue_op(p.P, LP, n, y0, x0, H, W, sb, wave);
-    w3_issue_op(p.S, LS, n, y0 - haloS, x0 - haloS, H, W, sb + pbytes, wave);
+    // P: no halo; a tile inside the image needs no per-lane test at all
+    if (y0 + th <= H && x0 + tw <= W) {
+      const char* const bp = LP.base + (n * LP.sn + y0 * LP.sh + x0 * LP.sw);
+#pragma unroll
+      for (int k = 0; k < W3_PN; ++k)
+        if (wave + 4 * k < ninP) {
+          const char* src = ((vmask >> k) & 1) ? bp + poff[k] : zero;
+          if (LP.active) w3_dma16(src, __builtin_amdgcn_readfirstlane(sb + (wave + 4 * k) * stepP));
+        }
+      if (wave + 4 * W3_PN < ninP) w3_issue_op(p.P, LP, n, y0, x0, H, W, sb, wave + 4 * W3_PN);
+    } else {
+      w3_issue_op(p.P, LP, n, y0, x0, H, W, sb, wave);
+    }
+    {
+      const int ys = y0 - haloS, xs = x0 - haloS;
+      const bool inside = ys >= 0 && xs >= 0 && ys + p.S.rows <= H && xs + p.S.rowpx <= W;  // (wave-uniform)
+      const char* const bs = LS.base + (n * LS.sn + ys * LS.sh + xs * LS.sw);
+#pragma unroll
+      for (int k = 0; k < W3_SN; ++k)
+        if (wave + 4 * k < ninS) {
+          bool ok = ((vmask >> (8 + k)) & 1) != 0;
+          if (!inside) {
+            const uint32_t f = syx[k >> 1] >> (12 * (k & 1));
+            const int gy = ys + (int)((f >> 6) & 63), gx = xs + (int)(f & 63);
+            ok = ok && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+          }
+          const char* src = ok ? bs + soff[k] : zero;
+          if (LS.active) w3_dma16(src, __builtin_amdgcn_readfirstlane(sb + pbytes + (wave + 4 * k) * stepS));
+        }
+      if (wave + 4 * W3_SN < ninS) w3_issue_op(p.S, LS, n, ys, xs, H, W, sb + pbytes, wave + 4 * W3_SN);
+    }
   };
   // DMA instructions this wave issues per tile (instruction i goes to wave i & 3)
   const int ipt = ((p.P.ninstr + 3 - wave) >> 2) + ((p.S.ninstr + 3 - wave) >> 2);
@@ -201,6 +443,7 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
   const int spP = p.P.sp, spS = p.S.sp;
   const int klin0 = 8 * kh + r;  // pixel of the FIRST read inside the K16-step (linear over the tile's pixels); second: + 4
   const uint32_t lp0 = klin0 * spP + (ch16 * 16 + 4 * q) * 2 + (wm * MPW) * 64, lp1 = lp0 + 4 * spP;
+  const int fs0 = swin * (WN * NSW);  // first S fragment of this workgroup's column window
   uint32_t ls0[NSW], ls1[NSW];
   {
     const int cs8 = p.S.c8, ncols = p.taps * cs8;
@@ -208,11 +451,11 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
     const int py1 = tw == 16 ? 0 : (klin0 + 4) >> 3, px1 = tw == 16 ? klin0 + 4 : (klin0 + 4) & 7;
 #pragma unroll
     for (int j = 0; j < NSW; ++j) {
-      const int fs = min(wn * NSW + j, p.NS - 1);
+      const int fs = min(fs0 + wn * NSW + j, p.NS - 1);
       int n = fs * 32 + ch16 * 16 + 4 * q;
       if (n >= ncols) n = 0;  // padding column: any valid address (never stored)
       const int tap = n / cs8, c = n - tap * cs8;
-      const int ey = p.ks == 3 ? tap / 3 : 0, ex = p.ks == 3 ? tap - 3 * ey : 0;
+      const int ey = tap / p.ks, ex = tap - p.ks * ey;
       ls0[j] = ((py0 + ey) * p.S.rowpx + px0 + ex) * spS + c * 2;
       ls1[j] = ((py1 + ey) * p.S.rowpx + px1 + ex) * spS + c * 2;
     }
@@ -221,7 +464,7 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
   const int ksteps = p.ksteps;
   const bool relu_p = p.act == CGEN_ACT_RELU && !x_is_s, relu_s = p.act == CGEN_ACT_RELU && x_is_s;
   const bool gelu = p.act == CGEN_ACT_GELU;
-  const bool bias_p = p.pb != nullptr && x_is_s && wn == 0;                // G is the P operand: row sums of my P fragments
+  const bool bias_p = p.pb != nullptr && x_is_s && wn == 0 && swin == 0;                // G is the P operand: row sums of my P fragments
   const bool bias_s = p.pb != nullptr && !x_is_s && wm == 0 && pwin == 0;  // G is the S operand: column sums of my S fragments
 
   f32x16 acc[MPW][NSW];
@@ -236,22 +479,33 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
 #pragma unroll
   for (int i = 0; i < NB; ++i) bsum[i] = 0.f;
 
+  // optional cycle stamps (CGEN_WG3_STAMPS=<device address of 256 u64>, tools/wg3_stamps.py): first lane of every wave of the
+  // launch's first block, 4 stamps per tile for the first 14 tiles after 2 set-up stamps
+  unsigned long long* const stamp = (gp->stamps != nullptr && blockIdx.x == 0 && sp_i == 0 && pwin == 0 && swin == 0 && lane == 0) ? gp->stamps + wave * 64 : nullptr;
+  int nst = 0;
+#define W3_STAMP() do { if (stamp && nst < 62) stamp[nst++] = __builtin_readcyclecounter(); } while (0)
+  W3_STAMP();
   // ---- tile ring: tiles t .. t + nslot - 2 are in flight / resident while tile t is consumed; one barrier per tile
   const int ahead = nslot - 1;
+  const int dbg = gp->dbg;  // ablation (CGEN_WG3_DBG, wrong results): 1 no DMA, 2 no fragment reads / MFMAs
   for (int k = 0; k < ahead; ++k)
-    if (t_begin + k < t_end) issue(t_begin + k, k);
+    if (t_begin + k < t_end && !(dbg & 1)) issue(t_begin + k, k);
   int slot = 0;
+  W3_STAMP();
   for (int t = t_begin; t < t_end; ++t) {
     {  // tile t has landed (this wave's requests; the barrier makes it everybody's)
       const int later = min(t_end - 1 - t, ahead - 1);  // tiles after t already requested
       w3_vmwait(later * ipt);
+      W3_STAMP();
       W3_BARRIER();  // ... and every wave is done with the slot the next request overwrites (tile t - 1's)
+      W3_STAMP();
     }
-    if (t + ahead < t_end) {
+    if (t + ahead < t_end && !(dbg & 1)) {
       int s2 = slot + ahead;
       if (s2 >= nslot) s2 -= nslot;
       issue(t + ahead, s2);
     }
+    W3_STAMP();
     const uint32_t bufP = lds0 + slot * slot_bytes, bufS = bufP + pbytes;
     if (gelu) {  // in-place activation of the staged X tile (ReLU is applied to the fragments instead)
       const uint32_t xb = x_is_s ? bufS : bufP;
@@ -262,14 +516,15 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
       }
       W3_BARRIER();
     }
-#pragma unroll 2
-    for (int ks = wk; ks < ksteps; ks += WK) {
+    // K16-steps of the tile: the fragment reads of step k + 1 are issued before the MFMAs of step k (two register sets)
+    auto load = [&](const int ks, h16x8 (&pf)[MPW], h16x8 (&sf)[NSW]) {
       const uint32_t pa = bufP + ks * kstepP, sa = bufS + ks * kstepS;
-      h16x8 pf[MPW], sf[NSW];
 #pragma unroll
       for (int i = 0; i < MPW; ++i) pf[i] = w3_tr(pa + lp0 + i * 64, pa + lp1 + i * 64);
 #pragma unroll
       for (int j = 0; j < NSW; ++j) sf[j] = w3_tr(sa + ls0[j], sa + ls1[j]);
+    };
+    auto mac = [&](h16x8 (&pf)[MPW], h16x8 (&sf)[NSW]) {
       if (bias_p) {
 #pragma unroll
         for (int i = 0; i < MPW; ++i) bsum[i] = w3_sum8(pf[i], bsum[i]);
@@ -290,14 +545,76 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
       for (int i = 0; i < MPW; ++i)
 #pragma unroll
         for (int j = 0; j < NSW; ++j) acc[i][j] = w3_mfma(pf[i], sf[j], acc[i][j]);
+    };
+    {
+      const int kend = (dbg & 2) ? 0 : ksteps;
+      constexpr bool PIPE = MPW * NSW <= 6;  // (the 8- and 9-fragment blocks have no registers for a second fragment set)
+      if constexpr (PIPE) {
+        h16x8 pfA[MPW], sfA[NSW], pfB[MPW], sfB[NSW];
+        int ks = wk;
+        if (ks < kend) load(ks, pfA, sfA);
+        while (ks < kend) {
+          if (ks + WK < kend) load(ks + WK, pfB, sfB);
+          mac(pfA, sfA);
+          ks += WK;
+          if (ks >= kend) break;
+          if (ks + WK < kend) load(ks + WK, pfA, sfA);
+          mac(pfB, sfB);
+          ks += WK;
+        }
+      } else {
+        for (int ks = wk; ks < kend; ks += WK) {
+          h16x8 pf[MPW], sf[NSW];
+          load(ks, pf, sf);
+          mac(pf, sf);
+        }
+      }
     }
+    W3_STAMP();
     if (++slot == nslot) slot = 0;
   }
+#undef W3_STAMP
   // (the caller's barrier separates this problem's last LDS reads from the next problem's first DMA)
 
   // ---- write the partial slab straight from the accumulators.  Fragment (i, j): lane l holds rows (e & 3) + 8 (e >> 2) + 4 (l >> 5),
   // column l & 31: consecutive lanes -> consecutive (tap, channel) of S -> 128-byte runs in both layouts.
-  const int split_eff = sp_i * WK + wk;
+  // K-split waves (WK > 1: small slabs, every wave takes every WK-th K16-step of a tile): summed here through LDS in the fixed order
+  // wk = 0, 1, 2, 3, one source wave at a time, so the workgroup writes ONE slab (the first version wrote WK of them: the 192^2
+  // layers then had 768 partial slabs of 9 KB each and cgen_wgrad_reduce walked them serially, LABNOTES 10.2)
+  if (WK > 1) {
+    W3_BARRIER();  // every wave is done with the tile ring
+    float* const red = (float*)smem + (size_t)(wave >> lwk) * ((MPW * NSW * 16 + NB) * 64) + lane;
+    for (int src = 1; src < WK; ++src) {
+      if (wk == src) {
+#pragma unroll
+        for (int i = 0; i < MPW; ++i)
+#pragma unroll
+          for (int j = 0; j < NSW; ++j) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[((i * NSW + j) * 16 + e) * 64] = acc[i][j][e];
+            asm volatile("" ::: "memory");
+          }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) red[(MPW * NSW * 16 + i) * 64] = bsum[i];
+      }
+      W3_BARRIER();
+      if (wk == 0) {
+#pragma unroll
+        for (int i = 0; i < MPW; ++i)
+#pragma unroll
+          for (int j = 0; j < NSW; ++j) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] += red[((i * NSW + j) * 16 + e) * 64];
+            asm volatile("" ::: "memory");  // (one fragment at a time: hoisting all the loads needs a second accumulator set)
+          }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) bsum[i] += red[(MPW * NSW * 16 + i) * 64];
+      }
+      W3_BARRIER();
+    }
+    if (wk != 0) return;
+  }
+  const int split_eff = sp_i;
   const int taps = p.taps;
   const int ncol = x_is_s ? p.ci_total : p.co;  // innermost extent of the partial layout
   const int nrow = x_is_s ? p.co : p.ci_total;
@@ -307,7 +624,7 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
     int coff[NSW];  // tap * ncol + real column channel, -1: nothing to store
 #pragma unroll
     for (int j = 0; j < NSW; ++j) {
-      const int fs = wn * NSW + j;
+      const int fs = fs0 + wn * NSW + j;
       const int n = fs * 32 + (lane & 31);
       coff[j] = -1;
       if (fs < p.NS && n < ncols) {
@@ -349,7 +666,7 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
           if (cwin < widthP && co < p.co) pb[co] = tot;
         }
         if (bias_s && i < NSW) {
-          const int fs = wn * NSW + i;
+          const int fs = fs0 + wn * NSW + i;
           const int n = fs * 32 + lane;
           const int cs8 = p.S.c8;
           const int tap = n / cs8, c = n - tap * cs8;
@@ -361,27 +678,30 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
 }
 
 #define W3_DISPATCH(p, a, b, c)                                  \
-  switch ((p)->variant) {                                          \
-    case 4 * 1 + 1: wg3_body<1, 1>(p, a, b); break;               \
-    case 4 * 1 + 2: wg3_body<1, 2>(p, a, b); break;               \
-    case 4 * 1 + 3: wg3_body<1, 3>(p, a, b); break;               \
-    case 4 * 2 + 1: wg3_body<2, 1>(p, a, b); break;               \
-    case 4 * 2 + 2: wg3_body<2, 2>(p, a, b); break;               \
-    case 4 * 2 + 3: wg3_body<2, 3>(p, a, b); break;               \
-    case 4 * 3 + 1: wg3_body<3, 1>(p, a, b); break;               \
-    case 4 * 3 + 2: wg3_body<3, 2>(p, a, b); break;               \
-    case 4 * 3 + 3: wg3_body<3, 3>(p, a, b); break;               \
-    case 4 * 4 + 1: wg3_body<4, 1>(p, a, b); break;               \
-    default: wg3_body<4, 2>(p, a, b); break;                      \
+  switch ((p)->variant) {                                         \
+    case 8 * 1 + 1: wg3_body<1, 1>(p, a, b, c); break;            \
+    case 8 * 1 + 2: wg3_body<1, 2>(p, a, b, c); break;            \
+    case 8 * 1 + 3: wg3_body<1, 3>(p, a, b, c); break;            \
+    case 8 * 1 + 4: wg3_body<1, 4>(p, a, b, c); break;            \
+    case 8 * 2 + 1: wg3_body<2, 1>(p, a, b, c); break;            \
+    case 8 * 2 + 2: wg3_body<2, 2>(p, a, b, c); break;            \
+    case 8 * 2 + 3: wg3_body<2, 3>(p, a, b, c); break;            \
+    case 8 * 2 + 4: wg3_body<2, 4>(p, a, b, c); break;            \
+    case 8 * 3 + 1: wg3_body<3, 1>(p, a, b, c); break;            \
+    case 8 * 3 + 2: wg3_body<3, 2>(p, a, b, c); break;            \
+    case 8 * 3 + 3: wg3_body<3, 3>(p, a, b, c); break;            \
+    case 8 * 4 + 1: wg3_body<4, 1>(p, a, b, c); break;            \
+    default: wg3_body<4, 2>(p, a, b, c); break;                   \
   }
 
 __global__ __launch_bounds__(256, 2) void wg3_single_kernel(Wg3P p_) {
   // (the record is read through a pointer, see w3_xreal: here it lives in the kernarg segment)
   const Wg3P* __restrict__ gp = (const Wg3P*)__builtin_amdgcn_kernarg_segment_ptr();
   const int b = blockIdx.x;
-  const int ns = gp->nsplit;
-  const int pwin = b / ns, sp_i = b - pwin * ns;
-  W3_DISPATCH(gp, sp_i, pwin, 0)
+  const int ns = gp->nsplit, npw = gp->n_pwin;
+  const int w = b / ns, sp_i = b - w * ns;
+  const int swin = w / npw, pwin = w - swin * npw;
+  W3_DISPATCH(gp, sp_i, pwin, swin)
 }
 
 // All problems of a flush in ONE launch (as wgrad_tile_mega_kernel): a resident set of workgroups walks the block list
@@ -390,8 +710,8 @@ __global__ __launch_bounds__(256, 2) void wg3_mega_kernel(const Wg3P* __restrict
   for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
     const int4 bi = blocks[b];
     const Wg3P* __restrict__ gp = probs + __builtin_amdgcn_readfirstlane(bi.x);
-    const int sp_i = __builtin_amdgcn_readfirstlane(bi.y), pwin = __builtin_amdgcn_readfirstlane(bi.z);
-    W3_DISPATCH(gp, sp_i, pwin, 0)
+    const int sp_i = __builtin_amdgcn_readfirstlane(bi.y), pwin = __builtin_amdgcn_readfirstlane(bi.z), swin = __builtin_amdgcn_readfirstlane(bi.w);
+    W3_DISPATCH(gp, sp_i, pwin, swin)
     __syncthreads();
   }
 }
@@ -415,9 +735,9 @@ static void w3_mk_op(W3Op& o, int c8_staged, int sp, int rows, int rowpx, int ha
 
 bool wg3_plan(const cgen_wgrad_args* a, Wg3Plan& g) {
   static const int on = w3_env("CGEN_WG3", 1);
-  if (!on || a->dtype != CGEN_F16 || !(a->ks == 1 || a->ks == 3)) return false;
+  if (!on || a->dtype != CGEN_F16 || !(a->ks == 1 || a->ks == 3 || a->ks == 7)) return false;
   if (a->nseg < 1 || a->nseg > CGEN_MAX_SEG || !a->gout.p || a->gout.c <= 0) return false;
-  static const int min_hw = w3_env("CGEN_WG3_MINHW", 2);
+  static const int min_hw = w3_env("CGEN_WG3_MINHW", 1);
   if (a->h < min_hw || a->w < min_hw) return false;
   if (!dma_clean(a->gout, 2)) return false;
   for (int s = 0; s < a->nseg; ++s)
@@ -452,36 +772,38 @@ bool wg3_plan(const cgen_wgrad_args* a, Wg3Plan& g) {
   q.layout = q.x_is_s ? 0 : 1;
   const int NS = (q.taps * cs8 + 31) / 32;
   const int MPT = (cp8 + 31) / 32;
-  if (NS > 12) return false;  // (S windows: not built; the wide low-resolution layers stay with the older kernel)
   q.NS = NS;
 
   // ---- wave grid and per-wave fragment block: fewest P windows (each re-reads S), then fewest MFMA slots, then fewest LDS reads
   static const int grids[6][3] = {{1, 4, 1}, {2, 2, 1}, {4, 1, 1}, {1, 2, 2}, {2, 1, 2}, {1, 1, 4}};
   long best_key = -1;
-  int bWM = 1, bWN = 4, bWK = 1, bMPW = 1, bNSW = 1, bNWIN = 1;
+  int bWM = 1, bWN = 4, bWK = 1, bMPW = 1, bNSW = 1;
   for (int gi = 0; gi < 6; ++gi) {
     const int WM = grids[gi][0], WN = grids[gi][1], WK = grids[gi][2];
-    const int NSW = (NS + WN - 1) / WN;
-    if (NSW > 3) continue;
-    const int mpw_max = NSW == 3 ? 3 : (NSW == 2 ? 4 : 4);
-    const int cap = WM * mpw_max;
-    const int nwin = (MPT + cap - 1) / cap;
-    const int mp_win = (MPT + nwin - 1) / nwin;  // balanced windows
-    const int MPW = (mp_win + WM - 1) / WM;
-    if (MPW == 4 && NSW == 3) continue;
-    // MFMA slots per K16-step of a tile, summed over the windows and normalised per wave
-    const long mfma = (long)nwin * MPW * NSW * 12 / WK;  // (x 12 keeps the division exact for WK in {1, 2, 4})
-    const long reads = (long)nwin * (MPW + NSW) * 12 / WK;
-    const long key = ((long)nwin << 40) + (mfma << 20) + reads;
-    if (best_key < 0 || key < best_key) { best_key = key; bWM = WM; bWN = WN; bWK = WK; bMPW = MPW; bNSW = NSW; bNWIN = nwin; }
+    for (int NSW = 1; NSW <= 4; ++NSW) {
+      if (NSW > 1 && WN * (NSW - 1) >= NS) break;  // (a narrower block already covers every S fragment)
+      const int mpw_max = NSW == 4 ? 2 : (NSW == 3 ? 3 : 4);
+      const int nswin = (NS + WN * NSW - 1) / (WN * NSW);
+      const int cap = WM * mpw_max;
+      const int nwin = (MPT + cap - 1) / cap;
+      const int mp_win = (MPT + nwin - 1) / nwin;  // balanced windows
+      const int MPW = (mp_win + WM - 1) / WM;
+      if (WK > 1 && (4 / WK) * (MPW * NSW * 16 + std::max(MPW, NSW)) * 256 > 48 * 1024) continue;  // (LDS of the K-split reduction)
+      // bytes a pixel position costs: every S window re-reads the P window, every P window re-reads the S tile
+      const long bytes = (long)nswin * cp8 + (long)nwin * nswin * cs8 * 2;
+      const long mfma = (long)nwin * nswin * MPW * NSW * 12 / WK;  // MFMA slots per K16-step and wave (x 12: exact for WK in {1, 2, 4})
+      const long reads = (long)nwin * nswin * (MPW + NSW) * 12 / WK;
+      const long key = (bytes << 36) + (mfma << 18) + reads;
+      if (best_key < 0 || key < best_key) { best_key = key; bWM = WM; bWN = WN; bWK = WK; bMPW = MPW; bNSW = NSW; }
+    }
   }
   if (best_key < 0) return false;
   q.WM = bWM; q.WN = bWN; q.WK = bWK;
-  q.n_pwin = bNWIN;
   q.MP = bMPW * bWM;
   q.pwin_c = q.MP * 32;
   q.n_pwin = (cp8 + q.pwin_c - 1) / q.pwin_c;
-  q.variant = bMPW * 4 + bNSW;
+  q.n_swin = (NS + bWN * bNSW - 1) / (bWN * bNSW);
+  q.variant = bMPW * 8 + bNSW;
 
   // ---- LDS pixel strides: P fragments read 64 contiguous bytes of 4 pixels -> stride = 64 x odd is conflict free; S (narrow,
   // tap-packed) 16 x odd
@@ -495,10 +817,10 @@ bool wg3_plan(const cgen_wgrad_args* a, Wg3Plan& g) {
   if (spP > 1024 || spS > 1024) return false;
 
   // ---- tile: tw = 16 (8 for narrow images), th from the LDS budget; ring of nslot tiles
-  static const int lds_cap = w3_env("CGEN_WG3_LDS", 48) * 1024;
+  static const int lds_cap = w3_env("CGEN_WG3_LDS", 64) * 1024;
   static const int want_slots = w3_env("CGEN_WG3_SLOTS", 3);
   static const int force_tpx = w3_env("CGEN_WG3_TPX", 0);
-  const int halo = a->ks == 3 ? 1 : 0;
+  const int halo = a->ks / 2;
   q.tw = a->w >= 12 ? 16 : 8;
   q.kst_rows = 16 / q.tw;
   const int hpad = w3_pad(a->h, q.kst_rows);
@@ -535,25 +857,32 @@ bool wg3_plan(const cgen_wgrad_args* a, Wg3Plan& g) {
 
   // ---- split-K: a workgroup's partial slab (written + re-read by the reduce) must stay a few % of the bytes it streams
   const long dbytes = 4L * q.co * q.taps * q.ci_total;
-  const long tile_bytes = 2L * (q.th * q.tw * (long)cp8 + (long)q.n_pwin * q.S.npx * cs8);
-  static const int part_pct = w3_env("CGEN_WG3_PARTIAL_PCT", 8);
-  static const int max_split = w3_env("CGEN_WG3_MAXSPLIT", 64);
+  const long tile_bytes = 2L * ((long)q.n_swin * q.th * q.tw * (long)cp8 + (long)q.n_pwin * q.n_swin * q.S.npx * cs8);
+  static const int part_pct = w3_env("CGEN_WG3_PARTIAL_PCT", 30);
+  static const int max_kb = w3_env("CGEN_WG3_BLOCK_KB", 1536);  // HBM bytes per workgroup: ~60 us at a CU's share of the bandwidth; short blocks balance the packed launch
   static const int min_tps = w3_env("CGEN_WG3_MINTPS", 4);
-  long tps = (2 * dbytes * 100 + part_pct * tile_bytes - 1) / (part_pct * tile_bytes);
+  const long blk_tile_bytes = 2L * (q.th * q.tw * (long)wP + (long)q.S.npx * cs8);  // one tile of one workgroup
+  long tps = std::max<long>(1, (long)max_kb * 1024 / blk_tile_bytes);
+  const long tps_lo = (2 * dbytes * 100 + part_pct * tile_bytes - 1) / (part_pct * tile_bytes);
+  tps = std::max<long>(tps, tps_lo);
   tps = std::max<long>(tps, min_tps);
-  tps = std::max<long>(tps, ceil_div(q.ntiles, std::max(1, max_split / (q.n_pwin * q.WK))));
   tps = std::min<long>(tps, q.ntiles);
   q.tps = (int)tps;
   q.nsplit = ceil_div(q.ntiles, q.tps);
-  g.nsplit_total = q.nsplit * q.WK;
-  g.nblocks = q.nsplit * q.n_pwin;
+  g.nsplit_total = q.nsplit;
+  g.nblocks = q.nsplit * q.n_pwin * q.n_swin;
   g.lds = (size_t)q.nslot * q.slot_bytes;
+  if (q.WK > 1) g.lds = std::max(g.lds, (size_t)(4 / q.WK) * ((q.variant / 8) * (q.variant % 8) * 16 + std::max(q.variant / 8, q.variant % 8)) * 256);
   g.block_bytes = (long)q.tps * (2L * (q.th * q.tw * (long)wP + (long)q.S.npx * cs8));
   q.pw = a->partial_w; q.pb = a->partial_b;
+  static unsigned long long* const stamps = [] { const char* e = getenv("CGEN_WG3_STAMPS"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }();
+  q.stamps = stamps;
+  static const int dbg = w3_env("CGEN_WG3_DBG", 0);
+  q.dbg = dbg;
   if (getenv("CGEN_WG3_PLAN_DEBUG"))
-    fprintf(stderr, "wg3 plan: %dx%dx%d ks%d cx8 %3d co %3d act %d | S=%s cs8 %3d NS %2d | cp8 %3d pwin %3d x%d | grid %dx%dx%d frag %dx%d | tile %2dx%2d sp %3d/%3d "
+    fprintf(stderr, "wg3 plan: %dx%dx%d ks%d cx8 %3d co %3d act %d | S=%s cs8 %3d NS %2d | cp8 %3d pwin %3d x%d swin x%d | grid %dx%dx%d frag %dx%d | tile %2dx%2d sp %3d/%3d "
             "instr %2d+%2d slot %5d x%d | tiles %5d tps %4d nsplit %3d (x%d) blocks %4d\n",
-            a->n, a->h, a->w, a->ks, cx8, q.co, a->act, q.x_is_s ? "X" : "G", cs8, NS, cp8, q.pwin_c, q.n_pwin, q.WM, q.WN, q.WK, q.variant / 4, q.variant % 4,
+            a->n, a->h, a->w, a->ks, cx8, q.co, a->act, q.x_is_s ? "X" : "G", cs8, NS, cp8, q.pwin_c, q.n_pwin, q.n_swin, q.WM, q.WN, q.WK, q.variant / 8, q.variant % 8,
             q.th, q.tw, spP, spS, q.P.ninstr, q.S.ninstr, q.slot_bytes, q.nslot, q.ntiles, q.tps, q.nsplit, q.WK, g.nblocks);
   return true;
 }

@@ -69,9 +69,11 @@ def test_pure_queries_and_arg_validation_without_gpu():
     assert lib.conv2d_wgrad_plan(ctypes.byref(w), ctypes.byref(tiled)) >= 1 and tiled.value == 3
     w.seg[0], w.gout = _lib.View(8192, 192 * 192 * 8, 192 * 8, 8, 8, 0), _lib.View(4096, 192 * 192 * 32, 192 * 32, 32, 32, 0)
     assert lib.conv2d_wgrad_plan(ctypes.byref(w), ctypes.byref(tiled)) >= 1 and tiled.value == 2  # 8 -> 32: X is the narrow operand
-    w.ks = 7  # the 7x7 stem stays with the tiled kernel of rounds 2-4
+    w.ks = 7  # the 7x7 stem (one input channel, zero padded to 8): X is the shifted operand, 49 taps x 8 = 13 fragments
     w.seg[0] = _lib.View(4096, 192 * 192 * 8, 192 * 8, 8, 1, 8)
-    assert lib.conv2d_wgrad_plan(ctypes.byref(w), ctypes.byref(tiled)) >= 1 and tiled.value == 1
+    assert lib.conv2d_wgrad_plan(ctypes.byref(w), ctypes.byref(tiled)) >= 1 and tiled.value == 2
+    w.dtype = 0  # f32: the generic kernel
+    assert lib.conv2d_wgrad_plan(ctypes.byref(w), ctypes.byref(tiled)) >= 1 and tiled.value == 0
     # argument validation happens before any launch, so it is testable on a CPU-only host
     a = _lib.ConvArgs()
     a.dtype = 7
