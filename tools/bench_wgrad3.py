@@ -66,5 +66,63 @@ def main():
     print("sum %.1f us, %.2f TB/s over the set" % (tot_t, tot_b / tot_t / 1e6))
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "batch"):
     main()
+
+
+def batch_main():
+    """Full-chip form: R independent copies of ONE shape in one packed launch (>= ~1500 workgroups), so that every CU holds its two
+    workgroups for the whole measurement -- the regime of the engine's flush."""
+    lib = _lib.require_gpu()
+    st = torch.cuda.current_stream().cuda_stream
+    only = sys.argv[2:] and [int(v) for v in sys.argv[2].split(",")]
+    for idx, case in enumerate(UKBB):
+        if only and idx not in only:
+            continue
+        N, H, W, segc, Co, ks, act = case
+        xt = [torch.randn(N, H, W, (c + 7) // 8 * 8, device="cuda").half() for c in segc]
+        gt = torch.randn(N, H, W, (Co + 7) // 8 * 8, device="cuda").half()
+        a0 = _lib.WgradArgs()
+        a0.dtype, a0.n, a0.h, a0.w, a0.ks, a0.nseg, a0.act = 1, N, H, W, ks, len(segc), act
+        for k, (t, c) in enumerate(zip(xt, segc)):
+            a0.seg[k] = view(t, c)
+        a0.gout = view(gt, Co)
+        nsplit = lib.conv2d_wgrad_plan(C.byref(a0), None)
+        ci = sum(segc)
+        nw = Co * ks * ks * ci
+        byts = 2.0 * N * H * W * (ci + Co)
+        R = max(1, min(64, int(8e9 / byts / 8)))  # ~1 GB of input per launch
+        parts, args = [], []
+        for r in range(R):
+            part = torch.empty(nsplit * (nw + Co), dtype=torch.float32, device="cuda")
+            a = _lib.WgradArgs.from_buffer_copy(bytes(a0))
+            a.nsplit, a.partial_w, a.partial_b = nsplit, part.data_ptr(), part.data_ptr() + 4 * nsplit * nw
+            parts.append(part)
+            args.append(a)
+        arr = (_lib.WgradArgs * R)(*args)
+        nbytes, nl = C.c_int64(0), C.c_int32(0)
+        elig = (C.c_int32 * R)()
+        lib.conv2d_wgrad_batch_plan(arr, R, None, 0, C.byref(nbytes), None, 0, C.byref(nl), elig)
+        host = (C.c_char * max(nbytes.value, 1))()
+        launches = (_lib.WgradBatchLaunch * max(nl.value, 1))()
+        lib.conv2d_wgrad_batch_plan(arr, R, host, nbytes.value, C.byref(nbytes), launches, nl.value, C.byref(nl), elig)
+        blob = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
+        nblk = sum(launches[i].nblocks for i in range(nl.value))
+        for _ in range(2):
+            lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl.value, 0, st)
+        torch.cuda.synchronize()
+        reps = 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl.value, 0, st)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        flop = 2.0 * N * H * W * ci * Co * ks * ks * R
+        print("%-34s x%2d  %5d blocks | %8.1f us | %5.2f TB/s algorithmic | %6.1f TF/s" % (
+            "%dx%dx%d %s->%d k%d" % (N, H, W, "+".join(map(str, segc)), Co, ks), R, nblk, us, byts * R / us / 1e6, flop / us / 1e6), flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "batch":
+    batch_main()

@@ -32,8 +32,28 @@ def main():
     nw = Co * ks * ks * sum(segc)
     part = torch.empty(nsplit * (nw + Co), dtype=torch.float32, device="cuda")
     a.nsplit, a.partial_w, a.partial_b = nsplit, part.data_ptr(), part.data_ptr() + 4 * nsplit * nw
-    for _ in range(3):
-        lib.conv2d_wgrad(C.byref(a), st)
+    R = int(os.environ.get("STAMP_COPIES", "0"))
+    if R:  # full-chip regime: R copies of the problem in one packed launch; the stamps are those of the launch's first workgroup
+        keep, args = [], []
+        for r in range(R):
+            pr = torch.empty(nsplit * (nw + Co), dtype=torch.float32, device="cuda")
+            ar = _lib.WgradArgs.from_buffer_copy(bytes(a))
+            ar.partial_w, ar.partial_b = pr.data_ptr(), pr.data_ptr() + 4 * nsplit * nw
+            keep.append(pr)
+            args.append(ar)
+        arr = (_lib.WgradArgs * R)(*args)
+        nbytes, nl = C.c_int64(0), C.c_int32(0)
+        elig = (C.c_int32 * R)()
+        lib.conv2d_wgrad_batch_plan(arr, R, None, 0, C.byref(nbytes), None, 0, C.byref(nl), elig)
+        host = (C.c_char * max(nbytes.value, 1))()
+        launches = (_lib.WgradBatchLaunch * max(nl.value, 1))()
+        lib.conv2d_wgrad_batch_plan(arr, R, host, nbytes.value, C.byref(nbytes), launches, nl.value, C.byref(nl), elig)
+        blob = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
+        for _ in range(3):
+            lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl.value, 0, st)
+    else:
+        for _ in range(3):
+            lib.conv2d_wgrad(C.byref(a), st)
     torch.cuda.synchronize()
     s = buf.cpu().view(4, 64).tolist()
     t0 = min(w[0] for w in s)
