@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "wgrad3.h"
 
@@ -264,6 +265,20 @@ __device__ __forceinline__ h16x8 w3_relu8(const h16x8 v) {  // ReLU on the raw b
   for (int e = 0; e < 4; ++e) c.s[e] = __builtin_elementwise_max(c.s[e], (w3s16x2){0, 0});
   return c.h;
 }
+// GELU of the eight binary16 values of a 16-byte group, INLINE (common.h's gelu8_fwd_h16 is a real function: a call inside the tile
+// loop makes every live register around it caller-saved -- spills in the fragment blocks that have none to spare)
+__device__ __forceinline__ uint4 w3_gelu8(const uint4 x) {
+  uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = h_lo(w[i]), b = h_hi(w[i]);
+    float ca, cb, pa, pb;
+    gelu_terms_fast(a, ca, pa);
+    gelu_terms_fast(b, cb, pb);
+    w[i] = f2h_pk(a * ca, b * cb);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
 __device__ __forceinline__ f32x16 w3_mfma(const h16x8 a, const h16x8 b, const f32x16 c) {
 #ifdef CGEN_H16_BF16
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -287,15 +302,24 @@ __device__ __forceinline__ float w3_sum8(const h16x8 v, float s) {
 #endif
 }
 
-// real (OIHW) input-channel index of 8-granular concatenated channel c8i of X, -1 for padding.  The segment tables are indexed
-// THROUGH THE POINTER into the problem record (global memory): a by-value struct indexed by a lane-dependent number ends up in
-// scratch (block.hip has the same note); these lookups happen once per workgroup.
-__device__ __forceinline__ int w3_xreal(const Wg3P* __restrict__ gp, const int nsegx, const int cx8, const int c8i) {
-  int si = 0;
-#pragma unroll
-  for (int k = 1; k < CGEN_MAX_SEG; ++k) si += (k < nsegx && c8i >= gp->x_k8[k]) ? 1 : 0;
-  const int cs = c8i - gp->x_k8[si];
-  return (c8i < cx8 && cs < gp->segx[si].c) ? gp->x_off[si] + cs : -1;
+// real (OIHW) input-channel index of 8-granular concatenated channel c8i of X, -1 for padding: a select chain over the segment
+// table held in scalars (statically indexed fields only -- a by-value table indexed by a lane-dependent number ends up in scratch,
+// and per-row lookups through global memory made hipcc hoist hundreds of loads into registers in the unrolled epilogue)
+struct W3XMap { int nseg, cx8, k1, k2, k3, o0, o1, o2, o3, c0, c1, c2, c3; };
+__device__ __forceinline__ W3XMap w3_xmap(const Wg3P* __restrict__ gp) {
+  W3XMap m;
+  m.nseg = gp->nsegx; m.cx8 = gp->cx8;
+  m.k1 = gp->x_k8[1]; m.k2 = gp->x_k8[2]; m.k3 = gp->x_k8[3];
+  m.o0 = gp->x_off[0]; m.o1 = gp->x_off[1]; m.o2 = gp->x_off[2]; m.o3 = gp->x_off[3];
+  m.c0 = gp->segx[0].c; m.c1 = gp->segx[1].c; m.c2 = gp->segx[2].c; m.c3 = gp->segx[3].c;
+  return m;
+}
+__device__ __forceinline__ int w3_xreal(const W3XMap& m, const int c8i) {
+  int cs = c8i, off = m.o0, cnt = m.c0;
+  if (m.nseg > 1 && c8i >= m.k1) { cs = c8i - m.k1; off = m.o1; cnt = m.c1; }
+  if (m.nseg > 2 && c8i >= m.k2) { cs = c8i - m.k2; off = m.o2; cnt = m.c2; }
+  if (m.nseg > 3 && c8i >= m.k3) { cs = c8i - m.k3; off = m.o3; cnt = m.c3; }
+  return (c8i < m.cx8 && cs < cnt) ? off + cs : -1;
 }
 
 struct W3Lane {
@@ -344,128 +368,175 @@ __device__ __forceinline__ void w3_issue_op(const W3Op& o, const W3Lane& L, cons
 
 template <int MPW, int NSW>
 __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int sp_i, const int pwin, const int swin) {
-  // the hot fields of the problem record, once (scalar loads); everything lane-indexed goes through gp
-  struct { int H, W, ks, taps, act, x_is_s, th, tw, tiles_x, tiles_y, ntiles, tps, ksteps, kst_rows, pwin_c, NS, WN, WK, nslot, slot_bytes, co, ci_total,
-           nsegx, cx8; W3Div d_tx, d_ty; W3Op P, S; float* pw; float* pb; } p;
-  p.H = gp->H; p.W = gp->W; p.ks = gp->ks; p.taps = gp->taps; p.act = gp->act; p.x_is_s = gp->x_is_s; p.th = gp->th; p.tw = gp->tw;
-  p.tiles_x = gp->tiles_x; p.tiles_y = gp->tiles_y; p.ntiles = gp->ntiles; p.tps = gp->tps; p.ksteps = gp->ksteps; p.kst_rows = gp->kst_rows;
-  p.pwin_c = gp->pwin_c; p.NS = gp->NS; p.WN = gp->WN; p.WK = gp->WK; p.nslot = gp->nslot; p.slot_bytes = gp->slot_bytes; p.co = gp->co;
-  p.ci_total = gp->ci_total; p.nsegx = gp->nsegx; p.cx8 = gp->cx8; p.d_tx = gp->d_tx; p.d_ty = gp->d_ty; p.P = gp->P; p.S = gp->S;
-  p.pw = gp->pw; p.pb = gp->pb;
   typedef __attribute__((address_space(3))) void* lds_ptr;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_ptr)smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int WK = p.WK, WN = p.WN;
+  // (fields of the problem record are read where they are used -- scalar loads through the uniform pointer; only what the tile
+  //  loop needs stays live: the first version copied ~80 scalars up front and the loop ran on v_readlane'd SGPR spills)
+  const int WK = gp->WK, WN = gp->WN;
   const int lwk = __builtin_ctz(WK), lwn = __builtin_ctz(WN);
   const int wk = wave & (WK - 1), wn = (wave >> lwk) & (WN - 1), wm = wave >> (lwk + lwn);
-  const int H = p.H, W = p.W;
-  const bool x_is_s = p.x_is_s != 0;
-  const int t_begin = sp_i * p.tps, t_end = min(p.ntiles, t_begin + p.tps);
-  const int c0P = pwin * p.pwin_c;
-  const int widthP = min(p.pwin_c, p.P.c8 - c0P);
+  const int H = gp->H, W = gp->W;
+  const bool x_is_s = gp->x_is_s != 0;
+  const int c0P = pwin * gp->pwin_c;
+  const int widthP = min(gp->pwin_c, gp->P.c8 - c0P);
+  const int th = gp->th, tw = gp->tw;
+  const int nslot = gp->nslot, slot_bytes = gp->slot_bytes, pbytes = gp->P.bytes;
+  const int ksteps = gp->ksteps;
 
   // ---- DMA lane constants.  Everything about a lane's share of a tile but the tile origin is a launch constant: the byte offset of
   // its pixel of the wave's k-th P / S instruction (poff / soff), that pixel's (row, column) inside the S tile for the image-border
-  // test (syx, 6 bits each), and whether the slot carries data at all (vmask).  Per tile and instruction that leaves a 64-bit add and
-  // a select (interior tiles) -- the first version redid a division and three multiplies per instruction: ~350 cycles each, 2000 per
-  // tile (stamps, LABNOTES 10.1).  Instructions beyond the W3_PN / W3_SN kept in registers, and ragged P tiles, take the slow path.
-  const W3Lane LP = w3_lane(gp, p.P, !x_is_s, c0P, widthP, lane);
-  const W3Lane LS = w3_lane(gp, p.S, x_is_s, 0, p.S.c8, lane);
-  const int nslot = p.nslot, slot_bytes = p.slot_bytes, pbytes = p.P.bytes;
-  const int haloS = p.S.halo, th = p.th, tw = p.tw;
+  // test (syx, 6 bits each), and whether the slot carries data at all (vmask).  Per tile and instruction that leaves one 64-bit add
+  // under an exec mask.  Instructions beyond the W3_PN / W3_SN kept in registers, and ragged P tiles, take the slow form.
   int poff[W3_PN], soff[W3_SN];
   uint32_t syx[(W3_SN + 1) / 2], vmask = 0;
+  W3Lane LP, LS;
+  int ninP, ninS, stepP, stepS, haloS, s_rows, s_rowpx;
+  {
+    const W3Op P = gp->P, S = gp->S;
+    LP = w3_lane(gp, P, !x_is_s, c0P, widthP, lane);
+    LS = w3_lane(gp, S, x_is_s, 0, S.c8, lane);
+    ninP = P.ninstr; ninS = S.ninstr; stepP = P.ppi * P.sp; stepS = S.ppi * S.sp; haloS = S.halo; s_rows = S.rows; s_rowpx = S.rowpx;
 #pragma unroll
-  for (int k = 0; k < (W3_SN + 1) / 2; ++k) syx[k] = 0;
+    for (int k = 0; k < (W3_SN + 1) / 2; ++k) syx[k] = 0;
 #pragma unroll
-  for (int k = 0; k < W3_PN; ++k) {
-    const int lin = (wave + 4 * k) * p.P.ppi + LP.pl;
-    const int ry = w3div(lin, p.P.d_row), rx = lin - ry * p.P.rowpx;
-    poff[k] = ry * LP.sh + rx * LP.sw;
-    if (LP.data && lin < p.P.npx && wave + 4 * k < p.P.ninstr) vmask |= 1u << k;
-  }
-#pragma unroll
-  for (int k = 0; k < W3_SN; ++k) {
-    const int lin = (wave + 4 * k) * p.S.ppi + LS.pl;
-    const int ry = w3div(lin, p.S.d_row), rx = lin - ry * p.S.rowpx;
-    soff[k] = ry * LS.sh + rx * LS.sw;
-    syx[k >> 1] |= (uint32_t)((ry & 63) << 6 | (rx & 63)) << (12 * (k & 1));
-    if (LS.data && lin < p.S.npx && wave + 4 * k < p.S.ninstr) vmask |= 1u << (8 + k);
-  }
-  const int stepP = p.P.ppi * p.P.sp, stepS = p.S.ppi * p.S.sp;
-  const int ninP = p.P.ninstr, ninS = p.S.ninstr;
-  const char* const zero = (const char*)g_w3zero;
-  auto issue = [&](const int t, const int slot) {
-    const int b1 = w3div(t, p.d_tx), tx = t - b1 * p.tiles_x;
-    const int n = w3div(b1, p.d_ty), ty = b1 - n * p.tiles_y;
-    const int y0 = ty * th, x0 = tx * tw;
-    const uint32_t sb = lds0 + slot * slot_bytes;
-    // P: no halo; a tile inside the image needs no per-lane test at all
-    if (y0 + th <= H && x0 + tw <= W) {
-      const char* const bp = LP.base + (n * LP.sn + y0 * LP.sh + x0 * LP.sw);
-#pragma unroll
-      for (int k = 0; k < W3_PN; ++k)
-        if (wave + 4 * k < ninP) {
-          const char* src = ((vmask >> k) & 1) ? bp + poff[k] : zero;
-          if (LP.active) w3_dma16(src, __builtin_amdgcn_readfirstlane(sb + (wave + 4 * k) * stepP));
-        }
-      if (wave + 4 * W3_PN < ninP) w3_issue_op(p.P, LP, n, y0, x0, H, W, sb, wave + 4 * W3_PN);
-    } else {
-      w3_issue_op(p.P, LP, n, y0, x0, H, W, sb, wave);
+    for (int k = 0; k < W3_PN; ++k) {
+      const int lin = (wave + 4 * k) * P.ppi + LP.pl;
+      const int ry = w3div(lin, P.d_row), rx = lin - ry * P.rowpx;
+      poff[k] = ry * LP.sh + rx * LP.sw;
+      if (LP.data && lin < P.npx && wave + 4 * k < P.ninstr) vmask |= 1u << k;
     }
-    {
-      const int ys = y0 - haloS, xs = x0 - haloS;
-      const bool inside = ys >= 0 && xs >= 0 && ys + p.S.rows <= H && xs + p.S.rowpx <= W;  // (wave-uniform)
-      const char* const bs = LS.base + (n * LS.sn + ys * LS.sh + xs * LS.sw);
 #pragma unroll
-      for (int k = 0; k < W3_SN; ++k)
-        if (wave + 4 * k < ninS) {
-          bool ok = ((vmask >> (8 + k)) & 1) != 0;
-          if (!inside) {
-            const uint32_t f = syx[k >> 1] >> (12 * (k & 1));
-            const int gy = ys + (int)((f >> 6) & 63), gx = xs + (int)(f & 63);
-            ok = ok && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-          }
-          const char* src = ok ? bs + soff[k] : zero;
-          if (LS.active) w3_dma16(src, __builtin_amdgcn_readfirstlane(sb + pbytes + (wave + 4 * k) * stepS));
-        }
-      if (wave + 4 * W3_SN < ninS) w3_issue_op(p.S, LS, n, ys, xs, H, W, sb + pbytes, wave + 4 * W3_SN);
+    for (int k = 0; k < W3_SN; ++k) {
+      const int lin = (wave + 4 * k) * S.ppi + LS.pl;
+      const int ry = w3div(lin, S.d_row), rx = lin - ry * S.rowpx;
+      soff[k] = ry * LS.sh + rx * LS.sw;
+      syx[k >> 1] |= (uint32_t)((ry & 63) << 6 | (rx & 63)) << (12 * (k & 1));
+      if (LS.data && lin < S.npx && wave + 4 * k < S.ninstr) vmask |= 1u << (8 + k);
+    }
+  }
+  const char* const zero = (const char*)g_w3zero;
+  // tile walk: the NEXT tile to request, as (image, tile row, tile column), advanced incrementally
+  const int tiles_x = gp->tiles_x, tiles_y = gp->tiles_y;
+  const int t_begin = sp_i * gp->tps, t_end = min(gp->ntiles, t_begin + gp->tps);
+  int q_n, q_ty, q_tx;
+  {
+    const int b1 = w3div(t_begin, gp->d_tx);
+    q_tx = t_begin - b1 * tiles_x;
+    q_n = w3div(b1, gp->d_ty);
+    q_ty = b1 - q_n * tiles_y;
+  }
+  // The requests of a tile are SPREAD over the first K16-steps of the tile being consumed (positions 0..3): a burst of ~19 KiB right
+  // after the barrier fills the CU's memory queue (a CU drains ~10 B/cycle, its share of HBM) and every further request stalls its
+  // wave at issue -- ~2000 cycles per tile in which the wave computes nothing (stamps, LABNOTES 10.1); on the full chip the spread
+  // form measured 8 % faster than the burst.  dma_begin: per-tile state; dma_pos<p>: the register-offset requests of position p.
+  const char* d_bp = nullptr;
+  const char* d_bs = nullptr;
+  uint32_t d_sb = 0;
+  int d_n = 0, d_y0 = 0, d_x0 = 0;
+  bool d_inside = false, d_on = false, d_pfast = false;
+  auto dma_begin = [&](const int slot) {
+    d_n = q_n; d_y0 = q_ty * th; d_x0 = q_tx * tw;
+    if (++q_tx == tiles_x) { q_tx = 0; if (++q_ty == tiles_y) { q_ty = 0; ++q_n; } }
+    d_sb = lds0 + slot * slot_bytes;
+    d_on = true;
+    const int ys = d_y0 - haloS, xs = d_x0 - haloS;
+    d_inside = ys >= 0 && xs >= 0 && ys + s_rows <= H && xs + s_rowpx <= W;  // (wave-uniform)
+    d_bs = LS.base + (d_n * LS.sn + ys * LS.sh + xs * LS.sw);
+    d_pfast = d_y0 + th <= H && d_x0 + tw <= W;  // P has no halo: a tile inside the image needs no per-lane test at all
+    if (d_pfast) d_bp = LP.base + (d_n * LP.sn + d_y0 * LP.sh + d_x0 * LP.sw);
+    else w3_issue_op(gp->P, LP, d_n, d_y0, d_x0, H, W, d_sb, wave);  // ragged P tile: the slow form, now
+  };
+  auto dma_p = [&](const int k) {
+    if (wave + 4 * k < ninP) {
+      const char* b = d_bp;
+      asm volatile("" : "+v"(b));  // (opaque: or hipcc forms all nine addresses of a tile ahead of the K loop and keeps 18 registers live across it)
+      if ((vmask >> k) & 1) w3_dma16(b + poff[k], __builtin_amdgcn_readfirstlane(d_sb + (wave + 4 * k) * stepP));
     }
   };
+  auto dma_s = [&](const int k) {
+    if (wave + 4 * k < ninS) {
+      const uint32_t dst = __builtin_amdgcn_readfirstlane(d_sb + pbytes + (wave + 4 * k) * stepS);
+      const char* d_bs_ = d_bs;
+      asm volatile("" : "+v"(d_bs_));
+      if (d_inside) {
+        if ((vmask >> (8 + k)) & 1) w3_dma16(d_bs_ + soff[k], dst);
+      } else {
+        const uint32_t f = syx[k >> 1] >> (12 * (k & 1));
+        const int gy = d_y0 - haloS + (int)((f >> 6) & 63), gx = d_x0 - haloS + (int)(f & 63);
+        const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const char* src = ok ? d_bs_ + soff[k] : zero;
+        if ((vmask >> (8 + k)) & 1) w3_dma16(src, dst);
+      }
+    }
+  };
+  auto dma_pos = [&](auto pc) {  // position p of the tile's first four K16-steps: requests k with k % 4 == p (P), (W3_PN + k) % 4 == p (S)
+    constexpr int p = decltype(pc)::value;
+    if (!d_on) return;
+#pragma unroll
+    for (int k = 0; k < W3_PN; ++k)
+      if (k % 4 == p && d_pfast) dma_p(k);
+#pragma unroll
+    for (int k = 0; k < W3_SN; ++k)
+      if ((W3_PN + k) % 4 == p) dma_s(k);
+  };
+  auto dma_rest = [&]() {  // the instructions beyond the register-offset ones (slow form), end of the tile's requests
+    if (!d_on) return;
+    if (d_pfast && wave + 4 * W3_PN < ninP) w3_issue_op(gp->P, LP, d_n, d_y0, d_x0, H, W, d_sb, wave + 4 * W3_PN);
+    if (wave + 4 * W3_SN < ninS) w3_issue_op(gp->S, LS, d_n, d_y0 - haloS, d_x0 - haloS, H, W, d_sb + pbytes, wave + 4 * W3_SN);
+    d_on = false;
+  };
+  typedef std::integral_constant<int, 0> P0;
+  typedef std::integral_constant<int, 1> P1;
+  typedef std::integral_constant<int, 2> P2;
+  typedef std::integral_constant<int, 3> P3;
+  auto issue_all = [&](const int slot) {  // a whole tile at once (prologue)
+    dma_begin(slot);
+    dma_pos(P0()); dma_pos(P1()); dma_pos(P2()); dma_pos(P3());
+    dma_rest();
+  };
   // DMA instructions this wave issues per tile (instruction i goes to wave i & 3)
-  const int ipt = ((p.P.ninstr + 3 - wave) >> 2) + ((p.S.ninstr + 3 - wave) >> 2);
+  const int ipt = ((ninP + 3 - wave) >> 2) + ((ninS + 3 - wave) >> 2);
 
   // ---- fragment lane constants.  16-lane group g: K half g >> 1 (pixels 8 (g >> 1) .. + 8 of the K16-step), channel / column half
   // g & 1; lane t = 4 r + q of the group supplies (pixel r of the read, channels 4 q .. 4 q + 3) and receives column t's 4 pixels.
-  const int g = lane >> 4, t16 = lane & 15, r = t16 >> 2, q = t16 & 3;
-  const int kh = g >> 1, ch16 = g & 1;
-  const int spP = p.P.sp, spS = p.S.sp;
-  const int klin0 = 8 * kh + r;  // pixel of the FIRST read inside the K16-step (linear over the tile's pixels); second: + 4
-  const uint32_t lp0 = klin0 * spP + (ch16 * 16 + 4 * q) * 2 + (wm * MPW) * 64, lp1 = lp0 + 4 * spP;
+  const int spP = gp->P.sp, spS = gp->S.sp;
   const int fs0 = swin * (WN * NSW);  // first S fragment of this workgroup's column window
-  uint32_t ls0[NSW], ls1[NSW];
+  uint32_t aP0, aS0[NSW], aS1[NSW];  // running LDS addresses of this lane's fragment reads (first / second read of a pair: P second = + 4 spP)
+  uint32_t bmask = 0;  // S fragments of this wave that hold columns of the centre tap (bias gradient when grad_out is the S operand)
   {
-    const int cs8 = p.S.c8, ncols = p.taps * cs8;
+    const int g = lane >> 4, t16 = lane & 15, r = t16 >> 2, q = t16 & 3;
+    const int kh = g >> 1, ch16 = g & 1;
+    const int klin0 = 8 * kh + r;  // pixel of the FIRST read inside the K16-step (linear over the tile's pixels); second: + 4
+    aP0 = lds0 + klin0 * spP + (ch16 * 16 + 4 * q) * 2 + (wm * MPW) * 64 + wk * (16 * spP);
+    const int cs8 = gp->S.c8, taps = gp->taps, ksz = gp->ks, ncols = taps * cs8, NS = gp->NS, rowpx = gp->S.rowpx;
     const int py0 = tw == 16 ? 0 : klin0 >> 3, px0 = tw == 16 ? klin0 : klin0 & 7;           // first read's pixel inside the K-step
     const int py1 = tw == 16 ? 0 : (klin0 + 4) >> 3, px1 = tw == 16 ? klin0 + 4 : (klin0 + 4) & 7;
 #pragma unroll
     for (int j = 0; j < NSW; ++j) {
-      const int fs = min(fs0 + wn * NSW + j, p.NS - 1);
+      const int fsj = fs0 + wn * NSW + j;
+      const int fs = min(fsj, NS - 1);
       int n = fs * 32 + ch16 * 16 + 4 * q;
       if (n >= ncols) n = 0;  // padding column: any valid address (never stored)
       const int tap = n / cs8, c = n - tap * cs8;
-      const int ey = tap / p.ks, ex = tap - p.ks * ey;
-      ls0[j] = ((py0 + ey) * p.S.rowpx + px0 + ex) * spS + c * 2;
-      ls1[j] = ((py1 + ey) * p.S.rowpx + px1 + ex) * spS + c * 2;
+      const int ey = tap / ksz, ex = tap - ksz * ey;
+      const uint32_t sbase = lds0 + pbytes + wk * (gp->kst_rows * rowpx * spS);
+      aS0[j] = sbase + ((py0 + ey) * rowpx + px0 + ex) * spS + c * 2;
+      aS1[j] = sbase + ((py1 + ey) * rowpx + px1 + ex) * spS + c * 2;
+      const int ctr = taps >> 1;
+      if (fsj < NS && fsj * 32 < (ctr + 1) * cs8 && fsj * 32 + 32 > ctr * cs8) bmask |= 1u << j;
     }
   }
-  const int kstepP = 16 * spP, kstepS = p.kst_rows * p.S.rowpx * spS;
-  const int ksteps = p.ksteps;
-  const bool relu_p = p.act == CGEN_ACT_RELU && !x_is_s, relu_s = p.act == CGEN_ACT_RELU && x_is_s;
-  const bool gelu = p.act == CGEN_ACT_GELU;
-  const bool bias_p = p.pb != nullptr && x_is_s && wn == 0 && swin == 0;                // G is the P operand: row sums of my P fragments
-  const bool bias_s = p.pb != nullptr && !x_is_s && wm == 0 && pwin == 0;  // G is the S operand: column sums of my S fragments
+  const int kstepP = 16 * spP * WK, kstepS = gp->kst_rows * gp->S.rowpx * spS * WK;  // address advance per K16-step of this wave
+  const int sp4 = 4 * spP;
+  const int nkw = wk < ksteps ? (ksteps - wk + WK - 1) >> lwk : 0;  // K16-steps of a tile this wave takes = fragment loads per tile
+  const int act = gp->act;
+  const bool relu_p = act == CGEN_ACT_RELU && !x_is_s, relu_s = act == CGEN_ACT_RELU && x_is_s;
+  const bool gelu = act == CGEN_ACT_GELU;
+  float* const pb_ptr = gp->pb;
+  const bool bias_p = pb_ptr != nullptr && x_is_s && wn == 0 && swin == 0;   // G is the P operand: row sums of my P fragments
+  const bool bias_s = pb_ptr != nullptr && !x_is_s && wm == 0 && pwin == 0 && bmask != 0;  // G is the S operand: column sums of my centre-tap fragments
 
   f32x16 acc[MPW][NSW];
 #pragma unroll
@@ -481,15 +552,19 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
 
   // optional cycle stamps (CGEN_WG3_STAMPS=<device address of 256 u64>, tools/wg3_stamps.py): first lane of every wave of the
   // launch's first block, 4 stamps per tile for the first 14 tiles after 2 set-up stamps
+#ifdef CGEN_WG3_STAMPS_BUILD  // (a debug build, -DCGEN_WG3_STAMPS_BUILD: the stamps cost registers and ~20 instructions per tile)
   unsigned long long* const stamp = (gp->stamps != nullptr && blockIdx.x == 0 && sp_i == 0 && pwin == 0 && swin == 0 && lane == 0) ? gp->stamps + wave * 64 : nullptr;
   int nst = 0;
 #define W3_STAMP() do { if (stamp && nst < 62) stamp[nst++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define W3_STAMP() do {} while (0)
+#endif
   W3_STAMP();
   // ---- tile ring: tiles t .. t + nslot - 2 are in flight / resident while tile t is consumed; one barrier per tile
   const int ahead = nslot - 1;
-  const int dbg = gp->dbg;  // ablation (CGEN_WG3_DBG, wrong results): 1 no DMA, 2 no fragment reads / MFMAs
+  const int dbg = gp->dbg;  // ablation (CGEN_WG3_DBG, wrong results): 1 no DMA, 2 no fragment reads / MFMAs, 4 burst DMA
   for (int k = 0; k < ahead; ++k)
-    if (t_begin + k < t_end && !(dbg & 1)) issue(t_begin + k, k);
+    if (t_begin + k < t_end && !(dbg & 1)) issue_all(k);
   int slot = 0;
   W3_STAMP();
   for (int t = t_begin; t < t_end; ++t) {
@@ -503,41 +578,51 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
     if (t + ahead < t_end && !(dbg & 1)) {
       int s2 = slot + ahead;
       if (s2 >= nslot) s2 -= nslot;
-      issue(t + ahead, s2);
+      if (dbg & 4) issue_all(s2); else dma_begin(s2);
     }
     W3_STAMP();
     const uint32_t bufP = lds0 + slot * slot_bytes, bufS = bufP + pbytes;
+    (void)bufS;
     if (gelu) {  // in-place activation of the staged X tile (ReLU is applied to the fragments instead)
       const uint32_t xb = x_is_s ? bufS : bufP;
-      const int nb16 = (x_is_s ? p.S.bytes : pbytes) >> 4;
+      const int nb16 = (x_is_s ? gp->S.bytes : pbytes) >> 4;
       for (int s = tid; s < nb16; s += 256) {
         uint4* ptr = (uint4*)(smem + (xb - lds0) + s * 16);
-        *ptr = gelu8_fwd_h16(*ptr);
+        *ptr = w3_gelu8(*ptr);
       }
       W3_BARRIER();
     }
-    // K16-steps of the tile: the fragment reads of step k + 1 are issued before the MFMAs of step k (two register sets)
-    auto load = [&](const int ks, h16x8 (&pf)[MPW], h16x8 (&sf)[NSW]) {
-      const uint32_t pa = bufP + ks * kstepP, sa = bufS + ks * kstepS;
+    // K16-steps of the tile.  Lane addresses advance by increments (two adds per operand base, the P fragments hang off one base by
+    // immediate offsets); the fragment reads of step k + 1 are issued before the MFMAs of step k (two register sets) where the
+    // fragment block leaves room; the first four steps carry the DMA requests of the tile two ahead.
+    auto load = [&](h16x8 (&pf)[MPW], h16x8 (&sf)[NSW]) {
 #pragma unroll
-      for (int i = 0; i < MPW; ++i) pf[i] = w3_tr(pa + lp0 + i * 64, pa + lp1 + i * 64);
+      for (int i = 0; i < MPW; ++i) pf[i] = w3_tr(aP0 + i * 64, aP0 + sp4 + i * 64);
 #pragma unroll
-      for (int j = 0; j < NSW; ++j) sf[j] = w3_tr(sa + ls0[j], sa + ls1[j]);
+      for (int j = 0; j < NSW; ++j) sf[j] = w3_tr(aS0[j], aS1[j]);
+      aP0 += kstepP;
+#pragma unroll
+      for (int j = 0; j < NSW; ++j) { aS0[j] += kstepS; aS1[j] += kstepS; }
     };
     auto mac = [&](h16x8 (&pf)[MPW], h16x8 (&sf)[NSW]) {
-      if (bias_p) {
+      if (bias_p) {  // (real branches: the empty asm keeps hipcc from if-converting them into selects on every wave)
+        asm volatile("" : "+v"(bsum[0]));
 #pragma unroll
         for (int i = 0; i < MPW; ++i) bsum[i] = w3_sum8(pf[i], bsum[i]);
       }
       if (bias_s) {
+        asm volatile("" : "+v"(bsum[0]));
 #pragma unroll
-        for (int j = 0; j < NSW; ++j) bsum[j] = w3_sum8(sf[j], bsum[j]);
+        for (int j = 0; j < NSW; ++j)
+          if ((bmask >> j) & 1) bsum[j] = w3_sum8(sf[j], bsum[j]);
       }
       if (relu_p) {
+        asm volatile("" : "+v"(pf[0]));
 #pragma unroll
         for (int i = 0; i < MPW; ++i) pf[i] = w3_relu8(pf[i]);
       }
       if (relu_s) {
+        asm volatile("" : "+v"(sf[0]));
 #pragma unroll
         for (int j = 0; j < NSW; ++j) sf[j] = w3_relu8(sf[j]);
       }
@@ -549,35 +634,57 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
     {
       const int kend = (dbg & 2) ? 0 : ksteps;
       constexpr bool PIPE = MPW * NSW <= 6;  // (the 8- and 9-fragment blocks have no registers for a second fragment set)
+      // (loop shape matters: ONE back edge, no exit in the middle -- with a break between the two halves hipcc kept two copies of the
+      //  accumulators and moved 16 registers per MFMA between them)
+      const int nk = (dbg & 2) ? 0 : nkw;
+      (void)kend;
       if constexpr (PIPE) {
         h16x8 pfA[MPW], sfA[NSW], pfB[MPW], sfB[NSW];
-        int ks = wk;
-        if (ks < kend) load(ks, pfA, sfA);
-        while (ks < kend) {
-          if (ks + WK < kend) load(ks + WK, pfB, sfB);
+        if (nk > 0) load(pfA, sfA);
+        int i = 0;
+        for (; i + 2 <= nk; i += 2) {
+          load(pfB, sfB);
+          if (i == 0) dma_pos(P0()); else if (i == 2) dma_pos(P2());
           mac(pfA, sfA);
-          ks += WK;
-          if (ks >= kend) break;
-          if (ks + WK < kend) load(ks + WK, pfA, sfA);
+          if (i + 2 < nk) load(pfA, sfA);
+          if (i == 0) dma_pos(P1()); else if (i == 2) dma_pos(P3());
           mac(pfB, sfB);
-          ks += WK;
         }
+        if (i < nk) mac(pfA, sfA);
       } else {
-        for (int ks = wk; ks < kend; ks += WK) {
+        for (int i = 0; i < nk; ++i) {
           h16x8 pf[MPW], sf[NSW];
-          load(ks, pf, sf);
+          load(pf, sf);
+          if (i == 0) { dma_pos(P0()); dma_pos(P1()); } else if (i == 1) { dma_pos(P2()); dma_pos(P3()); }
           mac(pf, sf);
         }
       }
+      {  // request groups the K16-steps above did not reach (short tiles / K-split waves), then the slow-form remainder
+        constexpr int per = PIPE ? 2 : 1;  // steps per pair of positions
+        const int done = (nk / per) * 2;   // positions issued inside the loop (pairs of them)
+        if (done < 2) { dma_pos(P0()); dma_pos(P1()); }
+        if (done < 4) { dma_pos(P2()); dma_pos(P3()); }
+        dma_rest();
+      }
     }
     W3_STAMP();
-    if (++slot == nslot) slot = 0;
+    {  // the running addresses advanced by this wave's K16-steps: rewind them onto the next slot of the ring (scalar deltas)
+      int dslot = slot_bytes;
+      if (++slot == nslot) { slot = 0; dslot = -(nslot - 1) * slot_bytes; }
+      if (!(dbg & 2)) {
+        aP0 += dslot - nkw * kstepP;
+#pragma unroll
+        for (int j = 0; j < NSW; ++j) { aS0[j] += dslot - nkw * kstepS; aS1[j] += dslot - nkw * kstepS; }
+      } else {
+        aP0 += dslot;
+#pragma unroll
+        for (int j = 0; j < NSW; ++j) { aS0[j] += dslot; aS1[j] += dslot; }
+      }
+    }
   }
 #undef W3_STAMP
   // (the caller's barrier separates this problem's last LDS reads from the next problem's first DMA)
 
-  // ---- write the partial slab straight from the accumulators.  Fragment (i, j): lane l holds rows (e & 3) + 8 (e >> 2) + 4 (l >> 5),
-  // column l & 31: consecutive lanes -> consecutive (tap, channel) of S -> 128-byte runs in both layouts.
   // K-split waves (WK > 1: small slabs, every wave takes every WK-th K16-step of a tile): summed here through LDS in the fixed order
   // wk = 0, 1, 2, 3, one source wave at a time, so the workgroup writes ONE slab (the first version wrote WK of them: the 192^2
   // layers then had 768 partial slabs of 9 KB each and cgen_wgrad_reduce walked them serially, LABNOTES 10.2)
@@ -614,22 +721,27 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
     }
     if (wk != 0) return;
   }
-  const int split_eff = sp_i;
-  const int taps = p.taps;
-  const int ncol = x_is_s ? p.ci_total : p.co;  // innermost extent of the partial layout
-  const int nrow = x_is_s ? p.co : p.ci_total;
-  float* const pw = p.pw + (size_t)split_eff * ((size_t)p.co * taps * p.ci_total);
+
+  // ---- write the partial slab straight from the accumulators.  Fragment (i, j): lane l holds rows (e & 3) + 8 (e >> 2) + 4 (l >> 5),
+  // column l & 31: consecutive lanes -> consecutive (tap, channel) of S -> 128-byte runs in both layouts.
+  int el = lane;  // (opaque from here on: everything the epilogue derives from the lane index is computed AFTER the tile loop -- hipcc hoisted
+  asm volatile("" : "+v"(el));  //  those ~50 loop-invariant values above the loop and spilled them around it)
+  const int taps = gp->taps, co_n = gp->co, ci_n = gp->ci_total, NS = gp->NS;
+  const W3XMap xm = w3_xmap(gp);
+  const int ncol = x_is_s ? ci_n : co_n;  // innermost extent of the partial layout
+  const int nrow = x_is_s ? co_n : ci_n;
+  float* const pw = gp->pw + (size_t)sp_i * ((size_t)co_n * taps * ci_n);
   {
-    const int cs8 = p.S.c8, ncols = taps * cs8;
+    const int cs8 = gp->S.c8, ncols = taps * cs8;
     int coff[NSW];  // tap * ncol + real column channel, -1: nothing to store
 #pragma unroll
     for (int j = 0; j < NSW; ++j) {
       const int fs = fs0 + wn * NSW + j;
-      const int n = fs * 32 + (lane & 31);
+      const int n = fs * 32 + (el & 31);
       coff[j] = -1;
-      if (fs < p.NS && n < ncols) {
+      if (fs < NS && n < ncols) {
         const int tap = n / cs8, c8i = n - tap * cs8;
-        const int cc = x_is_s ? w3_xreal(gp, p.nsegx, p.cx8, c8i) : (c8i < p.co ? c8i : -1);
+        const int cc = x_is_s ? w3_xreal(xm, c8i) : (c8i < co_n ? c8i : -1);
         if (cc >= 0) coff[j] = tap * ncol + cc;
       }
     }
@@ -640,10 +752,10 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
       for (int e4 = 0; e4 < 4; ++e4) {
 #pragma unroll
         for (int e1 = 0; e1 < 4; ++e1) {
-          const int row = e1 + 8 * e4 + 4 * (lane >> 5);
+          const int row = e1 + 8 * e4 + 4 * (el >> 5);
           const int pc = c0P + cwin + row;
           int rr = -1;
-          if (cwin + row < widthP) rr = x_is_s ? (pc < p.co ? pc : -1) : w3_xreal(gp, p.nsegx, p.cx8, pc);
+          if (cwin + row < widthP) rr = x_is_s ? (pc < co_n ? pc : -1) : w3_xreal(xm, pc);
           if (rr >= 0 && rr < nrow) {
             float* const rowp = pw + (size_t)rr * taps * ncol;
 #pragma unroll
@@ -655,22 +767,22 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
     }
   }
   if (bias_p || bias_s) {
-    float* const pb = p.pb + (size_t)split_eff * p.co;
+    float* const pb = pb_ptr + (size_t)sp_i * co_n;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const float tot = bsum[i] + __shfl_xor(bsum[i], 32, 64);  // the two K halves of the fragment
-      if (lane < 32) {
+      if (el < 32) {
         if (bias_p && i < MPW) {
-          const int cwin = (wm * MPW + i) * 32 + lane;
+          const int cwin = (wm * MPW + i) * 32 + el;
           const int co = c0P + cwin;
-          if (cwin < widthP && co < p.co) pb[co] = tot;
+          if (cwin < widthP && co < co_n) pb[co] = tot;
         }
-        if (bias_s && i < NSW) {
+        if (bias_s && i < NSW && ((bmask >> i) & 1)) {
           const int fs = fs0 + wn * NSW + i;
-          const int n = fs * 32 + lane;
-          const int cs8 = p.S.c8;
+          const int n = fs * 32 + el;
+          const int cs8 = gp->S.c8;
           const int tap = n / cs8, c = n - tap * cs8;
-          if (fs < p.NS && tap == (taps >> 1) && c < p.co) pb[c] = tot;
+          if (fs < NS && tap == (taps >> 1) && c < co_n) pb[c] = tot;
         }
       }
     }
@@ -812,32 +924,42 @@ bool wg3_plan(const cgen_wgrad_args* a, Wg3Plan& g) {
   if (((spP / 64) & 1) == 0) spP += 64;
   int spS = w3_pad(cs8 * 2, 16);
   if (((spS / 16) & 1) == 0) spS += 16;
-  static const int sp_plain = w3_env("CGEN_WG3_PLAINSTRIDE", 0);  // (A/B: no padding)
-  if (sp_plain) { spP = w3_pad(wP * 2, 16); spS = w3_pad(cs8 * 2, 16); }
+  static const int sp_plain = w3_env("CGEN_WG3_PLAINSTRIDE", 1);  // no padding: tools/probe_tr16_bw.hip measured the transpose reads at the same rate for every pixel stride but 256 / 272 B, and the LDS is 7 % busy (PMC)
+  if (sp_plain) {
+    spP = w3_pad(wP * 2, 16); spS = w3_pad(cs8 * 2, 16);
+    if (spP == 256 || spP == 272) spP = 288;
+  }
   if (spP > 1024 || spS > 1024) return false;
 
   // ---- tile: tw = 16 (8 for narrow images), th from the LDS budget; ring of nslot tiles
-  static const int lds_cap = w3_env("CGEN_WG3_LDS", 64) * 1024;
+  static const int lds_cap = w3_env("CGEN_WG3_LDS", 72) * 1024;
   static const int want_slots = w3_env("CGEN_WG3_SLOTS", 3);
   static const int force_tpx = w3_env("CGEN_WG3_TPX", 0);
   const int halo = a->ks / 2;
   q.tw = a->w >= 12 ? 16 : 8;
   q.kst_rows = 16 / q.tw;
   const int hpad = w3_pad(a->h, q.kst_rows);
-  static const int tpx_order[3] = {64, 128, 32};
+  // the LARGEST tile (pixels) whose ring fits the LDS budget and whose requests fit the register-offset tables: the per-tile costs
+  // (barrier, counted wait, request set-up) are fixed, so the narrow 192^2 / 96^2 layers -- 60 % of the bytes of a ukbb192 step --
+  // want 256-pixel tiles where the 96-channel layers of 48^2 take 64 (same ~18 KB per ring slot).  Pass 0: three slots and only
+  // register-offset requests; pass 1: two slots; pass 2: anything that fits.
+  static const int tpx_order[5] = {512, 256, 128, 64, 32};
   int pick = -1, pick_slots = 0;
-  for (int pass = 0; pass < 2 && pick < 0; ++pass) {
-    for (int k = 0; k < 3; ++k) {
+  for (int pass = 0; pass < 3 && pick < 0; ++pass) {
+    for (int k = 0; k < 5; ++k) {
       const int tpx = force_tpx ? force_tpx : tpx_order[k];
       int th = tpx / q.tw;
-      if (th < q.kst_rows) continue;
-      if (th > hpad && tpx != tpx_order[2] && !force_tpx) continue;  // (a tile taller than the image: only as the last resort)
+      if (th < q.kst_rows || th + 2 * halo > 60) continue;
+      if (th > hpad && k != 4 && !force_tpx) continue;  // (a tile taller than the image: only as the last resort)
       W3Op P, S;
       w3_mk_op(P, wP, spP, th, q.tw, 0, cp8);
       w3_mk_op(S, cs8, spS, th + 2 * halo, q.tw + 2 * halo, halo, cs8);
       const int slot = w3_pad(P.bytes + S.bytes, 16);
-      const int ns = std::min(want_slots + 1, lds_cap / slot);
-      if (ns >= (pass == 0 ? want_slots : 2)) { pick = tpx; pick_slots = std::min(ns, want_slots); break; }
+      const int ns = std::min(want_slots, lds_cap / slot);
+      const bool fast = ceil_div(P.ninstr, 4) <= W3_PN && ceil_div(S.ninstr, 4) <= W3_SN;
+      const bool counted = (ceil_div(P.ninstr, 4) + ceil_div(S.ninstr, 4)) * std::max(0, ns - 2) <= 47;
+      const bool ok = pass == 0 ? (ns >= want_slots && fast && counted) : (pass == 1 ? (ns >= 2 && fast && counted) : ns >= 2);
+      if (ok) { pick = tpx; pick_slots = ns; break; }
       if (force_tpx) break;
     }
   }
@@ -907,3 +1029,11 @@ void wg3_launch_mega(const Wg3P* probs_dev, const int4* blocks_dev, int nblocks,
 }
 
 }  // namespace cgen
+
+#ifdef W3_VARIANT_KERNELS  // register audit: one kernel per fragment block (tools/b3_regs.sh style: hipcc -DW3_VARIANT_KERNELS -Rpass-analysis=kernel-resource-usage)
+namespace cgen {
+#define W3_VK(M, N) __global__ __launch_bounds__(256, 2) void wg3_variant_##M##x##N(const Wg3P* __restrict__ probs, const int4* __restrict__ blocks, const int nblocks) { \
+    for (int b = blockIdx.x; b < nblocks; b += gridDim.x) { const int4 bi = blocks[b]; wg3_body<M, N>(probs + __builtin_amdgcn_readfirstlane(bi.x), __builtin_amdgcn_readfirstlane(bi.y), __builtin_amdgcn_readfirstlane(bi.z), __builtin_amdgcn_readfirstlane(bi.w)); __syncthreads(); } }
+W3_VK(1, 1) W3_VK(1, 2) W3_VK(1, 3) W3_VK(1, 4) W3_VK(2, 1) W3_VK(2, 2) W3_VK(2, 3) W3_VK(2, 4) W3_VK(3, 1) W3_VK(3, 2) W3_VK(3, 3) W3_VK(4, 1) W3_VK(4, 2)
+}
+#endif
