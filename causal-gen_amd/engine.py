@@ -67,7 +67,7 @@ class _Tape(list):
 
     def append(self, item):
         if len(item) == 2:
-            item = (item[0], item[1], self.eng._in_side)
+            item = (item[0], item[1], self.eng._bw_tag)
         list.append(self, item)
 
 
@@ -258,6 +258,21 @@ class Engine(StageMixin, WgradMixin):
         self._wg_events = []
         self._wg_reduced, self._wg_seen = 0, set()
         self._in_side = False
+        # Backward strands (round 5): tape entries recorded inside `on_side(fn, bw=1)` -- the prior Block of a
+        # decoder layer and the upsampling of the z chain -- run on the side stream in backward() as well, next to the h strand
+        # (posterior Block, conv Block, z_proj).  ONE fork edge per layer (the event recorded behind every reparam backward)
+        # and one join (the first main-strand op that touches a gradient buffer the side strand wrote: z_feat_proj's backward);
+        # every accumulation into a buffer both strands contribute to stays on the main stream.  Bit-identical to the one-chain
+        # backward (tests/test_gpu_train.py) and concurrent in the trace (k = 3 residency 0.5 ms, the prior Block's 18 us under the
+        # posterior's) -- but OFF by default (CGEN_BW_BRANCH=1 turns it on): each fork and each join is a cross-queue hop of ~6 us
+        # on the main chain under hipGraph replay, 38 layers x 2, and the replayed step measured 15.5 ms against 14.07 (LABNOTES 10.4).
+        self.bw_branch = os.environ.get("CGEN_BW_BRANCH", "0") != "0"
+        self._bw_tag = 0
+        self._bw_live = False      # inside backward() with strands on: the gradient accessors report to _bw_touch
+        self._bw_forked = False
+        self._bw_mark = None       # event behind the last reparam backward (main stream)
+        self._bw_mark_synced = None
+        self._bw_sets = (set(), set(), set(), set())  # buffers written / read since the mark by: main (w, r), side (w, r)
         self._rng_override = None
         self._dbg_names = {} if os.environ.get("CGEN_DEBUG_NAMES") else None  # id(tensor) -> producing conv (tools/ab_grads.py)
         self._riders = {}
@@ -279,7 +294,7 @@ class Engine(StageMixin, WgradMixin):
         self.wgrad_batch = os.environ.get("CGEN_WGRAD_BATCH", "1") != "0"
         # background flushes: once this many GFLOP of weight gradients are pending they are issued on a side stream with a
         # capped grid, so that they fill the CUs the latency-bound backward chain leaves idle (0: one batch at the end)
-        self.wgrad_flush_frac = [float(v) for v in os.environ.get("CGEN_WGRAD_FLUSH_FRAC", "0.58").split(",") if v]
+        self.wgrad_flush_frac = [float(v) for v in os.environ.get("CGEN_WGRAD_FLUSH_FRAC", "0.65").split(",") if v]
         self.wgrad_bg_wgs = int(os.environ.get("CGEN_WGRAD_BG_WGS", "304"))
         self.wgrad_bg_reduce = os.environ.get("CGEN_WGRAD_BG_REDUCE", "1") != "0"
         self._wg_cum, self._wg_total, self._wg_nflush = 0.0, 0.0, 0
@@ -638,7 +653,7 @@ class Engine(StageMixin, WgradMixin):
         if self.recording:
             if self._dbg_names is not None:
                 self._dbg_names[id(out.base)] = site.name
-            (self.tape if tape_hold is None else tape_hold).append((self._bw_conv, (site, segs, act, out, res1, res2), self._in_side))
+            (self.tape if tape_hold is None else tape_hold).append((self._bw_conv, (site, segs, act, out, res1, res2), self._bw_tag))
         return out
 
     @staticmethod
@@ -696,10 +711,10 @@ class Engine(StageMixin, WgradMixin):
             if self._dbg_names is not None:
                 self._dbg_names[id(out.base)] = site2.name
             if self.blk3_on >= 2:
-                self.tape.append((self._bw_block3, (site1, site2, segs, t, out, res1), self._in_side))
+                self.tape.append((self._bw_block3, (site1, site2, segs, t, out, res1), self._bw_tag))
             else:
-                self.tape.append((self._bw_conv, (site1, segs, ACT_RELU, t, None, None), self._in_side))
-                self.tape.append((self._bw_conv, (site2, [t], ACT_RELU, out, res1, None), self._in_side))
+                self.tape.append((self._bw_conv, (site1, segs, ACT_RELU, t, None, None), self._bw_tag))
+                self.tape.append((self._bw_conv, (site2, [t], ACT_RELU, out, res1, None), self._bw_tag))
         return out
 
     def _bw_block3(self, site1, site2, segs, t, out, res1):
@@ -1078,18 +1093,21 @@ class Engine(StageMixin, WgradMixin):
             self._fwd_side.wait_stream(torch.cuda.current_stream(self.device))
         return True
 
-    def on_side(self, fn):
-        """Run `fn()` with every launch going to the side stream."""
+    def on_side(self, fn, bw=0):
+        """Run `fn()` with every launch going to the side stream.  `bw` = 1: the backward of what fn records belongs to the side
+        strand of backward() too (see _bw_tag)."""
         self.stage_flush()
-        old = self.stream
+        old, old_tag = self.stream, self._bw_tag
         self.stream = self._fwd_side.cuda_stream
         self._in_side = True
+        self._bw_tag = bw
         try:
             return fn()
         finally:
             self.stage_flush()
             self.stream = old
             self._in_side = False
+            self._bw_tag = old_tag
 
     def join_side(self):
         self.stage_flush()
@@ -1120,6 +1138,9 @@ class Engine(StageMixin, WgradMixin):
         job = self._riders.pop(id(base), None)
         if job is not None:
             gv, g, acc = job
+            if self._bw_live:
+                self._bw_touch(id(g.base), False)
+                self._bw_touch(id(gv.base), True)
             self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
             self.launches += 1
 
@@ -1129,6 +1150,8 @@ class Engine(StageMixin, WgradMixin):
         if self._riders:
             self._land_rider(t.base)
         g, ivs, base = self._gentry(t.base)
+        if self._bw_live:
+            self._bw_touch(id(g.base), True)
         a, b = t.coff, t.coff + t.c
         miss = self._missing(ivs, a, b)
         if miss != [(a, b)] and not defer_hazard and self._frozen(t):
@@ -1153,6 +1176,8 @@ class Engine(StageMixin, WgradMixin):
         if e is None:
             return None
         g, ivs, _ = e
+        if self._bw_live:
+            self._bw_touch(id(g.base), False)
         a, b = t.coff, t.coff + t.c
         miss = self._missing(ivs, a, b)
         if miss == [(a, b)]:
@@ -1231,8 +1256,20 @@ class Engine(StageMixin, WgradMixin):
         main_t = torch.cuda.current_stream(self.device)
         if self._side_join_pending:  # side-stream work of the forward pass nobody has joined yet (the stem's im2col)
             self.join_side()
-        for fn, args, _ in reversed(self.tape):
-            fn(*args)
+        strands = (self.bw_branch and self.fwd_branch and self.prof is None and any(tag == 1 for _, _, tag in self.tape))
+        if strands:
+            self._bw_begin()
+            for fn, args, tag in reversed(self.tape):
+                if tag == 1:
+                    self._bw_side(fn, args)
+                else:
+                    fn(*args)
+                    if fn == self._bw_reparam:
+                        self._bw_set_mark()
+            self._bw_end()
+        else:
+            for fn, args, _ in reversed(self.tape):
+                fn(*args)
         for bid in list(self._riders):
             gv, g, acc = self._riders.pop(bid)
             self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
@@ -1246,6 +1283,60 @@ class Engine(StageMixin, WgradMixin):
             self.launches += 1
         self.stage_flush()
         self.tape.clear()
+
+    # ------------------------------------------------------------------ backward strands (see __init__)
+    def _bw_begin(self):
+        if self._fwd_side is None:
+            self._fwd_side = torch.cuda.Stream(self.device)
+        self._bw_live = True
+        self._bw_forked = False
+        self._bw_set_mark()
+
+    def _bw_set_mark(self):
+        """The fork point of the coming side-strand ops: everything the main stream has enqueued so far.  Main-strand accesses are
+        tracked from here on."""
+        self.stage_flush()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._bw_mark = ev
+        self._bw_sets[0].clear()
+        self._bw_sets[1].clear()
+
+    def _bw_side(self, fn, args):
+        if self._bw_mark_synced is not self._bw_mark:  # one fork edge per mark
+            self.stage_flush()
+            self._fwd_side.wait_event(self._bw_mark)
+            self._bw_mark_synced = self._bw_mark
+            self._bw_forked = True
+        self.on_side(lambda: fn(*args))
+
+    def _bw_touch(self, key, write):
+        """A backward op is about to read (write) gradient buffer `key` on the current strand: order it behind the other strand's
+        conflicting accesses.  Main after side -> join (the main stream waits for the side stream); side after main -> a fresh mark."""
+        mw, mr, sw, sr = self._bw_sets
+        if self._in_side:
+            if key in mw or (write and key in mr):
+                self._bw_set_mark()
+                self._fwd_side.wait_event(self._bw_mark)
+                self._bw_mark_synced = self._bw_mark
+            (sw if write else sr).add(key)
+        else:
+            if self._bw_forked and (key in sw or (write and key in sr)):
+                self.stage_flush()
+                torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)
+                sw.clear()
+                sr.clear()
+            (mw if write else mr).add(key)
+
+    def _bw_end(self):
+        self.stage_flush()
+        if self._bw_forked:
+            torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)
+        self._bw_live = False
+        self._bw_forked = False
+        self._bw_mark = self._bw_mark_synced = None
+        for st in self._bw_sets:
+            st.clear()
 
     def _bw_conv(self, site, segs, act, out, res1, res2):
         g = self.grad_read(out)
@@ -1307,6 +1398,8 @@ class Engine(StageMixin, WgradMixin):
         self.launches += 1
 
     def _param_reduce(self, param, g):
+        if self._bw_live:  # (the decoder's per-resolution bias is added to h AND to the z chain: both strands accumulate into it)
+            self._bw_touch(("param", id(param)), True)
         acc = id(param) in self.pgrad_init
         _, c, h, w = param.shape
         if h * w == 1 or c == 1:
@@ -1350,6 +1443,8 @@ class Engine(StageMixin, WgradMixin):
         passes of DSCM.forward draw z from q but contribute no KL term: their coefficient is a device-side zero)."""
         gz = self.grad_read(z)
         job = self._riders.pop(id(p_loc.base), None)  # (taken before grad_write would land it as a launch of its own)
+        if job is not None and self._bw_live:
+            self._bw_touch(id(job[1].base), False)
         gql, a1 = self.grad_write(q_loc)
         gqs, a2 = self.grad_write(q_ls)
         gpl, a3 = self.grad_write(p_loc)

@@ -771,7 +771,7 @@ class HVAE(nn.Module):
                         z = h
                     elif side_ahead:
                         z_lo = z
-                        z = eng.on_side(lambda: eng.upsample(z_lo, res, bp))
+                        z = eng.on_side(lambda: eng.upsample(z_lo, res, bp), bw=1)
                     else:
                         z = eng.upsample(z, res, bp)
             p_in = h if blk.q_correction else z
@@ -781,12 +781,19 @@ class HVAE(nn.Module):
             want_two = blk.stochastic and acts is not None and rec2 and not eng.stage_covers(res)
             # (a fresh fork: the posterior Block -- the main chain -- is enqueued first, the prior Block behind the mark: Engine.fork_mark)
             mark = eng.fork_mark() if want_two and not side_ahead else None
+            t_q0 = len(eng.tape)
             qout = self._run_block(eng, blk.posterior, [h, pa, acts[res]]) if mark is not None else None
+            t_q1 = len(eng.tape)
             two = want_two and (side_ahead or eng.fork_side(after=mark))
             if side_ahead and not two:
                 eng.join_side()
                 side_ahead = False
-            pout = eng.on_side(run_prior) if two else run_prior()
+            pout = eng.on_side(run_prior, bw=1) if two else run_prior()
+            if t_q1 > t_q0 and eng.recording:
+                # tape order [prior][posterior] whichever was launched first: backward() then enqueues the posterior Block's
+                # backward (main strand) BEFORE the prior Block's (side strand) behind the fork -- the main chain must be the first
+                # edge out of a fork for a captured graph to keep it on its queue (Engine.fork_mark)
+                eng.tape[t_q0:] = eng.tape[t_q1:] + eng.tape[t_q0:t_q1]
             zd = blk.z_dim
             p_loc, p_ls, p_feat = pout.chan(0, zd), pout.chan(zd, 2 * zd), pout.chan(2 * zd, pout.c)
             if blk.stochastic:
@@ -832,12 +839,17 @@ class HVAE(nn.Module):
                 side_ahead = True
                 feat = False
             h = eng.conv(self._site(eng, blk.z_proj), [z_cur, pa], ACT_NONE, res1=h, res2=p_feat, trunk=True)
+            t_zp = len(eng.tape)
             if mark is not None and eng.fork_side(after=mark):
                 z = eng.on_side(lambda: eng.conv(self._site(eng, blk.z_feat_proj), [z_cur, p_feat], ACT_NONE, tape_hold=hold))
                 side_ahead = True
                 feat = False
             h = self._run_block(eng, blk.conv, [h])
-            eng.tape.extend(hold)  # (backward order as before: z_feat_proj after the conv Block)
+            # z_feat_proj's backward goes between the conv Block's and z_proj's (tape: right behind z_proj): it is the op that joins the
+            # side strand of backward() (it reads the gradient the prior Block's backward wrote), so it sits late; and it stays in
+            # FRONT of z_proj's backward, whose residual copy into grad(p_feat) then still rides on the reparam backward (a rider
+            # parked before another writer of that buffer would have to land as a launch of its own: +5.6 us per layer, measured)
+            eng.tape[t_zp:t_zp] = hold
             if feat:
                 z = eng.conv(self._site(eng, blk.z_feat_proj), [z_cur, p_feat], ACT_NONE)
         if side_ahead:

@@ -53,6 +53,8 @@ class WgradMixin:
     def _wgrad_marks(self):
         """Background-flush and data-parallel split marks of the weight-gradient work deferred so far (see _wgrad)."""
         k = self._wg_nflush  # cumulative-cost marks, fractions of the pass's total
+        if self._in_side:  # (a side-strand op of backward(): the mark is looked at again by the next main-strand weight gradient)
+            return
         if (self.wgrad_batch and self.prof is None and k < len(self.wgrad_flush_frac) and self._wg_total > 0
                 and self._wg_cum >= self.wgrad_flush_frac[k] * self._wg_total):
             self._wg_nflush += 1
@@ -165,6 +167,8 @@ class WgradMixin:
                 side = main
             else:
                 side.wait_stream(main)
+                if getattr(self, "_bw_forked", False):  # problems queued by side-strand ops read what that strand wrote
+                    side.wait_stream(self._fwd_side)
                 self._wg_forked = True
             if blob is not None and nl:
                 self.lib.conv2d_wgrad_batch_run(blob.data_ptr(), launches, nl, self.wgrad_bg_wgs, side.cuda_stream)

@@ -344,6 +344,17 @@ def test_backward_is_bit_reproducible_next_to_the_background_weight_gradient_ker
     torch.cuda.synchronize()
     bad = [n for n, p in m.named_parameters() if p.grad is not None and not torch.equal(runs[0][n], p.grad)]
     assert not bad, (len(bad), bad[:4])
+    # ... and so does the two-strand backward of round 5 (prior Blocks on the side stream next to the h strand; opt-in): the same bits as one chain
+    assert not eng.bw_branch, "the two-strand backward is opt-in (CGEN_BW_BRANCH=1)"
+    eng.bw_branch = True
+    m.zero_grad()
+    eng.rng.copy_(torch.tensor([11, 0], dtype=torch.int64, device=eng.rng.device))
+    out = m(x, pa, beta=1.0)
+    out["elbo"].backward()
+    torch.cuda.synchronize()
+    bad = [n for n, p in m.named_parameters() if p.grad is not None and not torch.equal(runs[0][n], p.grad)]
+    assert not bad, ("one-chain backward differs from the two-strand backward", len(bad), bad[:4])
+    eng.bw_branch = False
 
 
 def test_full_size_bf16_path_agrees_with_the_f32_parity_path():
