@@ -775,7 +775,9 @@ static int b3_fill(const cgen_block3_args* a, B3P& p) {
     if (o > 0 && s.bias) return 0;  // (only the first output's bias has an LDS copy: the forward pass has one output)
   }
   b3_tiles(p, 8);
-  { const char* e = getenv("CGEN_BLK3_STAMPS"); p.stamps = e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }
+  // (debug hook, read ONCE per process: the address of a device buffer for cycle stamps, tools/blk_stamps.py)
+  static unsigned long long* const stamps_env = [] { const char* e = getenv("CGEN_BLK3_STAMPS"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : (unsigned long long*)nullptr; }();
+  p.stamps = stamps_env;
   return 1;
 }
 
@@ -832,8 +834,8 @@ static B3Launch b3_plan(B3P& p) {
 
 template <bool PRE, int NB, int NPG, int SM, int TH, bool REM>
 static void b3_launch_rem(const B3P& p, const B3Launch& L, hipStream_t st) {
-  static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)blk3_kernel<PRE, NB, NPG, SM, TH, REM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  // (per call: the attribute is per device and per function, the call is a few hundred ns and thread-safe; a `static bool once` was neither)
+  (void)hipFuncSetAttribute((const void*)blk3_kernel<PRE, NB, NPG, SM, TH, REM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL((blk3_kernel<PRE, NB, NPG, SM, TH, REM>), dim3(L.grid), dim3(256), L.lds, st, p);
 }
 template <bool PRE, int NB, int NPG, int SM, int TH = 8>
@@ -880,6 +882,7 @@ extern "C" int cgen_block3(const cgen_block3_args* a, cgen_stream_t stream) {
   const B3Launch L = b3_plan(p);
   if (a->pre_act) b3_launch_pre<true>(p, L, (hipStream_t)stream);
   else b3_launch_pre<false>(p, L, (hipStream_t)stream);
-  if (getenv("CGEN_CONV_TRACE")) fprintf(stderr, "blk3[%s] %dx%dx%d ctot8 %d b %d Co %d nseg %d nout %d | ring %d slots, lds %zu, grid %d, persist wb %d, tile rows %d\n", a->mid_aux.p ? "bwd" : "fwd", a->n, a->h, a->w, p.ctot8, p.b, p.o[0].Co, a->nseg, a->nout, p.ns, L.lds, L.grid, p.wb_persist, L.th);
+  static const bool trace = getenv("CGEN_CONV_TRACE") != nullptr;
+  if (trace) fprintf(stderr, "blk3[%s] %dx%dx%d ctot8 %d b %d Co %d nseg %d nout %d | ring %d slots, lds %zu, grid %d, persist wb %d, tile rows %d\n", a->mid_aux.p ? "bwd" : "fwd", a->n, a->h, a->w, p.ctot8, p.b, p.o[0].Co, a->nseg, a->nout, p.ns, L.lds, L.grid, p.wb_persist, L.th);
   return check_launch("cgen_block3");
 }

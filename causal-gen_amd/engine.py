@@ -304,6 +304,10 @@ class Engine(StageMixin, WgradMixin):
         self._wg_deferred = []
         # independent sub-graphs of the forward pass (prior / posterior Block of a decoder layer) run on two streams
         self.fwd_branch = os.environ.get("CGEN_FWD_BRANCH", "1") != "0"
+        # (read once: the decoder loop asks per layer and per call)  two-stream decoder sections in non-recording passes (abduct,
+        # eval forward); main chain enqueued first behind a fork (fork_mark)
+        self.infer_branch = os.environ.get("CGEN_INFER_BRANCH", "1") != "0"
+        self.fwd_mainfirst = os.environ.get("CGEN_FWD_MAINFIRST", "1") != "0"
         self._fwd_side = None
         self._side_join_pending = False
         # fused light Block, round 4 (csrc/block.hip, cgen_block3): 0 off, 1 forward only, 2 forward + data gradient; images at
@@ -754,17 +758,26 @@ class Engine(StageMixin, WgradMixin):
         a.seg[0] = g.cv()
         a.w_a, a.bias_a = site2.frag["a_dg"], None
         a.mid, a.mid_aux = gt.cv(), t.cv()
+        tgt = []
         for j, k in enumerate(dsegs):
             sg = segs[k]
             gv, prev, acc = self._dgrad_target(sg)
+            tgt.append((k, gv, prev, acc))
             a.o[j].w, a.o[j].bias = site1.frag[("b_dg", k)], None
             a.o[j].out, a.o[j].aux = gv.cv(), sg.cv()
             a.o[j].res1 = prev.cv() if acc else NULL_VIEW
         x0 = segs[0]
         if self._ablate and any(x0.h == r and ("r%d" % r) in self._ablate for r in (24, 48, 96, 192)):
             pass
-        else:
+        elif self.lib.block3_supported(C.byref(a)):
             self._timed_blk("conv_dgrad", site1, site2, x0, lambda: self.lib.block3(C.byref(a), self.stream))
+        else:
+            # The REAL gradient views are not served (the probe above saw the forward tensors' views; a gradient buffer may be laid
+            # out differently: an out-of-place accumulate target, a copy-on-write -- ADVICE r4): the two data-gradient convs, into
+            # the targets already acquired (the bookkeeping above has run and must not run twice)
+            self._dgrad_launch(site2, g, t, 0, act, t, gt, gt, False)
+            for (k, gv, prev, acc) in tgt:
+                self._dgrad_launch(site1, gt, segs[k], k, act, x0, gv, prev, acc)
         if self._needs_wgrad(site1) and "wg" not in self._ablate:
             self._wgrad(site1, segs, act, gt)
 
@@ -1355,6 +1368,10 @@ class Engine(StageMixin, WgradMixin):
 
     def _dgrad_one(self, site, g, s, k, act, x0):
         gv, prev, acc = self._dgrad_target(s)
+        self._dgrad_launch(site, g, s, k, act, x0, gv, prev, acc)
+
+    def _dgrad_launch(self, site, g, s, k, act, x0, gv, prev, acc):
+        """The data-gradient conv of input segment k into an already acquired target (see _dgrad_target)."""
         a = _lib.ConvArgs()
         gn, gh, gw, vw = self._geom(site.ks, [g, gv, s, prev])
         a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = self.dt, gn, gh, gw, site.ks, 1, ACT_NONE, act

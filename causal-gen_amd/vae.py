@@ -752,7 +752,7 @@ class HVAE(nn.Module):
         # the prior Block of layer k + 1 form a chain that only needs z_k and p_feat_k -- it runs on the side stream while the
         # main stream does z_proj, the conv Block and the posterior Block of layer k + 1.  Same kernels, same tape order.
         # (inference passes too -- the abduction pass of the counterfactual loop: +1.5 % cf/s, +3 % on the plain trunk; CGEN_INFER_BRANCH=0 off)
-        rec2 = eng.recording or os.environ.get("CGEN_INFER_BRANCH", "1") != "0"
+        rec2 = eng.recording or eng.infer_branch
         pipeline = acts is not None and rec2 and eng.fwd_branch and eng.prof is None
         if pipeline:
             for p_ in dec.bias:  # (lazily built NHWC images: build them before any side-stream section needs one)
@@ -833,7 +833,7 @@ class HVAE(nn.Module):
             # the next layer's prior chain (z_feat_proj -> prior Block) on the side stream, forked HERE but enqueued behind z_proj:
             # the main chain must be the first edge out of the fork for a captured graph to keep it on one queue (Engine.fork_mark)
             ahead = feat and pipeline and two and dec.blocks[i + 1].stochastic and not dec.blocks[i + 1].q_correction
-            mark = eng.fork_mark() if ahead and os.environ.get("CGEN_FWD_MAINFIRST", "1") != "0" else None
+            mark = eng.fork_mark() if ahead and eng.fwd_mainfirst else None
             if ahead and mark is None and eng.fork_side():
                 z = eng.on_side(lambda: eng.conv(self._site(eng, blk.z_feat_proj), [z_cur, p_feat], ACT_NONE, tape_hold=hold))
                 side_ahead = True

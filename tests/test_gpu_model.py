@@ -313,3 +313,52 @@ def test_counterfactual_reusing_the_abduction_pass_gives_the_same_bits(name, te,
             outs.append((reuse, dt, cf.clone(), eng.rng.clone()))
     for (r0, d0, c0, g0), (r1, d1, c1, g1) in zip(outs[:2], outs[2:]):
         assert d0 == d1 and torch.equal(c0, c1) and torch.equal(g0, g1), (d0,)
+
+
+def test_two_stream_inference_sections_are_bit_identical_to_one_stream():
+    """non-recording passes with encoder activations (abduct, eval forward) run the decoder's prior / posterior sections on
+    two streams by default (Engine.infer_branch, CGEN_INFER_BRANCH).  Fork / join only order launches: the latents of an abduction pass,
+    the eval-mode ELBO and the counterfactual loop under hipGraph capture must be bit-identical with the sections on one stream."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from causal_gen_amd import dscm
+
+    m, hp = bench.build_model("ukbb192", "f16")
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(torch.randn(p.shape, generator=g).cuda() * 0.02)
+    x, pa = bench.synth_batch("ukbb192", hp, 4, "cuda", 3)
+    cf_pa = pa.roll(1, 0)
+    eng = m.engine()
+    eng.rng_ptr()
+    assert eng.infer_branch, "two-stream inference sections are the default"
+    res = {}
+    for two in (True, False):
+        eng.infer_branch = two
+        with torch.no_grad():
+            eng.rng.copy_(torch.tensor([21, 0], dtype=torch.int64, device=eng.rng.device))
+            zs = m.abduct(x, pa)
+            eng.rng.copy_(torch.tensor([21, 0], dtype=torch.int64, device=eng.rng.device))
+            out = m(x, pa, beta=1.0)
+            eng.rng.copy_(torch.tensor([21, 0], dtype=torch.int64, device=eng.rng.device))
+            cf = dscm.counterfactual(m, x, pa, cf_pa, t_abduct=1.0)
+            gcf = dscm.GraphedCounterfactual(m, t_abduct=1.0)
+            gcf(x, pa, cf_pa)  # eager warm-up + capture (with the sections as `two` says)
+            eng.rng.copy_(torch.tensor([21, 0], dtype=torch.int64, device=eng.rng.device))
+            cfg = gcf(x, pa, cf_pa).clone()  # replay
+        torch.cuda.synchronize()
+        res[two] = ([z.clone() for z in zs], [out[k].clone() for k in ("elbo", "nll", "kl")], cf.clone(), cfg)
+    eng.infer_branch = True
+    assert len(res[True][0]) == len(res[False][0]) > 30
+    for a, b in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[True][1], res[False][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(res[True][2], res[False][2])
+    assert torch.equal(res[True][3], res[False][3])
