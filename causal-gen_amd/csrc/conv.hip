@@ -2461,7 +2461,7 @@ __global__ __launch_bounds__(256) void wprep_kernel(const cgen_wprep_desc* descs
       const int row = 16 * ((r32 >> 2) & 1) + (r32 & 3) + 4 * (r32 >> 3);  // channel (inside its 32-block) that fragment row r32 carries
       float v = 0.f;
       if (d.mode <= 3) {  // phase A: frag = chunk * 18 + kk
-        const int j = frag / 18, kk = frag - j * 18, half = kk >= 9 ? 1 : 0, tap = kk - 9 * half;  // (a wave's nine fragments are contiguous)
+        const int j = (int)((uint32_t)frag / 18u), kk = frag - j * 18, half = kk >= 9 ? 1 : 0, tap = kk - 9 * half;  // (a wave's nine fragments are contiguous)
         const int kc = 32 * j + 16 * half + 8 * kg + e;  // position on the concatenated input axis (segments in whole chunks)
         if (d.mode == 2) {
           if (row < d.co) {
@@ -2477,10 +2477,10 @@ __global__ __launch_bounds__(256) void wprep_kernel(const cgen_wprep_desc* descs
           v = d.src[((int64_t)kc * d.ci_total + row) * 9 + (8 - tap)];
         }
       } else {  // phase B: frag = pair * k_pad + K16-step
-        const int pair = frag / d.k_pad, ks16 = frag - pair * d.k_pad;
+        const int pair = (int)((uint32_t)frag / (uint32_t)d.k_pad), ks16 = frag - pair * d.k_pad;
         const int k = 16 * ks16 + 8 * kg + e;
         const int bw = d.mode == 4 ? d.ci_total : d.co;  // bottleneck width (a multiple of 8)
-        const int tap = k / bw, c = k - tap * bw;
+        const int tap = (int)((uint32_t)k / (uint32_t)bw), c = k - tap * bw;
         const int och = pair * 32 + row;
         if (tap < 9) {
           if (d.mode == 4) { if (och < d.co) v = d.src[((int64_t)och * d.ci_total + c) * 9 + tap]; }
@@ -2494,9 +2494,12 @@ __global__ __launch_bounds__(256) void wprep_kernel(const cgen_wprep_desc* descs
   for (int i = threadIdx.x; i < MT_CHUNK; i += 256) {
     const int64_t o = base + i;
     if (o >= d.numel) break;
-    const int k = (int)(o % d.k_pad);
-    const int r = (int)(o / d.k_pad);
-    const int tap = k / ctot8, c = k - tap * ctot8;
+    // (32-bit unsigned index arithmetic: an image has < 2^31 elements -- the 64-bit division cost ~100 instructions per element
+    //  and the launch was 0.2 ms at the head of every step's critical path)
+    const uint32_t o32 = (uint32_t)o;
+    const int r = (int)(o32 / (uint32_t)d.k_pad);
+    const int k = (int)(o32 - (uint32_t)r * (uint32_t)d.k_pad);
+    const int tap = (int)((uint32_t)k / (uint32_t)ctot8), c = k - tap * ctot8;
     float v = 0.f;
     if (tap < taps) {
       if (d.mode == 0) {  // forward image: r = co
