@@ -2836,11 +2836,39 @@ extern "C" int cgen_conv2d_wgrad_batch_plan(const cgen_wgrad_args* args, int32_t
       if ((int32_t)items3[i].g.lds > launches[li].lds_bytes) launches[li].lds_bytes = (int32_t)items3[i].g.lds;
       maxb = std::max(maxb, items3[i].g.nblocks);
     }
-    for (int k = 0; k < maxb; ++k)
+    // Block order = start order (the final flush launches one workgroup per block, the background flush walks the list with a
+    // resident set): LONGEST FIRST over all blocks, by estimated duration -- bytes over the rate the problem's image side streams at
+    // (tools/bench_wgrad3.py batch: >= 96^2 ~4 TB/s, 48^2 ~3, 24^2 ~1.4, 12^2 and below ~0.9).  The first version dealt the
+    // problems round-robin (block k of every problem, k = 0, 1, ...): the list then ENDED with blocks 30..63 of the dozen 192^2
+    // problems alone, ~300 of the longest blocks on a half-empty chip, and the launch took 2.5 ms whatever the kernel's speed.
+    if (getenv("CGEN_WG3_ORDER") && atoi(getenv("CGEN_WG3_ORDER")) == 0) {
+      for (int k = 0; k < maxb; ++k)
+        for (size_t i = 0; i < items3.size(); ++i) {
+          const Wg3P& q3 = items3[i].g.q;
+          if (k < items3[i].g.nblocks) { const int w = k / q3.nsplit; blocks3[b3] = make_int4((int)i, k % q3.nsplit, w % q3.n_pwin, w / q3.n_pwin); ++b3; }
+        }
+    } else {
+      struct Ord { double cost; int i, k; };
+      std::vector<Ord> ord;
+      ord.reserve((size_t)nblocks3);
       for (size_t i = 0; i < items3.size(); ++i) {
         const Wg3P& q3 = items3[i].g.q;
-        if (k < items3[i].g.nblocks) { const int w = k / q3.nsplit; blocks3[b3] = make_int4((int)i, k % q3.nsplit, w % q3.n_pwin, w / q3.n_pwin); ++b3; }
+        const int side = std::min(q3.H, q3.W);
+        const double slow = side >= 96 ? 1.0 : side >= 48 ? 1.35 : side >= 24 ? 2.9 : 4.5;
+        // the last split of a problem may be short: tiles of split s
+        for (int k = 0; k < items3[i].g.nblocks; ++k) {
+          const int sp = k % q3.nsplit;
+          const int nt = std::min(q3.tps, q3.ntiles - sp * q3.tps);
+          ord.push_back({(double)items3[i].g.block_bytes * slow * (double)nt / (double)q3.tps, (int)i, k});
+        }
       }
+      std::stable_sort(ord.begin(), ord.end(), [](const Ord& a, const Ord& b) { return a.cost > b.cost; });
+      for (const Ord& o : ord) {
+        const Wg3P& q3 = items3[o.i].g.q;
+        const int w = o.k / q3.nsplit;
+        blocks3[b3] = make_int4(o.i, o.k % q3.nsplit, w % q3.n_pwin, w / q3.n_pwin); ++b3;
+      }
+    }
   }
   return CGEN_OK;
 }

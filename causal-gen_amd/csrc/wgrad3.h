@@ -46,6 +46,8 @@ struct Wg3P {
   float* pw;
   float* pb;
   unsigned long long* stamps;
+  unsigned long long* blocklog;      // CGEN_WG3_BLOCKLOG: per-block (problem, split, start, end) log of the packed launch, or null
+  unsigned long long blocklog_cap;   // entries the log holds
   int dbg, cx8;  // cx8: X channels at 8-channel granularity, all segments
 };
 

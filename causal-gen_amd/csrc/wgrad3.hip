@@ -25,6 +25,8 @@
 #include <algorithm>
 #include <type_traits>
 
+#include <atomic>
+
 #include "wgrad3.h"
 
 namespace cgen {
@@ -34,6 +36,9 @@ typedef short w3s16x4 __attribute__((ext_vector_type(4)));
 typedef short w3s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ uint4 g_w3zero[4];  // DMA source of out-of-image pixels
+#ifndef W3_UNIFORM_MODE
+#define W3_UNIFORM_MODE 0
+#endif
 #define W3_PN 6  // DMA instructions per wave and tile whose lane offsets live in registers: P tile, S tile
 #define W3_SN 3
 
@@ -58,6 +63,26 @@ __device__ __forceinline__ void w3_dma16(const char* src, const uint32_t lds) {
 // wait until at most n of this wave's DMA requests are outstanding (n is wave-uniform; requests return in order).  s_waitcnt takes
 // an immediate: a binary decision tree over 0 .. 47 (six scalar branches; a 48-way switch compiled to a compare chain of ~500
 // cycles per tile -- stamps, LABNOTES 10.1); anything above waits for 47, which is more than asked: always safe.
+// The tile loop's wait: 16 leaves (a larger count is clamped: waiting for MORE of the requests is always safe, and a wave has 4-12
+// per tile).  The loop exists in 91 instances; the 48-leaf tree was a fifth of each one's code, and the flush's mix of instances
+// runs out of the instruction cache two CUs share (profiles/r05c: LABNOTES 10.5).
+__device__ __forceinline__ void w3_vmwait16(int n) {
+#define W3_VMW(k) asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory")
+  if (n < 8) {
+    if (n < 4) {
+      if (n < 2) { if (n < 1) W3_VMW(0); else W3_VMW(1); } else { if (n < 3) W3_VMW(2); else W3_VMW(3); }
+    } else {
+      if (n < 6) { if (n < 5) W3_VMW(4); else W3_VMW(5); } else { if (n < 7) W3_VMW(6); else W3_VMW(7); }
+    }
+  } else {
+    if (n < 12) {
+      if (n < 10) { if (n < 9) W3_VMW(8); else W3_VMW(9); } else { if (n < 11) W3_VMW(10); else W3_VMW(11); }
+    } else {
+      if (n < 14) { if (n < 13) W3_VMW(12); else W3_VMW(13); } else { if (n < 15) W3_VMW(14); else W3_VMW(15); }
+    }
+  }
+#undef W3_VMW
+}
 __device__ __forceinline__ void w3_vmwait(int n) {
   n = n > 47 ? 47 : n;
   if (n < 24) {
@@ -253,9 +278,14 @@ __device__ __forceinline__ void w3_vmwait(int n) {
 
 __device__ __forceinline__ h16x8 w3_tr(const uint32_t a0, const uint32_t a1) {
   typedef w3s16x4 __attribute__((address_space(3))) * lp;
-  union { w3s16x4 h[2]; h16x8 v; } u;
+  union { w3s16x4 h[2]; h16x8 v; uint32_t w[4]; } u;
+#ifdef W3_ABL_NOREAD  // (ablation build, wrong results: fragments made from the addresses, no LDS traffic)
+  u.w[0] = a0; u.w[1] = a1; u.w[2] = a0 ^ 0x3c00u; u.w[3] = a1 ^ 0x3c00u;
+  asm volatile("" : "+v"(u.w[0]), "+v"(u.w[1]), "+v"(u.w[2]), "+v"(u.w[3]));
+#else
   u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)a0);
   u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)a1);
+#endif
   return u.v;
 }
 __device__ __forceinline__ h16x8 w3_relu8(const h16x8 v) {  // ReLU on the raw bits (-0 -> +0; a NaN with the sign bit set -> 0, as block.hip)
@@ -280,6 +310,10 @@ __device__ __forceinline__ uint4 w3_gelu8(const uint4 x) {
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 __device__ __forceinline__ f32x16 w3_mfma(const h16x8 a, const h16x8 b, const f32x16 c) {
+#ifdef W3_ABL_NOMFMA  // (ablation build, wrong results: the fragments stay live, no matrix instruction)
+  asm volatile("" :: "v"(a), "v"(b));
+  return c;
+#endif
 #ifdef CGEN_H16_BF16
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 #else
@@ -537,6 +571,13 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
   float* const pb_ptr = gp->pb;
   const bool bias_p = pb_ptr != nullptr && x_is_s && wn == 0 && swin == 0;   // G is the P operand: row sums of my P fragments
   const bool bias_s = pb_ptr != nullptr && !x_is_s && wm == 0 && pwin == 0 && bmask != 0;  // G is the S operand: column sums of my centre-tap fragments
+  // K-phase instance of this wave (see kphase below): 0 plain, 1 ReLU on P, 2 bias from S, 3 both | 4 ReLU on S, 5 bias from P, 6 both
+  // -- chosen per PROBLEM, not per wave: the waves without bias duty add up sums nobody stores (4 dot products per fragment and
+  // K16-step) rather than run a second copy of the loop next to their neighbours'
+  const bool bias_any = pb_ptr != nullptr;
+  const bool w3_uni = W3_UNIFORM_MODE;
+  const bool bp_ = w3_uni ? bias_any : bias_p, bs_ = w3_uni ? bias_any : bias_s;
+  const int kmode = __builtin_amdgcn_readfirstlane(x_is_s ? (relu_s ? (bp_ ? 6 : 4) : (bp_ ? 5 : 0)) : ((relu_p ? 1 : 0) | (bs_ ? 2 : 0)));
 
   f32x16 acc[MPW][NSW];
 #pragma unroll
@@ -567,10 +608,17 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
     if (t_begin + k < t_end && !(dbg & 1)) issue_all(k);
   int slot = 0;
   W3_STAMP();
+  // The tile loop is instantiated once per (ReLU on P / on S / none) x (bias sums from P / from S / none) and entered through ONE
+  // switch: with the four flag tests inside every K16-step (the form up to round 5b) half of the kernel's time outside the DMA went
+  // into those branches -- two waves per SIMD do not hide a taken branch's fetch bubble (tools/bench_wgrad3.py batch with the
+  // W3_ABL_* builds: 192^2 32->8 without DMA 132 us, of which 54 us the flag tests, 13 us the fragment reads + MFMAs; LABNOTES 10.5).
+  // (The switch sits outside the loop: inside it, seven K phases joining per tile cost the 3x3 block 300 spilled registers.)
+  auto tile_loop = [&](auto c_rp, auto c_rs, auto c_bp, auto c_bs) {
+  constexpr bool RP = decltype(c_rp)::value, RS = decltype(c_rs)::value, BP = decltype(c_bp)::value, BS = decltype(c_bs)::value;
   for (int t = t_begin; t < t_end; ++t) {
     {  // tile t has landed (this wave's requests; the barrier makes it everybody's)
       const int later = min(t_end - 1 - t, ahead - 1);  // tiles after t already requested
-      w3_vmwait(later * ipt);
+      w3_vmwait16(later * ipt);
       W3_STAMP();
       W3_BARRIER();  // ... and every wave is done with the slot the next request overwrites (tile t - 1's)
       W3_STAMP();
@@ -578,12 +626,12 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
     if (t + ahead < t_end && !(dbg & 1)) {
       int s2 = slot + ahead;
       if (s2 >= nslot) s2 -= nslot;
-      if (dbg & 4) issue_all(s2); else dma_begin(s2);
+      dma_begin(s2);
     }
     W3_STAMP();
     const uint32_t bufP = lds0 + slot * slot_bytes, bufS = bufP + pbytes;
     (void)bufS;
-    if (gelu) {  // in-place activation of the staged X tile (ReLU is applied to the fragments instead)
+    if constexpr (!RP && !RS) if (gelu) {  // in-place activation of the staged X tile (ReLU is applied to the fragments instead)
       const uint32_t xb = x_is_s ? bufS : bufP;
       const int nb16 = (x_is_s ? gp->S.bytes : pbytes) >> 4;
       for (int s = tid; s < nb16; s += 256) {
@@ -604,50 +652,49 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
 #pragma unroll
       for (int j = 0; j < NSW; ++j) { aS0[j] += kstepS; aS1[j] += kstepS; }
     };
-    auto mac = [&](h16x8 (&pf)[MPW], h16x8 (&sf)[NSW]) {
-      if (bias_p) {  // (real branches: the empty asm keeps hipcc from if-converting them into selects on every wave)
-        asm volatile("" : "+v"(bsum[0]));
-#pragma unroll
-        for (int i = 0; i < MPW; ++i) bsum[i] = w3_sum8(pf[i], bsum[i]);
-      }
-      if (bias_s) {
-        asm volatile("" : "+v"(bsum[0]));
-#pragma unroll
-        for (int j = 0; j < NSW; ++j)
-          if ((bmask >> j) & 1) bsum[j] = w3_sum8(sf[j], bsum[j]);
-      }
-      if (relu_p) {
-        asm volatile("" : "+v"(pf[0]));
-#pragma unroll
-        for (int i = 0; i < MPW; ++i) pf[i] = w3_relu8(pf[i]);
-      }
-      if (relu_s) {
-        asm volatile("" : "+v"(sf[0]));
-#pragma unroll
-        for (int j = 0; j < NSW; ++j) sf[j] = w3_relu8(sf[j]);
-      }
-#pragma unroll
-      for (int i = 0; i < MPW; ++i)
-#pragma unroll
-        for (int j = 0; j < NSW; ++j) acc[i][j] = w3_mfma(pf[i], sf[j], acc[i][j]);
-    };
     {
-      const int kend = (dbg & 2) ? 0 : ksteps;
+      auto mac = [&](h16x8 (&pf)[MPW], h16x8 (&sf)[NSW]) {
+#ifndef W3_ABL_NOACT
+        if constexpr (BP) {
+#pragma unroll
+          for (int i = 0; i < MPW; ++i) bsum[i] = w3_sum8(pf[i], bsum[i]);
+        }
+        if constexpr (BS) {  // (every S fragment of the wave: the epilogue takes the centre-tap ones, bmask)
+#pragma unroll
+          for (int j = 0; j < NSW; ++j) bsum[j] = w3_sum8(sf[j], bsum[j]);
+        }
+        if constexpr (RP) {
+#pragma unroll
+          for (int i = 0; i < MPW; ++i) pf[i] = w3_relu8(pf[i]);
+        }
+        if constexpr (RS) {
+#pragma unroll
+          for (int j = 0; j < NSW; ++j) sf[j] = w3_relu8(sf[j]);
+        }
+#endif
+#pragma unroll
+        for (int i = 0; i < MPW; ++i)
+#pragma unroll
+          for (int j = 0; j < NSW; ++j) acc[i][j] = w3_mfma(pf[i], sf[j], acc[i][j]);
+      };
       constexpr bool PIPE = MPW * NSW <= 6;  // (the 8- and 9-fragment blocks have no registers for a second fragment set)
       // (loop shape matters: ONE back edge, no exit in the middle -- with a break between the two halves hipcc kept two copies of the
       //  accumulators and moved 16 registers per MFMA between them)
       const int nk = (dbg & 2) ? 0 : nkw;
-      (void)kend;
       if constexpr (PIPE) {
         h16x8 pfA[MPW], sfA[NSW], pfB[MPW], sfB[NSW];
         if (nk > 0) load(pfA, sfA);
         int i = 0;
         for (; i + 2 <= nk; i += 2) {
           load(pfB, sfB);
+#ifndef W3_ABL_NOPOS
           if (i == 0) dma_pos(P0()); else if (i == 2) dma_pos(P2());
+#endif
           mac(pfA, sfA);
           if (i + 2 < nk) load(pfA, sfA);
+#ifndef W3_ABL_NOPOS
           if (i == 0) dma_pos(P1()); else if (i == 2) dma_pos(P3());
+#endif
           mac(pfB, sfB);
         }
         if (i < nk) mac(pfA, sfA);
@@ -661,7 +708,11 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
       }
       {  // request groups the K16-steps above did not reach (short tiles / K-split waves), then the slow-form remainder
         constexpr int per = PIPE ? 2 : 1;  // steps per pair of positions
+#ifdef W3_ABL_NOPOS
+        const int done = PIPE ? 0 : (nk / per) * 2;
+#else
         const int done = (nk / per) * 2;   // positions issued inside the loop (pairs of them)
+#endif
         if (done < 2) { dma_pos(P0()); dma_pos(P1()); }
         if (done < 4) { dma_pos(P2()); dma_pos(P3()); }
         dma_rest();
@@ -680,6 +731,20 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
 #pragma unroll
         for (int j = 0; j < NSW; ++j) { aS0[j] += dslot; aS1[j] += dslot; }
       }
+    }
+  }
+  };
+  {
+    typedef std::integral_constant<bool, false> F_;
+    typedef std::integral_constant<bool, true> T_;
+    switch (kmode) {  // (uniform per wave; x_is_s decides which operand is X: ReLU and the bias sums sit on opposite operands)
+      case 0: tile_loop(F_(), F_(), F_(), F_()); break;
+      case 1: tile_loop(T_(), F_(), F_(), F_()); break;   // ReLU on P (= X)
+      case 2: tile_loop(F_(), F_(), F_(), T_()); break;   // bias sums from S (= grad_out)
+      case 3: tile_loop(T_(), F_(), F_(), T_()); break;
+      case 4: tile_loop(F_(), T_(), F_(), F_()); break;   // ReLU on S (= X)
+      case 5: tile_loop(F_(), F_(), T_(), F_()); break;   // bias sums from P (= grad_out)
+      default: tile_loop(F_(), T_(), T_(), F_()); break;
     }
   }
 #undef W3_STAMP
@@ -806,25 +871,55 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
     default: wg3_body<4, 2>(p, a, b, c); break;                   \
   }
 
-__global__ __launch_bounds__(256, 2) void wg3_single_kernel(Wg3P p_) {
-  // (the record is read through a pointer, see w3_xreal: here it lives in the kernarg segment)
-  const Wg3P* __restrict__ gp = (const Wg3P*)__builtin_amdgcn_kernarg_segment_ptr();
-  const int b = blockIdx.x;
-  const int ns = gp->nsplit, npw = gp->n_pwin;
-  const int w = b / ns, sp_i = b - w * ns;
-  const int swin = w / npw, pwin = w - swin * npw;
-  W3_DISPATCH(gp, sp_i, pwin, swin)
+// ONE kernel for both launch forms (the 13 fragment blocks x 7 tile-loop instances take hipcc ~4 minutes; two kernels took ten):
+//   packed: all problems of a flush in one launch (as wgrad_tile_mega_kernel): a resident set of workgroups walks the block list
+//     (longest first), blocks[b] = {problem, split, P window, S window}; problems are read through a uniform pointer;
+//   single (single_slot >= 0): one problem, one workgroup per (S window, P window, split).  Its record reaches the kernel through
+//     device memory as well -- wg3_stash_kernel copies it from ITS kernel argument into g_w3single[slot] on the same stream just
+//     before -- because a record pointer that is either global memory or the kernarg segment becomes a flat pointer, every field
+//     read a vector load, and the body spills a thousand registers (measured).  Both launches are plain kernel launches with
+//     by-value arguments: capturable, and a replay re-stashes the same record.
+#define W3_SINGLE_SLOTS 512
+__device__ Wg3P g_w3single[W3_SINGLE_SLOTS];
+
+__global__ __launch_bounds__(64) void wg3_stash_kernel(const Wg3P p_, const int slot) {
+  (void)p_;
+  const uint32_t* src = (const uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();
+  uint32_t* dst = (uint32_t*)(g_w3single + slot);
+  for (int i = threadIdx.x; i < (int)(sizeof(Wg3P) / 4); i += 64) dst[i] = src[i];
 }
 
-// All problems of a flush in ONE launch (as wgrad_tile_mega_kernel): a resident set of workgroups walks the block list
-// (longest first), blocks[b] = {problem, split, P window, 0}; problems are read through a uniform pointer, by value.
-__global__ __launch_bounds__(256, 2) void wg3_mega_kernel(const Wg3P* __restrict__ probs, const int4* __restrict__ blocks, const int nblocks) {
+__global__ __launch_bounds__(256, 2) void wg3_mega_kernel(const Wg3P* __restrict__ probs, const int4* __restrict__ blocks, const int nblocks, const int single_slot) {
+  const Wg3P* __restrict__ const base = single_slot >= 0 ? g_w3single + single_slot : probs;
   for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
-    const int4 bi = blocks[b];
-    const Wg3P* __restrict__ gp = probs + __builtin_amdgcn_readfirstlane(bi.x);
+    int4 bi;
+    if (single_slot >= 0) {
+      const int ns = base->nsplit, npw = base->n_pwin;
+      const int w = b / ns;
+      bi.x = 0; bi.y = b - w * ns; bi.w = w / npw; bi.z = w - bi.w * npw;
+    } else {
+      bi = blocks[b];
+    }
+    const Wg3P* __restrict__ gp = base + __builtin_amdgcn_readfirstlane(bi.x);
     const int sp_i = __builtin_amdgcn_readfirstlane(bi.y), pwin = __builtin_amdgcn_readfirstlane(bi.z), swin = __builtin_amdgcn_readfirstlane(bi.w);
+    // optional block log (CGEN_WG3_BLOCKLOG=<device address of u64[1 + 4 n]>, tools/wg3_blocklog.py): [0] = entries so far, then per
+    // block {problem << 32 | H << 16 | ks << 8 | variant, ci << 48 | co << 32 | split << 16 | P window << 8 | S window, start, end}
+    // on the 100 MHz wall clock
+    unsigned long long* const blog = gp->blocklog;
+    unsigned long long t0 = 0;
+    if (blog != nullptr) t0 = wall_clock64();
     W3_DISPATCH(gp, sp_i, pwin, swin)
     __syncthreads();
+    if (blog != nullptr && threadIdx.x == 0) {
+      const unsigned long long t1 = wall_clock64();
+      const unsigned long long e = atomicAdd(blog, 1ull);
+      if (e < gp->blocklog_cap) {
+        unsigned long long* r = blog + 1 + 4 * e;
+        r[0] = ((unsigned long long)(unsigned)bi.x << 32) | ((unsigned)gp->H << 16) | ((unsigned)gp->ks << 8) | (unsigned)gp->variant;
+        r[1] = ((unsigned long long)(unsigned)gp->ci_total << 48) | ((unsigned long long)(unsigned)gp->co << 32) | ((unsigned)sp_i << 16) | ((unsigned)pwin << 8) | (unsigned)swin;
+        r[2] = t0; r[3] = t1;
+      }
+    }
   }
 }
 
@@ -936,30 +1031,45 @@ bool wg3_plan(const cgen_wgrad_args* a, Wg3Plan& g) {
   static const int want_slots = w3_env("CGEN_WG3_SLOTS", 3);
   static const int force_tpx = w3_env("CGEN_WG3_TPX", 0);
   const int halo = a->ks / 2;
-  q.tw = a->w >= 12 ? 16 : 8;
+  // 16 pixels of one row per K16-step, or 8 + 8 of two rows where that wastes fewer columns (24-pixel rows: 16 + 16 would carry a
+  // quarter of zeros through the DMA, the LDS and the MFMAs -- the 24^2 layers are a quarter of the final flush's time, LABNOTES 10.5)
+  {
+    const int pad16 = w3_pad(a->w, 16), pad8 = w3_pad(a->w, 8);
+    // (a tie -- 12-pixel rows -- goes to 8 as well: every 16-wide tile of such an image is ragged and takes the slow request form)
+    q.tw = (a->w < 12 || ((pad8 < pad16 || (pad8 == pad16 && a->w % 16 != 0 && w3_env("CGEN_WG3_TW8", 2) > 1)) && w3_env("CGEN_WG3_TW8", 2))) ? 8 : 16;
+  }
   q.kst_rows = 16 / q.tw;
   const int hpad = w3_pad(a->h, q.kst_rows);
   // the LARGEST tile (pixels) whose ring fits the LDS budget and whose requests fit the register-offset tables: the per-tile costs
   // (barrier, counted wait, request set-up) are fixed, so the narrow 192^2 / 96^2 layers -- 60 % of the bytes of a ukbb192 step --
   // want 256-pixel tiles where the 96-channel layers of 48^2 take 64 (same ~18 KB per ring slot).  Pass 0: three slots and only
   // register-offset requests; pass 1: two slots; pass 2: anything that fits.
-  static const int tpx_order[5] = {512, 256, 128, 64, 32};
+  // Candidates also with 3 / 6 / 12 / 24 rows: a 12- or 24-row image cut into 8-row tiles carries a third of padding rows.  Among the
+  // candidates a pass admits, the lowest estimated cost per valid pixel wins: (padded rows / rows) x (K16-steps + 2.5) / K16-steps,
+  // the 2.5 being the per-tile fixed cost in K16-steps (tools/bench_wgrad3.py batch with CGEN_WG3_TPX: LABNOTES 10.5).
+  static const int tpx_order[9] = {512, 384, 256, 192, 128, 96, 64, 48, 32};
   int pick = -1, pick_slots = 0;
   for (int pass = 0; pass < 3 && pick < 0; ++pass) {
-    for (int k = 0; k < 5; ++k) {
+    double best = 1e30;
+    for (int k = 0; k < 9; ++k) {
       const int tpx = force_tpx ? force_tpx : tpx_order[k];
+      if (tpx % q.tw) continue;
       int th = tpx / q.tw;
-      if (th < q.kst_rows || th + 2 * halo > 60) continue;
-      if (th > hpad && k != 4 && !force_tpx) continue;  // (a tile taller than the image: only as the last resort)
+      if (th < q.kst_rows || th % q.kst_rows || th + 2 * halo > 60) continue;
+      if (th > hpad && k != 8 && !force_tpx) continue;  // (a tile taller than the image: only as the last resort)
       W3Op P, S;
       w3_mk_op(P, wP, spP, th, q.tw, 0, cp8);
       w3_mk_op(S, cs8, spS, th + 2 * halo, q.tw + 2 * halo, halo, cs8);
       const int slot = w3_pad(P.bytes + S.bytes, 16);
       const int ns = std::min(want_slots, lds_cap / slot);
       const bool fast = ceil_div(P.ninstr, 4) <= W3_PN && ceil_div(S.ninstr, 4) <= W3_SN;
-      const bool counted = (ceil_div(P.ninstr, 4) + ceil_div(S.ninstr, 4)) * std::max(0, ns - 2) <= 47;
+      const bool counted = (ceil_div(P.ninstr, 4) + ceil_div(S.ninstr, 4)) * std::max(0, ns - 2) <= 15;
       const bool ok = pass == 0 ? (ns >= want_slots && fast && counted) : (pass == 1 ? (ns >= 2 && fast && counted) : ns >= 2);
-      if (ok) { pick = tpx; pick_slots = ns; break; }
+      if (ok) {
+        const int kst = th * q.tw / 16;
+        const double cost = (double)(ceil_div(a->h, th) * th) / a->h * (kst + 2.5) / kst;
+        if (cost < best - 1e-9) { best = cost; pick = tpx; pick_slots = ns; }
+      }
       if (force_tpx) break;
     }
   }
@@ -999,6 +1109,9 @@ bool wg3_plan(const cgen_wgrad_args* a, Wg3Plan& g) {
   q.pw = a->partial_w; q.pb = a->partial_b;
   static unsigned long long* const stamps = [] { const char* e = getenv("CGEN_WG3_STAMPS"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }();
   q.stamps = stamps;
+  static unsigned long long* const blog = [] { const char* e = getenv("CGEN_WG3_BLOCKLOG"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : nullptr; }();
+  q.blocklog = blog;
+  q.blocklog_cap = (unsigned long long)w3_env("CGEN_WG3_BLOCKLOG_CAP", 0);
   static const int dbg = w3_env("CGEN_WG3_DBG", 0);
   q.dbg = dbg;
   if (getenv("CGEN_WG3_PLAN_DEBUG"))
@@ -1012,7 +1125,6 @@ bool wg3_plan(const cgen_wgrad_args* a, Wg3Plan& g) {
 static void w3_attr_once() {
   static bool once = false;
   if (!once) {
-    (void)hipFuncSetAttribute((const void*)wg3_single_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)wg3_mega_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
@@ -1020,12 +1132,15 @@ static void w3_attr_once() {
 
 void wg3_launch_single(const Wg3Plan& g, hipStream_t st) {
   w3_attr_once();
-  hipLaunchKernelGGL(wg3_single_kernel, dim3(g.nblocks), dim3(256), g.lds, st, g.q);
+  static std::atomic<unsigned> next{0};
+  const int slot = (int)(next.fetch_add(1) % W3_SINGLE_SLOTS);  // (a slot is rewritten 512 single launches later; a captured launch keeps its slot)
+  hipLaunchKernelGGL(wg3_stash_kernel, dim3(1), dim3(64), 0, st, g.q, slot);
+  hipLaunchKernelGGL(wg3_mega_kernel, dim3(g.nblocks), dim3(256), g.lds, st, (const Wg3P*)nullptr, (const int4*)nullptr, g.nblocks, slot);
 }
 
 void wg3_launch_mega(const Wg3P* probs_dev, const int4* blocks_dev, int nblocks, int grid, size_t lds, hipStream_t st) {
   w3_attr_once();
-  hipLaunchKernelGGL(wg3_mega_kernel, dim3(grid), dim3(256), lds, st, probs_dev, blocks_dev, nblocks);
+  hipLaunchKernelGGL(wg3_mega_kernel, dim3(grid), dim3(256), lds, st, probs_dev, blocks_dev, nblocks, -1);
 }
 
 }  // namespace cgen

@@ -294,7 +294,7 @@ class Engine(StageMixin, WgradMixin):
         self.wgrad_batch = os.environ.get("CGEN_WGRAD_BATCH", "1") != "0"
         # background flushes: once this many GFLOP of weight gradients are pending they are issued on a side stream with a
         # capped grid, so that they fill the CUs the latency-bound backward chain leaves idle (0: one batch at the end)
-        self.wgrad_flush_frac = [float(v) for v in os.environ.get("CGEN_WGRAD_FLUSH_FRAC", "0.65").split(",") if v]
+        self.wgrad_flush_frac = [float(v) for v in os.environ.get("CGEN_WGRAD_FLUSH_FRAC", "0.7").split(",") if v]
         self.wgrad_bg_wgs = int(os.environ.get("CGEN_WGRAD_BG_WGS", "304"))
         self.wgrad_bg_reduce = os.environ.get("CGEN_WGRAD_BG_REDUCE", "1") != "0"
         self._wg_cum, self._wg_total, self._wg_nflush = 0.0, 0.0, 0

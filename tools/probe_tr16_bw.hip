@@ -47,9 +47,9 @@ int main() {
       {"all lanes same 128 B", 0, 32, 0},
   };
   for (auto& p : pats) {
-    for (int waves : {4, 8}) {
+    for (int waves : {1, 2, 4, 8, 16}) {
       hipLaunchKernelGGL(k, dim3(1), dim3(64 * waves), 64 * 1024, 0, d, p.A, p.SP, p.B, iters);
-      unsigned long long h[8];
+      unsigned long long h[16];
       hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
       unsigned long long mx = 0;
       for (int w = 0; w < waves; ++w) mx = h[w] > mx ? h[w] : mx;
