@@ -2542,6 +2542,18 @@ __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, 
 #pragma unroll
       for (int c = 0; c < 4; ++c) b[c] = make_float4(0.f, 0.f, 0.f, 0.f);
       int sp = 0;
+      // sixteen loads in flight per thread first: a thread walks its element's splits alone, and the streaming weight-gradient kernel
+      // leaves up to 144 of them (192^2 layers) -- at four per round trip the final reduce was 36 dependent HBM latencies long
+      // (0.15 ms at the end of every step for 108 MB).  The order of the additions is the one below: bit-identical sums.
+      for (; sp + 16 <= d.nsplit; sp += 16) {
+        f32x4 t[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) t[c] = __builtin_nontemporal_load((const f32x4*)(src + (size_t)(sp + c) * stride));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { b[c].x += t[4 * u + c][0]; b[c].y += t[4 * u + c][1]; b[c].z += t[4 * u + c][2]; b[c].w += t[4 * u + c][3]; }
+      }
       for (; sp + 4 <= d.nsplit; sp += 4) {
         float4 v[4];
 #pragma unroll
@@ -2577,6 +2589,9 @@ __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, 
         const unsigned co = r / (unsigned)taps, tap = r - co * taps;
         o = ((size_t)co * d.ci_total + ci) * taps + tap;
       }
+#ifdef WRED_ABL_NOSCATTER  // (ablation build, wrong results: the sums go out in partial order, coalesced)
+      o = sidx;
+#endif
       d.grad_w[o] = d.accumulate ? d.grad_w[o] + a[e] * us : a[e] * us;
     }
   }
@@ -2586,7 +2601,15 @@ __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, 
       if (o >= nw && o < d.numel) {
         const int co = o - nw;
         float acc = 0.f;
-        for (int sp = 0; sp < d.nsplit; ++sp) acc += d.partial_b[(size_t)sp * d.co + co];
+        int sp = 0;
+        for (; sp + 16 <= d.nsplit; sp += 16) {  // (loads first, additions in split order)
+          float t[16];
+#pragma unroll
+          for (int c = 0; c < 16; ++c) t[c] = d.partial_b[(size_t)(sp + c) * d.co + co];
+#pragma unroll
+          for (int c = 0; c < 16; ++c) acc += t[c];
+        }
+        for (; sp < d.nsplit; ++sp) acc += d.partial_b[(size_t)sp * d.co + co];
         d.grad_b[co] = d.accumulate ? d.grad_b[co] + acc * us : acc * us;
       }
     }
