@@ -22,6 +22,7 @@
 #include <stddef.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -148,8 +149,9 @@ __device__ __forceinline__ void b3_chunk(const char* __restrict__ Xc, const h16x
 // first use of an ordinary load's result, so ordinary loads are kept out of the spans a burst should survive: weights are
 // PERSISTENT in registers where a tile needs <= 2 chunks / the wave's output pair never changes (loaded once per launch), the
 // epilogue operands are requested BEFORE the next tile's burst and consumed at the very end of the tile.
+// (the kernel body: `bid` of `nb` workgroups walk the tiles of problem p -- the whole grid, or one half of a pair launch)
 template <bool PRE, int NB, int NPG, int SM, int TH, bool REM>
-__global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
+__device__ __forceinline__ void blk3_body(const B3P& p, const int bid, const int nb, const int koff) {  // koff: byte offset of p in the kernarg segment
   constexpr int NMP = b3_nmp(TH), XB = b3_xbytes(TH), NDI = b3_ndi(TH);
   constexpr int NG = (NMP + 63) / 64;  // bottleneck pixel groups (of 32) per wave in phase A: 3 / 4
   constexpr int PGW = (TH / 2) / (NPG == 4 ? 1 : (NPG == 2 ? 2 : 4));  // output pixel groups a wave owns in phase B
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   const int H = p.H, W = p.W, nch = p.nch, bch = p.b;
   constexpr bool bwd = !PRE;  // (the host pairs them: forward = ReLU on the input + bias, backward = mask from mid_aux)
   const char* const zero = (const char*)g_b3zero;
-  unsigned long long* const stamp = (p.stamps != nullptr && blockIdx.x == 0 && lane == 0) ? p.stamps + wave * 256 : nullptr;  // (every wave's first lane: 256 slots each)
+  unsigned long long* const stamp = (p.stamps != nullptr && bid == 0 && lane == 0) ? p.stamps + wave * 256 : nullptr;  // (every wave's first lane: 256 slots each)
   int nstamp = 2;
 #define B3_STAMP(k) do { if (stamp && nstamp + (k) < 250) stamp[nstamp + (k)] = __builtin_readcyclecounter(); } while (0)
   if (stamp) stamp[0] = __builtin_readcyclecounter();
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     // (scalar loads straight from the kernarg segment, indexed by the wave-uniform segment number: written as a chain of selects
     //  over p.seg[...], hipcc builds a table in SCRATCH and the lookups land on vmcnt, in the middle of the DMA requests)
     typedef const char __attribute__((address_space(4)))* karg_ptr;
-    const karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + koff;
     typedef const BV3 __attribute__((address_space(4)))* kseg_ptr;
     typedef const int __attribute__((address_space(4)))* kint_ptr;
     const kseg_ptr ks = (kseg_ptr)(ka + offsetof(B3P, seg)) + sg;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     if (nch > 1) dma_chunk(ring + XB, tn, ty0, tx0, tvb, 1);
   };
   if constexpr (SM == 0) {
-    if ((int)blockIdx.x < p.ntiles) issue_tile(smem, blockIdx.x);
+    if (bid < p.ntiles) issue_tile(smem, bid);
   }
   if (stamp) stamp[1] = __builtin_readcyclecounter();
   // The tile loop sees LDS through TWO __restrict__ views of the same memory: `lw` is only ever the destination of LDS-DMA, `lr` is
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   int sbase = 0;            // ring slot of the current tile's chunk 0
   bool prefetched = false;  // this tile's chunks were requested during the previous tile
   int tmsel = 0;            // which mask buffer holds the current tile's (SM > 0, backward)
-  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+  for (int tile = bid; tile < p.ntiles; tile += nb) {
     int n, y0, x0, vb;
     if constexpr (SM == 0) {
       n = tn; y0 = ty0; x0 = tx0; vb = tvb;  // (requested by issue_tile: in the prologue, or at the end of the previous tile)
@@ -397,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     constexpr int NEPI = SM > 0 ? PGW : 1;
     uint4 ea0[NEPI][2], er0[NEPI][2];
     constexpr bool early_epi = SM > 0;  // (SM > 0: one output, the wave's pair is fixed -- checked by the host)
-    const int next_tile = tile + gridDim.x;
+    const int next_tile = tile + nb;
     const bool burst_next = SM > 0 && next_tile < p.ntiles && NS >= nch + 1;
     // One chunk step.  Xc (the slot being read) and the ring (DMA destinations: always OTHER slots) are __restrict__ parameters
     // of ONE body: that is what lets hipcc keep a DMA in flight under the fragment reads.
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
       // (read through the kernarg segment: `p.o[oi]` with a run-time index takes the address of the by-value struct, and hipcc
       //  then keeps a 472-byte copy of it in scratch -- every later field read becomes a scratch load counted on vmcnt)
       typedef const B3Out __attribute__((address_space(4)))* kout_ptr;
-      const kout_ptr Ok = (kout_ptr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(B3P, o)) + oi;
+      const kout_ptr Ok = (kout_ptr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + koff + offsetof(B3P, o)) + oi;
       const char* const Ow = Ok->w;
       const char* const Oout = Ok->out.p; const int Oout_sn = Ok->out.sn, Oout_sh = Ok->out.sh, Oout_sw = Ok->out.sw;
       const char* const Oaux = Ok->aux.p; const int Oaux_sn = Ok->aux.sn, Oaux_sh = Ok->aux.sh, Oaux_sw = Ok->aux.sw;
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
     }
     // (the next tile's first barrier separates these reads of the bottleneck tile from its next writes)
     if constexpr (SM == 0) {
-      if (tile + (int)gridDim.x < p.ntiles) issue_tile(lw, tile + gridDim.x);  // (every ring slot is free: the exchange through them ended before phase B)
+      if (tile + nb < p.ntiles) issue_tile(lw, tile + nb);  // (every ring slot is free: the exchange through them ended before phase B)
     }
     B3_STAMP(6);
     nstamp += 8;
@@ -717,6 +719,26 @@ __global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
   asm volatile("" : "+s"(off_r));
   asm volatile("" : "+s"(off_w));
   run(smem + off_r, smem + off_w);
+}
+
+template <bool PRE, int NB, int NPG, int SM, int TH, bool REM>
+__global__ __launch_bounds__(256, 2) void blk3_kernel(B3P p) {
+  blk3_body<PRE, NB, NPG, SM, TH, REM>(p, (int)blockIdx.x, (int)gridDim.x, 0);
+}
+
+// Two independent problems of the SAME instance in one launch: workgroups 0 .. na - 1 take the first, the rest the second (the data
+// gradients of a decoder layer's posterior and prior Blocks: two kernels of 100-400 workgroups each on 512 resident slots, which a
+// second queue can only overlap at ~6 us per cross-queue edge on the main chain, LABNOTES 9.9 / 10.4).  The record is picked by
+// address inside the kernarg segment, so its fields stay scalar loads.
+template <bool PRE, int NB, int NPG, int SM, int TH, bool REM>
+__global__ __launch_bounds__(256, 2) void blk3_pair_kernel(B3P pa, B3P pb, const int na) {
+  (void)pa; (void)pb;
+  const bool second = (int)blockIdx.x >= na;
+  constexpr size_t off_b = (sizeof(B3P) + alignof(B3P) - 1) / alignof(B3P) * alignof(B3P);
+  const int koff = second ? (int)off_b : 0;
+  typedef const B3P __attribute__((address_space(4)))* kp_ptr;
+  const B3P& p = *(const B3P*)(kp_ptr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + koff);
+  blk3_body<PRE, NB, NPG, SM, TH, REM>(p, second ? (int)blockIdx.x - na : (int)blockIdx.x, second ? (int)gridDim.x - na : na, koff);
 }
 
 // ----------------------------------------------------------------------------- host side
@@ -784,7 +806,7 @@ static int b3_fill(const cgen_block3_args* a, B3P& p) {
 struct B3Launch { int npg, grid, sm, th; size_t lds; };
 // Ring depth, persistence and LDS size.  Two workgroups per CU (78 KB each) unless the launch has at most one tile per CU, which
 // may take a whole CU's LDS; a ring one slot deeper than a tile needs lets the next tile's burst travel under this tile's work.
-static B3Launch b3_plan(B3P& p) {
+static B3Launch b3_plan(B3P& p, const int co_tiles = 0) {  // co_tiles: tiles of the problem sharing the launch (cgen_block3_pair)
   B3Launch L;
   int npb = 0;
   for (int o = 0; o < p.nout; ++o) npb = p.o[o].npb > npb ? p.o[o].npb : npb;
@@ -810,7 +832,7 @@ static B3Launch b3_plan(B3P& p) {
   const int nmi = (nmp * nb + 63) / 64;  // DMA instructions of a mask tile
   const int extra = p.nch <= 2 ? ((nmp + 63) / 64) * 4096 : 0;  // second half of the partial-sum exchange (one-chunk tiles, and every streaming launch): 4 KiB per pixel group
   L.grid = p.ntiles < slots_wg ? p.ntiles : slots_wg;
-  const int cap = (p.ntiles <= 256 ? 150 : (per_cu >= 3 ? 52 : 78)) * 1024;
+  const int cap = (p.ntiles + co_tiles <= 256 ? 150 : (per_cu >= 3 ? 52 : 78)) * 1024;
   int ns;
   if (L.sm == 0) {  // two chunks ahead where three slots fit next to a second workgroup (<= 73 KB with eight rows and a 32-wide bottleneck)
     ns = (p.nch >= 3 && 3 * xb + mid_bytes + extra + 1024 <= cap) ? 3 : 2;
@@ -866,9 +888,55 @@ static void b3_launch_pre(const B3P& p, const B3Launch& L, hipStream_t st) {
   }
 }
 
+// pair launch: the data-gradient instances without the streaming mode (both problems must plan to the SAME one)
+template <int NB, int NPG, int TH = 8>
+static void b3_pair_inst(const B3P& pa, const B3P& pb, const B3Launch& La, const B3Launch& Lb, hipStream_t st) {
+  (void)hipFuncSetAttribute((const void*)blk3_pair_kernel<false, NB, NPG, 0, TH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((blk3_pair_kernel<false, NB, NPG, 0, TH, false>), dim3(La.grid + Lb.grid), dim3(256), std::max(La.lds, Lb.lds), st, pa, pb, La.grid);
+}
+template <int NB>
+static void b3_pair_nb(const B3P& pa, const B3P& pb, const B3Launch& La, const B3Launch& Lb, hipStream_t st) {
+  if (La.npg == 1) b3_pair_inst<NB, 1>(pa, pb, La, Lb, st);
+  else if (La.npg == 2) b3_pair_inst<NB, 2>(pa, pb, La, Lb, st);
+  else if (NB <= 3 && La.th == 12) { if constexpr (NB <= 3) b3_pair_inst<NB, 4, 12>(pa, pb, La, Lb, st); }
+  else b3_pair_inst<NB, 4>(pa, pb, La, Lb, st);
+}
+// 0: the two problems cannot share a launch
+static int b3_pair_plan(const cgen_block3_args* a, const cgen_block3_args* b, B3P& pa, B3P& pb, B3Launch& La, B3Launch& Lb) {
+  if (!a || !b || a->pre_act || b->pre_act || !a->mid_aux.p || !b->mid_aux.p) return 0;
+  if (!b3_fill(a, pa) || !b3_fill(b, pb)) return 0;
+  const int ta = pa.ntiles, tb = pb.ntiles;  // (eight-row tiles: the cap decision below only needs "more than one tile per CU or not")
+  La = b3_plan(pa, tb);
+  Lb = b3_plan(pb, ta);
+  if (La.sm || Lb.sm || La.npg != Lb.npg || La.th != Lb.th || pa.b != pb.b) return 0;
+  if (pa.o[0].out_rem || pa.o[0].res_rem || pb.o[0].out_rem || pb.o[0].res_rem) return 0;
+  return 1;
+}
+
 }  // namespace cgen
 
 using namespace cgen;
+
+extern "C" int cgen_block3_pair_supported(const cgen_block3_args* a, const cgen_block3_args* b) {
+  B3P pa, pb;
+  B3Launch La, Lb;
+  return b3_pair_plan(a, b, pa, pb, La, Lb);
+}
+
+extern "C" int cgen_block3_pair(const cgen_block3_args* a, const cgen_block3_args* b, cgen_stream_t stream) {
+  B3P pa, pb;
+  B3Launch La, Lb;
+  CGEN_REQUIRE(b3_pair_plan(a, b, pa, pb, La, Lb), "cgen_block3_pair: the two problems do not plan to the same data-gradient instance (ask cgen_block3_pair_supported first)");
+  switch (pa.b / 8) {
+    case 1: b3_pair_nb<1>(pa, pb, La, Lb, (hipStream_t)stream); break;
+    case 2: b3_pair_nb<2>(pa, pb, La, Lb, (hipStream_t)stream); break;
+    case 3: b3_pair_nb<3>(pa, pb, La, Lb, (hipStream_t)stream); break;
+    default: b3_pair_nb<4>(pa, pb, La, Lb, (hipStream_t)stream); break;
+  }
+  static const bool trace = getenv("CGEN_CONV_TRACE") != nullptr;
+  if (trace) fprintf(stderr, "blk3 pair[bwd] %dx%dx%d b %d | grids %d + %d, lds %zu, tile rows %d\n", a->n, a->h, a->w, pa.b, La.grid, Lb.grid, std::max(La.lds, Lb.lds), La.th);
+  return check_launch("cgen_block3_pair");
+}
 
 extern "C" int cgen_block3_supported(const cgen_block3_args* a) {
   B3P p;

@@ -295,6 +295,12 @@ class Engine(StageMixin, WgradMixin):
         # background flushes: once this many GFLOP of weight gradients are pending they are issued on a side stream with a
         # capped grid, so that they fill the CUs the latency-bound backward chain leaves idle (0: one batch at the end)
         self.wgrad_flush_frac = [float(v) for v in os.environ.get("CGEN_WGRAD_FLUSH_FRAC", "0.7").split(",") if v]
+        # Data gradients of two ADJACENT fused Blocks of the tape (a decoder layer's posterior and prior Block) in one launch
+        # (cgen_block3_pair): backward() arms the first one, whose launch is held until the second reaches its own launch point.
+        self.blk3_pair = os.environ.get("CGEN_BLK3_PAIR", "1") != "0"
+        self._blk3_arm = 0      # 1: the next fused data-gradient launch is to be held; 2: one is held, waiting for its partner
+        self._blk3_hold = None  # (args, launch counter at hold time, tensors touched, the held Block's late bookkeeping)
+        self.blk3_pairs = 0     # pair launches of the last backward pass
         self.wgrad_bg_wgs = int(os.environ.get("CGEN_WGRAD_BG_WGS", "304"))
         self.wgrad_bg_reduce = os.environ.get("CGEN_WGRAD_BG_REDUCE", "1") != "0"
         self._wg_cum, self._wg_total, self._wg_nflush = 0.0, 0.0, 0
@@ -727,6 +733,7 @@ class Engine(StageMixin, WgradMixin):
         Block: h and the encoder activation) -- else the two conv launches."""
         g = self.grad_read(out)
         if g is None:
+            self._blk3_flush()
             return
         act = ACT_RELU
         dsegs = [k for k, sg in enumerate(segs) if sg.rg and site1.seg_rg[k]]
@@ -744,10 +751,12 @@ class Engine(StageMixin, WgradMixin):
                 probe.o[j].out, probe.o[j].aux, probe.o[j].res1 = sg.cv(), sg.cv(), NULL_VIEW
             ok = bool(self.lib.block3_supported(C.byref(probe)))
         if not ok:
+            self._blk3_flush()
             self._bw_conv(site2, [t], act, out, res1, None)
             self._bw_conv(site1, segs, act, t, None, None)
             return
         if res1 is not None and res1.rg:
+            self._blk3_flush()  # (a residual Block is never the second of a pair: its residual gradient is a launch of its own)
             self._grad_residual(res1, g, out, [t])
         if self._needs_wgrad(site2) and "wg" not in self._ablate:
             self._wgrad(site2, [t], act, g)
@@ -767,19 +776,51 @@ class Engine(StageMixin, WgradMixin):
             a.o[j].out, a.o[j].aux = gv.cv(), sg.cv()
             a.o[j].res1 = prev.cv() if acc else NULL_VIEW
         x0 = segs[0]
+        late = (lambda: self._wgrad(site1, segs, act, gt)) if (self._needs_wgrad(site1) and "wg" not in self._ablate) else (lambda: None)
         if self._ablate and any(x0.h == r and ("r%d" % r) in self._ablate for r in (24, 48, 96, 192)):
-            pass
+            self._blk3_flush()
         elif self.lib.block3_supported(C.byref(a)):
+            # tensors this launch writes / reads (storage identity): a pair must not touch each other's
+            wr = {id(gt.base)} | {id(gv.base) for (_, gv, _, _) in tgt}
+            rd = {id(g.base), id(t.base)} | {id(segs[k].base) for (k, _, _, _) in tgt} | {id(prev.base) for (_, _, prev, acc) in tgt if acc}
+            if self._blk3_arm == 1 and self.prof is None:
+                # held: the partner launches both.  The weight gradient that READS gt is queued only after that launch (a background
+                # flush triggered in between must not see it)
+                self._blk3_hold = (a, self.launches, wr, rd, late, (site1, site2, x0))
+                self._blk3_arm = 2
+                return
+            if self._blk3_hold is not None:
+                ha, hl, hwr, hrd, hlate, hinfo = self._blk3_hold
+                if (hl == self.launches and not (hwr & (wr | rd)) and not (wr & hrd)
+                        and self.lib.block3_pair_supported(C.byref(ha), C.byref(a))):
+                    self._blk3_hold, self._blk3_arm = None, 0
+                    self.lib.block3_pair(C.byref(ha), C.byref(a), self.stream)
+                    self.launches += 1
+                    self.blk3_pairs += 1
+                    hlate()
+                    late()
+                    return
+                self._blk3_flush()
             self._timed_blk("conv_dgrad", site1, site2, x0, lambda: self.lib.block3(C.byref(a), self.stream))
         else:
             # The REAL gradient views are not served (the probe above saw the forward tensors' views; a gradient buffer may be laid
             # out differently: an out-of-place accumulate target, a copy-on-write -- ADVICE r4): the two data-gradient convs, into
             # the targets already acquired (the bookkeeping above has run and must not run twice)
+            self._blk3_flush()
             self._dgrad_launch(site2, g, t, 0, act, t, gt, gt, False)
             for (k, gv, prev, acc) in tgt:
                 self._dgrad_launch(site1, gt, segs[k], k, act, x0, gv, prev, acc)
-        if self._needs_wgrad(site1) and "wg" not in self._ablate:
-            self._wgrad(site1, segs, act, gt)
+        late()
+
+    def _blk3_flush(self):
+        """Launch a held fused data gradient on its own (its partner did not come, or cannot share the launch)."""
+        self._blk3_arm = 0
+        if self._blk3_hold is None:
+            return
+        ha, _, _, _, hlate, (s1, s2, x0) = self._blk3_hold
+        self._blk3_hold = None
+        self._timed_blk("conv_dgrad", s1, s2, x0, lambda: self.lib.block3(C.byref(ha), self.stream))
+        hlate()
 
     def _timed(self, kind, site, x0, fn, ci=None):
         """Launch `fn`; when profiling, bracket it with events on the launch stream and tally algorithmic FLOPs
@@ -1281,8 +1322,23 @@ class Engine(StageMixin, WgradMixin):
                         self._bw_set_mark()
             self._bw_end()
         else:
-            for fn, args, _ in reversed(self.tape):
-                fn(*args)
+            self.blk3_pairs = 0
+            tape = self.tape
+            for i in range(len(tape) - 1, -1, -1):
+                fn, args, _ = tape[i]
+                if fn == self._bw_block3:
+                    # (armed when the NEXT entry is a fused Block of the same image size without a residual: the layer's prior Block)
+                    nxt = tape[i - 1] if i > 0 else None
+                    if (self.blk3_pair and self._blk3_hold is None and nxt is not None and nxt[0] == self._bw_block3
+                            and nxt[1][5] is None and nxt[1][2][0].h == args[2][0].h and nxt[1][2][0].w == args[2][0].w):
+                        self._blk3_arm = 1
+                    fn(*args)
+                    if self._blk3_arm == 1:  # (it did not reach its launch point)
+                        self._blk3_arm = 0
+                else:
+                    self._blk3_flush()
+                    fn(*args)
+            self._blk3_flush()
         for bid in list(self._riders):
             gv, g, acc = self._riders.pop(bid)
             self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)

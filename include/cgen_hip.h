@@ -52,7 +52,7 @@ typedef struct cgen_view {
 /* ABI version of this header.  cgen_version() of the loaded library must equal it (causal-gen_amd/_lib.py checks): struct layouts,
  * enum values and signatures are only compatible within one version.  cgen_h16_format(): the 16-bit storage format the library was
  * BUILT for -- 0 = IEEE binary16 (default), 1 = bfloat16 (-DCGEN_H16_BF16, an A/B build); CGEN_F16 tensors must be in that format. */
-#define CGEN_ABI_VERSION 402
+#define CGEN_ABI_VERSION 403
 int cgen_version(void);
 int cgen_h16_format(void);
 const char* cgen_last_error(void);
@@ -113,6 +113,13 @@ typedef struct cgen_block3_args {
 } cgen_block3_args;
 int cgen_block3_supported(const cgen_block3_args* a);
 int cgen_block3(const cgen_block3_args* a, cgen_stream_t stream);
+/* Two independent DATA-GRADIENT problems (pre_act = 0) in ONE launch: the backward of a decoder layer's posterior and prior Blocks
+ * (vae.py:240-301: both hang off the layer's reparameterisation, neither reads what the other writes).  Each is 100-400 workgroups on
+ * 512 resident slots; one launch runs them side by side without a second queue.  Served when both plan to the same kernel instance
+ * (same bottleneck width, same widest-output class, no streaming mode, no remainder planes): ask _supported first.  The caller
+ * guarantees that neither problem reads or accumulates into a tensor the other one writes. */
+int cgen_block3_pair_supported(const cgen_block3_args* a, const cgen_block3_args* b);
+int cgen_block3_pair(const cgen_block3_args* a, const cgen_block3_args* b, cgen_stream_t stream);
 
 /* Weight gradient (aten::convolution_backward, weight/bias part) as split-K partials:
  *   partial_w[split][Co][KS*KS][Ci_total] (f32), partial_b[split][Co] (f32, may be NULL)

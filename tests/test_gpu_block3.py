@@ -184,3 +184,70 @@ def test_fused_block3_remainder_planes(shape):
         assert float(e2.mean()) * 20 < float(plain.mean()), (fuse, float(e2.mean()), float(plain.mean()))
     d = float(((outs[2][1][0] + outs[2][1][1]) - (outs[0][1][0] + outs[0][1][1])).abs().max())
     assert d <= 0.02 * float(outs[0][1][0].abs().max()), d  # (a bottleneck value within rounding of an f16 boundary may round the other way)
+
+
+def _run_two(N, H, W, b, segA, rgA, coA, segB, rgB, coB, pair, seed=0):
+    """Two independent light Blocks recorded back to back (the posterior and the prior Block of a decoder layer, vae.py:240-301), one
+    backward pass: with `pair` their data gradients share a launch (cgen_block3_pair)."""
+    from causal_gen_amd.engine import ConvSite, Engine
+
+    g = torch.Generator().manual_seed(77 + seed + H)
+    convs, sites, ins, gouts = [], [], [], []
+    for k, (segc, co) in enumerate(((segA, coA), (segB, coB))):
+        ci = sum(segc)
+        c1, c2 = torch.nn.Conv2d(ci, b, 3, padding=1), torch.nn.Conv2d(b, co, 3, padding=1)
+        with torch.no_grad():
+            c1.weight.copy_(torch.randn(c1.weight.shape, generator=g) / math.sqrt(ci * 9 / 2))
+            c2.weight.copy_(torch.randn(c2.weight.shape, generator=g) / math.sqrt(b * 9 / 2))
+            c1.bias.copy_(torch.randn(b, generator=g) * 0.2)
+            c2.bias.copy_(torch.randn(co, generator=g) * 0.2)
+        convs += [c1, c2]
+        ins.append([torch.randn(N, c, H, W, generator=g).half().float() for c in segc])
+        gouts.append(torch.randn(N, co, H, W, generator=g).half().float())
+    eng = Engine("cuda", "f16")
+    eng.blk3_on, eng.blk3_minres, eng.blk3_res, eng.blk3_res3 = 2, 8, [], []
+    eng.blk3_pair = pair
+    holder = torch.nn.ModuleList(convs).cuda()
+    for k, (segc, rg) in enumerate(((segA, rgA), (segB, rgB))):
+        s1 = ConvSite("c%da" % k, holder[2 * k], segc, [bool(r) for r in rg], 2 * k)
+        s2 = ConvSite("c%db" % k, holder[2 * k + 1], [b], [True], 2 * k + 1)
+        s1.blk3, s2.blk3 = ("a", s2), ("b", s1)
+        sites += [s1, s2]
+    eng.bind(holder, sites)
+    eng.begin()
+    eng.prepare_weights(force=True)
+    eng.recording = True
+    nts, ys = [], []
+    for k in (1, 0):  # tape: [B][A] -- backward() meets A first, then B
+        rg = (rgA, rgB)[k]
+        t = [eng.from_nchw(x.cuda(), rg=bool(r)) for x, r in zip(ins[k], rg)]
+        nts.append((k, t))
+        ys.append((k, eng.block2(sites[2 * k], sites[2 * k + 1], t, 1)))
+    for k, y in ys:
+        gy = eng.seed_grad(y)
+        eng.lib.axpby(eng.dt, N, H, W, eng.from_nchw(gouts[k].cuda()).cv(), gy.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
+    eng.recording = False
+    eng.backward()
+    torch.cuda.synchronize()
+    out = []
+    for k, t in nts:
+        out += [eng.to_nchw(eng.grad_read(v)).cpu() for v in t if v.rg]
+    out += [eng.param_grad_view(p).cpu().clone() for c in holder for p in (c.weight, c.bias)]
+    return out, eng.blk3_pairs
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 48, 48, 24, [96, 4, 96], [1, 0, 1], 32, [96, 4], [1, 0], 128),    # a 48^2 decoder layer at batch 2: posterior cat[h, pa, acts] | prior cat[z, pa]
+    (32, 48, 48, 24, [96, 4, 96], [1, 0, 1], 32, [96, 4], [1, 0], 128),   # ... at the bench batch: twelve-row tiles, 768 workgroups for 512 slots
+    (8, 24, 24, 32, [128, 4, 128], [1, 0, 1], 32, [128], [1], 160),       # 24^2
+    (3, 20, 28, 16, [64], [1], 96, [64, 4], [1, 0], 32),                   # ragged image, different output classes (no pair: two launches)
+], ids=["48x48-b2", "48x48-b32", "24x24", "mismatch"])
+def test_block3_pair_launch_is_bit_identical_to_two_launches(shape):
+    a, pa = _run_two(*shape, pair=False)
+    b, pb = _run_two(*shape, pair=True)
+    assert pa == 0
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), float((x - y).abs().max())
+    print("pair launches:", pb)
+    if shape[0] != 3:
+        assert pb == 1
