@@ -96,6 +96,8 @@ PROTOTYPES = {
     "cgen_h16_format": [],
     "cgen_last_error": [],
     "cgen_conv2d": [C.POINTER(ConvArgs), vp],
+    "cgen_conv2d_pair_supported": [C.POINTER(ConvArgs), C.POINTER(ConvArgs)],
+    "cgen_conv2d_pair": [C.POINTER(ConvArgs), C.POINTER(ConvArgs), vp],
     "cgen_block3_supported": [C.POINTER(Block3Args)],
     "cgen_block3": [C.POINTER(Block3Args), vp],
     "cgen_block3_pair_supported": [C.POINTER(Block3Args), C.POINTER(Block3Args)],
@@ -160,9 +162,9 @@ PROTOTYPES = {
     "cgen_stage_run": [vp, i32, i32, i32, vp],
 }
 _RESTYPES = {"cgen_last_error": C.c_char_p}
-ABI_VERSION = 403  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
+ABI_VERSION = 404  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
 _NOCHECK = {"cgen_version", "cgen_h16_format", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks",
-            "cgen_block3_supported", "cgen_block3_pair_supported", "cgen_stem_conv_supported", "cgen_stage_accepts"}
+            "cgen_block3_supported", "cgen_block3_pair_supported", "cgen_conv2d_pair_supported", "cgen_stem_conv_supported", "cgen_stage_accepts"}
 
 
 class WgradBatchLaunch(C.Structure):

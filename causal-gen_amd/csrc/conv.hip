@@ -821,22 +821,23 @@ static bool launch_conv_px(const ConvP& p, hipStream_t st);  // lean persistent 
 // lane: a weight-image row slice and an im2col slice of one pixel) with four K-steps in flight, and the four partial sums
 // are added through LDS in a fixed order (deterministic).  One workgroup = 16*SP_NCO output channels x 32 pixels.
 template <int KS, int SP_NCO, int KU, bool ONESEG>
-__global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, FastDiv d_ctot8, FastDiv d_hw, FastDiv d_w, unsigned long long* stamps) {
+__device__ __forceinline__ void conv_smallp_body(const ConvP& p, const int nks, const FastDiv d_ctot8, const FastDiv d_hw, const FastDiv d_w, unsigned long long* stamps,
+                                                 const int bx, const int by, const int gx) {
   CGEN_SETPRIO();
-  unsigned long long* stamp = (stamps != nullptr && threadIdx.x == 0) ? stamps + 8 * (blockIdx.y * gridDim.x + blockIdx.x) : nullptr;
+  unsigned long long* stamp = (stamps != nullptr && threadIdx.x == 0) ? stamps + 8 * (by * gx + bx) : nullptr;
   if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
   typedef h16_t T;
   constexpr int HALO = KS / 2, TAPS = KS * KS;  // KU K-steps are issued together per wave
   __shared__ __attribute__((aligned(16))) float red[4 * SP_NCO * 2 * 256];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
-  const int co_base = blockIdx.y * (SP_NCO * 16);
+  const int co_base = by * (SP_NCO * 16);
   const int HWp = p.H * p.W;
   int pn[2], py[2], px[2];
   bool pv[2];
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
-    const int m = blockIdx.x * 32 + f * 16 + fr;
+    const int m = bx * 32 + f * 16 + fr;
     pv[f] = m < p.P;
     const int mm = pv[f] ? m : p.P - 1;
     pn[f] = fdiv(mm, d_hw);
@@ -958,11 +959,47 @@ __global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, Fast
   if (stamp) stamp[3] = __builtin_amdgcn_s_memrealtime();
 }
 
+template <int KS, int SP_NCO, int KU, bool ONESEG>
+__global__ __launch_bounds__(256) void conv_smallp_kernel(ConvP p, int nks, FastDiv d_ctot8, FastDiv d_hw, FastDiv d_w, unsigned long long* stamps) {
+  conv_smallp_body<KS, SP_NCO, KU, ONESEG>(p, nks, d_ctot8, d_hw, d_w, stamps, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+
+// Two independent small-image convs of the same instance in ONE launch (cgen_conv2d_pair): the data gradients of the posterior and the
+// prior Block's convs on the <= 12x12 layers, whose launches are latency-bound whatever their size (see launch_conv_smallp) -- two of
+// them side by side cost what one costs.  Workgroups with blockIdx.x < a.gx take the first problem; the record is picked by address
+// inside the kernarg segment (scalar loads), rows of the grid a problem does not need leave at once.
+struct SpArgs { ConvP p; int nks, gx, gy, pad; FastDiv d_ctot8, d_hw, d_w; };
+template <int KS, int SP_NCO, int KU, bool ONESEG>
+__global__ __launch_bounds__(256) void conv_smallp_pair_kernel(SpArgs a, SpArgs b) {
+  (void)a; (void)b;
+  typedef const SpArgs __attribute__((address_space(4)))* ka_ptr;
+  const int gxa = ((ka_ptr)__builtin_amdgcn_kernarg_segment_ptr())->gx;
+  const bool second = (int)blockIdx.x >= gxa;
+  constexpr size_t off_b = (sizeof(SpArgs) + alignof(SpArgs) - 1) / alignof(SpArgs) * alignof(SpArgs);
+  const SpArgs& s = *(const SpArgs*)(ka_ptr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + (second ? off_b : 0));
+  if ((int)blockIdx.y >= s.gy) return;
+  conv_smallp_body<KS, SP_NCO, KU, ONESEG>(s.p, s.nks, s.d_ctot8, s.d_hw, s.d_w, nullptr, second ? (int)blockIdx.x - gxa : (int)blockIdx.x, (int)blockIdx.y, s.gx);
+}
+
 // every element offset of the view (extent n x h x w) fits 32-bit byte arithmetic
 static inline bool fits_i32(const View& v, int n, int h, int w) {
   if (!v.p) return true;
   const int64_t ext = (int64_t)n * v.sn + (int64_t)h * v.sh + (int64_t)w * v.sw + v.c;
   return ext * 2 < ((int64_t)1 << 31);
+}
+
+// would launch_conv hand this f16 conv to conv_smallp_kernel?  (the selection of launch_conv + the checks of launch_conv_smallp)
+static bool smallp_takes(const ConvP& p) {
+  static const int smallp_maxp = [] { const char* e = getenv("CGEN_SMALLP_MAXP"); return e ? atoi(e) : 6000; }();
+  static const int smallp_maxp_longk = [] { const char* e = getenv("CGEN_SMALLP_MAXP_LONGK"); return e ? atoi(e) : 19000; }();
+  static const int smallp_longk = [] { const char* e = getenv("CGEN_SMALLP_LONGK"); return e ? atoi(e) : 60; }();
+  const bool longk = ceil_div(p.taps * p.ctot8, 32) >= smallp_longk;
+  const bool by_size = (p.P <= smallp_maxp || (longk && p.P <= smallp_maxp_longk)) && (p.KS == 1 || p.KS == 3);
+  const bool by_side = (p.H < 5 || p.W < 5) && (p.KS == 1 || p.KS == 3) && !getenv("CGEN_CONV_NO_SMALLP");
+  if (p.force_generic || !(by_size || by_side)) return false;
+  for (int s = 0; s < p.nseg; ++s)
+    if (!p.seg_vec[s] || !fits_i32(p.seg[s], p.N, p.H + 2, p.W + 2)) return false;
+  return p.dma_ok != 0;
 }
 
 static bool launch_conv_smallp(const ConvP& p, hipStream_t st) {
@@ -2620,7 +2657,7 @@ __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, 
 
 using namespace cgen;
 
-extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
+static int conv_fill(const cgen_conv_args* a, ConvP& p) {
   CGEN_REQUIRE(a, "cgen_conv2d: null args");
   CGEN_REQUIRE(a->dtype == CGEN_F32 || a->dtype == CGEN_F16, "cgen_conv2d: bad dtype %d", a->dtype);
   CGEN_REQUIRE(a->ks == 1 || a->ks == 3 || a->ks == 5 || a->ks == 7, "cgen_conv2d: kernel size %d unsupported", a->ks);
@@ -2628,7 +2665,6 @@ extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
   CGEN_REQUIRE(a->n > 0 && a->h > 0 && a->w > 0 && a->out.c > 0 && a->out.p && a->weight, "cgen_conv2d: bad shape/pointers");
   CGEN_REQUIRE((int64_t)a->n * a->h * a->w < (1ll << 31), "cgen_conv2d: too many pixels");
   const int esz = a->dtype == CGEN_F32 ? 4 : 2;
-  ConvP p;
   memset(&p, 0, sizeof(p));
   p.N = a->n; p.H = a->h; p.W = a->w; p.KS = a->ks; p.pad = a->ks / 2; p.nseg = a->nseg; p.act = a->act; p.dact = a->dact;
   p.Co = a->out.c; p.P = a->n * a->h * a->w; p.taps = a->ks * a->ks;
@@ -2663,7 +2699,45 @@ extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
   p.force_generic = getenv("CGEN_CONV_GENERIC") != nullptr;
   p.epi_vec = epi_ok(a->out) && epi_ok(a->aux) && epi_ok(a->res1) && epi_ok(a->res2) && (!a->bias || ((uintptr_t)a->bias % 16 == 0));
   p.epi_vec16 = vec16_ok(a->out, esz) && vec16_ok(a->aux, esz) && vec16_ok(a->res1, esz) && vec16_ok(a->res2, esz) && (!a->bias || ((uintptr_t)a->bias % 16 == 0));
+  return CGEN_OK;
+}
+
+extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
+  ConvP p;
+  const int rc = conv_fill(a, p);
+  if (rc != CGEN_OK) return rc;
   return a->dtype == CGEN_F32 ? launch_conv<float>(p, (hipStream_t)stream) : launch_conv<h16_t>(p, (hipStream_t)stream);
+}
+
+// ---- pair launch of two small-image convs (conv_smallp_pair_kernel)
+static bool smallp_pair_fill(const cgen_conv_args* a, SpArgs& s) {
+  if (!a || a->dtype != CGEN_F16 || conv_fill(a, s.p) != CGEN_OK) return false;
+  const ConvP& p = s.p;
+  if (!smallp_takes(p)) return false;
+  s.nks = ceil_div((p.tap1 - p.tap0) * p.ctot8, 32);
+  s.gx = ceil_div(p.P, 32); s.gy = ceil_div(p.Co, 2 * 16); s.pad = 0;
+  s.d_ctot8 = mk_fastdiv(p.ctot8); s.d_hw = mk_fastdiv(p.H * p.W); s.d_w = mk_fastdiv(p.W);
+  return true;
+}
+
+extern "C" int cgen_conv2d_pair_supported(const cgen_conv_args* a, const cgen_conv_args* b) {
+  SpArgs sa, sb;
+  if (!smallp_pair_fill(a, sa) || !smallp_pair_fill(b, sb)) return 0;
+  return sa.p.KS == sb.p.KS && (sa.p.nseg == 1) == (sb.p.nseg == 1) ? 1 : 0;
+}
+
+extern "C" int cgen_conv2d_pair(const cgen_conv_args* a, const cgen_conv_args* b, cgen_stream_t stream) {
+  SpArgs sa, sb;
+  CGEN_REQUIRE(smallp_pair_fill(a, sa) && smallp_pair_fill(b, sb) && sa.p.KS == sb.p.KS && (sa.p.nseg == 1) == (sb.p.nseg == 1),
+               "cgen_conv2d_pair: the two convs are not served by one small-image instance (ask cgen_conv2d_pair_supported first)");
+  const dim3 grid(sa.gx + sb.gx, std::max(sa.gy, sb.gy));
+  hipStream_t st = (hipStream_t)stream;
+#define SPP_LAUNCH(KS_) do { if (sa.p.nseg == 1) hipLaunchKernelGGL((conv_smallp_pair_kernel<KS_, 2, 4, true>), grid, dim3(256), 0, st, sa, sb); \
+    else hipLaunchKernelGGL((conv_smallp_pair_kernel<KS_, 2, 4, false>), grid, dim3(256), 0, st, sa, sb); } while (0)
+  if (sa.p.KS == 1) SPP_LAUNCH(1); else SPP_LAUNCH(3);
+#undef SPP_LAUNCH
+  conv_trace(sa.p, "smlp2");
+  return check_launch("cgen_conv2d_pair");
 }
 
 static int count_chunks(const cgen_view* seg, int nseg) {

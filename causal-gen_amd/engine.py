@@ -301,6 +301,13 @@ class Engine(StageMixin, WgradMixin):
         self._blk3_arm = 0      # 1: the next fused data-gradient launch is to be held; 2: one is held, waiting for its partner
         self._blk3_hold = None  # (args, launch counter at hold time, tensors touched, the held Block's late bookkeeping)
         self.blk3_pairs = 0     # pair launches of the last backward pass
+        # ... and the same for data-gradient convs on the small-image path (cgen_conv2d_pair): the two gradient outputs of one conv
+        # (cat[z, p_feat] of z_feat_proj, cat[h, pa, acts] of an unfused posterior Block), and the second convs of an unfused
+        # posterior / prior Block pair, which backward() brings next to each other
+        self.conv_pair = os.environ.get("CGEN_CONV_PAIR", "1") != "0"
+        self._conv_arm = 0
+        self._conv_hold = None
+        self.conv_pairs = 0
         self.wgrad_bg_wgs = int(os.environ.get("CGEN_WGRAD_BG_WGS", "304"))
         self.wgrad_bg_reduce = os.environ.get("CGEN_WGRAD_BG_REDUCE", "1") != "0"
         self._wg_cum, self._wg_total, self._wg_nflush = 0.0, 0.0, 0
@@ -1322,7 +1329,8 @@ class Engine(StageMixin, WgradMixin):
                         self._bw_set_mark()
             self._bw_end()
         else:
-            self.blk3_pairs = 0
+            self.blk3_pairs = self.conv_pairs = 0
+            skip = 0
             tape = self.tape
             for i in range(len(tape) - 1, -1, -1):
                 fn, args, _ = tape[i]
@@ -1337,8 +1345,28 @@ class Engine(StageMixin, WgradMixin):
                         self._blk3_arm = 0
                 else:
                     self._blk3_flush()
+                    if skip:
+                        skip -= 1
+                        continue
+                    if self.conv_pair and fn == self._bw_conv and self.dt != F32 and self._two_unfused_blocks(i):
+                        # X.conv2 | Y.conv2 in one launch, then X.conv1, Y.conv1 (their own gradient outputs pair inside _bw_conv)
+                        self._conv_arm = 1
+                        fn(*args)
+                        if self._conv_arm == 1:
+                            self._conv_arm = 0
+                        y2, x1, y1 = tape[i - 2], tape[i - 1], tape[i - 3]
+                        y2[0](*y2[1])
+                        self._conv_flush()
+                        x1[0](*x1[1])
+                        self._conv_flush()
+                        y1[0](*y1[1])
+                        self._conv_flush()
+                        skip = 3
+                        continue
                     fn(*args)
+                    self._conv_flush()
             self._blk3_flush()
+            self._conv_flush()
         for bid in list(self._riders):
             gv, g, acc = self._riders.pop(bid)
             self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
@@ -1417,10 +1445,13 @@ class Engine(StageMixin, WgradMixin):
         x0 = segs[0]
         if self._needs_wgrad(site) and "wg" not in self._ablate:  # ("wg": timing-only ablation, no weight gradients at all)
             self._wgrad(site, segs, act, g)
-        for k, s in enumerate(segs):
-            if not (s.rg and site.seg_rg[k]):
-                continue
-            self._dgrad_one(site, g, s, k, act, x0)
+        todo = [k for k, s in enumerate(segs) if s.rg and site.seg_rg[k]]
+        if self.conv_pair and len(todo) >= 2 and self._conv_hold is None and self._conv_arm == 0 and self.dt != F32:
+            self._conv_arm = 1  # the first of this conv's data gradients waits for the second (independent outputs, same input)
+        for k in todo:
+            self._dgrad_one(site, g, segs[k], k, act, x0)
+        if len(todo) >= 2:
+            self._conv_flush()
 
     def _dgrad_one(self, site, g, s, k, act, x0):
         gv, prev, acc = self._dgrad_target(s)
@@ -1441,7 +1472,51 @@ class Engine(StageMixin, WgradMixin):
         if self._ablate and ((site.name.endswith(".conv.3") and "d3" in self._ablate) or ("r12" in self._ablate and x0.h <= 12)
                              or any(x0.h == r and ("r%d" % r) in self._ablate for r in (24, 48, 96, 192))):
             return  # TIMING-ONLY ablation: the data gradient of every Block's second conv is not launched
+        if self._conv_arm or self._conv_hold is not None:
+            wr = {id(gv.base)}
+            rd = {id(g.base), id(s.base)} | ({id(prev.base)} if acc else set())
+            if self._conv_arm == 1 and self.prof is None:
+                self._conv_hold = (a, self.launches, wr, rd, (site, x0, s.c))
+                self._conv_arm = 2
+                return
+            if self._conv_hold is not None:
+                ha, hl, hwr, hrd, _ = self._conv_hold
+                if (hl == self.launches and not (hwr & (wr | rd)) and not (wr & hrd)
+                        and self.lib.conv2d_pair_supported(C.byref(ha), C.byref(a))):
+                    self._conv_hold, self._conv_arm = None, 0
+                    self.lib.conv2d_pair(C.byref(ha), C.byref(a), self.stream)
+                    self.launches += 1
+                    self.conv_pairs += 1
+                    return
+                self._conv_flush()
         self._timed("conv_dgrad", site, x0, lambda: self.lib.conv2d(C.byref(a), self.stream), ci=s.c)
+
+    def _conv_flush(self):
+        """Launch a held data-gradient conv on its own (no partner came, or it cannot share a launch)."""
+        self._conv_arm = 0
+        if self._conv_hold is None:
+            return
+        ha, _, _, _, (site, x0, ci) = self._conv_hold
+        self._conv_hold = None
+        self._timed("conv_dgrad", site, x0, lambda: self.lib.conv2d(C.byref(ha), self.stream), ci=ci)
+
+    def _two_unfused_blocks(self, i):
+        """tape[i], [i-1] = conv2, conv1 of Block X and tape[i-2], [i-3] = conv2, conv1 of Block Y (backward order), both unfused,
+        without residuals, on one image size, and Y's output is not an input of X: the two Blocks are independent in the backward
+        pass (the posterior and the prior Block of a decoder layer), so conv2 of X may be followed by conv2 of Y."""
+        if i < 3:
+            return False
+        e = [self.tape[i - j] for j in range(4)]
+        if any(x[0] != self._bw_conv for x in e):
+            return False
+        (s0, g0, _, o0, r01, r02), (s1, g1, _, o1, r11, r12), (s2, g2, _, o2, r21, r22), (s3, g3, _, o3, r31, r32) = [x[1] for x in e]
+        if any(r is not None for r in (r01, r02, r11, r12, r21, r22, r31, r32)):
+            return False
+        if len(g0) != 1 or len(g2) != 1 or g0[0].base is not o1.base or g2[0].base is not o3.base:
+            return False
+        if any(sg.base is o2.base for sg in g1) or (o0.h, o0.w) != (o2.h, o2.w):
+            return False
+        return s0.ks == s2.ks
 
     def _dgrad_target(self, s):
         """Where the data gradient of input tensor `s` goes: (view to write, view to add when accumulating, accumulate?)."""

@@ -52,7 +52,7 @@ typedef struct cgen_view {
 /* ABI version of this header.  cgen_version() of the loaded library must equal it (causal-gen_amd/_lib.py checks): struct layouts,
  * enum values and signatures are only compatible within one version.  cgen_h16_format(): the 16-bit storage format the library was
  * BUILT for -- 0 = IEEE binary16 (default), 1 = bfloat16 (-DCGEN_H16_BF16, an A/B build); CGEN_F16 tensors must be in that format. */
-#define CGEN_ABI_VERSION 403
+#define CGEN_ABI_VERSION 404
 int cgen_version(void);
 int cgen_h16_format(void);
 const char* cgen_last_error(void);
@@ -81,6 +81,12 @@ typedef struct cgen_conv_args {
   int64_t out_rem, res1_rem;
 } cgen_conv_args;
 int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream);
+/* Two independent convolutions in ONE launch where both are small-image problems of the same kernel instance (f16, 1x1 or 3x3, the
+ * <= ~6000-pixel batches of the <= 12x12 layers: conv_smallp, whose launches are latency-bound whatever their size).  In the reference's
+ * graph: the data gradients of the posterior and the prior Block's convs of a DecoderBlock (vae.py:240-301), which autograd runs back to
+ * back.  Bit-identical to two cgen_conv2d calls; the caller guarantees that neither reads or accumulates into what the other writes. */
+int cgen_conv2d_pair_supported(const cgen_conv_args* a, const cgen_conv_args* b);
+int cgen_conv2d_pair(const cgen_conv_args* a, const cgen_conv_args* b, cgen_stream_t stream);
 
 /* ------------------------------------------------------------------ fused "light" Block (csrc/block.hip; binary16)
  * Block.forward with version == "light" (vae.py:49-56, 60-71, 73-84) as ONE launch, the bottleneck tensor resident in LDS:

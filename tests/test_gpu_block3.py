@@ -186,7 +186,7 @@ def test_fused_block3_remainder_planes(shape):
     assert d <= 0.02 * float(outs[0][1][0].abs().max()), d  # (a bottleneck value within rounding of an f16 boundary may round the other way)
 
 
-def _run_two(N, H, W, b, segA, rgA, coA, segB, rgB, coB, pair, seed=0):
+def _run_two(N, H, W, b, segA, rgA, coA, segB, rgB, coB, pair, seed=0, fuse=2):
     """Two independent light Blocks recorded back to back (the posterior and the prior Block of a decoder layer, vae.py:240-301), one
     backward pass: with `pair` their data gradients share a launch (cgen_block3_pair)."""
     from causal_gen_amd.engine import ConvSite, Engine
@@ -206,7 +206,7 @@ def _run_two(N, H, W, b, segA, rgA, coA, segB, rgB, coB, pair, seed=0):
         gouts.append(torch.randn(N, co, H, W, generator=g).half().float())
     eng = Engine("cuda", "f16")
     eng.blk3_on, eng.blk3_minres, eng.blk3_res, eng.blk3_res3 = 2, 8, [], []
-    eng.blk3_pair = pair
+    eng.blk3_pair = eng.conv_pair = pair
     holder = torch.nn.ModuleList(convs).cuda()
     for k, (segc, rg) in enumerate(((segA, rgA), (segB, rgB))):
         s1 = ConvSite("c%da" % k, holder[2 * k], segc, [bool(r) for r in rg], 2 * k)
@@ -214,6 +214,7 @@ def _run_two(N, H, W, b, segA, rgA, coA, segB, rgB, coB, pair, seed=0):
         s1.blk3, s2.blk3 = ("a", s2), ("b", s1)
         sites += [s1, s2]
     eng.bind(holder, sites)
+    eng.blk3_on = fuse
     eng.begin()
     eng.prepare_weights(force=True)
     eng.recording = True
@@ -233,7 +234,7 @@ def _run_two(N, H, W, b, segA, rgA, coA, segB, rgB, coB, pair, seed=0):
     for k, t in nts:
         out += [eng.to_nchw(eng.grad_read(v)).cpu() for v in t if v.rg]
     out += [eng.param_grad_view(p).cpu().clone() for c in holder for p in (c.weight, c.bias)]
-    return out, eng.blk3_pairs
+    return out, (eng.blk3_pairs if fuse else eng.conv_pairs)
 
 
 @pytest.mark.parametrize("shape", [
@@ -251,3 +252,18 @@ def test_block3_pair_launch_is_bit_identical_to_two_launches(shape):
     print("pair launches:", pb)
     if shape[0] != 3:
         assert pb == 1
+
+
+@pytest.mark.parametrize("shape", [
+    (32, 12, 12, 40, [160, 4, 160], [1, 0, 1], 32, [160, 4], [1, 0], 192),   # a 12^2 decoder layer: bottleneck 40 (not served fused)
+    (32, 6, 6, 48, [192, 4, 192], [1, 0, 1], 32, [192], [1], 224),           # 6^2
+    (4, 1, 1, 32, [128, 4, 128], [1, 0, 1], 32, [128, 4], [1, 0], 160),      # 1x1 images (centre tap only)
+], ids=["12x12", "6x6", "1x1"])
+def test_small_image_conv_pair_launches_are_bit_identical_to_single_launches(shape):
+    """Unfused posterior / prior Blocks on the small-image conv path: conv2 of one Block with conv2 of the other, and the two gradient
+    outputs of the posterior's conv1, share launches (cgen_conv2d_pair); same bits as five single launches."""
+    a, pa = _run_two(*shape, pair=False, fuse=0)
+    b, pb = _run_two(*shape, pair=True, fuse=0)
+    assert pa == 0 and pb == 2, (pa, pb)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), float((x - y).abs().max())

@@ -358,16 +358,17 @@ def test_backward_is_bit_reproducible_next_to_the_background_weight_gradient_ker
     # ... and the pair launch of a decoder layer's two fused data gradients (cgen_block3_pair, on by default): it was on in every run
     # above; off gives the same bits
     assert eng.blk3_pair and eng.blk3_pairs > 0, "the posterior / prior data gradients of the 24^2 and 48^2 layers share launches"
-    eng.blk3_pair = False
+    assert eng.conv_pair and eng.conv_pairs > 0, "... and so do small-image data-gradient convs (cgen_conv2d_pair)"
+    eng.blk3_pair = eng.conv_pair = False
     m.zero_grad()
     eng.rng.copy_(torch.tensor([11, 0], dtype=torch.int64, device=eng.rng.device))
     out = m(x, pa, beta=1.0)
     out["elbo"].backward()
     torch.cuda.synchronize()
-    assert eng.blk3_pairs == 0
+    assert eng.blk3_pairs == 0 and eng.conv_pairs == 0
     bad = [n for n, p in m.named_parameters() if p.grad is not None and not torch.equal(runs[0][n], p.grad)]
     assert not bad, ("paired data-gradient launches differ from single ones", len(bad), bad[:4])
-    eng.blk3_pair = True
+    eng.blk3_pair = eng.conv_pair = True
 
 
 def test_full_size_bf16_path_agrees_with_the_f32_parity_path():
