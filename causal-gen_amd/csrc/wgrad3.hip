@@ -283,8 +283,8 @@ __device__ __forceinline__ h16x8 w3_tr(const uint32_t a0, const uint32_t a1) {
   u.w[0] = a0; u.w[1] = a1; u.w[2] = a0 ^ 0x3c00u; u.w[3] = a1 ^ 0x3c00u;
   asm volatile("" : "+v"(u.w[0]), "+v"(u.w[1]), "+v"(u.w[2]), "+v"(u.w[3]));
 #else
-  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)a0);
-  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)a1);
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)a0);
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(uintptr_t)a1);
 #endif
   return u.v;
 }

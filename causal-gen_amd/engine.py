@@ -381,6 +381,8 @@ class Engine(StageMixin, WgradMixin):
         self._wg_events = []
         self._wg_reduced, self._wg_seen = 0, set()
         self._riders = {}
+        self._blk3_arm = self._conv_arm = 0  # (a pass that ended in an exception may have left a launch held)
+        self._blk3_hold = self._conv_hold = None
         self.pgrad_init = set()
         self._pnhwc, self._pgrad_tmp = {}, {}
         self._adopted = set()
