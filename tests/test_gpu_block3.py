@@ -186,7 +186,7 @@ def test_fused_block3_remainder_planes(shape):
     assert d <= 0.02 * float(outs[0][1][0].abs().max()), d  # (a bottleneck value within rounding of an f16 boundary may round the other way)
 
 
-def _run_two(N, H, W, b, segA, rgA, coA, segB, rgB, coB, pair, seed=0, fuse=2):
+def _run_two(N, H, W, b, segA, rgA, coA, segB, rgB, coB, pair, seed=0, fuse=2, chain=False):
     """Two independent light Blocks recorded back to back (the posterior and the prior Block of a decoder layer, vae.py:240-301), one
     backward pass: with `pair` their data gradients share a launch (cgen_block3_pair)."""
     from causal_gen_amd.engine import ConvSite, Engine
@@ -221,10 +221,13 @@ def _run_two(N, H, W, b, segA, rgA, coA, segB, rgB, coB, pair, seed=0, fuse=2):
     nts, ys = [], []
     for k in (1, 0):  # tape: [B][A] -- backward() meets A first, then B
         rg = (rgA, rgB)[k]
-        t = [eng.from_nchw(x.cuda(), rg=bool(r)) for x, r in zip(ins[k], rg)]
-        nts.append((k, t))
+        if chain and k == 0:
+            t = [ys[0][1]]  # A reads B's output: the two Blocks are NOT independent in the backward pass
+        else:
+            t = [eng.from_nchw(x.cuda(), rg=bool(r)) for x, r in zip(ins[k], rg)]
+            nts.append((k, t))
         ys.append((k, eng.block2(sites[2 * k], sites[2 * k + 1], t, 1)))
-    for k, y in ys:
+    for k, y in (ys[1:] if chain else ys):
         gy = eng.seed_grad(y)
         eng.lib.axpby(eng.dt, N, H, W, eng.from_nchw(gouts[k].cuda()).cv(), gy.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
     eng.recording = False
@@ -265,5 +268,26 @@ def test_small_image_conv_pair_launches_are_bit_identical_to_single_launches(sha
     a, pa = _run_two(*shape, pair=False, fuse=0)
     b, pb = _run_two(*shape, pair=True, fuse=0)
     assert pa == 0 and pb == 2, (pa, pb)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), float((x - y).abs().max())
+
+
+def test_dependent_unfused_blocks_are_not_reordered_for_a_pair_launch():
+    """Block A consumes Block B's output (consecutive trunk Blocks without residuals): the backward tape shows the same four-conv
+    pattern as a posterior / prior pair, but B.conv2's gradient comes from A.conv1 -- backward() must leave the order alone."""
+    shape = (8, 12, 12, 40, [160], [1], 160, [160], [1], 160)
+    a, pa = _run_two(*shape, pair=False, fuse=0, chain=True)
+    b, pb = _run_two(*shape, pair=True, fuse=0, chain=True)
+    assert pa == 0 and pb == 0, (pa, pb)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), float((x - y).abs().max())
+
+
+def test_dependent_fused_blocks_do_not_share_a_launch():
+    """... and the fused form: A's data gradient WRITES the gradient B's reads, so the held launch must go out on its own."""
+    shape = (8, 24, 24, 32, [128], [1], 128, [128], [1], 128)
+    a, pa = _run_two(*shape, pair=False, fuse=2, chain=True)
+    b, pb = _run_two(*shape, pair=True, fuse=2, chain=True)
+    assert pa == 0 and pb == 0, (pa, pb)
     for x, y in zip(a, b):
         assert torch.equal(x, y), float((x - y).abs().max())
