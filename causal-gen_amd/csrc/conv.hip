@@ -2632,24 +2632,31 @@ __global__ __launch_bounds__(256) void wred_kernel(const cgen_wred_desc* descs, 
       d.grad_w[o] = d.accumulate ? d.grad_w[o] + a[e] * us : a[e] * us;
     }
   }
-  if (d.grad_b) {  // elements nw .. numel-1 are the bias gradient
-    for (int e = 0; e < 4; ++e) {
-      const int o = s0 + e;
-      if (o >= nw && o < d.numel) {
-        const int co = o - nw;
-        float acc = 0.f;
-        int sp = 0;
-        for (; sp + 16 <= d.nsplit; sp += 16) {  // (loads first, additions in split order)
-          float t[16];
+  if (d.grad_b && s0 + 3 >= nw) {  // elements nw .. numel-1 are the bias gradient: this thread's (up to four) sums run side by side --
+    // one after the other they were 4 x nsplit / 16 dependent round trips on the one thread that owns them, the end of the launch
+    int co4[4];
+    bool ok4[4];
+    float acc4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int c = 0; c < 16; ++c) t[c] = d.partial_b[(size_t)(sp + c) * d.co + co];
+    for (int e = 0; e < 4; ++e) { const int o = s0 + e; ok4[e] = o >= nw && o < d.numel; co4[e] = ok4[e] ? o - nw : 0; }
+    int sp = 0;
+    for (; sp + 16 <= d.nsplit; sp += 16) {  // (loads first, additions in split order: the same sums as a plain loop)
+      float t[4][16];
 #pragma unroll
-          for (int c = 0; c < 16; ++c) acc += t[c];
-        }
-        for (; sp < d.nsplit; ++sp) acc += d.partial_b[(size_t)sp * d.co + co];
-        d.grad_b[co] = d.accumulate ? d.grad_b[co] + acc * us : acc * us;
-      }
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) t[e][c] = d.partial_b[(size_t)(sp + c) * d.co + co4[e]];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc4[e] += t[e][c];
     }
+    for (; sp < d.nsplit; ++sp)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc4[e] += d.partial_b[(size_t)sp * d.co + co4[e]];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (ok4[e]) d.grad_b[co4[e]] = d.accumulate ? d.grad_b[co4[e]] + acc4[e] * us : acc4[e] * us;
   }
 }
 
