@@ -1339,8 +1339,12 @@ class Engine(StageMixin, WgradMixin):
                 if fn == self._bw_block3:
                     # (armed when the NEXT entry is a fused Block of the same image size without a residual: the layer's prior Block)
                     nxt = tape[i - 1] if i > 0 else None
+                    # ... and reads none of this Block's differentiable inputs: else its bookkeeping (an accumulate target, a
+                    # copy-on-write of the shared gradient) could launch work that must see this Block's result first
                     if (self.blk3_pair and self._blk3_hold is None and nxt is not None and nxt[0] == self._bw_block3
-                            and nxt[1][5] is None and nxt[1][2][0].h == args[2][0].h and nxt[1][2][0].w == args[2][0].w):
+                            and nxt[1][5] is None and nxt[1][2][0].h == args[2][0].h and nxt[1][2][0].w == args[2][0].w
+                            and not ({id(v.base) for v in args[2] if v.rg} & {id(v.base) for v in nxt[1][2] if v.rg})
+                            and not any(v.base is nxt[1][4].base for v in args[2])):
                         self._blk3_arm = 1
                     fn(*args)
                     if self._blk3_arm == 1:  # (it did not reach its launch point)
@@ -1517,6 +1521,8 @@ class Engine(StageMixin, WgradMixin):
         if len(g0) != 1 or len(g2) != 1 or g0[0].base is not o1.base or g2[0].base is not o3.base:
             return False
         if any(sg.base is o2.base for sg in g1) or (o0.h, o0.w) != (o2.h, o2.w):
+            return False
+        if {id(v.base) for v in g1 if v.rg} & {id(v.base) for v in g3 if v.rg}:  # both would accumulate into one gradient
             return False
         return s0.ks == s2.ks
 

@@ -186,7 +186,7 @@ def test_fused_block3_remainder_planes(shape):
     assert d <= 0.02 * float(outs[0][1][0].abs().max()), d  # (a bottleneck value within rounding of an f16 boundary may round the other way)
 
 
-def _run_two(N, H, W, b, segA, rgA, coA, segB, rgB, coB, pair, seed=0, fuse=2, chain=False):
+def _run_two(N, H, W, b, segA, rgA, coA, segB, rgB, coB, pair, seed=0, fuse=2, chain=False, share=False):
     """Two independent light Blocks recorded back to back (the posterior and the prior Block of a decoder layer, vae.py:240-301), one
     backward pass: with `pair` their data gradients share a launch (cgen_block3_pair)."""
     from causal_gen_amd.engine import ConvSite, Engine
@@ -223,6 +223,8 @@ def _run_two(N, H, W, b, segA, rgA, coA, segB, rgB, coB, pair, seed=0, fuse=2, c
         rg = (rgA, rgB)[k]
         if chain and k == 0:
             t = [ys[0][1]]  # A reads B's output: the two Blocks are NOT independent in the backward pass
+        elif share and k == 0:
+            t = nts[0][1]   # A reads B's INPUT tensor: both data gradients accumulate into one buffer
         else:
             t = [eng.from_nchw(x.cuda(), rg=bool(r)) for x, r in zip(ins[k], rg)]
             nts.append((k, t))
@@ -288,6 +290,18 @@ def test_dependent_fused_blocks_do_not_share_a_launch():
     shape = (8, 24, 24, 32, [128], [1], 128, [128], [1], 128)
     a, pa = _run_two(*shape, pair=False, fuse=2, chain=True)
     b, pb = _run_two(*shape, pair=True, fuse=2, chain=True)
+    assert pa == 0 and pb == 0, (pa, pb)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), float((x - y).abs().max())
+
+
+@pytest.mark.parametrize("fuse,shape", [(2, (8, 24, 24, 32, [128], [1], 128, [128], [1], 160)), (0, (8, 12, 12, 40, [160], [1], 160, [160], [1], 192))],
+                         ids=["fused", "unfused"])
+def test_blocks_sharing_an_input_keep_their_order(fuse, shape):
+    """Two Blocks read the same tensor (a decoder layer with q_correction: the prior reads h like the posterior): their data gradients
+    accumulate into ONE buffer, the second one's bookkeeping may copy or extend it -- no held launch, same bits."""
+    a, pa = _run_two(*shape, pair=False, fuse=fuse, share=True)
+    b, pb = _run_two(*shape, pair=True, fuse=fuse, share=True)
     assert pa == 0 and pb == 0, (pa, pb)
     for x, y in zip(a, b):
         assert torch.equal(x, y), float((x - y).abs().max())
