@@ -481,7 +481,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start one rank per GPU ourselves (the driver's torch.distributed.run form sets
+        # WORLD_SIZE and lands below).  With fewer devices than ranks the ranks share them (local % device_count): a dry run of
+        # the DP path, which RCCL refuses (two ranks on one device) -- say CGEN_DIST_BACKEND=gloo for that.
+        import socket
+        import subprocess
+
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} (launched under torch.distributed.run with a different --nproc-per-node)")
     local = local % max(torch.cuda.device_count(), 1)  # (a 1-GPU box can host a 2-rank gloo dry run of the DP path)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -498,6 +512,9 @@ def main():
         else:
             dist.init_process_group(backend)
         pg = dist.group.WORLD
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)  # every rank adds 1 through the collective the gradients use: the ranks that backend really reached
+        ranks_seen = int(seen.item())
 
     from causal_gen_amd.train import TrainStep
 
@@ -564,7 +581,9 @@ def main():
                                                2.0 * (world - 1) / max(world, 1) * 4.0 * ts._gbuf().numel() / (exposed_comm * 1e-3) / 1e9),
                          "gradient_bytes": 4 * ts._gbuf().numel(),
                          "overlap_policy": getattr(ts, "dp_policy", None),
-                         "backend": os.environ.get("CGEN_DIST_BACKEND", "nccl")}
+                         "backend": os.environ.get("CGEN_DIST_BACKEND", "nccl"),
+                         ("rccl_ranks_seen" if os.environ.get("CGEN_DIST_BACKEND", "nccl") == "nccl" else "gloo_ranks_seen"): ranks_seen,
+                         "devices_visible": torch.cuda.device_count()}
         res["roofline"] = roof
         if not a.no_cf:
             res.update(cf_leg(ts.ema_model, x, pa, a.config))

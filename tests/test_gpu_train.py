@@ -252,10 +252,12 @@ def test_dp_two_ranks_reproduce_the_single_process_step():
     assert r.returncode == 0 and "DP_TRAINSTEP_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
-def test_dp_bench_path_two_gloo_ranks_on_one_gpu():
+@pytest.mark.parametrize("launcher", ["torch.distributed.run", "self"])
+def test_dp_bench_path_two_gloo_ranks_on_one_gpu(launcher):
     """The data-parallel step (hipGraph fwd+bwd -> bucketed gradient all-reduce -> hipGraph step tail) end to end: two
     ranks share this GPU over gloo (RCCL wants one device per rank; the code path is the same).  Both ranks must finish
-    and rank 0 must print one JSON line with n_gpus = 2 and a finite ELBO."""
+    and rank 0 must print one JSON line with n_gpus = 2 and a finite ELBO.  "self": the plain `python bench.py --gpus 2`
+    command starts its own ranks."""
     import json
     import os
     import subprocess
@@ -263,9 +265,14 @@ def test_dp_bench_path_two_gloo_ranks_on_one_gpu():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, CGEN_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", _free_port(), os.path.join(root, "bench.py"), "--gpus", "2", "--config", "morphomnist", "--batch", "16",
-           "--steps", "2", "--warmup", "1", "--prep-steps", "1", "--no-cf"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    args = ["--gpus", "2", "--config", "morphomnist", "--batch", "16", "--steps", "2", "--warmup", "1", "--prep-steps", "1", "--no-cf"]
+    if launcher == "self":
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", _free_port(), os.path.join(root, "bench.py")] + args
     r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -273,6 +280,7 @@ def test_dp_bench_path_two_gloo_ranks_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 32 and d["elbo_nats_per_dim"] == d["elbo_nats_per_dim"]
     assert d["opt_steps"] == 4 and "roofline" in d
+    assert d["dp"]["gloo_ranks_seen"] == 2 and d["dp"]["gradient_bytes"] > 0
 
 
 def test_dp_allreduce_overlapped_with_backward_equals_the_serialized_exchange():
