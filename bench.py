@@ -260,6 +260,12 @@ def cf_leg(model, x, pa, config, n_cf=10):
                                             "reconstruction_from_abduction_pass": reuse}}
 
 
+def cf_path_name(model):
+    """What the compliant counterfactual loop computes with (engine.split_mode: f32 storage with hi + lo binary16 MFMA operands)."""
+    eng = model.engine()
+    return "f32 storage, " + ("3 x f16 split-operand MFMA (hi*hi + hi*lo + lo*hi), f32 accumulate" if getattr(eng, "f32_split", 0) else "f32 MFMA")
+
+
 def cf_deviation(m_a, m_b, x, pa):
     """max |cf_x| difference between two models holding the SAME weights (f16 path vs f32 parity path) on the benched batch,
     same Philox state: what the reduced precision does to counterfactual pixels (north_star: 1e-3 abs vs the reference)."""
@@ -376,11 +382,21 @@ def side_config(name, dmol, B, dev, steps=10, prep=12, cf=True, parity=True):
          "model_mfma_frac": img_s * gf / 1e3 / MFMA_PEAK_TF["f16"], "elbo_nats_per_dim": float(out[0]),
          "launches_per_step_eager": None}
     if cf:
-        r.update({k: v for k, v in cf_leg(ts.ema_model, x, pa, name, n_cf=6).items() if k != "cf_gflop_per_counterfactual"})
+        f16cf = cf_leg(ts.ema_model, x, pa, name, n_cf=6)
+        r["f16_loop"] = {"counterfactuals_per_s": f16cf["counterfactuals_per_s"], "cf_tflops": f16cf["cf_tflops"]}
     if parity:
         m32, _ = build_model(name, "f32", dmol)
         m32 = m32.to(dev)
         m32.load_state_dict(m.state_dict())
+        if cf:
+            # the rate that meets north_star's 1e-3 on the reference-made fixtures: the f32-storage loop (tests/test_gpu_fullsize.py)
+            m32e, _ = build_model(name, "f32", dmol)
+            m32e = m32e.to(dev)
+            m32e.load_state_dict(ts.ema_model.state_dict())
+            c32 = cf_leg(m32e, x, pa, name, n_cf=4)
+            r["counterfactuals_per_s"], r["cf_tflops"] = c32["counterfactuals_per_s"], c32["cf_tflops"]
+            r["cf_path"] = cf_path_name(m32e)
+            del m32e
         vals = {}
         for tag, mod in (("f16", m), ("f32", m32)):
             was = mod.training
@@ -395,7 +411,7 @@ def side_config(name, dmol, B, dev, steps=10, prep=12, cf=True, parity=True):
         r["elbo_f32_same_weights"] = vals["f32"]
         r["f16_vs_f32_elbo_rel"] = abs(vals["f16"] - vals["f32"]) / max(abs(vals["f32"]), 1e-12)
         if cf:
-            r["f16_vs_f32_cf_maxabs"] = cf_deviation(m, m32, x, pa)
+            r["f16_loop"]["vs_f32_cf_maxabs"] = cf_deviation(m, m32, x, pa)
         del m32
     del ts, m
     torch.cuda.empty_cache()
@@ -586,15 +602,23 @@ def main():
                          "devices_visible": torch.cuda.device_count()}
         res["roofline"] = roof
         if not a.no_cf:
-            res.update(cf_leg(ts.ema_model, x, pa, a.config))
-            eng_cf = ts.ema_model.engine()
-            if a.dtype == "f16" and world == 1 and eng_cf.trunk_mode == 1:
-                # the headline counterfactual rate runs with the remainder planes of the residual trunk (the parity-grade default of
-                # inference passes); the same loop on the plain 16-bit trunk, for the price of that accuracy
-                eng_cf.trunk_mode = 0
-                plain = cf_leg(ts.ema_model, x, pa, a.config, n_cf=6)
-                eng_cf.trunk_mode = 1
-                res["cf_plain_trunk"] = {"counterfactuals_per_s": plain["counterfactuals_per_s"]}
+            # top-level counterfactuals_per_s = the loop that meets north_star's 1e-3 absolute on the reference-made fixtures
+            # (tests/test_gpu_fullsize.py): f32 storage (cf_path says which MFMAs).  The all-16-bit loop is reported beside it
+            # as `f16_loop`, labelled with the bound it is held to (5e-3) and its deviation on this batch.
+            f16cf = cf_leg(ts.ema_model, x, pa, a.config) if a.dtype == "f16" else None
+            m32cf, _ = build_model(a.config, "f32", a.dmol)
+            m32cf = m32cf.to(dev)
+            m32cf.load_state_dict(ts.ema_model.state_dict())
+            m32cf.eval()
+            res.update(cf_leg(m32cf, x, pa, a.config, n_cf=6))
+            res["cf_path"] = cf_path_name(m32cf)
+            res["cf_pixel_bound_held_vs_reference"] = 1e-3
+            if f16cf is not None:
+                res["f16_loop"] = {"counterfactuals_per_s": f16cf["counterfactuals_per_s"], "cf_tflops": f16cf["cf_tflops"],
+                                   "pixel_bound_held_vs_reference": 5e-3,
+                                   "vs_f32_cf_maxabs_this_batch": cf_deviation(ts.ema_model, m32cf, x, pa)}
+            del m32cf
+            torch.cuda.empty_cache()
         if world == 1 and a.dtype == "f16" and not a.no_f32:
             res["f32"] = f32_leg(a, hp, B, dev, x, pa, m)
         if world == 1 and not a.no_extra and a.config == "ukbb192" and a.batch is None and a.dtype == "f16":
@@ -614,11 +638,12 @@ def main():
                 "f32_path": "held at 1e-4 / 1e-3 against the reference-made full-size fixtures on all four presets (tests/test_gpu_fullsize.py)",
                 "f16_timed_path_vs_f32_elbo_rel": f["timed_path"]["f16_vs_f32_elbo_rel"],
                 "f16_inference_path_vs_f32_elbo_rel": f["f16_vs_f32_elbo_rel"],
-                "counterfactuals": {"f16_per_s": res.get("counterfactuals_per_s"), "f16_vs_f32_pixels_maxabs_this_batch": f["f16_vs_f32_cf_maxabs"],
-                                    "f16_pixel_bound_held_vs_reference": 5e-3, "f32_per_s": f["counterfactuals_per_s"],
-                                    "f32_pixel_bound_held_vs_reference": 1e-3,
-                                    "note": "counterfactuals_per_s at top level is the 16-bit loop: a 5e-3 number on the adversarial fixtures; "
-                                            "the rate that meets north_star's 1e-3 everywhere is f32_per_s"}}
+                "counterfactuals": {"per_s": res.get("counterfactuals_per_s"), "path": res.get("cf_path"), "pixel_bound_held_vs_reference": 1e-3,
+                                    "f16_loop_per_s": (res.get("f16_loop") or {}).get("counterfactuals_per_s"),
+                                    "f16_loop_vs_f32_pixels_maxabs_this_batch": f["f16_vs_f32_cf_maxabs"],
+                                    "f16_loop_pixel_bound_held_vs_reference": 5e-3,
+                                    "note": "counterfactuals_per_s at top level is the loop that meets north_star's 1e-3 on the reference-made "
+                                            "fixtures (f32 storage); f16_loop is the all-16-bit approximation, a 5e-3 number on those fixtures"}}
         if world == 1 and not a.no_cpu:
             res["cpu_baseline"] = cpu_baseline(a.config)
         print(json.dumps(res))

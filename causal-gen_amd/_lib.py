@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CGEN_LIB") or os.path.join(_HERE, "libcgen_hip.so")  # (CGEN_LIB: another build of the same ABI, for A/B runs)
 
-F32, F16 = 0, 1
+F32, F16, F32S = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 UNARY_LEAKY_RELU, UNARY_CLAMP_MIN, UNARY_ADD = 3, 4, 5
 MAX_SEG = 4
@@ -162,7 +162,7 @@ PROTOTYPES = {
     "cgen_stage_run": [vp, i32, i32, i32, vp],
 }
 _RESTYPES = {"cgen_last_error": C.c_char_p}
-ABI_VERSION = 404  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
+ABI_VERSION = 405  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
 _NOCHECK = {"cgen_version", "cgen_h16_format", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks",
             "cgen_block3_supported", "cgen_block3_pair_supported", "cgen_conv2d_pair_supported", "cgen_stem_conv_supported", "cgen_stage_accepts"}
 

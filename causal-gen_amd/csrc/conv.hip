@@ -73,6 +73,7 @@ struct ConvP {
   long long out_rem, r1_rem;  // byte offsets of the remainder planes of out / res1 (f16 residual trunk: value = hi + rem); 0 = none
   int epi_vec, force_generic, dma_ok, epi_vec16;
   int tap0, tap1;  // taps that can touch the image (a 3x3 conv on a 1x1 image only ever sees its centre tap)
+  int split, pad_s;  // CGEN_F32S: f32 tensors, products as three binary16 MFMAs (hi*hi + hi*lo + lo*hi), f32 accumulate
 };
 
 // 4-element (16B f32 / 8B bf16) vector access
@@ -563,15 +564,38 @@ __device__ __forceinline__ void act_pieces(char* buf, const int wave, const int 
   }
 }
 
-template <typename T, int NTC, int KS, bool REM>
+// Split-operand form of an f32 value for the binary16 MFMAs of the CGEN_F32S path: v = hi + lo' * 2^-11 (+ O(2^-22 |v|)),
+// hi = rn16(v), lo' = rn16((v - hi) * 2^11).  The scaled remainder has the magnitude of hi's last place times 2^11, i.e. of hi
+// itself: it is a NORMAL binary16 number whenever hi is (an unscaled remainder of |v| < 0.125 would be subnormal), and the cross
+// products are summed in an accumulator of their own that joins the main one scaled by 2^-11 at the end.
+// In: 8 consecutive f32 (two 16-byte groups).  Out: the same 32 bytes as [8 x hi][8 x lo'].
+__device__ __forceinline__ void split8_f32(const uint4 a, const uint4 b, const int act, uint4& hi, uint4& lo) {
+  float v[8] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
+  _Float16 h[8], l[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (act != CGEN_ACT_NONE) v[e] = act_fwd(act, v[e]);
+    h[e] = (_Float16)v[e];
+    l[e] = (_Float16)((v[e] - (float)h[e]) * 2048.f);
+  }
+  union { _Float16 f[8]; uint4 q; } uh, ul;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { uh.f[e] = h[e]; ul.f[e] = l[e]; }
+  hi = uh.q; lo = ul.q;
+}
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+
+template <typename T, int NTC, int KS, bool REM, bool SPLIT = false>
 __global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP p, TileP q) {  // REM: remainder planes of the f16 trunk (own instance: the plain one keeps its registers)
   CGEN_SETPRIO();  // the chain's waves win issue arbitration over background weight-gradient waves on the same SIMD
+  static_assert(!SPLIT || sizeof(T) == 4, "split operands are the f32-storage path");
   constexpr int G = 16 / sizeof(T);
   constexpr int HALO = KS / 2, HH = TILE_H + 2 * HALO, HW = TILE_W + 2 * HALO, HPX = HH * HW;
   constexpr int TAPS = KS * KS;
   constexpr int WROWS = NTC * 16;
-  constexpr int KSTEP = sizeof(T) == 4 ? 16 : 32;
-  constexpr int GK = KSTEP / 4;  // K elements one lane contributes per K-step (f32: 4 via the j-trick, bf16: 8)
+  constexpr int KSTEP = (sizeof(T) == 4 && !SPLIT) ? 16 : 32;
+  constexpr int GK = KSTEP / 4;  // K elements one lane contributes per K-step (f32: 4 via the j-trick, 16-bit and split: 8)
   typedef __attribute__((address_space(3))) void* lds_ptr;
   typedef const __attribute__((address_space(1))) void* gbl_ptr;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -590,11 +614,15 @@ __global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP 
   const int co_base = blockIdx.y * WROWS;
   const int fr = lane & 15, fg = lane >> 4;
 
-  f32x4 acc[NTC][2];
+  f32x4 acc[NTC][2], accx[SPLIT ? NTC : 1][2];  // (accx: the cross products hi * lo' + lo' * hi of the split form, in units of 2^-11)
 #pragma unroll
   for (int t = 0; t < NTC; ++t)
 #pragma unroll
     for (int f = 0; f < 2; ++f) acc[t][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < (SPLIT ? NTC : 1); ++t)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) accx[t][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int gpr_w = q.ldw / G, gpr_x = q.ldc / G;  // 16-byte groups per LDS row (incl. padding)
   const bool single = q.cw == p.ctot8;
@@ -670,6 +698,28 @@ __global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP 
       }
     }
     __syncthreads();  // hipcc drains vmcnt (incl. the LDS DMA) before the barrier
+    if constexpr (SPLIT) {
+      // activation (in f32) and the split, once per element, in place: every 32-byte run of 8 f32 becomes [8 x hi][8 x lo'] -- the
+      // halo tile (cw / 8 runs per pixel) and the weight slab (kreal / 8 runs per row; zero padding splits to zeros)
+      const int xr8 = cw >> 3, nx = HPX * xr8, wr8 = kreal >> 3, nw = WROWS * wr8;
+#pragma unroll 1
+      for (int i = tid; i < nx + nw; i += 256) {
+        char* ptr;
+        int act;
+        if (i < nx) {
+          const int rr = i / xr8, cc = i - rr * xr8;
+          ptr = (char*)(Xs + rr * q.ldc + cc * 8); act = p.act;
+        } else {
+          const int j = i - nx, rr = j / wr8, cc = j - rr * wr8;
+          ptr = (char*)(Ws + rr * q.ldw + cc * 8); act = CGEN_ACT_NONE;
+        }
+        uint4 hi, lo;
+        split8_f32(*(const uint4*)ptr, *(const uint4*)(ptr + 16), act, hi, lo);
+        *(uint4*)ptr = hi;
+        *(uint4*)(ptr + 16) = lo;
+      }
+      __syncthreads();
+    } else
     if (p.act != CGEN_ACT_NONE && !(q.dbg & 4)) {  // activation once per element, in place (not once per tap at fragment-read time)
       const int rstep = fdiv(256, q.d_gprx), cstep = 256 - rstep * gpr_x;
       int rr = fdiv(tid, q.d_gprx), cc = tid - rr * gpr_x;
@@ -695,7 +745,27 @@ __global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP 
     for (int k0 = 0; k0 < kend; k0 += KSTEP) {
       const int tp = tap < TAPS ? tap : TAPS - 1;  // lanes past the last tap multiply zero weights; keep the address legal
       const int off = ((tp / KS) * HW + (tp % KS)) * q.ldc + c;
-      if constexpr (sizeof(T) == 4) {
+      if constexpr (SPLIT) {
+        f16x8_t bh[2], bl[2], ah[NTC], al[NTC];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const char* bp = (const char*)(xb + f * HW * q.ldc + off);
+          bh[f] = *(const f16x8_t*)bp; bl[f] = *(const f16x8_t*)(bp + 16);
+        }
+#pragma unroll
+        for (int t = 0; t < NTC; ++t) {
+          const char* ap = (const char*)(wb + t * 16 * q.ldw + k0);
+          ah[t] = *(const f16x8_t*)ap; al[t] = *(const f16x8_t*)(ap + 16);
+        }
+#pragma unroll
+        for (int t = 0; t < NTC; ++t)
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh[f], acc[t][f], 0, 0, 0);
+            accx[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl[f], accx[t][f], 0, 0, 0);
+            accx[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh[f], accx[t][f], 0, 0, 0);
+          }
+      } else if constexpr (sizeof(T) == 4) {
         f32x4 bq[2], aq[NTC];
 #pragma unroll
         for (int f = 0; f < 2; ++f) bq[f] = *(const f32x4*)(xb + f * HW * q.ldc + off);
@@ -723,6 +793,14 @@ __global__ __launch_bounds__(256, NTC == 4 ? 3 : 4) void conv_tile_kernel(ConvP 
     }
   }
   if (q.dbg & 16) return;
+  if constexpr (SPLIT) {
+#pragma unroll
+    for (int t = 0; t < NTC; ++t)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][f][e] = fmaf(accx[t][f][e], 1.f / 2048.f, acc[t][f][e]);
+  }
   if constexpr (sizeof(T) == 2) {
     // LDS-staged epilogue: the MFMA layout gives a lane 4 channels of one pixel (8-byte pieces, 32 B runs per pixel);
     // re-reading the wave's 32 pixels x COT channels from LDS as 16-byte chunks makes consecutive lanes cover consecutive
@@ -768,7 +846,8 @@ static inline int lds_stride(int width, int esz) {
 template <typename T, int KS>
 static bool launch_conv_tile(const ConvP& p, hipStream_t st) {
   constexpr int HALO = KS / 2, HPX = (TILE_H + 2 * HALO) * (TILE_W + 2 * HALO), TAPS = KS * KS;
-  constexpr int esz = sizeof(T), G = 16 / esz, KSTEP = esz == 4 ? 16 : 32;
+  constexpr int esz = sizeof(T), G = 16 / esz;
+  const int KSTEP = (esz == 4 && !p.split) ? 16 : 32;
   TileP q;
   q.tiles_x = ceil_div(p.W, TILE_W); q.tiles_y = ceil_div(p.H, TILE_H);
   const int ntiles = p.N * q.tiles_y * q.tiles_x;
@@ -800,6 +879,14 @@ static bool launch_conv_tile(const ConvP& p, hipStream_t st) {
       if (ntc == 1) hipLaunchKernelGGL((conv_tile_kernel<T, 1, KS, true>), dim3(ntiles, ceil_div(p.Co, 16)), block, lds, st, p, q);
       else if (ntc == 2) hipLaunchKernelGGL((conv_tile_kernel<T, 2, KS, true>), dim3(ntiles, ceil_div(p.Co, 32)), block, lds, st, p, q);
       else hipLaunchKernelGGL((conv_tile_kernel<T, 4, KS, true>), dim3(ntiles, ceil_div(p.Co, 64)), block, lds, st, p, q);
+      return true;
+    }
+  }
+  if constexpr (sizeof(T) == 4) {
+    if (p.split) {
+      if (ntc == 1) hipLaunchKernelGGL((conv_tile_kernel<T, 1, KS, false, true>), dim3(ntiles, ceil_div(p.Co, 16)), block, lds, st, p, q);
+      else if (ntc == 2) hipLaunchKernelGGL((conv_tile_kernel<T, 2, KS, false, true>), dim3(ntiles, ceil_div(p.Co, 32)), block, lds, st, p, q);
+      else hipLaunchKernelGGL((conv_tile_kernel<T, 4, KS, false, true>), dim3(ntiles, ceil_div(p.Co, 64)), block, lds, st, p, q);
       return true;
     }
   }
@@ -2666,13 +2753,14 @@ using namespace cgen;
 
 static int conv_fill(const cgen_conv_args* a, ConvP& p) {
   CGEN_REQUIRE(a, "cgen_conv2d: null args");
-  CGEN_REQUIRE(a->dtype == CGEN_F32 || a->dtype == CGEN_F16, "cgen_conv2d: bad dtype %d", a->dtype);
+  CGEN_REQUIRE(a->dtype == CGEN_F32 || a->dtype == CGEN_F16 || a->dtype == CGEN_F32S, "cgen_conv2d: bad dtype %d", a->dtype);
   CGEN_REQUIRE(a->ks == 1 || a->ks == 3 || a->ks == 5 || a->ks == 7, "cgen_conv2d: kernel size %d unsupported", a->ks);
   CGEN_REQUIRE(a->nseg >= 1 && a->nseg <= CGEN_MAX_SEG, "cgen_conv2d: nseg %d", a->nseg);
   CGEN_REQUIRE(a->n > 0 && a->h > 0 && a->w > 0 && a->out.c > 0 && a->out.p && a->weight, "cgen_conv2d: bad shape/pointers");
   CGEN_REQUIRE((int64_t)a->n * a->h * a->w < (1ll << 31), "cgen_conv2d: too many pixels");
-  const int esz = a->dtype == CGEN_F32 ? 4 : 2;
+  const int esz = a->dtype == CGEN_F16 ? 2 : 4;
   memset(&p, 0, sizeof(p));
+  p.split = a->dtype == CGEN_F32S ? 1 : 0;
   p.N = a->n; p.H = a->h; p.W = a->w; p.KS = a->ks; p.pad = a->ks / 2; p.nseg = a->nseg; p.act = a->act; p.dact = a->dact;
   p.Co = a->out.c; p.P = a->n * a->h * a->w; p.taps = a->ks * a->ks;
   int koff = 0;
@@ -2713,7 +2801,7 @@ extern "C" int cgen_conv2d(const cgen_conv_args* a, cgen_stream_t stream) {
   ConvP p;
   const int rc = conv_fill(a, p);
   if (rc != CGEN_OK) return rc;
-  return a->dtype == CGEN_F32 ? launch_conv<float>(p, (hipStream_t)stream) : launch_conv<h16_t>(p, (hipStream_t)stream);
+  return a->dtype != CGEN_F16 ? launch_conv<float>(p, (hipStream_t)stream) : launch_conv<h16_t>(p, (hipStream_t)stream);
 }
 
 // ---- pair launch of two small-image convs (conv_smallp_pair_kernel)

@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from .stage import StagedLib, StageMixin
 from .wgrad_sched import WgradMixin
-from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, F16, F32, NULL_VIEW, UNARY_CLAMP_MIN, UNARY_LEAKY_RELU, View
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, F16, F32, F32S, NULL_VIEW, UNARY_CLAMP_MIN, UNARY_LEAKY_RELU, View
 
 _ALIGN = 256
 
@@ -239,6 +239,11 @@ class Engine(StageMixin, WgradMixin):
         # traffic of the trunk convs (HBM-bound at >= 96x96): counterfactuals/s -12.6 %, a training step -8.5 % -- for an ELBO
         # that is within 1.2e-5 of the reference either way, which is why training keeps the plain trunk.
         self.trunk_mode = int(os.environ.get("CGEN_TRUNK_REM", "1"))
+        # f32 engine: convolutions of NON-recording passes (abduct / forward_latents / sample / a no-grad forward: the counterfactual
+        # loop) hand cgen_conv2d CGEN_F32S -- f32 tensors, every product from split binary16 operands (three f16 MFMAs per K-step,
+        # ~2^-21 relative): the path that meets north_star's 1e-3 on counterfactual pixels at a fifth of the f32 MFMA's cycles.
+        # Recorded (training) passes stay on exact f32 MFMA chains (gradients leave binary16's range).  CGEN_F32_SPLIT=0: off.
+        self.f32_split = int(os.environ.get("CGEN_F32_SPLIT", "1")) if self.dt == F32 else 0
         # CGEN_ABLATE="f1,d3" (planning tool, results are WRONG): what would the step cost if a light Block were one launch as
         # long as its HBM-bound half -- the upper bound of Block fusion on the critical path
         self._ablate = frozenset(t for t in os.environ.get("CGEN_ABLATE", "").split(",") if t)  # exact tokens
@@ -652,6 +657,8 @@ class Engine(StageMixin, WgradMixin):
         a = _lib.ConvArgs()
         gn, gh, gw, vw = self._geom(site.ks, list(segs) + [out, res1, res2])
         a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act, a.dact = self.dt, gn, gh, gw, site.ks, len(segs), act, 0
+        if self.f32_split and not self.recording:
+            a.dtype = F32S
         for k, s in enumerate(segs):
             assert s.c == site.seg_c[k] and (s.n, s.h, s.w) == (x0.n, x0.h, x0.w), (site.name, k, s.shape, site.seg_c)
             a.seg[k] = vw(s)

@@ -32,7 +32,13 @@ extern "C" {
 typedef void* cgen_stream_t; /* hipStream_t */
 
 enum cgen_status { CGEN_OK = 0, CGEN_EINVAL = -1, CGEN_ELAUNCH = -2, CGEN_EUNSUPPORTED = -3 };
-enum cgen_dtype { CGEN_F32 = 0, CGEN_F16 = 1 };
+enum cgen_dtype { CGEN_F32 = 0, CGEN_F16 = 1,
+                  /* cgen_conv2d only (ABI 405): CGEN_F32 tensors and weight image, but the tiled kernel forms every product from
+                   * SPLIT binary16 operands -- v = hi + lo, three v_mfma_f32_16x16x32_f16 per K-step (hi*hi + hi*lo + lo*hi), f32
+                   * accumulate: ~2^-21 relative per product instead of binary16's 2^-11, at a fifth of the f32 MFMA's cycles.  The
+                   * inference passes of the f32 engine use it (counterfactual pixels within 1e-3 of the reference, north_star);
+                   * shapes the tiled kernel does not take run the exact f32 kernels.  Operands must lie inside binary16's range. */
+                  CGEN_F32S = 2 };
 enum cgen_act { CGEN_ACT_NONE = 0, CGEN_ACT_RELU = 1, CGEN_ACT_GELU = 2 };
 
 /* NHWC strided view; strides in elements; p == NULL means "absent".
@@ -52,7 +58,7 @@ typedef struct cgen_view {
 /* ABI version of this header.  cgen_version() of the loaded library must equal it (causal-gen_amd/_lib.py checks): struct layouts,
  * enum values and signatures are only compatible within one version.  cgen_h16_format(): the 16-bit storage format the library was
  * BUILT for -- 0 = IEEE binary16 (default), 1 = bfloat16 (-DCGEN_H16_BF16, an A/B build); CGEN_F16 tensors must be in that format. */
-#define CGEN_ABI_VERSION 404
+#define CGEN_ABI_VERSION 405
 int cgen_version(void);
 int cgen_h16_format(void);
 const char* cgen_last_error(void);

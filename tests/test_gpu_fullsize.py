@@ -146,6 +146,25 @@ def test_fullsize_forward_backward_counterfactual(name, B, dmol):
     d_cf = (R.sample_img(cf_x).cpu() - row["cf"]["cf_x"]).abs()
     assert float(d_cf[ok].max()) < CF_TOL, float(d_cf[ok].max())
     assert abs(float((cf_x.cpu() - x).abs().mean()) - row["cf"]["moved"]) < 1e-3
+    # That loop ran on SPLIT binary16 operands (the f32 engine's non-recording passes: CGEN_F32S, three f16 MFMAs per K-step in the
+    # tiled conv kernel) -- the path bench.py's top-level counterfactuals_per_s times.  Its no-grad ELBO against the reference,
+    # and the same loop on exact f32 MFMA chains for the record.
+    eng32 = m.engine()
+    assert eng32.f32_split == 1, "the compliant counterfactual path is the split-operand one"
+    m.noise = [e.clone() for e in eps]
+    with torch.no_grad():
+        o_s = m(x.cuda(), pa.cuda(), beta=row["beta"])
+    dev_s = {k: _rel(o_s[k], row[k]) for k in ("elbo", "nll", "kl")}
+    assert max(dev_s.values()) < ELBO_TOL, dev_s
+    eng32.f32_split = 0
+    m.noise = R.eps_sequence(21, row["cf"]["eps_shapes"])
+    with torch.no_grad():
+        cf_e = dscm.counterfactual(m, x.cuda(), pa.cuda(), cf_pa.cuda(), t_abduct=1.0)
+    eng32.f32_split = 1
+    d_cfe = float((R.sample_img(cf_e).cpu() - row["cf"]["cf_x"]).abs()[ok].max())
+    assert d_cfe < CF_TOL, d_cfe
+    print("FULLSIZE %s: f32 storage, split binary16 operands (inference passes) vs reference elbo %.2e nll %.2e kl %.2e cf %.2e | exact f32 MFMA cf %.2e" % (
+        R.key(name, dmol), dev_s["elbo"], dev_s["nll"], dev_s["kl"], float(d_cf[ok].max()), d_cfe))
 
     # ---- f16 throughput path: measured deviation from the reference's values on the same inputs
     del m

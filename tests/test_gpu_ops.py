@@ -107,6 +107,42 @@ def test_conv_fwd_bwd(case, dtype):
     torch.testing.assert_close(eng.param_grad_view(site.conv.bias).cpu(), b_ref.grad, **wtol)
 
 
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[5] in (1, 3)])
+def test_conv_f32_split_operands(case):
+    """CGEN_F32S (the inference flavour of the f32 engine): f32 tensors, every product from split binary16 operands (three f16
+    MFMAs per K-step in the tiled kernel).  Against torch f64 on the same f32 inputs: far inside binary16's 2^-11 -- the bound is
+    5e-6 of the output scale, where a 16-bit-operand conv of these shapes sits at ~3e-4 -- and it really is another kernel than
+    the exact f32 path on the shapes the tiled kernel takes (bits differ), on the others the exact kernels serve the call."""
+    N, H, W, segc, Co, ks, act, with_res = case
+    g = torch.Generator().manual_seed(N * 1000 + H * 37 + Co + 5)
+    conv = torch.nn.Conv2d(sum(segc), Co, ks, padding=ks // 2)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) / math.sqrt(sum(segc) * ks * ks))
+        conv.bias.copy_(torch.randn(Co, generator=g) * 0.3)
+    # values over six decades: the scaled remainder keeps small operands exact as well
+    xs = [torch.randn(N, c, H, W, generator=g) * 10.0 ** (torch.rand(N, c, H, W, generator=g) * 5.5 - 4.0) for c in segc]
+    res = torch.randn(N, Co, H, W, generator=g) if with_res else None
+    a = torch.cat([x.double() for x in xs], dim=1)
+    a = F.relu(a) if act == 1 else (F.gelu(a) if act == 2 else a)
+    y_ref = F.conv2d(a, conv.weight.detach().double(), conv.bias.detach().double(), padding=ks // 2)
+    if with_res:
+        y_ref = y_ref + res.double()
+    eng, (site,) = make_engine([conv], [segc], "f32")
+    assert eng.f32_split == 1 and not eng.recording
+    nts = [eng.from_nchw(x.cuda()) for x in xs]
+    rt = eng.from_nchw(res.cuda()) if with_res else None
+    y_split = nhwc_to_torch(eng, eng.conv(site, nts, act, res1=rt)).double()
+    eng.f32_split = 0
+    y_exact = nhwc_to_torch(eng, eng.conv(site, nts, act, res1=rt)).double()
+    scale = float(y_ref.abs().max())
+    err_s, err_e = float((y_split - y_ref).abs().max()) / scale, float((y_exact - y_ref).abs().max()) / scale
+    assert err_e < 2e-6, err_e
+    assert err_s < 5e-6, (err_s, err_e)
+    tiled = ks in (1, 3) and H >= 8 and W >= 16 and all(c % 4 == 0 for c in segc)
+    if tiled and min(H, W) >= 16:
+        assert not torch.equal(y_split, y_exact), "the split-operand kernel did not run"
+
+
 def test_double_use_accumulates_input_grad():
     """A tensor consumed by two convs and as a residual gets the sum of the three gradients."""
     g = torch.Generator().manual_seed(3)
