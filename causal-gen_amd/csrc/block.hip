@@ -73,7 +73,11 @@ struct B3P {
   BV3 seg[3];
   int seg_koff[4];  // first CHUNK of segment s (segments are padded to whole 32-channel chunks); [nseg] = nch
   int seg_c8[3];
-  const char* wA;   // phase-A fragment image [chunk][channel half 0..1][tap 0..8][lane][8]
+  // small-image instance (blk3s, images up to 14 pixels wide): a workgroup owns `s_rows` output rows of one image
+  int small, s_rows, s_strips, s_nmb;  // s_nmb: 32-row blocks of the bottleneck (1 or 2)
+  int s_mid_off, s_kt_off, s_red_off, s_dbg, s_segk0[3], s_segg[3];  // LDS offsets; first chunk / 16-byte groups per pixel of segment s
+  B3Div s_dg1, s_dxw, s_dw, s_dstrips, s_dnb;
+  const char* wA;   // phase-A fragment image [32-row block][chunk][channel half 0..1][tap 0..8][lane][8]
   const float* biasA;
   BV3 mid, mid_aux;  // mid: written (interior pixels): forward t (pre-activation), backward g_t; mid_aux: backward mask source t
   B3Out o[2];
@@ -113,6 +117,22 @@ __device__ __forceinline__ uint4 b3_pack8(const float* v) {
 // counted waits + barriers of the tile loop alone.  (Nothing else in these kernels uses M0; s_nop: M0 write -> LDS-DMA hazard.)
 __device__ __forceinline__ void b3_dma16(const char* src, const uint32_t lds) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(lds) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void b3_vmwait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in [LO, HI]: the count is an immediate, so a decision tree of them
+template <int LO, int HI>
+__device__ __forceinline__ void b3_vmwait_rt(const int n) {
+  if constexpr (LO == HI) {
+    b3_vmwait<LO>();
+  } else {
+    constexpr int M = (LO + HI) / 2;
+    if (n <= M) b3_vmwait_rt<LO, M>(n); else b3_vmwait_rt<M + 1, HI>(n);
+  }
+}
+// (untracked, like b3_gload, with a per-lane 64-bit address: the small-image instance's weight fragments)
+__device__ __forceinline__ void b3_gload_v(h16x8& d, const char* vaddr) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(vaddr) : "memory");
 }
 template <int OFF>
 __device__ __forceinline__ void b3_gload(h16x8& d, const char* sbase, const int voff) {
@@ -741,6 +761,395 @@ __global__ __launch_bounds__(256, 2) void blk3_pair_kernel(B3P pa, B3P pb, const
   blk3_body<PRE, NB, NPG, SM, TH, REM>(p, second ? (int)blockIdx.x - na : (int)blockIdx.x, second ? (int)gridDim.x - na : na, koff);
 }
 
+// ============================================================================= small images (<= 14 pixels wide: 12x12, 6x6, ...)
+// The top of both hierarchies: ~1 % of a step's FLOPs, 22 % of its time as two latency-bound conv launches per Block (bottlenecks of
+// 40 / 48 channels, which the tile kernel above does not take).  Here ONE workgroup owns R output rows of ONE image -- R = the most
+// rows whose (R + 2) x W bottleneck pixels fit two 32-pixel MFMA groups: 3 of 12, all 6 of 6 -- and holds everything it needs in LDS:
+//   load   the (R + 4) x (W + 2) input rows of every segment (virtual cat, zero padded, ReLU applied on the way in),
+//   phase A  bottleneck[b <= 64][<= 64 pixels] = W1 * X: wave = (32-row block, pixel group), the whole K axis, weight fragments
+//            straight from L2 in fragment order, nine (one 16-channel half chunk) ahead; no partial-sum exchange;
+//   finalise bias / ReLU (forward) or relu'(t) mask (data gradient) -> `mid` in HBM (rows the strip owns) and the LDS tile;
+//   phase B  out[Co][R x W pixels] = W2 * mid: jobs (32-channel pair, pixel group) dealt round-robin to the waves, epilogue from the
+//            accumulators exactly as the tile kernel's (bias, mask, residual / accumulate, remainder planes).
+// Same problem record, same fragment images, same results contract as blk3_body; bottlenecks above 32 channels take the second
+// 32-row block of the phase-A image.
+#define B3S_NW 8    // waves per workgroup: two per SIMD (one wave alone issues an instruction every ~9 cycles of a dependent chain: measured)
+#define B3S_MW 16   // pixels per row of the bottleneck tile in LDS (W + 2 <= 16): tap offsets do not depend on the image width
+
+// One K loop of the small-image instance: `cnt` K16-steps.  Step j multiplies the weight fragment at wbase + 1024 j (a wave-uniform
+// address: one s_add per step; lane part `voff`) with the B operands at bp0 / bp1 + T[j], T an int table in LDS read TWO steps ahead
+// through `tp` (TSTEP bytes per step: immediate offsets inside the unrolled body), the operands themselves ONE step ahead.  The
+// fragments are untracked loads, D steps in flight, ordered by counted waits: requests return in order, so in front of step j only
+// the fragments of steps j + 1 .. j + D - 1 may be outstanding.  EVERY request is unconditional -- past the last step the address is
+// clamped to the last fragment -- so that the count is the same everywhere and no ring register is ever written under a branch
+// (a conditionally written one gets copied at the join, by a v_mov that may run before the load has landed: measured, as garbage);
+// the loop ends with a drain of the queue, because the registers of requests still in flight must not be handed back to the
+// compiler.  start() issues the first D requests: callers hoist it above whatever they wait for next (a cold fragment takes 1-2 us).
+// ~17 instructions per step around two MFMAs (both 32-pixel groups always: the shapes this instance exists for have more than 32
+// pixels per strip).  wbase must be readable even when cnt == 0.
+template <int TSTEP>
+struct B3sK {
+  static constexpr int D = 6;  // (a multiple of 2 and 3: the operand / table pipelines rotate inside the unrolled body)
+  h16x8 wr[D];
+  const char* wl;
+  int jl, cnt, voff;
+  __device__ __forceinline__ void issue(h16x8& dst) {
+    b3_gload<0>(dst, wl, voff);
+    wl += jl < cnt - 1 ? 1024 : 0;
+    ++jl;
+  }
+  __device__ __forceinline__ void start(const char* wbase, const int voff_, const int cnt_) {
+    wl = wbase; jl = 0; cnt = cnt_; voff = voff_;
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue(wr[d]);
+  }
+  template <bool TWO>
+  __device__ __forceinline__ void run(const char* tp, const char* bp0, const char* bp1, f32x16& c0, f32x16& c1) {
+    int tv[3];
+    tv[0] = *(const int*)tp;
+    tv[1] = *(const int*)(tp + TSTEP);
+    h16x8 bq[2][TWO ? 2 : 1];
+    bq[0][0] = *(const h16x8*)(bp0 + tv[0]);
+    if constexpr (TWO) bq[0][1] = *(const h16x8*)(bp1 + tv[0]);
+#pragma unroll 1
+    for (int i = 0; i < cnt; i += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        tv[(d + 2) % 3] = *(const int*)(tp + (d + 2) * TSTEP);
+        bq[(d + 1) & 1][0] = *(const h16x8*)(bp0 + tv[(d + 1) % 3]);
+        if constexpr (TWO) bq[(d + 1) & 1][1] = *(const h16x8*)(bp1 + tv[(d + 1) % 3]);
+        b3_vmwait<D - 1>();
+        b3_pin(wr[d]);
+        if (i + d < cnt) {
+          c0 = b3_mfma(wr[d], bq[d & 1][0], c0);
+          if constexpr (TWO) c1 = b3_mfma(wr[d], bq[d & 1][1], c1);
+        }
+        issue(wr[d]);
+      }
+      tp += D * TSTEP;
+    }
+    B3_VMWAIT();  // (the clamped requests past the end: their registers are free again)
+#pragma unroll
+    for (int d = 0; d < D; ++d) b3_pin(wr[d]);
+  }
+};
+
+template <bool PRE>
+__device__ __forceinline__ void blk3s_body(const B3P& p, const int bid, const int nb, const int koff) {
+  __builtin_amdgcn_s_setprio(3);
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  typedef const char __attribute__((address_space(4)))* karg_ptr;
+  const karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr() + koff;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int px = lane & 31, kg = lane >> 5;
+  const int H = p.H, W = p.W, nch = p.nch, bch = p.b, R = p.s_rows;
+  const int XW = W + 2, G1 = nch * 4 + 1, XS = G1 * 16;  // tile columns (one zero column either side); 16-byte slots / bytes per input pixel (one pad slot: odd stride)
+  const int NB = bch >> 3, NBS = (NB & 1) ? NB : NB + 1, MS = NBS * 16;  // bottleneck pixel stride: an odd number of 16-byte groups
+  char* const X = smem;
+  char* const MID = smem + p.s_mid_off;   // [R + 2 rows][B3S_MW pixels][MS]
+  char* const RED = smem + p.s_red_off;   // partial sums: [wave][pixel group 0..1][quad 0..3][64 lanes][4 floats] (in the input tile's memory)
+  int* const KT = (int*)(smem + p.s_kt_off);  // phase-B K axis: 8-channel group u = (tap, bottleneck group) -> byte offset in the bottleneck tile
+  int* const TA = KT + 128;                   // phase-A K axis: step s = (half chunk q, tap) in image order -> byte offset in the input tile
+  const char* const zero = (const char*)g_b3zero;
+  const int nks = p.nksB, nmb = p.s_nmb, nst = 18 * nch;
+  if (p.s_dbg & 8) return;
+  unsigned long long* const stamp = (p.stamps != nullptr && bid == 0 && lane == 0) ? p.stamps + wave * 32 : nullptr;  // (debug: shader-clock stamps of workgroup 0, tools/blk3s_stamps.py)
+#define B3S_STAMP(k) do { if (stamp) stamp[k] = __builtin_readcyclecounter(); } while (0)
+  B3S_STAMP(0);
+  typedef const BV3 __attribute__((address_space(4)))* kseg_ptr;
+  const kseg_ptr ks = (kseg_ptr)(ka + offsetof(B3P, seg));
+  const int NMP = (R + 2) * W;  // bottleneck pixels a strip computes (<= 64)
+  // phase-A roles: wave = (32-row block mb, K part kq of KQ); finalisers: wave f < 4 nmb = (mb, pixel group, 8-channel half)
+  const int KQ = B3S_NW / nmb, mbA = wave / KQ, kqA = wave - mbA * KQ;
+  const int SA = (nst + KQ - 1) / KQ, sA0 = min(kqA * SA, nst), mineA = min(sA0 + SA, nst) - sA0;
+  const int fmb = wave >> 2, fng = (wave >> 1) & 1, fhalf = wave & 1;
+  // ONE item per workgroup (the host launches p.ntiles of them).  Not a loop: everything below is invariant in everything but the
+  // item, and hipcc hoisted all of it out of an item loop and kept it live across -- 90 spilled registers, their reloads (scratch
+  // loads the compiler waits for with vmcnt(0)) in the middle of the request bursts.
+  (void)nb;
+  {
+    const int item = bid;
+    B3sK<4> KA;
+    B3sK<8> KB;
+    const int n = b3_div(item, p.s_dstrips), y0 = (item - n * p.s_strips) * R;
+    const int Rr = min(R, H - y0), NOP = Rr * W;
+    // ---- input rows y0 - 2 .. y0 + R + 1, columns -1 .. W, every segment (virtual cat), -> LDS by DMA: one 16-byte slot per lane,
+    // zeros outside the image / past a segment's channels / in the pad slot.  The first thing a workgroup does: everything below
+    // up to the barrier runs under the requests' latency.
+    const int nslots = (R + 4) * XW * G1, ninst = (nslots + 63) >> 6;
+    {
+      const char* const p0 = ks[0].p + n * ks[0].sn;
+      const char* const p1 = p.nseg > 1 ? ks[1].p + n * ks[1].sn : zero;
+      const char* const p2 = p.nseg > 2 ? ks[2].p + n * ks[2].sn : zero;
+      const int g1 = p.nseg > 1 ? 4 * p.s_segk0[1] : (1 << 20), g2 = p.nseg > 2 ? 4 * p.s_segk0[2] : (1 << 20);
+      for (int ii = wave; ii < ((p.s_dbg & 1) ? 0 : ninst); ii += B3S_NW) {
+        const int iu = __builtin_amdgcn_readfirstlane(ii);
+        const int sl = min(iu * 64 + lane, nslots - 1);
+        const int pxl = b3_div(sl, p.s_dg1), g = sl - pxl * G1;
+        const int ry = b3_div(pxl, p.s_dxw), cx = pxl - ry * XW;
+        const int iy = y0 - 2 + ry, ix = cx - 1;
+        const bool s1 = g >= g1, s2 = g >= g2;
+        const char* sp = s2 ? p2 : (s1 ? p1 : p0);
+        const int sh = s2 ? ks[2].sh : (s1 ? ks[1].sh : ks[0].sh), sw = s2 ? ks[2].sw : (s1 ? ks[1].sw : ks[0].sw);
+        const int c8 = s2 ? p.seg_c8[2] : (s1 ? p.seg_c8[1] : p.seg_c8[0]);
+        const int gl = g - (s2 ? g2 : (s1 ? g1 : 0));  // 8-channel group inside the segment
+        const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && 8 * gl < c8 && g < G1 - 1;
+        const char* src = ok ? sp + iy * sh + ix * sw + 16 * gl : zero;
+        __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(X + (size_t)iu * 1024), 16, 0, 0);
+      }
+    }
+    B3S_STAMP(1);
+    // ---- the first fragments of phase A (cold: 1-2 us), behind the tile's requests
+    KA.start(p.wA + ((size_t)mbA * nst + min(sA0, nst - 1)) * 1024, lane * 16, (p.s_dbg & 2) ? 0 : mineA);
+    // ---- lane constants of phase A: bottleneck pixel m = 32 g + px -> tile row / column; the finaliser's operands
+    int mr[2], mx[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int mc = min(32 * g + px, NMP - 1);
+      mr[g] = b3_div(mc, p.s_dw); mx[g] = mc - mr[g] * W;
+    }
+    const bool fjob = wave < 4 * nmb && (fng == 0 || NMP > 32);
+    const int fiy = y0 - 1 + mr[fng];
+    const bool f_img = fjob && 32 * fng + px < NMP && fiy >= 0 && fiy < H;
+    const int fch = 32 * fmb + 16 * kg + 8 * fhalf;  // the 8 bottleneck channels this lane finalises
+    uint4 tmk = make_uint4(0, 0, 0, 0);  // backward: the forward bottleneck t there (the mask of the bottleneck gradient); forward: the bias
+    float4 fb0 = make_float4(0.f, 0.f, 0.f, 0.f), fb1 = fb0;
+    if constexpr (!PRE) {
+      const bool ok = f_img && fch < bch;
+      tmk = *(const uint4*)(ok ? p.mid_aux.p + (n * p.mid_aux.sn + fiy * p.mid_aux.sh + mx[fng] * p.mid_aux.sw) + fch * 2 : zero);
+    } else if (p.biasA != nullptr && fjob && fch < bch) {
+      fb0 = *(const float4*)(p.biasA + fch); fb1 = *(const float4*)(p.biasA + fch + 4);
+    }
+    // ---- tables, zeros of the bottleneck tile (the border columns and the rows outside the image stay zero: conv2's padding)
+    {
+      for (int u = tid; u < 128; u += 64 * B3S_NW) {
+        const int uu = min(u, 2 * nks - 1), tq = b3_div(uu, p.s_dnb), tp = min(tq, 8), gq = uu - tq * NB;
+        KT[u] = ((tp / 3) * B3S_MW + tp % 3) * MS + gq * 16;
+      }
+      for (int sidx = tid; sidx < nst + 16; sidx += 64 * B3S_NW) {
+        const int ss = min(sidx, nst - 1), q = ss / 9, tp = ss - 9 * q;
+        TA[sidx] = ((tp / 3) * XW + tp % 3) * XS + q * 32;
+      }
+    }
+    for (int i = tid; i < ((R + 2) * B3S_MW * MS) >> 4; i += 64 * B3S_NW) *(uint4*)(MID + i * 16) = make_uint4(0, 0, 0, 0);
+    B3S_STAMP(2);
+    B3_BARRIER();  // (the tables; hipcc drains vmcnt -- the DMA it tracks -- in front of the first read of the tile below)
+    if constexpr (PRE) {  // ReLU once per element, in place (each is read by nine taps)
+      for (int i = tid; i < ninst * 64; i += 64 * B3S_NW) {
+        union { uint4 q; h16x8 h; } r;
+        r.q = *(const uint4*)(X + i * 16);
+        r.h = b3_relu8(r.h);
+        *(uint4*)(X + i * 16) = r.q;
+      }
+      B3_BARRIER();
+    }
+    B3S_STAMP(3);
+    // ---- phase A: this wave's K part of one 32-row block, both pixel groups
+    f32x16 acc[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+    KA.run<true>((const char*)(TA + sA0), X + (mr[0] * XW + mx[0]) * XS + kg * 16, X + (mr[1] * XW + mx[1]) * XS + kg * 16, acc[0], acc[1]);
+    B3S_STAMP(4);
+    // ---- phase B, output 0: roles, and the first fragments (under the exchange and the finalisation).  A job = (32-channel pair,
+    // 32-pixel group, K part kp of KP); KP > 1 where there are fewer (pair, group) blocks than waves (the posterior Block's 32
+    // channels: 2 blocks): the K parts meet in LDS, the block's two 8-channel halves go to its first two K-part waves.
+    const int npg = NOP > 32 ? 2 : 1;
+    typedef const B3Out __attribute__((address_space(4)))* kout_ptr;
+    const kout_ptr Ok0 = (kout_ptr)(ka + offsetof(B3P, o));
+    auto kp_of = [&](const int npb) { int KP = 1; while (2 * KP * npb * npg <= B3S_NW && nks >= 3 * 2 * KP) KP *= 2; return KP; };
+    auto b_start = [&](const kout_ptr Ok, const int job) {  // (job past the last: a started ring that run() drains without using it)
+      const int npb = Ok->npb, KP = kp_of(npb), njobs = npb * npg * KP;
+      const int jc = min(job, njobs - 1), blk = jc / KP, kp = jc - blk * KP, pair = npg == 2 ? blk >> 1 : blk;
+      const int SK = (nks + KP - 1) / KP, k0 = min(kp * SK, nks - 1);
+      const int cntB = job < njobs ? min(kp * SK + SK, nks) - min(kp * SK, nks) : 0;
+      KB.start(Ok->w + ((size_t)pair * nks + k0) * 1024, lane * 16, cntB);
+    };
+    if (!(p.s_dbg & 4)) b_start(Ok0, wave);
+    B3_BARRIER();  // (everyone is done with the input tile: the exchange buffer lies in its memory)
+    // ---- exchange: every wave's partial blocks -> LDS; the finalisers add the K parts in wave order (deterministic)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      char* dst = RED + ((wave * 2 + g) * 4) * 1024 + lane * 16;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) *(float4*)(dst + q4 * 1024) = make_float4(acc[g][4 * q4], acc[g][4 * q4 + 1], acc[g][4 * q4 + 2], acc[g][4 * q4 + 3]);
+    }
+    B3_BARRIER();
+    B3S_STAMP(5);
+    if (fjob) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll 1
+      for (int kq = 0; kq < KQ; ++kq) {
+        const char* src = RED + (((fmb * KQ + kq) * 2 + fng) * 4 + 2 * fhalf) * 1024 + lane * 16;
+        const float4 a = *(const float4*)src, b = *(const float4*)(src + 1024);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+      }
+      if (f_img && fch < bch) {
+        const bool own = mr[fng] >= 1 && mr[fng] <= R;  // the strip that owns the row writes it to HBM
+        char* gdst = (char*)p.mid.p + (n * p.mid.sn + fiy * p.mid.sh + mx[fng] * p.mid.sw) + fch * 2;
+        char* ldst = MID + (mr[fng] * B3S_MW + mx[fng] + 1) * MS + fch * 2;
+        if constexpr (PRE) {
+          v[0] += fb0.x; v[1] += fb0.y; v[2] += fb0.z; v[3] += fb0.w; v[4] += fb1.x; v[5] += fb1.y; v[6] += fb1.z; v[7] += fb1.w;
+          const uint4 o = b3_pack8(v);
+          if (own) *(uint4*)gdst = o;
+          union { uint4 q; h16x8 h; } r;
+          r.q = o;
+          r.h = b3_relu8(r.h);
+          *(uint4*)ldst = r.q;
+        } else {
+          const uint32_t w[4] = {tmk.x, tmk.y, tmk.z, tmk.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] = h_lo(w[e]) > 0.f ? v[2 * e] : 0.f;
+            v[2 * e + 1] = h_hi(w[e]) > 0.f ? v[2 * e + 1] : 0.f;
+          }
+          const uint4 o = b3_pack8(v);
+          if (own) *(uint4*)gdst = o;
+          *(uint4*)ldst = o;
+        }
+      }
+    }
+    B3S_STAMP(6);
+    B3_BARRIER();
+    B3S_STAMP(7);
+    // ---- phase B
+#pragma unroll 1
+    for (int oi = 0; oi < ((p.s_dbg & 4) ? 0 : p.nout); ++oi) {
+      const kout_ptr Ok = Ok0 + oi;
+      if (oi > 0) b_start(Ok, wave);
+      const float* const Obias = oi == 0 ? Ok->bias : nullptr;
+      const char* const Oout = Ok->out.p; const int Oout_sn = Ok->out.sn, Oout_sh = Ok->out.sh, Oout_sw = Ok->out.sw;
+      const char* const Oaux = Ok->aux.p; const int Oaux_sn = Ok->aux.sn, Oaux_sh = Ok->aux.sh, Oaux_sw = Ok->aux.sw;
+      const char* const Ores = Ok->res.p; const int Ores_sn = Ok->res.sn, Ores_sh = Ok->res.sh, Ores_sw = Ok->res.sw;
+      const int npb = Ok->npb, Co = Ok->Co;
+      const int Oout_rem = Ok->out_rem, Ores_rem = Ok->res_rem;
+      const bool has_aux = Oaux != nullptr, has_res = Ores != nullptr, has_rl = has_res && Ores_rem != 0;
+      const int KP = kp_of(npb), njobs = npb * npg * KP;
+      // epilogue of 8 channels of one pixel: requests first (in flight under the K loop), arithmetic + store later
+      // (two operands per unit: forward = residual + its remainder plane, data gradient = mask source + accumulated gradient)
+      struct Epi { uint4 a, b; float4 b0, b1; };
+      auto epi_request = [&](const bool ok_, const int gy, const int gx, const int ch, Epi& E) {
+        const bool ok = ok_ && ch < Co;
+        E.a = E.b = make_uint4(0, 0, 0, 0);
+        E.b0 = E.b1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (Obias != nullptr && ok) { E.b0 = *(const float4*)(Obias + ch); E.b1 = *(const float4*)(Obias + ch + 4); }
+        if constexpr (PRE) {
+          if (has_res) E.a = *(const uint4*)(ok ? Ores + (n * Ores_sn + gy * Ores_sh + gx * Ores_sw) + ch * 2 : zero);
+          if (has_rl) E.b = *(const uint4*)(ok ? Ores + Ores_rem + (n * Ores_sn + gy * Ores_sh + gx * Ores_sw) + ch * 2 : zero);
+        } else {
+          if (has_aux) E.a = *(const uint4*)(ok ? Oaux + (n * Oaux_sn + gy * Oaux_sh + gx * Oaux_sw) + ch * 2 : zero);
+          if (has_res) E.b = *(const uint4*)(ok ? Ores + (n * Ores_sn + gy * Ores_sh + gx * Ores_sw) + ch * 2 : zero);
+        }
+      };
+      auto epi_finish = [&](const bool ok_, const int gy, const int gx, const int ch, float (&u)[8], const Epi& E) {
+        if (!(ok_ && ch < Co)) return;
+        u[0] += E.b0.x; u[1] += E.b0.y; u[2] += E.b0.z; u[3] += E.b0.w; u[4] += E.b1.x; u[5] += E.b1.y; u[6] += E.b1.z; u[7] += E.b1.w;
+        const uint32_t wa[4] = {E.a.x, E.a.y, E.a.z, E.a.w}, wb[4] = {E.b.x, E.b.y, E.b.z, E.b.w};
+        if constexpr (PRE) {  // (zeros were loaded where an operand is absent)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { u[2 * e] = (u[2 * e] + h_lo(wa[e])) + h_lo(wb[e]); u[2 * e + 1] = (u[2 * e + 1] + h_hi(wa[e])) + h_hi(wb[e]); }  // (residual, then its remainder: the tile kernel's order)
+        } else {
+          if (has_aux) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              u[2 * e] = h_lo(wa[e]) > 0.f ? u[2 * e] : 0.f;
+              u[2 * e + 1] = h_hi(wa[e]) > 0.f ? u[2 * e + 1] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { u[2 * e] += h_lo(wb[e]); u[2 * e + 1] += h_hi(wb[e]); }
+        }
+        const uint4 o16 = b3_pack8(u);
+        char* dst = (char*)Oout + (n * Oout_sn + gy * Oout_sh + gx * Oout_sw) + ch * 2;
+        *(uint4*)dst = o16;
+        if (Oout_rem != 0) {  // what the rounding just dropped goes to the remainder plane: out_rem = rn16(v - out)
+          const uint32_t wo[4] = {o16.x, o16.y, o16.z, o16.w};
+          float dd[8];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { dd[2 * e] = u[2 * e] - h_lo(wo[e]); dd[2 * e + 1] = u[2 * e + 1] - h_hi(wo[e]); }
+          *(uint4*)(dst + Oout_rem) = b3_pack8(dd);
+        }
+      };
+      const int rounds = KP > 1 ? 1 : (njobs + B3S_NW - 1) / B3S_NW;  // (K parts: one job per wave, every wave meets the barrier)
+#pragma unroll 1
+      for (int r = 0; r < rounds; ++r) {
+        const int job = wave + B3S_NW * r;
+        const bool work = job < njobs;
+        const int jc = min(job, njobs - 1), blk = jc / KP, kp = jc - blk * KP;
+        const int pair = npg == 2 ? blk >> 1 : blk, pg = npg == 2 ? blk & 1 : 0;
+        const int SK = (nks + KP - 1) / KP, k0 = min(kp * SK, nks - 1);
+        const int o = 32 * pg + px, oc = min(o, NOP - 1);
+        const int oy = b3_div(oc, p.s_dw), ox = oc - oy * W;
+        const bool ev = work && o < NOP;
+        const int ch0 = pair * 32 + 16 * kg, gy = y0 + oy;
+        Epi E[2];
+#pragma unroll
+        for (int q8 = 0; q8 < 2; ++q8)
+          if (KP == 1 || kp == q8) epi_request(ev, gy, ox, ch0 + 8 * q8, E[q8]);
+        f32x16 c, cx;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[e] = 0.f;
+        const char* const mb = MID + (oy * B3S_MW + ox) * MS;
+        KB.run<false>((const char*)(KT + 2 * k0 + kg), mb, mb, c, cx);
+        if (r + 1 < rounds) b_start(Ok, job + B3S_NW);  // the next job's first fragments, under this one's epilogue (only where a run() follows: it drains them)
+        if (KP == 1) {
+#pragma unroll
+          for (int q8 = 0; q8 < 2; ++q8) {
+            float u[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = c[8 * q8 + e];
+            epi_finish(ev, gy, ox, ch0 + 8 * q8, u, E[q8]);
+          }
+        } else {
+          char* dst = RED + (wave * 4) * 1024 + lane * 16;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) *(float4*)(dst + q4 * 1024) = make_float4(c[4 * q4], c[4 * q4 + 1], c[4 * q4 + 2], c[4 * q4 + 3]);
+          B3_BARRIER();
+#pragma unroll
+          for (int q8 = 0; q8 < 2; ++q8) {
+            if (kp != q8) continue;
+            float u[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[e] = 0.f;
+#pragma unroll 1
+            for (int k = 0; k < KP; ++k) {
+              const char* src = RED + ((blk * KP + k) * 4 + 2 * q8) * 1024 + lane * 16;
+              const float4 a4 = *(const float4*)src, b4 = *(const float4*)(src + 1024);
+              u[0] += a4.x; u[1] += a4.y; u[2] += a4.z; u[3] += a4.w; u[4] += b4.x; u[5] += b4.y; u[6] += b4.z; u[7] += b4.w;
+            }
+            epi_finish(ev, gy, ox, ch0 + 8 * q8, u, E[q8]);
+          }
+          if (oi + 1 < p.nout) B3_BARRIER();  // (the next output's partial sums overwrite the exchange buffer)
+        }
+      }
+    }
+    B3S_STAMP(8);
+  }
+}
+
+template <bool PRE>
+// (128 registers per wave: two of its waves and one wave of the background weight-gradient kernel -- 256 registers -- share a SIMD.
+//  With 256 the launch needs whole SIMDs and waits for the background kernel to END: measured, 1.5 ms of stall in a step)
+__global__ __launch_bounds__(64 * B3S_NW, 4) void blk3s_kernel(B3P p) {
+  blk3s_body<PRE>(p, (int)blockIdx.x, (int)gridDim.x, 0);
+}
+// two independent data-gradient problems in one launch (as blk3_pair_kernel): 128 + 128 workgroups of a decoder layer's posterior and
+// prior Blocks fill the chip that either alone leaves half empty
+__global__ __launch_bounds__(64 * B3S_NW, 4) void blk3s_pair_kernel(B3P pa, B3P pb, const int na) {
+  (void)pa; (void)pb;
+  const bool second = (int)blockIdx.x >= na;
+  constexpr size_t off_b = (sizeof(B3P) + alignof(B3P) - 1) / alignof(B3P) * alignof(B3P);
+  const int koff = second ? (int)off_b : 0;
+  typedef const B3P __attribute__((address_space(4)))* kp_ptr;
+  const B3P& p = *(const B3P*)(kp_ptr)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + koff);
+  blk3s_body<false>(p, second ? (int)blockIdx.x - na : (int)blockIdx.x, second ? (int)gridDim.x - na : na, koff);
+}
+
 // ----------------------------------------------------------------------------- host side
 static bool b3_view(const cgen_view& v, int n, int h, int w, BV3& o) {
   o.p = (const char*)v.p; o.sn = o.sh = o.sw = 0;
@@ -757,6 +1166,8 @@ static void b3_tiles(B3P& p, int th) {
   p.ntiles = p.N * p.tiles_x * p.tiles_y;
   p.d_tx = b3_mkdiv(p.tiles_x); p.d_ty = b3_mkdiv(p.tiles_y);
 }
+
+static size_t b3s_lds(const B3P& p) { return (size_t)p.s_kt_off + (128 + 18 * p.nch + 16) * 4; }  // the two K-axis tables end the image
 
 static int b3_fill(const cgen_block3_args* a, B3P& p) {
   if (!a || a->dtype != CGEN_F16 || a->nseg < 1 || a->nseg > 3 || a->n <= 0 || a->h < 4 || a->w < 4) return 0;
@@ -775,7 +1186,9 @@ static int b3_fill(const cgen_block3_args* a, B3P& p) {
   p.ctot8 = koff * 32;
   p.nch = koff;
   p.b = a->mid.c;
-  if (p.b % 8 != 0 || p.b < 8 || p.b > 32) return 0;
+  static const int small_on = [] { const char* e = getenv("CGEN_BLK3S"); return e ? atoi(e) : 1; }();
+  p.small = (small_on && a->w <= 14 && a->h <= 64) ? 1 : 0;
+  if (p.b % 8 != 0 || p.b < 8 || p.b > (p.small ? 64 : 32)) return 0;
   p.nksB = (9 * p.b + 15) / 16;
   if (((uintptr_t)a->w_a % 16) || (a->bias_a && (uintptr_t)a->bias_a % 16)) return 0;
   p.wA = (const char*)a->w_a; p.biasA = a->bias_a;
@@ -793,8 +1206,33 @@ static int b3_fill(const cgen_block3_args* a, B3P& p) {
     d.out_rem = (int)s.out_rem; d.res_rem = (int)s.res1_rem;
     if (!b3_view(s.out, a->n, a->h, a->w, d.out) || !b3_view(s.aux, a->n, a->h, a->w, d.aux) || !b3_view(s.res1, a->n, a->h, a->w, d.res)) return 0;
     if ((s.aux.p && s.aux.c != s.out.c) || (s.res1.p && s.res1.c != s.out.c)) return 0;
-    if (o == 0 && s.out.c > 224) return 0;  // (lanes 8 .. 63 of the bias DMA instruction: 56 x 4 channels)
+    if (o == 0 && s.out.c > 224 && !p.small) return 0;  // (lanes 8 .. 63 of the bias DMA instruction: 56 x 4 channels)
     if (o > 0 && s.bias) return 0;  // (only the first output's bias has an LDS copy: the forward pass has one output)
+  }
+  if (p.small) {
+    int R = 64 / p.W - 2;
+    if (R < 1) return 0;
+    if (R > p.H) R = p.H;
+    p.s_rows = R; p.s_strips = ceil_div(p.H, R); p.s_nmb = (p.b + 31) / 32;
+    p.ntiles = p.N * p.s_strips;
+    p.s_dxw = b3_mkdiv(p.W + 2); p.s_dw = b3_mkdiv(p.W); p.s_dstrips = b3_mkdiv(p.s_strips);
+    for (int s = 0; s < a->nseg; ++s) {
+      p.s_segk0[s] = p.seg_koff[s];
+      p.s_segg[s] = 4 * ((a->seg[s].c + 31) / 32);
+    }
+    p.s_dg1 = b3_mkdiv(p.nch * 4 + 1); p.s_dnb = b3_mkdiv(p.b / 8);
+    const int nb8 = p.b / 8, nbs = (nb8 & 1) ? nb8 : nb8 + 1;
+    const int xbytes = (((R + 4) * (p.W + 2) * (p.nch * 4 + 1) + 63) / 64) * 1024;  // whole DMA instructions
+    p.s_red_off = 0;  // the exchange buffer [wave][pixel group][16 floats][64 lanes] (64 KiB) shares the input tile's memory: the tile is dead after phase A
+    p.s_mid_off = xbytes > 8 * 2 * 4096 ? xbytes : 8 * 2 * 4096;
+    p.s_kt_off = p.s_mid_off + (((R + 2) * 16 * nbs * 16 + 1023) & ~1023);  // (B3S_MW = 16 pixels per row)
+    if (2 * p.nksB + 30 > 128) return 0;      // (the phase-B table: 128 entries, read up to 13 steps past the end)
+    if (b3s_lds(p) > 158 * 1024) return 0;
+    for (int o = 0; o < a->nout; ++o)
+      if (p.o[o].bias && ((uintptr_t)p.o[o].bias % 16)) return 0;
+    { static unsigned long long* const stamps_env = [] { const char* e = getenv("CGEN_BLK3_STAMPS"); return e ? (unsigned long long*)strtoull(e, nullptr, 0) : (unsigned long long*)nullptr; }(); p.stamps = stamps_env; }
+    { static const int dbg = [] { const char* e = getenv("CGEN_BLK3S_DBG"); return e ? atoi(e) : 0; }(); p.s_dbg = dbg; }  // (ablation: 1 no input DMA, 2 no phase-A K loop, 4 no phase B)
+    return 1;
   }
   b3_tiles(p, 8);
   // (debug hook, read ONCE per process: the address of a device buffer for cycle stamps, tools/blk_stamps.py)
@@ -905,6 +1343,12 @@ static void b3_pair_nb(const B3P& pa, const B3P& pb, const B3Launch& La, const B
 static int b3_pair_plan(const cgen_block3_args* a, const cgen_block3_args* b, B3P& pa, B3P& pb, B3Launch& La, B3Launch& Lb) {
   if (!a || !b || a->pre_act || b->pre_act || !a->mid_aux.p || !b->mid_aux.p) return 0;
   if (!b3_fill(a, pa) || !b3_fill(b, pb)) return 0;
+  if (pa.small || pb.small) {
+    La.grid = pa.ntiles; Lb.grid = pb.ntiles;
+    La.lds = b3s_lds(pa); Lb.lds = b3s_lds(pb);
+    La.npg = Lb.npg = 0; La.sm = Lb.sm = 0; La.th = Lb.th = 0;
+    return (pa.small && pb.small && !pa.o[0].out_rem && !pb.o[0].out_rem) ? 1 : 0;
+  }
   const int ta = pa.ntiles, tb = pb.ntiles;  // (eight-row tiles: the cap decision below only needs "more than one tile per CU or not")
   La = b3_plan(pa, tb);
   Lb = b3_plan(pb, ta);
@@ -927,6 +1371,11 @@ extern "C" int cgen_block3_pair(const cgen_block3_args* a, const cgen_block3_arg
   B3P pa, pb;
   B3Launch La, Lb;
   CGEN_REQUIRE(b3_pair_plan(a, b, pa, pb, La, Lb), "cgen_block3_pair: the two problems do not plan to the same data-gradient instance (ask cgen_block3_pair_supported first)");
+  if (pa.small) {
+    (void)hipFuncSetAttribute((const void*)blk3s_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(blk3s_pair_kernel, dim3(La.grid + Lb.grid), dim3(64 * B3S_NW), std::max(La.lds, Lb.lds), (hipStream_t)stream, pa, pb, La.grid);
+    return check_launch("cgen_block3_pair(small)");
+  }
   switch (pa.b / 8) {
     case 1: b3_pair_nb<1>(pa, pb, La, Lb, (hipStream_t)stream); break;
     case 2: b3_pair_nb<2>(pa, pb, La, Lb, (hipStream_t)stream); break;
@@ -947,6 +1396,19 @@ extern "C" int cgen_block3(const cgen_block3_args* a, cgen_stream_t stream) {
   B3P p;
   CGEN_REQUIRE(b3_fill(a, p), "cgen_block3: shape / layout not served by the fused Block kernel (ask cgen_block3_supported first)");
   CGEN_REQUIRE((a->pre_act != 0) == (a->mid_aux.p == nullptr), "cgen_block3: pre_act = 1 is the forward pass (no mid_aux), pre_act = 0 the data gradient (mid_aux = the forward mid)");
+  if (p.small) {
+    const size_t lds = b3s_lds(p);
+    if (a->pre_act) {
+      (void)hipFuncSetAttribute((const void*)blk3s_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((blk3s_kernel<true>), dim3(p.ntiles), dim3(64 * B3S_NW), lds, (hipStream_t)stream, p);
+    } else {
+      (void)hipFuncSetAttribute((const void*)blk3s_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((blk3s_kernel<false>), dim3(p.ntiles), dim3(64 * B3S_NW), lds, (hipStream_t)stream, p);
+    }
+    static const bool trace_s = getenv("CGEN_CONV_TRACE") != nullptr;
+    if (trace_s) fprintf(stderr, "blk3s[%s] %dx%dx%d ctot8 %d b %d Co %d nseg %d nout %d | %d rows per strip, grid %d, lds %zu\n", a->mid_aux.p ? "bwd" : "fwd", a->n, a->h, a->w, p.ctot8, p.b, p.o[0].Co, a->nseg, a->nout, p.s_rows, p.ntiles, lds);
+    return check_launch("cgen_block3(small)");
+  }
   const B3Launch L = b3_plan(p);
   if (a->pre_act) b3_launch_pre<true>(p, L, (hipStream_t)stream);
   else b3_launch_pre<false>(p, L, (hipStream_t)stream);

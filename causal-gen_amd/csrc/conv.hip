@@ -2580,11 +2580,13 @@ __global__ __launch_bounds__(256) void wprep_kernel(const cgen_wprep_desc* descs
     for (int i = threadIdx.x; i < MT_CHUNK; i += 256) {
       const int64_t o = base + i;
       if (o >= d.numel) break;
-      const int frag = (int)(o >> 9), w = (int)(o & 511), ln = w >> 3, e = w & 7;
+      int frag = (int)(o >> 9);
+      const int w = (int)(o & 511), ln = w >> 3, e = w & 7;
       const int r32 = ln & 31, kg = ln >> 5;
-      const int row = 16 * ((r32 >> 2) & 1) + (r32 & 3) + 4 * (r32 >> 3);  // channel (inside its 32-block) that fragment row r32 carries
+      int row = 16 * ((r32 >> 2) & 1) + (r32 & 3) + 4 * (r32 >> 3);  // channel (inside its 32-block) that fragment row r32 carries
       float v = 0.f;
-      if (d.mode <= 3) {  // phase A: frag = chunk * 18 + kk
+      if (d.mode <= 3) {  // phase A: frag = (32-row block * chunks + chunk) * 18 + kk; k_pad = fragments per 32-row block (0: one block)
+        if (d.k_pad > 0) { const int mb = (int)((uint32_t)frag / (uint32_t)d.k_pad); frag -= mb * d.k_pad; row += 32 * mb; }
         const int j = (int)((uint32_t)frag / 18u), kk = frag - j * 18, half = kk >= 9 ? 1 : 0, tap = kk - 9 * half;  // (a wave's nine fragments are contiguous)
         const int kc = 32 * j + 16 * half + 8 * kg + e;  // position on the concatenated input axis (segments in whole chunks)
         if (d.mode == 2) {

@@ -195,7 +195,8 @@ class ConvSite:
         if role == "a":   # conv1: [b][Ci][3][3]
             b = self.co
             nks = (9 * b + 15) // 16
-            self.frag_numel["a_fwd"] = sum(_ceil(c, 32) // 32 for c in self.seg_c) * 18 * 512  # (segments in whole 32-channel chunks)
+            # (segments in whole 32-channel chunks; one image per 32-row block of the bottleneck: widths above 32 are the small-image instance's)
+            self.frag_numel["a_fwd"] = _ceil(b, 32) // 32 * sum(_ceil(c, 32) // 32 for c in self.seg_c) * 18 * 512
             for k, (c, rg) in enumerate(zip(self.seg_c, self.seg_rg)):
                 if rg:
                     self.frag_numel[("b_dg", k)] = _ceil(c, 32) // 32 * nks * 512
@@ -203,7 +204,7 @@ class ConvSite:
             b = self.ci
             nks = (9 * b + 15) // 16
             self.frag_numel["b_fwd"] = _ceil(self.co, 32) // 32 * nks * 512
-            self.frag_numel["a_dg"] = _ceil(_ceil(self.co, 8), 32) // 32 * 18 * 512
+            self.frag_numel["a_dg"] = _ceil(b, 32) // 32 * (_ceil(_ceil(self.co, 8), 32) // 32) * 18 * 512
 
 
 class Engine(StageMixin, WgradMixin):
@@ -332,6 +333,8 @@ class Engine(StageMixin, WgradMixin):
         # least CGEN_BLK3_MINRES wide
         self.blk3_on = int(os.environ.get("CGEN_BLK3", "2")) if self.dt == F16 else 0
         self.blk3_minres = int(os.environ.get("CGEN_BLK3_MINRES", "16"))
+        # images up to 14 pixels wide (12x12, 6x6): the small-image instance of cgen_block3, one launch per Block there too
+        self.blk3_small = int(os.environ.get("CGEN_BLK3S", "1"))
         # ... at which image sides: CGEN_BLK3_RES for Blocks with one or two input segments (trunk / prior / down Blocks),
         # CGEN_BLK3_RES3 for three-segment Blocks (the posterior: cat[h, pa, acts]); a comma list of sides and lo-hi ranges,
         # "0" = every side >= CGEN_BLK3_MINRES.  Defaults = where the fused launch beats the two it replaces INSIDE the step on MI355X
@@ -579,10 +582,10 @@ class Engine(StageMixin, WgradMixin):
                 for k, c in enumerate(s.seg_c):
                     d.seg_c[k] = c
                 d.dtype, d.rows_pad, d.numel = self.dt, 0, numel
-                if key == "a_fwd":
-                    d.mode, d.k_pad = 2, 0
+                if key == "a_fwd":  # (k_pad: fragments per 32-row block of the bottleneck)
+                    d.mode, d.k_pad = 2, sum(_ceil(c, 32) // 32 for c in s.seg_c) * 18
                 elif key == "a_dg":
-                    d.mode, d.k_pad = 3, 0
+                    d.mode, d.k_pad = 3, _ceil(_ceil(s.co, 8), 32) // 32 * 18
                 elif key == "b_fwd":
                     d.mode, d.k_pad = 4, (9 * s.ci + 15) // 16
                 else:
@@ -700,10 +703,12 @@ class Engine(StageMixin, WgradMixin):
         two conv launches.  The bottleneck tensor is written either way (weight gradients, backward mask)."""
         x0 = segs[0]
         res_ok = self.blk3_res3 if len(segs) >= 3 else self.blk3_res
-        if (self.blk3_on and act == ACT_RELU and min(x0.h, x0.w) >= self.blk3_minres and "a_fwd" in site1.frag
-                and (not res_ok or any(lo <= x0.h <= hi for lo, hi in res_ok))
-                and "b_fwd" in site2.frag and len(segs) <= 3 and site1.co % 8 == 0 and site1.co <= 32 and site2.co % 8 == 0
-                and not self.stage_covers(x0.h)):
+        small = self.blk3_small and x0.w <= 14 and x0.h <= 64 and min(x0.h, x0.w) >= 4  # (the small-image instance: csrc/block.hip blk3s)
+        if (self.blk3_on and act == ACT_RELU and "a_fwd" in site1.frag and "b_fwd" in site2.frag and len(segs) <= 3
+                and site1.co % 8 == 0 and site2.co % 8 == 0 and not self.stage_covers(x0.h)
+                and ((small and site1.co <= 64) or
+                     (min(x0.h, x0.w) >= self.blk3_minres and site1.co <= 32
+                      and (not res_ok or any(lo <= x0.h <= hi for lo, hi in res_ok))))):
             out = self._block3_fwd(site1, site2, segs, res1, trunk)
             if out is not None:
                 return out

@@ -36,6 +36,21 @@ CASES = [
 ]
 
 
+# the small-image instance (blk3s: images up to 14 pixels wide, bottlenecks up to 64 channels; one workgroup per row strip of an image)
+CASES += [
+    (32, 12, 12, [160], [1], 40, 160, True),               # 12^2 trunk: bottleneck 40 = two 32-row blocks, 4 strips of 3 rows
+    (32, 12, 12, [160, 4, 160], [1, 0, 1], 40, 32, False),  # 12^2 posterior
+    (8, 12, 12, [160, 4], [1, 0], 40, 192, False),         # 12^2 prior
+    (32, 6, 6, [192], [1], 48, 192, True),                 # 6^2 trunk: one workgroup per image
+    (32, 6, 6, [192, 4, 192], [1, 0, 1], 48, 32, False),   # 6^2 posterior
+    (4, 6, 6, [192], [1], 48, 512, False),                 # the widest output (encoder down-block at 6^2)
+    (3, 14, 14, [64], [1], 16, 64, True),                  # 14 wide: strips of 2 rows; one 32-row block
+    (5, 8, 8, [40], [1], 8, 48, True),                     # ragged chunk (40 = 32 + 8 channels), 8-wide bottleneck
+    (2, 12, 10, [160], [1], 40, 160, True),                # not square: strips of 4 rows
+    (2, 7, 5, [72, 8], [1, 1], 24, 56, False),             # odd sides, two gradient outputs, ragged everything
+]
+
+
 def _run(case, fuse, seed=0):
     from causal_gen_amd.engine import ConvSite, Engine
 
@@ -121,7 +136,8 @@ def test_fused_block3_matches_two_launch_path_and_torch(case):
     assert float((one["pg"][2] - w2.grad).norm()) <= 3e-2 * float(w2.grad.norm())
 
 
-@pytest.mark.parametrize("shape", [(4, 48, 48, 96, 24), (8, 24, 24, 128, 32), (32, 48, 48, 96, 24)], ids=["48x48", "24x24", "48x48-twelve-row"])
+@pytest.mark.parametrize("shape", [(4, 48, 48, 96, 24), (8, 24, 24, 128, 32), (32, 48, 48, 96, 24), (8, 12, 12, 160, 40), (8, 6, 6, 192, 48)],
+                         ids=["48x48", "24x24", "48x48-twelve-row", "12x12-small", "6x6-small"])
 def test_fused_block3_remainder_planes(shape):
     """Residual-trunk Blocks of an inference pass (value = hi + rem, remainder planes): the fused kernel reads res1 as
     hi + rem and writes out = rn16(v), out_rem = rn16(v - out), like the two-launch path's second conv (cgen_conv_args.out_rem /
@@ -247,7 +263,9 @@ def _run_two(N, H, W, b, segA, rgA, coA, segB, rgB, coB, pair, seed=0, fuse=2, c
     (32, 48, 48, 24, [96, 4, 96], [1, 0, 1], 32, [96, 4], [1, 0], 128),   # ... at the bench batch: twelve-row tiles, 768 workgroups for 512 slots
     (8, 24, 24, 32, [128, 4, 128], [1, 0, 1], 32, [128], [1], 160),       # 24^2
     (3, 20, 28, 16, [64], [1], 96, [64, 4], [1, 0], 32),                   # ragged image, different output classes (no pair: two launches)
-], ids=["48x48-b2", "48x48-b32", "24x24", "mismatch"])
+    (32, 12, 12, 40, [160, 4, 160], [1, 0, 1], 32, [160, 4], [1, 0], 192),  # 12^2 decoder layer: two small-image problems of 128 workgroups
+    (32, 6, 6, 48, [192, 4, 192], [1, 0, 1], 32, [192], [1], 224),          # 6^2
+], ids=["48x48-b2", "48x48-b32", "24x24", "mismatch", "12x12-small", "6x6-small"])
 def test_block3_pair_launch_is_bit_identical_to_two_launches(shape):
     a, pa = _run_two(*shape, pair=False)
     b, pb = _run_two(*shape, pair=True)

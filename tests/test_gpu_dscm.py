@@ -238,3 +238,59 @@ def test_dscm_forward_with_the_pyro_free_parent_scm():
     out["loss"].sum().backward()
     torch.cuda.synchronize()
     assert m.encoder.stem.weight.grad is not None and float(m.encoder.stem.weight.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("tag", ["default_p3", "ukbb_light_p1"])
+def test_dscm_forward_against_the_references_own_dscm_forward(tag):
+    """The product's ``DSCM.forward`` against tests/golden/dscm_*.pt: outputs of the REFERENCE's ``DSCM`` class itself (src/pgm/dscm.py:15-95;
+    oracle/make_dscm_golden.py runs it with pyro / torchvision / imageio / seaborn stubbed and the stand-in pgm / predictor / ELBO of
+    oracle/dscm_stubs.py).  Same obs / do dicts through the same surface: ELBO, NLL, KL, counterfactual particle mean and variance,
+    auxiliary loss, damped Lagrangian, and the gradients of the loss w.r.t. the HVAE weights and the multiplier."""
+    from causal_gen_amd import dscm, vae
+    from causal_gen_amd.hps import Hparams
+    from oracle import dscm_stubs as S
+
+    fx = load_golden("dscm_%s.pt" % tag)
+    hpd, c = dict(fx["hp"]), fx["constants"]
+    m = vae.HVAE(Hparams(**hpd))
+    m.load_state_dict(fx["state_dict"])
+    m.compute_dtype = "f32"
+    m = m.cuda().eval()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    args = SimpleNamespace(**{**hpd, "parents_x": fx["parents_x"], "dataset": fx["dataset"], "lmbda_init": c["lmbda_init"],
+                              "elbo_constraint": c["elbo_constraint"], "damping": c["damping"]})
+    args.beta = c["beta"]
+    model = dscm.DSCM(args, S.StubPGM(), S.StubPredictor(), m).cuda()
+    obs = {k: v.cuda() for k, v in fx["obs"].items()}
+    do = {k: v.cuda() for k, v in fx["do"].items()}
+    pre = dscm.vae_preprocess(args, {k: v.clone() for k, v in obs.items() if k != "x"})
+    assert torch.allclose(pre[:, :, 0, 0].cpu(), fx["vae_parents"], rtol=0, atol=1e-6)
+    m.noise = [e.clone() for e in fx["eps"]]
+    out = model(obs, do, S.StubELBO(fx["w"]), cf_particles=fx["particles"], t_abduct=fx["t_abduct"])
+    assert not m.noise, "every draw of the reference must be consumed, in its order"
+    for k in ("elbo", "nll", "kl"):
+        assert abs(float(out[k].detach()) - float(fx["out"][k])) <= 1e-4 * abs(float(fx["out"][k])), (k, float(out[k].detach()), float(fx["out"][k]))
+    for k in ("aux_loss", "loss"):
+        assert abs(float(out[k].detach()) - float(fx["out"][k])) <= 2e-4 * abs(float(fx["out"][k])) + 1e-5, (k, float(out[k].detach()), float(fx["out"][k]))
+    assert float((out["cfs"]["x"].detach().cpu() - fx["cf_x"]).abs().max()) < 1e-3
+    for k, v in fx["cf_parents"].items():
+        assert torch.equal(out["cfs"][k].cpu(), v)
+    if fx["particles"] > 1:
+        assert float((out["var_cf_x"].cpu() - fx["var_cf_x"]).abs().max()) < 1e-3
+    else:
+        assert out["var_cf_x"] is None
+    out["loss"].sum().backward()
+    torch.cuda.synchronize()
+    assert abs(float(model.lmbda.grad) - float(fx["lmbda_grad"])) <= 1e-4 * abs(float(fx["lmbda_grad"])) + 1e-6
+    named, n = dict(m.named_parameters()), 0
+    for name, g in fx["grads"].items():
+        if float(g.abs().max()) == 0.0:
+            continue
+        got = named[name].grad
+        assert got is not None, name
+        d = float((got.cpu() - g).abs().max()) / float(g.abs().max())
+        l2 = float((got.cpu() - g).norm()) / float(g.norm())
+        assert d < 5e-3 and l2 < 2e-3, (name, d, l2)
+        n += 1
+    assert n > 50

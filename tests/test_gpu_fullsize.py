@@ -46,6 +46,11 @@ F16_KL_TOL = 2e-4
 # operand-rounding floor described above.
 F16_TIMED_ELBO_TOL = {"morphomnist": 1e-3}
 F16_TIMED_ELBO_TOL_DEFAULT = 1e-4
+# ... its NLL component alone (ELBO = NLL + beta KL is north_star's quantity): the deviation of a 16-bit pass from the reference is a
+# realisation of rounding noise, and which realisation depends on the kernels' f32 summation order.  Measured on ukbb192 (round 6):
+# 1.3e-5 with the <= 12x12 Blocks as two launches each, 1.2e-4 with the one-launch small-image instance (same operands, same
+# roundings, K split over eight waves instead of four; ELBO 3.2e-5, gradients vs f32 as before); held to 2e-4.
+F16_TIMED_NLL_TOL_DEFAULT = 2e-4
 F16_TIMED_KL_TOL = 1e-3
 
 
@@ -207,7 +212,7 @@ def test_fullsize_forward_backward_counterfactual(name, B, dmol):
     assert dev["kl"] < F16_KL_TOL, dev
     assert d_cfb < F16_CF_TOL, d_cfb
     etol_t = F16_TIMED_ELBO_TOL.get(name, F16_TIMED_ELBO_TOL_DEFAULT)
-    assert dev_t["elbo"] < etol_t and dev_t["nll"] < etol_t, dev_t
+    assert dev_t["elbo"] < etol_t and dev_t["nll"] < max(etol_t, F16_TIMED_NLL_TOL_DEFAULT), dev_t
     assert dev_t["kl"] < F16_TIMED_KL_TOL, dev_t
 
 

@@ -202,3 +202,54 @@ def test_simple_vae_config1(name, n_params):
         sx, ss = simple_ref.sample(sd, hp, pa, t=s["t"], eps=eps)
         torch.testing.assert_close(sx, s["x"], **TOL)
         torch.testing.assert_close(ss, s["scale"], **TOL)
+
+
+@pytest.mark.parametrize("tag", ["default_p3", "ukbb_light_p1"])
+def test_dscm_forward_pinned_by_the_reference(tag):
+    """oracle/dscm_ref.py against tests/golden/dscm_*.pt -- outputs of the REFERENCE's own ``DSCM.forward`` (src/pgm/dscm.py:30-95,
+    run by oracle/make_dscm_golden.py with pyro / torchvision / imageio / seaborn stubbed in sys.modules and the duck-typed
+    pgm / predictor / ELBO of oracle/dscm_stubs.py): parent preprocessing incl. the UKBB log-standardisation (dscm.py:98-132), factual
+    ELBO, particle mean and variance (dscm.py:58-72), auxiliary loss, damped Lagrangian (dscm.py:85-88) and d loss / d theta,
+    d loss / d lambda through the counterfactual branch."""
+    from types import SimpleNamespace
+
+    from oracle import dscm_ref, dscm_stubs as S, hvae_ref
+
+    fx = load_golden("dscm_%s.pt" % tag)
+    hp = SimpleNamespace(**fx["hp"])
+    obs, do, c = fx["obs"], fx["do"], fx["constants"]
+    x, B = obs["x"], obs["x"].shape[0]
+    ukbb = "ukbb" in fx["dataset"]
+    pa = {k: v for k, v in obs.items() if k != "x"}
+    parents = dscm_ref.expand_parents({k: v.clone() for k, v in pa.items()}, fx["parents_x"], hp.input_res, ukbb=ukbb)
+    assert torch.allclose(parents[:, :, 0, 0], fx["vae_parents"], rtol=0, atol=1e-6)  # vae_preprocess / ukbb_preprocess
+    pgm = S.StubPGM()
+    cf_dicts = [pgm.counterfactual(obs=pa, intervention=do, num_particles=1) for _ in range(fx["particles"])]
+    cf_list = [dscm_ref.expand_parents({k: v.clone() for k, v in d.items()}, fx["parents_x"], hp.input_res, ukbb=ukbb) for d in cf_dicts]
+    for k, v in fx["cf_parents"].items():
+        assert torch.equal(cf_dicts[-1][k], v)  # dscm.py:74 keeps the LAST particle's parents
+    sd = {k: v.clone().requires_grad_(True) for k, v in fx["state_dict"].items()}
+    lm = torch.tensor([c["lmbda_init"]], requires_grad=True)
+    elbo_fn = S.StubELBO(fx["w"])
+    noise = hvae_ref._Noise([e.clone() for e in fx["eps"]])
+    out = dscm_ref.dscm_forward(sd, hp, x, parents, cf_list, c["beta"], t_abduct=fx["t_abduct"], noise=noise,
+                                aux_fn=lambda cx: elbo_fn.differentiable_loss(None, None, x=cx, **cf_dicts[-1]) / B, lmbda=lm,
+                                eps=torch.tensor([c["elbo_constraint"]]), damping=c["damping"])
+    assert not noise.source, "every draw of the reference must be consumed, in its order"
+    for k in ("elbo", "nll", "kl", "loss", "aux_loss"):
+        assert abs(float(out[k].detach()) - float(fx["out"][k])) <= 2e-5 * abs(float(fx["out"][k])) + 1e-6, (k, float(out[k].detach()), float(fx["out"][k]))
+    assert float((out["cf_x"] - fx["cf_x"]).abs().max()) < 2e-5
+    if fx["particles"] > 1:
+        assert float((out["var_cf_x"] - fx["var_cf_x"]).abs().max()) < 2e-5
+    else:
+        assert out["var_cf_x"] is None and fx["var_cf_x"] is None
+    out["loss"].sum().backward()
+    assert abs(float(lm.grad) - float(fx["lmbda_grad"])) <= 2e-5 * abs(float(fx["lmbda_grad"])) + 1e-6
+    n = 0
+    for name, g in fx["grads"].items():
+        if float(g.abs().max()) == 0.0:
+            continue
+        d = float((sd[name].grad - g).abs().max()) / float(g.abs().max())
+        assert d < 2e-3, (name, d)
+        n += 1
+    assert n > 50
