@@ -265,7 +265,8 @@ def test_dscm_forward_against_the_references_own_dscm_forward(tag):
     obs = {k: v.cuda() for k, v in fx["obs"].items()}
     do = {k: v.cuda() for k, v in fx["do"].items()}
     pre = dscm.vae_preprocess(args, {k: v.clone() for k, v in obs.items() if k != "x"})
-    assert torch.allclose(pre[:, :, 0, 0].cpu(), fx["vae_parents"], rtol=0, atol=1e-6)
+    # (the UKBB log-standardisation runs where the parents live -- here the GPU: one f32 ulp of log(1.6e6) ~ 14, divided by sigma ~ 0.1)
+    assert torch.allclose(pre[:, :, 0, 0].cpu(), fx["vae_parents"], rtol=0, atol=3e-5)
     m.noise = [e.clone() for e in fx["eps"]]
     out = model(obs, do, S.StubELBO(fx["w"]), cf_particles=fx["particles"], t_abduct=fx["t_abduct"])
     assert not m.noise, "every draw of the reference must be consumed, in its order"
