@@ -6,6 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CGEN_LIB") or os.path.join(_HERE, "libcgen_hip.so")  # (CGEN_LIB: another build of the same ABI, for A/B runs)
 
 F32, F16, F32S = 0, 1, 2
+DMOL_LOW_BIT = 0x100  # OR-ed into the dtype of cgen_dmol_nll_fwd/bwd: the reference's low_bit=True branch (dmol.py:52-60)
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 UNARY_LEAKY_RELU, UNARY_CLAMP_MIN, UNARY_ADD = 3, 4, 5
 MAX_SEG = 4

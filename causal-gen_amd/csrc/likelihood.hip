@@ -24,6 +24,7 @@ struct DgP {
   float* part;
   const float* coef;
   int coef_stride;
+  float hb, logc;
 };
 
 // per-pixel parameter decode shared by fwd/bwd: loc[c], ls[c] (clamped), tanh coeffs
@@ -351,10 +352,11 @@ __device__ __forceinline__ float sigmoid_t(float x) { return 1.f / (1.f + expf(-
 __device__ __forceinline__ float softplus_grad(float x) { return x > 20.f ? 1.f : sigmoid_t(x); }
 
 // log-prob of one (channel, mixture) and its derivatives w.r.t. mean and RAW log-scale
-__device__ __forceinline__ float dm_logprob(float xv, float mean, float ls_raw, float* d_mean, float* d_ls) {
+// (hb: half a bin, 1/255 for 8-bit pixels, 1/31 for the reference's low_bit = 5-bit branch; logc = log(1 / (2 hb)), dmol.py:52-60, 88-116)
+__device__ __forceinline__ float dm_logprob(float xv, float mean, float ls_raw, float* d_mean, float* d_ls, const float hb, const float logc) {
   const float ls = fmaxf(ls_raw, DM_MIN_LS);
   const float inv = expf(-ls), d = xv - mean;
-  const float up = inv * (d + 1.f / 255.f), um = inv * (d - 1.f / 255.f), mid = inv * d;
+  const float up = inv * (d + hb), um = inv * (d - hb), mid = inv * d;
   float lp, dup = 0.f, dum = 0.f, dmid = 0.f, dls_direct = 0.f;
   if (xv < -0.999f) {
     lp = up - softplus_t(up);
@@ -369,7 +371,7 @@ __device__ __forceinline__ float dm_logprob(float xv, float mean, float ls_raw, 
       dup = cp * (1.f - cp) / de;
       dum = -cm * (1.f - cm) / de;
     } else {
-      lp = mid - ls - 2.f * softplus_t(mid) - DM_LOG_127_5;
+      lp = mid - ls - 2.f * softplus_t(mid) - logc;
       dmid = 1.f - 2.f * softplus_grad(mid);
       dls_direct = -1.f;
     }
@@ -393,10 +395,11 @@ struct DmP {
   float* part;
   const float* coef;
   int coef_stride;
+  float hb, logc;
 };
 
 // returns log p(x) for the pixel; if G != nullptr writes d(log p)/d logits into G[100]
-__device__ __forceinline__ float dm_pixel(const float (&l)[100], const float (&xv)[3], float* G) {
+__device__ __forceinline__ float dm_pixel(const float (&l)[100], const float (&xv)[3], float* G, const float hb = 1.f / 255.f, const float logc = DM_LOG_127_5) {
   float S[DM_NMIX];
   float mx = -INFINITY;
 #pragma unroll
@@ -414,9 +417,9 @@ __device__ __forceinline__ float dm_pixel(const float (&l)[100], const float (&x
     const float mg = l[10 + 30 + m] + k0 * xv[0];
     const float mb = l[10 + 60 + m] + k1 * xv[0] + k2 * xv[1];
     float s = l[m] - lse_logits;
-    s += dm_logprob(xv[0], mr, l[10 + 10 + m], G ? &dmean[0][m] : nullptr, G ? &dls[0][m] : nullptr);
-    s += dm_logprob(xv[1], mg, l[10 + 30 + 10 + m], G ? &dmean[1][m] : nullptr, G ? &dls[1][m] : nullptr);
-    s += dm_logprob(xv[2], mb, l[10 + 60 + 10 + m], G ? &dmean[2][m] : nullptr, G ? &dls[2][m] : nullptr);
+    s += dm_logprob(xv[0], mr, l[10 + 10 + m], G ? &dmean[0][m] : nullptr, G ? &dls[0][m] : nullptr, hb, logc);
+    s += dm_logprob(xv[1], mg, l[10 + 30 + 10 + m], G ? &dmean[1][m] : nullptr, G ? &dls[1][m] : nullptr, hb, logc);
+    s += dm_logprob(xv[2], mb, l[10 + 60 + 10 + m], G ? &dmean[2][m] : nullptr, G ? &dls[2][m] : nullptr, hb, logc);
     S[m] = s;
   }
   float smx = -INFINITY;
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(256) void dmol_nll_fwd_kernel(DmP p) {
       dm_load<T>(vptr<T>(p.logits, b, y, x), l);
       const T* xp = vptr<T>(p.x, b, y, x);
       xv[0] = Elem<T>::ld(xp); xv[1] = Elem<T>::ld(xp + 1); xv[2] = Elem<T>::ld(xp + 2);
-      acc -= dm_pixel(l, xv, nullptr);
+      acc -= dm_pixel(l, xv, nullptr, p.hb, p.logc);
     }
   }
   const float tot = block_sum_256(acc, sm);
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(256) void dmol_nll_bwd_kernel(DmP p) {
     dm_load<T>(vptr<T>(p.logits, b, y, x), l);
     const T* xp = vptr<T>(p.x, b, y, x);
     xv[0] = Elem<T>::ld(xp); xv[1] = Elem<T>::ld(xp + 1); xv[2] = Elem<T>::ld(xp + 2);
-    dm_pixel(l, xv, G);
+    dm_pixel(l, xv, G, p.hb, p.logc);
     const float coef = -p.coef[(int64_t)b * p.coef_stride];
     T* go = vptr<T>(p.g, b, y, x);
 #pragma unroll
@@ -712,10 +715,13 @@ extern "C" int cgen_dgauss_params(int32_t dtype, int32_t n, int32_t h, int32_t w
 
 extern "C" int cgen_dmol_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, cgen_view x, float* nll_part,
                                  cgen_stream_t stream) {
+  const bool low_bit = (dtype & CGEN_DMOL_LOW_BIT) != 0;
+  dtype &= ~CGEN_DMOL_LOW_BIT;
   CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_dmol_nll_fwd: bad dtype");
   CGEN_REQUIRE(logits.p && x.p && nll_part && logits.c == 100 && x.c == 3, "cgen_dmol_nll_fwd: bad args");
   DmP p;
   memset(&p, 0, sizeof(p));
+  p.hb = low_bit ? 1.f / 31.f : 1.f / 255.f; p.logc = low_bit ? 2.7408400239252009f : DM_LOG_127_5;  // log 15.5 | log 127.5
   p.n = n; p.h = h; p.w = w; p.logits = mk(logits); p.x = mk(x); p.part = nll_part;
   dim3 grid(cgen_like_chunks(h, w), n);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(dmol_nll_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, p);
@@ -725,10 +731,13 @@ extern "C" int cgen_dmol_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w,
 
 extern "C" int cgen_dmol_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, cgen_view x,
                                  const float* coef_dev, int32_t coef_stride, cgen_view g_logits, cgen_stream_t stream) {
+  const bool low_bit = (dtype & CGEN_DMOL_LOW_BIT) != 0;
+  dtype &= ~CGEN_DMOL_LOW_BIT;
   CGEN_REQUIRE(dtype == CGEN_F32 || dtype == CGEN_F16, "cgen_dmol_nll_bwd: bad dtype");
   CGEN_REQUIRE(logits.p && x.p && coef_dev && g_logits.p && logits.c == 100 && g_logits.c == 100, "cgen_dmol_nll_bwd: bad args");
   DmP p;
   memset(&p, 0, sizeof(p));
+  p.hb = low_bit ? 1.f / 31.f : 1.f / 255.f; p.logc = low_bit ? 2.7408400239252009f : DM_LOG_127_5;
   p.n = n; p.h = h; p.w = w; p.logits = mk(logits); p.x = mk(x); p.g = mk(g_logits); p.coef = coef_dev; p.coef_stride = coef_stride;
   const int grid = like_grid((int64_t)n * h * w);
   if (dtype == CGEN_F32) hipLaunchKernelGGL(dmol_nll_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);

@@ -40,15 +40,16 @@ def _prep(name, l, nr_mix=NR_MIX):
 
 class _DmolLoss(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, l, x):
+    def forward(ctx, l, x, low_bit=False):
         lib, lc = _prep("discretized_mix_logistic_loss", l)
+        ctx.dt = _lib.F32 | (_lib.DMOL_LOW_BIT if low_bit else 0)
         xc = x.detach().to(lc.device, torch.float32).contiguous()
         B, H, W, _ = lc.shape
         if tuple(xc.shape) != (B, H, W, 3):
             raise ValueError(f"discretized_mix_logistic_loss: x must be [B,H,W,3], got {tuple(xc.shape)}")
         st = torch.cuda.current_stream(lc.device).cuda_stream
         part = torch.empty((B, lib.like_chunks(H, W)), dtype=torch.float32, device=lc.device)
-        lib.dmol_nll_fwd(_lib.F32, B, H, W, _cl_view(lc, 100), _cl_view(xc, 3), part.data_ptr(), st)
+        lib.dmol_nll_fwd(ctx.dt, B, H, W, _cl_view(lc, 100), _cl_view(xc, 3), part.data_ptr(), st)
         ctx.save_for_backward(lc, xc)
         return part.sum(1) / float(H * W * 3)
 
@@ -59,17 +60,16 @@ class _DmolLoss(torch.autograd.Function):
         B, H, W, _ = lc.shape
         coef = (g.to(torch.float32) / float(H * W * 3)).contiguous()
         gl = torch.empty_like(lc)
-        lib.dmol_nll_bwd(_lib.F32, B, H, W, _cl_view(lc, 100), _cl_view(xc, 3), coef.data_ptr(), 1, _cl_view(gl, 100),
+        lib.dmol_nll_bwd(ctx.dt, B, H, W, _cl_view(lc, 100), _cl_view(xc, 3), coef.data_ptr(), 1, _cl_view(gl, 100),
                          torch.cuda.current_stream(lc.device).cuda_stream)
-        return gl, None
+        return gl, None, None
 
 
 def discretized_mix_logistic_loss(x, l, low_bit=False):
     """-log p(x) / (H*W*3) per sample for the mixture of discretised logistics (dmol.py:24-118): ``x`` [B,H,W,3] in [-1,1],
-    ``l`` [B,H,W,100].  Differentiable w.r.t. ``l`` (`cgen_dmol_nll_bwd`)."""
-    if low_bit:
-        raise NotImplementedError("low_bit=True (5-bit bins, dmol.py:52-60) is not used by any preset and not built")
-    return _DmolLoss.apply(l, x)
+    ``l`` [B,H,W,100].  Differentiable w.r.t. ``l`` (`cgen_dmol_nll_bwd`).  ``low_bit``: the reference's 5-bit branch (half-bin 1/31,
+    mid-bin fallback log 15.5; dmol.py:52-60, 88-102)."""
+    return _DmolLoss.apply(l, x, bool(low_bit))
 
 
 _FREE_RNG = {}

@@ -345,7 +345,10 @@ int cgen_gauss_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c
                        cgen_view g_params, cgen_stream_t);
 int cgen_gauss_sample(int32_t dtype, int32_t n, int32_t h, int32_t w, int32_t c, cgen_view params, float logt,
                       const uint64_t* rng, uint32_t stream_id, float* x_nchw, float* scale_nchw, cgen_stream_t);
-/* Discretised mixture of logistics, 10 mixtures, 3 channels (dmol.py:24-118, 164-215, 121-161). logits: [.,100] */
+/* Discretised mixture of logistics, 10 mixtures, 3 channels (dmol.py:24-118, 164-215, 121-161). logits: [.,100].
+ * nll_fwd / nll_bwd: dtype may be OR-ed with CGEN_DMOL_LOW_BIT for the reference's low_bit = True branch (5-bit pixels: half-bin
+ * 1/31 and the mid-bin fallback's log 15.5 instead of 1/255 and log 127.5; dmol.py:52-60, 88-102). */
+#define CGEN_DMOL_LOW_BIT 0x100
 int cgen_dmol_nll_fwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, cgen_view x, float* nll_part,
                       cgen_stream_t);
 int cgen_dmol_nll_bwd(int32_t dtype, int32_t n, int32_t h, int32_t w, cgen_view logits, cgen_view x,

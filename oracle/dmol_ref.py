@@ -1,7 +1,7 @@
 """Functional CPU restatement of the reference's discretised mixture of logistics (src/dmol.py)
 -- ORACLE, test-only.
 
-  dmol_nll .......... discretized_mix_logistic_loss, dmol.py:24-118 (8-bit branch)
+  dmol_nll .......... discretized_mix_logistic_loss, dmol.py:24-118 (8-bit and low_bit branches)
   dmol_mean ......... mean_discretized_mix_logistic, dmol.py:164-215 (soft / hard / top-k)
   dmol_sample ....... sample_from_discretized_mix_logistic, dmol.py:121-161
   dmolnet_* ......... DmolNet, dmol.py:218-245
@@ -30,8 +30,9 @@ def _unpack(l):
     return logits, rest[..., :NMIX], rest[..., NMIX:2 * NMIX], rest[..., 2 * NMIX:]
 
 
-def dmol_nll(x, l):
-    """-log p(x) / (H*W*3) per sample (nats/dim), dmol.py:24-118."""
+def dmol_nll(x, l, low_bit=False):
+    """-log p(x) / (H*W*3) per sample (nats/dim), dmol.py:24-118; ``low_bit``: the 5-bit branch (dmol.py:52-60, 88-102)."""
+    hb, scale = (1.0 / 31.0, 15.5) if low_bit else (1.0 / 255.0, 127.5)
     logits, means, ls, co = _unpack(l)
     ls = torch.clamp(ls, min=MIN_LOG_SCALE)
     co = torch.tanh(co)
@@ -42,8 +43,8 @@ def dmol_nll(x, l):
     mu = torch.stack([m_r, m_g, m_b], dim=3)
     d = xe - mu
     inv = torch.exp(-ls)
-    up = inv * (d + 1.0 / 255.0)
-    um = inv * (d - 1.0 / 255.0)
+    up = inv * (d + hb)
+    um = inv * (d - hb)
     delta = torch.sigmoid(up) - torch.sigmoid(um)
     log_cdf_plus = up - F.softplus(up)
     log_one_minus_cdf_min = -F.softplus(um)
@@ -53,7 +54,7 @@ def dmol_nll(x, l):
         xe < -0.999, log_cdf_plus,
         torch.where(xe > 0.999, log_one_minus_cdf_min,
                     torch.where(delta > 1e-5, torch.log(torch.clamp(delta, min=1e-12)),
-                                log_pdf_mid - np.log(127.5))))
+                                log_pdf_mid - np.log(scale))))
     lp = lp.sum(dim=3) + _log_softmax(logits)
     return -1.0 * torch.logsumexp(lp, -1).sum(dim=[1, 2]) / np.prod(x.shape[1:])
 

@@ -253,3 +253,18 @@ def test_dscm_forward_pinned_by_the_reference(tag):
         assert d < 2e-3, (name, d)
         n += 1
     assert n > 50
+
+
+def test_dmol_low_bit_branch():
+    """dmol.py:52-60, 88-102 (low_bit=True: 5-bit pixels) -- oracle vs the reference-made vectors (oracle/make_dmol_lowbit_golden.py),
+    values and gradient; the 8-bit branch on the same inputs gives other numbers."""
+    from oracle import dmol_ref
+
+    d = load_golden("dmol_lowbit.pt")
+    l = d["l"].clone().requires_grad_(True)
+    loss = dmol_ref.dmol_nll(d["x"], l, low_bit=True)
+    torch.testing.assert_close(loss.detach(), d["loss"], rtol=1e-5, atol=1e-6)
+    (g,) = torch.autograd.grad(loss.sum(), l)
+    torch.testing.assert_close(g, d["grad_l"], rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(dmol_ref.dmol_nll(d["x"], d["l"]), d["loss_8bit"], rtol=1e-5, atol=1e-6)
+    assert float((d["loss"] - d["loss_8bit"]).abs().min()) > 1.0
