@@ -1075,14 +1075,16 @@ static inline bool fits_i32(const View& v, int n, int h, int w) {
   return ext * 2 < ((int64_t)1 << 31);
 }
 
-// would launch_conv hand this f16 conv to conv_smallp_kernel?  (the selection of launch_conv + the checks of launch_conv_smallp)
+// does this f16 conv go to conv_smallp_kernel?  THE decision: launch_conv and the pair launch (cgen_conv2d_pair) both ask here, so a
+// paired and an unpaired backward pass cannot pick different kernels
 static bool smallp_takes(const ConvP& p) {
   static const int smallp_maxp = [] { const char* e = getenv("CGEN_SMALLP_MAXP"); return e ? atoi(e) : 6000; }();
   static const int smallp_maxp_longk = [] { const char* e = getenv("CGEN_SMALLP_MAXP_LONGK"); return e ? atoi(e) : 19000; }();
   static const int smallp_longk = [] { const char* e = getenv("CGEN_SMALLP_LONGK"); return e ? atoi(e) : 60; }();
   const bool longk = ceil_div(p.taps * p.ctot8, 32) >= smallp_longk;
   const bool by_size = (p.P <= smallp_maxp || (longk && p.P <= smallp_maxp_longk)) && (p.KS == 1 || p.KS == 3);
-  const bool by_side = (p.H < 5 || p.W < 5) && (p.KS == 1 || p.KS == 3) && !getenv("CGEN_CONV_NO_SMALLP");
+  static const bool no_smallp = getenv("CGEN_CONV_NO_SMALLP") != nullptr;
+  const bool by_side = (p.H < 5 || p.W < 5) && (p.KS == 1 || p.KS == 3) && !no_smallp;
   if (p.force_generic || !(by_size || by_side)) return false;
   for (int s = 0; s < p.nseg; ++s)
     if (!p.seg_vec[s] || !fits_i32(p.seg[s], p.N, p.H + 2, p.W + 2)) return false;
@@ -1125,11 +1127,7 @@ static void conv_trace(const ConvP& p, const char* which) {  // CGEN_CONV_TRACE=
 template <typename T>
 static int launch_conv(const ConvP& p, hipStream_t st) {
   if constexpr (sizeof(T) == 2) {
-    static const int smallp_maxp = [] { const char* e = getenv("CGEN_SMALLP_MAXP"); return e ? atoi(e) : 6000; }();
-    static const int smallp_maxp_longk = [] { const char* e = getenv("CGEN_SMALLP_MAXP_LONGK"); return e ? atoi(e) : 19000; }();
-    static const int smallp_longk = [] { const char* e = getenv("CGEN_SMALLP_LONGK"); return e ? atoi(e) : 60; }();  // K-steps: the 3-segment cat[h,pa,acts] convs at 24x24
-    const bool longk = ceil_div(p.taps * p.ctot8, 32) >= smallp_longk;
-    if ((p.P <= smallp_maxp || (longk && p.P <= smallp_maxp_longk)) && (p.KS == 1 || p.KS == 3) && !p.force_generic && launch_conv_smallp(p, st)) {
+    if (smallp_takes(p) && launch_conv_smallp(p, st)) {  // (few pixels in the batch, or an image side below 5: by size or by side)
       conv_trace(p, "smlp");
       return check_launch("cgen_conv2d(smallp)");
     }
@@ -1149,12 +1147,6 @@ static int launch_conv(const ConvP& p, hipStream_t st) {
   if ((p.KS == 1 || p.KS == 3) && p.H >= 5 && p.W >= 5 && !p.force_generic && p.dma_ok) {
     const bool ok = p.KS == 3 ? launch_conv_tile<T, 3>(p, st) : launch_conv_tile<T, 1>(p, st);
     if (ok) { conv_trace(p, "tile"); return check_launch("cgen_conv2d(tile)"); }
-  }
-  if constexpr (sizeof(T) == 2) {
-    if ((p.H < 5 || p.W < 5) && !p.force_generic && !getenv("CGEN_CONV_NO_SMALLP") && launch_conv_smallp(p, st)) {
-      conv_trace(p, "smlp");
-      return check_launch("cgen_conv2d(smallp)");
-    }
   }
   dim3 block(256);
   const int px_tiles = ceil_div(p.P, CONV_PT);

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void clip_decide_kernel(const float* partial, 
     if (out3) skip = skip || isnan(out3[1]) || isnan(out3[2]);
     state[3] = skip ? 1.f : 0.f;
     if (skip) state[4] += 1.f;
+    if (skip && !(norm <= 3.402823466e38f)) state[6] += 1.f;  // ... of which for a NON-FINITE norm (an f16 overflow: what the loss-scale back-off counts)
   }
 }
 

@@ -1132,8 +1132,23 @@ static void w3_attr_once() {
 
 void wg3_launch_single(const Wg3Plan& g, hipStream_t st) {
   w3_attr_once();
-  static std::atomic<unsigned> next{0};
-  const int slot = (int)(next.fetch_add(1) % W3_SINGLE_SLOTS);  // (a slot is rewritten 512 single launches later; a captured launch keeps its slot)
+  // The record travels through a rotating stash slot.  A CAPTURED launch bakes its slot into the graph and replays it for ever, so
+  // captured launches draw from the upper half of the slots and eager ones from the lower half: an eager launch on another stream can
+  // never overwrite a record between a replaying graph's stash and its kernel.  Graphs keep distinct slots among
+  // themselves until W3_SINGLE_SLOTS / 2 captured single launches are alive (the train step packs its weight gradients into one
+  // batched launch: single launches are the stand-alone C-ABI calls); past that the wrap is reported once.
+  static std::atomic<unsigned> next_eager{0}, next_cap{0};
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cs);
+  constexpr unsigned HALF = W3_SINGLE_SLOTS / 2;
+  int slot;
+  if (cs == hipStreamCaptureStatusActive) {
+    const unsigned k = next_cap.fetch_add(1);
+    if (k == HALF) fprintf(stderr, "cgen: more than %u captured single weight-gradient launches: stash slots of captured graphs are being reused\n", HALF);
+    slot = (int)(HALF + k % HALF);
+  } else {
+    slot = (int)(next_eager.fetch_add(1) % HALF);
+  }
   hipLaunchKernelGGL(wg3_stash_kernel, dim3(1), dim3(64), 0, st, g.q, slot);
   hipLaunchKernelGGL(wg3_mega_kernel, dim3(g.nblocks), dim3(256), g.lds, st, (const Wg3P*)nullptr, (const int4*)nullptr, g.nblocks, slot);
 }

@@ -20,7 +20,7 @@ from ._lib import (F16, NULL_VIEW, ST_AVGPOOL_BWD, ST_AVGPOOL_FWD, ST_AXPBY, ST_
                    ST_UPSAMPLE_BWD, ST_UPSAMPLE_FWD, StageElemArgs, StageReparamArgs, StageReparamBwdArgs)
 
 # entry points that answer on the host and launch nothing
-_PURE = {"version", "last_error", "block3_supported", "stem_conv_supported", "stage_accepts", "stage_plan",
+_PURE = {"version", "last_error", "block3_supported", "block3_pair_supported", "conv2d_pair_supported", "stem_conv_supported", "stage_accepts", "stage_plan",
          "reparam_kl_chunks", "like_chunks", "conv2d_wgrad_plan", "conv2d_wgrad_batch_plan"}
 
 

@@ -154,6 +154,7 @@ class TrainStep:
         # previous step, which is identical on all data-parallel ranks (all-reduced gradient + scalars feed clip_decide).
         self.overflow_backoffs, self._clean_checks, self.ls_growth_interval = 0, 0, 20
         self.ls_check_interval, self._ls_checked_it, self._ls_last_growth_it = 16, 0, None
+        self._ls_nonfinite_seen = 0.0  # state[6] (steps dropped for a non-finite norm) at the previous check
         self.LS_SHIFT_MIN = -16
         self.acc_g = torch.zeros(n, device=dev) if self.accu > 1 else None
 
@@ -506,6 +507,7 @@ class TrainStep:
         self.state.copy_(st)
         self.it = int(extra.get("it", st[5]))
         self._ls_checked_it, self._clean_checks, self._ls_last_growth_it = self.it, 0, None
+        self._ls_nonfinite_seen = 0.0  # (state[6] restarts at zero with the state vector)
         self.overflow_backoffs = int(extra.get("overflow_backoffs", 0))
         self.ls_growth_interval = int(extra.get("ls_growth_interval", self.ls_growth_interval))
         shift = max(self.LS_SHIFT_MIN, min(0, int(extra.get("loss_scale_shift", 0))))
@@ -515,8 +517,8 @@ class TrainStep:
             self.acc_g.copy_(extra["acc_g"])
 
     def _loss_scale_check(self):
-        """Every `ls_check_interval` iterations (f16 engine only): one host read of the device step state.  The last step was
-        dropped for a NON-FINITE gradient norm => an activation gradient left binary16's range: halve the scale (captured graphs
+        """Every `ls_check_interval` iterations (f16 engine only): one host read of the device step state.  A step since the
+        previous check was dropped for a NON-FINITE gradient norm => an activation gradient left binary16's range: halve the scale (captured graphs
         and coefficient tables are rebuilt at this step) instead of dropping every later step as well.  After
         `ls_growth_interval` clean checks the scale is doubled back towards the rule's value; a growth that overflows again
         within one interval doubles that interval (no flapping).  The shift is clamped to [LS_SHIFT_MIN, 0]."""
@@ -524,7 +526,11 @@ class TrainStep:
             return
         self._ls_checked_it = self.it
         s = self.state.cpu().tolist()
-        overflow = bool(s[3]) and not math.isfinite(s[1])
+        # decided from a COUNTER, not from a sample of the last step: state[6] counts the steps dropped for a non-finite
+        # norm; any of the ls_check_interval steps since the previous check having overflowed backs the scale off, and a check only
+        # counts as clean when none did
+        overflow = s[6] > self._ls_nonfinite_seen
+        self._ls_nonfinite_seen = s[6]
         if overflow:
             if self.eng.loss_scale_shift > self.LS_SHIFT_MIN:
                 self._rescale(-1)

@@ -28,7 +28,11 @@ class WgradMixin:
             a.seg[k] = vw(s)
         a.gout = vw(g)
         use = sum(1 for e in self._wg_events if e[0] is site)
-        key = (site.index, use, x0.n, x0.h, x0.w)
+        # (the plan -- kernel, split count, partial LAYOUT -- also depends on how the views are laid out: strides and 16-byte alignment
+        #  decide between the streaming, tiled and generic kernels.  They are part of the key, so a differently laid-out view of the
+        #  same site can never be reduced with a stale layout)
+        lay = tuple((v.sn, v.sh, v.sw, v.c, v.p % 16 if v.p else 0) for v in [a.seg[k] for k in range(len(segs))] + [a.gout])
+        key = (site.index, use, x0.n, x0.h, x0.w, lay)
         ent = self._partials.get(key)
         nw = site.co * site.taps * site.ci
         if ent is None:

@@ -382,7 +382,7 @@ int cgen_cf_pixels(int64_t count, const float* x, const float* rec_loc, const fl
 
 /* ------------------------------------------------------------------ step tail (K17; trainer.py:67-87, utils.py:178-225)
  * Flat-buffer fused global-norm -> clip -> skip predicate -> AdamW -> EMA.
- * state_dev: f32[8] = {sum_sq, grad_norm, clip_coef, skip_flag, n_skipped, opt_steps, -, -}.  LambdaLR warm-up, Adam
+ * state_dev: f32[8] = {sum_sq, grad_norm, clip_coef, skip_flag, n_skipped, opt_steps, n_skipped_nonfinite, -}.  LambdaLR warm-up, Adam
  * bias correction and the EMA warm-up decay are all derived ON DEVICE from opt_steps (successful steps so far), so
  * the host never reads the skip decision (the reference syncs three times per step).
  * out3 (optional) = {elbo, nll, kl}: NaN nll/kl forces a skip as trainer.py:71-74 does. */
