@@ -35,7 +35,7 @@ class Block3Out(C.Structure):
 class Block3Args(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("nseg", C.c_int32),
                 ("nout", C.c_int32), ("pre_act", C.c_int32), ("reserved", C.c_int32), ("seg", View * MAX_SEG),
-                ("w_a", C.c_void_p), ("bias_a", C.c_void_p), ("mid", View), ("mid_aux", View), ("o", Block3Out * 2)]
+                ("w_a", C.c_void_p), ("bias_a", C.c_void_p), ("mid", View), ("mid_aux", View), ("o", Block3Out * 2), ("w_a16", C.c_void_p)]
 
 
 class WgradArgs(C.Structure):
@@ -64,29 +64,6 @@ class AdamwArgs(C.Structure):
                 ("wd", C.c_float), ("ema_beta", C.c_float), ("warmup_steps", C.c_int32), ("ema_update_after", C.c_int32),
                 ("state_dev", C.c_void_p)]
 
-
-class StageElemArgs(C.Structure):
-    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("d", C.c_int32), ("hi", C.c_int32),
-                ("wi", C.c_int32), ("accumulate", C.c_int32), ("c_from", C.c_int32), ("reserved", C.c_int32),
-                ("alpha", C.c_float), ("beta", C.c_float), ("src", C.c_void_p), ("inp", View), ("out", View)]
-
-
-class StageReparamArgs(C.Structure):
-    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("kl_stride", C.c_int32),
-                ("stream_id", C.c_uint32), ("logt", C.c_float),
-                ("q_loc", View), ("q_ls", View), ("p_loc", View), ("p_ls", View), ("eps_in", View), ("z", View),
-                ("rng", C.c_void_p), ("kl_part", C.c_void_p)]
-
-
-class StageReparamBwdArgs(C.Structure):
-    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("coef_stride", C.c_int32),
-                ("acc_q", C.c_int32), ("acc_p", C.c_int32), ("ride_acc", C.c_int32), ("logt", C.c_float),
-                ("q_loc", View), ("q_ls", View), ("p_loc", View), ("p_ls", View), ("z", View), ("gz", View),
-                ("g_q_loc", View), ("g_q_ls", View), ("g_p_loc", View), ("g_p_ls", View), ("ride_src", View), ("ride_dst", View),
-                ("kl_coef_dev", C.c_void_p), ("kl_chan_scale", C.c_void_p)]
-
-
-ST_CONV, ST_AVGPOOL_FWD, ST_AVGPOOL_BWD, ST_UPSAMPLE_FWD, ST_UPSAMPLE_BWD, ST_BCAST, ST_AXPBY, ST_REPARAM_FWD, ST_REPARAM_BWD = range(9)
 
 i32, i64, u32, u64, f32, vp = C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_void_p
 
@@ -158,14 +135,11 @@ PROTOTYPES = {
     "cgen_step_commit": [vp, vp],
     "cgen_philox_normal": [vp, i64, vp, u32, vp],
     "cgen_rng_advance": [vp, u64, vp],
-    "cgen_stage_accepts": [i32, vp],
-    "cgen_stage_plan": [vp, vp, i32, vp, i64, vp, vp],
-    "cgen_stage_run": [vp, i32, i32, i32, vp],
 }
 _RESTYPES = {"cgen_last_error": C.c_char_p}
 ABI_VERSION = 405  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
 _NOCHECK = {"cgen_version", "cgen_h16_format", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks",
-            "cgen_block3_supported", "cgen_block3_pair_supported", "cgen_conv2d_pair_supported", "cgen_stem_conv_supported", "cgen_stage_accepts"}
+            "cgen_block3_supported", "cgen_block3_pair_supported", "cgen_conv2d_pair_supported", "cgen_stem_conv_supported"}
 
 
 class WgradBatchLaunch(C.Structure):

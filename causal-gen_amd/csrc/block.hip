@@ -77,6 +77,9 @@ struct B3P {
   int small, s_rows, s_strips, s_nmb;  // s_nmb: 32-row blocks of the bottleneck (1 or 2)
   int s_mid_off, s_kt_off, s_red_off, s_dbg, s_segk0[3], s_segg[3];  // LDS offsets; first chunk / 16-byte groups per pixel of segment s
   B3Div s_dg1, s_dxw, s_dw, s_dstrips, s_dnb;
+  // row-streaming instance (blk3r): strips of 32 columns x r_rs rows
+  int rows, r_rs, r_sx, r_sy, r_res_tile, r_pad;
+  const char* wA16;  // 16-row image of conv1 ([tap][chunk][lane][8]; cgen_weight_prep modes 6 / 7)
   const char* wA;   // phase-A fragment image [32-row block][chunk][channel half 0..1][tap 0..8][lane][8]
   const float* biasA;
   BV3 mid, mid_aux;  // mid: written (interior pixels): forward t (pre-activation), backward g_t; mid_aux: backward mask source t
@@ -134,6 +137,12 @@ __device__ __forceinline__ void b3_vmwait_rt(const int n) {
 __device__ __forceinline__ void b3_gload_v(h16x8& d, const char* vaddr) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(vaddr) : "memory");
 }
+typedef unsigned int b3_u32x4 __attribute__((ext_vector_type(4)));  // (native vectors: an asm operand cannot be a HIP_vector_type struct)
+typedef unsigned int b3_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void b3_gload_v16(b3_u32x4& d, const char* vaddr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(vaddr) : "memory"); }
+__device__ __forceinline__ void b3_gload_v8(b3_u32x2& d, const char* vaddr) { asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(d) : "v"(vaddr) : "memory"); }
+__device__ __forceinline__ void b3_pin4(b3_u32x4& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void b3_pin2(b3_u32x2& v) { asm volatile("" : "+v"(v)); }
 template <int OFF>
 __device__ __forceinline__ void b3_gload(h16x8& d, const char* sbase, const int voff) {
   asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
@@ -1150,6 +1159,279 @@ __global__ __launch_bounds__(64 * B3S_NW, 4) void blk3s_pair_kernel(B3P pa, B3P 
   blk3s_body<false>(p, second ? (int)blockIdx.x - na : (int)blockIdx.x, second ? (int)gridDim.x - na : na, koff);
 }
 
+// ============================================================================= wide images, narrow channels (96x96, 192x192)
+// The Blocks that carry 42 % of a step's FLOPs are HBM-bound: 32 / 64 channels in, a bottleneck of 8 / 16, 32 / 64 out, one input
+// segment.  As two launches a 192x192 Block moves 264 MB (x, the bottleneck out and back in, x again for the residual, out) in
+// 90 us; the floor of one launch is x + out + the bottleneck once = 170 MB = 27 us.  This instance STREAMS rows:
+//   * a workgroup (8 waves) owns a column strip of 32 output pixels and walks down `rs` rows in bands of four; the input rows it
+//     has seen stay in an LDS ring (four groups of four rows, 36 pixels wide), so only the strip's own border is fetched twice
+//     (36 / 32 columns, (rs + 4) / rs rows), and the residual is read from that ring, not from HBM;
+//   * the rows of band k + 3 are requested (LDS-DMA, untracked) at the top of band k: two to three bands of latency hiding; the one
+//     counted wait of a band sits behind its phase-A MFMAs and in FRONT of its first store, so that no store is ever younger than
+//     a request it has to outlive (a wait that must let stores pass would wait for them);
+//   * phase A: the four NEW bottleneck rows of the band (136 pixels = 9 groups of 16) with v_mfma_f32_16x16x32 -- 16 rows are
+//     exactly the bottleneck -- every wave keeps ALL of conv1's weights in registers for the whole launch (36 / 72 registers), a
+//     B operand is one ds_read_b128 with an immediate offset; the bottleneck rows go into a 16-row LDS ring (+ HBM once);
+//   * phase B: a wave owns one output row of 32 pixels for one 32-channel pair (32x32x16, weights in registers), epilogue from the
+//     accumulators: bias, residual from the input ring / mask and accumulated gradient from HBM, two 16-byte stores per lane.
+// Two barriers per band.  Forward and data gradient (one output) share the body like the tile instance.
+#define B3R_NW 8
+#define B3R_XC 36
+#define B3R_MC 34
+#define B3R_NG 4
+#define B3R_MR 16
+constexpr int b3r_grpb(int nch) { return ((4 * B3R_XC * (nch * 4 + 1) * 16 + 1023) / 1024) * 1024; }  // one ring group: four input rows, whole DMA instructions
+constexpr int b3r_mrowb(int nb) { return B3R_MC * ((nb & 1) ? nb : nb + 1) * 16; }
+constexpr size_t b3r_lds(int nch, int nb) { return (size_t)B3R_NG * b3r_grpb(nch) + (size_t)B3R_MR * b3r_mrowb(nb) + 1024; }
+
+// RES: where the epilogue's added operand comes from -- 0 none, 1 the input ring (forward: the residual IS the input), 2 HBM
+// (forward: another tensor; data gradient: the accumulated gradient)
+template <bool PRE, int NCH, int NB, int RES>
+__global__ __launch_bounds__(64 * B3R_NW, 2) void blk3r_kernel(B3P p) {
+  __builtin_amdgcn_s_setprio(3);
+  constexpr int G1 = NCH * 4 + 1, XS = G1 * 16, ROWB = B3R_XC * XS, GRPB = b3r_grpb(NCH), NINST = GRPB / 1024, IPW = (NINST + B3R_NW - 1) / B3R_NW;
+  constexpr int NBS = (NB & 1) ? NB : NB + 1, MS = NBS * 16, MROWB = B3R_MC * MS;
+  constexpr int KA = 9 * NCH, NKB = (9 * NB + 1) / 2;
+  constexpr bool AUX = !PRE;  // (the data gradient masks its output with the forward input; the forward pass has no mask)
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const X = smem;
+  char* const MID = smem + B3R_NG * GRPB;
+  char* const SCR = MID + B3R_MR * MROWB;  // destination of the DMA instructions a wave issues beyond the group's last (uniform count per wave)
+  const char* const zero = (const char*)g_b3zero;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, W = p.W, bch = p.b;
+  // ---- work item: (image, row strip, column strip)
+  const int item = blockIdx.x;
+  const int sx = item % p.r_sx, t1 = item / p.r_sx, sy = t1 % p.r_sy, n = t1 / p.r_sy;
+  const int x0 = sx * 32, Y0 = sy * p.r_rs, Yend = min(Y0 + p.r_rs, H), nbands = (Yend - Y0 + 3) >> 2;
+  const BV3 sv = p.seg[0];
+  const char* const xin = sv.p + n * sv.sn;
+  // ---- the four input rows of ring group gi (rows Y0 - 2 + 4 gi ..), every wave IPW instructions
+  auto dma_group = [&](const int gi) {
+    const uint32_t gbase = (uint32_t)(uintptr_t)(lds_ptr)(X + (gi & (B3R_NG - 1)) * GRPB);
+    const uint32_t sbase = (uint32_t)(uintptr_t)(lds_ptr)SCR;
+    const int row0 = Y0 - 2 + 4 * gi;
+#pragma unroll
+    for (int t = 0; t < IPW; ++t) {
+      const int ii = wave + B3R_NW * t;
+      const int sl = ii * 64 + lane;
+      const int r = sl / (B3R_XC * G1), rem = sl - r * (B3R_XC * G1), px = rem / G1, g = rem - px * G1;
+      const int iy = row0 + r, ix = x0 - 2 + px;
+      const bool ok = ii < NINST && r < 4 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W && g < G1 - 1;
+      const char* src = ok ? xin + iy * sv.sh + ix * sv.sw + g * 16 : zero;
+      b3_dma16(src, ii < NINST ? gbase + ii * 1024 : sbase);
+    }
+  };
+  dma_group(0);
+  dma_group(1);
+  dma_group(2);  // (a strip of one band never reads it: harmless rows of the image, or zeros)
+  // ---- weights: all of conv1 (16-row fragments, [tap][chunk]) and this wave's pair of conv2, in registers for the launch
+  h16x8 Aw[KA], Bw[NKB];
+  {
+    const char* wa = p.wA16 + lane * 16;
+#pragma unroll
+    for (int s_ = 0; s_ < KA; ++s_) Aw[s_] = *(const h16x8*)(wa + s_ * 1024);
+    const int pair_w = min(wave >> 2, p.o[0].npb - 1);
+    const char* wb = p.o[0].w + (size_t)pair_w * NKB * 1024 + lane * 16;
+#pragma unroll
+    for (int i = 0; i < NKB; ++i) Bw[i] = *(const h16x8*)(wb + i * 1024);
+  }
+  // ---- phase-A lane constants: bottleneck pixel q = 16 g + (lane & 15) of a band's new rows (34 wide), groups wave and wave + 8
+  const int l16 = lane & 15, l4 = lane >> 4;
+  int pr[2], pc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int q = min(16 * (wave + B3R_NW * j) + l16, 4 * B3R_MC - 1);
+    pr[j] = q / B3R_MC; pc[j] = q - pr[j] * B3R_MC;
+  }
+  const int chA = 4 * l4;  // the four bottleneck channels this lane finalises
+  float biasA[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (PRE) {
+    if (p.biasA != nullptr && chA < bch) { const float4 b4 = *(const float4*)(p.biasA + chA); biasA[0] = b4.x; biasA[1] = b4.y; biasA[2] = b4.z; biasA[3] = b4.w; }
+  }
+  // ---- phase-B roles: wave = (pair, output row of the band); lane = (pixel of the row, 16-channel half)
+  const B3Out& O = p.o[0];
+  const int npb = O.npb, Co = O.Co;
+  const int pairB = wave >> 2, rB = wave & 3;
+  const bool jobB = pairB < npb;
+  const int pxB = lane & 31, kgB = lane >> 5;
+  const int ch0 = pairB * 32 + 16 * kgB;
+  // K16-step i: this lane half reads 8-channel group u = 2 i + kg of (tap, bottleneck group): static per lane
+  int koff[NKB], kty[NKB];
+#pragma unroll
+  for (int i = 0; i < NKB; ++i) {
+    const int u = 2 * i + kgB, tp = min(u / NB, 8), gq = u - (u / NB) * NB;
+    kty[i] = tp / 3;
+    koff[i] = (pxB + tp % 3) * MS + gq * 16;
+  }
+  float biasB[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) biasB[e] = 0.f;
+  if (jobB && O.bias != nullptr) {
+#pragma unroll
+    for (int e = 0; e < 16; e += 4)
+      if (ch0 + e < Co) { const float4 b4 = *(const float4*)(O.bias + ch0 + e); biasB[e] = b4.x; biasB[e + 1] = b4.y; biasB[e + 2] = b4.z; biasB[e + 3] = b4.w; }
+  }
+  // Everything loaded so far is in its registers BEFORE the band loop, as far as the compiler is concerned too: a load it still
+  // considers pending inside the loop would be waited for there with a small vmcnt -- a drain of the requests in flight, per band
+  B3_VMWAIT();
+#pragma unroll
+  for (int s_ = 0; s_ < KA; ++s_) b3_pin(Aw[s_]);
+#pragma unroll
+  for (int i = 0; i < NKB; ++i) b3_pin(Bw[i]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) asm volatile("" : "+v"(biasA[e]));
+#pragma unroll
+  for (int e = 0; e < 16; ++e) asm volatile("" : "+v"(biasB[e]));
+  B3_BARRIER();
+
+  // The loads of a band that are not DMA (data gradient: the forward bottleneck under this lane's two bottleneck pixels, the forward
+  // input under its output pixel, the accumulated gradient) are UNTRACKED too, requested at the top of the band in front of the
+  // DMA request: the band's one counted wait -- "only the DMA request just issued may be in flight" -- covers them, and the compiler
+  // never puts a wait of its own into the loop.
+  b3_u32x2 tm[2];
+  b3_u32x4 ea[2], er[2];
+  tm[0] = tm[1] = (b3_u32x2){0u, 0u};
+  ea[0] = ea[1] = er[0] = er[1] = (b3_u32x4){0u, 0u, 0u, 0u};
+  auto band_loads = [&](const int m0, const int nrow, const int y) {
+    if constexpr (!PRE) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = m0 + pr[j], col = x0 - 1 + pc[j];
+        const bool ok = 16 * (wave + B3R_NW * j) + l16 < nrow * B3R_MC && (unsigned)m < (unsigned)H && (unsigned)col < (unsigned)W && chA < bch;
+        b3_gload_v8(tm[j], ok ? p.mid_aux.p + (n * p.mid_aux.sn + m * p.mid_aux.sh + col * p.mid_aux.sw) + chA * 2 : zero);
+      }
+    }
+    if constexpr (AUX || RES == 2) {
+      const int ox = x0 + pxB;
+#pragma unroll
+      for (int q8 = 0; q8 < 2; ++q8) {
+        const bool ok = jobB && y >= 0 && y < Yend && ox < W && ch0 + 8 * q8 < Co;
+        if constexpr (AUX) b3_gload_v16(ea[q8], ok ? O.aux.p + (n * O.aux.sn + y * O.aux.sh + ox * O.aux.sw) + ch0 * 2 + 16 * q8 : zero);
+        if constexpr (RES == 2) b3_gload_v16(er[q8], ok ? O.res.p + (n * O.res.sn + y * O.res.sh + ox * O.res.sw) + ch0 * 2 + 16 * q8 : zero);
+      }
+    }
+  };
+  // bottleneck rows m0 .. m0 + nrow - 1 (nrow = 2: the strip's first two; 4: a band's); WAIT: the counted wait of the band, behind
+  // the MFMAs and in front of the first store (0: everything; 1: all but the DMA request just issued)
+  auto phaseA = [&](const int m0, const int nrow, const int WAIT) {
+    const int npix = nrow * B3R_MC;
+    f32x4_t acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      const int g = wave + B3R_NW * j;
+      if (16 * g >= npix) continue;
+      const int m = m0 + pr[j];
+      // input row (m - 1 + ty) -> ring group / row in group
+      int rowoff[3];
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) {
+        const int rel = m - 1 + ty - (Y0 - 2);
+        rowoff[ty] = ((rel >> 2) & (B3R_NG - 1)) * GRPB + (rel & 3) * ROWB;
+      }
+      const char* const xb = X + pc[j] * XS + l4 * 16;
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+        for (int tx = 0; tx < 3; ++tx)
+#pragma unroll
+          for (int q = 0; q < NCH; ++q) {
+            h16x8 bq = *(const h16x8*)(xb + rowoff[ty] + tx * XS + q * 64);
+            if constexpr (PRE) bq = b3_relu8(bq);
+            acc[j] = mfma_h16(Aw[(ty * 3 + tx) * NCH + q], bq, acc[j], 0, 0, 0);
+          }
+    }
+    if (WAIT) b3_vmwait<IPW>(); else b3_vmwait<0>();
+    if constexpr (!PRE) { b3_pin2(tm[0]); b3_pin2(tm[1]); }
+    if constexpr (AUX) { b3_pin4(ea[0]); b3_pin4(ea[1]); }
+    if constexpr (RES == 2) { b3_pin4(er[0]); b3_pin4(er[1]); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int g = wave + B3R_NW * j;
+      if (16 * g + l16 >= npix || chA >= bch) continue;
+      const int m = m0 + pr[j], col = x0 - 1 + pc[j];
+      const bool in_img = (unsigned)m < (unsigned)H && (unsigned)col < (unsigned)W;
+      const bool own = in_img && m >= Y0 && m < Yend && pc[j] >= 1 && pc[j] <= 32;
+      float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+      uint2 o, ol;
+      if constexpr (PRE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += biasA[e];
+        o.x = f2h_pk(v[0], v[1]); o.y = f2h_pk(v[2], v[3]);
+        union { uint2 u; s16x2v s[2]; } r;
+        r.u = o;
+        r.s[0] = __builtin_elementwise_max(r.s[0], (s16x2v){0, 0});
+        r.s[1] = __builtin_elementwise_max(r.s[1], (s16x2v){0, 0});
+        ol = r.u;
+      } else {
+        v[0] = h_lo(tm[j].x) > 0.f ? v[0] : 0.f; v[1] = h_hi(tm[j].x) > 0.f ? v[1] : 0.f;
+        v[2] = h_lo(tm[j].y) > 0.f ? v[2] : 0.f; v[3] = h_hi(tm[j].y) > 0.f ? v[3] : 0.f;
+        o.x = f2h_pk(v[0], v[1]); o.y = f2h_pk(v[2], v[3]);
+        ol = o;
+      }
+      if (own) *(uint2*)((char*)p.mid.p + (n * p.mid.sn + m * p.mid.sh + col * p.mid.sw) + chA * 2) = o;
+      *(uint2*)(MID + (m & (B3R_MR - 1)) * MROWB + pc[j] * MS + chA * 2) = in_img ? ol : make_uint2(0, 0);
+    }
+  };
+  // ---- prologue: the strip's first two bottleneck rows
+  band_loads(Y0 - 1, 2, -1);
+  phaseA(Y0 - 1, 2, 0);
+  for (int k = 0; k < nbands; ++k) {
+    const int Y = Y0 + 4 * k, y = Y + rB;
+    B3_BARRIER();            // everyone is through band k - 1: the group the next request overwrites is free, the two new rows above are visible
+    band_loads(Y + 1, 4, y);
+    dma_group(k + 3);        // (past the strip's last group: rows nobody reads -- the count of requests stays the same)
+    phaseA(Y + 1, 4, 1);     // ... group k + 2 has landed (this wave's pieces): only the request just issued may still be in flight
+    B3_BARRIER();            // the band's bottleneck rows, and everyone's pieces of group k + 2
+    if (jobB) {
+      const int ox = x0 + pxB;
+      const bool ev = y < Yend && ox < W;
+      int rowb[3];
+#pragma unroll
+      for (int ty = 0; ty < 3; ++ty) rowb[ty] = ((y - 1 + ty) & (B3R_MR - 1)) * MROWB;
+      f32x16 c;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) c[e] = biasB[e];
+#pragma unroll
+      for (int i = 0; i < NKB; ++i) {
+        const int rb = kty[i] == 0 ? rowb[0] : (kty[i] == 1 ? rowb[1] : rowb[2]);
+        const h16x8 bq = *(const h16x8*)(MID + rb + koff[i]);
+        c = b3_mfma(Bw[i], bq, c);
+      }
+      if constexpr (RES == 1) {  // the residual is the input: pixel (y, ox) of the ring, raw (the ReLU was applied to the fragments)
+        const int rel = y - (Y0 - 2);
+        const char* rp = X + ((rel >> 2) & (B3R_NG - 1)) * GRPB + (rel & 3) * ROWB + (pxB + 2) * XS + (ch0 >> 3) * 16;
+        er[0] = *(const b3_u32x4*)rp;
+        er[1] = *(const b3_u32x4*)(rp + 16);
+      }
+#pragma unroll
+      for (int q8 = 0; q8 < 2; ++q8) {
+        if (!(ev && ch0 + 8 * q8 < Co)) continue;
+        float u[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u[e] = c[8 * q8 + e];
+        if constexpr (AUX) {
+          const uint32_t w[4] = {ea[q8].x, ea[q8].y, ea[q8].z, ea[q8].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            u[2 * e] = h_lo(w[e]) > 0.f ? u[2 * e] : 0.f;
+            u[2 * e + 1] = h_hi(w[e]) > 0.f ? u[2 * e + 1] : 0.f;
+          }
+        }
+        if constexpr (RES != 0) {
+          const uint32_t w[4] = {er[q8].x, er[q8].y, er[q8].z, er[q8].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { u[2 * e] += h_lo(w[e]); u[2 * e + 1] += h_hi(w[e]); }
+        }
+        *(uint4*)((char*)O.out.p + (n * O.out.sn + y * O.out.sh + ox * O.out.sw) + ch0 * 2 + 16 * q8) = b3_pack8(u);
+      }
+    }
+  }
+  B3_VMWAIT();  // (requests past the strip's last band: nothing may land after the wave has ended)
+}
+
 // ----------------------------------------------------------------------------- host side
 static bool b3_view(const cgen_view& v, int n, int h, int w, BV3& o) {
   o.p = (const char*)v.p; o.sn = o.sh = o.sw = 0;
@@ -1208,6 +1490,33 @@ static int b3_fill(const cgen_block3_args* a, B3P& p) {
     if ((s.aux.p && s.aux.c != s.out.c) || (s.res1.p && s.res1.c != s.out.c)) return 0;
     if (o == 0 && s.out.c > 224 && !p.small) return 0;  // (lanes 8 .. 63 of the bias DMA instruction: 56 x 4 channels)
     if (o > 0 && s.bias) return 0;  // (only the first output's bias has an LDS copy: the forward pass has one output)
+  }
+  {  // row-streaming instance (blk3r)
+    static const int rows_on = [] { const char* e = getenv("CGEN_BLK3R"); return e ? atoi(e) : 1; }();
+    const int c0 = a->seg[0].c, co0 = a->o[0].out.c;
+    p.rows = (rows_on && !p.small && a->w_a16 && a->nseg == 1 && a->nout == 1 && (c0 == 32 || c0 == 64) && (p.b == 8 || p.b == 16)
+              && (co0 == 32 || co0 == 64) && a->w >= 48 && a->h >= 16 && !a->o[0].out_rem && !a->o[0].res1_rem
+              && ((uintptr_t)a->w_a16 % 16) == 0) ? 1 : 0;
+    if (p.rows) {
+      p.wA16 = (const char*)a->w_a16;
+      p.r_sx = ceil_div(p.W, 32);
+      // strip height: whole bands of four rows; the cheapest (rounds of resident workgroups) x (rows + the prologue's worth)
+      const int slots = 256;  // (one workgroup of eight waves per CU: 160-215 registers)
+      long best = -1;
+      for (int rs = 8; rs < p.H + 4; rs += 4) {
+        const int rsc = rs > p.H ? ((p.H + 3) & ~3) : rs;
+        const long wgs = (long)p.N * p.r_sx * ceil_div(p.H, rsc), cost = (long)ceil_div(wgs, slots) * (rsc + 16);
+        if (best < 0 || cost < best) { best = cost; p.r_rs = rsc; }
+      }
+      { static const int rs_env = [] { const char* e = getenv("CGEN_BLK3R_RS"); return e ? atoi(e) : 0; }(); if (rs_env >= 4) p.r_rs = std::min((rs_env + 3) & ~3, (p.H + 3) & ~3); }
+      p.r_sy = ceil_div(p.H, p.r_rs);
+      p.ntiles = p.N * p.r_sx * p.r_sy;
+      const cgen_view& rv = a->o[0].res1;
+      p.r_res_tile = (a->pre_act && rv.p && rv.p == a->seg[0].p && rv.sn == a->seg[0].sn && rv.sh == a->seg[0].sh && rv.sw == a->seg[0].sw && co0 == c0) ? 1 : 0;
+      p.stamps = nullptr;
+      { static const int dbg = [] { const char* e = getenv("CGEN_BLK3R_DBG"); return e ? atoi(e) : 0; }(); p.s_dbg = dbg; }  // (unused)
+      return 2;
+    }
   }
   if (p.small) {
     int R = 64 / p.W - 2;
@@ -1343,6 +1652,7 @@ static void b3_pair_nb(const B3P& pa, const B3P& pb, const B3Launch& La, const B
 static int b3_pair_plan(const cgen_block3_args* a, const cgen_block3_args* b, B3P& pa, B3P& pb, B3Launch& La, B3Launch& Lb) {
   if (!a || !b || a->pre_act || b->pre_act || !a->mid_aux.p || !b->mid_aux.p) return 0;
   if (!b3_fill(a, pa) || !b3_fill(b, pb)) return 0;
+  if (pa.rows || pb.rows) return 0;
   if (pa.small || pb.small) {
     La.grid = pa.ntiles; Lb.grid = pb.ntiles;
     La.lds = b3s_lds(pa); Lb.lds = b3s_lds(pb);
@@ -1396,6 +1706,24 @@ extern "C" int cgen_block3(const cgen_block3_args* a, cgen_stream_t stream) {
   B3P p;
   CGEN_REQUIRE(b3_fill(a, p), "cgen_block3: shape / layout not served by the fused Block kernel (ask cgen_block3_supported first)");
   CGEN_REQUIRE((a->pre_act != 0) == (a->mid_aux.p == nullptr), "cgen_block3: pre_act = 1 is the forward pass (no mid_aux), pre_act = 0 the data gradient (mid_aux = the forward mid)");
+  if (p.rows) {
+    const int nch = a->seg[0].c / 32, nb = p.b / 8;
+    const size_t lds = b3r_lds(nch, nb);
+#define B3R_LAUNCH(PRE_, NCH_, NB_, RES_) do { (void)hipFuncSetAttribute((const void*)blk3r_kernel<PRE_, NCH_, NB_, RES_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((blk3r_kernel<PRE_, NCH_, NB_, RES_>), dim3(p.ntiles), dim3(64 * B3R_NW), lds, (hipStream_t)stream, p); } while (0)
+#define B3R_RES(PRE_, NCH_, NB_) do { if (res_mode == 0) B3R_LAUNCH(PRE_, NCH_, NB_, 0); else if (res_mode == 1) B3R_LAUNCH(PRE_, NCH_, NB_, 1); else B3R_LAUNCH(PRE_, NCH_, NB_, 2); } while (0)
+#define B3R_RES_BWD(NCH_, NB_) do { if (res_mode == 0) B3R_LAUNCH(false, NCH_, NB_, 0); else B3R_LAUNCH(false, NCH_, NB_, 2); } while (0)
+    const int res_mode = !a->o[0].res1.p ? 0 : (p.r_res_tile ? 1 : 2);
+    if (a->pre_act) { if (nch == 1) { if (nb == 1) B3R_RES(true, 1, 1); else B3R_RES(true, 1, 2); } else { if (nb == 1) B3R_RES(true, 2, 1); else B3R_RES(true, 2, 2); } }
+    else { if (nch == 1) { if (nb == 1) B3R_RES_BWD(1, 1); else B3R_RES_BWD(1, 2); } else { if (nb == 1) B3R_RES_BWD(2, 1); else B3R_RES_BWD(2, 2); } }
+#undef B3R_RES
+#undef B3R_RES_BWD
+#undef B3R_LAUNCH
+    static const bool trace_r = getenv("CGEN_CONV_TRACE") != nullptr;
+    if (trace_r) fprintf(stderr, "blk3r[%s] %dx%dx%d c %d b %d Co %d | strips %d x %d of %d rows, grid %d, lds %zu, residual from the tile %d\n", a->mid_aux.p ? "bwd" : "fwd", a->n, a->h, a->w,
+                         a->seg[0].c, p.b, p.o[0].Co, p.r_sx, p.r_sy, p.r_rs, p.ntiles, lds, p.r_res_tile);
+    return check_launch("cgen_block3(rows)");
+  }
   if (p.small) {
     const size_t lds = b3s_lds(p);
     if (a->pre_act) {

@@ -2568,6 +2568,20 @@ __global__ __launch_bounds__(256) void wprep_kernel(const cgen_wprep_desc* descs
   int ctot8 = 0;
   if (d.mode == 0) { for (int s = 0; s < d.nseg; ++s) ctot8 += (d.seg_c[s] + 7) & ~7; }
   else ctot8 = (d.co + 7) & ~7;
+  if (d.mode >= 6) {  // 16-row images of the row-streaming Block instance: frag = tap * chunks + q (k_pad = chunks)
+    for (int i = threadIdx.x; i < MT_CHUNK; i += 256) {
+      const int64_t o = base + i;
+      if (o >= d.numel) break;
+      const int frag = (int)(o >> 9), w = (int)(o & 511), ln = w >> 3, e = w & 7;
+      const int row = ln & 15, kc = 8 * (ln >> 4) + e;
+      const int tap = (int)((uint32_t)frag / (uint32_t)d.k_pad), q = frag - tap * d.k_pad, c = 32 * q + kc;
+      float v = 0.f;
+      if (d.mode == 6) { if (row < d.co && c < d.ci_total) v = d.src[((int64_t)row * d.ci_total + c) * 9 + tap]; }
+      else if (row < d.ci_total && c < d.co) v = d.src[((int64_t)c * d.ci_total + row) * 9 + (8 - tap)];
+      ((h16_t*)d.dst)[o] = f2h(v);
+    }
+    return;
+  }
   if (d.mode >= 2) {  // fragment-ordered images of the fused Block kernel (csrc/block.hip; layout in include/cgen_hip.h)
     for (int i = threadIdx.x; i < MT_CHUNK; i += 256) {
       const int64_t o = base + i;

@@ -16,7 +16,6 @@ import math
 import torch
 
 from . import _lib
-from .stage import StagedLib, StageMixin
 from .wgrad_sched import WgradMixin
 from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, F16, F32, F32S, NULL_VIEW, UNARY_CLAMP_MIN, UNARY_LEAKY_RELU, View
 
@@ -197,6 +196,8 @@ class ConvSite:
             nks = (9 * b + 15) // 16
             # (segments in whole 32-channel chunks; one image per 32-row block of the bottleneck: widths above 32 are the small-image instance's)
             self.frag_numel["a_fwd"] = _ceil(b, 32) // 32 * sum(_ceil(c, 32) // 32 for c in self.seg_c) * 18 * 512
+            if len(self.seg_c) == 1 and b <= 16 and self.seg_c[0] % 32 == 0 and self.seg_c[0] <= 64:
+                self.frag_numel["a16_fwd"] = 9 * (self.seg_c[0] // 32) * 512  # (the row-streaming instance: 16-row image, modes 6 / 7)
             for k, (c, rg) in enumerate(zip(self.seg_c, self.seg_rg)):
                 if rg:
                     self.frag_numel[("b_dg", k)] = _ceil(c, 32) // 32 * nks * 512
@@ -205,15 +206,16 @@ class ConvSite:
             nks = (9 * b + 15) // 16
             self.frag_numel["b_fwd"] = _ceil(self.co, 32) // 32 * nks * 512
             self.frag_numel["a_dg"] = _ceil(b, 32) // 32 * (_ceil(_ceil(self.co, 8), 32) // 32) * 18 * 512
+            if b <= 16 and self.co % 32 == 0 and self.co <= 64:
+                self.frag_numel["a16_dg"] = 9 * (self.co // 32) * 512
 
 
-class Engine(StageMixin, WgradMixin):
+class Engine(WgradMixin):
     CHUNK = 1024  # elements per block of the multi-tensor kernels (MT_CHUNK in conv.hip)
 
     def __init__(self, device, dtype="f32"):
         rawlib = _lib.require_gpu()
-        # every launch goes through this proxy: ops at staged resolutions are collected into per-image op lists (stage.py)
-        self.lib = StagedLib(rawlib, self)
+        self.lib = rawlib
         self.device = torch.device(device)
         assert self.device.type == "cuda"
         if self.device.index is None:
@@ -335,6 +337,9 @@ class Engine(StageMixin, WgradMixin):
         self.blk3_minres = int(os.environ.get("CGEN_BLK3_MINRES", "16"))
         # images up to 14 pixels wide (12x12, 6x6): the small-image instance of cgen_block3, one launch per Block there too
         self.blk3_small = int(os.environ.get("CGEN_BLK3S", "1"))
+        # the row-streaming instance (96x96 / 192x192 Blocks, csrc/block.hip blk3r): CGEN_BLK3R=0 off; where it serves a shape the side
+        # policy below (blk3_res) does not apply
+        self.blk3_rows = int(os.environ.get("CGEN_BLK3R", "1"))
         # ... at which image sides: CGEN_BLK3_RES for Blocks with one or two input segments (trunk / prior / down Blocks),
         # CGEN_BLK3_RES3 for three-segment Blocks (the posterior: cat[h, pa, acts]); a comma list of sides and lo-hi ranges,
         # "0" = every side >= CGEN_BLK3_MINRES.  Defaults = where the fused launch beats the two it replaces INSIDE the step on MI355X
@@ -349,7 +354,6 @@ class Engine(StageMixin, WgradMixin):
         self.split_frac = float(os.environ.get("CGEN_DP_SPLIT_FRAC", "0.8"))
         self.on_split = None
         self.early_final = None
-        self._stage_init(rawlib)
 
     @property
     def trunk_rem(self):
@@ -380,7 +384,6 @@ class Engine(StageMixin, WgradMixin):
     # ------------------------------------------------------------------ memory
     def begin(self):
         """Start a new step/pass: recycle the arena, clear the tape and gradient bookkeeping."""
-        self.stage_flush()
         self.generation = getattr(self, "generation", 0) + 1  # a recorded pass is only valid within its generation
         self.kl_coef_override = None
         self.arena.reset()
@@ -470,19 +473,14 @@ class Engine(StageMixin, WgradMixin):
         """engine tensor -> torch tensor of NCHW *shape* in channels-last memory (zero-copy view of a clone)."""
         t = torch.empty((x.n, x.h, x.w, x.c), dtype=self.tdtype, device=self.device)
         dst = self.wrap_nhwc(t)
-        # `t` leaves the engine: the copy must be ON the stream before the caller can read -- or FREE -- it (a deferred stage
-        # op would write into memory torch may have handed to somebody else by then), and its address is not stable
-        # across passes: never part of a stage list
-        self.stage_flush()
-        self._rawlib.axpby(self.dt, x.n, x.h, x.w, x.cv(), dst.cv(), 1.0, 1.0, 1 << 30, 0, self.stream)
+        self.lib.axpby(self.dt, x.n, x.h, x.w, x.cv(), dst.cv(), 1.0, 1.0, 1 << 30, 0, self.stream)
         self.launches += 1
         return t.permute(0, 3, 1, 2)
 
     def copy_in(self, x):
-        """Arena copy of a tensor that lives in torch-allocated memory (stable addresses for the stage op lists)."""
+        """Arena copy of a tensor that lives in torch-allocated memory."""
         out = self.new(x.n, x.h, x.w, x.c, rg=False)
-        self.stage_flush()
-        self._rawlib.axpby(self.dt, x.n, x.h, x.w, x.cv(), out.cv(), 1.0, 1.0, 1 << 30, 0, self.stream)
+        self.lib.axpby(self.dt, x.n, x.h, x.w, x.cv(), out.cv(), 1.0, 1.0, 1 << 30, 0, self.stream)
         self.launches += 1
         return out
 
@@ -586,6 +584,10 @@ class Engine(StageMixin, WgradMixin):
                     d.mode, d.k_pad = 2, sum(_ceil(c, 32) // 32 for c in s.seg_c) * 18
                 elif key == "a_dg":
                     d.mode, d.k_pad = 3, _ceil(_ceil(s.co, 8), 32) // 32 * 18
+                elif key == "a16_fwd":
+                    d.mode, d.k_pad = 6, s.seg_c[0] // 32
+                elif key == "a16_dg":
+                    d.mode, d.k_pad = 7, s.co // 32
                 elif key == "b_fwd":
                     d.mode, d.k_pad = 4, (9 * s.ci + 15) // 16
                 else:
@@ -630,7 +632,6 @@ class Engine(StageMixin, WgradMixin):
             self.launches += 1
             self._pnhwc[id(p)] = ptr
             if self._in_side:
-                self.stage_flush()
                 # created lazily inside a side-stream section, cached for everybody: the main stream must not read it before
                 # this conversion has run (found by tools/fuzz_model.py: two concurrent replays sharing the decoder biases)
                 torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)
@@ -704,18 +705,22 @@ class Engine(StageMixin, WgradMixin):
         x0 = segs[0]
         res_ok = self.blk3_res3 if len(segs) >= 3 else self.blk3_res
         small = self.blk3_small and x0.w <= 14 and x0.h <= 64 and min(x0.h, x0.w) >= 4  # (the small-image instance: csrc/block.hip blk3s)
+        tile_ok = (min(x0.h, x0.w) >= self.blk3_minres and site1.co <= 32
+                   and (not res_ok or any(lo <= x0.h <= hi for lo, hi in res_ok)))
+        # the row-streaming instance (blk3r: 96x96 / 192x192, one segment): taken where the kernel says it serves the shape with it,
+        # whatever the side policy of the tile instance says
+        rows = (self.blk3_rows and len(segs) == 1 and "a16_fwd" in site1.frag and "a16_dg" in site2.frag and x0.w >= 48 and x0.h >= 16
+                and not (trunk and self.trunk_rem))
         if (self.blk3_on and act == ACT_RELU and "a_fwd" in site1.frag and "b_fwd" in site2.frag and len(segs) <= 3
-                and site1.co % 8 == 0 and site2.co % 8 == 0 and not self.stage_covers(x0.h)
-                and ((small and site1.co <= 64) or
-                     (min(x0.h, x0.w) >= self.blk3_minres and site1.co <= 32
-                      and (not res_ok or any(lo <= x0.h <= hi for lo, hi in res_ok))))):
-            out = self._block3_fwd(site1, site2, segs, res1, trunk)
+                and site1.co % 8 == 0 and site2.co % 8 == 0
+                and ((small and site1.co <= 64) or tile_ok or rows)):
+            out = self._block3_fwd(site1, site2, segs, res1, trunk, need_rows=rows and not tile_ok and not small)
             if out is not None:
                 return out
         t = self.conv(site1, segs, act)
         return self.conv(site2, [t], act, res1=res1, trunk=trunk)
 
-    def _block3_fwd(self, site1, site2, segs, res1, trunk=False):
+    def _block3_fwd(self, site1, site2, segs, res1, trunk=False, need_rows=False):
         """One launch of cgen_block3 for a light Block (forward); None when the kernel declines the layout.  A residual-trunk Block
         of a pass with remainder planes (section 1a) reads res1 as hi + rem and writes out as rn16(v), rn16(v - out), like conv()."""
         x0 = segs[0]
@@ -725,6 +730,7 @@ class Engine(StageMixin, WgradMixin):
             a.seg[k] = sg.cv()
         b1, b2 = site1.conv.bias, site2.conv.bias
         a.w_a, a.bias_a = site1.frag["a_fwd"], (b1.data_ptr() if b1 is not None else None)
+        a.w_a16 = site1.frag.get("a16_fwd") if self.blk3_rows else None
         t = self.new(x0.n, x0.h, x0.w, site1.co)
         out = self.new(x0.n, x0.h, x0.w, site2.co, rem=trunk and self.trunk_rem and max(x0.h, x0.w) <= self.trunk_maxres)
         a.mid, a.mid_aux = t.cv(), NULL_VIEW
@@ -732,7 +738,8 @@ class Engine(StageMixin, WgradMixin):
         o.w, o.bias = site2.frag["b_fwd"], (b2.data_ptr() if b2 is not None else None)
         o.out, o.aux, o.res1 = out.cv(), NULL_VIEW, (res1.cv() if res1 is not None else NULL_VIEW)
         o.out_rem, o.res1_rem = out.rem, (res1.rem if res1 is not None else 0)
-        if not self.lib.block3_supported(C.byref(a)):
+        sup = self.lib.block3_supported(C.byref(a))
+        if not sup or (need_rows and sup != 2):  # (2: the row-streaming instance serves it)
             return None  # (the two tensors just allocated are simply not used: the arena is reset per step)
         if self._ablate and any(x0.h == r and ("r%d" % r) in self._ablate for r in (24, 48, 96, 192)):
             pass
@@ -765,6 +772,7 @@ class Engine(StageMixin, WgradMixin):
             probe.dtype, probe.n, probe.h, probe.w, probe.nseg, probe.nout, probe.pre_act = self.dt, g.n, g.h, g.w, 1, len(dsegs), 0
             probe.seg[0] = g.cv()
             probe.w_a, probe.bias_a = site2.frag["a_dg"], None
+            probe.w_a16 = site2.frag.get("a16_dg") if self.blk3_rows else None
             probe.mid, probe.mid_aux = t.cv(), t.cv()
             for j, k in enumerate(dsegs):
                 sg = segs[k]
@@ -787,6 +795,7 @@ class Engine(StageMixin, WgradMixin):
         a.dtype, a.n, a.h, a.w, a.nseg, a.nout, a.pre_act = self.dt, g.n, g.h, g.w, 1, len(dsegs), 0
         a.seg[0] = g.cv()
         a.w_a, a.bias_a = site2.frag["a_dg"], None
+        a.w_a16 = site2.frag.get("a16_dg") if self.blk3_rows else None
         a.mid, a.mid_aux = gt.cv(), t.cv()
         tgt = []
         for j, k in enumerate(dsegs):
@@ -851,16 +860,9 @@ class Engine(StageMixin, WgradMixin):
             return fn()
         ci = site.ci if ci is None else ci
         flops = 2.0 * ci * site.taps * site.co * x0.n * x0.h * x0.w
-        if not self.stage_covers(x0.h):
-            self.stage_flush()  # (so that a pending list is not launched -- and timed -- inside this conv's event pair)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        self._stage_deferred = False
         fn()
-        if self._stage_deferred:
-            # deferred into a stage list: its time is that of the list's launch (stage_flush tallies the list's FLOPs)
-            self._stage_flops[kind] = self._stage_flops.get(kind, 0.0) + flops
-            return
         e1.record()
         key = (kind, site.ks, ci, site.co, x0.h)
         ent = self.prof.setdefault(key, [0.0, [], 0])
@@ -1015,7 +1017,7 @@ class Engine(StageMixin, WgradMixin):
         self.launches += 1
 
     # ------------------------------------------------------------------ gradient bookkeeping
-    def _geom(self, ks, ts, stageable=True):
+    def _geom(self, ks, ts):
         """Launch geometry (n, h, w) and the view constructor for a conv over tensors `ts` (None entries allowed).
         A 1x1 conv does not care about the spatial structure: on tiny images (< 5x5, where the tiled kernels do not apply)
         pixel-contiguous tensors are presented as ONE image of 16-pixel rows, [1, P/16, 16, C], which the tiled /
@@ -1023,8 +1025,6 @@ class Engine(StageMixin, WgradMixin):
         t0 = next(t for t in ts if t is not None)
         n, h, w = t0.n, t0.h, t0.w
         P = n * h * w
-        if stageable and self.stage_covers(h):  # (the stage interpreter works per image: keep the real geometry)
-            return n, h, w, (lambda t: NULL_VIEW if t is None else t.cv())
         if ks == 1 and h * w < 25 and P % 16 == 0 and P >= 256 and all(
                 t is None or (t.sh == t.w * t.sw and t.sn == t.h * t.sh) for t in ts):
             return 1, P // 16, 16, (lambda t: NULL_VIEW if t is None else View(t.ptr, P * t.sw, 16 * t.sw, t.sw, t.c, t.cpad))
@@ -1150,7 +1150,6 @@ class Engine(StageMixin, WgradMixin):
         twice per decoder layer, ~11 us each (LABNOTES 9.7)."""
         if not self.fwd_branch or self.prof is not None:
             return None
-        self.stage_flush()
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         return ev
@@ -1159,7 +1158,6 @@ class Engine(StageMixin, WgradMixin):
         """Returns True when a side stream is available; everything enqueued so far (up to the mark `after`) is visible to it."""
         if not self.fwd_branch or self.prof is not None:
             return False
-        self.stage_flush()
         if self._fwd_side is None:
             self._fwd_side = torch.cuda.Stream(self.device)
         if after is not None:
@@ -1171,7 +1169,6 @@ class Engine(StageMixin, WgradMixin):
     def on_side(self, fn, bw=0):
         """Run `fn()` with every launch going to the side stream.  `bw` = 1: the backward of what fn records belongs to the side
         strand of backward() too (see _bw_tag)."""
-        self.stage_flush()
         old, old_tag = self.stream, self._bw_tag
         self.stream = self._fwd_side.cuda_stream
         self._in_side = True
@@ -1179,13 +1176,11 @@ class Engine(StageMixin, WgradMixin):
         try:
             return fn()
         finally:
-            self.stage_flush()
             self.stream = old
             self._in_side = False
             self._bw_tag = old_tag
 
     def join_side(self):
-        self.stage_flush()
         torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)
         self._side_join_pending = False
 
@@ -1327,7 +1322,6 @@ class Engine(StageMixin, WgradMixin):
                                  for fn, a, _ in self.tape if fn == self._bw_conv and self._needs_wgrad(a[0]))
             self._wg_total += sum(2.0 * st.ci * st.taps * st.co * a[2][0].n * a[2][0].h * a[2][0].w
                                   for fn, a, _ in self.tape if fn == self._bw_block3 for st in a[:2] if self._needs_wgrad(st))
-        self.stage_flush()
         main_t = torch.cuda.current_stream(self.device)
         if self._side_join_pending:  # side-stream work of the forward pass nobody has joined yet (the stem's im2col)
             self.join_side()
@@ -1389,14 +1383,12 @@ class Engine(StageMixin, WgradMixin):
             gv, g, acc = self._riders.pop(bid)
             self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
             self.launches += 1
-        self.stage_flush()
         self._reduce_wgrads()
         for p, ptr in self._pgrad_tmp.values():  # NHWC-accumulated gradients of [1,C,h,w] parameters -> NCHW
             _, c, h, w = p.shape
             v = NT(ptr, 1, h, w, c, h * w * c, w * c, c, 4, rg=False)
             self.lib.nhwc_to_nchw(F32, 1, c, h, w, v.cv(), self.param_grad_ptr(p), self.stream)
             self.launches += 1
-        self.stage_flush()
         self.tape.clear()
 
     # ------------------------------------------------------------------ backward strands (see __init__)
@@ -1410,7 +1402,6 @@ class Engine(StageMixin, WgradMixin):
     def _bw_set_mark(self):
         """The fork point of the coming side-strand ops: everything the main stream has enqueued so far.  Main-strand accesses are
         tracked from here on."""
-        self.stage_flush()
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self._bw_mark = ev
@@ -1419,7 +1410,6 @@ class Engine(StageMixin, WgradMixin):
 
     def _bw_side(self, fn, args):
         if self._bw_mark_synced is not self._bw_mark:  # one fork edge per mark
-            self.stage_flush()
             self._fwd_side.wait_event(self._bw_mark)
             self._bw_mark_synced = self._bw_mark
             self._bw_forked = True
@@ -1437,14 +1427,12 @@ class Engine(StageMixin, WgradMixin):
             (sw if write else sr).add(key)
         else:
             if self._bw_forked and (key in sw or (write and key in sr)):
-                self.stage_flush()
                 torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)
                 sw.clear()
                 sr.clear()
             (mw if write else mr).add(key)
 
     def _bw_end(self):
-        self.stage_flush()
         if self._bw_forked:
             torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)
         self._bw_live = False

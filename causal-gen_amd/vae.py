@@ -625,70 +625,10 @@ class HVAE(nn.Module):
                                      "there is no CPU fallback")
             eng = Engine(dev, self.compute_dtype)
             eng.bind(self, self._make_sites())
-            eng.stage_res = self._stage_resolutions()
             self.__dict__["_eng"] = eng
         else:
             eng.check_params()
         return eng
-
-    def _stage_resolutions(self):
-        """Resolutions whose layers run inside the per-image stage interpreter (csrc/stage.hip) instead of one launch per op:
-        those at which EVERY conv of the hierarchy is small enough for one CU per image -- at most ``CGEN_STAGE_MFMA_RES``
-        (3000) MFMAs per image and a staged input (halo included) that fits one CU's LDS.  For ukbb192 that is 1, 6 and 12
-        (24x24 has 5 400-MFMA convs: a chip-wide launch is faster there), for the 32x32 presets every resolution.
-        ``CGEN_STAGE_RES="1,6"`` overrides the rule, ``CGEN_STAGE=0`` switches the interpreter off."""
-        if not hasattr(self.decoder, "blocks") or not hasattr(self.encoder, "blocks"):
-            return frozenset()  # (the config-1 model: f32, its own layer types)
-        env = os.environ.get("CGEN_STAGE_RES")
-        if env is not None:
-            return frozenset(int(v) for v in env.split(",") if v.strip())
-        budget = int(os.environ.get("CGEN_STAGE_MFMA_RES", "3000"))
-        worst = {}  # res -> [max MFMAs per image, max staged bytes]
-
-        def see(res, conv, cin8):
-            k = conv.kernel_size[0]
-            if k not in (1, 3):
-                return
-            taps = 1 if (res == 1 and k == 3) else k * k
-            mf = -(-res * res // 16) * -(-conv.out_channels // 16) * -(-taps * cin8 // 32)
-            g = cin8 // 8
-            g += 1 - (g & 1)
-            lds = (res + 2 * (k // 2)) ** 2 * g * 16 + 1024
-            w = worst.setdefault(res, [0, 0])
-            w[0], w[1] = max(w[0], mf), max(w[1], lds)
-
-        c8 = lambda *cs: sum(-(-c // 8) * 8 for c in cs)
-        ctx = self.context_dim
-
-        def see_block(res, blk, first_c8):
-            cs = blk.convs()
-            see(res, cs[0], first_c8)
-            for cv in cs[1:]:
-                see(res, cv, c8(cv.in_channels))
-            if hasattr(blk, "width_proj"):
-                see(res, blk.width_proj, first_c8)
-
-        res = None
-        for b in self.decoder.blocks:
-            w = b.in_width
-            see_block(b.res, b.prior, c8(w, ctx) if b.cond_prior else c8(w))
-            if b.stochastic:
-                see_block(b.res, b.posterior, c8(w, ctx, w))
-            see(b.res, b.z_proj, c8(self.z_dim, ctx))
-            if not b.q_correction:
-                see(b.res, b.z_feat_proj, c8(self.z_dim, w))
-            see_block(b.res, b.conv, c8(w))
-            res = b.res
-        r = res  # the encoder walks down from the input resolution (= the decoder's last)
-        for blk in self.encoder.blocks:
-            if r is None:
-                break
-            see_block(int(r), blk, c8(blk.convs()[0].in_channels))
-            if blk.d:
-                r = int(r / blk.d) if isinstance(blk.d, float) else r // blk.d
-                if r % 2 and r > 1:
-                    r += 1  # (vae.py:131-133: odd resolutions are zero-padded to even)
-        return frozenset(rr for rr, (mf, lds) in worst.items() if mf <= budget and lds <= 156 * 1024)
 
     def _make_sites(self):
         """Enumerate every conv with its input segmentation (the virtual torch.cat's of vae.py:176,188,294,300)."""
@@ -777,8 +717,7 @@ class HVAE(nn.Module):
             p_in = h if blk.q_correction else z
             run_prior = lambda: self._run_block(eng, blk.prior, [p_in, pa_sto] if blk.cond_prior else [p_in])
             # the prior and the posterior Block of a layer are independent: two streams (one fork / join per layer)
-            # (not at a staged resolution: there the whole layer is one op list on one stream, a fork would only cut it)
-            want_two = blk.stochastic and acts is not None and rec2 and not eng.stage_covers(res)
+            want_two = blk.stochastic and acts is not None and rec2
             # (a fresh fork: the posterior Block -- the main chain -- is enqueued first, the prior Block behind the mark: Engine.fork_mark)
             mark = eng.fork_mark() if want_two and not side_ahead else None
             t_q0 = len(eng.tape)
@@ -1217,9 +1156,7 @@ class HVAE(nn.Module):
             z = z.to(eng.device)
             if z.dtype == eng.tdtype and z.permute(0, 2, 3, 1).is_contiguous():
                 nt = eng.wrap_nhwc(z.permute(0, 2, 3, 1))
-                # (at a staged resolution the latent moves into the arena: the op lists of a captured pass then hold the same
-                #  addresses as the eager warm-up's -- a torch allocation inside the capture would not)
-                ins.append(eng.copy_in(nt) if eng.stage_covers(nt.h) else nt)
+                ins.append(nt)
             else:
                 ins.append(eng.from_nchw(z.float()))
         return ins

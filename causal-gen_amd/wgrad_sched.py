@@ -22,7 +22,7 @@ class WgradMixin:
     def _wgrad(self, site, segs, act, g):
         x0 = segs[0]
         a = _lib.WgradArgs()
-        gn, gh, gw, vw = self._geom(site.ks, list(segs) + [g], stageable=False)
+        gn, gh, gw, vw = self._geom(site.ks, list(segs) + [g])
         a.dtype, a.n, a.h, a.w, a.ks, a.nseg, a.act = self.dt, gn, gh, gw, site.ks, len(segs), act
         for k, s in enumerate(segs):
             a.seg[k] = vw(s)
@@ -66,7 +66,6 @@ class WgradMixin:
         if (self.on_split is not None and not self._split_done and self._wg_nflush >= max(1, len(self.wgrad_flush_frac)) and self._wg_total > 0
                 and self._wg_cum >= self.split_frac * self._wg_total):
             self._split_done = True
-            self.stage_flush()
             if self._wg_forked:  # join the background flush + its reduction: by now it has long finished (no stall)
                 main = torch.cuda.current_stream(self.device)
                 for st in self._wg_pool:
@@ -81,7 +80,6 @@ class WgradMixin:
             self.on_split()
 
     def _launch_deferred_wgrads(self, final=True):
-        self.stage_flush()
         main = torch.cuda.current_stream(self.device)
         if self.wgrad_batch:
             if self._wg_deferred:
@@ -114,7 +112,6 @@ class WgradMixin:
     def _launch_batched_wgrads(self, background=False):
         """All deferred weight-gradient problems in a handful of launches.  The packed problem table is planned once per
         distinct set of launch arguments (addresses are stable: the arena is deterministic) and kept on the device."""
-        self.stage_flush()  # (the batch forks from / joins the main stream: everything issued so far must be ON the stream)
         args = [a for a, _ in self._wg_deferred]
         n = len(args)
         if os.environ.get("CGEN_WG_DEBUG"):

@@ -122,6 +122,9 @@ typedef struct cgen_block3_args {
   const float* bias_a;
   cgen_view mid, mid_aux;
   cgen_block3_out o[2];
+  const void* w_a16; /* optional (NULL: absent): the first conv's weights as the 16-row image of cgen_weight_prep modes 6 / 7, which the
+                      * row-streaming instance (wide images, one input segment of 32 or 64 channels, bottleneck <= 16: the 96x96 and
+                      * 192x192 Blocks) reads; without it those shapes run on the tile instance */
 } cgen_block3_args;
 int cgen_block3_supported(const cgen_block3_args* a);
 int cgen_block3(const cgen_block3_args* a, cgen_stream_t stream);
@@ -177,7 +180,10 @@ typedef struct cgen_wprep_desc { /* OIHW f32 parameter -> forward image or dgrad
                                    * 3: w_a of the data gradient (conv2: rows = ci_total, K = co, taps flipped),
                                    * 4: o[].w of the forward pass (conv2: rows = co, K = tap * ci_total + c; k_pad = K16-steps per pair),
                                    * 5: o[].w of the data gradient w.r.t. segment [seg_off, seg_off + seg_c[0]) (conv1: rows = the
-                                   *    segment's channels, K = tap * co + c, taps flipped; k_pad = K16-steps per pair) */
+                                   *    segment's channels, K = tap * co + c, taps flipped; k_pad = K16-steps per pair)
+                                   * 6 / 7: w_a16 of the forward pass / the data gradient -- 1 KiB fragments in v_mfma_f32_16x16x32 A-operand lane
+                                   *    order, [tap 0..8][32-channel chunk q][64 lanes][8]: lane l holds row (l & 15) (bottleneck channel, <= 16),
+                                   *    k = 32 q + 8 (l >> 4) .. + 8 (6: conv1's input channel; 7: conv2's output channel, taps flipped) */
   int32_t nseg, seg_off;
   int32_t seg_c[CGEN_MAX_SEG];
   int32_t dtype, rows_pad, k_pad, reserved; /* k_pad = krow of the image */
@@ -404,55 +410,6 @@ int cgen_step_commit(float* state_dev, cgen_stream_t);
 int cgen_philox_normal(float* out, int64_t count, const uint64_t* rng, uint32_t stream_id, cgen_stream_t);
 /* rng[1] += inc (device-side counter bump so graph replays draw fresh noise) */
 int cgen_rng_advance(uint64_t* rng, uint64_t inc, cgen_stream_t);
-
-/* ------------------------------------------------------------------ per-image stage interpreter (CGEN_F16 16-bit storage; csrc/stage.hip)
- * One launch executes a LIST of consecutive low-resolution ops -- Block convs, z_proj / z_feat_proj and their data gradients
- * (vae.py:53-71,165-167), avg-pool / nearest upsample + bias (vae.py:79-83,233-241), reparameterise + KL and its gradient
- * (vae.py:14-30), gradient copies -- with ONE workgroup per image walking the list front to back: an image's tensors at
- * <= ~16x16 (every resolution of the 32x32 models) fit one CU's LDS, every op of the list only touches its own image, so
- * workgroup barriers replace the kernel boundaries of the launch-per-op chain (~10 us each, ~900 per train step).
- * Arguments of an op are exactly those of its stand-alone entry point (same views, same math, same Philox indexing):
- *   CGEN_ST_CONV          cgen_conv_args               (cgen_conv2d)
- *   CGEN_ST_AVGPOOL_FWD   cgen_stage_elem_args  h,w = output size, d, in, out                      (cgen_avgpool_fwd)
- *   CGEN_ST_AVGPOOL_BWD   cgen_stage_elem_args  h,w = pooled size, d, in = gout, out = gin, accumulate  (cgen_avgpool_bwd)
- *   CGEN_ST_UPSAMPLE_FWD  cgen_stage_elem_args  hi,wi -> h,w, in, src = bias [h][w][c] f32 or NULL, out  (cgen_upsample_fwd)
- *   CGEN_ST_UPSAMPLE_BWD  cgen_stage_elem_args  hi,wi <- h,w, in = gout, out = gin, accumulate       (cgen_upsample_bwd)
- *   CGEN_ST_BCAST         cgen_stage_elem_args  src [h][w][c] f32 -> out                            (cgen_batch_broadcast)
- *   CGEN_ST_AXPBY         cgen_stage_elem_args  in (or NULL), out, alpha, beta, c_from, accumulate  (cgen_axpby)
- *   CGEN_ST_REPARAM_FWD   cgen_stage_reparam_args                                                  (cgen_reparam_kl_fwd)
- *   CGEN_ST_REPARAM_BWD   cgen_stage_reparam_bwd_args  ride_src.p == NULL: no rider               (cgen_reparam_kl_bwd[_rider])
- * cgen_stage_accepts answers, without launching, whether an op is served (returns the dynamic LDS bytes it needs, >= 1;
- * 0 = not served: dtype, alignment, an image too large for one CU's LDS, or more MFMA work per image than one CU should
- * take -- the caller then issues the stand-alone launch).  cgen_stage_plan packs `count` accepted ops into a host blob
- * (call with blob_host = NULL for the size); the caller copies it to the device once per distinct list (addresses are stable
- * across steps) and cgen_stage_run launches n_images workgroups of 512 threads over it. */
-enum cgen_stage_kind { CGEN_ST_CONV = 0, CGEN_ST_AVGPOOL_FWD = 1, CGEN_ST_AVGPOOL_BWD = 2, CGEN_ST_UPSAMPLE_FWD = 3, CGEN_ST_UPSAMPLE_BWD = 4,
-                       CGEN_ST_BCAST = 5, CGEN_ST_AXPBY = 6, CGEN_ST_REPARAM_FWD = 7, CGEN_ST_REPARAM_BWD = 8 };
-typedef struct cgen_stage_elem_args {
-  int32_t dtype, n, h, w, d, hi, wi, accumulate, c_from, reserved;
-  float alpha, beta;
-  const float* src;
-  cgen_view in, out;
-} cgen_stage_elem_args;
-typedef struct cgen_stage_reparam_args {
-  int32_t dtype, n, h, w, c, kl_stride;
-  uint32_t stream_id;
-  float logt;
-  cgen_view q_loc, q_ls, p_loc, p_ls, eps_in, z;
-  const uint64_t* rng;
-  float* kl_part;
-} cgen_stage_reparam_args;
-typedef struct cgen_stage_reparam_bwd_args {
-  int32_t dtype, n, h, w, c, coef_stride, acc_q, acc_p, ride_acc;
-  float logt;
-  cgen_view q_loc, q_ls, p_loc, p_ls, z, gz, g_q_loc, g_q_ls, g_p_loc, g_p_ls, ride_src, ride_dst;
-  const float* kl_coef_dev;
-  const float* kl_chan_scale;
-} cgen_stage_reparam_bwd_args;
-int cgen_stage_accepts(int32_t kind, const void* args);
-int cgen_stage_plan(const int32_t* kinds, const void* const* args, int32_t count, void* blob_host, int64_t capacity,
-                    int64_t* blob_bytes, int32_t* lds_bytes);
-int cgen_stage_run(const void* blob_dev, int32_t count, int32_t n_images, int32_t lds_bytes, cgen_stream_t);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,17 @@ CASES += [
 ]
 
 
+# the row-streaming instance (blk3r: >= 48 pixels wide, one segment of 32 / 64 channels, bottleneck 8 / 16, 32 / 64 out)
+CASES += [
+    (2, 192, 192, [32], [1], 8, 32, True),     # 192^2 trunk: residual read from the input ring
+    (2, 192, 192, [32], [1], 8, 64, False),    # 192^2 prior / down Block: two channel pairs
+    (4, 96, 96, [64], [1], 16, 64, True),      # 96^2 trunk: two chunks, 16-wide bottleneck
+    (3, 52, 70, [32], [1], 8, 32, True),       # ragged: 70 = 2.19 strips wide, 52 rows = 13 bands
+    (2, 100, 60, [64], [1], 16, 32, False),    # ragged, 64 -> 16 -> 32
+    (2, 18, 48, [32], [1], 16, 64, False),     # a strip of five bands with a partial last one; 32 -> 16 -> 64
+]
+
+
 def _run(case, fuse, seed=0):
     from causal_gen_amd.engine import ConvSite, Engine
 
@@ -323,3 +334,50 @@ def test_blocks_sharing_an_input_keep_their_order(fuse, shape):
     assert pa == 0 and pb == 0, (pa, pb)
     for x, y in zip(a, b):
         assert torch.equal(x, y), float((x - y).abs().max())
+
+
+@pytest.mark.parametrize("shape", [(2, 192, 192, 32, 8), (3, 96, 96, 64, 16), (2, 52, 70, 32, 8)], ids=["192x192", "96x96", "ragged"])
+def test_row_streaming_block_reads_the_residual_from_its_input_ring(shape):
+    """A trunk Block (out = x + f(x): the residual IS the input, vae.py:73-78) on the row-streaming instance: the residual comes from
+    the LDS ring of input rows (RES = 1), not from HBM.  Forward and data gradient against the two-launch path."""
+    from causal_gen_amd.engine import ConvSite, Engine
+
+    N, H, W, ci, b = shape
+    g = torch.Generator().manual_seed(H + ci)
+    c1, c2 = torch.nn.Conv2d(ci, b, 3, padding=1), torch.nn.Conv2d(b, ci, 3, padding=1)
+    with torch.no_grad():
+        c1.weight.copy_(torch.randn(c1.weight.shape, generator=g) / math.sqrt(ci * 9 / 2))
+        c2.weight.copy_(torch.randn(c2.weight.shape, generator=g) / math.sqrt(b * 9 / 2))
+    x = torch.randn(N, ci, H, W, generator=g).half().float()
+    gout = torch.randn(N, ci, H, W, generator=g).half().float()
+    outs = {}
+    for fuse in (0, 2):
+        eng = Engine("cuda", "f16")
+        eng.blk3_minres, eng.blk3_res, eng.blk3_res3 = 8, [], []
+        holder = torch.nn.ModuleList([c1, c2]).cuda()
+        s1, s2 = ConvSite("c1", holder[0], [ci], [True], 0), ConvSite("c2", holder[1], [b], [True], 1)
+        s1.blk3, s2.blk3 = ("a", s2), ("b", s1)
+        eng.blk3_on = 2
+        eng.bind(holder, [s1, s2])
+        eng.blk3_on = fuse
+        eng.begin()
+        eng.prepare_weights(force=True)
+        eng.recording = True
+        xt = eng.from_nchw(x.cuda(), rg=True)
+        n0 = eng.launches
+        y = eng.block2(s1, s2, [xt], 1, res1=xt, trunk=True)
+        assert eng.launches - n0 == (1 if fuse else 2)
+        yt = eng.to_nchw(y).cpu()
+        gy = eng.seed_grad(y)
+        eng.lib.axpby(eng.dt, N, H, W, eng.from_nchw(gout.cuda()).cv(), gy.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
+        eng.recording = False
+        eng.backward()
+        torch.cuda.synchronize()
+        outs[fuse] = (yt, eng.to_nchw(eng.grad_read(xt)).cpu())
+    (y0, g0), (y2, g2) = outs[0], outs[2]
+    sy, sg = float(y0.abs().max()), float(g0.abs().max())
+    assert float((y2 - y0).abs().max()) <= 0.02 * sy and float(((y2 - y0).abs() > 0).float().mean()) < 0.05
+    assert float((g2 - g0).abs().max()) <= 0.03 * sg and float((g2 - g0).norm()) <= 5e-3 * float(g0.norm())
+    w1, w2 = c1.weight.detach().cpu().half().float(), c2.weight.detach().cpu().half().float()
+    ref = x + F.conv2d(F.relu(F.conv2d(F.relu(x), w1, c1.bias.detach().cpu(), padding=1).half().float()), w2, c2.bias.detach().cpu(), padding=1)
+    torch.testing.assert_close(y2, ref, rtol=3e-2, atol=3e-2)
