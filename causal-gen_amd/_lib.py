@@ -38,6 +38,12 @@ class Block3Args(C.Structure):
                 ("w_a", C.c_void_p), ("bias_a", C.c_void_p), ("mid", View), ("mid_aux", View), ("o", Block3Out * 2), ("w_a16", C.c_void_p)]
 
 
+class Block4Args(C.Structure):
+    _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("nseg", C.c_int32),
+                ("nout", C.c_int32), ("fwd", C.c_int32), ("b", C.c_int32), ("seg", View * MAX_SEG),
+                ("wimg", C.c_void_p * 3), ("bias", C.c_void_p * 3), ("mid", View * 3), ("mid_aux", View * 3), ("o", Block3Out * 3)]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [("dtype", C.c_int32), ("n", C.c_int32), ("h", C.c_int32), ("w", C.c_int32), ("ks", C.c_int32),
                 ("nseg", C.c_int32), ("act", C.c_int32), ("nsplit", C.c_int32), ("seg", View * MAX_SEG), ("gout", View),
@@ -80,6 +86,8 @@ PROTOTYPES = {
     "cgen_block3": [C.POINTER(Block3Args), vp],
     "cgen_block3_pair_supported": [C.POINTER(Block3Args), C.POINTER(Block3Args)],
     "cgen_block3_pair": [C.POINTER(Block3Args), C.POINTER(Block3Args), vp],
+    "cgen_block4_supported": [C.POINTER(Block4Args)],
+    "cgen_block4": [C.POINTER(Block4Args), vp],
     "cgen_conv2d_wgrad_plan": [C.POINTER(WgradArgs), C.POINTER(i32)],
     "cgen_conv2d_wgrad_batch_plan": [vp, i32, vp, i64, vp, vp, i32, vp, vp],
     "cgen_conv2d_wgrad_batch_run": [vp, vp, i32, i32, vp],
@@ -137,9 +145,9 @@ PROTOTYPES = {
     "cgen_rng_advance": [vp, u64, vp],
 }
 _RESTYPES = {"cgen_last_error": C.c_char_p}
-ABI_VERSION = 405  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
+ABI_VERSION = 406  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
 _NOCHECK = {"cgen_version", "cgen_h16_format", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks",
-            "cgen_block3_supported", "cgen_block3_pair_supported", "cgen_conv2d_pair_supported", "cgen_stem_conv_supported"}
+            "cgen_block3_supported", "cgen_block4_supported", "cgen_block3_pair_supported", "cgen_conv2d_pair_supported", "cgen_stem_conv_supported"}
 
 
 class WgradBatchLaunch(C.Structure):

@@ -8,7 +8,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=libcgen_hip.so
 NOPK="-Xclang -target-feature -Xclang -packed-fp32-ops"
-SRCS="csrc/runtime.hip csrc/block.hip csrc/conv.hip csrc/wgrad3.hip csrc/elementwise.hip csrc/latent.hip csrc/likelihood.hip csrc/optim.hip"
+SRCS="csrc/runtime.hip csrc/block.hip csrc/block4.hip csrc/conv.hip csrc/wgrad3.hip csrc/elementwise.hip csrc/latent.hip csrc/likelihood.hip csrc/optim.hip"
 mkdir -p build
 OBJS=""
 pids=""

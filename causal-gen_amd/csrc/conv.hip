@@ -2568,6 +2568,53 @@ __global__ __launch_bounds__(256) void wprep_kernel(const cgen_wprep_desc* descs
   int ctot8 = 0;
   if (d.mode == 0) { for (int s = 0; s < d.nseg; ++s) ctot8 += (d.seg_c[s] + 7) & ~7; }
   else ctot8 = (d.co + 7) & ~7;
+  if (d.mode >= 8) {  // fragment-ordered images of the fused default Block (csrc/block4.hip; layout in include/cgen_hip.h)
+    for (int i = threadIdx.x; i < MT_CHUNK; i += 256) {
+      const int64_t o = base + i;
+      if (o >= d.numel) break;
+      const int frag = (int)(o >> 9), w = (int)(o & 511), ln = w >> 3, e = w & 7;
+      const int r32 = ln & 31, kg = ln >> 5;
+      const int q = (int)((uint32_t)frag / (uint32_t)d.k_pad), r = frag - q * d.k_pad;
+      // channel (inside its 32-row block) that fragment row r32 carries.  Phase 3 (modes 12 / 13): the lane (pixel, kg) of the accumulator
+      // tile ends up with 16 consecutive channels, 16 kg ..; phases 0-2 (modes 8-11): with HW = half the block's real channels (the
+      // bottleneck rounded up to 8: 4, 8, 12 or 16), channels HW kg .. + HW in its first HW accumulators -- no lane idles on padding
+      const int kgr = (r32 >> 2) & 1, jr = (r32 & 3) + 4 * (r32 >> 3);
+      int perm = 16 * kgr + jr;
+      if (d.mode <= 11) {
+        const int bw = (d.mode == 8 || d.mode == 10) ? d.co : d.ci_total;  // bottleneck width
+        const int mbq = d.mode <= 9 ? q : q / 9;
+        const int hw = min(32, ((bw + 7) & ~7) - 32 * mbq) / 2;
+        perm = jr < hw ? hw * kgr + jr : 1 << 20;
+      }
+      float v = 0.f;
+      if (d.mode <= 9) {  // phase 0: frag = (32-row block * chunks + chunk) * 2 + step; a lane's K = 32 chunk + 16 step + 8 kg + e
+        const int row = 32 * q + perm, kc = 32 * (r >> 1) + 16 * (r & 1) + 8 * kg + e;
+        if (d.mode == 8) {
+          if (row < d.co) {
+            int cc = kc, off = 0, ci = -1;
+            for (int s = 0; s < d.nseg; ++s) {  // (every segment padded to whole 32-channel chunks)
+              const int c32 = (d.seg_c[s] + 31) & ~31;
+              if (cc < c32) { if (cc < d.seg_c[s]) ci = off + cc; break; }
+              cc -= c32; off += d.seg_c[s];
+            }
+            if (ci >= 0) v = d.src[(int64_t)row * d.ci_total + ci];
+          }
+        } else if (row < d.ci_total && kc < d.co) {
+          v = d.src[(int64_t)kc * d.ci_total + row];
+        }
+      } else if (d.mode <= 11) {  // 3x3: frag = ((32-row block * 9 + tap) * groups + 16-channel group); k_pad = groups
+        const int tap = q % 9, row = 32 * (q / 9) + perm, k = 16 * r + 8 * kg + e;
+        if (d.mode == 10) { if (row < d.co && k < d.ci_total) v = d.src[((int64_t)row * d.ci_total + k) * 9 + tap]; }
+        else if (row < d.ci_total && k < d.co) v = d.src[((int64_t)k * d.ci_total + row) * 9 + (8 - tap)];
+      } else {  // phase 3: frag = 32-row block * groups + 16-channel group of the bottleneck; k_pad = groups
+        const int row = 32 * q + perm, k = 16 * r + 8 * kg + e;
+        if (d.mode == 12) { if (row < d.co && k < d.ci_total) v = d.src[(int64_t)row * d.ci_total + k]; }
+        else if (row < d.seg_c[0] && k < d.co) v = d.src[(int64_t)k * d.ci_total + d.seg_off + row];
+      }
+      ((h16_t*)d.dst)[o] = f2h(v);
+    }
+    return;
+  }
   if (d.mode >= 6) {  // 16-row images of the row-streaming Block instance: frag = tap * chunks + q (k_pad = chunks)
     for (int i = threadIdx.x; i < MT_CHUNK; i += 256) {
       const int64_t o = base + i;

@@ -36,7 +36,7 @@ __global__ void rng_advance_kernel(uint64_t* rng, uint64_t inc) { rng[1] += inc;
 
 using namespace cgen;
 
-extern "C" int cgen_version(void) { return 405; }  // ABI version (include/cgen_hip.h CGEN_ABI_VERSION): bumped whenever a struct, an enum value or a signature moves
+extern "C" int cgen_version(void) { return CGEN_ABI_VERSION; }  // ABI version (include/cgen_hip.h CGEN_ABI_VERSION): bumped whenever a struct, an enum value or a signature moves
 extern "C" int cgen_h16_format(void) {
 #ifdef CGEN_H16_BF16
   return 1;

@@ -181,13 +181,37 @@ class ConvSite:
         # fused light Block (csrc/block.hip): `blk3` = ("a", partner) for the Block's first conv, ("b", partner) for its second;
         # fragment-ordered weight images (include/cgen_hip.h, cgen_block3_args): device addresses, set by Engine.bind
         self.blk3 = None
-        self.frag = {}        # "a_fwd" / "b_fwd" / "a_dg" / ("b_dg", k)
+        # fused default Block (csrc/block4.hip): `blk4` = (role 0..3, [the Block's four sites])
+        self.blk4 = None
+        self.frag = {}        # "a_fwd" / "b_fwd" / "a_dg" / ("b_dg", k); blk4: "p0_fwd" ... (plan_frag_images4)
         self.frag_numel = {}
+
+    def plan_frag_images4(self):
+        """Fragment images of the fused DEFAULT Block (cgen_block4, include/cgen_hip.h): phase p of the forward pass reads
+        "p<p>_fwd" of conv p; phase p of the data gradient reads the transposed image of conv 3 - p ("p<p>_dg" lives at that conv)."""
+        if self.blk4 is None:
+            return
+        role, sites = self.blk4
+        b = sites[0].co
+        if b > 64 or sites[1].ks != 3 or sites[2].ks != 3:
+            return
+        g, nmb = _ceil(b, 16) // 16, _ceil(b, 32) // 32
+        if role == 0:
+            self.frag_numel["p0_fwd"] = nmb * sum(_ceil(c, 32) // 32 for c in self.seg_c) * 2 * 512
+            for k, (c, rg) in enumerate(zip(self.seg_c, self.seg_rg)):
+                if rg:
+                    self.frag_numel[("p3_dg", k)] = _ceil(c, 32) // 32 * g * 512
+        elif role == 1:
+            self.frag_numel["p1_fwd"] = self.frag_numel["p2_dg"] = nmb * 9 * g * 512
+        elif role == 2:
+            self.frag_numel["p2_fwd"] = self.frag_numel["p1_dg"] = nmb * 9 * g * 512
+        else:
+            self.frag_numel["p3_fwd"] = _ceil(self.co, 32) // 32 * g * 512
+            self.frag_numel["p0_dg"] = nmb * (_ceil(self.co, 32) // 32) * 2 * 512
 
     def plan_frag_images(self):
         """Element counts of the fragment-ordered images this site needs as part of a fused Block (512 elements = one KiB
         fragment: 64 lanes x 8)."""
-        self.frag_numel = {}
         if self.blk3 is None or self.ks != 3:
             return
         role, other = self.blk3
@@ -337,6 +361,9 @@ class Engine(WgradMixin):
         self.blk3_minres = int(os.environ.get("CGEN_BLK3_MINRES", "16"))
         # images up to 14 pixels wide (12x12, 6x6): the small-image instance of cgen_block3, one launch per Block there too
         self.blk3_small = int(os.environ.get("CGEN_BLK3S", "1"))
+        # fused default Block (vae.py:57-71; csrc/block4.hip): the four convs of a non-light Block as one launch, forward and data gradient
+        self.blk4_on = int(os.environ.get("CGEN_BLK4", "1")) if self.dt == F16 else 0
+        self.blk4_launches = 0
         # the row-streaming instance (96x96 / 192x192 Blocks, csrc/block.hip blk3r): CGEN_BLK3R=0 off; where it serves a shape the side
         # policy below (blk3_res) does not apply
         self.blk3_rows = int(os.environ.get("CGEN_BLK3R", "1"))
@@ -502,6 +529,8 @@ class Engine(WgradMixin):
             s.frag, s.frag_numel = {}, {}
             if self.dt == F16 and self.blk3_on:
                 s.plan_frag_images()
+            if self.dt == F16 and self.blk4_on:
+                s.plan_frag_images4()
             for key, numel in s.frag_numel.items():
                 offs.append(total)
                 total += _ceil(numel * 2, _ALIGN)
@@ -590,6 +619,23 @@ class Engine(WgradMixin):
                     d.mode, d.k_pad = 7, s.co // 32
                 elif key == "b_fwd":
                     d.mode, d.k_pad = 4, (9 * s.ci + 15) // 16
+                elif isinstance(key, str) and key[0] == "p" or (isinstance(key, tuple) and key[0] == "p3_dg"):
+                    g16 = _ceil(s.blk4[1][0].co, 16) // 16  # (16-channel groups of the bottleneck)
+                    if key == "p0_fwd":
+                        d.mode, d.k_pad = 8, 2 * sum(_ceil(c, 32) // 32 for c in s.seg_c)
+                    elif key == "p0_dg":
+                        d.mode, d.k_pad = 9, 2 * (_ceil(s.co, 32) // 32)
+                    elif key in ("p1_fwd", "p2_fwd"):
+                        d.mode, d.k_pad = 10, g16
+                    elif key in ("p1_dg", "p2_dg"):
+                        d.mode, d.k_pad = 11, g16
+                    elif key == "p3_fwd":
+                        d.mode, d.k_pad = 12, g16
+                    else:
+                        k = key[1]
+                        d.mode, d.k_pad, d.nseg, d.seg_off = 13, g16, 1, s.seg_off[k]
+                        d.seg_c[0] = s.seg_c[k]
+                    d.ks = s.ks
                 else:
                     k = key[1]
                     d.mode, d.k_pad, d.nseg, d.seg_off = 5, (9 * s.co + 15) // 16, 1, s.seg_off[k]
@@ -841,6 +887,124 @@ class Engine(WgradMixin):
             for (k, gv, prev, acc) in tgt:
                 self._dgrad_launch(site1, gt, segs[k], k, act, x0, gv, prev, acc)
         late()
+
+    def block4(self, sites, segs, res1=None, trunk=False):
+        """A whole default Block -- 1x1(gelu(cat segs)) -> 3x3(gelu) -> 3x3(gelu) -> 1x1(gelu) (+ res1), vae.py:57-71,73-84 -- as ONE
+        launch of cgen_block4 (csrc/block4.hip); None when the kernel does not serve the shape (the caller then runs the four convs).
+        The three bottleneck tensors are written (pre-activations: weight gradients, backward)."""
+        s0, s1, s2, s3 = sites
+        x0 = segs[0]
+        if not (self.blk4_on and "p0_fwd" in s0.frag and "p3_fwd" in s3.frag and len(segs) <= 3 and s3.co % 8 == 0 and s3.co <= 256):
+            return None
+        a = _lib.Block4Args()
+        a.dtype, a.n, a.h, a.w, a.nseg, a.nout, a.fwd, a.b = self.dt, x0.n, x0.h, x0.w, len(segs), 1, 1, s0.co
+        for k, sg in enumerate(segs):
+            assert sg.c == s0.seg_c[k] and (sg.n, sg.h, sg.w) == (x0.n, x0.h, x0.w), (s0.name, k, sg.shape, s0.seg_c)
+            a.seg[k] = sg.cv()
+        ts = []
+        for k, (st, key) in enumerate(((s0, "p0_fwd"), (s1, "p1_fwd"), (s2, "p2_fwd"))):
+            a.wimg[k] = st.frag[key]
+            bp = st.conv.bias
+            a.bias[k] = bp.data_ptr() if bp is not None else None
+            t = self.new(x0.n, x0.h, x0.w, s0.co)
+            if s0.co % 8:
+                t.cpad = _ceil(s0.co, 8)  # (the kernel writes whole 8-channel groups: zeros in the padding)
+            a.mid[k], a.mid_aux[k] = t.cv(), NULL_VIEW
+            ts.append(t)
+        out = self.new(x0.n, x0.h, x0.w, s3.co, rem=trunk and self.trunk_rem and max(x0.h, x0.w) <= self.trunk_maxres)
+        o = a.o[0]
+        b3 = s3.conv.bias
+        o.w, o.bias = s3.frag["p3_fwd"], (b3.data_ptr() if b3 is not None else None)
+        o.out, o.aux, o.res1 = out.cv(), NULL_VIEW, (res1.cv() if res1 is not None else NULL_VIEW)
+        o.out_rem, o.res1_rem = out.rem, (res1.rem if res1 is not None else 0)
+        if not self.lib.block4_supported(C.byref(a)):
+            return None
+        self._timed_blk4("conv_fwd", sites, x0, lambda: self.lib.block4(C.byref(a), self.stream))
+        self.blk4_launches += 1
+        if self.recording:
+            if self._dbg_names is not None:
+                self._dbg_names[id(out.base)] = s3.name
+            self.tape.append((self._bw_block4, (sites, segs, tuple(ts), out, res1), self._bw_tag))
+        return out
+
+    def _bw_block4(self, sites, segs, ts, out, res1):
+        """Backward of a fused default Block: weight gradients as for the four convs (deferred, batched); the four data-gradient
+        convs + GELU derivatives as ONE launch of cgen_block4 (fwd = 0), with one output per differentiable input segment."""
+        g = self.grad_read(out)
+        if g is None:
+            return
+        s0, s1, s2, s3 = sites
+        t0, t1, t2 = ts
+        act = ACT_GELU
+        x0 = segs[0]
+        dsegs = [k for k, sg in enumerate(segs) if sg.rg and s0.seg_rg[k]]
+        ok = (1 <= len(dsegs) <= 3 and "p0_dg" in s3.frag and "p1_dg" in s2.frag and "p2_dg" in s1.frag
+              and all(("p3_dg", k) in s0.frag for k in dsegs) and all(segs[k].c % 8 == 0 for k in dsegs) and g.c % 8 == 0)
+        if not ok:
+            self._bw_conv(s3, [t2], act, out, res1, None)
+            self._bw_conv(s2, [t1], act, t2, None, None)
+            self._bw_conv(s1, [t0], act, t1, None, None)
+            self._bw_conv(s0, segs, act, t0, None, None)
+            return
+        if res1 is not None and res1.rg:
+            # (the fused launch reads grad(out) WITH a halo while it writes grad(x): x may adopt grad(out)'s buffer only when its
+            #  later accumulation goes out of place -- which is the case exactly when weight gradients are deferred, _dgrad_target)
+            self._grad_residual(res1, g, out, [t2] if self._defer_wgrad() else [t2] + list(segs))
+        wg = "wg" not in self._ablate
+        if wg and self._needs_wgrad(s3):
+            self._wgrad(s3, [t2], act, g)
+        g2, acc2 = self.grad_write(t2)
+        g1, acc1 = self.grad_write(t1)
+        g0, acc0 = self.grad_write(t0)
+        assert not (acc0 or acc1 or acc2)
+        a = _lib.Block4Args()
+        a.dtype, a.n, a.h, a.w, a.nseg, a.nout, a.fwd, a.b = self.dt, g.n, g.h, g.w, 1, len(dsegs), 0, s0.co
+        a.seg[0] = g.cv()
+        for k, (st, key, gm, tm) in enumerate(((s3, "p0_dg", g2, t2), (s2, "p1_dg", g1, t1), (s1, "p2_dg", g0, t0))):
+            a.wimg[k], a.bias[k] = st.frag[key], None
+            a.mid[k], a.mid_aux[k] = gm.cv(), tm.cv()
+        tgt = []
+        for j, k in enumerate(dsegs):
+            sg = segs[k]
+            gv, prev, acc = self._dgrad_target(sg)
+            tgt.append((k, gv, prev, acc))
+            a.o[j].w, a.o[j].bias = s0.frag[("p3_dg", k)], None
+            a.o[j].out, a.o[j].aux = gv.cv(), sg.cv()
+            a.o[j].res1 = prev.cv() if acc else NULL_VIEW
+        if self.lib.block4_supported(C.byref(a)):
+            self._timed_blk4("conv_dgrad", sites, x0, lambda: self.lib.block4(C.byref(a), self.stream))
+            self.blk4_launches += 1
+        else:
+            # the REAL gradient views are not served (an oddly laid-out accumulate target): the four data-gradient convs, into the
+            # targets already acquired (the bookkeeping above has run and must not run twice)
+            self._dgrad_launch(s3, g, t2, 0, act, t2, g2, g2, False)
+            self._dgrad_launch(s2, g2, t1, 0, act, t1, g1, g1, False)
+            self._dgrad_launch(s1, g1, t0, 0, act, t0, g0, g0, False)
+            for (k, gv, prev, acc) in tgt:
+                self._dgrad_launch(s0, g0, segs[k], k, act, x0, gv, prev, acc)
+            self._conv_flush()
+        if wg:
+            if self._needs_wgrad(s2):
+                self._wgrad(s2, [t1], act, g2)
+            if self._needs_wgrad(s1):
+                self._wgrad(s1, [t0], act, g1)
+            if self._needs_wgrad(s0):
+                self._wgrad(s0, segs, act, g0)
+
+    def _timed_blk4(self, kind, sites, x0, fn):
+        """A fused default-Block launch, tallied (when profiling) with the algorithmic FLOPs of the FOUR convs it executes."""
+        self.launches += 1
+        if self.prof is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        flops = 2.0 * sum(st.ci * st.taps * st.co for st in sites) * x0.n * x0.h * x0.w
+        ent = self.prof.setdefault((kind + "_blk", 3, sites[0].ci, sites[3].co, x0.h), [0.0, [], 0])
+        ent[0] += flops
+        ent[1].append((e0, e1))
+        ent[2] += 1
 
     def _blk3_flush(self):
         """Launch a held fused data gradient on its own (its partner did not come, or cannot share the launch)."""
@@ -1322,6 +1486,8 @@ class Engine(WgradMixin):
                                  for fn, a, _ in self.tape if fn == self._bw_conv and self._needs_wgrad(a[0]))
             self._wg_total += sum(2.0 * st.ci * st.taps * st.co * a[2][0].n * a[2][0].h * a[2][0].w
                                   for fn, a, _ in self.tape if fn == self._bw_block3 for st in a[:2] if self._needs_wgrad(st))
+            self._wg_total += sum(2.0 * st.ci * st.taps * st.co * a[1][0].n * a[1][0].h * a[1][0].w
+                                  for fn, a, _ in self.tape if fn == self._bw_block4 for st in a[0] if self._needs_wgrad(st))
         main_t = torch.cuda.current_stream(self.device)
         if self._side_join_pending:  # side-stream work of the forward pass nobody has joined yet (the stem's im2col)
             self.join_side()

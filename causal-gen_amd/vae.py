@@ -94,6 +94,11 @@ def _block_sites(sites, name, blk, seg_c, seg_rg):
     if blk.light and len(cs) == 2 and cs[0].kernel_size[0] == 3 and cs[1].kernel_size[0] == 3:
         # the two 3x3 convs of a light Block run as ONE launch (Engine.block2 -> cgen_block3): fragment-ordered weight images
         sites[first].blk3, sites[first + 1].blk3 = ("a", sites[first + 1]), ("b", sites[first])
+    if not blk.light and len(cs) == 4 and cs[1].kernel_size[0] == 3 and cs[2].kernel_size[0] == 3:
+        # the four convs of a default Block run as ONE launch (Engine.block4 -> cgen_block4): fragment-ordered weight images
+        four = sites[first:first + 4]
+        for r in range(4):
+            sites[first + r].blk4 = (r, four)
     if hasattr(blk, "width_proj"):
         sites.append(ConvSite(f"{name}.width_proj", blk.width_proj, seg_c, seg_rg, len(sites)))
 
@@ -130,11 +135,15 @@ def run_block(eng, blk, segs):
     if blk.light and len(cs) == 2:  # the two 3x3 convs of a light Block: one fused launch where the kernel serves the shape
         h = eng.block2(site(cs[0]), site(cs[1]), segs, act, res1=res, trunk=blk.residual)
     else:
-        # (a residual Block's last conv writes the next value of the trunk: h = x + f(x), vae.py:78)
-        h = eng.conv(site(cs[0]), segs, act, res1=res if len(cs) == 1 else None, trunk=blk.residual and len(cs) == 1)
-        for j, c in enumerate(cs[1:]):
-            last = j == len(cs) - 2
-            h = eng.conv(site(c), [h], act, res1=res if last else None, trunk=blk.residual and last)
+        h = None
+        if not blk.light and len(cs) == 4 and site(cs[0]).blk4 is not None:  # a default Block: one fused launch where the kernel serves it
+            h = eng.block4([site(c) for c in cs], segs, res1=res, trunk=blk.residual)
+        if h is None:
+            # (a residual Block's last conv writes the next value of the trunk: h = x + f(x), vae.py:78)
+            h = eng.conv(site(cs[0]), segs, act, res1=res if len(cs) == 1 else None, trunk=blk.residual and len(cs) == 1)
+            for j, c in enumerate(cs[1:]):
+                last = j == len(cs) - 2
+                h = eng.conv(site(c), [h], act, res1=res if last else None, trunk=blk.residual and last)
     if blk.d:
         h = eng.pool(h, blk.d)  # int: avg_pool2d; float: adaptive_avg_pool2d (vae.py:79-83)
     return h

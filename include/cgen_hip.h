@@ -58,7 +58,7 @@ typedef struct cgen_view {
 /* ABI version of this header.  cgen_version() of the loaded library must equal it (causal-gen_amd/_lib.py checks): struct layouts,
  * enum values and signatures are only compatible within one version.  cgen_h16_format(): the 16-bit storage format the library was
  * BUILT for -- 0 = IEEE binary16 (default), 1 = bfloat16 (-DCGEN_H16_BF16, an A/B build); CGEN_F16 tensors must be in that format. */
-#define CGEN_ABI_VERSION 405
+#define CGEN_ABI_VERSION 406
 int cgen_version(void);
 int cgen_h16_format(void);
 const char* cgen_last_error(void);
@@ -136,6 +136,41 @@ int cgen_block3(const cgen_block3_args* a, cgen_stream_t stream);
 int cgen_block3_pair_supported(const cgen_block3_args* a, const cgen_block3_args* b);
 int cgen_block3_pair(const cgen_block3_args* a, const cgen_block3_args* b, cgen_stream_t stream);
 
+/* ------------------------------------------------------------------ fused DEFAULT Block (csrc/block4.hip; binary16)
+ * Block.forward of the non-"light" version (vae.py:57-71, 73-84: GELU -> 1x1 -> GELU -> 3x3 -> GELU -> 3x3 -> GELU -> 1x1) as ONE launch,
+ * the three bottleneck tensors' activated tiles resident in LDS:
+ *   fwd = 1:  mid[0] = bias[0] + conv1x1(gelu(cat_C(seg)); w[0]),  mid[1] = bias[1] + conv3x3(gelu(mid[0]); w[1]),
+ *             mid[2] = bias[2] + conv3x3(gelu(mid[1]); w[2]),       o[0].out = o[0].bias + conv1x1(gelu(mid[2]); o[0].w) + o[0].res1
+ *             (mid[]: pre-activations, written once -- the weight gradients and the backward pass read them; mid_aux absent)
+ *   fwd = 0 (data gradient: aten::convolution_backward x4 + gelu_backward x4, the input part; seg[0] = grad_out, nseg = 1;
+ *             mid_aux[0..2] = the forward mid[2], mid[1], mid[0]):
+ *             mid[0] = conv1x1(seg[0]; w[0] = image of the last conv's transpose) * gelu'(mid_aux[0])       (gradient w.r.t. forward mid[2])
+ *             mid[1] = conv3x3(mid[0]; w[1] = flipped transpose of the second 3x3) * gelu'(mid_aux[1])      (... forward mid[1])
+ *             mid[2] = conv3x3(mid[1]; w[2] = flipped transpose of the first 3x3) * gelu'(mid_aux[2])       (... forward mid[0])
+ *             o[k].out = conv1x1(mid[2]; o[k].w = transpose of the first conv w.r.t. segment k) * gelu'(o[k].aux) + o[k].res1
+ *             for up to three differentiable input segments (the posterior Block: h and the encoder activation).
+ * Weight images are FRAGMENT-ORDERED (1 KiB = one v_mfma_f32_32x32x16 A operand: lane l holds fragment row r = l & 31, k-group kg = l >> 5),
+ * built by cgen_weight_prep modes 8-13; G = ceil(b / 16).  Row permutation, with kr = (r >> 2) & 1 and j = (r & 3) + 4 (r >> 3):
+ * o[].w rows carry channel 16 kr + j of their 32-row block (a lane of the accumulator tile ends up with 16 consecutive channels);
+ * w[0..2] rows carry channel HW kr + j for j < HW (zero rows otherwise), HW = half of the block's channels after rounding b up to 8
+ * (4, 8, 12 or 16): every lane of the post-operation works on real channels whatever the bottleneck width.
+ *   w[0]        [ceil(b / 32) row blocks][sum_s ceil(seg[s].c / 32) chunks][2 steps][64 lanes][8]: lane (row, kg), step s, element e
+ *               multiplies input channel 32 chunk + 16 s + 8 kg + e (segments in whole chunks, zero padded)
+ *   w[1], w[2]  [ceil(b / 32)][9 taps][G][64][8]: k = 16 g + 8 kg + e
+ *   o[].w       [ceil(Co / 32)][G][64][8]
+ * Served: b <= 48 or 57..64, up to 3 input segments, output widths multiples of 8 (<= 256 forward), every view 16-byte aligned, below 2^31
+ * bytes, ragged channel counts zero padded to 8 (cgen_view.cpad); any image size (8 x 16 output tiles).  mid[k].c = mid_aux[k].c = b. */
+typedef struct cgen_block4_args {
+  int32_t dtype, n, h, w, nseg, nout, fwd, b;
+  cgen_view seg[CGEN_MAX_SEG];
+  const void* wimg[3]; /* w[0..2] below */
+  const float* bias[3];
+  cgen_view mid[3], mid_aux[3];
+  cgen_block3_out o[3];
+} cgen_block4_args;
+int cgen_block4_supported(const cgen_block4_args* a);
+int cgen_block4(const cgen_block4_args* a, cgen_stream_t stream);
+
 /* Weight gradient (aten::convolution_backward, weight/bias part) as split-K partials:
  *   partial_w[split][Co][KS*KS][Ci_total] (f32), partial_b[split][Co] (f32, may be NULL)
  * with Ci_total = sum_s seg[s].c and nsplit = cgen_conv2d_wgrad_plan(args) (call it with the views filled in).  *tiled_out says
@@ -183,7 +218,11 @@ typedef struct cgen_wprep_desc { /* OIHW f32 parameter -> forward image or dgrad
                                    *    segment's channels, K = tap * co + c, taps flipped; k_pad = K16-steps per pair)
                                    * 6 / 7: w_a16 of the forward pass / the data gradient -- 1 KiB fragments in v_mfma_f32_16x16x32 A-operand lane
                                    *    order, [tap 0..8][32-channel chunk q][64 lanes][8]: lane l holds row (l & 15) (bottleneck channel, <= 16),
-                                   *    k = 32 q + 8 (l >> 4) .. + 8 (6: conv1's input channel; 7: conv2's output channel, taps flipped) */
+                                   *    k = 32 q + 8 (l >> 4) .. + 8 (6: conv1's input channel; 7: conv2's output channel, taps flipped)
+                                   * 8-13: images of cgen_block4 (layouts there): 8 / 9 = w[0] forward (src = the first 1x1 [b][ci_total]; k_pad = 2 x chunks)
+                                   *    / data gradient (src = the last 1x1 [co][b]: rows = ci_total, K = co), 10 / 11 = a 3x3 forward / flipped
+                                   *    transpose (k_pad = G), 12 = o[].w forward (src = the last 1x1), 13 = o[].w of the data gradient w.r.t. segment
+                                   *    [seg_off, seg_off + seg_c[0]) (src = the first 1x1; k_pad = G) */
   int32_t nseg, seg_off;
   int32_t seg_c[CGEN_MAX_SEG];
   int32_t dtype, rows_pad, k_pad, reserved; /* k_pad = krow of the image */

@@ -36,8 +36,8 @@ def test_struct_layouts_match_header():
     prog = r'''
 #include <stdio.h>
 #include "cgen_hip.h"
-int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(cgen_view), sizeof(cgen_conv_args), sizeof(cgen_wgrad_args),
-                         sizeof(cgen_wprep_desc), sizeof(cgen_wred_desc), sizeof(cgen_adamw_args), sizeof(cgen_block3_args)); return 0; }
+int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(cgen_view), sizeof(cgen_conv_args), sizeof(cgen_wgrad_args),
+                         sizeof(cgen_wprep_desc), sizeof(cgen_wred_desc), sizeof(cgen_adamw_args), sizeof(cgen_block3_args), sizeof(cgen_block4_args)); return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
@@ -45,7 +45,7 @@ int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(cgen_view), size
         exe = os.path.join(d, "s")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
-    mine = [ctypes.sizeof(t) for t in (_lib.View, _lib.ConvArgs, _lib.WgradArgs, _lib.WprepDesc, _lib.WredDesc, _lib.AdamwArgs, _lib.Block3Args)]
+    mine = [ctypes.sizeof(t) for t in (_lib.View, _lib.ConvArgs, _lib.WgradArgs, _lib.WprepDesc, _lib.WredDesc, _lib.AdamwArgs, _lib.Block3Args, _lib.Block4Args)]
     assert sizes == mine, (sizes, mine)
 
 

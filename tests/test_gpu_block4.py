@@ -1,0 +1,145 @@
+"""Fused default-Block kernel of round 6 (csrc/block4.hip, cgen_block4: GELU -> 1x1 -> GELU -> 3x3 -> GELU -> 3x3 -> GELU -> 1x1 per
+launch, forward and data gradient; vae.py:57-71,73-84) against (a) the four-launch HIP path it replaces -- same binary16 storage points
+(every intermediate tensor is rounded to f16 in both), so the results agree up to an f16 ulp here and there -- and (b) a torch f32
+reference of the reference's Block on the same f16-quantised operands."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+# (N, H, W, input segments, differentiable?, bottleneck, out channels, residual?)  -- default-Block shapes of morphomnist / cmnist / mimic224
+CASES = [
+    (4, 32, 32, [16], [1], 4, 16, True),             # MNIST 32^2 trunk: ragged 4-channel bottleneck (zero padded to 8)
+    (4, 32, 32, [16, 12, 16], [1, 0, 1], 4, 32, False),  # MNIST 32^2 posterior: cat[h, pa (12 channels), acts]
+    (4, 16, 16, [32, 12], [1, 0], 8, 64, False),     # MNIST 16^2 conditional prior: 2 z_dim + width out
+    (8, 8, 8, [64], [1], 16, 64, True),              # one tile per image
+    (8, 4, 4, [128], [1], 32, 128, True),            # 4^2: a tile that is mostly outside the image
+    (2, 40, 52, [32], [1], 8, 32, True),             # 224^2 widths, ragged tiles (52 = 3.25 tiles wide)
+    (2, 112, 112, [64], [1], 16, 64, True),          # 112^2 trunk
+    (2, 56, 56, [96], [1], 24, 96, True),            # bottleneck 24: two 16-channel groups, the second half full
+    (2, 56, 56, [96, 6, 96], [1, 0, 1], 24, 32, False),   # mimic posterior at 56^2: 6 parent channels
+    (2, 28, 28, [128], [1], 32, 160, False),         # 28^2 prior: five 32-row output blocks
+    (2, 14, 14, [160], [1], 40, 160, True),          # bottleneck 40: two 32-row blocks, three 16-channel groups
+    (2, 14, 14, [160, 6, 160], [1, 0, 1], 40, 32, False),
+    (2, 8, 8, [192], [1], 48, 192, True),            # bottleneck 48
+    (2, 8, 8, [192], [1], 48, 224, False),           # the widest forward output: 2 z_dim + 192
+    (2, 7, 9, [72, 8], [1, 1], 20, 56, False),       # odd sides, two gradient outputs, ragged everything
+    (32, 28, 28, [128], [1], 32, 128, True),         # a full batch
+]
+
+
+def _run(case, fuse, seed=0):
+    from causal_gen_amd.engine import ConvSite, Engine
+    from causal_gen_amd import _lib
+
+    N, H, W, segc, segrg, b, co, with_res = case
+    g = torch.Generator().manual_seed(1000 * seed + H * 7 + co)
+    ci = sum(segc)
+    cs = [torch.nn.Conv2d(ci, b, 1), torch.nn.Conv2d(b, b, 3, padding=1), torch.nn.Conv2d(b, b, 3, padding=1), torch.nn.Conv2d(b, co, 1)]
+    with torch.no_grad():
+        for c in cs:
+            fan = c.in_channels * c.kernel_size[0] ** 2
+            c.weight.copy_(torch.randn(c.weight.shape, generator=g) * 1.6 / math.sqrt(fan))
+            c.bias.copy_(torch.randn(c.out_channels, generator=g) * 0.2)
+    xs = [torch.randn(N, c, H, W, generator=g).half().float() for c in segc]
+    res = torch.randn(N, co, H, W, generator=g).half().float() if with_res else None
+    gout = torch.randn(N, co, H, W, generator=g).half().float()
+    eng = Engine("cuda", "f16")
+    holder = torch.nn.ModuleList(cs).cuda()
+    sites = [ConvSite("c0", holder[0], segc, [bool(r) for r in segrg], 0)]
+    sites += [ConvSite(f"c{k}", holder[k], [b], [True], k) for k in (1, 2, 3)]
+    for r in range(4):
+        sites[r].blk4 = (r, sites)
+    eng.blk4_on = 1  # (images are planned at bind time)
+    eng.bind(holder, sites)
+    eng.blk4_on = fuse
+    eng.begin()
+    eng.prepare_weights(force=True)
+    eng.recording = True
+    nts = [eng.from_nchw(x.cuda(), rg=bool(r)) for x, r in zip(xs, segrg)]
+    rt = eng.from_nchw(res.cuda(), rg=False) if with_res else None
+    n0 = eng.launches
+    y = eng.block4(sites, nts, res1=rt) if fuse else None
+    if y is None:
+        assert not fuse, "cgen_block4 declined a shape it should serve"
+        h = eng.conv(sites[0], nts, _lib.ACT_GELU)
+        h = eng.conv(sites[1], [h], _lib.ACT_GELU)
+        h = eng.conv(sites[2], [h], _lib.ACT_GELU)
+        y = eng.conv(sites[3], [h], _lib.ACT_GELU, res1=rt)
+    fwd_launches = eng.launches - n0
+    y_t = eng.to_nchw(y).cpu()
+    gy = eng.seed_grad(y)
+    eng.lib.axpby(eng.dt, N, H, W, eng.from_nchw(gout.cuda()).cv(), gy.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
+    eng.recording = False
+    n1 = eng.launches
+    eng.backward()
+    bwd_launches = eng.launches - n1
+    torch.cuda.synchronize()
+    gxs = [eng.to_nchw(eng.grad_read(t)).cpu() if t.rg else None for t in nts]
+    pg = [eng.param_grad_view(p).cpu().clone() for c in holder for p in (c.weight, c.bias)]
+    return dict(y=y_t, gx=gxs, pg=pg, fwd_launches=fwd_launches, bwd_launches=bwd_launches, xs=xs, res=res, gout=gout, convs=cs)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"{c[3]}x{c[5]}x{c[6]}@{c[1]}x{c[2]}n{c[0]}" for c in CASES])
+def test_fused_block4_matches_four_launch_path_and_torch(case):
+    N, H, W, segc, segrg, b, co, with_res = case
+    four = _run(case, 0)
+    one = _run(case, 1)
+    assert four["fwd_launches"] == 4 and one["fwd_launches"] == 1, (four["fwd_launches"], one["fwd_launches"])
+    assert one["bwd_launches"] < four["bwd_launches"], (one["bwd_launches"], four["bwd_launches"])
+    # ---- (a) against the four-launch path: f16 flips of the intermediates at most (the fused kernel evaluates GELU from a Taylor table,
+    # the conv kernels by an erf polynomial: both ~2e-7 from the exact value, so a bottleneck value within that of a rounding boundary
+    # lands on the other side, and every output sums a few hundred of them: up to ~10 % of the outputs move by one ulp)
+    scale = float(four["y"].abs().max())
+    dy = (one["y"] - four["y"]).abs()
+    assert float(dy.max()) <= 0.02 * scale and float((dy > 0).float().mean()) < 0.2, (float(dy.max()), scale, float((dy > 0).float().mean()))
+    assert float((one["y"] - four["y"]).norm()) <= 1e-3 * float(four["y"].norm())
+    for a, c in zip(one["gx"], four["gx"]):
+        if c is None:
+            assert a is None
+            continue
+        s = float(c.abs().max())
+        assert float((a - c).abs().max()) <= 0.03 * s, (float((a - c).abs().max()), s)
+        assert float((a - c).norm()) <= 5e-3 * float(c.norm())
+    for a, c in zip(one["pg"], four["pg"]):
+        assert float((a - c).norm()) <= 1e-2 * float(c.norm()) + 1e-6, (float((a - c).norm()), float(c.norm()))
+    # ---- (b) against torch f32 (vae.py:57-71,73-84) on the same f16-quantised operands
+    cs = one["convs"]
+    ws = [c.weight.detach().cpu().half().float().requires_grad_(True) for c in cs]
+    bs = [c.bias.detach().cpu().clone().requires_grad_(True) for c in cs]
+    xr = [x.clone().requires_grad_(True) for x in one["xs"]]
+    h = F.conv2d(F.gelu(torch.cat(xr, 1)), ws[0], bs[0])
+    h = F.conv2d(F.gelu(h), ws[1], bs[1], padding=1)
+    h = F.conv2d(F.gelu(h), ws[2], bs[2], padding=1)
+    y = F.conv2d(F.gelu(h), ws[3], bs[3])
+    if with_res:
+        y = y + one["res"]
+    y.backward(one["gout"])
+    sy = float(y.detach().abs().max())
+    assert float((one["y"] - y.detach()).abs().max()) <= 1.5e-2 * sy, (float((one["y"] - y.detach()).abs().max()), sy)
+    assert float((one["y"] - y.detach()).norm()) <= 4e-3 * float(y.detach().norm())
+    for a, x in zip(one["gx"], xr):
+        if a is None:
+            continue
+        r = x.grad
+        assert float((a - r).norm()) <= 1.2e-2 * float(r.norm()), (float((a - r).norm()), float(r.norm()))
+    refs = [t.grad for wb in zip(ws, bs) for t in wb]
+    for a, r in zip(one["pg"], refs):
+        assert float((a.reshape(-1) - r.reshape(-1)).norm()) <= 1.5e-2 * float(r.norm()) + 1e-5, (float((a.reshape(-1) - r.reshape(-1)).norm()), float(r.norm()))
+
+
+def test_block4_declines_what_it_does_not_serve():
+    """b > 64, a 1x1-only Block, the f32 engine: the caller runs the four convs."""
+    import ctypes as C
+
+    from causal_gen_amd import _lib
+
+    lib = _lib.load()
+    a = _lib.Block4Args()
+    a.dtype, a.n, a.h, a.w, a.nseg, a.nout, a.fwd, a.b = _lib.F16, 2, 8, 8, 1, 1, 1, 128
+    assert lib.block4_supported(C.byref(a)) == 0
+    a.b, a.dtype = 16, _lib.F32
+    assert lib.block4_supported(C.byref(a)) == 0

@@ -34,6 +34,10 @@ GRAD_TOL = 2e-3       # of the tensor's max |gradient|
 # nats/dim, dominated by a few tail pixels -- already deviates by 5e-4), i.e. the floor of a 16-bit MFMA path.
 F16_ELBO_TOL = {"morphomnist": 6e-4}
 F16_ELBO_TOL_DEFAULT = 5e-5
+# (its NLL component alone on that fixture: 5.9e-4 with the default Blocks as four launches, 6.2e-4 with the fused launch of round 6,
+#  whose table GELU is CLOSER to the exact function -- 17 of 36 866 binary16 inputs round differently from exact-then-round, against 457
+#  for the erf polynomial of the conv kernels: which realisation of the rounding noise one gets depends on the kernels; ELBO 5.5e-4)
+F16_NLL_TOL = {"morphomnist": 7e-4}
 # ... and its counterfactual pixels (u = (x - rec_loc) / rec_scale amplifies the rounding of the reconstruction): measured
 # 9.5e-4 (cmnist + DMoL), 2.3e-3 (mimic224), 3.9e-3 (morphomnist), 3.9e-3 (ukbb192) absolute against the reference-made sample
 # (bf16 storage, round 2: 1.1e-2 .. 5.9e-2; binary16 without the remainder planes: 2.4e-3 .. 7.9e-3).  Held to 5e-3; the
@@ -208,7 +212,7 @@ def test_fullsize_forward_backward_counterfactual(name, B, dmol):
               R.key(name, dmol), _rel(got["elbo"], row["elbo"]), _rel(got["nll"], row["nll"]), _rel(got["kl"], row["kl"]), worst_fx,
               worst, n_checked, _grad_err.exempted, float(d_cf[ok].max()), n_masked, n_pix, dev["elbo"], dev["nll"], dev["kl"], d_cfb))
     etol = F16_ELBO_TOL.get(name, F16_ELBO_TOL_DEFAULT)
-    assert dev["elbo"] < etol and dev["nll"] < etol, dev
+    assert dev["elbo"] < etol and dev["nll"] < F16_NLL_TOL.get(name, etol), dev
     assert dev["kl"] < F16_KL_TOL, dev
     assert d_cfb < F16_CF_TOL, d_cfb
     etol_t = F16_TIMED_ELBO_TOL.get(name, F16_TIMED_ELBO_TOL_DEFAULT)

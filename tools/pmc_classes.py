@@ -8,7 +8,7 @@ import csv
 import json
 import sys
 
-CLASSES = {"conv_fwd+dgrad": ("conv_tile_kernel", "conv_ws_kernel", "conv_px_kernel", "conv_smallp_kernel", "conv_smallp_pair_kernel", "conv_kernel", "stem7", "blk3_kernel", "blk3_pair_kernel"),
+CLASSES = {"conv_fwd+dgrad": ("conv_tile_kernel", "conv_ws_kernel", "conv_px_kernel", "conv_smallp_kernel", "conv_smallp_pair_kernel", "conv_kernel", "stem7", "blk3", "blk4_kernel"),
            "conv_wgrad": ("wgrad_tile", "wgrad_kernel", "wg3_"), "wgrad_reduce": ("wred_kernel",), "reparam_kl": ("reparam_kl",),
            "likelihood": ("dgauss", "dmol"), "optimizer": ("adamw", "sumsq", "clip_decide")}
 tag = sys.argv[1]

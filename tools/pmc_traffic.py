@@ -8,7 +8,7 @@ import csv
 import json
 import sys
 
-CLASSES = {"conv_fwd+dgrad": ("conv_tile_kernel", "conv_ws_kernel", "conv_px_kernel", "conv_smallp_kernel", "conv_smallp_pair_kernel", "conv_kernel", "blk3_kernel", "blk3_pair_kernel"), "conv_wgrad": ("wgrad_tile_kernel", "wgrad_tile_batched_kernel", "wgrad_tile_mega_kernel", "wgrad_kernel", "wg3_mega_kernel", "wg3_single_kernel"),
+CLASSES = {"conv_fwd+dgrad": ("conv_tile_kernel", "conv_ws_kernel", "conv_px_kernel", "conv_smallp_kernel", "conv_smallp_pair_kernel", "conv_kernel", "blk3", "blk4_kernel"), "conv_wgrad": ("wgrad_tile_kernel", "wgrad_tile_batched_kernel", "wgrad_tile_mega_kernel", "wgrad_kernel", "wg3_mega_kernel", "wg3_single_kernel"),
            "wgrad_reduce": ("wred_kernel",), "reparam_kl": ("reparam_kl",), "elementwise": ("axpby", "avgpool", "upsample", "im2col", "batch_")}
 
 
