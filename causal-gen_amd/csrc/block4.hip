@@ -84,9 +84,9 @@ struct B4P {
 // forward table: Phi(x);  data-gradient table: gelu'(x) = Phi(x) + x phi(x)  (gelu'' = phi (2 - x^2), gelu''' = phi (x^3 - 4 x))
 #define B4_LUT_N 385
 #define B4_LUT_BYTES (B4_LUT_N * 16)
-template <bool FWD>
+template <bool FWD, int NT>
 __device__ __forceinline__ void b4_lut_fill(float4* lut, const int tid) {
-  for (int i = tid; i < B4_LUT_N; i += 256) {
+  for (int i = tid; i < B4_LUT_N; i += NT) {
     const float x0 = (float)(i - 192) * (1.f / 32.f);
     const float cdf = 0.5f * (1.f + erff(x0 * CGEN_SQRT1_2)), pdf = CGEN_INV_SQRT_2PI * __expf(-0.5f * x0 * x0);
     float4 c;
@@ -216,7 +216,7 @@ __device__ __forceinline__ void b4_clear(char* __restrict__ pix, const int kg, c
 // A 3x3 phase over the ACTUAL extent of the tile (edge tiles and small images enumerate only the pixels they have): input tile Uin
 // (row pitch PIN pixels) -> rows x cols pixels (cols * inv >> 16 divides) of the tile Uout (row pitch POUT) whose pixel (0, 0) is image
 // pixel (y0 - OFF, x0 - OFF); PH: phase index (1 or 2).  Pixel groups of 32 are dealt to the four waves.
-template <bool FWD, int NB8, int PIN, int POUT, int OFF, int PH>
+template <bool FWD, int NB8, int NW, int PIN, int POUT, int OFF, int PH>
 __device__ __forceinline__ void b4_conv3(const B4P& p, const char* __restrict__ Uin, char* __restrict__ Uout, const float* __restrict__ biasL,
                                          const float4* __restrict__ lut0, const int n, const int y0, const int x0, const int th, const int tw,
                                          const int inv, const int wave, const int lane) {
@@ -224,7 +224,7 @@ __device__ __forceinline__ void b4_conv3(const B4P& p, const char* __restrict__ 
   const int px = lane & 31, kg = lane >> 5;
   const int cols = tw + 2 * OFF, nout = (th + 2 * OFF) * cols;
   const char* const wl = p.w[PH] + lane * 16;
-  for (int g = wave; 32 * g < nout; g += 4) {
+  for (int g = wave; 32 * g < nout; g += NW) {
     const int m = 32 * g + px, mc = min(m, nout - 1);
     const int my = (mc * inv) >> 16, mx = mc - my * cols;
     const int iy = y0 - OFF + my, ix = x0 - OFF + mx;
@@ -253,8 +253,11 @@ __device__ __forceinline__ void b4_conv3(const B4P& p, const char* __restrict__ 
   }
 }
 
-template <bool FWD, int NB8>
-__global__ __launch_bounds__(256, NB8 <= 2 ? 4 : (NB8 <= 4 ? 3 : 2)) void blk4_kernel(const B4P p) {
+// NW: waves per workgroup -- 4, or 8 where the launch has few tiles (<= 1024: one round of resident workgroups, the time of the launch is
+// the dependent chain of ONE tile, and twice the waves halve the pixel groups each has to walk)
+template <bool FWD, int NB8, int NW>
+__global__ __launch_bounds__(64 * NW, NB8 <= 2 ? 4 : (NB8 <= 4 ? (NW == 8 ? 4 : 3) : 2)) void blk4_kernel(const B4P p) {
+  constexpr int NT = 64 * NW;
   constexpr int NB16 = (NB8 + 1) / 2, NMB = (NB16 + 1) / 2, PS = (2 * NB16 + 1) * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const U0 = smem;
@@ -273,23 +276,25 @@ __global__ __launch_bounds__(256, NB8 <= 2 ? 4 : (NB8 <= 4 ? 3 : 2)) void blk4_k
   const int lastx = tx == p.tiles_x - 1 ? 1 : 0;
   const char* const zero = (const char*)g_b4zero;
 
-  b4_lut_fill<FWD>(lut, tid);
+  b4_lut_fill<FWD, NT>(lut, tid);
   if constexpr (FWD) {
     if (tid < 192) {
       const int ph = tid >> 6, c = tid & 63;
       biasL[tid] = (p.bias[ph] != nullptr && c < p.nbias[ph]) ? p.bias[ph][c] : 0.f;
     }
-    biasL[192 + tid] = (p.o[0].bias != nullptr && tid < p.o[0].Co) ? p.o[0].bias[tid] : 0.f;
+    if (tid < 256) biasL[192 + tid] = (p.o[0].bias != nullptr && tid < p.o[0].Co) ? p.o[0].bias[tid] : 0.f;
   }
   if constexpr (NB8 & 1) {  // the upper half of the last 16-channel group is never written: K padding of phases 1-3 (zero weights, but 0 x NaN = NaN)
-    for (int q = tid; q < B4_N0 + B4_N1 + B4_N2; q += 256) *(uint4*)(U0 + q * PS + 16 * NB8) = make_uint4(0, 0, 0, 0);
+    for (int q = tid; q < B4_N0 + B4_N1 + B4_N2; q += NT) *(uint4*)(U0 + q * PS + 16 * NB8) = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
 
   // ------------------------------------------------------------------ phase 0: 1x1 over the halo tile ((th + 4) x (tw + 4) pixels), B operand from global
   {
     const int cols = tw + 4, n0 = (th + 4) * cols, inv = p.inv[0][lastx];
-    for (int g = wave; 32 * g < n0; g += 4) {
+    const int nch = p.nch0, k1 = p.seg_nch[0];
+    const int wmb = nch * 2048;                                        // bytes per 32-row block of the image
+    for (int g = wave; 32 * g < n0; g += NW) {
       const int m = 32 * g + px, mc = min(m, n0 - 1);
       const int hy = (mc * inv) >> 16, hx = mc - hy * cols;
       const int iy = y0 - 2 + hy, ix = x0 - 2 + hx;
@@ -302,39 +307,55 @@ __global__ __launch_bounds__(256, NB8 <= 2 ? 4 : (NB8 <= 4 ? 3 : 2)) void blk4_k
       for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[mb][e] = 0.f;
-      const char* wl = p.w[0] + lane * 16;
-      const int wmb = p.nch0 * 2048;  // bytes per 32-row block of the image
-#pragma unroll
-      for (int sg = 0; sg < 3; ++sg) {
-        if (sg < p.nseg) {
-          const B4V S = p.seg[sg];
-          const int c8 = p.seg_c8[sg];
-          const char* const src = S.p + (n * S.sn + iy * S.sh + ix * S.sw) + kg * 16;
-          for (int jl = 0; jl < p.seg_nch[sg]; ++jl) {
-            // K order of a chunk: step s, lane half kg, element e <-> channel 32 jl + 16 s + 8 kg + e (the two lanes of a pixel read 32
-            // contiguous bytes per step); a step that lies wholly beyond the segment's channels is skipped (wave-uniform)
-            const bool two = 32 * jl + 16 < c8;
-            uint4 b0 = *(const uint4*)((ok && 32 * jl + 8 * kg < c8) ? src + 64 * jl : zero);
-            uint4 b1 = make_uint4(0, 0, 0, 0);
-            if (two) b1 = *(const uint4*)((ok && 32 * jl + 16 + 8 * kg < c8) ? src + 64 * jl + 32 : zero);
-            h16x8 A[2][NMB];
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-              for (int mb = 0; mb < NMB; ++mb) A[s][mb] = *(const h16x8*)(wl + mb * wmb + s * 1024);
-            wl += 2048;
-            if constexpr (FWD) {
-              b0 = b4_gelu8(b0, lut0);
-              if (two) b1 = b4_gelu8(b1, lut0);
-            }
-#pragma unroll
-            for (int mb = 0; mb < NMB; ++mb) acc[mb] = b4_mfma(A[0][mb], b4_as_h(b0), acc[mb]);
-            if (two) {
-#pragma unroll
-              for (int mb = 0; mb < NMB; ++mb) acc[mb] = b4_mfma(A[1][mb], b4_as_h(b1), acc[mb]);
-            }
-          }
+      // this lane's pixel in every segment (absent segments are never dereferenced)
+      const char* const sp0 = p.seg[0].p + (n * p.seg[0].sn + iy * p.seg[0].sh + ix * p.seg[0].sw) + kg * 16;
+      const char* const sp1 = p.seg[1].p + (n * p.seg[1].sn + iy * p.seg[1].sh + ix * p.seg[1].sw) + kg * 16;
+      const char* const sp2 = p.seg[2].p + (n * p.seg[2].sn + iy * p.seg[2].sh + ix * p.seg[2].sw) + kg * 16;
+      const char* const wl = p.w[0] + lane * 16;
+      const int c80 = p.seg_c8[0], c81 = p.seg_c8[1], c82 = p.seg_c8[2];  // (locals: a lambda that captured the kernarg struct would force a scratch copy of it)
+      // One chunk = 32 input channels.  K order: step s, lane half kg, element e <-> channel 32 jl + 16 s + 8 kg + e (the two lanes of a
+      // pixel read 32 contiguous bytes per step); a step that lies wholly beyond the segment's channels is skipped (wave-uniform).
+      // The chunks run through a two-stage software pipeline: the loads (activations + weight fragments) of chunk j + 1 are in flight
+      // under the GELU + MFMAs of chunk j -- with one chunk at a time a 12-chunk posterior Block was 12 dependent memory round trips.
+      struct Stage { uint4 b0, b1; h16x8 A[2][NMB]; bool two; };
+      // (the segment walk is incremental state -- written as selects over (sp0, sp1, sp2) by the chunk's segment number, hipcc builds a
+      //  table of the three pointers in SCRATCH and indexes it)
+      const char* cur = sp0;
+      int c8 = c80, left = k1, jl = 0, sgi = 0;
+      const int nc1 = p.seg_nch[1];
+      auto issue = [&](const int j, Stage& st) {
+        if (jl == left) {
+          jl = 0;
+          if (sgi == 0) { cur = sp1; c8 = c81; left = nc1; } else { cur = sp2; c8 = c82; left = 1 << 20; }
+          ++sgi;
         }
+        const char* const src = cur + 64 * jl;
+        st.two = 32 * jl + 16 < c8;
+        st.b0 = *(const uint4*)((ok && 32 * jl + 8 * kg < c8) ? src : zero);
+        st.b1 = *(const uint4*)((ok && 32 * jl + 16 + 8 * kg < c8) ? src + 32 : zero);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int mb = 0; mb < NMB; ++mb) st.A[s][mb] = *(const h16x8*)(wl + j * 2048 + mb * wmb + s * 1024);
+        ++jl;
+      };
+      auto consume = [&](Stage& st) {
+        if constexpr (FWD) st.b0 = b4_gelu8(st.b0, lut0);
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) acc[mb] = b4_mfma(st.A[0][mb], b4_as_h(st.b0), acc[mb]);
+        if (st.two) {
+          if constexpr (FWD) st.b1 = b4_gelu8(st.b1, lut0);
+#pragma unroll
+          for (int mb = 0; mb < NMB; ++mb) acc[mb] = b4_mfma(st.A[1][mb], b4_as_h(st.b1), acc[mb]);
+        }
+      };
+      Stage sa, sb;
+      issue(0, sa);
+      for (int j = 0; j < nch; j += 2) {
+        if (j + 1 < nch) issue(j + 1, sb);
+        consume(sa);
+        if (j + 2 < nch) issue(j + 2, sa);
+        if (j + 1 < nch) consume(sb);
       }
       const bool centre = ok && hy >= 2 && hy < 2 + th && hx >= 2 && hx < 2 + tw;
       b4_post_mb<FWD, NB8, 0>(acc[0], kg, biasL, lut0, p.mid[0], p.aux[0], n, iy, ix, ok, centre, live, pix);
@@ -343,13 +364,13 @@ __global__ __launch_bounds__(256, NB8 <= 2 ? 4 : (NB8 <= 4 ? 3 : 2)) void blk4_k
   }
   __syncthreads();
   // ------------------------------------------------------------------ phases 1, 2: 3x3 over LDS tiles
-  b4_conv3<FWD, NB8, B4_P0, B4_P1, 1, 1>(p, U0, U1, biasL, lut0, n, y0, x0, th, tw, p.inv[1][lastx], wave, lane);
+  b4_conv3<FWD, NB8, NW, B4_P0, B4_P1, 1, 1>(p, U0, U1, biasL, lut0, n, y0, x0, th, tw, p.inv[1][lastx], wave, lane);
   __syncthreads();
-  b4_conv3<FWD, NB8, B4_P1, B4_TW, 0, 2>(p, U1, U2, biasL, lut0, n, y0, x0, th, tw, p.inv[2][lastx], wave, lane);
+  b4_conv3<FWD, NB8, NW, B4_P1, B4_TW, 0, 2>(p, U1, U2, biasL, lut0, n, y0, x0, th, tw, p.inv[2][lastx], wave, lane);
   __syncthreads();
   // ------------------------------------------------------------------ phase 3: 1x1 to every output, epilogue from the accumulators
   const int n3 = th * tw, inv3 = p.inv[2][lastx];
-  for (int g = wave; 32 * g < n3; g += 4) {
+  for (int g = wave; 32 * g < n3; g += NW) {
     const int m = 32 * g + px, mc = min(m, n3 - 1);
     const int oy = (mc * inv3) >> 16, ox = mc - oy * tw;
     const int iy = y0 + oy, ix = x0 + ox;
@@ -505,8 +526,17 @@ template <bool FWD, int NB8>
 static void b4_launch(const B4P& p, hipStream_t st) {
   constexpr int PS = (2 * ((NB8 + 1) / 2) + 1) * 16;
   const size_t lds = (size_t)(B4_N0 + B4_N1 + B4_N2) * PS + B4_BIAS_BYTES + B4_LUT_BYTES;
-  (void)hipFuncSetAttribute((const void*)blk4_kernel<FWD, NB8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL((blk4_kernel<FWD, NB8>), dim3(p.ntiles), dim3(256), lds, st, p);
+  static const int nw_env = [] { const char* e = getenv("CGEN_BLK4_NW"); return e ? atoi(e) : 0; }();  // (4 / 8: force; measurements only)
+  // (the data gradient runs next to the background weight-gradient kernel: an eight-wave workgroup has to find eight free wave slots on
+  //  one CU at once and waits for that kernel's workgroups to retire -- mimic224 22.4 -> 24.7 ms/step with eight waves there)
+  const bool eight = nw_env == 84 ? FWD && p.ntiles <= 1024 : (nw_env ? nw_env == 8 : FWD && p.ntiles <= 1024);
+  if (eight) {
+    (void)hipFuncSetAttribute((const void*)blk4_kernel<FWD, NB8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((blk4_kernel<FWD, NB8, 8>), dim3(p.ntiles), dim3(512), lds, st, p);
+  } else {
+    (void)hipFuncSetAttribute((const void*)blk4_kernel<FWD, NB8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((blk4_kernel<FWD, NB8, 4>), dim3(p.ntiles), dim3(256), lds, st, p);
+  }
 }
 template <bool FWD>
 static void b4_launch_dir(const B4P& p, const int nb8, hipStream_t st) {

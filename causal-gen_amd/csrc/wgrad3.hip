@@ -631,6 +631,7 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
     W3_STAMP();
     const uint32_t bufP = lds0 + slot * slot_bytes, bufS = bufP + pbytes;
     (void)bufS;
+#ifndef W3_ABL_NOGELU
     if constexpr (!RP && !RS) if (gelu) {  // in-place activation of the staged X tile (ReLU is applied to the fragments instead)
       const uint32_t xb = x_is_s ? bufS : bufP;
       const int nb16 = (x_is_s ? gp->S.bytes : pbytes) >> 4;
@@ -640,6 +641,7 @@ __device__ __forceinline__ void wg3_body(const Wg3P* __restrict__ gp, const int 
       }
       W3_BARRIER();
     }
+#endif
     // K16-steps of the tile.  Lane addresses advance by increments (two adds per operand base, the P fragments hang off one base by
     // immediate offsets); the fragment reads of step k + 1 are issued before the MFMAs of step k (two register sets) where the
     // fragment block leaves room; the first four steps carry the DMA requests of the tile two ahead.
