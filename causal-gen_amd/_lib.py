@@ -88,6 +88,8 @@ PROTOTYPES = {
     "cgen_block3_pair": [C.POINTER(Block3Args), C.POINTER(Block3Args), vp],
     "cgen_block4_supported": [C.POINTER(Block4Args)],
     "cgen_block4": [C.POINTER(Block4Args), vp],
+    "cgen_block4_pair_supported": [C.POINTER(Block4Args), C.POINTER(Block4Args)],
+    "cgen_block4_pair": [C.POINTER(Block4Args), C.POINTER(Block4Args), vp],
     "cgen_conv2d_wgrad_plan": [C.POINTER(WgradArgs), C.POINTER(i32)],
     "cgen_conv2d_wgrad_batch_plan": [vp, i32, vp, i64, vp, vp, i32, vp, vp],
     "cgen_conv2d_wgrad_batch_run": [vp, vp, i32, i32, vp],
@@ -145,9 +147,9 @@ PROTOTYPES = {
     "cgen_rng_advance": [vp, u64, vp],
 }
 _RESTYPES = {"cgen_last_error": C.c_char_p}
-ABI_VERSION = 406  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
+ABI_VERSION = 407  # CGEN_ABI_VERSION of include/cgen_hip.h this binding was written against
 _NOCHECK = {"cgen_version", "cgen_h16_format", "cgen_last_error", "cgen_conv2d_wgrad_plan", "cgen_reparam_kl_chunks", "cgen_like_chunks",
-            "cgen_block3_supported", "cgen_block4_supported", "cgen_block3_pair_supported", "cgen_conv2d_pair_supported", "cgen_stem_conv_supported"}
+            "cgen_block3_supported", "cgen_block4_supported", "cgen_block4_pair_supported", "cgen_block3_pair_supported", "cgen_conv2d_pair_supported", "cgen_stem_conv_supported"}
 
 
 class WgradBatchLaunch(C.Structure):

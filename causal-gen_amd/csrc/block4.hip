@@ -151,11 +151,10 @@ __device__ __forceinline__ h16x8 b4_as_h(const uint4 v) {
 //   data gradient:  v = acc * gelu'(aux);  mid <- rn16(v) (centre);  LDS <- rn16(v), zero outside the image
 template <bool FWD, int HW>
 __device__ __forceinline__ void b4_post(const b4_f32x16& acc, const int chb, const float* __restrict__ biasL, const float4* __restrict__ lut0,
-                                        const B4V& mid, const B4V& aux, const int n, const int iy, const int ix, const bool inimg, const bool centre,
+                                        const B4V& mid, const uint2* apre, const int n, const int iy, const int ix, const bool inimg, const bool centre,
                                         const bool write, char* __restrict__ dst) {
   constexpr int NU = HW / 4;
   uint2 h[NU];
-  const char* ap = FWD ? nullptr : aux.p + (n * aux.sn + iy * aux.sh + ix * aux.sw) + chb * 2;
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
     float v[4] = {acc[4 * u], acc[4 * u + 1], acc[4 * u + 2], acc[4 * u + 3]};
@@ -163,7 +162,7 @@ __device__ __forceinline__ void b4_post(const b4_f32x16& acc, const int chb, con
       const float4 bq = *(const float4*)(biasL + chb + 4 * u);
       v[0] += bq.x; v[1] += bq.y; v[2] += bq.z; v[3] += bq.w;
     } else {
-      const uint2 t = *(const uint2*)(inimg ? ap + 8 * u : (const char*)g_b4zero);
+      const uint2 t = apre[u];  // (requested before the group's K loop: b4_aux_load)
       float d[4];
       b4_gelu4_bwd(t, d, lut0);
       v[0] *= d[0]; v[1] *= d[1]; v[2] *= d[2]; v[3] *= d[3];
@@ -198,11 +197,21 @@ __device__ __forceinline__ void b4_post(const b4_f32x16& acc, const int chb, con
 // (the post-operation of 32-row block MB of a bottleneck of NB8 eight-channel groups)
 template <bool FWD, int NB8, int MB>
 __device__ __forceinline__ void b4_post_mb(const b4_f32x16& acc, const int kg, const float* __restrict__ biasL, const float4* __restrict__ lut0,
-                                           const B4V& mid, const B4V& aux, const int n, const int iy, const int ix, const bool inimg, const bool centre,
+                                           const B4V& mid, const uint2* apre, const int n, const int iy, const int ix, const bool inimg, const bool centre,
                                            const bool write, char* __restrict__ pix) {
   constexpr int NREAL = (8 * NB8 - 32 * MB) < 32 ? (8 * NB8 - 32 * MB) : 32, HW = NREAL / 2;
   const int chb = 32 * MB + HW * kg;
-  b4_post<FWD, HW>(acc, chb, biasL, lut0, mid, aux, n, iy, ix, inimg, centre, write, pix + chb * 2);
+  b4_post<FWD, HW>(acc, chb, biasL, lut0, mid, apre, n, iy, ix, inimg, centre, write, pix + chb * 2);
+}
+// (data gradient) the gelu' sources of a pixel group, requested BEFORE its K loop: up to four 8-byte units per 32-row block and lane
+template <bool FWD, int NB8, int MB>
+__device__ __forceinline__ void b4_aux_load(uint2* apre, const B4V& aux, const int n, const int iy, const int ix, const bool inimg, const int kg) {
+  constexpr int NREAL = (8 * NB8 - 32 * MB) < 32 ? (8 * NB8 - 32 * MB) : 32, HW = NREAL / 2;
+  if constexpr (!FWD) {
+    const char* ap = aux.p + (n * aux.sn + iy * aux.sh + ix * aux.sw) + (32 * MB + HW * kg) * 2;
+#pragma unroll
+    for (int u = 0; u < HW / 4; ++u) apre[u] = *(const uint2*)(inimg ? ap + 8 * u : (const char*)g_b4zero);
+  }
 }
 // a pixel group wholly outside the image: its activated values are zeros (the lane pair of a pixel clears its NB16 32-byte groups)
 template <int NB16>
@@ -233,6 +242,9 @@ __device__ __forceinline__ void b4_conv3(const B4P& p, const char* __restrict__ 
     char* const pix = Uout + (my * POUT + mx) * PS;
     if (__builtin_amdgcn_ballot_w64(inimg) == 0) { b4_clear<NB16>(pix, kg, live); continue; }
     const char* const bsrc = Uin + (my * PIN + mx) * PS + kg * 16;
+    uint2 apre[NMB][4];
+    b4_aux_load<FWD, NB8, 0>(apre[0], p.aux[PH], n, iy, ix, inimg, kg);
+    if constexpr (NMB > 1) b4_aux_load<FWD, NB8, 1>(apre[1], p.aux[PH], n, iy, ix, inimg, kg);
     b4_f32x16 acc[NMB];
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
@@ -248,15 +260,16 @@ __device__ __forceinline__ void b4_conv3(const B4P& p, const char* __restrict__ 
       }
     }
     const bool centre = inimg && my >= OFF && my < OFF + th && mx >= OFF && mx < OFF + tw;
-    b4_post_mb<FWD, NB8, 0>(acc[0], kg, biasL + 64 * PH, lut0, p.mid[PH], p.aux[PH], n, iy, ix, inimg, centre, live, pix);
-    if constexpr (NMB > 1) b4_post_mb<FWD, NB8, 1>(acc[1], kg, biasL + 64 * PH, lut0, p.mid[PH], p.aux[PH], n, iy, ix, inimg, centre, live, pix);
+    b4_post_mb<FWD, NB8, 0>(acc[0], kg, biasL + 64 * PH, lut0, p.mid[PH], apre[0], n, iy, ix, inimg, centre, live, pix);
+    if constexpr (NMB > 1) b4_post_mb<FWD, NB8, 1>(acc[1], kg, biasL + 64 * PH, lut0, p.mid[PH], apre[1], n, iy, ix, inimg, centre, live, pix);
   }
 }
 
 // NW: waves per workgroup -- 4, or 8 where the launch has few tiles (<= 1024: one round of resident workgroups, the time of the launch is
 // the dependent chain of ONE tile, and twice the waves halve the pixel groups each has to walk)
+// (the kernel body: workgroup `tile` of problem p)
 template <bool FWD, int NB8, int NW>
-__global__ __launch_bounds__(64 * NW, NB8 <= 2 ? 4 : (NB8 <= 4 ? (NW == 8 ? 4 : 3) : 2)) void blk4_kernel(const B4P p) {
+__device__ __forceinline__ void blk4_body(const B4P& p, const int tile) {
   constexpr int NT = 64 * NW;
   constexpr int NB16 = (NB8 + 1) / 2, NMB = (NB16 + 1) / 2, PS = (2 * NB16 + 1) * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -268,7 +281,6 @@ __global__ __launch_bounds__(64 * NW, NB8 <= 2 ? 4 : (NB8 <= 4 ? (NW == 8 ? 4 : 
   const float4* const lut0 = lut + 192;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int px = lane & 31, kg = lane >> 5;
-  const int tile = blockIdx.x;
   const int b1 = b4_div(tile, p.d_tx), tx = tile - b1 * p.tiles_x;
   const int n = b4_div(b1, p.d_ty);
   const int y0 = (b1 - n * p.tiles_y) * B4_TH, x0 = tx * B4_TW;
@@ -302,6 +314,9 @@ __global__ __launch_bounds__(64 * NW, NB8 <= 2 ? 4 : (NB8 <= 4 ? (NW == 8 ? 4 : 
       const bool ok = live && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
       char* const pix = U0 + (hy * B4_P0 + hx) * PS;
       if (__builtin_amdgcn_ballot_w64(ok) == 0) { b4_clear<NB16>(pix, kg, live); continue; }
+      uint2 apre[NMB][4];
+      b4_aux_load<FWD, NB8, 0>(apre[0], p.aux[0], n, iy, ix, ok, kg);
+      if constexpr (NMB > 1) b4_aux_load<FWD, NB8, 1>(apre[1], p.aux[0], n, iy, ix, ok, kg);
       b4_f32x16 acc[NMB];
 #pragma unroll
       for (int mb = 0; mb < NMB; ++mb)
@@ -358,8 +373,8 @@ __global__ __launch_bounds__(64 * NW, NB8 <= 2 ? 4 : (NB8 <= 4 ? (NW == 8 ? 4 : 
         if (j + 1 < nch) consume(sb);
       }
       const bool centre = ok && hy >= 2 && hy < 2 + th && hx >= 2 && hx < 2 + tw;
-      b4_post_mb<FWD, NB8, 0>(acc[0], kg, biasL, lut0, p.mid[0], p.aux[0], n, iy, ix, ok, centre, live, pix);
-      if constexpr (NMB > 1) b4_post_mb<FWD, NB8, 1>(acc[1], kg, biasL, lut0, p.mid[0], p.aux[0], n, iy, ix, ok, centre, live, pix);
+      b4_post_mb<FWD, NB8, 0>(acc[0], kg, biasL, lut0, p.mid[0], apre[0], n, iy, ix, ok, centre, live, pix);
+      if constexpr (NMB > 1) b4_post_mb<FWD, NB8, 1>(acc[1], kg, biasL, lut0, p.mid[0], apre[1], n, iy, ix, ok, centre, live, pix);
     }
   }
   __syncthreads();
@@ -445,6 +460,19 @@ __global__ __launch_bounds__(64 * NW, NB8 <= 2 ? 4 : (NB8 <= 4 ? (NW == 8 ? 4 : 
       }
     }
   }
+}
+
+template <bool FWD, int NB8, int NW>
+__global__ __launch_bounds__(64 * NW, NB8 <= 2 ? 4 : (NB8 <= 4 ? (NW == 8 ? 4 : 3) : 2)) void blk4_kernel(const B4P p) {
+  blk4_body<FWD, NB8, NW>(p, blockIdx.x);
+}
+// Two independent DATA-GRADIENT problems of one instance in one launch: workgroups 0 .. na - 1 take the first, the rest the second
+// (the backward of a decoder layer's posterior and prior Blocks, vae.py:240-301: at <= 28x28 a launch is <= 256 tiles and its time is
+// ONE tile's dependent chain -- two launches back to back are two chains, one launch is one)
+template <int NB8>
+__global__ __launch_bounds__(256, NB8 <= 2 ? 4 : (NB8 <= 4 ? 3 : 2)) void blk4_pair_kernel(const B4P pa, const B4P pb, const int na) {
+  if ((int)blockIdx.x < na) blk4_body<false, NB8, 4>(pa, blockIdx.x);
+  else blk4_body<false, NB8, 4>(pb, blockIdx.x - na);
 }
 
 // ----------------------------------------------------------------------------- host side
@@ -559,6 +587,40 @@ extern "C" int cgen_block4_supported(const cgen_block4_args* a) {
   B4P p;
   int nb8;
   return b4_fill(a, p, nb8);
+}
+
+template <int NB8>
+static void b4_launch_pair(const B4P& pa, const B4P& pb, hipStream_t st) {
+  constexpr int PS = (2 * ((NB8 + 1) / 2) + 1) * 16;
+  const size_t lds = (size_t)(B4_N0 + B4_N1 + B4_N2) * PS + B4_BIAS_BYTES + B4_LUT_BYTES;
+  (void)hipFuncSetAttribute((const void*)blk4_pair_kernel<NB8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL((blk4_pair_kernel<NB8>), dim3(pa.ntiles + pb.ntiles), dim3(256), lds, st, pa, pb, pa.ntiles);
+}
+static int b4_pair_fill(const cgen_block4_args* a, const cgen_block4_args* b, B4P& pa, B4P& pb, int& nb8) {
+  int nb8b = 0;
+  if (!a || !b || a->fwd || b->fwd) return 0;
+  if (!b4_fill(a, pa, nb8) || !b4_fill(b, pb, nb8b) || nb8 != nb8b) return 0;
+  return (int64_t)pa.ntiles + pb.ntiles < ((int64_t)1 << 30);
+}
+extern "C" int cgen_block4_pair_supported(const cgen_block4_args* a, const cgen_block4_args* b) {
+  B4P pa, pb;
+  int nb8;
+  return b4_pair_fill(a, b, pa, pb, nb8);
+}
+extern "C" int cgen_block4_pair(const cgen_block4_args* a, const cgen_block4_args* b, cgen_stream_t stream) {
+  B4P pa, pb;
+  int nb8 = 0;
+  CGEN_REQUIRE(b4_pair_fill(a, b, pa, pb, nb8), "cgen_block4_pair: two data-gradient problems of one bottleneck class (ask cgen_block4_pair_supported first)");
+  switch (nb8) {
+    case 1: b4_launch_pair<1>(pa, pb, (hipStream_t)stream); break;
+    case 2: b4_launch_pair<2>(pa, pb, (hipStream_t)stream); break;
+    case 3: b4_launch_pair<3>(pa, pb, (hipStream_t)stream); break;
+    case 4: b4_launch_pair<4>(pa, pb, (hipStream_t)stream); break;
+    case 5: b4_launch_pair<5>(pa, pb, (hipStream_t)stream); break;
+    case 6: b4_launch_pair<6>(pa, pb, (hipStream_t)stream); break;
+    default: b4_launch_pair<8>(pa, pb, (hipStream_t)stream); break;
+  }
+  return check_launch("cgen_block4_pair");
 }
 
 extern "C" int cgen_block4(const cgen_block4_args* a, cgen_stream_t stream) {

@@ -364,6 +364,10 @@ class Engine(WgradMixin):
         # fused default Block (vae.py:57-71; csrc/block4.hip): the four convs of a non-light Block as one launch, forward and data gradient
         self.blk4_on = int(os.environ.get("CGEN_BLK4", "1")) if self.dt == F16 else 0
         self.blk4_launches = 0
+        # ... and the data gradients of a decoder layer's posterior and prior Blocks in one launch (cgen_block4_pair), as _bw_block3 does
+        self.blk4_pair = os.environ.get("CGEN_BLK4_PAIR", "1") != "0"
+        self.blk4_pairs = 0
+        self._blk4_arm, self._blk4_hold = 0, None
         # the row-streaming instance (96x96 / 192x192 Blocks, csrc/block.hip blk3r): CGEN_BLK3R=0 off; where it serves a shape the side
         # policy below (blk3_res) does not apply
         self.blk3_rows = int(os.environ.get("CGEN_BLK3R", "1"))
@@ -419,8 +423,8 @@ class Engine(WgradMixin):
         self._wg_events = []
         self._wg_reduced, self._wg_seen = 0, set()
         self._riders = {}
-        self._blk3_arm = self._conv_arm = 0  # (a pass that ended in an exception may have left a launch held)
-        self._blk3_hold = self._conv_hold = None
+        self._blk3_arm = self._conv_arm = self._blk4_arm = 0  # (a pass that ended in an exception may have left a launch held)
+        self._blk3_hold = self._conv_hold = self._blk4_hold = None
         self.pgrad_init = set()
         self._pnhwc, self._pgrad_tmp = {}, {}
         self._adopted = set()
@@ -929,9 +933,11 @@ class Engine(WgradMixin):
 
     def _bw_block4(self, sites, segs, ts, out, res1):
         """Backward of a fused default Block: weight gradients as for the four convs (deferred, batched); the four data-gradient
-        convs + GELU derivatives as ONE launch of cgen_block4 (fwd = 0), with one output per differentiable input segment."""
+        convs + GELU derivatives as ONE launch of cgen_block4 (fwd = 0), with one output per differentiable input segment -- or half of
+        a pair launch with the layer's other Block (cgen_block4_pair; armed by backward())."""
         g = self.grad_read(out)
         if g is None:
+            self._blk4_flush()
             return
         s0, s1, s2, s3 = sites
         t0, t1, t2 = ts
@@ -941,12 +947,14 @@ class Engine(WgradMixin):
         ok = (1 <= len(dsegs) <= 3 and "p0_dg" in s3.frag and "p1_dg" in s2.frag and "p2_dg" in s1.frag
               and all(("p3_dg", k) in s0.frag for k in dsegs) and all(segs[k].c % 8 == 0 for k in dsegs) and g.c % 8 == 0)
         if not ok:
+            self._blk4_flush()
             self._bw_conv(s3, [t2], act, out, res1, None)
             self._bw_conv(s2, [t1], act, t2, None, None)
             self._bw_conv(s1, [t0], act, t1, None, None)
             self._bw_conv(s0, segs, act, t0, None, None)
             return
         if res1 is not None and res1.rg:
+            self._blk4_flush()  # (a residual Block is never the second of a pair: its residual gradient is a launch of its own)
             # (the fused launch reads grad(out) WITH a halo while it writes grad(x): x may adopt grad(out)'s buffer only when its
             #  later accumulation goes out of place -- which is the case exactly when weight gradients are deferred, _dgrad_target)
             self._grad_residual(res1, g, out, [t2] if self._defer_wgrad() else [t2] + list(segs))
@@ -971,25 +979,61 @@ class Engine(WgradMixin):
             a.o[j].w, a.o[j].bias = s0.frag[("p3_dg", k)], None
             a.o[j].out, a.o[j].aux = gv.cv(), sg.cv()
             a.o[j].res1 = prev.cv() if acc else NULL_VIEW
+        def late():  # the weight gradients that READ what the launch writes: queued only behind it (a background flush must not see them earlier)
+            if wg:
+                if self._needs_wgrad(s2):
+                    self._wgrad(s2, [t1], act, g2)
+                if self._needs_wgrad(s1):
+                    self._wgrad(s1, [t0], act, g1)
+                if self._needs_wgrad(s0):
+                    self._wgrad(s0, segs, act, g0)
+
         if self.lib.block4_supported(C.byref(a)):
+            # tensors this launch writes / reads (storage identity): a pair must not touch each other's
+            wr = {id(g2.base), id(g1.base), id(g0.base)} | {id(gv.base) for (_, gv, _, _) in tgt}
+            rd = ({id(g.base), id(t0.base), id(t1.base), id(t2.base)} | {id(segs[k].base) for (k, _, _, _) in tgt}
+                  | {id(prev.base) for (_, _, prev, acc) in tgt if acc})
+            if self._blk4_arm == 1 and self.prof is None:
+                self._blk4_hold = (a, self.launches, wr, rd, late, (sites, x0))  # held: the partner launches both
+                self._blk4_arm = 2
+                return
+            if self._blk4_hold is not None:
+                ha, hl, hwr, hrd, hlate, _ = self._blk4_hold
+                if (hl == self.launches and not (hwr & (wr | rd)) and not (wr & hrd)
+                        and self.lib.block4_pair_supported(C.byref(ha), C.byref(a))):
+                    self._blk4_hold, self._blk4_arm = None, 0
+                    self.lib.block4_pair(C.byref(ha), C.byref(a), self.stream)
+                    self.launches += 1
+                    self.blk4_pairs += 1
+                    self.blk4_launches += 1
+                    hlate()
+                    late()
+                    return
+                self._blk4_flush()
             self._timed_blk4("conv_dgrad", sites, x0, lambda: self.lib.block4(C.byref(a), self.stream))
             self.blk4_launches += 1
         else:
             # the REAL gradient views are not served (an oddly laid-out accumulate target): the four data-gradient convs, into the
             # targets already acquired (the bookkeeping above has run and must not run twice)
+            self._blk4_flush()
             self._dgrad_launch(s3, g, t2, 0, act, t2, g2, g2, False)
             self._dgrad_launch(s2, g2, t1, 0, act, t1, g1, g1, False)
             self._dgrad_launch(s1, g1, t0, 0, act, t0, g0, g0, False)
             for (k, gv, prev, acc) in tgt:
                 self._dgrad_launch(s0, g0, segs[k], k, act, x0, gv, prev, acc)
             self._conv_flush()
-        if wg:
-            if self._needs_wgrad(s2):
-                self._wgrad(s2, [t1], act, g2)
-            if self._needs_wgrad(s1):
-                self._wgrad(s1, [t0], act, g1)
-            if self._needs_wgrad(s0):
-                self._wgrad(s0, segs, act, g0)
+        late()
+
+    def _blk4_flush(self):
+        """Launch a held fused default-Block data gradient on its own (its partner did not come, or cannot share the launch)."""
+        self._blk4_arm = 0
+        if self._blk4_hold is None:
+            return
+        ha, _, _, _, hlate, (sites, x0) = self._blk4_hold
+        self._blk4_hold = None
+        self._timed_blk4("conv_dgrad", sites, x0, lambda: self.lib.block4(C.byref(ha), self.stream))
+        self.blk4_launches += 1
+        hlate()
 
     def _timed_blk4(self, kind, sites, x0, fn):
         """A fused default-Block launch, tallied (when profiling) with the algorithmic FLOPs of the FOUR convs it executes."""
@@ -1503,12 +1547,13 @@ class Engine(WgradMixin):
                         self._bw_set_mark()
             self._bw_end()
         else:
-            self.blk3_pairs = self.conv_pairs = 0
+            self.blk3_pairs = self.conv_pairs = self.blk4_pairs = 0
             skip = 0
             tape = self.tape
             for i in range(len(tape) - 1, -1, -1):
                 fn, args, _ = tape[i]
                 if fn == self._bw_block3:
+                    self._blk4_flush()
                     # (armed when the NEXT entry is a fused Block of the same image size without a residual: the layer's prior Block)
                     nxt = tape[i - 1] if i > 0 else None
                     # ... and reads none of this Block's differentiable inputs: else its bookkeeping (an accumulate target, a
@@ -1521,8 +1566,22 @@ class Engine(WgradMixin):
                     fn(*args)
                     if self._blk3_arm == 1:  # (it did not reach its launch point)
                         self._blk3_arm = 0
+                elif fn == self._bw_block4:
+                    self._blk3_flush()
+                    # (armed when the NEXT entry is a fused default Block of the same image size without a residual -- the layer's prior
+                    #  Block -- that reads none of this Block's differentiable inputs nor its output: the rule of the light Blocks above)
+                    nxt = tape[i - 1] if i > 0 else None
+                    if (self.blk4_pair and self._blk4_hold is None and nxt is not None and nxt[0] == self._bw_block4
+                            and nxt[1][4] is None and nxt[1][1][0].h == args[1][0].h and nxt[1][1][0].w == args[1][0].w
+                            and not ({id(v.base) for v in args[1] if v.rg} & {id(v.base) for v in nxt[1][1] if v.rg})
+                            and not any(v.base is nxt[1][3].base for v in args[1])):
+                        self._blk4_arm = 1
+                    fn(*args)
+                    if self._blk4_arm == 1:  # (it did not reach its launch point)
+                        self._blk4_arm = 0
                 else:
                     self._blk3_flush()
+                    self._blk4_flush()
                     if skip:
                         skip -= 1
                         continue
@@ -1544,6 +1603,7 @@ class Engine(WgradMixin):
                     fn(*args)
                     self._conv_flush()
             self._blk3_flush()
+            self._blk4_flush()
             self._conv_flush()
         for bid in list(self._riders):
             gv, g, acc = self._riders.pop(bid)

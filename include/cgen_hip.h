@@ -58,7 +58,7 @@ typedef struct cgen_view {
 /* ABI version of this header.  cgen_version() of the loaded library must equal it (causal-gen_amd/_lib.py checks): struct layouts,
  * enum values and signatures are only compatible within one version.  cgen_h16_format(): the 16-bit storage format the library was
  * BUILT for -- 0 = IEEE binary16 (default), 1 = bfloat16 (-DCGEN_H16_BF16, an A/B build); CGEN_F16 tensors must be in that format. */
-#define CGEN_ABI_VERSION 406
+#define CGEN_ABI_VERSION 407
 int cgen_version(void);
 int cgen_h16_format(void);
 const char* cgen_last_error(void);
@@ -170,6 +170,11 @@ typedef struct cgen_block4_args {
 } cgen_block4_args;
 int cgen_block4_supported(const cgen_block4_args* a);
 int cgen_block4(const cgen_block4_args* a, cgen_stream_t stream);
+/* Two independent DATA-GRADIENT problems (fwd = 0) of the same bottleneck class (ceil(b / 8) equal) in ONE launch: the backward of a
+ * decoder layer's posterior and prior Blocks (vae.py:240-301).  Bit-identical to two cgen_block4 calls; the caller guarantees that
+ * neither problem reads or accumulates into a tensor the other one writes. */
+int cgen_block4_pair_supported(const cgen_block4_args* a, const cgen_block4_args* b);
+int cgen_block4_pair(const cgen_block4_args* a, const cgen_block4_args* b, cgen_stream_t stream);
 
 /* Weight gradient (aten::convolution_backward, weight/bias part) as split-K partials:
  *   partial_w[split][Co][KS*KS][Ci_total] (f32), partial_b[split][Co] (f32, may be NULL)

@@ -143,3 +143,82 @@ def test_block4_declines_what_it_does_not_serve():
     assert lib.block4_supported(C.byref(a)) == 0
     a.b, a.dtype = 16, _lib.F32
     assert lib.block4_supported(C.byref(a)) == 0
+
+
+def _run_two(N, H, W, b, segA, rgA, coA, segB, rgB, coB, pair, share=False, seed=0):
+    """Two independent default Blocks recorded back to back (the posterior and the prior Block of a decoder layer, vae.py:240-301), one
+    backward pass: with `pair` their data gradients share a launch (cgen_block4_pair)."""
+    from causal_gen_amd.engine import ConvSite, Engine
+
+    g = torch.Generator().manual_seed(91 + seed + H)
+    convs, blocks, ins, gouts = [], [], [], []
+    for k, (segc, co) in enumerate(((segA, coA), (segB, coB))):
+        ci = sum(segc)
+        cs = [torch.nn.Conv2d(ci, b, 1), torch.nn.Conv2d(b, b, 3, padding=1), torch.nn.Conv2d(b, b, 3, padding=1), torch.nn.Conv2d(b, co, 1)]
+        with torch.no_grad():
+            for c in cs:
+                c.weight.copy_(torch.randn(c.weight.shape, generator=g) * 1.6 / math.sqrt(c.in_channels * c.kernel_size[0] ** 2))
+                c.bias.copy_(torch.randn(c.out_channels, generator=g) * 0.2)
+        convs += cs
+        ins.append([torch.randn(N, c, H, W, generator=g).half().float() for c in segc])
+        gouts.append(torch.randn(N, co, H, W, generator=g).half().float())
+    eng = Engine("cuda", "f16")
+    eng.blk4_on, eng.blk4_pair = 1, pair
+    holder = torch.nn.ModuleList(convs).cuda()
+    sites = []
+    for k, (segc, rg) in enumerate(((segA, rgA), (segB, rgB))):
+        four = [ConvSite("b%dc0" % k, holder[4 * k], segc, [bool(r) for r in rg], 4 * k)]
+        four += [ConvSite("b%dc%d" % (k, j), holder[4 * k + j], [b], [True], 4 * k + j) for j in (1, 2, 3)]
+        for r in range(4):
+            four[r].blk4 = (r, four)
+        blocks.append(four)
+        sites += four
+    eng.bind(holder, sites)
+    eng.begin()
+    eng.prepare_weights(force=True)
+    eng.recording = True
+    nts, ys = [], []
+    for k in (1, 0):  # tape: [B][A] -- backward() meets A first, then B
+        rg = (rgA, rgB)[k]
+        if share and k == 0:
+            t = nts[0][1]   # A reads B's INPUT tensor: both data gradients accumulate into one buffer -> no pair
+        else:
+            t = [eng.from_nchw(x.cuda(), rg=bool(r)) for x, r in zip(ins[k], rg)]
+            nts.append((k, t))
+        y = eng.block4(blocks[k], t)
+        assert y is not None
+        ys.append((k, y))
+    for k, y in ys:
+        gy = eng.seed_grad(y)
+        eng.lib.axpby(eng.dt, N, H, W, eng.from_nchw(gouts[k].cuda()).cv(), gy.cv(), 1.0, 1.0, 1 << 30, 0, eng.stream)
+    eng.recording = False
+    eng.backward()
+    torch.cuda.synchronize()
+    out = []
+    for k, t in nts:
+        out += [eng.to_nchw(eng.grad_read(v)).cpu() for v in t if v.rg]
+    out += [eng.param_grad_view(p).cpu().clone() for c in holder for p in (c.weight, c.bias)]
+    return out, eng.blk4_pairs
+
+
+@pytest.mark.parametrize("shape", [
+    (32, 28, 28, 32, [128, 6, 128], [1, 0, 1], 32, [128], [1], 160),      # a 28^2 decoder layer of mimic224: posterior cat[h, pa, acts] | prior
+    (256, 16, 16, 8, [32, 12, 32], [1, 0, 1], 32, [32, 12], [1, 0], 64),  # a 16^2 layer of morphomnist (conditional prior) at batch 256
+    (4, 8, 8, 48, [192, 6, 192], [1, 0, 1], 32, [192], [1], 224),         # 8^2: bottleneck 48
+    (3, 20, 28, 16, [64], [1], 96, [64, 4], [1, 0], 32),                  # ragged image
+], ids=["28x28", "16x16-b256", "8x8", "ragged"])
+def test_block4_pair_launch_is_bit_identical_to_two_launches(shape):
+    a, pa = _run_two(*shape, pair=False)
+    b, pb = _run_two(*shape, pair=True)
+    assert pa == 0 and pb == 1, (pa, pb)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), float((x - y).abs().max())
+
+
+def test_block4_blocks_that_share_an_input_are_not_paired():
+    shape = (4, 16, 16, 8, [32], [1], 32, [32], [1], 64)
+    a, pa = _run_two(*shape, pair=False, share=True)
+    b, pb = _run_two(*shape, pair=True, share=True)
+    assert pa == 0 and pb == 0
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
