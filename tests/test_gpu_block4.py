@@ -222,3 +222,95 @@ def test_block4_blocks_that_share_an_input_are_not_paired():
     assert pa == 0 and pb == 0
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("shape", [(4, 28, 28, 128, 32), (8, 16, 16, 32, 8), (4, 14, 14, 160, 40)], ids=["28x28", "16x16", "14x14"])
+def test_fused_block4_remainder_planes(shape):
+    """Residual-trunk default Blocks of an inference pass (value = hi + rem): cgen_block4 reads res1 as hi + rem and writes
+    out = rn16(v), out_rem = rn16(v - out), like the four-launch path's last conv.  Two chained trunk Blocks, so the second one CONSUMES
+    a remainder plane; hi + rem against an f64 reference (torch erf GELU) on the f16-quantised operands, and against the plain tensor."""
+    from causal_gen_amd.engine import NT, ConvSite, Engine
+
+    N, H, W, ci, b = shape
+    g = torch.Generator().manual_seed(H + ci)
+    cs = [torch.nn.Conv2d(ci, b, 1), torch.nn.Conv2d(b, b, 3, padding=1), torch.nn.Conv2d(b, b, 3, padding=1), torch.nn.Conv2d(b, ci, 1)]
+    with torch.no_grad():
+        for c in cs:
+            c.weight.copy_(torch.randn(c.weight.shape, generator=g) * 1.6 / math.sqrt(c.in_channels * c.kernel_size[0] ** 2))
+    x = (torch.randn(N, ci, H, W, generator=g) * 3).half().float()
+    eng = Engine("cuda", "f16")
+    holder = torch.nn.ModuleList(cs).cuda()
+    sites = [ConvSite("c0", holder[0], [ci], [True], 0)] + [ConvSite(f"c{k}", holder[k], [b], [True], k) for k in (1, 2, 3)]
+    for r in range(4):
+        sites[r].blk4 = (r, sites)
+    eng.blk4_on = 1
+    eng.bind(holder, sites)
+    eng.begin()
+    eng.prepare_weights(force=True)
+    eng.recording = False
+    assert eng.trunk_rem
+    h0 = eng.from_nchw(x.cuda())
+    n0 = eng.launches
+    h1 = eng.block4(sites, [h0], res1=h0, trunk=True)   # produces a remainder plane
+    h2 = eng.block4(sites, [h1], res1=h1, trunk=True)   # consumes one and produces one
+    assert eng.launches - n0 == 2 and h1.rem and h2.rem
+    planes = []
+    for t in (h1, h2):
+        r = NT(t.ptr + t.rem, t.n, t.h, t.w, t.c, t.sn, t.sh, t.sw, t.es, rg=False, keep=t.keep)
+        planes.append((eng.to_nchw(t).double().cpu(), eng.to_nchw(r).double().cpu()))
+    torch.cuda.synchronize()
+    ws = [c.weight.detach().cpu().half().double() for c in cs]
+    bs = [c.bias.detach().cpu().double() for c in cs]
+
+    def act(t):  # an MFMA operand: GELU of the stored f16 value, rounded to f16
+        return F.gelu(t).half().double()
+
+    def block(hi, v):  # conv inputs read hi alone; the residual adds the full value; the bottleneck tensors are stored in f16
+        t = F.conv2d(act(hi), ws[0], bs[0]).half().double()
+        t = F.conv2d(act(t), ws[1], bs[1], padding=1).half().double()
+        t = F.conv2d(act(t), ws[2], bs[2], padding=1).half().double()
+        return v + F.conv2d(act(t), ws[3], bs[3])
+
+    (hi1, rem1), (hi2, rem2) = planes
+    v1 = block(x.double(), x.double())
+    assert float((hi1.half() != (hi1 + rem1).half()).float().mean()) < 1e-3
+    e1 = ((hi1 + rem1) - v1).abs()
+    assert float(e1.mean()) <= 2e-5 * float(v1.abs().max()) and float(e1.max()) <= 2e-2, (float(e1.mean()), float(e1.max()))
+    v2 = block(hi1, hi1 + rem1)
+    e2, plain = ((hi2 + rem2) - v2).abs(), (hi2 - v2).abs()
+    assert float(e2.mean()) <= 2e-5 * float(v2.abs().max()) and float(e2.max()) <= 2e-2, (float(e2.mean()), float(e2.max()))
+    assert float(e2.mean()) * 5 < float(plain.mean()), (float(e2.mean()), float(plain.mean()))
+
+
+def test_fused_block4_fuzzed_shapes():
+    """Random default-Block shapes (sides 1..40, bottlenecks 4..48, one to three segments, ragged channel counts) through the kernel
+    against the four-launch path: forward and every gradient."""
+    import random
+
+    rnd = random.Random(20260930)
+    n_ok = 0
+    for it in range(24):
+        H, W = rnd.randint(1, 40), rnd.randint(1, 40)
+        b = rnd.choice([4, 8, 12, 16, 20, 24, 32, 40, 48])
+        nseg = rnd.randint(1, 3)
+        segc = [rnd.choice([8, 16, 24, 32, 40, 64, 72, 96]) for _ in range(nseg)]
+        segrg = [1] + [rnd.randint(0, 1) for _ in range(nseg - 1)]
+        if nseg >= 2 and rnd.random() < 0.5:
+            segc[1], segrg[1] = rnd.choice([4, 6, 12, 20]), 0  # a parents-like segment: ragged, no gradient
+        with_res = rnd.random() < 0.5
+        co = segc[0] if with_res else rnd.choice([8, 16, 32, 48, 64, 104, 160])
+        case = (rnd.randint(1, 5), H, W, segc, segrg, b, co, with_res)
+        four, one = _run(case, 0, seed=it), _run(case, 1, seed=it)
+        assert one["fwd_launches"] == 1, case
+        sy = float(four["y"].abs().max())
+        assert float((one["y"] - four["y"]).abs().max()) <= 0.02 * sy + 1e-6, (case, float((one["y"] - four["y"]).abs().max()), sy)
+        for a, c in zip(one["gx"], four["gx"]):
+            if c is None:
+                assert a is None
+                continue
+            assert float((a - c).abs().max()) <= 0.04 * float(c.abs().max()) + 1e-6, case
+            assert float((a - c).norm()) <= 1e-2 * float(c.norm()) + 1e-6, case
+        for a, c in zip(one["pg"], four["pg"]):
+            assert float((a - c).norm()) <= 2e-2 * float(c.norm()) + 1e-5, (case, float((a - c).norm()), float(c.norm()))
+        n_ok += 1
+    assert n_ok == 24
