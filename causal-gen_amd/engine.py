@@ -290,21 +290,10 @@ class Engine(WgradMixin):
         self._wg_events = []
         self._wg_reduced, self._wg_seen = 0, set()
         self._in_side = False
-        # Backward strands (round 5): tape entries recorded inside `on_side(fn, bw=1)` -- the prior Block of a
-        # decoder layer and the upsampling of the z chain -- run on the side stream in backward() as well, next to the h strand
-        # (posterior Block, conv Block, z_proj).  ONE fork edge per layer (the event recorded behind every reparam backward)
-        # and one join (the first main-strand op that touches a gradient buffer the side strand wrote: z_feat_proj's backward);
-        # every accumulation into a buffer both strands contribute to stays on the main stream.  Bit-identical to the one-chain
-        # backward (tests/test_gpu_train.py) and concurrent in the trace (k = 3 residency 0.5 ms, the prior Block's 18 us under the
-        # posterior's) -- but OFF by default (CGEN_BW_BRANCH=1 turns it on): each fork and each join is a cross-queue hop of ~6 us
-        # on the main chain under hipGraph replay, 38 layers x 2, and the replayed step measured 15.5 ms against 14.07 (LABNOTES 10.4).
-        self.bw_branch = os.environ.get("CGEN_BW_BRANCH", "0") != "0"
+        # (tape entries carry a strand tag: 1 = recorded inside `on_side(fn, bw=1)`.  The two-strand backward that used it -- rounds 2, 4
+        #  and 5, bit-identical and slower under hipGraph replay each time, LABNOTES 9.9 / 10.4 -- was removed in round 6; the tag stays in
+        #  the tape's tuples)
         self._bw_tag = 0
-        self._bw_live = False      # inside backward() with strands on: the gradient accessors report to _bw_touch
-        self._bw_forked = False
-        self._bw_mark = None       # event behind the last reparam backward (main stream)
-        self._bw_mark_synced = None
-        self._bw_sets = (set(), set(), set(), set())  # buffers written / read since the mark by: main (w, r), side (w, r)
         self._rng_override = None
         self._dbg_names = {} if os.environ.get("CGEN_DEBUG_NAMES") else None  # id(tensor) -> producing conv (tools/ab_grads.py)
         self._riders = {}
@@ -1416,9 +1405,6 @@ class Engine(WgradMixin):
         job = self._riders.pop(id(base), None)
         if job is not None:
             gv, g, acc = job
-            if self._bw_live:
-                self._bw_touch(id(g.base), False)
-                self._bw_touch(id(gv.base), True)
             self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
             self.launches += 1
 
@@ -1428,8 +1414,6 @@ class Engine(WgradMixin):
         if self._riders:
             self._land_rider(t.base)
         g, ivs, base = self._gentry(t.base)
-        if self._bw_live:
-            self._bw_touch(id(g.base), True)
         a, b = t.coff, t.coff + t.c
         miss = self._missing(ivs, a, b)
         if miss != [(a, b)] and not defer_hazard and self._frozen(t):
@@ -1454,8 +1438,6 @@ class Engine(WgradMixin):
         if e is None:
             return None
         g, ivs, _ = e
-        if self._bw_live:
-            self._bw_touch(id(g.base), False)
         a, b = t.coff, t.coff + t.c
         miss = self._missing(ivs, a, b)
         if miss == [(a, b)]:
@@ -1535,76 +1517,64 @@ class Engine(WgradMixin):
         main_t = torch.cuda.current_stream(self.device)
         if self._side_join_pending:  # side-stream work of the forward pass nobody has joined yet (the stem's im2col)
             self.join_side()
-        strands = (self.bw_branch and self.fwd_branch and self.prof is None and any(tag == 1 for _, _, tag in self.tape))
-        if strands:
-            self._bw_begin()
-            for fn, args, tag in reversed(self.tape):
-                if tag == 1:
-                    self._bw_side(fn, args)
-                else:
+        self.blk3_pairs = self.conv_pairs = self.blk4_pairs = 0
+        skip = 0
+        tape = self.tape
+        for i in range(len(tape) - 1, -1, -1):
+            fn, args, _ = tape[i]
+            if fn == self._bw_block3:
+                self._blk4_flush()
+                # (armed when the NEXT entry is a fused Block of the same image size without a residual: the layer's prior Block)
+                nxt = tape[i - 1] if i > 0 else None
+                # ... and reads none of this Block's differentiable inputs: else its bookkeeping (an accumulate target, a
+                # copy-on-write of the shared gradient) could launch work that must see this Block's result first
+                if (self.blk3_pair and self._blk3_hold is None and nxt is not None and nxt[0] == self._bw_block3
+                        and nxt[1][5] is None and nxt[1][2][0].h == args[2][0].h and nxt[1][2][0].w == args[2][0].w
+                        and not ({id(v.base) for v in args[2] if v.rg} & {id(v.base) for v in nxt[1][2] if v.rg})
+                        and not any(v.base is nxt[1][4].base for v in args[2])):
+                    self._blk3_arm = 1
+                fn(*args)
+                if self._blk3_arm == 1:  # (it did not reach its launch point)
+                    self._blk3_arm = 0
+            elif fn == self._bw_block4:
+                self._blk3_flush()
+                # (armed when the NEXT entry is a fused default Block of the same image size without a residual -- the layer's prior
+                #  Block -- that reads none of this Block's differentiable inputs nor its output: the rule of the light Blocks above)
+                nxt = tape[i - 1] if i > 0 else None
+                if (self.blk4_pair and self._blk4_hold is None and nxt is not None and nxt[0] == self._bw_block4
+                        and nxt[1][4] is None and nxt[1][1][0].h == args[1][0].h and nxt[1][1][0].w == args[1][0].w
+                        and not ({id(v.base) for v in args[1] if v.rg} & {id(v.base) for v in nxt[1][1] if v.rg})
+                        and not any(v.base is nxt[1][3].base for v in args[1])):
+                    self._blk4_arm = 1
+                fn(*args)
+                if self._blk4_arm == 1:  # (it did not reach its launch point)
+                    self._blk4_arm = 0
+            else:
+                self._blk3_flush()
+                self._blk4_flush()
+                if skip:
+                    skip -= 1
+                    continue
+                if self.conv_pair and fn == self._bw_conv and self.dt != F32 and self._two_unfused_blocks(i):
+                    # X.conv2 | Y.conv2 in one launch, then X.conv1, Y.conv1 (their own gradient outputs pair inside _bw_conv)
+                    self._conv_arm = 1
                     fn(*args)
-                    if fn == self._bw_reparam:
-                        self._bw_set_mark()
-            self._bw_end()
-        else:
-            self.blk3_pairs = self.conv_pairs = self.blk4_pairs = 0
-            skip = 0
-            tape = self.tape
-            for i in range(len(tape) - 1, -1, -1):
-                fn, args, _ = tape[i]
-                if fn == self._bw_block3:
-                    self._blk4_flush()
-                    # (armed when the NEXT entry is a fused Block of the same image size without a residual: the layer's prior Block)
-                    nxt = tape[i - 1] if i > 0 else None
-                    # ... and reads none of this Block's differentiable inputs: else its bookkeeping (an accumulate target, a
-                    # copy-on-write of the shared gradient) could launch work that must see this Block's result first
-                    if (self.blk3_pair and self._blk3_hold is None and nxt is not None and nxt[0] == self._bw_block3
-                            and nxt[1][5] is None and nxt[1][2][0].h == args[2][0].h and nxt[1][2][0].w == args[2][0].w
-                            and not ({id(v.base) for v in args[2] if v.rg} & {id(v.base) for v in nxt[1][2] if v.rg})
-                            and not any(v.base is nxt[1][4].base for v in args[2])):
-                        self._blk3_arm = 1
-                    fn(*args)
-                    if self._blk3_arm == 1:  # (it did not reach its launch point)
-                        self._blk3_arm = 0
-                elif fn == self._bw_block4:
-                    self._blk3_flush()
-                    # (armed when the NEXT entry is a fused default Block of the same image size without a residual -- the layer's prior
-                    #  Block -- that reads none of this Block's differentiable inputs nor its output: the rule of the light Blocks above)
-                    nxt = tape[i - 1] if i > 0 else None
-                    if (self.blk4_pair and self._blk4_hold is None and nxt is not None and nxt[0] == self._bw_block4
-                            and nxt[1][4] is None and nxt[1][1][0].h == args[1][0].h and nxt[1][1][0].w == args[1][0].w
-                            and not ({id(v.base) for v in args[1] if v.rg} & {id(v.base) for v in nxt[1][1] if v.rg})
-                            and not any(v.base is nxt[1][3].base for v in args[1])):
-                        self._blk4_arm = 1
-                    fn(*args)
-                    if self._blk4_arm == 1:  # (it did not reach its launch point)
-                        self._blk4_arm = 0
-                else:
-                    self._blk3_flush()
-                    self._blk4_flush()
-                    if skip:
-                        skip -= 1
-                        continue
-                    if self.conv_pair and fn == self._bw_conv and self.dt != F32 and self._two_unfused_blocks(i):
-                        # X.conv2 | Y.conv2 in one launch, then X.conv1, Y.conv1 (their own gradient outputs pair inside _bw_conv)
-                        self._conv_arm = 1
-                        fn(*args)
-                        if self._conv_arm == 1:
-                            self._conv_arm = 0
-                        y2, x1, y1 = tape[i - 2], tape[i - 1], tape[i - 3]
-                        y2[0](*y2[1])
-                        self._conv_flush()
-                        x1[0](*x1[1])
-                        self._conv_flush()
-                        y1[0](*y1[1])
-                        self._conv_flush()
-                        skip = 3
-                        continue
-                    fn(*args)
+                    if self._conv_arm == 1:
+                        self._conv_arm = 0
+                    y2, x1, y1 = tape[i - 2], tape[i - 1], tape[i - 3]
+                    y2[0](*y2[1])
                     self._conv_flush()
-            self._blk3_flush()
-            self._blk4_flush()
-            self._conv_flush()
+                    x1[0](*x1[1])
+                    self._conv_flush()
+                    y1[0](*y1[1])
+                    self._conv_flush()
+                    skip = 3
+                    continue
+                fn(*args)
+                self._conv_flush()
+        self._blk3_flush()
+        self._blk4_flush()
+        self._conv_flush()
         for bid in list(self._riders):
             gv, g, acc = self._riders.pop(bid)
             self.lib.axpby(self.dt, g.n, g.h, g.w, g.cv(), gv.cv(), 1.0, 1.0, 1 << 30, 1 if acc else 0, self.stream)
@@ -1616,56 +1586,6 @@ class Engine(WgradMixin):
             self.lib.nhwc_to_nchw(F32, 1, c, h, w, v.cv(), self.param_grad_ptr(p), self.stream)
             self.launches += 1
         self.tape.clear()
-
-    # ------------------------------------------------------------------ backward strands (see __init__)
-    def _bw_begin(self):
-        if self._fwd_side is None:
-            self._fwd_side = torch.cuda.Stream(self.device)
-        self._bw_live = True
-        self._bw_forked = False
-        self._bw_set_mark()
-
-    def _bw_set_mark(self):
-        """The fork point of the coming side-strand ops: everything the main stream has enqueued so far.  Main-strand accesses are
-        tracked from here on."""
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        self._bw_mark = ev
-        self._bw_sets[0].clear()
-        self._bw_sets[1].clear()
-
-    def _bw_side(self, fn, args):
-        if self._bw_mark_synced is not self._bw_mark:  # one fork edge per mark
-            self._fwd_side.wait_event(self._bw_mark)
-            self._bw_mark_synced = self._bw_mark
-            self._bw_forked = True
-        self.on_side(lambda: fn(*args))
-
-    def _bw_touch(self, key, write):
-        """A backward op is about to read (write) gradient buffer `key` on the current strand: order it behind the other strand's
-        conflicting accesses.  Main after side -> join (the main stream waits for the side stream); side after main -> a fresh mark."""
-        mw, mr, sw, sr = self._bw_sets
-        if self._in_side:
-            if key in mw or (write and key in mr):
-                self._bw_set_mark()
-                self._fwd_side.wait_event(self._bw_mark)
-                self._bw_mark_synced = self._bw_mark
-            (sw if write else sr).add(key)
-        else:
-            if self._bw_forked and (key in sw or (write and key in sr)):
-                torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)
-                sw.clear()
-                sr.clear()
-            (mw if write else mr).add(key)
-
-    def _bw_end(self):
-        if self._bw_forked:
-            torch.cuda.current_stream(self.device).wait_stream(self._fwd_side)
-        self._bw_live = False
-        self._bw_forked = False
-        self._bw_mark = self._bw_mark_synced = None
-        for st in self._bw_sets:
-            st.clear()
 
     def _bw_conv(self, site, segs, act, out, res1, res2):
         g = self.grad_read(out)
@@ -1780,8 +1700,6 @@ class Engine(WgradMixin):
         self.launches += 1
 
     def _param_reduce(self, param, g):
-        if self._bw_live:  # (the decoder's per-resolution bias is added to h AND to the z chain: both strands accumulate into it)
-            self._bw_touch(("param", id(param)), True)
         acc = id(param) in self.pgrad_init
         _, c, h, w = param.shape
         if h * w == 1 or c == 1:
@@ -1825,8 +1743,6 @@ class Engine(WgradMixin):
         passes of DSCM.forward draw z from q but contribute no KL term: their coefficient is a device-side zero)."""
         gz = self.grad_read(z)
         job = self._riders.pop(id(p_loc.base), None)  # (taken before grad_write would land it as a launch of its own)
-        if job is not None and self._bw_live:
-            self._bw_touch(id(job[1].base), False)
         gql, a1 = self.grad_write(q_loc)
         gqs, a2 = self.grad_write(q_ls)
         gpl, a3 = self.grad_write(p_loc)

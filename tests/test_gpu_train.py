@@ -352,17 +352,6 @@ def test_backward_is_bit_reproducible_next_to_the_background_weight_gradient_ker
     torch.cuda.synchronize()
     bad = [n for n, p in m.named_parameters() if p.grad is not None and not torch.equal(runs[0][n], p.grad)]
     assert not bad, (len(bad), bad[:4])
-    # ... and so does the two-strand backward of round 5 (prior Blocks on the side stream next to the h strand; opt-in): the same bits as one chain
-    assert not eng.bw_branch, "the two-strand backward is opt-in (CGEN_BW_BRANCH=1)"
-    eng.bw_branch = True
-    m.zero_grad()
-    eng.rng.copy_(torch.tensor([11, 0], dtype=torch.int64, device=eng.rng.device))
-    out = m(x, pa, beta=1.0)
-    out["elbo"].backward()
-    torch.cuda.synchronize()
-    bad = [n for n, p in m.named_parameters() if p.grad is not None and not torch.equal(runs[0][n], p.grad)]
-    assert not bad, ("one-chain backward differs from the two-strand backward", len(bad), bad[:4])
-    eng.bw_branch = False
     # ... and the pair launch of a decoder layer's two fused data gradients (cgen_block3_pair, on by default): it was on in every run
     # above; off gives the same bits
     assert eng.blk3_pair and eng.blk3_pairs > 0, "the posterior / prior data gradients of the 24^2 and 48^2 layers share launches"
