@@ -237,6 +237,7 @@ def test_fused_block4_remainder_planes(shape):
     with torch.no_grad():
         for c in cs:
             c.weight.copy_(torch.randn(c.weight.shape, generator=g) * 1.6 / math.sqrt(c.in_channels * c.kernel_size[0] ** 2))
+            c.bias.copy_(torch.randn(c.out_channels, generator=g) * 0.2)  # (the default init draws from the unseeded global generator)
     x = (torch.randn(N, ci, H, W, generator=g) * 3).half().float()
     eng = Engine("cuda", "f16")
     holder = torch.nn.ModuleList(cs).cuda()
@@ -274,11 +275,14 @@ def test_fused_block4_remainder_planes(shape):
     (hi1, rem1), (hi2, rem2) = planes
     v1 = block(x.double(), x.double())
     assert float((hi1.half() != (hi1 + rem1).half()).float().mean()) < 1e-3
+    # hi + rem carries ~22 bits; what is left is a bottleneck value within f32 rounding of an f16 boundary taking the other side than the
+    # f64 reference's (one f16 ulp of a bottleneck value times a weight, a handful of pixels): the MEAN error is held tight and against
+    # the plain tensor's, the maximum loosely
     e1 = ((hi1 + rem1) - v1).abs()
-    assert float(e1.mean()) <= 2e-5 * float(v1.abs().max()) and float(e1.max()) <= 2e-2, (float(e1.mean()), float(e1.max()))
+    assert float(e1.mean()) <= 2e-5 * float(v1.abs().max()) and float(e1.max()) <= 1e-3 * float(v1.abs().max()), (float(e1.mean()), float(e1.max()))
     v2 = block(hi1, hi1 + rem1)
     e2, plain = ((hi2 + rem2) - v2).abs(), (hi2 - v2).abs()
-    assert float(e2.mean()) <= 2e-5 * float(v2.abs().max()) and float(e2.max()) <= 2e-2, (float(e2.mean()), float(e2.max()))
+    assert float(e2.mean()) <= 2e-5 * float(v2.abs().max()) and float(e2.max()) <= 1e-3 * float(v2.abs().max()), (float(e2.mean()), float(e2.max()))
     assert float(e2.mean()) * 5 < float(plain.mean()), (float(e2.mean()), float(plain.mean()))
 
 
