@@ -1,6 +1,6 @@
 """Per-block timeline of the packed weight-gradient launches inside the real train step (csrc/wgrad3.hip, CGEN_WG3_BLOCKLOG): how long
 the blocks of each problem class take next to each other, how many are resident over time, what the end of each launch looks like.
-usage: python tools/wg3_blocklog.py [bench.py-style env]      (ukbb192, batch 32, f16)"""
+usage: python tools/wg3_blocklog.py [config [batch]]      (default ukbb192, batch 32; f16)"""
 import os
 import sys
 
@@ -16,11 +16,13 @@ import bench  # noqa: E402
 
 
 def main():
-    m, hp = bench.build_model("ukbb192", "f16", False)
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "ukbb192"
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else (256 if cfg in ("morphomnist", "cmnist") else 32)
+    m, hp = bench.build_model(cfg, "f16", False)
     m = m.cuda()
     from causal_gen_amd.train import TrainStep
     ts = TrainStep(m, hp, ema=True, use_graph=True)
-    x, pa = bench.synth_batch("ukbb192", hp, 32, "cuda", seed=100)
+    x, pa = bench.synth_batch(cfg, hp, B, "cuda", seed=100)
     for _ in range(26):
         ts.step(x, pa)
     torch.cuda.synchronize()
