@@ -94,8 +94,13 @@ def run(shape, fuse):
     return out
 
 
+only = os.environ.get("B4_ONLY")  # "0" / "1": run only the four-launch / only the fused path (for counter passes: one kernel family per run)
 for i in sel:
     s = SHAPES[i]
+    if only is not None:
+        r = run(s, int(only))
+        print(i, s, "fused" if int(only) else "four launches", r, flush=True)
+        continue
     a, b_ = run(s, 0), run(s, 1)
     N, R, segc, _, b, co, wr = s
     gb = N * R * R * 2 * (sum(segc) + co * (2 if wr else 1) + 3 * b) / 1e9  # forward algorithmic bytes (inputs, output, residual, three bottlenecks)
