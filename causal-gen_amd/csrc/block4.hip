@@ -63,7 +63,7 @@ struct B4Out {
 };
 struct B4P {
   int N, H, W, nseg;
-  int nch0, bc8, nout, pad0;  // phase-0 chunks of 32 input channels; bottleneck width rounded up to 8 (stored channel groups)
+  int nch0, bc8, nout, xcd_order;  // phase-0 chunks of 32 input channels; bottleneck width rounded up to 8 (stored channel groups)
   int tiles_x, tiles_y, ntiles, pad1;
   int inv[3][2];  // ceil(65536 / columns) of phases 0, 1, 2 (tile width + 4, + 2, + 0) for a full-width tile [0] and the last tile of a row [1]
   B4Div d_tx, d_ty;
@@ -464,7 +464,11 @@ __device__ __forceinline__ void blk4_body(const B4P& p, const int tile) {
 
 template <bool FWD, int NB8, int NW>
 __global__ __launch_bounds__(64 * NW, NB8 <= 2 ? 4 : (NB8 <= 4 ? (NW == 8 ? 4 : 3) : 2)) void blk4_kernel(const B4P p) {
-  blk4_body<FWD, NB8, NW>(p, blockIdx.x);
+  // XCD-contiguous tile order: the dispatcher deals consecutive workgroups round-robin to the eight XCDs (each with its own L2), so
+  // with tile = workgroup index no L2 ever sees two neighbouring tiles and every halo column comes over the fabric again (measured:
+  // fetch 2.7 x the input at 224x224).  Workgroup i takes tile (i mod 8) * (ntiles / 8) + i / 8: an XCD walks a contiguous range.
+  const int bid = blockIdx.x, per = p.ntiles >> 3;
+  blk4_body<FWD, NB8, NW>(p, (p.xcd_order && bid < 8 * per) ? (bid & 7) * per + (bid >> 3) : bid);
 }
 // Two independent DATA-GRADIENT problems of one instance in one launch: workgroups 0 .. na - 1 take the first, the rest the second
 // (the backward of a decoder layer's posterior and prior Blocks, vae.py:240-301: at <= 28x28 a launch is <= 256 tiles and its time is
@@ -538,6 +542,8 @@ static int b4_fill(const cgen_block4_args* a, B4P& p, int& nb8) {
   const int64_t nt = (int64_t)p.N * p.tiles_x * p.tiles_y;
   if (nt >= ((int64_t)1 << 30)) return 0;
   p.ntiles = (int)nt;
+  static const int xcd_env = [] { const char* e = getenv("CGEN_BLK4_XCD"); return e ? atoi(e) : 1; }();
+  p.xcd_order = xcd_env && nt >= 512;  // (launches of at least two tiles per CU: below that placement decides nothing)
   p.d_tx = b4_mkdiv(p.tiles_x); p.d_ty = b4_mkdiv(p.tiles_y);
   {
     const int twl = p.W - B4_TW * (p.tiles_x - 1);  // width of a row's last tile
